@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py -- GSM updates/sec + achieved HBM GB/s at D=1024, B=32 (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one GSM update -- gsm_update(samples, vs, mu0, S0) -> (mu, S), reference
+gsmvi/gsm_numpy.py:27-55 -- at configs[2] of BASELINE.json (D=1024, B=32, dense covariance,
+synthetic Gaussian target, fp64), inputs resident in HBM before the timed region.  To keep the
+Infinity Cache (256 MiB) from serving the covariance, the steps cycle over a ring of independent
+problem instances whose footprint exceeds it; the cache-resident rate (one instance, what a real
+fit loop sees) is reported beside it as "value_cache_resident".
+
+N > 1: the batch is sharded across ranks (B/N samples each), records are all-gathered over RCCL
+and every replica applies the combined update (gsm-vi_amd/dist.py); total work is fixed ->
+"scaling": "strong".  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (guide: MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--D", type=int, default=1024)
+    ap.add_argument("--B", type=int, default=32)
+    ap.add_argument("--instances", type=int, default=0, help="ring size (0 = enough to exceed the Infinity Cache)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--tune", action="append", default=[], help="name=value launch knob (experiments)")
+    return ap.parse_args()
+
+
+def make_instances(eng, D, B, n_inst, seed0=0):
+    """Synthetic state per SURVEY 8(d): target m, P; per instance mu0, S0 = A A^T/D + 0.1 I,
+    samples = mu0 + z chol(S0)^T, scores from the HIP Gaussian-score kernel.  Data generation
+    uses torch (plumbing); the benchmarked path does not."""
+    dev = eng.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + seed0)
+    m = torch.rand(D, dtype=torch.float64, device=dev, generator=g)
+    L = torch.randn(D, D, dtype=torch.float64, device=dev, generator=g)
+    cov_t = L @ L.T + 1e-3 * torch.eye(D, dtype=torch.float64, device=dev)
+    P = torch.linalg.inv(cov_t)
+    P = 0.5 * (P + P.T)
+    inst = []
+    for k in range(n_inst):
+        mu0 = torch.randn(D, dtype=torch.float64, device=dev, generator=g)
+        A = torch.randn(D, D, dtype=torch.float64, device=dev, generator=g)
+        S0 = A @ A.T / D + 0.1 * torch.eye(D, dtype=torch.float64, device=dev)
+        S0 = 0.5 * (S0 + S0.T)
+        Lc = torch.linalg.cholesky(S0)
+        Z = torch.randn(B, D, dtype=torch.float64, device=dev, generator=g)
+        X = mu0[None, :] + Z @ Lc.T
+        G = eng.gaussian_score(X, m, P)
+        inst.append(dict(X=X.contiguous(), G=G, mu0=mu0, S0=S0.contiguous(), mu=eng.empty(D), S=eng.empty(D, D)))
+    torch.cuda.synchronize()
+    return inst, m, P
+
+
+def cpu_baseline(D, B, seconds):
+    """The oracle's faithful restatement of gsm_numpy.gsm_update ("port") on the host cores."""
+    from oracle import gsm_oracle as orc
+    st = orc.make_update_state(D, B, 0)
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    orc.gsm_update_faithful(st["samples"][:2], st["vs"][:2], st["mu0"], st["S0"])      # touch BLAS
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.gsm_update_faithful(st["samples"], st["vs"], st["mu0"], st["S0"])
+        n += 1
+        el = time.perf_counter() - t0
+        if (el >= seconds and n >= 2) or n >= 200:
+            break
+    tb0 = time.perf_counter()
+    nb = 0
+    while time.perf_counter() - tb0 < min(2.0, seconds / 4) or nb < 3:
+        orc.gsm_update_batched(st["samples"], st["vs"], st["mu0"], st["S0"])
+        nb += 1
+    tb = time.perf_counter() - tb0
+    return {"value": n / el, "unit": "updates/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n} updates of D={D},B={B} (oracle/gsm_oracle.py:gsm_update_faithful, numpy fp64, "
+                      f"{os.cpu_count()} host cpus)",
+            "best_effort_blas3_value": nb / tb}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import gsmvi_amd
+    from gsmvi_amd.dist import sharded_gsm_update, shard_bounds
+    eng = gsmvi_amd.get_engine(local_rank)
+    for kv in args.tune:
+        k, v = kv.split("=")
+        eng.set_tuning(k, int(v))
+    D, B = args.D, args.B
+    per_inst = 2 * D * D * 8
+    n_inst = args.instances or max(2, int(np.ceil(320 * 2 ** 20 / per_inst)) + 1)
+    inst, m, P = make_instances(eng, D, B, n_inst)
+    lo, hi = shard_bounds(B, world, rank)
+    rec_all = eng.empty(B, eng.record_len(D)) if world > 1 else None
+
+    def step(k):
+        it = inst[k % n_inst]
+        if world == 1:
+            eng.gsm_update(it["X"], it["G"], it["mu0"], it["S0"], out=(it["mu"], it["S"]))
+        else:
+            sharded_gsm_update(eng, it["X"][lo:hi], it["G"][lo:hi], it["mu0"], it["S0"], rec_all=rec_all,
+                               out=(it["mu"], it["S"]))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- optional hipGraph of one trip round the ring (single GPU only) ------------------------
+    graph, launch = None, "eager"
+    if world == 1 and not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for k in range(n_inst):
+                    step(k)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for k in range(n_inst):
+                    step(k)
+            launch = f"hipGraph({n_inst} updates/replay)"
+        except Exception as e:           # capture unsupported -> stay on eager launches of the same kernels
+            graph, launch = None, f"eager (graph capture failed: {type(e).__name__})"
+            torch.cuda.synchronize()
+
+    def run(nsteps):
+        done = 0
+        if graph is not None:
+            while nsteps - done >= n_inst:
+                graph.replay()
+                done += n_inst
+        for k in range(nsteps - done):
+            step(k)
+
+    run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    ms_per_step = el / args.steps * 1e3
+    value = args.steps / el
+
+    # ---- cache-resident rate: one instance, what a fit loop with a single covariance sees ------
+    value_hot = None
+    if world == 1:
+        it = inst[0]
+        g1 = None
+        try:
+            if graph is not None:
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    for _ in range(n_inst):
+                        eng.gsm_update(it["X"], it["G"], it["mu0"], it["S0"], out=(it["mu"], it["S"]))
+        except Exception:
+            g1 = None
+        reps = max(1, args.steps // n_inst)
+        for _ in range(3):
+            g1.replay() if g1 is not None else [step(0) for _ in range(n_inst)]
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for _ in range(reps):
+            if g1 is not None:
+                g1.replay()
+            else:
+                for _ in range(n_inst):
+                    eng.gsm_update(it["X"], it["G"], it["mu0"], it["S0"], out=(it["mu"], it["S"]))
+        torch.cuda.synchronize()
+        value_hot = reps * n_inst / (time.perf_counter() - th)
+
+    # ---- roofline of the dominant kernel (covariance update), dispatch-timestamp events --------
+    eng.set_profiling(True)
+    kt = {"panel": [], "scalars": [], "cov_update": []}
+    for k in range(2 * n_inst):
+        it = inst[k % n_inst]
+        eng.gsm_update(it["X"], it["G"], it["mu0"], it["S0"], out=(it["mu"], it["S"]))
+        pr = eng.get_profile()
+        if k >= n_inst // 2:
+            for key in kt:
+                kt[key].append(pr[key])
+    eng.set_profiling(False)
+    avg_ms = {k: float(np.mean(v)) for k, v in kt.items()}
+    alg_bytes_update = 16.0 * D * D + 16.0 * B * D                     # pass B
+    alg_bytes_total = 24.0 * D * D + 72.0 * B * D                      # whole update
+    achieved = alg_bytes_update / (avg_ms["cov_update"] * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_gsm_cov_update_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_gsm_cov_update", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes_update,
+                "avg_kernel_us": {k: v * 1e3 for k, v in avg_ms.items()},
+                "whole_update_algorithmic_GBs": alg_bytes_total * value / 1e9}
+
+    out = {"metric": "GSM updates/sec at D=%d,B=%d (dense-cov gsm_update, fp64)" % (D, B),
+           "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"BASELINE configs[2]: D={D} dense-cov Gaussian target, B={B}, one GSM update "
+                                  f"per step", "D": D, "B": B, "instances": n_inst,
+                      "ring_bytes": n_inst * per_inst, "launch": launch,
+                      "parallelism": "single GPU" if world == 1 else f"batch-sharded x{world} + RCCL all-gather"},
+           "value_cache_resident": value_hot, "roofline": roofline}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(D, B, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,86 @@
+"""ctypes binding of libgsmvi_hip.so (C ABI: include/gsmvi_hip.h).  Fails loudly when missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class GsmviError(RuntimeError):
+    """A C-ABI call returned a non-zero gsmvi_status."""
+
+    def __init__(self, fn, status, msg):
+        super().__init__(f"{fn} failed with status {status}: {msg}")
+        self.status = status
+
+
+def library_path():
+    return os.path.join(_HERE, "libgsmvi_hip.so")
+
+
+_c_dp = C.c_void_p   # device pointers travel as integers
+_SIGS = {
+    # name: (restype, argtypes)
+    "gsmvi_abi_version": (C.c_int, []),
+    "gsmvi_status_string": (C.c_char_p, [C.c_int]),
+    "gsmvi_last_error": (C.c_char_p, []),
+    "gsmvi_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "gsmvi_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "gsmvi_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
+    "gsmvi_destroy": (C.c_int, [C.c_void_p]),
+    "gsmvi_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "gsmvi_gsm_update_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int,
+                                       _c_dp, _c_dp, C.c_int, _c_dp, _c_dp, C.c_int]),
+    "gsmvi_gsm_record_len": (C.c_int, [C.c_int]),
+    "gsmvi_gsm_local_stage_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp,
+                                            C.c_int, _c_dp, _c_dp, C.c_int, _c_dp, C.c_int]),
+    "gsmvi_gsm_apply_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, _c_dp,
+                                      C.c_int, _c_dp, _c_dp, C.c_int]),
+    "gsmvi_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "gsmvi_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
+    "gsmvi_gaussian_score_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp,
+                                           _c_dp, C.c_int, _c_dp, C.c_int]),
+    "gsmvi_potrf_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int, _c_dp]),
+    "gsmvi_sample_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, _c_dp,
+                                   C.c_int, _c_dp, C.c_int]),
+    "gsmvi_commit_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, C.c_int, _c_dp, _c_dp,
+                                   C.c_int, _c_dp]),
+    "gsmvi_bam_update_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int,
+                                       _c_dp, _c_dp, C.c_int, C.c_double, C.c_double, _c_dp, _c_dp, C.c_int,
+                                       _c_dp]),
+}
+
+
+def exported_symbols():
+    """Names every build of the library must export (kept in sync with include/gsmvi_hip.h)."""
+    return sorted(_SIGS)
+
+
+def load_library():
+    """Loads the HIP library once.  Raises ImportError with build instructions if it is absent:
+    the product path has no CPU fallback."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: the HIP extension is not built.  Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C gsm-vi_amd/csrc`. "
+            "gsmvi_amd has no CPU fallback.")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)     # AttributeError here = ABI mismatch, surface it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gsmvi_abi_version() != 1:
+        raise ImportError(f"{path}: ABI version {lib.gsmvi_abi_version()} != 1")
+    _LIB = lib
+    return lib
+
+
+def check(fn_name, status):
+    if status != 0:
+        lib = load_library()
+        raise GsmviError(fn_name, status, (lib.gsmvi_last_error() or b"").decode() or
+                         lib.gsmvi_status_string(status).decode())

@@ -1,0 +1,157 @@
+"""BaM fit driver, update functions and regularizer schedules with the reference's signatures
+(gsmvi/bam.py).  The update runs in HIP kernels through the engine; see csrc/gsmvi_bam.hip."""
+import numpy as np
+import torch
+
+from .engine import get_engine
+from .gsm import _legacy_mvn, _is_torch
+
+
+def bam_lowrank_update(samples, vs, mu0, S0, reg, engine=None, jitter=0.0):
+    """Drop-in for ``bam_lowrank_update(samples, vs, mu0, S0, reg)`` (gsmvi/bam.py:72-114).
+
+    The D x B ARPACK factor of U (bam.py:10-13,104) is replaced by U's exact rank-(B+1) factor, so
+    there is no B < D restriction; the returned S is symmetrised (the reference symmetrises in
+    ``fit``, bam.py:199)."""
+    assert len(samples.shape) == 2
+    assert len(vs.shape) == 2
+    eng = engine if engine is not None else get_engine()
+    want_torch = _is_torch(samples)
+    mu, S, _ = eng.bam_update(eng.asarray(samples), eng.asarray(vs), eng.asarray(mu0), eng.asarray(S0),
+                              float(reg), float(jitter))
+    return (mu, S) if want_torch else (eng.to_numpy(mu), eng.to_numpy(S))
+
+
+def bam_update(samples, vs, mu0, S0, reg, engine=None, jitter=0.0):
+    """Drop-in for ``bam_update(samples, vs, mu0, S0, reg)`` (gsmvi/bam.py:31-69).  The full-rank
+    formula (D x D sqrtm + solve) equals the low-rank one to round-off, so both names
+    run the same kernels."""
+    return bam_lowrank_update(samples, vs, mu0, S0, reg, engine=engine, jitter=jitter)
+
+
+class Regularizers:
+    """Regularizer schedules for BaM (gsmvi/bam.py:237-274).  As in the reference the schedules
+    count CALLS and ignore the ``iteration`` argument, so retries advance them."""
+
+    def __init__(self):
+        self.counter = 0
+
+    def reset(self):
+        self.counter = 0
+
+    def constant(self, reg0):
+        def reg_iter(iteration):
+            self.counter += 1
+            return reg0
+        return reg_iter
+
+    def linear(self, reg0):
+        def reg_iter(iteration):
+            self.counter += 1
+            return reg0 / self.counter
+        return reg_iter
+
+    def custom(self, func):
+        def reg_iter(iteration):
+            self.counter += 1
+            return func(self.counter)
+        return reg_iter
+
+
+class BaM:
+    """Wrapper class for using BaM updates to fit a distribution (gsmvi/bam.py:117-137).
+    ``use_lowrank`` and ``jit_compile`` are accepted for signature compatibility; both update
+    forms run the same HIP kernels and there is nothing to jit."""
+
+    def __init__(self, D, lp, lp_g, use_lowrank=False, jit_compile=True, engine=None):
+        self.D = D
+        self.lp = lp
+        self.lp_g = lp_g
+        self.use_lowrank = use_lowrank
+        self.jit_compile = jit_compile
+        self._engine = engine
+
+    def fit(self, key, regf, mean=None, cov=None, batch_size=2, niter=5000, nprint=10, verbose=True,
+            check_goodness=True, monitor=None, retries=10, jitter=1e-6, *, sampler="cholesky", rng="numpy",
+            as_torch=False, forced_samples=None):
+        """gsmvi/bam.py:140-216.  Kept: niter+1 iterations (:178); nprint clamp (:177); reg = regf(i)
+        per attempt (:196); jitter on the diagonal and symmetrisation (:198-199, done in-kernel);
+        retry on any exception up to ``retries`` then re-raise (:189-206); Cholesky accept/revert of
+        both mean and cov (:208-212); monitor cadence (:182-185,:214-215).
+        Deviation: the JAX threefry key split + per-iteration numpy re-seed (:191-192) is replaced by
+        one private RandomState(key) stream (JAX is not a dependency)."""
+        eng = self._engine if self._engine is not None else get_engine()
+        D, B = self.D, int(batch_size)
+        mean_t = eng.zeros(D) if mean is None else eng.clone(mean).reshape(D)
+        cov_t = eng.eye(D) if cov is None else eng.clone(cov).reshape(D, D)
+        seed = int(np.asarray(key.cpu() if _is_torch(key) else key).flatten()[-1])
+        rs = np.random.RandomState(seed)
+        gen = None
+        if rng == "device":
+            gen = torch.Generator(device=eng.device)
+            gen.manual_seed(seed)
+        native = bool(getattr(self.lp_g, "device_native", False))
+        mon_native = bool(getattr(monitor, "device_native", False)) if monitor is not None else False
+
+        mean_new, cov_new = eng.empty(D), eng.empty(D, D)
+        R, R_new = eng.empty(D, D), eng.empty(D, D)
+        Xbuf = eng.empty(B, D)
+        flag, uflag, n_rev = eng.new_flag(), eng.new_flag(), eng.new_flag()
+        use_factor = sampler == "cholesky" and forced_samples is None
+        if use_factor:                      # the sampling factor of the initial covariance
+            eng.potrf(cov_t, out=R, flag=flag)
+            if eng.read_flag(flag) != 0:
+                raise ValueError("initial covariance is not positive definite")
+
+        nevals = 1
+        if nprint > niter:
+            nprint = niter
+        every = max(1, niter // nprint) if nprint > 0 else 1
+        reverts_seen = 0
+        i = 0
+        for i in range(niter + 1):
+            if verbose and i % every == 0:
+                print(f"Iteration {i} of {niter}")
+                r = eng.read_flag(n_rev)
+                if r > reverts_seen:
+                    print(f"Bad update for covariance matrix. Revert ({r - reverts_seen} since last print)")
+                    reverts_seen = r
+            if monitor is not None and i % monitor.checkpoint == 0:
+                mc = [mean_t, cov_t] if mon_native else [eng.to_numpy(mean_t).copy(), eng.to_numpy(cov_t).copy()]
+                monitor(i, mc, self.lp, key, nevals=nevals)
+                nevals = 0
+            j = 0
+            while True:
+                try:
+                    if forced_samples is not None:
+                        X = eng.asarray(forced_samples[i])
+                    elif sampler == "svd":
+                        X = eng.asarray(_legacy_mvn(rs, eng.to_numpy(mean_t), eng.to_numpy(cov_t), B))
+                    else:
+                        Z = eng.normal(B, D, gen) if gen is not None else \
+                            eng.normal_from_host(rs.standard_normal((B, D)))
+                        X = eng.sample(Z, mean_t, R, out=Xbuf)
+                    vs = self.lp_g(X) if native else eng.asarray(self.lp_g(eng.to_numpy(X)))
+                    nevals += B
+                    reg = regf(i)
+                    eng.bam_update(X, vs, mean_t, cov_t, reg, jitter, out=(mean_new, cov_new), flag=uflag)
+                    break
+                except Exception as e:                      # noqa: BLE001 -- reference behaviour
+                    if j < retries:
+                        j += 1
+                        print(f"Failed with exception {e}")
+                        print(f"Trying again {j} of {retries}")
+                    else:
+                        raise e
+            eng.potrf(cov_new, out=R_new, flag=flag)
+            eng.commit(flag, mean_new, cov_new, mean_t, cov_t, n_rev)
+            if use_factor:
+                eng.commit(flag, mean_new, R_new, mean_t, R, None)
+
+        if monitor is not None:
+            mc = [mean_t, cov_t] if mon_native else [eng.to_numpy(mean_t).copy(), eng.to_numpy(cov_t).copy()]
+            monitor(i, mc, self.lp, key, nevals=nevals)
+        self.n_reverts = eng.read_flag(n_rev)
+        if as_torch:
+            return mean_t, cov_t
+        return eng.to_numpy(mean_t), eng.to_numpy(cov_t)

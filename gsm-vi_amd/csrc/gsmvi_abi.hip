@@ -1,0 +1,375 @@
+// C ABI of the gfx950 GSM/BaM engine (declared in include/gsmvi_hip.h).
+// Host side only: argument validation, workspace, launch geometry.  No torch types, no
+// exceptions across the boundary, no host synchronisation inside the update entry points.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../../include/gsmvi_hip.h"
+
+// ---- kernels (gsmvi_kernels.hip / gsmvi_potrf.hip / gsmvi_bam.hip) -------------------------
+void gsmvi_launch_panel_partial(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int nrows,
+                                const double* A, int lda, const double* shift, double alpha, const double* M,
+                                int ldm, double* Pp, int chunks_per_wg, int a_vec_ok);
+void gsmvi_launch_panel_finish(hipStream_t st, hipEvent_t* ev, int D, int nrows, int KC, const double* Pp,
+                               const double* addvec, double* Out, int ldo);
+void gsmvi_launch_gsm_scalars(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, const double* X, int ldx,
+                              const double* G, int ldg, const double* mu0, const double* Pp, double* SG, int ldsg,
+                              double* coef, int ldc, double* Xout, int ldxo);
+size_t gsmvi_cov_update_lds_bytes(int SB);
+hipError_t gsmvi_cov_update_prepare();
+void gsmvi_launch_gsm_cov_update(hipStream_t st, hipEvent_t* ev, int D, int B, const double* X, int ldx,
+                                 const double* SG, int ldsg, const double* mu0, const double* coef, int ldc,
+                                 const double* S0, int lds0, double* S, int lds, double* mu_out, int SB,
+                                 int s_vec_ok);
+void gsmvi_launch_commit(hipStream_t st, int D, const int* info, const double* mu_new, const double* S_new,
+                         int lds_new, double* mu, double* S, int lds, int* n_reverts);
+int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
+                     int* info_dev);
+int gsmvi_bam_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X, int ldx,
+                   const double* G, int ldg, const double* mu0, const double* S0, int lds0, double reg,
+                   double jitter, double* mu, double* S, int lds, int* info_dev);
+
+#include "gsmvi_ctx.h"
+
+static thread_local std::string g_last_error;
+
+void gsmvi_set_error(const char* fmt, const char* a, const char* b) {
+    char buf[512];
+    snprintf(buf, sizeof buf, fmt, a ? a : "", b ? b : "");
+    g_last_error = buf;
+}
+
+#define HIP_TRY(expr)                                                     \
+    do {                                                                  \
+        hipError_t e_ = (expr);                                           \
+        if (e_ != hipSuccess) {                                           \
+            gsmvi_set_error("%s failed: %s", #expr, hipGetErrorString(e_)); \
+            return GSMVI_ERR_HIP;                                         \
+        }                                                                 \
+    } while (0)
+
+#define BAD_ARG(cond, msg)                          \
+    do {                                            \
+        if (cond) {                                 \
+            gsmvi_set_error("%s: %s", __func__, msg); \
+            return GSMVI_ERR_BAD_ARG;               \
+        }                                           \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        gsmvi_set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return GSMVI_ERR_HIP;
+    }
+    return GSMVI_OK;
+}
+
+extern "C" {
+
+int gsmvi_abi_version(void) { return GSMVI_ABI_VERSION; }
+
+const char* gsmvi_status_string(int s) {
+    switch (s) {
+        case GSMVI_OK: return "ok";
+        case GSMVI_ERR_BAD_ARG: return "bad argument";
+        case GSMVI_ERR_HIP: return "HIP runtime error";
+        case GSMVI_ERR_NO_DEVICE: return "no HIP device";
+        case GSMVI_ERR_WORKSPACE: return "problem larger than the context's workspace";
+        case GSMVI_ERR_UNSUPPORTED: return "unsupported";
+        default: return "unknown status";
+    }
+}
+
+const char* gsmvi_last_error(void) { return g_last_error.c_str(); }
+
+int gsmvi_device_count(int* n) {
+    if (!n) return GSMVI_ERR_BAD_ARG;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess || c <= 0) {
+        (void)hipGetLastError();
+        *n = 0;
+        gsmvi_set_error("%s%s", "no HIP device visible: ", e != hipSuccess ? hipGetErrorString(e) : "count 0");
+        return GSMVI_ERR_NO_DEVICE;
+    }
+    *n = c;
+    return GSMVI_OK;
+}
+
+// Workspace layout (doubles): panel partials [KCmax][Rmax][D], SG [Rmax][D], coef [8][Rmax],
+// small-matrix scratch for BaM / potrf, plus a few ints.
+static void ws_sizes(int D, int B, size_t* n_pp, size_t* n_sg, size_t* n_small, int* rmax) {
+    const int R = 2 * B + 8;                                   // BaM uses up to B+1 panel rows twice
+    *rmax = R;
+    *n_pp = (size_t)GSMVI_MAX_KC * R * D;
+    *n_sg = (size_t)R * D * 4;                                 // SG + BaM factor panels
+    *n_small = (size_t)8 * R + (size_t)6 * R * R + 4096;
+}
+
+size_t gsmvi_workspace_bytes(int max_D, int max_B) {
+    if (max_D <= 0 || max_B <= 0) return 0;
+    size_t a, b, c;
+    int r;
+    ws_sizes(max_D, max_B, &a, &b, &c, &r);
+    return (a + b + c) * sizeof(double) + 256;
+}
+
+int gsmvi_create(gsmvi_ctx** out, int device, int max_D, int max_B) {
+    BAD_ARG(!out, "out is NULL");
+    BAD_ARG(max_D <= 0 || max_B <= 0, "max_D and max_B must be positive");
+    *out = nullptr;
+    int n = 0;
+    int st = gsmvi_device_count(&n);
+    if (st != GSMVI_OK) return st;
+    BAD_ARG(device < 0 || device >= n, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    gsmvi_ctx* c = new gsmvi_ctx();
+    c->device = device;
+    c->max_D = max_D;
+    c->max_B = max_B;
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    size_t n_pp, n_sg, n_small;
+    ws_sizes(max_D, max_B, &n_pp, &n_sg, &n_small, &c->rmax);
+    c->ws_bytes = (n_pp + n_sg + n_small) * sizeof(double) + 256;
+    hipError_t e = hipMalloc(&c->ws, c->ws_bytes);
+    if (e != hipSuccess) {
+        gsmvi_set_error("hipMalloc of the workspace failed: %s%s", hipGetErrorString(e), "");
+        delete c;
+        return GSMVI_ERR_HIP;
+    }
+    c->pp = reinterpret_cast<double*>(c->ws);
+    c->sg = c->pp + n_pp;
+    c->small = c->sg + n_sg;
+    c->ints = reinterpret_cast<int*>(c->small + n_small);
+    e = hipMemset(c->ws, 0, c->ws_bytes);
+    if (e == hipSuccess) e = gsmvi_cov_update_prepare();
+    for (int k = 0; k < 8 && e == hipSuccess; ++k) e = hipEventCreate(&c->ev[k]);
+    if (e != hipSuccess) {
+        gsmvi_set_error("context initialisation failed: %s%s", hipGetErrorString(e), "");
+        (void)hipFree(c->ws);
+        delete c;
+        return GSMVI_ERR_HIP;
+    }
+    *out = c;
+    return GSMVI_OK;
+}
+
+int gsmvi_destroy(gsmvi_ctx* ctx) {
+    if (!ctx) return GSMVI_OK;
+    (void)hipSetDevice(ctx->device);
+    for (int k = 0; k < 8; ++k)
+        if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
+    hipError_t e = hipFree(ctx->ws);
+    delete ctx;
+    if (e != hipSuccess) {
+        gsmvi_set_error("hipFree failed: %s%s", hipGetErrorString(e), "");
+        return GSMVI_ERR_HIP;
+    }
+    return GSMVI_OK;
+}
+
+int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
+    BAD_ARG(!ctx || !name, "NULL argument");
+    if (!strcmp(name, "panel_kc")) ctx->tune_panel_kc = value;
+    else if (!strcmp(name, "update_sb")) ctx->tune_update_sb = value;
+    else {
+        gsmvi_set_error("%s: unknown tuning knob %s", __func__, name);
+        return GSMVI_ERR_BAD_ARG;
+    }
+    return GSMVI_OK;
+}
+
+int gsmvi_set_profiling(gsmvi_ctx* ctx, int on) {
+    BAD_ARG(!ctx, "ctx is NULL");
+    ctx->profiling = on ? 1 : 0;
+    for (int k = 0; k < 4; ++k) ctx->ev_valid[k] = 0;
+    return GSMVI_OK;
+}
+
+int gsmvi_get_profile(gsmvi_ctx* ctx, float* ms, int n) {
+    BAD_ARG(!ctx || !ms || n < 1, "bad argument");
+    for (int k = 0; k < n; ++k) {
+        ms[k] = -1.0f;
+        if (k < 4 && ctx->ev_valid[k]) {
+            HIP_TRY(hipEventSynchronize(ctx->ev[2 * k + 1]));
+            HIP_TRY(hipEventElapsedTime(&ms[k], ctx->ev[2 * k], ctx->ev[2 * k + 1]));
+        }
+    }
+    return GSMVI_OK;
+}
+
+}  // extern "C"
+
+// ---- panel product driver: Pp partials for Out = alpha (A - shift) M ----------------------
+// Returns KC (number of partial slabs written) through *kc_out.
+int gsmvi_panel_product(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D, int nrows, const double* A, int lda,
+                        const double* shift, double alpha, const double* M, int ldm, double* Pp, int* kc_out) {
+    const int strips = (D + 15) / 16;
+    const int nchunks = (D + 255) / 256;
+    const int MT = nrows <= 16 ? 1 : (nrows <= 32 ? 2 : 4);
+    const int zblocks = (nrows + 16 * MT - 1) / (16 * MT);
+    int kc = ctx->tune_panel_kc > 0 ? ctx->tune_panel_kc
+                                    : (2 * ctx->num_cu + strips * zblocks - 1) / (strips * zblocks);
+    if (kc > nchunks) kc = nchunks;
+    if (kc > GSMVI_MAX_KC) kc = GSMVI_MAX_KC;
+    if (kc < 1) kc = 1;
+    const int cpw = (nchunks + kc - 1) / kc;
+    kc = (nchunks + cpw - 1) / cpw;
+    const int a_vec_ok = (lda % 2 == 0) && aligned16(A);
+    gsmvi_launch_panel_partial(st, ev, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm, Pp,
+                               cpw, a_vec_ok);
+    *kc_out = kc;
+    return check_launch("k_panel_partial");
+}
+
+static int check_common(gsmvi_ctx* ctx, int D, int B, const char* fn) {
+    if (!ctx) {
+        gsmvi_set_error("%s: %s", fn, "ctx is NULL");
+        return GSMVI_ERR_BAD_ARG;
+    }
+    if (D <= 0 || B <= 0) {
+        gsmvi_set_error("%s: %s", fn, "D and B must be positive");
+        return GSMVI_ERR_BAD_ARG;
+    }
+    if (D > ctx->max_D || B > ctx->max_B) {
+        gsmvi_set_error("%s: %s", fn, "(D,B) exceeds the context's workspace; create a larger context");
+        return GSMVI_ERR_WORKSPACE;
+    }
+    return GSMVI_OK;
+}
+
+extern "C" {
+
+static int gsm_local_stage(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, const double* X, int ldx, const double* G,
+                           int ldg, const double* mu0, const double* S0, int lds0, double* SG, int ldsg,
+                           double* coef, int ldc, double* Xout, int ldxo) {
+    int kc = 1;
+    int st = gsmvi_panel_product(ctx, hs, ctx->stage_events(0), D, B, G, ldg, nullptr, 1.0, S0, lds0, ctx->pp, &kc);
+    if (st != GSMVI_OK) return st;
+    gsmvi_launch_gsm_scalars(hs, ctx->stage_events(1), D, B, kc, X, ldx, G, ldg, mu0, ctx->pp, SG, ldsg, coef, ldc,
+                             Xout, ldxo);
+    return check_launch("k_gsm_scalars");
+}
+
+static int gsm_apply(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, const double* X, int ldx, const double* SG,
+                     int ldsg, const double* coef, int ldc, const double* mu0, const double* S0, int lds0,
+                     double* mu, double* S, int lds) {
+    int SB = ctx->tune_update_sb > 0 ? ctx->tune_update_sb : ((B + 1) & ~1);
+    if (SB > 64) SB = 64;
+    SB = (SB + 1) & ~1;
+    const int s_vec_ok = (lds0 % 2 == 0) && (lds % 2 == 0) && aligned16(S0) && aligned16(S);
+    gsmvi_launch_gsm_cov_update(hs, ctx->stage_events(2), D, B, X, ldx, SG, ldsg, mu0, coef, ldc, S0, lds0, S, lds,
+                                mu, SB, s_vec_ok);
+    return check_launch("k_gsm_cov_update");
+}
+
+int gsmvi_gsm_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* X, int ldx, const double* G,
+                         int ldg, const double* mu0, const double* S0, int lds0, double* mu, double* S, int lds) {
+    int st = check_common(ctx, D, B, __func__);
+    if (st != GSMVI_OK) return st;
+    BAD_ARG(!X || !G || !mu0 || !S0 || !mu || !S, "NULL array");
+    BAD_ARG(ldx < D || ldg < D || lds0 < D || lds < D, "leading dimension smaller than D");
+    BAD_ARG(S == S0 || mu == mu0, "outputs must not alias inputs");
+    hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    double* coef = ctx->small;
+    st = gsm_local_stage(ctx, hs, D, B, X, ldx, G, ldg, mu0, S0, lds0, ctx->sg, D, coef, 4, nullptr, 0);
+    if (st != GSMVI_OK) return st;
+    return gsm_apply(ctx, hs, D, B, X, ldx, ctx->sg, D, coef, 4, mu0, S0, lds0, mu, S, lds);
+}
+
+int gsmvi_gsm_record_len(int D) { return 2 * D + 4; }
+
+int gsmvi_gsm_local_stage_f64(gsmvi_ctx* ctx, void* stream, int D, int B_local, const double* X, int ldx,
+                              const double* G, int ldg, const double* mu0, const double* S0, int lds0, double* rec,
+                              int ldrec) {
+    int st = check_common(ctx, D, B_local, __func__);
+    if (st != GSMVI_OK) return st;
+    BAD_ARG(!X || !G || !mu0 || !S0 || !rec, "NULL array");
+    BAD_ARG(ldx < D || ldg < D || lds0 < D || ldrec < 2 * D + 4, "leading dimension too small");
+    hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    return gsm_local_stage(ctx, hs, D, B_local, X, ldx, G, ldg, mu0, S0, lds0, rec + D, ldrec, rec + 2 * D, ldrec,
+                           rec, ldrec);
+}
+
+int gsmvi_gsm_apply_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* rec, int ldrec, const double* mu0,
+                        const double* S0, int lds0, double* mu, double* S, int lds) {
+    int st = check_common(ctx, D, B, __func__);
+    if (st != GSMVI_OK) return st;
+    BAD_ARG(!rec || !mu0 || !S0 || !mu || !S, "NULL array");
+    BAD_ARG(ldrec < 2 * D + 4 || lds0 < D || lds < D, "leading dimension too small");
+    BAD_ARG(S == S0 || mu == mu0, "outputs must not alias inputs");
+    hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    return gsm_apply(ctx, hs, D, B, rec, ldrec, rec + D, ldrec, rec + 2 * D, ldrec, mu0, S0, lds0, mu, S, lds);
+}
+
+int gsmvi_gaussian_score_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* X, int ldx,
+                             const double* m, const double* P, int ldp, double* G, int ldg) {
+    int st = check_common(ctx, D, B, __func__);
+    if (st != GSMVI_OK) return st;
+    BAD_ARG(!X || !m || !P || !G, "NULL array");
+    BAD_ARG(ldx < D || ldp < D || ldg < D, "leading dimension smaller than D");
+    hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    int kc = 1;
+    st = gsmvi_panel_product(ctx, hs, nullptr, D, B, X, ldx, m, -1.0, P, ldp, ctx->pp, &kc);
+    if (st != GSMVI_OK) return st;
+    gsmvi_launch_panel_finish(hs, nullptr, D, B, kc, ctx->pp, nullptr, G, ldg);
+    return check_launch("k_panel_finish");
+}
+
+int gsmvi_sample_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* Z, int ldz, const double* mu,
+                     const double* R, int ldr, double* X, int ldx) {
+    int st = check_common(ctx, D, B, __func__);
+    if (st != GSMVI_OK) return st;
+    BAD_ARG(!Z || !mu || !R || !X, "NULL array");
+    BAD_ARG(ldz < D || ldr < D || ldx < D, "leading dimension smaller than D");
+    hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    int kc = 1;
+    st = gsmvi_panel_product(ctx, hs, nullptr, D, B, Z, ldz, nullptr, 1.0, R, ldr, ctx->pp, &kc);
+    if (st != GSMVI_OK) return st;
+    gsmvi_launch_panel_finish(hs, nullptr, D, B, kc, ctx->pp, mu, X, ldx);
+    return check_launch("k_panel_finish");
+}
+
+int gsmvi_commit_f64(gsmvi_ctx* ctx, void* stream, int D, const int* info_dev, const double* mu_new,
+                     const double* S_new, int lds_new, double* mu, double* S, int lds, int* n_reverts_dev) {
+    BAD_ARG(!ctx || !info_dev || !mu_new || !S_new || !mu || !S, "NULL argument");
+    BAD_ARG(D <= 0 || lds_new < D || lds < D, "bad size");
+    gsmvi_launch_commit(reinterpret_cast<hipStream_t>(stream), D, info_dev, mu_new, S_new, lds_new, mu, S, lds,
+                        n_reverts_dev);
+    return check_launch("k_commit");
+}
+
+int gsmvi_potrf_f64(gsmvi_ctx* ctx, void* stream, int D, const double* S, int lds, double* R, int ldr,
+                    int* info_dev) {
+    BAD_ARG(!ctx || !S || !R || !info_dev, "NULL argument");
+    BAD_ARG(D <= 0 || lds < D || ldr < D, "bad size");
+    if (D > ctx->max_D) {
+        gsmvi_set_error("%s: %s", __func__, "D exceeds the context's workspace");
+        return GSMVI_ERR_WORKSPACE;
+    }
+    return gsmvi_potrf_impl(ctx, reinterpret_cast<hipStream_t>(stream), D, S, lds, R, ldr, info_dev);
+}
+
+int gsmvi_bam_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* X, int ldx, const double* G,
+                         int ldg, const double* mu0, const double* S0, int lds0, double reg, double jitter,
+                         double* mu, double* S, int lds, int* info_dev) {
+    int st = check_common(ctx, D, B, __func__);
+    if (st != GSMVI_OK) return st;
+    BAD_ARG(!X || !G || !mu0 || !S0 || !mu || !S, "NULL array");
+    BAD_ARG(ldx < D || ldg < D || lds0 < D || lds < D, "leading dimension smaller than D");
+    BAD_ARG(S == S0 || mu == mu0, "outputs must not alias inputs");
+    BAD_ARG(!(reg > 0.0), "reg must be positive");
+    return gsmvi_bam_impl(ctx, reinterpret_cast<hipStream_t>(stream), D, B, X, ldx, G, ldg, mu0, S0, lds0, reg,
+                          jitter, mu, S, lds, info_dev);
+}
+
+}  // extern "C"

@@ -1,0 +1,34 @@
+// Context shared by the ABI translation units (opaque to callers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+
+#define GSMVI_MAX_KC 8
+
+struct gsmvi_ctx {
+    int device = 0;
+    int max_D = 0, max_B = 0;
+    int num_cu = 256;
+    int rmax = 0;              // panel rows the workspace is sized for
+    void* ws = nullptr;        // one hipMalloc
+    size_t ws_bytes = 0;
+    double* pp = nullptr;      // panel partials [GSMVI_MAX_KC][rmax][max_D]
+    double* sg = nullptr;      // [4][rmax][max_D] finished panels (SG, BaM factor panels)
+    double* small = nullptr;   // coefficients and small dense matrices
+    int* ints = nullptr;       // device ints (flags)
+    int tune_panel_kc = 0;
+    int tune_update_sb = 0;
+    int profiling = 0;         // when set, the update kernels are launched with dispatch-timestamp events
+    hipEvent_t ev[8] = {};     // [2*stage], [2*stage+1]: panel, scalars, cov-update, spare
+    int ev_valid[4] = {};
+
+    hipEvent_t* stage_events(int stage) {
+        if (!profiling) return nullptr;
+        ev_valid[stage] = 1;
+        return &ev[2 * stage];
+    }
+};
+
+void gsmvi_set_error(const char* fmt, const char* a, const char* b);
+int gsmvi_panel_product(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D, int nrows, const double* A, int lda,
+                        const double* shift, double alpha, const double* M, int ldm, double* Pp, int* kc_out);

@@ -1,0 +1,256 @@
+"""HipEngine: the device-side operations of the GSM/BaM hot path on torch-ROCm storage.
+
+Every numeric operation is one call into libgsmvi_hip.so on the current torch stream; torch only
+allocates tensors.  The fit drivers (gsm.py, bam.py) talk to an *engine object* with this
+interface, which is how the CPU test-suite exercises their host logic with an oracle-backed
+engine (tests/engines.py) while the product default is always this class.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("gsmvi_amd needs an AMD GPU visible to torch (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback.")
+
+
+class HipEngine:
+    """One context (workspace + launch heuristics) on one device; grows on demand."""
+
+    name = "hip"
+
+    def __init__(self, device=None, max_D=0, max_B=0):
+        self.lib = _lib.load_library()
+        _require_gpu()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else
+                                   (device if isinstance(device, int) else torch.device(device).index or 0))
+        self._ctx = C.c_void_p()
+        self._max_D = 0
+        self._max_B = 0
+        if max_D and max_B:
+            self._ensure(max_D, max_B)
+
+    # ---- context management -------------------------------------------------------------
+    def _ensure(self, D, B):
+        if self._ctx and D <= self._max_D and B <= self._max_B:
+            return
+        newD, newB = max(D, self._max_D), max(B, self._max_B)
+        if self._ctx:
+            torch.cuda.synchronize(self.device)
+            _lib.check("gsmvi_destroy", self.lib.gsmvi_destroy(self._ctx))
+            self._ctx = C.c_void_p()
+        ctx = C.c_void_p()
+        _lib.check("gsmvi_create", self.lib.gsmvi_create(C.byref(ctx), self.device.index, newD, newB))
+        self._ctx, self._max_D, self._max_B = ctx, newD, newB
+
+    def close(self):
+        if self._ctx:
+            torch.cuda.synchronize(self.device)
+            self.lib.gsmvi_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+            self._max_D = self._max_B = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_tuning(self, name, value):
+        self._ensure(max(self._max_D, 1), max(self._max_B, 1))
+        _lib.check("gsmvi_set_tuning", self.lib.gsmvi_set_tuning(self._ctx, name.encode(), int(value)))
+
+    # ---- array helpers ------------------------------------------------------------------
+    def asarray(self, x):
+        """float64 device tensor with unit inner stride (copies host data to the device)."""
+        if isinstance(x, torch.Tensor):
+            t = x.to(device=self.device, dtype=torch.float64)
+        else:
+            t = torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float64)), device=self.device)
+        if t.dim() >= 1 and t.stride(-1) != 1:
+            t = t.contiguous()
+        return t
+
+    def clone(self, x):
+        """Owned device copy (the drivers never alias or mutate the caller's arrays)."""
+        return self.asarray(x).clone()
+
+    def to_numpy(self, t):
+        return t.detach().to("cpu").numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float64, device=self.device)
+
+    def eye(self, D):
+        return torch.eye(D, dtype=torch.float64, device=self.device)
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float64, device=self.device)
+
+    def new_flag(self):
+        return torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def read_flag(self, flag):
+        return int(flag.item())          # synchronises
+
+    def normal_from_host(self, z_host):
+        """Upload a host (B,D) array of standard normals (parity mode: numpy MT19937 stream)."""
+        return torch.as_tensor(z_host, dtype=torch.float64).to(self.device, non_blocking=False)
+
+    def normal(self, B, D, generator=None):
+        return torch.randn(B, D, dtype=torch.float64, device=self.device, generator=generator)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _mat(t, name):
+        assert isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64, \
+            f"{name}: expected a float64 CUDA tensor"
+        assert t.dim() == 2 and t.stride(1) == 1, f"{name}: expected a 2-D tensor with unit inner stride"
+        return C.c_void_p(t.data_ptr()), int(t.stride(0)) if t.shape[0] > 1 else int(max(t.stride(0), t.shape[1]))
+
+    @staticmethod
+    def _vec(t, name):
+        assert isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.dim() == 1 \
+            and (t.numel() <= 1 or t.stride(0) == 1), f"{name}: expected a contiguous float64 CUDA vector"
+        return C.c_void_p(t.data_ptr())
+
+    # ---- the hot path -------------------------------------------------------------------
+    def gsm_update(self, X, G, mu0, S0, out=None):
+        """(mu, S) = gsm_update(samples, vs, mu0, S0)   [gsmvi/gsm_numpy.py:27-55]."""
+        assert X.dim() == 2 and G.dim() == 2            # gsm_numpy.py:43-44
+        B, D = X.shape
+        assert G.shape == (B, D) and mu0.shape == (D,) and S0.shape == (D, D)
+        self._ensure(D, B)
+        mu, S = (self.empty(D), self.empty(D, D)) if out is None else out
+        px, ldx = self._mat(X, "samples")
+        pg, ldg = self._mat(G, "vs")
+        ps0, lds0 = self._mat(S0, "S0")
+        ps, lds = self._mat(S, "S")
+        _lib.check("gsmvi_gsm_update_f64", self.lib.gsmvi_gsm_update_f64(
+            self._ctx, self._stream(), D, B, px, ldx, pg, ldg, self._vec(mu0, "mu0"), ps0, lds0,
+            self._vec(mu, "mu"), ps, lds))
+        return mu, S
+
+    def record_len(self, D):
+        return int(self.lib.gsmvi_gsm_record_len(int(D)))
+
+    def gsm_local_stage(self, X, G, mu0, S0, out=None):
+        """Per-sample records [x | S0 g | alpha beta c rho] for this rank's samples (batch-sharded
+        path; gsmvi/gsm_numpy.py:7-11,15 for each local sample)."""
+        Bl, D = X.shape
+        self._ensure(D, Bl)
+        rec = self.empty(Bl, self.record_len(D)) if out is None else out
+        px, ldx = self._mat(X, "samples")
+        pg, ldg = self._mat(G, "vs")
+        ps0, lds0 = self._mat(S0, "S0")
+        pr, ldr = self._mat(rec, "rec")
+        _lib.check("gsmvi_gsm_local_stage_f64", self.lib.gsmvi_gsm_local_stage_f64(
+            self._ctx, self._stream(), D, Bl, px, ldx, pg, ldg, self._vec(mu0, "mu0"), ps0, lds0, pr, ldr))
+        return rec
+
+    def gsm_apply(self, rec, mu0, S0, out=None):
+        """Combined rank-2B update from ALL samples' records (gsmvi/gsm_numpy.py:17-23,50-53)."""
+        B = rec.shape[0]
+        D = mu0.shape[0]
+        self._ensure(D, B)
+        mu, S = (self.empty(D), self.empty(D, D)) if out is None else out
+        pr, ldr = self._mat(rec, "rec")
+        ps0, lds0 = self._mat(S0, "S0")
+        ps, lds = self._mat(S, "S")
+        _lib.check("gsmvi_gsm_apply_f64", self.lib.gsmvi_gsm_apply_f64(
+            self._ctx, self._stream(), D, B, pr, ldr, self._vec(mu0, "mu0"), ps0, lds0, self._vec(mu, "mu"),
+            ps, lds))
+        return mu, S
+
+    def set_profiling(self, on):
+        self._ensure(max(self._max_D, 1), max(self._max_B, 1))
+        _lib.check("gsmvi_set_profiling", self.lib.gsmvi_set_profiling(self._ctx, int(bool(on))))
+
+    def get_profile(self):
+        """Kernel durations (ms) of the last profiled update: panel, scalars, cov_update."""
+        ms = (C.c_float * 3)()
+        _lib.check("gsmvi_get_profile", self.lib.gsmvi_get_profile(self._ctx, ms, 3))
+        return {"panel": ms[0], "scalars": ms[1], "cov_update": ms[2]}
+
+    def gaussian_score(self, X, m, P, out=None):
+        """G = -(X - m) P   [examples/example_gsm_numpy.py:24-29]."""
+        B, D = X.shape
+        self._ensure(D, B)
+        G = self.empty(B, D) if out is None else out
+        px, ldx = self._mat(X, "X")
+        pp, ldp = self._mat(P, "P")
+        pg, ldg = self._mat(G, "G")
+        _lib.check("gsmvi_gaussian_score_f64", self.lib.gsmvi_gaussian_score_f64(
+            self._ctx, self._stream(), D, B, px, ldx, self._vec(m, "m"), pp, ldp, pg, ldg))
+        return G
+
+    def potrf(self, S, out=None, flag=None):
+        """Upper Cholesky factor R (R^T R = S) and a device flag (0 = positive definite)."""
+        D = S.shape[0]
+        self._ensure(D, max(self._max_B, 1))
+        R = self.empty(D, D) if out is None else out
+        flag = self.new_flag() if flag is None else flag
+        ps, lds = self._mat(S, "S")
+        pr, ldr = self._mat(R, "R")
+        _lib.check("gsmvi_potrf_f64", self.lib.gsmvi_potrf_f64(
+            self._ctx, self._stream(), D, ps, lds, pr, ldr, C.c_void_p(flag.data_ptr())))
+        return R, flag
+
+    def sample(self, Z, mu, R, out=None):
+        """X = mu + Z R   [replaces np.random.multivariate_normal, gsmvi/gsm_numpy.py:116]."""
+        B, D = Z.shape
+        self._ensure(D, B)
+        X = self.empty(B, D) if out is None else out
+        pz, ldz = self._mat(Z, "Z")
+        pr, ldr = self._mat(R, "R")
+        px, ldx = self._mat(X, "X")
+        _lib.check("gsmvi_sample_f64", self.lib.gsmvi_sample_f64(
+            self._ctx, self._stream(), D, B, pz, ldz, self._vec(mu, "mu"), pr, ldr, px, ldx))
+        return X
+
+    def commit(self, flag, mu_new, S_new, mu, S, n_reverts=None):
+        """In place: (mu, S) <- (mu_new, S_new) iff flag == 0   [gsmvi/gsm_numpy.py:121-125]."""
+        D = mu.shape[0]
+        self._ensure(D, max(self._max_B, 1))
+        psn, ldsn = self._mat(S_new, "S_new")
+        ps, lds = self._mat(S, "S")
+        _lib.check("gsmvi_commit_f64", self.lib.gsmvi_commit_f64(
+            self._ctx, self._stream(), D, C.c_void_p(flag.data_ptr()), self._vec(mu_new, "mu_new"), psn, ldsn,
+            self._vec(mu, "mu"), ps, lds, C.c_void_p(n_reverts.data_ptr()) if n_reverts is not None else None))
+
+    def bam_update(self, X, G, mu0, S0, reg, jitter=0.0, out=None, flag=None):
+        """(mu, S) of BaM [gsmvi/bam.py:72-114]; S symmetrised, jitter on the diagonal."""
+        assert X.dim() == 2 and G.dim() == 2            # bam.py:47-48
+        B, D = X.shape
+        self._ensure(D, B)
+        mu, S = (self.empty(D), self.empty(D, D)) if out is None else out
+        flag = self.new_flag() if flag is None else flag
+        px, ldx = self._mat(X, "samples")
+        pg, ldg = self._mat(G, "vs")
+        ps0, lds0 = self._mat(S0, "S0")
+        ps, lds = self._mat(S, "S")
+        _lib.check("gsmvi_bam_update_f64", self.lib.gsmvi_bam_update_f64(
+            self._ctx, self._stream(), D, B, px, ldx, pg, ldg, self._vec(mu0, "mu0"), ps0, lds0,
+            float(reg), float(jitter), self._vec(mu, "mu"), ps, lds, C.c_void_p(flag.data_ptr())))
+        return mu, S, flag
+
+
+_ENGINES = {}
+
+
+def get_engine(device=None):
+    """Process-wide engine per device (created on first use; raises if the library or GPU is missing)."""
+    _lib.load_library()
+    _require_gpu()
+    idx = torch.cuda.current_device() if device is None else (device if isinstance(device, int)
+                                                              else (torch.device(device).index or 0))
+    if idx not in _ENGINES:
+        _ENGINES[idx] = HipEngine(idx)
+    return _ENGINES[idx]

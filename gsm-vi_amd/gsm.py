@@ -1,0 +1,147 @@
+"""GSM fit driver and update function with the reference's signatures.
+
+Mirrors ``gsmvi/gsm_numpy.py`` / ``gsmvi/gsm.py`` (reference file:line in each docstring).  The
+driver is host Python exactly like the reference's; every array operation inside the loop is a
+HIP kernel call through the engine (``engine.py`` -> C ABI -> ``csrc/``).
+"""
+import numpy as np
+import torch
+
+from .engine import get_engine
+
+
+def _is_torch(x):
+    return isinstance(x, torch.Tensor)
+
+
+def gsm_update(samples, vs, mu0, S0, engine=None):
+    """Drop-in for ``gsm_update(samples, vs, mu0, S0)`` (gsmvi/gsm_numpy.py:27-55, gsmvi/gsm.py:31-58).
+
+    Inputs (B,D), (B,D), (D,), (D,D); returns new ``(mu, S)`` and never modifies its inputs.
+    numpy in -> float64 numpy out (as gsm_numpy.py:47 does); CUDA torch tensors in -> torch out.
+    Shape errors raise AssertionError like the reference (gsm_numpy.py:43-44).
+    """
+    assert len(samples.shape) == 2
+    assert len(vs.shape) == 2
+    eng = engine if engine is not None else get_engine()
+    want_torch = _is_torch(samples)
+    mu, S = eng.gsm_update(eng.asarray(samples), eng.asarray(vs), eng.asarray(mu0), eng.asarray(S0))
+    return (mu, S) if want_torch else (eng.to_numpy(mu), eng.to_numpy(S))
+
+
+def _legacy_mvn(rs, mean, cov, size):
+    """Compat sampler: the exact stream of ``np.random.multivariate_normal`` after
+    ``np.random.seed(key)`` (gsmvi/gsm_numpy.py:105,116): z from MT19937, SVD factor of cov."""
+    D = mean.shape[0]
+    z = rs.standard_normal((size, D))
+    _, s, vt = np.linalg.svd(cov)
+    return mean + z @ (np.sqrt(s)[:, None] * vt)
+
+
+class GSM:
+    """Wrapper class for using GSM updates to fit a distribution (gsmvi/gsm_numpy.py:60-75,
+    gsmvi/gsm.py:62-77).
+
+    D    : dimensionality.
+    lp   : target log-probability; only handed to ``monitor`` (gsm_numpy.py:68-69).
+    lp_g : score function (B,D) -> (B,D).  A plain callable receives and returns numpy arrays,
+           exactly as in the reference (its samples are host numpy arrays, gsm_numpy.py:116-117).
+           A callable marked ``device_native`` (``gsmvi_amd.device_score`` /
+           ``GaussianTarget.lp_g`` / ``score_from_logp``) receives and returns float64 CUDA
+           tensors and keeps the whole iteration on the GPU.
+    """
+
+    def __init__(self, D, lp, lp_g, engine=None):
+        self.D = D
+        self.lp = lp
+        self.lp_g = lp_g
+        self._engine = engine
+
+    # ------------------------------------------------------------------------------
+    def fit(self, key, mean=None, cov=None, batch_size=2, niter=5000, nprint=10, verbose=True,
+            check_goodness=True, monitor=None, *, sampler="cholesky", rng="numpy", as_torch=False,
+            forced_samples=None):
+        """Fit N(mean, cov) to the target (gsmvi/gsm_numpy.py:77-129, gsmvi/gsm.py:79-133).
+
+        Same arguments and return value as the reference.  Behaviour kept: ``niter + 1`` updates
+        (:106); monitor called every ``monitor.checkpoint`` iterations and once at the end with
+        the reference's ``nevals`` bookkeeping (:103,:110-113,:119,:127-128); a covariance that
+        fails the Cholesky test reverts BOTH mean and cov (:121-125); ``check_goodness`` is
+        accepted and, as in the reference (:77 vs :121), the test always runs.
+        Documented deviations: ``nprint`` is clamped to ``niter`` like bam.py:177 instead of
+        raising ZeroDivisionError (:107); the RNG is a private ``RandomState(key)`` with the same
+        z-stream as ``np.random.seed(key)`` (:105); revert messages are printed at the progress
+        prints (count since the last print) so that the loop never synchronises per iteration.
+
+        Extra keyword-only arguments (not in the reference):
+          sampler : "cholesky" (default) x = mean + R^T z from the device Cholesky factor, or "svd":
+                    the reference's legacy host sampler, bit-compatible sample stream (small D).
+          rng     : "numpy" (host MT19937 z-stream, uploaded) or "device" (torch generator).
+          forced_samples : (niter+1, B, D) teacher-forced samples replacing the sampler.
+        """
+        eng = self._engine if self._engine is not None else get_engine()
+        D, B = self.D, int(batch_size)
+        mean_t = eng.zeros(D) if mean is None else eng.clone(mean).reshape(D)
+        cov_t = eng.eye(D) if cov is None else eng.clone(cov).reshape(D, D)
+        nevals = 1
+        rs = np.random.RandomState(key if not _is_torch(key) else int(key.flatten()[0]))
+        gen = None
+        if rng == "device":
+            gen = torch.Generator(device=eng.device)
+            gen.manual_seed(int(key) if not _is_torch(key) else int(key.flatten()[0]))
+        native = bool(getattr(self.lp_g, "device_native", False))
+        mon_native = bool(getattr(monitor, "device_native", False)) if monitor is not None else False
+
+        # working buffers (the user's arrays are never aliased or mutated)
+        mean_new, cov_new = eng.empty(D), eng.empty(D, D)
+        R, R_new = eng.empty(D, D), eng.empty(D, D)
+        Xbuf = eng.empty(B, D)
+        flag, n_rev = eng.new_flag(), eng.new_flag()
+        use_factor = sampler == "cholesky" and forced_samples is None
+        if use_factor:                      # the sampling factor of the initial covariance
+            eng.potrf(cov_t, out=R, flag=flag)
+            if eng.read_flag(flag) != 0:
+                raise ValueError("initial covariance is not positive definite")
+
+        nprint = max(1, min(int(nprint), int(niter))) if niter > 0 else 1   # bam.py:177 guard
+        every = max(1, niter // nprint) if niter > 0 else 1
+        reverts_seen = 0
+        i = 0
+        for i in range(niter + 1):
+            if verbose and i % every == 0:
+                print(f"Iteration {i} of {niter}")
+                r = eng.read_flag(n_rev)
+                if r > reverts_seen:
+                    print(f"Bad update for covariance matrix. Revert ({r - reverts_seen} since last print)")
+                    reverts_seen = r
+            if monitor is not None and i % monitor.checkpoint == 0:
+                mc = [mean_t, cov_t] if mon_native else [eng.to_numpy(mean_t).copy(), eng.to_numpy(cov_t).copy()]
+                monitor(i, mc, self.lp, key, nevals=nevals)
+                nevals = 0
+
+            if forced_samples is not None:
+                X = eng.asarray(forced_samples[i])
+            elif sampler == "svd":
+                X = eng.asarray(_legacy_mvn(rs, eng.to_numpy(mean_t), eng.to_numpy(cov_t), B))
+            else:
+                Z = eng.normal(B, D, gen) if gen is not None else eng.normal_from_host(rs.standard_normal((B, D)))
+                X = eng.sample(Z, mean_t, R, out=Xbuf)
+            vs = self.lp_g(X) if native else eng.asarray(self.lp_g(eng.to_numpy(X)))
+            eng.gsm_update(X, vs, mean_t, cov_t, out=(mean_new, cov_new))
+            nevals += B
+            eng.potrf(cov_new, out=R_new, flag=flag)              # _check_goodness, :121,:132-146
+            eng.commit(flag, mean_new, cov_new, mean_t, cov_t, n_rev)
+            if use_factor:
+                eng.commit(flag, mean_new, R_new, mean_t, R, None)
+
+        if verbose:
+            r = eng.read_flag(n_rev)
+            if r > reverts_seen:
+                print(f"Bad update for covariance matrix. Revert ({r - reverts_seen} since last print)")
+        if monitor is not None:
+            mc = [mean_t, cov_t] if mon_native else [eng.to_numpy(mean_t).copy(), eng.to_numpy(cov_t).copy()]
+            monitor(i, mc, self.lp, key, nevals=nevals)
+        self.n_reverts = eng.read_flag(n_rev)
+        if as_torch:
+            return mean_t, cov_t
+        return eng.to_numpy(mean_t), eng.to_numpy(cov_t)

@@ -1,0 +1,56 @@
+"""Score providers for the fit drivers.
+
+``GaussianTarget`` is the benchmark target of the reference's examples
+(examples/example_gsm_numpy.py:8-31: ``lp_g(x) = -icov (x - mean)``) evaluated by the HIP panel
+kernel.  ``device_score`` marks a user callable as taking/returning CUDA tensors;
+``score_from_logp`` is the sum-then-autograd helper matching the JAX examples
+(examples/example_gsm.py:34-35: ``lp_g = jit(grad(lambda x: sum(lp(x))))``).
+"""
+import numpy as np
+import torch
+
+from .engine import get_engine
+
+
+def device_score(fn):
+    """Decorator: ``fn`` maps a float64 CUDA tensor (B,D) to a float64 CUDA tensor (B,D)."""
+    fn.device_native = True
+    return fn
+
+
+def score_from_logp(logp):
+    """Score via torch autograd of a *summed* log-probability (examples/example_gsm.py:34-35)."""
+    def lp_g(x):
+        xg = x.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            total = logp(xg).sum()
+            (g,) = torch.autograd.grad(total, xg)
+        return g.detach()
+    lp_g.device_native = True
+    return lp_g
+
+
+class GaussianTarget:
+    """N(mean, cov) with device-resident precision matrix; ``lp`` / ``lp_g`` follow
+    examples/example_gsm_numpy.py:17-29."""
+
+    def __init__(self, mean, cov=None, precision=None, engine=None):
+        self.engine = engine if engine is not None else get_engine()
+        eng = self.engine
+        if precision is None:
+            precision = np.linalg.inv(np.asarray(cov, dtype=np.float64))
+        P = np.asarray(precision, dtype=np.float64)
+        self.mean = eng.asarray(np.asarray(mean, dtype=np.float64))
+        self.P = eng.asarray(0.5 * (P + P.T))
+        self.D = int(self.mean.shape[0])
+
+        def lp_g(x):
+            return eng.gaussian_score(x, self.mean, self.P)
+        lp_g.device_native = True
+        self.lp_g = lp_g
+
+    def lp(self, x):
+        """sum_b -1/2 (m - x_b)^T P (m - x_b); monitor-only, so plain torch is fine here."""
+        x = self.engine.asarray(x)
+        r = self.mean[None, :] - x
+        return -0.5 * torch.einsum("bi,ij,bj->", r, self.P, r)

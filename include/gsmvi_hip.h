@@ -1,0 +1,151 @@
+/*
+ * gsmvi_hip.h -- C ABI of the MI355X (gfx950) GSM / BaM update engine.
+ *
+ * The reference (modichirag/GSM-VI) has no FFI layer: its boundary for this path is the set of
+ * pure Python callables listed below.  Each entry point here is what a binding for that callable
+ * would bind; the Python mirror in gsm-vi_amd/ calls them through ctypes.
+ *
+ *   reference callable (file:line, relative to the reference tree)     ->  entry point
+ *   gsmvi/gsm_numpy.py:27-55  gsm_update(samples, vs, mu0, S0)          ->  gsmvi_gsm_update_f64
+ *   gsmvi/gsm.py:31-58        gsm_update (JAX twin)                     ->  gsmvi_gsm_update_f64
+ *   examples/example_gsm_numpy.py:24-29  lp_g of the Gaussian target    ->  gsmvi_gaussian_score_f64
+ *   gsmvi/gsm_numpy.py:116    np.random.multivariate_normal(mean,cov,B) ->  gsmvi_sample_f64 (+ gsmvi_potrf_f64)
+ *   gsmvi/gsm_numpy.py:132-146 _check_goodness(cov)                     ->  gsmvi_potrf_f64 (info flag)
+ *   gsmvi/bam.py:72-114       bam_lowrank_update(samples,vs,mu0,S0,reg) ->  gsmvi_bam_update_f64
+ *   gsmvi/bam.py:31-69        bam_update(samples,vs,mu0,S0,reg)         ->  gsmvi_bam_update_f64 (same result, K6)
+ *
+ * Conventions
+ *   - All matrices are row-major float64 in DEVICE memory; `ld*` are leading dimensions in elements.
+ *   - Calls are asynchronous on `stream` (a hipStream_t passed as void*); nothing synchronises.
+ *   - Inputs are never modified; outputs must not alias inputs (reference updates are pure,
+ *     gsm_numpy.py:47-55) unless an entry point says otherwise.
+ *   - S0 must be symmetric (it is a covariance); the kernels read it once, by rows.
+ *   - Every function returns a gsmvi_status; no C++ exception crosses the ABI.
+ *   - One context per stream; calls on one context are not thread-safe (the reference is
+ *     single-threaded: gsm_numpy.py:105 uses the global numpy RNG).
+ */
+#ifndef GSMVI_HIP_H
+#define GSMVI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSMVI_ABI_VERSION 1
+
+typedef enum gsmvi_status {
+    GSMVI_OK = 0,
+    GSMVI_ERR_BAD_ARG = 1,    /* NULL pointer, non-positive size, ld < D, aliasing, ...            */
+    GSMVI_ERR_HIP = 2,        /* a HIP runtime call failed; see gsmvi_last_error()                 */
+    GSMVI_ERR_NO_DEVICE = 3,  /* no gfx950 device visible                                          */
+    GSMVI_ERR_WORKSPACE = 4,  /* (D,B) exceeds what the context was created for                    */
+    GSMVI_ERR_UNSUPPORTED = 5
+} gsmvi_status;
+
+typedef struct gsmvi_ctx gsmvi_ctx;   /* opaque: device id, workspace, launch heuristics */
+
+int gsmvi_abi_version(void);
+const char* gsmvi_status_string(int status);
+/* Message of the last failing call on this host thread ("" if none). */
+const char* gsmvi_last_error(void);
+/* Number of HIP devices; GSMVI_ERR_NO_DEVICE (and *n = 0) when there is none. */
+int gsmvi_device_count(int* n);
+
+/* Workspace bytes a context allocates for problems up to (max_D, max_B). */
+size_t gsmvi_workspace_bytes(int max_D, int max_B);
+/* Creates a context on `device` with workspace for D <= max_D, B <= max_B. */
+int gsmvi_create(gsmvi_ctx** out, int device, int max_D, int max_B);
+int gsmvi_destroy(gsmvi_ctx* ctx);
+/* Launch-heuristic knob for experiments: name in {"panel_kc","update_tile", ...}; value<=0 = auto */
+int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value);
+
+/*
+ * GSM batch update (dense-covariance path).  Replaces gsmvi/gsm_numpy.py:27-55.
+ *   X  (B x D, ldx)  samples            G  (B x D, ldg)  scores lp_g(X)
+ *   mu0 (D)          current mean       S0 (D x D, lds0) current covariance (symmetric)
+ *   mu  (D)          new mean           S  (D x D, lds)  new covariance
+ * mu = mu0 + mean_b dmu_b ; S = S0 + mean_b (d_b d_b^T - e_b e_b^T), d_b = mu0 - x_b, e_b = d_b + dmu_b.
+ * Three kernels: panel product SG = G S0 (fp64 MFMA), per-sample scalars, rank-2B update (fp64 MFMA).
+ */
+int gsmvi_gsm_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
+                         const double* X, int ldx, const double* G, int ldg,
+                         const double* mu0, const double* S0, int lds0,
+                         double* mu, double* S, int lds);
+
+/*
+ * The same update in two stages, for the batch-sharded multi-GPU path (one process per GPU):
+ *   local stage : for this rank's B_local samples, panel product + per-sample scalars; writes one
+ *                 record per sample  rec[b] = [ x_b (D) | S0 g_b (D) | alpha, beta, c, rho ]  with row
+ *                 stride ldrec >= gsmvi_gsm_record_len(D) = 2D+4.  Records of all ranks are
+ *                 all-gathered (RCCL) by the caller;
+ *   apply       : every replica applies the combined rank-2B update from all B records.
+ * gsmvi_gsm_update_f64 == local stage with B_local = B followed by apply.
+ */
+int gsmvi_gsm_record_len(int D);
+int gsmvi_gsm_local_stage_f64(gsmvi_ctx* ctx, void* stream, int D, int B_local,
+                              const double* X, int ldx, const double* G, int ldg,
+                              const double* mu0, const double* S0, int lds0,
+                              double* rec, int ldrec);
+int gsmvi_gsm_apply_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
+                        const double* rec, int ldrec, const double* mu0,
+                        const double* S0, int lds0, double* mu, double* S, int lds);
+
+/*
+ * Profiling mode (used by bench.py for the roofline line): when on, the three kernels of the GSM
+ * update are launched with dispatch-timestamp events; gsmvi_get_profile waits for the last call
+ * and returns the kernel durations in milliseconds: ms[0] panel product, ms[1] per-sample
+ * scalars, ms[2] covariance update (-1 where a stage did not run).
+ */
+int gsmvi_set_profiling(gsmvi_ctx* ctx, int on);
+int gsmvi_get_profile(gsmvi_ctx* ctx, float* ms, int n);
+
+/*
+ * Score of the Gaussian target N(m, P^-1) at the rows of X: G = -(X - 1 m^T) P.
+ * Replaces the user callback of examples/example_gsm_numpy.py:24-29 (P symmetric precision matrix).
+ */
+int gsmvi_gaussian_score_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
+                             const double* X, int ldx, const double* m,
+                             const double* P, int ldp, double* G, int ldg);
+
+/*
+ * Upper Cholesky factor R (R^T R = S, R upper triangular, strictly-lower part zeroed) of a
+ * symmetric matrix; *info_dev (device int) = 0 if S is positive definite, else 1 + index of the
+ * first failing pivot (also set when a NaN is met).  Replaces np.linalg.cholesky inside
+ * _check_goodness (gsm_numpy.py:132-146) and supplies the sampling factor.
+ */
+int gsmvi_potrf_f64(gsmvi_ctx* ctx, void* stream, int D, const double* S, int lds,
+                    double* R, int ldr, int* info_dev);
+
+/*
+ * Draw samples X = 1 mu^T + Z R for whitened draws Z (B x D) and an upper factor R (R^T R = cov).
+ * Replaces np.random.multivariate_normal(mean, cov, size=B) (gsm_numpy.py:116); Z is supplied by
+ * the caller (host MT19937 stream in parity mode, device Philox in throughput mode).
+ */
+int gsmvi_sample_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
+                     const double* Z, int ldz, const double* mu, const double* R, int ldr,
+                     double* X, int ldx);
+
+/*
+ * Commit-or-revert (gsm_numpy.py:121-125): if *info_dev == 0 copy (mu_new, S_new) over (mu, S),
+ * else leave them; *n_reverts_dev is incremented on a revert.  Device-side, no host sync.
+ */
+int gsmvi_commit_f64(gsmvi_ctx* ctx, void* stream, int D, const int* info_dev,
+                     const double* mu_new, const double* S_new, int lds_new,
+                     double* mu, double* S, int lds, int* n_reverts_dev);
+
+/*
+ * BaM update (gsmvi/bam.py:72-114 with the exact rank-(B+1) factor of U; equals bam.py:31-69).
+ * Symmetrised output (bam.py:199 does this in fit); jitter is added to the diagonal (bam.py:198).
+ */
+int gsmvi_bam_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
+                         const double* X, int ldx, const double* G, int ldg,
+                         const double* mu0, const double* S0, int lds0, double reg, double jitter,
+                         double* mu, double* S, int lds, int* info_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSMVI_HIP_H */

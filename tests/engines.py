@@ -1,0 +1,120 @@
+"""Test-only engine with the HipEngine interface backed by the numpy oracle.  It lets the CPU suite
+exercise the fit drivers' HOST logic (RNG stream, monitor cadence, revert, retries, sharding).  It is
+never importable from the product package."""
+import numpy as np
+
+from oracle import gsm_oracle as orc
+from oracle import bam_oracle as borc
+
+
+class Flag:
+    def __init__(self):
+        self.v = 0
+
+
+class OracleEngine:
+    name = "oracle(test-only)"
+    device = "cpu"
+
+    def asarray(self, x):
+        return np.array(x, dtype=np.float64, copy=True) if not isinstance(x, np.ndarray) else x.astype(np.float64)
+
+    def clone(self, x):
+        return np.array(x, dtype=np.float64, copy=True)
+
+    def to_numpy(self, t):
+        return np.asarray(t)
+
+    def empty(self, *shape):
+        return np.empty(shape)
+
+    def zeros(self, *shape):
+        return np.zeros(shape)
+
+    def eye(self, D):
+        return np.eye(D)
+
+    def new_flag(self):
+        return Flag()
+
+    def read_flag(self, f):
+        return f.v
+
+    def normal_from_host(self, z):
+        return np.asarray(z, dtype=np.float64)
+
+    def normal(self, B, D, generator=None):
+        raise NotImplementedError
+
+    def gsm_update(self, X, G, mu0, S0, out=None):
+        mu, S = orc.gsm_update_batched(X, G, mu0, S0)
+        if out is not None:
+            out[0][...] = mu
+            out[1][...] = S
+            return out
+        return mu, S
+
+    def record_len(self, D):
+        return 2 * D + 4
+
+    def gsm_local_stage(self, X, G, mu0, S0, out=None):
+        t = orc.gsm_per_sample_terms(X, G, mu0, S0)
+        beta = 1 / (1 + t["rho"])
+        c = (t["gSg"] - t["mv"]) / t["den"]
+        rec = np.concatenate([X, t["SG"], np.stack([1 - (1 + c) * beta, beta, c, t["rho"]], axis=1)], axis=1)
+        if out is not None:
+            out[...] = rec
+            return out
+        return rec
+
+    def gsm_apply(self, rec, mu0, S0, out=None):
+        D = mu0.shape[0]
+        B = rec.shape[0]
+        X, SG, al, be, c = rec[:, :D], rec[:, D:2 * D], rec[:, 2 * D], rec[:, 2 * D + 1], rec[:, 2 * D + 2]
+        d = mu0[None, :] - X
+        e = al[:, None] * d + be[:, None] * SG
+        dmu = be[:, None] * ((SG - d) - c[:, None] * d)
+        mu = mu0 + dmu.mean(axis=0)
+        S = S0 + (d.T @ d - e.T @ e) / B
+        if out is not None:
+            out[0][...] = mu
+            out[1][...] = S
+            return out
+        return mu, S
+
+    def gaussian_score(self, X, m, P, out=None):
+        return orc.gaussian_score(X, m, P)
+
+    def potrf(self, S, out=None, flag=None):
+        flag = Flag() if flag is None else flag
+        R = np.zeros_like(S) if out is None else out
+        if orc.cov_is_good(S):
+            R[...] = np.linalg.cholesky(S).T
+            flag.v = 0
+        else:
+            flag.v = 1
+        return R, flag
+
+    def sample(self, Z, mu, R, out=None):
+        X = mu[None, :] + Z @ R
+        if out is not None:
+            out[...] = X
+            return out
+        return X
+
+    def commit(self, flag, mu_new, S_new, mu, S, n_reverts=None):
+        if flag.v == 0:
+            mu[...] = mu_new
+            S[...] = S_new
+        elif n_reverts is not None:
+            n_reverts.v += 1
+
+    def bam_update(self, X, G, mu0, S0, reg, jitter=0.0, out=None, flag=None):
+        mu, S = borc.bam_lowrank_update_exact(X, G, mu0, S0, reg)
+        S = 0.5 * (S + S.T) + jitter * np.eye(S.shape[0])
+        flag = Flag() if flag is None else flag
+        if out is not None:
+            out[0][...] = mu
+            out[1][...] = S
+            return out[0], out[1], flag
+        return mu, S, flag

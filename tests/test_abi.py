@@ -1,0 +1,73 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/gsmvi_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "gsmvi_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gsmvi_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_is_built():
+    from gsmvi_amd import _lib
+    assert os.path.exists(_lib.library_path()), "run __graft_entry__.build() first"
+
+
+def test_exports_every_declared_symbol():
+    from gsmvi_amd import _lib
+    lib = _lib.load_library()
+    declared = _header_symbols()
+    assert len(declared) >= 12
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in gsmvi_hip.h but not exported"
+    assert set(_lib.exported_symbols()) == set(declared), "ctypes table out of sync with the header"
+
+
+def test_abi_version_and_status_strings():
+    from gsmvi_amd import _lib
+    lib = _lib.load_library()
+    assert lib.gsmvi_abi_version() == 1
+    assert lib.gsmvi_status_string(0) == b"ok"
+    assert b"argument" in lib.gsmvi_status_string(1)
+    assert lib.gsmvi_workspace_bytes(1024, 32) > 8 * 1024 * 32 * 8
+    assert lib.gsmvi_workspace_bytes(0, 1) == 0
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    from gsmvi_amd import _lib
+    lib = _lib.load_library()
+    ctx = ctypes.c_void_p()
+    assert lib.gsmvi_create(None, 0, 8, 2) == 1
+    assert lib.gsmvi_create(ctypes.byref(ctx), 0, -1, 2) == 1
+    assert lib.gsmvi_gsm_update_f64(None, None, 4, 2, None, 4, None, 4, None, None, 4, None, None, 4) == 1
+    assert b"ctx" in lib.gsmvi_last_error()
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a GPU the product path must raise, never compute on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import numpy as np
+    import gsmvi_amd
+    x = np.zeros((2, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gsmvi_amd.gsm_update(x, x, np.zeros(4), np.eye(4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gsmvi_amd.GSM(4, None, lambda s: s).fit(0, niter=1, verbose=False)
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "gsm-vi_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("oracle-backed", "").replace("oracle(test", ""), \
+                    f"{f} mentions the oracle"

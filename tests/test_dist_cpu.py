@@ -1,0 +1,72 @@
+"""The N>1 (batch-sharded) path on CPU: world_size=2 gloo processes, oracle-backed test engine.
+Checks the sharding/exchange logic of gsm-vi_amd/dist.py; the HIP kernels behind the same two
+stage calls are checked on the GPU in test_gpu_gsm_update.py::test_two_stage_equals_fused."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import gsm_oracle as orc
+        from engines import OracleEngine
+        from gsmvi_amd.dist import sharded_gsm_update, shard_bounds
+        eng = OracleEngine()
+        st = orc.make_update_state(24, 8, 3)
+        lo, hi = shard_bounds(8, world, rank)
+        mu, S = sharded_gsm_update(eng, st["samples"][lo:hi], st["vs"][lo:hi], st["mu0"], st["S0"])
+        mu_o, S_o = orc.gsm_update_faithful(st["samples"], st["vs"], st["mu0"], st["S0"])
+        err = max(np.abs(mu - mu_o).max(), np.abs(S - S_o).max())
+        # replicas must be bit-identical
+        t = torch.from_numpy(np.concatenate([mu, S.ravel()]))
+        gathered = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        same = all(torch.equal(gathered[0], x) for x in gathered)
+        q.put((rank, float(err), bool(same)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_update_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, same in res:
+        assert err < 1e-12 and same, (rank, err, same)
+
+
+def test_shard_bounds():
+    from gsmvi_amd.dist import shard_bounds
+    assert [shard_bounds(32, 8, r) for r in (0, 7)] == [(0, 4), (28, 32)]
+    with pytest.raises(AssertionError):
+        shard_bounds(10, 4, 0)
+
+
+def test_world1_no_process_group():
+    from oracle import gsm_oracle as orc
+    from engines import OracleEngine
+    from gsmvi_amd.dist import sharded_gsm_update
+    st = orc.make_update_state(12, 4, 1)
+    mu, S = sharded_gsm_update(OracleEngine(), st["samples"], st["vs"], st["mu0"], st["S0"])
+    mu_o, S_o = orc.gsm_update_batched(st["samples"], st["vs"], st["mu0"], st["S0"])
+    assert np.abs(mu - mu_o).max() < 1e-12 and np.abs(S - S_o).max() < 1e-12

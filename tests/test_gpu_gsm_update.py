@@ -1,0 +1,167 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the golden vectors generated
+from the reference and against the CPU oracle.  Tolerance: BASELINE.json's bar is 1e-5 relative on
+mean/cov; fp64 kernels are held to 1e-11 here."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-11
+NORTH_STAR_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import gsmvi_amd
+    return gsmvi_amd.get_engine()       # raises (never falls back) without library / GPU
+
+
+def _oracle():
+    from oracle import gsm_oracle as orc
+    return orc
+
+
+def test_engine_is_the_hip_engine(eng):
+    import gsmvi_amd
+    assert isinstance(eng, gsmvi_amd.HipEngine) and eng.name == "hip"
+
+
+def test_g1_golden_vectors(golden, eng):
+    import gsmvi_amd
+    g = golden("g1_update.npz")
+    for c in [str(x) for x in g["cases"]]:
+        mu, S = gsmvi_amd.gsm_update(g[f"{c}/samples"], g[f"{c}/vs"], g[f"{c}/mu0"], g[f"{c}/S0"])
+        assert isinstance(mu, np.ndarray) and mu.dtype == np.float64
+        assert rel_err(mu, g[f"{c}/mu"]) < TOL, c
+        assert rel_err(S, g[f"{c}/S"]) < TOL, c
+        assert rel_err(S, S.T) < 1e-14, c
+
+
+@pytest.mark.parametrize("D,B", [(1, 1), (2, 1), (3, 2), (5, 2), (10, 2), (17, 3), (63, 7), (64, 8), (65, 9),
+                                 (100, 31), (127, 33), (129, 16), (256, 8), (257, 17), (300, 64), (320, 65),
+                                 (200, 130)])
+def test_ragged_sizes_against_oracle(eng, D, B):
+    import gsmvi_amd
+    orc = _oracle()
+    st = orc.make_update_state(D, B, seed=D + B)
+    mu_o, S_o = orc.gsm_update_batched(st["samples"], st["vs"], st["mu0"], st["S0"])
+    mu, S = gsmvi_amd.gsm_update(st["samples"], st["vs"], st["mu0"], st["S0"])
+    assert rel_err(mu, mu_o) < TOL and rel_err(S, S_o) < TOL
+    if D <= 64:
+        mu_f, S_f = orc.gsm_update_faithful(st["samples"], st["vs"], st["mu0"], st["S0"])
+        assert rel_err(mu, mu_f) < TOL and rel_err(S, S_f) < TOL
+
+
+def test_headline_config_c3(eng):
+    """D=1024, B=32 (BASELINE configs[2]) against the batched oracle, within the north-star tolerance
+    and the tight fp64 tolerance."""
+    import gsmvi_amd
+    orc = _oracle()
+    for seed in (0, 1):
+        st = orc.make_update_state(1024, 32, seed)
+        mu_o, S_o = orc.gsm_update_batched(st["samples"], st["vs"], st["mu0"], st["S0"])
+        mu, S = gsmvi_amd.gsm_update(st["samples"], st["vs"], st["mu0"], st["S0"])
+        assert rel_err(mu, mu_o) < NORTH_STAR_TOL and rel_err(S, S_o) < NORTH_STAR_TOL
+        assert rel_err(mu, mu_o) < TOL and rel_err(S, S_o) < TOL
+
+
+def test_torch_in_torch_out_strided_and_pure(eng):
+    import torch
+    import gsmvi_amd
+    orc = _oracle()
+    st = orc.make_update_state(96, 12, 3)
+    big = torch.zeros(12, 200, dtype=torch.float64, device="cuda")
+    X = big[:, 7:103]                       # ldx = 200, unaligned start
+    X.copy_(torch.as_tensor(st["samples"]))
+    G = eng.asarray(st["vs"])
+    mu0 = eng.asarray(st["mu0"])
+    S0big = torch.zeros(96, 131, dtype=torch.float64, device="cuda")
+    S0 = S0big[:, :96]
+    S0.copy_(torch.as_tensor(st["S0"]))
+    keep = [t.clone() for t in (X, G, mu0, S0)]
+    mu, S = gsmvi_amd.gsm_update(X, G, mu0, S0)
+    assert isinstance(mu, torch.Tensor) and mu.is_cuda
+    for a, b in zip(keep, (X, G, mu0, S0)):
+        assert torch.equal(a, b)            # inputs untouched (gsm_numpy.py:47-55)
+    mu_o, S_o = orc.gsm_update_batched(st["samples"], st["vs"], st["mu0"], st["S0"])
+    assert rel_err(mu.cpu().numpy(), mu_o) < TOL and rel_err(S.cpu().numpy(), S_o) < TOL
+
+
+def test_k1_score_matching_property_full_size(eng):
+    """Size-independent property at B=1: after the update -S'^-1 (x - mu') = g (K1), D=512."""
+    import gsmvi_amd
+    orc = _oracle()
+    st = orc.make_update_state(512, 1, 9)
+    mu, S = gsmvi_amd.gsm_update(st["samples"], st["vs"], st["mu0"], st["S0"])
+    g = -np.linalg.solve(S, st["samples"][0] - mu)
+    assert rel_err(g, st["vs"][0]) < 1e-7
+
+
+def test_k2_fixed_point_full_size(eng):
+    """At the Gaussian target the update is zero (K2), D=1024, B=32."""
+    import gsmvi_amd
+    orc = _oracle()
+    m, cov_t, P = orc.make_gaussian_target(1024, 5)
+    rs = np.random.RandomState(0)
+    X = m + rs.standard_normal((32, 1024)) @ np.linalg.cholesky(cov_t).T
+    mu, S = gsmvi_amd.gsm_update(X, orc.gaussian_score(X, m, P), m, cov_t)
+    assert rel_err(mu, m) < 1e-8 and rel_err(S, cov_t) < 1e-8
+
+
+def test_run_to_run_determinism(eng):
+    import gsmvi_amd
+    orc = _oracle()
+    st = orc.make_update_state(384, 24, 1)
+    a = gsmvi_amd.gsm_update(st["samples"], st["vs"], st["mu0"], st["S0"])
+    b = gsmvi_amd.gsm_update(st["samples"], st["vs"], st["mu0"], st["S0"])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_gaussian_score_and_sampler(eng):
+    orc = _oracle()
+    for D, B in [(5, 2), (64, 8), (257, 33), (1024, 32)]:
+        st = orc.make_update_state(D, B, 2)
+        G = eng.gaussian_score(eng.asarray(st["samples"]), eng.asarray(st["m"]), eng.asarray(st["P"]))
+        assert rel_err(G.cpu().numpy(), orc.gaussian_score(st["samples"], st["m"], st["P"])) < TOL
+        R = np.linalg.cholesky(st["S0"]).T
+        X = eng.sample(eng.asarray(st["Z"]), eng.asarray(st["mu0"]), eng.asarray(R))
+        assert rel_err(X.cpu().numpy(), st["mu0"] + st["Z"] @ R) < TOL
+
+
+def test_bad_arguments_raise(eng):
+    import torch
+    import gsmvi_amd
+    x = torch.zeros(2, 4, dtype=torch.float64, device="cuda")
+    with pytest.raises(AssertionError):
+        gsmvi_amd.gsm_update(x[0], x, x[0], torch.eye(4, dtype=torch.float64, device="cuda"))
+    S0 = torch.eye(4, dtype=torch.float64, device="cuda")
+    with pytest.raises(gsmvi_amd.GsmviError):
+        eng.gsm_update(x, x, x[0].clone(), S0, out=(torch.zeros(4, dtype=torch.float64, device="cuda"), S0))
+
+
+def test_two_stage_equals_fused_and_profile(eng):
+    """local stage + apply (the batch-sharded split) == gsm_update, bit for bit; record contents
+    checked against the oracle's per-sample terms; profiling returns positive kernel times."""
+    orc = _oracle()
+    st = orc.make_update_state(320, 12, 4)
+    X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
+    mu_a, S_a = eng.gsm_update(X, G, mu0, S0)
+    # two shards of 8 and 4 samples, concatenated records
+    rec = eng.empty(12, eng.record_len(320))
+    eng.gsm_local_stage(X[:8], G[:8], mu0, S0, out=rec[:8])
+    eng.gsm_local_stage(X[8:], G[8:], mu0, S0, out=rec[8:])
+    mu_b, S_b = eng.gsm_apply(rec, mu0, S0)
+    assert np.array_equal(mu_a.cpu().numpy(), mu_b.cpu().numpy())
+    assert np.array_equal(S_a.cpu().numpy(), S_b.cpu().numpy())
+    t = orc.gsm_per_sample_terms(st["samples"], st["vs"], st["mu0"], st["S0"])
+    r = rec.cpu().numpy()
+    assert np.array_equal(r[:, :320], st["samples"])
+    assert rel_err(r[:, 320:640], t["SG"]) < TOL
+    assert rel_err(r[:, 643], t["rho"]) < TOL
+    assert rel_err(r[:, 641], 1 / (1 + t["rho"])) < TOL
+    eng.set_profiling(True)
+    eng.gsm_update(X, G, mu0, S0)
+    prof = eng.get_profile()
+    eng.set_profiling(False)
+    assert all(0 < v < 50 for v in prof.values()), prof

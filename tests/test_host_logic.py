@@ -1,0 +1,165 @@
+"""Host logic of the fit drivers (gsm-vi_amd/gsm.py, bam.py) exercised on CPU with the test-only
+oracle-backed engine: monitor cadence, nevals, niter+1, revert, RNG stream, retries, schedules."""
+import numpy as np
+import pytest
+
+import gsmvi_amd
+from gsmvi_amd.gsm import GSM, gsm_update
+from gsmvi_amd.bam import BaM, Regularizers, bam_update, bam_lowrank_update
+from oracle import gsm_oracle as orc
+from engines import OracleEngine
+from conftest import rel_err
+
+
+def test_update_functions_assert_on_shapes():
+    eng = OracleEngine()
+    with pytest.raises(AssertionError):
+        gsm_update(np.zeros(4), np.zeros((2, 4)), np.zeros(4), np.eye(4), engine=eng)
+    with pytest.raises(AssertionError):
+        bam_update(np.zeros((2, 4)), np.zeros(4), np.zeros(4), np.eye(4), 1.0, engine=eng)
+    with pytest.raises(AssertionError):
+        bam_lowrank_update(np.zeros(4), np.zeros((2, 4)), np.zeros(4), np.eye(4), 1.0, engine=eng)
+
+
+def test_update_is_pure():
+    eng = OracleEngine()
+    st = orc.make_update_state(6, 3, 0)
+    keep = {k: st[k].copy() for k in ("samples", "vs", "mu0", "S0")}
+    mu, S = gsm_update(st["samples"], st["vs"], st["mu0"], st["S0"], engine=eng)
+    for k in keep:
+        assert np.array_equal(keep[k], st[k])
+    assert mu is not st["mu0"] and S is not st["S0"]
+
+
+@pytest.mark.parametrize("D", [5, 10])
+def test_fit_teacher_forced_matches_reference_trajectory(golden, D):
+    g = golden(f"g2_traj_D{D}.npz")
+    m, P = g["target_m"], g["target_P"]
+    states = []
+
+    class Mon:
+        checkpoint = 1
+
+        def __call__(self, i, mc, lp, key, nevals=0):
+            states.append((i, mc[0].copy(), mc[1].copy(), nevals))
+
+    gsm = GSM(D, None, lambda x: orc.gaussian_score(x, m, P), engine=OracleEngine())
+    mean, cov = gsm.fit(99, niter=500, batch_size=2, verbose=False, monitor=Mon(), forced_samples=g["samples"])
+    assert len(states) == 502                         # 501 checkpoints + final call (G5-like)
+    for k, (i, mu_i, cov_i, _) in enumerate(states):
+        assert rel_err(mu_i, g["means"][k]) < 1e-9 and rel_err(cov_i, g["covs"][k]) < 1e-9, k
+    assert rel_err(mean, g["mean_fit"]) < 1e-9 and rel_err(cov, g["cov_fit"]) < 1e-9
+
+
+def test_fit_svd_sampler_reproduces_reference_samples(golden):
+    """sampler='svd' + rng='numpy' is the reference's sample stream: same samples at iteration 0 and
+    the same converged endpoint (G3)."""
+    g = golden("g2_traj_D5.npz")
+    m, P = g["target_m"], g["target_P"]
+    seen = []
+
+    def lp_g(x):
+        seen.append(x.copy())
+        return orc.gaussian_score(x, m, P)
+
+    mean, cov = GSM(5, None, lp_g, engine=OracleEngine()).fit(99, niter=500, verbose=False, sampler="svd")
+    assert rel_err(seen[0], g["samples"][0]) < 1e-12
+    assert rel_err(seen[7], g["samples"][7]) < 1e-7
+    assert rel_err(mean, m) < 1e-9 and rel_err(cov, g["target_cov"]) < 1e-9
+
+
+def test_fit_cholesky_sampler_converges(golden):
+    g = golden("g2_traj_D10.npz")
+    m, P = g["target_m"], g["target_P"]
+    mean, cov = GSM(10, None, lambda x: orc.gaussian_score(x, m, P), engine=OracleEngine()).fit(
+        99, niter=500, verbose=False)
+    assert rel_err(mean, m) < 1e-9 and rel_err(cov, g["target_cov"]) < 1e-9
+
+
+def test_monitor_cadence_and_nevals(golden):
+    g = golden("g5_monitor.npz")
+    m, P = g["target_m"], g["target_P"]
+    calls, n = [], [0]
+
+    class Mon:
+        checkpoint = 3
+
+        def __call__(self, i, mc, lp, key, nevals=0):
+            assert isinstance(mc, list) and len(mc) == 2 and mc[0].shape == (4,) and mc[1].shape == (4, 4)
+            assert lp == "LP" and key == 5
+            calls.append((i, nevals))
+
+    def lp_g(x):
+        n[0] += 1
+        return orc.gaussian_score(x, m, P)
+
+    GSM(4, "LP", lp_g, engine=OracleEngine()).fit(5, niter=10, batch_size=2, verbose=False, monitor=Mon())
+    assert calls == [tuple(r) for r in g["calls"].tolist()]
+    assert n[0] == 11                                  # niter + 1 updates
+
+
+def test_revert_keeps_mean_and_cov(golden, capsys):
+    g = golden("g4_revert.npz")
+    D = g["mu0"].shape[0]
+    gsm = GSM(D, None, lambda x: g["vs"], engine=OracleEngine())
+    mean, cov = gsm.fit(0, mean=g["mu0"], cov=g["S0"], niter=0, batch_size=2, verbose=True,
+                        forced_samples=g["samples"][None])
+    assert np.array_equal(mean, g["mu0"]) and np.array_equal(cov, g["S0"])
+    assert gsm.n_reverts == 1
+    assert "Bad update for covariance matrix. Revert" in capsys.readouterr().out
+
+
+def test_nprint_guard_and_user_arrays_untouched():
+    m, cov_t, P = orc.make_gaussian_target(3, 1)
+    mean0, cov0 = np.ones(3), 2 * np.eye(3)
+    a, b = mean0.copy(), cov0.copy()
+    GSM(3, None, lambda x: orc.gaussian_score(x, m, P), engine=OracleEngine()).fit(
+        1, mean=mean0, cov=cov0, niter=3, nprint=10, verbose=False)     # reference: ZeroDivisionError
+    assert np.array_equal(a, mean0) and np.array_equal(b, cov0)
+
+
+def test_initial_cov_must_be_pd():
+    with pytest.raises(ValueError):
+        GSM(2, None, lambda x: x, engine=OracleEngine()).fit(0, cov=-np.eye(2), niter=1, verbose=False)
+
+
+def test_bam_fit_converges_and_schedule_counts_calls():
+    D = 5
+    m, cov_t, P = orc.make_gaussian_target(D, 17)
+    reg = Regularizers()
+    bam = BaM(D, None, lambda x: orc.gaussian_score(x, m, P), use_lowrank=True, engine=OracleEngine())
+    mean, cov = bam.fit(99, regf=reg.custom(lambda i: 100 / (1 + i)), niter=100, batch_size=2, verbose=False)
+    assert reg.counter == 101
+    assert np.allclose(mean, m, atol=1e-3) and np.allclose(cov, cov_t, atol=1e-3, rtol=1e-3)
+
+
+def test_bam_retries_then_reraises(capsys):
+    D = 3
+    calls = [0]
+
+    def flaky(x):
+        calls[0] += 1
+        if calls[0] <= 2:
+            raise FloatingPointError("bad sample")
+        return -x
+
+    reg = Regularizers()
+    BaM(D, None, flaky, engine=OracleEngine()).fit(1, regf=reg.constant(1.0), niter=1, verbose=False, retries=3)
+    out = capsys.readouterr().out
+    assert "Trying again 2 of 3" in out and calls[0] == 4
+    assert reg.counter == 2                           # regf is reached only by successful attempts
+
+    def always(x):
+        raise FloatingPointError("nope")
+
+    with pytest.raises(FloatingPointError):
+        BaM(D, None, always, engine=OracleEngine()).fit(1, regf=reg.constant(1.0), niter=1, verbose=False,
+                                                        retries=2)
+
+
+def test_regularizers_match_reference_semantics():
+    r = Regularizers()
+    lin = r.linear(100.0)
+    assert [lin(0), lin(0), lin(5)] == [100.0, 50.0, 100.0 / 3]
+    r.reset()
+    assert r.custom(lambda i: 100 / (1 + i))(42) == 50.0
