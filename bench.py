@@ -57,13 +57,13 @@ def make_instances(eng, D, B, n_inst, seed0=0):
     L = torch.randn(D, D, dtype=torch.float64, device=dev, generator=g)
     cov_t = L @ L.T + 1e-3 * torch.eye(D, dtype=torch.float64, device=dev)
     P = torch.linalg.inv(cov_t)
-    P = 0.5 * (P + P.T)
+    P = (0.5 * (P + P.T)).contiguous()
     inst = []
     for k in range(n_inst):
         mu0 = torch.randn(D, dtype=torch.float64, device=dev, generator=g)
         A = torch.randn(D, D, dtype=torch.float64, device=dev, generator=g)
         S0 = A @ A.T / D + 0.1 * torch.eye(D, dtype=torch.float64, device=dev)
-        S0 = 0.5 * (S0 + S0.T)
+        S0 = (0.5 * (S0 + S0.T)).contiguous()
         Lc = torch.linalg.cholesky(S0)
         Z = torch.randn(B, D, dtype=torch.float64, device=dev, generator=g)
         X = mu0[None, :] + Z @ Lc.T

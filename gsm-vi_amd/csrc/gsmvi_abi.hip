@@ -27,6 +27,16 @@ void gsmvi_launch_gsm_cov_update(hipStream_t st, hipEvent_t* ev, int D, int B, c
                                  int s_vec_ok);
 void gsmvi_launch_commit(hipStream_t st, int D, const int* info, const double* mu_new, const double* S_new,
                          int lds_new, double* mu, double* S, int lds, int* n_reverts);
+// fast paths (gsmvi_fast.hip)
+void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int nrows, const double* A,
+                             int lda, const double* shift, double alpha, const double* M, int ldm, double* Pp,
+                             int chunks_per_wg);
+bool gsmvi_launch_gsm_scalars_fast(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, const double* X, int ldx,
+                                   const double* G, int ldg, const double* mu0, const double* Pp, double* SG,
+                                   int ldsg, double* coef, int ldc, double* Xout, int ldxo);
+bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, const double* X, int ldx,
+                              const double* SG, int ldsg, const double* mu0, const double* coef, int ldc,
+                              const double* S0, int lds0, double* S, int lds, double* mu_out, int dbg);
 int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                      int* info_dev);
 int gsmvi_bam_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X, int ldx,
@@ -181,6 +191,8 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     BAD_ARG(!ctx || !name, "NULL argument");
     if (!strcmp(name, "panel_kc")) ctx->tune_panel_kc = value;
     else if (!strcmp(name, "update_sb")) ctx->tune_update_sb = value;
+    else if (!strcmp(name, "no_fast")) ctx->tune_no_fast = value;
+    else if (!strcmp(name, "cov_dbg")) ctx->tune_cov_dbg = value;   // ablation bits, timing experiments only
     else {
         gsmvi_set_error("%s: unknown tuning knob %s", __func__, name);
         return GSMVI_ERR_BAD_ARG;
@@ -225,9 +237,14 @@ int gsmvi_panel_product(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D, i
     const int cpw = (nchunks + kc - 1) / kc;
     kc = (nchunks + cpw - 1) / cpw;
     const int a_vec_ok = (lda % 2 == 0) && aligned16(A);
+    *kc_out = kc;
+    if (!ctx->tune_no_fast && D % 64 == 0 && a_vec_ok && (!shift || aligned16(shift))) {
+        gsmvi_launch_panel_fast(st, ev, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm, Pp,
+                                cpw);
+        return check_launch("k_panel_fast");
+    }
     gsmvi_launch_panel_partial(st, ev, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm, Pp,
                                cpw, a_vec_ok);
-    *kc_out = kc;
     return check_launch("k_panel_partial");
 }
 
@@ -255,6 +272,10 @@ static int gsm_local_stage(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, const d
     int kc = 1;
     int st = gsmvi_panel_product(ctx, hs, ctx->stage_events(0), D, B, G, ldg, nullptr, 1.0, S0, lds0, ctx->pp, &kc);
     if (st != GSMVI_OK) return st;
+    if (!ctx->tune_no_fast && D <= 4096 &&
+        gsmvi_launch_gsm_scalars_fast(hs, ctx->stage_events(1), D, B, kc, X, ldx, G, ldg, mu0, ctx->pp, SG, ldsg,
+                                      coef, ldc, Xout, ldxo))
+        return check_launch("k_gsm_scalars_fast");
     gsmvi_launch_gsm_scalars(hs, ctx->stage_events(1), D, B, kc, X, ldx, G, ldg, mu0, ctx->pp, SG, ldsg, coef, ldc,
                              Xout, ldxo);
     return check_launch("k_gsm_scalars");
@@ -263,6 +284,10 @@ static int gsm_local_stage(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, const d
 static int gsm_apply(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, const double* X, int ldx, const double* SG,
                      int ldsg, const double* coef, int ldc, const double* mu0, const double* S0, int lds0,
                      double* mu, double* S, int lds) {
+    if (!ctx->tune_no_fast && D % 32 == 0 && (ldc % 2 == 0) && aligned16(coef) &&
+        gsmvi_launch_gsm_cov_sym(hs, ctx->stage_events(2), D, B, X, ldx, SG, ldsg, mu0, coef, ldc, S0, lds0, S, lds,
+                                 mu, ctx->tune_cov_dbg))
+        return check_launch("k_gsm_cov_sym");
     int SB = ctx->tune_update_sb > 0 ? ctx->tune_update_sb : ((B + 1) & ~1);
     if (SB > 64) SB = 64;
     SB = (SB + 1) & ~1;

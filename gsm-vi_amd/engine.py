@@ -32,6 +32,7 @@ class HipEngine:
         self._ctx = C.c_void_p()
         self._max_D = 0
         self._max_B = 0
+        self._tuning = {}
         if max_D and max_B:
             self._ensure(max_D, max_B)
 
@@ -47,6 +48,8 @@ class HipEngine:
         ctx = C.c_void_p()
         _lib.check("gsmvi_create", self.lib.gsmvi_create(C.byref(ctx), self.device.index, newD, newB))
         self._ctx, self._max_D, self._max_B = ctx, newD, newB
+        for k, v in self._tuning.items():          # knobs survive a context regrow
+            _lib.check("gsmvi_set_tuning", self.lib.gsmvi_set_tuning(self._ctx, k.encode(), int(v)))
 
     def close(self):
         if self._ctx:
@@ -62,6 +65,7 @@ class HipEngine:
             pass
 
     def set_tuning(self, name, value):
+        self._tuning[name] = int(value)
         self._ensure(max(self._max_D, 1), max(self._max_B, 1))
         _lib.check("gsmvi_set_tuning", self.lib.gsmvi_set_tuning(self._ctx, name.encode(), int(value)))
 

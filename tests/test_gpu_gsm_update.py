@@ -165,3 +165,25 @@ def test_two_stage_equals_fused_and_profile(eng):
     prof = eng.get_profile()
     eng.set_profiling(False)
     assert all(0 < v < 50 for v in prof.values()), prof
+
+
+@pytest.mark.parametrize("D,B", [(64, 8), (128, 16), (256, 8), (512, 64), (1024, 32), (96, 32), (2048, 16)])
+def test_fast_and_generic_kernel_families_agree_with_oracle(eng, D, B):
+    """The guard-free fast path (aligned, D%64==0, B in {8,16,32,64}) and the guarded generic path
+    (forced with the no_fast knob) are both checked against the oracle on the same inputs."""
+    orc = _oracle()
+    st = orc.make_update_state(D, B, seed=7)
+    mu_o, S_o = orc.gsm_update_batched(st["samples"], st["vs"], st["mu0"], st["S0"])
+    X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
+    try:
+        outs = []
+        for no_fast in (0, 1):
+            eng.set_tuning("no_fast", no_fast)
+            mu, S = eng.gsm_update(X, G, mu0, S0)
+            outs.append((mu.cpu().numpy(), S.cpu().numpy()))
+    finally:
+        eng.set_tuning("no_fast", 0)
+    for mu, S in outs:
+        assert rel_err(mu, mu_o) < TOL and rel_err(S, S_o) < TOL
+    assert np.array_equal(outs[0][1], outs[0][1].T)          # fast path: exactly symmetric
+    assert rel_err(outs[0][1], outs[1][1]) < 1e-13
