@@ -1,0 +1,213 @@
+// Device Cholesky factorisation S = R^T R (R upper triangular) for gfx950, fp64.
+//
+// Replaces np.linalg.cholesky inside _check_goodness (gsmvi/gsm_numpy.py:132-146, gsmvi/gsm.py:136-150,
+// gsmvi/bam.py:219-233) and provides the sampling factor for x = mu + z R (replacing the SVD inside
+// np.random.multivariate_normal, gsm_numpy.py:116).  A failed pivot (<= 0 or NaN) sets *info to
+// 1 + pivot index, mirroring "LinAlgError or NaN => not good".
+//
+// Blocked right-looking algorithm, block size 64, in place on R (initialised to triu(S)):
+//   for k = 0 .. D/64-1:
+//     k_potrf_panel    : every workgroup factors the 64x64 diagonal block in LDS (redundantly,
+//                        it is 32 KB), workgroup 0 stores it; each workgroup then solves
+//                        R_kk^T X = S_k,cols for its 256 columns of the block row (one column per
+//                        thread, forward substitution in registers).
+//     k_potrf_trailing : S_ij -= R_ki^T R_kj for the upper-triangle 64x64 tiles of the trailing
+//                        matrix, fp64 MFMA, K = 64.
+// The strictly lower triangle of R is zero on exit (the sampler's panel product reads all of R).
+#include "gsmvi_common.h"
+#include "gsmvi_ctx.h"
+#include "../../include/gsmvi_hip.h"
+
+#define NB 64
+
+// R = triu(S), lower part zero, *info = 0
+__global__ __launch_bounds__(256) void k_potrf_init(int D, const double* __restrict__ S, int lds,
+                                                    double* __restrict__ R, int ldr, int* __restrict__ info) {
+    const size_t n = (size_t)D * D;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
+        const int r = (int)(idx / D), c = (int)(idx % D);
+        R[(size_t)r * ldr + c] = (c >= r) ? S[(size_t)r * lds + c] : 0.0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *info = 0;
+}
+
+// Factor the nb x nb (nb <= 64) upper block held in T[64][66] (LDS); rinv[p] = 1/R[p][p].  Returns
+// through sh_fail the 1-based local index of the first bad pivot (0 = ok).  256 threads = 16 x 16.
+#define TS 66
+__device__ __forceinline__ void chol64_lds(double* T, double* rinv, int nb, int* sh_fail) {
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    if (tid == 0) *sh_fail = 0;
+    __syncthreads();
+    for (int p = 0; p < nb; ++p) {
+        if (tid == 0) {
+            const double piv = T[p * TS + p];
+            const bool ok = piv > 0.0 && piv < 1.7976931348623157e308;     // false for NaN, <= 0, inf
+            if (!ok && *sh_fail == 0) *sh_fail = p + 1;
+            const double r = ok ? sqrt(piv) : 1.0;
+            T[p * TS + p] = r;
+            rinv[p] = ok ? 1.0 / r : 0.0;
+        }
+        __syncthreads();
+        const double ri = rinv[p];
+        if (tid > p && tid < nb) T[p * TS + tid] *= ri;
+        __syncthreads();
+        for (int i = p + 1 + ty; i < nb; i += 16) {
+            const double tpi = T[p * TS + i];
+            for (int q = p + 1 + tx; q < nb; q += 16)
+                if (q >= i) T[i * TS + q] -= tpi * T[p * TS + q];
+        }
+        __syncthreads();
+    }
+}
+
+// Block step k: diagonal factor + block-row solve.  grid.x = 1 + ceil(cols_right / 256).
+// The factored diagonal block goes to diag_out (workspace), NOT into R: sibling workgroups of this
+// launch read the un-factored block from R with no ordering against workgroup 0.
+__global__ __launch_bounds__(256) void k_potrf_panel(int D, int k, double* __restrict__ R, int ldr,
+                                                     double* __restrict__ diag_out, int* __restrict__ info) {
+    __shared__ __attribute__((aligned(16))) double T[64 * TS];
+    __shared__ double rinv[64];
+    __shared__ int sh_fail;
+    const int tid = threadIdx.x;
+    const int k0 = k * NB;
+    const int nb = (D - k0) < NB ? (D - k0) : NB;
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int i = e >> 6, q = e & 63;
+        T[i * TS + q] = (i < nb && q < nb && q >= i) ? R[(size_t)(k0 + i) * ldr + k0 + q] : (i == q ? 1.0 : 0.0);
+    }
+    if (tid < 64) rinv[tid] = 1.0;
+    __syncthreads();
+    chol64_lds(T, rinv, nb, &sh_fail);
+    if (blockIdx.x == 0) {
+        for (int e = tid; e < 64 * 64; e += 256) diag_out[e] = T[(e >> 6) * TS + (e & 63)];
+        if (tid == 0 && sh_fail != 0 && *info == 0) *info = k0 + sh_fail;
+        return;
+    }
+    // Solve R_kk^T X = S_k,col, one column per thread, right-looking so that at pivot p only
+    // x[p..63] are live:  x[p] *= rinv[p];  x[t] -= R_kk[p][t] x[p]  (t > p).  Row p of the factor
+    // is the same LDS address for every lane (broadcast reads).  The scheduling fence per pivot
+    // stops the compiler from hoisting hundreds of LDS reads (which spilled to scratch).
+    const int col = k0 + NB + (blockIdx.x - 1) * 256 + tid;
+    const int colc = col < D ? col : D - 1;
+    // (a workgroup with blockIdx.x > 0 exists only when columns remain to the right, i.e. nb == 64)
+    double x[NB];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) x[p] = R[(size_t)(k0 + p) * ldr + colc];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+        x[p] *= rinv[p];
+        const double xp = x[p];
+#pragma unroll
+        for (int t = p + 1; t < NB; ++t) x[t] -= T[p * TS + t] * xp;
+    }
+    if (col < D) {
+#pragma unroll
+        for (int p = 0; p < NB; ++p) R[(size_t)(k0 + p) * ldr + col] = x[p];
+    }
+}
+
+// Trailing update with block row k: for 64x64 tiles (ti <= tj) of the trailing matrix,
+//   S[I][J] -= sum_p R[k0+p][I]^T R[k0+p][J],  MFMA K = 64.
+__global__ __launch_bounds__(256) void k_potrf_trailing(int D, int k, double* __restrict__ R, int ldr) {
+    constexpr int RS = 66;
+    __shared__ double FA[64 * RS];
+    __shared__ double FB[64 * RS];
+    const int k0 = k * NB, t0 = k0 + NB;
+    const int ntr = (D - t0 + 63) >> 6;
+    int ti, tj;
+    {
+        const int idx = blockIdx.x;
+        const double q = 2.0 * ntr + 1.0;
+        int t = (int)((q - sqrt(q * q - 8.0 * (double)idx)) * 0.5);
+        if (t < 0) t = 0;
+        while (t > 0 && t * ntr - (t * (t - 1)) / 2 > idx) --t;
+        while ((t + 1) * ntr - ((t + 1) * t) / 2 <= idx) ++t;
+        ti = t;
+        tj = t + (idx - (t * ntr - (t * (t - 1)) / 2));
+    }
+    const int I0 = t0 + ti * 64, J0 = t0 + tj * 64;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+    const int wr = w >> 1, wc = w & 1;
+
+    // stage R[k0 + p][I0 + i] -> FA[i][p], R[k0 + p][J0 + j] -> FB[j][p]
+    double va[16], vb[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int p = (tid >> 6) + 4 * q, i = tid & 63;
+        const int gi = I0 + i, gj = J0 + i;
+        va[q] = (gi < D) ? R[(size_t)(k0 + p) * ldr + gi] : 0.0;
+        vb[q] = (gj < D) ? R[(size_t)(k0 + p) * ldr + gj] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int p = (tid >> 6) + 4 * q, i = tid & 63;
+        FA[i * RS + p] = va[q];
+        FB[i * RS + p] = vb[q];
+    }
+    __syncthreads();
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const double* a0p = FA + (32 * wr + c) * RS + ks;
+    const double* a1p = a0p + 16 * RS;
+    const double* b0p = FB + (32 * wc + c) * RS + ks;
+    const double* b1p = b0p + 16 * RS;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const double a0 = a0p[4 * s], a1 = a1p[4 * s], b0 = b0p[4 * s], b1 = b1p[4 * s];
+        acc[0][0] = GSMVI_MFMA_F64(a0, b0, acc[0][0]);
+        acc[0][1] = GSMVI_MFMA_F64(a0, b1, acc[0][1]);
+        acc[1][0] = GSMVI_MFMA_F64(a1, b0, acc[1][0]);
+        acc[1][1] = GSMVI_MFMA_F64(a1, b1, acc[1][1]);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = I0 + 32 * wr + 16 * rt + ks + 4 * r;
+                const int col = J0 + 32 * wc + 16 * ct + c;
+                if (row < D && col < D && col >= row) R[(size_t)row * ldr + col] -= acc[rt][ct][r];
+            }
+}
+
+// copy the factored diagonal blocks from the workspace into R
+__global__ __launch_bounds__(256) void k_potrf_finish(int D, const double* __restrict__ diag, double* __restrict__ R,
+                                                      int ldr) {
+    const int k = blockIdx.x, k0 = k * NB;
+    const int nb = (D - k0) < NB ? (D - k0) : NB;
+    const double* T = diag + (size_t)k * NB * NB;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int i = e >> 6, q = e & 63;
+        if (i < nb && q < nb && q >= i) R[(size_t)(k0 + i) * ldr + k0 + q] = T[e];
+    }
+}
+
+int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
+                     int* info_dev) {
+    double* diag = ctx->pp;                       // nblk x 64 x 64 doubles; the panel-partial slab is idle here
+    int blocks = (int)(((size_t)D * D + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_potrf_init, dim3(blocks), dim3(256), 0, st, D, S, lds, R, ldr, info_dev);
+    const int nblk = (D + NB - 1) / NB;
+    for (int k = 0; k < nblk; ++k) {
+        const int right = D - (k + 1) * NB;
+        const int pg = 1 + (right > 0 ? (right + 255) / 256 : 0);
+        hipLaunchKernelGGL(k_potrf_panel, dim3(pg), dim3(256), 0, st, D, k, R, ldr,
+                           diag + (size_t)k * NB * NB, info_dev);
+        if (right > 0) {
+            const int ntr = (right + 63) / 64;
+            hipLaunchKernelGGL(k_potrf_trailing, dim3(ntr * (ntr + 1) / 2), dim3(256), 0, st, D, k, R, ldr);
+        }
+    }
+    hipLaunchKernelGGL(k_potrf_finish, dim3(nblk), dim3(256), 0, st, D, diag, R, ldr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        gsmvi_set_error("potrf launch failed: %s%s", hipGetErrorString(e), "");
+        return GSMVI_ERR_HIP;
+    }
+    return GSMVI_OK;
+}

@@ -187,3 +187,46 @@ def test_fast_and_generic_kernel_families_agree_with_oracle(eng, D, B):
         assert rel_err(mu, mu_o) < TOL and rel_err(S, S_o) < TOL
     assert np.array_equal(outs[0][1], outs[0][1].T)          # fast path: exactly symmetric
     assert rel_err(outs[0][1], outs[1][1]) < 1e-13
+
+
+@pytest.mark.parametrize("D", [1, 3, 17, 64, 65, 100, 128, 200, 256, 1024])
+def test_potrf_matches_numpy(eng, D):
+    """Device Cholesky (replaces np.linalg.cholesky in _check_goodness, gsm_numpy.py:132-146)."""
+    orc = _oracle()
+    st = orc.make_update_state(D, 2, D)
+    R, flag = eng.potrf(eng.asarray(st["S0"]))
+    assert eng.read_flag(flag) == 0
+    Rn = R.cpu().numpy()
+    assert rel_err(Rn, np.linalg.cholesky(st["S0"]).T) < 1e-10
+    assert np.array_equal(np.tril(Rn, -1), np.zeros_like(Rn))
+    assert rel_err(Rn.T @ Rn, st["S0"]) < 1e-12
+
+
+def test_potrf_flags_non_pd_and_nan(eng, golden):
+    g = golden("g4_revert.npz")
+    _, flag = eng.potrf(eng.asarray(g["S"]))            # the reference's failing covariance
+    assert eng.read_flag(flag) != 0
+    bad = np.eye(70)
+    bad[66, 66] = -1.0
+    _, flag = eng.potrf(eng.asarray(bad))
+    assert eng.read_flag(flag) == 67                    # 1 + index of the first bad pivot
+    nan = np.eye(40)
+    nan[5, 9] = nan[9, 5] = np.nan
+    _, flag = eng.potrf(eng.asarray(nan))
+    assert eng.read_flag(flag) != 0
+    ok = np.eye(130) * 2.0
+    _, flag = eng.potrf(eng.asarray(ok), flag=flag)     # flag is reset by every call
+    assert eng.read_flag(flag) == 0
+
+
+def test_commit_and_revert(eng):
+    import torch
+    mu, S = eng.zeros(5), eng.eye(5)
+    mu_new, S_new = eng.asarray(np.arange(5.0)), eng.asarray(np.full((5, 5), 3.0))
+    flag, nrev = eng.new_flag(), eng.new_flag()
+    flag.fill_(3)
+    eng.commit(flag, mu_new, S_new, mu, S, nrev)
+    assert torch.equal(mu, eng.zeros(5)) and torch.equal(S, eng.eye(5)) and eng.read_flag(nrev) == 1
+    flag.fill_(0)
+    eng.commit(flag, mu_new, S_new, mu, S, nrev)
+    assert torch.equal(mu, mu_new) and torch.equal(S, S_new) and eng.read_flag(nrev) == 1
