@@ -11,7 +11,7 @@
 #include "../../include/gsmvi_hip.h"
 
 // ---- kernels (gsmvi_kernels.hip / gsmvi_potrf.hip / gsmvi_bam.hip) -------------------------
-void gsmvi_launch_panel_partial(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int nrows,
+void gsmvi_launch_panel_partial(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int ncols, int nrows,
                                 const double* A, int lda, const double* shift, double alpha, const double* M,
                                 int ldm, double* Pp, int chunks_per_wg, int a_vec_ok);
 void gsmvi_launch_panel_finish(hipStream_t st, hipEvent_t* ev, int D, int nrows, int KC, const double* Pp,
@@ -21,6 +21,7 @@ void gsmvi_launch_gsm_scalars(hipStream_t st, hipEvent_t* ev, int D, int B, int 
                               double* coef, int ldc, double* Xout, int ldxo);
 size_t gsmvi_cov_update_lds_bytes(int SB);
 hipError_t gsmvi_cov_update_prepare();
+hipError_t gsmvi_bam_prepare();
 void gsmvi_launch_gsm_cov_update(hipStream_t st, hipEvent_t* ev, int D, int B, const double* X, int ldx,
                                  const double* SG, int ldsg, const double* mu0, const double* coef, int ldc,
                                  const double* S0, int lds0, double* S, int lds, double* mu_out, int SB,
@@ -162,6 +163,7 @@ int gsmvi_create(gsmvi_ctx** out, int device, int max_D, int max_B) {
     c->ints = reinterpret_cast<int*>(c->small + n_small);
     e = hipMemset(c->ws, 0, c->ws_bytes);
     if (e == hipSuccess) e = gsmvi_cov_update_prepare();
+    if (e == hipSuccess) e = gsmvi_bam_prepare();
     for (int k = 0; k < 8 && e == hipSuccess; ++k) e = hipEventCreate(&c->ev[k]);
     if (e != hipSuccess) {
         gsmvi_set_error("context initialisation failed: %s%s", hipGetErrorString(e), "");
@@ -221,11 +223,12 @@ int gsmvi_get_profile(gsmvi_ctx* ctx, float* ms, int n) {
 
 }  // extern "C"
 
-// ---- panel product driver: Pp partials for Out = alpha (A - shift) M ----------------------
-// Returns KC (number of partial slabs written) through *kc_out.
-int gsmvi_panel_product(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D, int nrows, const double* A, int lda,
-                        const double* shift, double alpha, const double* M, int ldm, double* Pp, int* kc_out) {
-    const int strips = (D + 15) / 16;
+// ---- panel product driver: partial slabs Pp[kc][nrows][ncols] of alpha (A - shift) M ------------
+// A: nrows x D, M: D x ncols (row-major, ldm).  Returns the number of slabs through *kc_out.
+int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D, int ncols, int nrows,
+                           const double* A, int lda, const double* shift, double alpha, const double* M, int ldm,
+                           double* Pp, int* kc_out) {
+    const int strips = (ncols + 15) / 16;
     const int nchunks = (D + 255) / 256;
     const int MT = nrows <= 16 ? 1 : (nrows <= 32 ? 2 : 4);
     const int zblocks = (nrows + 16 * MT - 1) / (16 * MT);
@@ -238,14 +241,26 @@ int gsmvi_panel_product(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D, i
     kc = (nchunks + cpw - 1) / cpw;
     const int a_vec_ok = (lda % 2 == 0) && aligned16(A);
     *kc_out = kc;
-    if (!ctx->tune_no_fast && D % 64 == 0 && a_vec_ok && (!shift || aligned16(shift))) {
+    if (!ctx->tune_no_fast && ncols == D && D % 64 == 0 && a_vec_ok && (!shift || aligned16(shift))) {
         gsmvi_launch_panel_fast(st, ev, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm, Pp,
                                 cpw);
         return check_launch("k_panel_fast");
     }
-    gsmvi_launch_panel_partial(st, ev, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm, Pp,
-                               cpw, a_vec_ok);
+    gsmvi_launch_panel_partial(st, ev, MT, dim3(strips, kc, zblocks), D, ncols, nrows, A, lda, shift, alpha, M,
+                               ldm, Pp, cpw, a_vec_ok);
     return check_launch("k_panel_partial");
+}
+
+int gsmvi_panel_product(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D, int nrows, const double* A, int lda,
+                        const double* shift, double alpha, const double* M, int ldm, double* Pp, int* kc_out) {
+    return gsmvi_panel_product_nc(ctx, st, ev, D, D, nrows, A, lda, shift, alpha, M, ldm, Pp, kc_out);
+}
+
+// Out (nrows x ncols, ldo) = addvec + sum of the kc slabs
+int gsmvi_panel_finish(hipStream_t st, int ncols, int nrows, int kc, const double* Pp, const double* addvec,
+                       double* Out, int ldo) {
+    gsmvi_launch_panel_finish(st, nullptr, ncols, nrows, kc, Pp, addvec, Out, ldo);
+    return check_launch("k_panel_finish");
 }
 
 static int check_common(gsmvi_ctx* ctx, int D, int B, const char* fn) {

@@ -1,0 +1,370 @@
+// BaM (batch-and-match) update for gfx950, fp64.   Reference: gsmvi/bam.py:72-114 (low-rank form),
+// which equals gsmvi/bam.py:31-69 (full form) to round-off.
+//
+// With n = B+1 and the exact factor U = Q Q^T (replacing ARPACK svds, bam.py:10-13):
+//   Qt (n x D) rows  sqrt(reg/B)(g_b - gbar), sqrt(reg/(1+reg)) gbar                      (bam.py:55-59)
+//   Vf (n x D) rows  sqrt(reg/B)(x_b - xbar), sqrt(reg/(1+reg)) (mu0 - xbar)   V = S0 + Vf^T Vf (bam.py:50-53,60)
+//   P  = Qt S0                      one pass over S0, fp64-MFMA panel product
+//   M1 = Vf Q,  N0 = P Q            (n x n) Gram matrices over D;  A^T = P + M1^T Vf        (bam.py:107)
+//   N  = A^T Q = N0 + M1^T M1;  BB = ((N + I/4)^(1/2) + I/2)^2 = N + I/2 + (N + I/4)^(1/2)  (bam.py:108-109)
+//   BB = L L^T;  Z = L^-1 A^T (n x D)  =>  A BB^-1 A^T = Z^T Z                              (bam.py:110)
+//   S  = V - Z^T Z = S0 + Vf^T Vf - Z^T Z     rank-2n symmetric update, fp64 MFMA           (bam.py:111)
+//   mu = mu0/(1+reg) + reg/(1+reg) (S gbar + xbar)                                         (bam.py:112)
+// The n x n symmetric eigen-problem behind the matrix square root and the n x n Cholesky are done
+// on the HOST inside this call (one stream synchronisation) -- the reference does the same step as
+// a host callback (jax.pure_callback, bam.py:15-22).  Only the square-root term goes through the
+// eigen-solve (N itself enters BB exactly) and BB^-1 is applied by triangular substitution, never
+// as an explicit inverse: with cond(N) ~ 1e7 the explicit-inverse form loses 3 digits.
+// Everything of size D runs in HIP kernels; S0 is read twice and S written once.
+#include <cmath>
+#include <vector>
+
+#include "gsmvi_common.h"
+#include "gsmvi_ctx.h"
+#include "../../include/gsmvi_hip.h"
+
+// ---- column means and the factor panels -----------------------------------------------------
+// thread i = column; Qt, Vf row-major n x D (ld D); Qm = Qt^T as D x n (ld nq).
+__global__ __launch_bounds__(256) void k_bam_stats(int D, int B, const double* __restrict__ X, int ldx,
+                                                   const double* __restrict__ G, int ldg,
+                                                   const double* __restrict__ mu0, double reg,
+                                                   double* __restrict__ xbar, double* __restrict__ gbar,
+                                                   double* __restrict__ Qt, double* __restrict__ Vf,
+                                                   double* __restrict__ Vf2, double* __restrict__ Qm, int nq) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= D) return;
+    double sx = 0.0, sg = 0.0;
+    for (int b = 0; b < B; ++b) {
+        sx += X[(size_t)b * ldx + i];
+        sg += G[(size_t)b * ldg + i];
+    }
+    const double xb = sx / B, gb = sg / B;
+    xbar[i] = xb;
+    gbar[i] = gb;
+    const double a = sqrt(reg / B), r1s = sqrt(reg / (1.0 + reg));
+    for (int b = 0; b < B; ++b) {
+        const double q = a * (G[(size_t)b * ldg + i] - gb);
+        Qt[(size_t)b * D + i] = q;
+        Qm[(size_t)i * nq + b] = q;
+        const double v = a * (X[(size_t)b * ldx + i] - xb);
+        Vf[(size_t)b * D + i] = v;
+        Vf2[(size_t)b * D + i] = v;
+    }
+    Qt[(size_t)B * D + i] = r1s * gb;
+    Qm[(size_t)i * nq + B] = r1s * gb;
+    Vf[(size_t)B * D + i] = r1s * (mu0[i] - xb);
+    Vf2[(size_t)B * D + i] = r1s * (mu0[i] - xb);
+}
+
+// ---- Z = L^-1 (P + M1^T Vf), the new mean, and the signed factor panel -------------------------
+// One column of D per thread, 64 threads per block; the thread's Vf column and running Z column live
+// in LDS ([k][64], conflict-free).  M1, L are read with wave-uniform indices (scalar loads, L2 hits).
+// Ft = [Vf; Z], Fs = [Vf; -Z]  (rows n..2n-1 written here; rows 0..n-1 by k_bam_stats).
+__global__ __launch_bounds__(64) void k_bam_forward(int D, int n, const double* __restrict__ P,
+                                                    const double* __restrict__ M1, const double* __restrict__ L,
+                                                    const double* __restrict__ Ldinv,
+                                                    const double* __restrict__ zg, const double* __restrict__ vg,
+                                                    const double* __restrict__ mu0,
+                                                    const double* __restrict__ xbar, double reg,
+                                                    double* __restrict__ Ft, double* __restrict__ Fs,
+                                                    double* __restrict__ mu) {
+    extern __shared__ double sm[];                 // vf[n][64], z[n][64]
+    double* vf = sm;
+    double* z = sm + (size_t)n * 64;
+    const int t = threadIdx.x;
+    const int i = blockIdx.x * 64 + t;
+    const int ic = i < D ? i : D - 1;
+    for (int k = 0; k < n; ++k) vf[k * 64 + t] = Ft[(size_t)k * D + ic];
+    double dot_v = 0.0, dot_z = 0.0;
+    for (int r = 0; r < n; ++r) {
+        double a = P[(size_t)r * D + ic];
+        for (int k = 0; k < n; ++k) a += M1[(size_t)k * n + r] * vf[k * 64 + t];       // (M1^T vf)_r
+        for (int k = 0; k < r; ++k) a -= L[(size_t)r * n + k] * z[k * 64 + t];
+        const double zr = a * Ldinv[r];
+        z[r * 64 + t] = zr;
+        dot_z += zr * zg[r];
+        dot_v += vf[r * 64 + t] * vg[r];
+        if (i < D) {
+            Ft[(size_t)(n + r) * D + i] = zr;
+            Fs[(size_t)(n + r) * D + i] = -zr;
+        }
+    }
+    if (i < D) {
+        const double r1 = reg / (1.0 + reg);
+        const double s0g = P[(size_t)(n - 1) * D + i] / sqrt(r1);        // (S0 gbar)_i = P[n-1][i]/sqrt(r1)
+        mu[i] = mu0[i] / (1.0 + reg) + r1 * (s0g + dot_v - dot_z + xbar[i]);
+    }
+}
+
+// ---- symmetric low-rank update  S = S0 + Ft^T Fs + jitter I   (Ft, Fs: KF x D row-major) --------
+// Ft^T Fs must be symmetric (Fs = K Ft with K symmetric).  One workgroup per 64x64 tile PAIR (I <= J)
+// of the upper triangle: W = S0[I,J] + Ft[:,I]^T Fs[:,J] (4 waves of 32x32, fp64 MFMA, factor rows
+// staged through LDS in chunks of 64), stores S[I,J] = W and the mirror S[J,I] = W^T through an
+// LDS transpose, so S is exactly symmetric (bam.py:199 symmetrises in fit) and S0 is read once.
+__global__ __launch_bounds__(256) void k_lowrank_update(int D, int KF, const double* __restrict__ Ft,
+                                                        const double* __restrict__ Fs,
+                                                        const double* __restrict__ S0, int lds0,
+                                                        double* __restrict__ S, int lds, double jitter) {
+    constexpr int RS = 66;
+    __shared__ double smem[2 * 64 * RS];
+    double* FA = smem;
+    double* FB = smem + 64 * RS;
+    const int nt = (D + 63) >> 6;
+    int ti, tj;
+    {
+        const int idx = blockIdx.x;
+        const double q = 2.0 * nt + 1.0;
+        int t = (int)((q - sqrt(q * q - 8.0 * (double)idx)) * 0.5);
+        if (t < 0) t = 0;
+        while (t > 0 && t * nt - (t * (t - 1)) / 2 > idx) --t;
+        while ((t + 1) * nt - ((t + 1) * t) / 2 <= idx) ++t;
+        ti = t;
+        tj = t + (idx - (t * nt - (t * (t - 1)) / 2));
+    }
+    const int I0 = ti * 64, J0 = tj * 64;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+    const int wr = w >> 1, wc = w & 1;
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int kb = 0; kb < KF; kb += 64) {
+        double va[16], vb[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int p = kb + (tid >> 6) + 4 * q, i = tid & 63;
+            const int pc = p < KF ? p : KF - 1;
+            const int gi = I0 + i, gj = J0 + i;
+            const double a = Ft[(size_t)pc * D + (gi < D ? gi : D - 1)];
+            const double b = Fs[(size_t)pc * D + (gj < D ? gj : D - 1)];
+            va[q] = (p < KF && gi < D) ? a : 0.0;
+            vb[q] = (p < KF && gj < D) ? b : 0.0;
+        }
+        if (kb > 0) __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int p = (tid >> 6) + 4 * q, i = tid & 63;
+            FA[i * RS + p] = va[q];
+            FB[i * RS + p] = vb[q];
+        }
+        __syncthreads();
+        const double* a0p = FA + (32 * wr + c) * RS + ks;
+        const double* a1p = a0p + 16 * RS;
+        const double* b0p = FB + (32 * wc + c) * RS + ks;
+        const double* b1p = b0p + 16 * RS;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const double a0 = a0p[4 * s], a1 = a1p[4 * s], b0 = b0p[4 * s], b1 = b1p[4 * s];
+            acc[0][0] = GSMVI_MFMA_F64(a0, b0, acc[0][0]);
+            acc[0][1] = GSMVI_MFMA_F64(a0, b1, acc[0][1]);
+            acc[1][0] = GSMVI_MFMA_F64(a1, b0, acc[1][0]);
+            acc[1][1] = GSMVI_MFMA_F64(a1, b1, acc[1][1]);
+        }
+    }
+    __syncthreads();                              // factor tiles are dead; smem becomes the 64x65 transpose buffer
+    double* LW = smem;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lr = 32 * wr + 16 * rt + ks + 4 * r, lc = 32 * wc + 16 * ct + c;
+                const int row = I0 + lr, col = J0 + lc;
+                double v = 0.0;
+                if (row < D && col < D) {
+                    v = S0[(size_t)row * lds0 + col] + acc[rt][ct][r] + (row == col ? jitter : 0.0);
+                    if (ti != tj || col >= row) S[(size_t)row * lds + col] = v;
+                }
+                LW[lr * 65 + lc] = v;
+            }
+    __syncthreads();
+    // mirror: S[J0 + lr][I0 + lc] = W[lc][lr]; on a diagonal tile pair only the strict lower part
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lr = 32 * wr + 16 * rt + ks + 4 * r, lc = 32 * wc + 16 * ct + c;
+                const int row = J0 + lr, col = I0 + lc;
+                if (row < D && col < D && (ti != tj || col < row)) S[(size_t)row * lds + col] = LW[lc * 65 + lr];
+            }
+}
+
+// ---- host: cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (row-major) -------------
+// A is destroyed; on return w = eigenvalues, E = eigenvectors in COLUMNS (row-major n x n).
+static bool jacobi_eigh(int n, std::vector<double>& A, std::vector<double>& w, std::vector<double>& E) {
+    E.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) E[(size_t)i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < n; ++i) {
+            diag += A[(size_t)i * n + i] * A[(size_t)i * n + i];
+            for (int j = i + 1; j < n; ++j) off += A[(size_t)i * n + j] * A[(size_t)i * n + j];
+        }
+        if (!(off == off) || !(diag == diag)) return false;        // NaN
+        if (off <= 1e-30 * (diag + off) || off == 0.0) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[(size_t)p * n + q];
+                if (apq == 0.0) continue;
+                const double app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q];
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; ++k) {                      // columns p, q
+                    const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+                    A[(size_t)k * n + p] = c * akp - s * akq;
+                    A[(size_t)k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {                      // rows p, q
+                    const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+                    A[(size_t)p * n + k] = c * apk - s * aqk;
+                    A[(size_t)q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double ekp = E[(size_t)k * n + p], ekq = E[(size_t)k * n + q];
+                    E[(size_t)k * n + p] = c * ekp - s * ekq;
+                    E[(size_t)k * n + q] = s * ekp + c * ekq;
+                }
+            }
+    }
+    w.resize(n);
+    for (int i = 0; i < n; ++i) w[i] = A[(size_t)i * n + i];
+    return true;
+}
+
+#define HIPCHK(expr)                                                          \
+    do {                                                                      \
+        hipError_t e_ = (expr);                                               \
+        if (e_ != hipSuccess) {                                               \
+            gsmvi_set_error("%s failed: %s", #expr, hipGetErrorString(e_));   \
+            return GSMVI_ERR_HIP;                                             \
+        }                                                                     \
+    } while (0)
+
+// host Cholesky of an SPD n x n matrix (row-major, lower factor written in place); false if not PD
+static bool host_cholesky(int n, std::vector<double>& A) {
+    for (int j = 0; j < n; ++j) {
+        double d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+        if (!(d > 0.0)) return false;
+        d = sqrt(d);
+        A[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double s = A[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+            A[(size_t)i * n + j] = s / d;
+        }
+    }
+    return true;
+}
+
+int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X, int ldx, const double* G,
+                   int ldg, const double* mu0, const double* S0, int lds0, double reg, double jitter, double* mu,
+                   double* S, int lds, int* info_dev) {
+    const int n = B + 1, n2 = 2 * n, nq = (n + 1) & ~1;
+    // workspace carve (ctx->sg holds 4*rmax*max_D doubles, rmax = 2B+8 >= 2n+6)
+    double* Qt = ctx->sg;                          // n x D
+    double* P = Qt + (size_t)n * D;                // n x D
+    double* Ft = P + (size_t)n * D;                // [Vf; Z]   2n x D
+    double* Fs = Ft + (size_t)n2 * D;              // [Vf; -Z]  2n x D
+    double* Qm = Fs + (size_t)n2 * D;              // D x nq
+    double* xbar = Qm + (size_t)D * nq;
+    double* gbar = xbar + D;
+    double* M1 = ctx->small;                       // n x n
+    double* N0 = M1 + (size_t)n * n;               // n x n
+    double* Ld = N0 + (size_t)n * n;               // n x n, then Ldinv (n), zg (n), vg (n)
+
+    hipLaunchKernelGGL(k_bam_stats, dim3((D + 255) / 256), dim3(256), 0, st, D, B, X, ldx, G, ldg, mu0, reg, xbar,
+                       gbar, Qt, Ft, Fs, Qm, nq);
+    int kc = 1, rc;
+    if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, D, n, Qt, D, nullptr, 1.0, S0, lds0, ctx->pp, &kc))) return rc;
+    if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, P, D))) return rc;
+    if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, n, n, Ft, D, nullptr, 1.0, Qm, nq, ctx->pp, &kc))) return rc;
+    if ((rc = gsmvi_panel_finish(st, n, n, kc, ctx->pp, nullptr, M1, n))) return rc;
+    if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, n, n, P, D, nullptr, 1.0, Qm, nq, ctx->pp, &kc))) return rc;
+    if ((rc = gsmvi_panel_finish(st, n, n, kc, ctx->pp, nullptr, N0, n))) return rc;
+
+    // ---- host: the (B+1) x (B+1) matrix function (bam.py:108-110) ----
+    std::vector<double> h((size_t)2 * n * n);
+    HIPCHK(hipMemcpyAsync(h.data(), M1, sizeof(double) * 2 * n * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const double* hM1 = h.data();
+    const double* hN0 = h.data() + (size_t)n * n;
+    std::vector<double> N((size_t)n * n), w, E;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += hM1[(size_t)k * n + i] * hM1[(size_t)k * n + j];
+            N[(size_t)i * n + j] = s + 0.5 * (hN0[(size_t)i * n + j] + hN0[(size_t)j * n + i]);
+        }
+    int bad = 0;
+    std::vector<double> Nc = N;
+    if (!jacobi_eigh(n, Nc, w, E)) bad = 1;
+    // BB = N + I/2 + E sqrt(w + 1/4) E^T
+    std::vector<double> BBm = N;
+    if (!bad) {
+        for (int i = 0; i < n; ++i) BBm[(size_t)i * n + i] += 0.5;
+        for (int k = 0; k < n; ++k) {
+            const double sq = sqrt((w[k] > 0.0 ? w[k] : 0.0) + 0.25);
+            for (int i = 0; i < n; ++i) {
+                const double eik = E[(size_t)i * n + k] * sq;
+                for (int j = 0; j < n; ++j) BBm[(size_t)i * n + j] += eik * E[(size_t)j * n + k];
+            }
+        }
+        for (int i = 0; i < n; ++i)
+            for (int j = i + 1; j < n; ++j) {
+                const double v = 0.5 * (BBm[(size_t)i * n + j] + BBm[(size_t)j * n + i]);
+                BBm[(size_t)i * n + j] = BBm[(size_t)j * n + i] = v;
+            }
+        if (!host_cholesky(n, BBm)) bad = 1;
+    }
+    std::vector<double> up((size_t)n * n + 3 * n, 0.0);      // L, Ldinv, zg, vg
+    if (!bad) {
+        const double r1s = sqrt(reg / (1.0 + reg));
+        double* hL = up.data();
+        double* hDi = hL + (size_t)n * n;
+        double* hzg = hDi + n;
+        double* hvg = hzg + n;
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j <= i; ++j) hL[(size_t)i * n + j] = BBm[(size_t)i * n + j];
+            hDi[i] = 1.0 / BBm[(size_t)i * n + i];
+            hvg[i] = hM1[(size_t)i * n + (n - 1)] / r1s;             // (Vf gbar)_i
+        }
+        // A^T gbar = P gbar + M1^T (Vf gbar);  zg = L^-1 (A^T gbar)
+        for (int r = 0; r < n; ++r) {
+            double a = hN0[(size_t)r * n + (n - 1)] / r1s;
+            for (int k = 0; k < n; ++k) a += hM1[(size_t)k * n + r] * hvg[k];
+            for (int k = 0; k < r; ++k) a -= hL[(size_t)r * n + k] * hzg[k];
+            hzg[r] = a * hDi[r];
+            if (!(hzg[r] == hzg[r])) bad = 1;
+        }
+    }
+    if (bad) {                                       // poison the outputs' inputs so nothing stale is applied
+        for (auto& v : up) v = std::nan("");
+    }
+    HIPCHK(hipMemcpyAsync(Ld, up.data(), sizeof(double) * up.size(), hipMemcpyHostToDevice, st));
+    if (info_dev) HIPCHK(hipMemcpyAsync(info_dev, &bad, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));             // `up` / `bad` live on this stack frame
+
+    const double* Ldinv = Ld + (size_t)n * n;
+    hipLaunchKernelGGL(k_bam_forward, dim3((D + 63) / 64), dim3(64), sizeof(double) * 2 * n * 64, st, D, n, P, M1, Ld,
+                       Ldinv, Ldinv + n, Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu);
+    const int nt = (D + 63) / 64;
+    hipLaunchKernelGGL(k_lowrank_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds,
+                       jitter);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        gsmvi_set_error("BaM launch failed: %s%s", hipGetErrorString(e), "");
+        return GSMVI_ERR_HIP;
+    }
+    return GSMVI_OK;
+}
+
+hipError_t gsmvi_bam_prepare() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_bam_forward),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}

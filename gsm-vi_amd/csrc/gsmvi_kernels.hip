@@ -27,7 +27,7 @@
 // doubles of one row of A (one 128-B line) and M is read as 16 coalesced 128-B row segments.
 // =====================================================================================
 template <int MT>
-__global__ __launch_bounds__(256) void k_panel_partial(int D, int nrows, const double* __restrict__ A,
+__global__ __launch_bounds__(256) void k_panel_partial(int D, int ncols, int nrows, const double* __restrict__ A,
                                                        int lda, const double* __restrict__ shift,
                                                        double alpha, const double* __restrict__ M, int ldm,
                                                        double* __restrict__ Pp, int chunks_per_wg,
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k_panel_partial(int D, int nrows, const d
     __shared__ double red[4][16 * MT][17];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
     const int j = blockIdx.x * 16 + c;
-    const int jc = j < D ? j : D - 1;
+    const int jc = j < ncols ? j : ncols - 1;
     const int r0 = blockIdx.z * (16 * MT);
 
     v4d acc[MT];
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_panel_partial(int D, int nrows, const d
             const int i = base + s;
             const int ic = i < D ? i : D - 1;
             const double v = M[(size_t)ic * ldm + jc];
-            m[s] = (i < D && j < D) ? v : 0.0;
+            m[s] = (i < D && j < ncols) ? v : 0.0;
         }
         double sh[16];
 #pragma unroll
@@ -102,14 +102,14 @@ __global__ __launch_bounds__(256) void k_panel_partial(int D, int nrows, const d
     for (int idx = tid; idx < 16 * MT * 16; idx += 256) {
         const int rr = idx >> 4, cc = idx & 15;
         const int row = r0 + rr, col = blockIdx.x * 16 + cc;
-        if (row < nrows && col < D) {
+        if (row < nrows && col < ncols) {
             const double s = (red[0][rr][cc] + red[1][rr][cc]) + (red[2][rr][cc] + red[3][rr][cc]);
-            Pp[((size_t)blockIdx.y * nrows + row) * D + col] = s;
+            Pp[((size_t)blockIdx.y * nrows + row) * ncols + col] = s;
         }
     }
 }
 
-// Out[r][i] = addvec[i] + sum_kc Pp[kc][r][i]
+// Out[r][i] = addvec[i] + sum_kc Pp[kc][r][i]      (D here = number of columns of the panel)
 __global__ __launch_bounds__(256) void k_panel_finish(int D, int nrows, int KC, const double* __restrict__ Pp,
                                                       const double* __restrict__ addvec,
                                                       double* __restrict__ Out, int ldo) {
@@ -315,20 +315,20 @@ __global__ __launch_bounds__(256) void k_commit(int D, const int* __restrict__ i
 }
 
 // ---- launch helpers used by gsmvi_abi.hip --------------------------------------------------
-void gsmvi_launch_panel_partial(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int nrows,
+void gsmvi_launch_panel_partial(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int ncols, int nrows,
                                 const double* A, int lda, const double* shift, double alpha, const double* M,
                                 int ldm, double* Pp, int chunks_per_wg, int a_vec_ok) {
     switch (MT) {
         case 1:
-            GSMVI_LAUNCH(k_panel_partial<1>, grid, dim3(256), 0, st, ev, D, nrows, A, lda, shift, alpha, M, ldm, Pp,
+            GSMVI_LAUNCH(k_panel_partial<1>, grid, dim3(256), 0, st, ev, D, ncols, nrows, A, lda, shift, alpha, M, ldm, Pp,
                          chunks_per_wg, a_vec_ok);
             break;
         case 2:
-            GSMVI_LAUNCH(k_panel_partial<2>, grid, dim3(256), 0, st, ev, D, nrows, A, lda, shift, alpha, M, ldm, Pp,
+            GSMVI_LAUNCH(k_panel_partial<2>, grid, dim3(256), 0, st, ev, D, ncols, nrows, A, lda, shift, alpha, M, ldm, Pp,
                          chunks_per_wg, a_vec_ok);
             break;
         default:
-            GSMVI_LAUNCH(k_panel_partial<4>, grid, dim3(256), 0, st, ev, D, nrows, A, lda, shift, alpha, M, ldm, Pp,
+            GSMVI_LAUNCH(k_panel_partial<4>, grid, dim3(256), 0, st, ev, D, ncols, nrows, A, lda, shift, alpha, M, ldm, Pp,
                          chunks_per_wg, a_vec_ok);
             break;
     }

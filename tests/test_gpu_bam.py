@@ -1,0 +1,88 @@
+"""BaM on the GPU (gsmvi/bam.py:31-114) against the scipy restatement (oracle/bam_oracle.py; parity
+UNPINNED against the reference because jax is absent) and the known-answer tests K4-K6 that tie it to
+the pinned GSM oracle."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8          # fp64; the host Jacobi eigen-solve and the oracle's scipy sqrtm differ at ~1e-12
+
+
+def _o():
+    from oracle import gsm_oracle as orc
+    from oracle import bam_oracle as borc
+    return orc, borc
+
+
+def test_r1_fixture_vectors(golden):
+    import gsmvi_amd
+    g = golden("r1_bam.npz")
+    for c in [str(x) for x in g["cases"]]:
+        args = (g[f"{c}/samples"], g[f"{c}/vs"], g[f"{c}/mu0"], g[f"{c}/S0"], float(g[f"{c}/reg"]))
+        for fn in (gsmvi_amd.bam_lowrank_update, gsmvi_amd.bam_update):
+            mu, S = fn(*args)
+            assert rel_err(mu, g[f"{c}/mu_lowrank"]) < TOL, c
+            assert rel_err(S, g[f"{c}/S_lowrank"]) < TOL, c
+            assert rel_err(S, 0.5 * (g[f"{c}/S_full"] + g[f"{c}/S_full"].T)) < 1e-5, c
+            assert rel_err(S, S.T) < 1e-13
+
+
+@pytest.mark.parametrize("D,B,reg", [(3, 1, 1.0), (7, 2, 0.01), (33, 5, 3.0), (64, 8, 100.0), (100, 17, 1.0),
+                                     (256, 32, 10.0), (130, 64, 0.5), (40, 50, 2.0), (1024, 32, 1.0)])
+def test_against_restatement(D, B, reg):
+    import gsmvi_amd
+    orc, borc = _o()
+    st = orc.make_update_state(D, B, seed=D)
+    mu_o, S_o = borc.bam_lowrank_update_exact(st["samples"], st["vs"], st["mu0"], st["S0"], reg)
+    mu, S = gsmvi_amd.bam_lowrank_update(st["samples"], st["vs"], st["mu0"], st["S0"], reg)
+    assert rel_err(mu, mu_o) < TOL and rel_err(S, 0.5 * (S_o + S_o.T)) < TOL
+
+
+def test_k4_fixed_point_and_k5_gsm_limit():
+    import gsmvi_amd
+    orc, borc = _o()
+    m, cov_t, P = orc.make_gaussian_target(48, 21)
+    rs = np.random.RandomState(1)
+    X = m + rs.standard_normal((6, 48)) @ np.linalg.cholesky(cov_t).T
+    mu, S = gsmvi_amd.bam_update(X, orc.gaussian_score(X, m, P), m, cov_t, 2.5)
+    assert rel_err(mu, m) < 1e-8 and rel_err(S, cov_t) < 1e-8                      # K4
+    st = orc.make_update_state(20, 1, 5)
+    mu_g, S_g = gsmvi_amd.gsm_update(st["samples"], st["vs"], st["mu0"], st["S0"])
+    mu_b, S_b = gsmvi_amd.bam_update(st["samples"], st["vs"], st["mu0"], st["S0"], 1e7)
+    assert rel_err(mu_b, mu_g) < 1e-5 and rel_err(S_b, S_g) < 1e-5                  # K5
+
+
+def test_jitter_and_flag():
+    import gsmvi_amd
+    orc, borc = _o()
+    eng = gsmvi_amd.get_engine()
+    st = orc.make_update_state(24, 4, 2)
+    X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
+    mu0_, S0_, f0 = eng.bam_update(X, G, mu0, S0, 1.0, jitter=0.0)
+    mu1_, S1_, f1 = eng.bam_update(X, G, mu0, S0, 1.0, jitter=1e-3)
+    assert eng.read_flag(f0) == 0 and eng.read_flag(f1) == 0
+    assert rel_err((S1_ - S0_).cpu().numpy(), 1e-3 * np.eye(24)) < 1e-9             # bam.py:198
+    G[0, 0] = float("nan")
+    _, _, fb = eng.bam_update(X, G, mu0, S0, 1.0)
+    assert eng.read_flag(fb) != 0
+
+
+def test_bam_fit_example_config():
+    """examples/example_bam.py:47-64: D=5, niter=100, B=2, reg schedule 100/(1+i), low-rank, jitter 1e-6.
+    The example's own check is np.allclose(mean, mean_fit) and np.allclose(cov, cov_fit)."""
+    import gsmvi_amd
+    orc, borc = _o()
+    D = 5
+    m, cov_t, P = orc.make_gaussian_target(D, 17)
+    tgt = gsmvi_amd.GaussianTarget(m, precision=P)
+    reg = gsmvi_amd.Regularizers()
+    bam = gsmvi_amd.BaM(D, tgt.lp, tgt.lp_g, use_lowrank=True, jit_compile=True)
+    mean, cov = bam.fit(99, regf=reg.custom(lambda i: 100 / (1 + i)), niter=100, batch_size=2, verbose=False)
+    assert reg.counter == 101 and bam.n_reverts == 0
+    assert np.allclose(mean, m, atol=1e-3) and np.allclose(cov, cov_t, atol=1e-3, rtol=1e-3)
+    # same run through the CPU restatement with the same z-stream lands on the same point
+    mean_o, cov_o = borc.bam_fit(D, None, lambda x: orc.gaussian_score(x, m, P), 99,
+                                 borc.Regularizers().custom(lambda i: 100 / (1 + i)), niter=100, batch_size=2)
+    assert np.allclose(mean, mean_o, atol=1e-3) and np.allclose(cov, cov_o, atol=1e-3, rtol=1e-3)
