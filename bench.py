@@ -46,7 +46,7 @@ def parse():
     return ap.parse_args()
 
 
-def make_instances(eng, D, B, n_inst, seed0=0):
+def make_instances(eng, D, B, n_inst, seed0=0, ldpad=0):
     """Synthetic state per SURVEY 8(d): target m, P; per instance mu0, S0 = A A^T/D + 0.1 I,
     samples = mu0 + z chol(S0)^T, scores from the HIP Gaussian-score kernel.  Data generation
     uses torch (plumbing); the benchmarked path does not."""
@@ -68,7 +68,13 @@ def make_instances(eng, D, B, n_inst, seed0=0):
         Z = torch.randn(B, D, dtype=torch.float64, device=dev, generator=g)
         X = mu0[None, :] + Z @ Lc.T
         G = eng.gaussian_score(X, m, P)
-        inst.append(dict(X=X.contiguous(), G=G, mu0=mu0, S0=S0.contiguous(), mu=eng.empty(D), S=eng.empty(D, D)))
+        if ldpad:                                  # padded leading dimension (row stride != power of two)
+            S0p = eng.empty(D, D + ldpad)[:, :D]
+            S0p.copy_(S0)
+            Sout = eng.empty(D, D + ldpad)[:, :D]
+        else:
+            S0p, Sout = S0.contiguous(), eng.empty(D, D)
+        inst.append(dict(X=X.contiguous(), G=G, mu0=mu0, S0=S0p, mu=eng.empty(D), S=Sout))
     torch.cuda.synchronize()
     return inst, m, P
 

@@ -17,15 +17,14 @@ void gsmvi_launch_panel_partial(hipStream_t st, hipEvent_t* ev, int MT, dim3 gri
 void gsmvi_launch_panel_finish(hipStream_t st, hipEvent_t* ev, int D, int nrows, int KC, const double* Pp,
                                const double* addvec, double* Out, int ldo);
 void gsmvi_launch_gsm_scalars(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, const double* X, int ldx,
-                              const double* G, int ldg, const double* mu0, const double* Pp, double* SG, int ldsg,
-                              double* coef, int ldc, double* Xout, int ldxo);
+                              const double* G, int ldg, const double* mu0, const double* Pp, double* rec,
+                              int ldrec);
 size_t gsmvi_cov_update_lds_bytes(int SB);
 hipError_t gsmvi_cov_update_prepare();
 hipError_t gsmvi_bam_prepare();
-void gsmvi_launch_gsm_cov_update(hipStream_t st, hipEvent_t* ev, int D, int B, const double* X, int ldx,
-                                 const double* SG, int ldsg, const double* mu0, const double* coef, int ldc,
-                                 const double* S0, int lds0, double* S, int lds, double* mu_out, int SB,
-                                 int s_vec_ok);
+void gsmvi_launch_gsm_cov_update(hipStream_t st, hipEvent_t* ev, int D, int B, const double* rec, int ldrec,
+                                 const double* mu0, const double* S0, int lds0, double* S, int lds, double* mu_out,
+                                 int SB, int s_vec_ok);
 void gsmvi_launch_commit(hipStream_t st, int D, const int* info, const double* mu_new, const double* S_new,
                          int lds_new, double* mu, double* S, int lds, int* n_reverts);
 // fast paths (gsmvi_fast.hip)
@@ -33,11 +32,11 @@ void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, 
                              int lda, const double* shift, double alpha, const double* M, int ldm, double* Pp,
                              int chunks_per_wg);
 bool gsmvi_launch_gsm_scalars_fast(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, const double* X, int ldx,
-                                   const double* G, int ldg, const double* mu0, const double* Pp, double* SG,
-                                   int ldsg, double* coef, int ldc, double* Xout, int ldxo);
-bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, const double* X, int ldx,
-                              const double* SG, int ldsg, const double* mu0, const double* coef, int ldc,
-                              const double* S0, int lds0, double* S, int lds, double* mu_out, int dbg);
+                                   const double* G, int ldg, const double* mu0, const double* Pp, double* rec,
+                                   int ldrec);
+bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, const double* rec, int ldrec,
+                              const double* mu0, const double* S0, int lds0, double* S, int lds, double* mu_out,
+                              int dbg, unsigned long long* stamps);
 int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                      int* info_dev);
 int gsmvi_bam_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X, int ldx,
@@ -202,6 +201,15 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     return GSMVI_OK;
 }
 
+/* Diagnostic: copies n 64-bit words from the start of the panel-partial slab (where the cov_dbg=16
+ * build of k_gsm_cov_sym writes its timeline stamps) to host memory.  Not part of the product path. */
+int gsmvi_debug_read_stamps(gsmvi_ctx* ctx, unsigned long long* out, int n) {
+    BAD_ARG(!ctx || !out || n < 1, "bad argument");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, ctx->pp, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost));
+    return GSMVI_OK;
+}
+
 int gsmvi_set_profiling(gsmvi_ctx* ctx, int on) {
     BAD_ARG(!ctx, "ctx is NULL");
     ctx->profiling = on ? 1 : 0;
@@ -282,33 +290,29 @@ static int check_common(gsmvi_ctx* ctx, int D, int B, const char* fn) {
 extern "C" {
 
 static int gsm_local_stage(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, const double* X, int ldx, const double* G,
-                           int ldg, const double* mu0, const double* S0, int lds0, double* SG, int ldsg,
-                           double* coef, int ldc, double* Xout, int ldxo) {
+                           int ldg, const double* mu0, const double* S0, int lds0, double* rec, int ldrec) {
     int kc = 1;
     int st = gsmvi_panel_product(ctx, hs, ctx->stage_events(0), D, B, G, ldg, nullptr, 1.0, S0, lds0, ctx->pp, &kc);
     if (st != GSMVI_OK) return st;
     if (!ctx->tune_no_fast && D <= 4096 &&
-        gsmvi_launch_gsm_scalars_fast(hs, ctx->stage_events(1), D, B, kc, X, ldx, G, ldg, mu0, ctx->pp, SG, ldsg,
-                                      coef, ldc, Xout, ldxo))
+        gsmvi_launch_gsm_scalars_fast(hs, ctx->stage_events(1), D, B, kc, X, ldx, G, ldg, mu0, ctx->pp, rec, ldrec))
         return check_launch("k_gsm_scalars_fast");
-    gsmvi_launch_gsm_scalars(hs, ctx->stage_events(1), D, B, kc, X, ldx, G, ldg, mu0, ctx->pp, SG, ldsg, coef, ldc,
-                             Xout, ldxo);
+    gsmvi_launch_gsm_scalars(hs, ctx->stage_events(1), D, B, kc, X, ldx, G, ldg, mu0, ctx->pp, rec, ldrec);
     return check_launch("k_gsm_scalars");
 }
 
-static int gsm_apply(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, const double* X, int ldx, const double* SG,
-                     int ldsg, const double* coef, int ldc, const double* mu0, const double* S0, int lds0,
-                     double* mu, double* S, int lds) {
-    if (!ctx->tune_no_fast && D % 32 == 0 && (ldc % 2 == 0) && aligned16(coef) &&
-        gsmvi_launch_gsm_cov_sym(hs, ctx->stage_events(2), D, B, X, ldx, SG, ldsg, mu0, coef, ldc, S0, lds0, S, lds,
-                                 mu, ctx->tune_cov_dbg))
+static int gsm_apply(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, const double* rec, int ldrec, const double* mu0,
+                     const double* S0, int lds0, double* mu, double* S, int lds) {
+    if (!ctx->tune_no_fast && D % 32 == 0 && (ldrec % 2 == 0) && aligned16(rec) &&
+        gsmvi_launch_gsm_cov_sym(hs, ctx->stage_events(2), D, B, rec, ldrec, mu0, S0, lds0, S, lds, mu,
+                                 ctx->tune_cov_dbg,
+                                 (ctx->tune_cov_dbg & 16) ? reinterpret_cast<unsigned long long*>(ctx->pp) : nullptr))
         return check_launch("k_gsm_cov_sym");
     int SB = ctx->tune_update_sb > 0 ? ctx->tune_update_sb : ((B + 1) & ~1);
     if (SB > 64) SB = 64;
     SB = (SB + 1) & ~1;
     const int s_vec_ok = (lds0 % 2 == 0) && (lds % 2 == 0) && aligned16(S0) && aligned16(S);
-    gsmvi_launch_gsm_cov_update(hs, ctx->stage_events(2), D, B, X, ldx, SG, ldsg, mu0, coef, ldc, S0, lds0, S, lds,
-                                mu, SB, s_vec_ok);
+    gsmvi_launch_gsm_cov_update(hs, ctx->stage_events(2), D, B, rec, ldrec, mu0, S0, lds0, S, lds, mu, SB, s_vec_ok);
     return check_launch("k_gsm_cov_update");
 }
 
@@ -320,13 +324,13 @@ int gsmvi_gsm_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const doubl
     BAD_ARG(ldx < D || ldg < D || lds0 < D || lds < D, "leading dimension smaller than D");
     BAD_ARG(S == S0 || mu == mu0, "outputs must not alias inputs");
     hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
-    double* coef = ctx->small;
-    st = gsm_local_stage(ctx, hs, D, B, X, ldx, G, ldg, mu0, S0, lds0, ctx->sg, D, coef, 4, nullptr, 0);
+    const int ldrec = 3 * D + (D & 1);            // even stride keeps every record 16-byte aligned
+    st = gsm_local_stage(ctx, hs, D, B, X, ldx, G, ldg, mu0, S0, lds0, ctx->sg, ldrec);
     if (st != GSMVI_OK) return st;
-    return gsm_apply(ctx, hs, D, B, X, ldx, ctx->sg, D, coef, 4, mu0, S0, lds0, mu, S, lds);
+    return gsm_apply(ctx, hs, D, B, ctx->sg, ldrec, mu0, S0, lds0, mu, S, lds);
 }
 
-int gsmvi_gsm_record_len(int D) { return 2 * D + 4; }
+int gsmvi_gsm_record_len(int D) { return 3 * D + (D & 1); }
 
 int gsmvi_gsm_local_stage_f64(gsmvi_ctx* ctx, void* stream, int D, int B_local, const double* X, int ldx,
                               const double* G, int ldg, const double* mu0, const double* S0, int lds0, double* rec,
@@ -334,10 +338,9 @@ int gsmvi_gsm_local_stage_f64(gsmvi_ctx* ctx, void* stream, int D, int B_local, 
     int st = check_common(ctx, D, B_local, __func__);
     if (st != GSMVI_OK) return st;
     BAD_ARG(!X || !G || !mu0 || !S0 || !rec, "NULL array");
-    BAD_ARG(ldx < D || ldg < D || lds0 < D || ldrec < 2 * D + 4, "leading dimension too small");
+    BAD_ARG(ldx < D || ldg < D || lds0 < D || ldrec < 3 * D, "leading dimension too small");
     hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
-    return gsm_local_stage(ctx, hs, D, B_local, X, ldx, G, ldg, mu0, S0, lds0, rec + D, ldrec, rec + 2 * D, ldrec,
-                           rec, ldrec);
+    return gsm_local_stage(ctx, hs, D, B_local, X, ldx, G, ldg, mu0, S0, lds0, rec, ldrec);
 }
 
 int gsmvi_gsm_apply_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* rec, int ldrec, const double* mu0,
@@ -345,10 +348,10 @@ int gsmvi_gsm_apply_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double
     int st = check_common(ctx, D, B, __func__);
     if (st != GSMVI_OK) return st;
     BAD_ARG(!rec || !mu0 || !S0 || !mu || !S, "NULL array");
-    BAD_ARG(ldrec < 2 * D + 4 || lds0 < D || lds < D, "leading dimension too small");
+    BAD_ARG(ldrec < 3 * D || lds0 < D || lds < D, "leading dimension too small");
     BAD_ARG(S == S0 || mu == mu0, "outputs must not alias inputs");
     hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
-    return gsm_apply(ctx, hs, D, B, rec, ldrec, rec + D, ldrec, rec + 2 * D, ldrec, mu0, S0, lds0, mu, S, lds);
+    return gsm_apply(ctx, hs, D, B, rec, ldrec, mu0, S0, lds0, mu, S, lds);
 }
 
 int gsmvi_gaussian_score_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* X, int ldx,

@@ -1,7 +1,7 @@
 // Guard-free fast paths of the dense-covariance GSM update for gfx950.
 //
 // Selected by the ABI when D % 64 == 0, every leading dimension is even, every base pointer is
-// 16-byte aligned and B is one of {8,16,32,64} (BASELINE configs c2, c3, c5).  Everything else
+// 16-byte aligned and B is one of {16,32,64} for the covariance kernel (BASELINE configs c3, c5).  Everything else
 // runs the guarded generic kernels of gsmvi_kernels.hip (same arithmetic, same reduction order
 // inside a kernel family is NOT promised across the two families).
 //
@@ -21,21 +21,23 @@
 
 // =====================================================================================
 // Panel product partials:  Pp[kc][r][j] = sum_{i in rows(kc)} alpha (A[r][i] - shift[i]) M[i][j]
-// Workgroup = 16 columns of M x 256-row chunks; wave w owns rows 64w..64w+63 of the chunk and
-// MFMA k-slot ks of step s is row 64w + 4s + ks.  M (the D x D covariance / precision / factor) is
+// Workgroup (512 threads) = 16 columns of M x 256-row chunks; wave w of 8 owns rows 32w..32w+31 of
+// the chunk (two waves per SIMD: the fp64 MFMA pipe needs two to reach its ~46 TF) and MFMA k-slot
+// ks of step s is row 32w + 4s + ks.  M (the D x D covariance / precision / factor) is
 // streamed once from HBM as 128-B row segments straight into registers.  The left operand chunk
 // A[:, 256 rows] (16*MT x 256 doubles) is loaded by the whole workgroup with fully coalesced 16-B
 // accesses and staged in LDS ([row][258]: conflict-free ds_read_b64 for the MFMA A operand), because
 // fragment-shaped loads of it touch 64 cache lines per instruction.
-// D % 64 == 0: a wave's 64 rows are all inside or all outside the matrix.
+// D % 64 == 0: a wave's 32 rows are all inside or all outside the matrix.
 // =====================================================================================
 template <int MT, bool HAS_SHIFT>
-__global__ __launch_bounds__(256) void k_panel_fast(int D, int nrows, const double* __restrict__ A, int lda,
+__global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const double* __restrict__ A, int lda,
                                                     const double* __restrict__ shift, double alpha,
                                                     const double* __restrict__ M, int ldm,
                                                     double* __restrict__ Pp, int chunks_per_wg) {
     constexpr int LDG = 258;                       // LDS row stride of the staged A chunk (doubles)
     constexpr int NR = 16 * MT;
+    constexpr int UPT = 4 * MT;                    // 16-B staging units per thread: NR*128 / 512
     __shared__ __attribute__((aligned(16))) double As[NR * LDG];   // also reused for the reduction
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
     const int j = blockIdx.x * 16 + c;
@@ -48,20 +50,20 @@ __global__ __launch_bounds__(256) void k_panel_fast(int D, int nrows, const doub
     for (int ch = 0; ch < chunks_per_wg; ++ch) {
         const int cbase = (blockIdx.y * chunks_per_wg + ch) * 256;          // block-uniform
         if (cbase >= D) break;
-        const int wbase = cbase + w * 64;                                   // wave-uniform
+        const int wbase = cbase + w * 32;                                   // wave-uniform: 8 waves x 32 rows
         const bool wave_in = wbase < D;
         // ---- every global load of this chunk in one batch ----
-        double m[16];
+        double m[8];
         {
             const double* mp = M + (size_t)((wave_in ? wbase : 0) + ks) * ldm + j;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) m[s] = mp[(size_t)(4 * s) * ldm];
+            for (int s = 0; s < 8; ++s) m[s] = mp[(size_t)(4 * s) * ldm];
         }
-        v2d ga[8 * MT];                    // 16*MT rows x 128 16-B units = 2048*MT units / 256 threads
-        v2d gs[8 * MT];
+        v2d ga[UPT];
+        v2d gs[UPT];
 #pragma unroll
-        for (int q = 0; q < 8 * MT; ++q) {
-            const int u = q * 256 + tid;
+        for (int q = 0; q < UPT; ++q) {
+            const int u = q * 512 + tid;
             const int row = u >> 7, c16 = u & 127;
             const int grow = r0 + row;
             const int col = cbase + 2 * c16;
@@ -73,8 +75,8 @@ __global__ __launch_bounds__(256) void k_panel_fast(int D, int nrows, const doub
         }
         if (ch > 0) __syncthreads();       // previous chunk's MFMA reads of As are done
 #pragma unroll
-        for (int q = 0; q < 8 * MT; ++q) {
-            const int u = q * 256 + tid;
+        for (int q = 0; q < UPT; ++q) {
+            const int u = q * 512 + tid;
             const int row = u >> 7, c16 = u & 127;
             v2d v = ga[q];
             if (HAS_SHIFT) { v.x -= gs[q].x; v.y -= gs[q].y; }
@@ -83,51 +85,52 @@ __global__ __launch_bounds__(256) void k_panel_fast(int D, int nrows, const doub
         }
         __syncthreads();
         if (wave_in) {
-            const double* ap = As + c * LDG + 64 * w + ks;
+            const double* ap = As + c * LDG + 32 * w + ks;
+            double av[MT][8];                       // operands to registers first: no LDS round trip per MFMA step
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt] = GSMVI_MFMA_F64(ap[mt * 16 * LDG + 4 * s], m[s], acc[mt]);
+                for (int s = 0; s < 8; ++s) av[mt][s] = ap[mt * 16 * LDG + 4 * s];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = GSMVI_MFMA_F64(av[mt][s], m[s], acc[mt]);
             }
         }
     }
 
-    // cross-wave reduction through LDS (fixed order => deterministic), red[w][row][17]
+    // cross-wave reduction through LDS (fixed order => deterministic), red[w][row][17], w = 0..7
     __syncthreads();
-    double* red = As;                      // 4 * NR * 17 <= NR * 258
+    double* red = As;                      // 8 * NR * 17 <= NR * 258
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[(w * NR + 16 * mt + ks + 4 * r) * 17 + c] = acc[mt][r];
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < MT; ++k) {
-        const int idx = tid + 256 * k;
+    for (int idx = tid; idx < NR * 16; idx += 512) {
         const int rr = idx >> 4, cc = idx & 15;
         const int row = r0 + rr;
         if (row < nrows) {
-            const double s = (red[(0 * NR + rr) * 17 + cc] + red[(1 * NR + rr) * 17 + cc]) +
-                             (red[(2 * NR + rr) * 17 + cc] + red[(3 * NR + rr) * 17 + cc]);
+            double s = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < 8; ww += 2) s += red[(ww * NR + rr) * 17 + cc] + red[((ww + 1) * NR + rr) * 17 + cc];
             Pp[((size_t)blockIdx.y * nrows + row) * D + blockIdx.x * 16 + cc] = s;
         }
     }
 }
 
 // =====================================================================================
-// Per-sample scalars (gsm_numpy.py:8-10,15): one 1024-thread workgroup per sample, every thread
-// owns EPT elements of the row; all loads first, one block reduction, thread 0 writes the
-// coefficients.  SG_b = sum_kc Pp[kc][b] is written out for the covariance kernel.
+// Per-sample stage (gsm_numpy.py:8-18): one 1024-thread workgroup per sample, every thread owns
+// EPT elements of the row; all loads first, one block reduction, then the record
+// rec[b] = [ d_b | e_b | dmu_b ] is written (see k_gsm_scalars for the algebra).
 // =====================================================================================
 template <int EPT, int KCT>
 __global__ __launch_bounds__(1024) void k_gsm_scalars_fast(int D, int B, int KC, const double* __restrict__ X,
                                                            int ldx, const double* __restrict__ G, int ldg,
                                                            const double* __restrict__ mu0,
                                                            const double* __restrict__ Pp,
-                                                           double* __restrict__ SG, int ldsg,
-                                                           double* __restrict__ coef, int ldc,
-                                                           double* __restrict__ Xout, int ldxo) {
-    __shared__ double lds[32];
+                                                           double* __restrict__ rec, int ldrec) {
+    __shared__ double lds[34];
     const int b = blockIdx.x, tid = threadIdx.x;
     double pp[EPT][KCT], xv[EPT], gv[EPT], mv0[EPT];
 #pragma unroll
@@ -141,19 +144,18 @@ __global__ __launch_bounds__(1024) void k_gsm_scalars_fast(int D, int B, int KC,
         gv[e] = G[(size_t)b * ldg + ic];
         mv0[e] = mu0[ic];
     }
-    double p0 = 0.0, p1 = 0.0;
+    double p0 = 0.0, p1 = 0.0, sg[EPT], dd[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = tid + 1024 * e;
-        double sg = 0.0;
+        double t = 0.0;
 #pragma unroll
-        for (int kc = 0; kc < KCT; ++kc) sg += (kc < KC) ? pp[e][kc] : 0.0;
+        for (int kc = 0; kc < KCT; ++kc) t += (kc < KC) ? pp[e][kc] : 0.0;
+        sg[e] = t;
+        dd[e] = mv0[e] - xv[e];
         if (i < D) {
-            SG[(size_t)b * ldsg + i] = sg;
-            if (Xout) Xout[(size_t)b * ldxo + i] = xv[e];
-            const double d = mv0[e] - xv[e];
-            p0 += gv[e] * sg;
-            p1 += d * gv[e];
+            p0 += gv[e] * t;
+            p1 += dd[e] * gv[e];
         }
     }
     p0 = wave_sum(p0);
@@ -173,142 +175,192 @@ __global__ __launch_bounds__(1024) void k_gsm_scalars_fast(int D, int B, int KC,
         }
         const double rho = 0.5 * sqrt(1.0 + 4.0 * (gSg + mv * mv)) - 0.5;
         const double den = 1.0 + rho + mv;
-        const double cc = (gSg - mv) / den;
-        const double beta = 1.0 / (1.0 + rho);
-        double* cb = coef + (size_t)b * ldc;
-        cb[0] = 1.0 - (1.0 + cc) * beta;
-        cb[1] = beta;
-        cb[2] = cc;
-        cb[3] = rho;
+        lds[32] = 1.0 / (1.0 + rho);
+        lds[33] = (gSg - mv) / den;
+    }
+    __syncthreads();
+    const double beta = lds[32], c = lds[33];
+    double* rb = rec + (size_t)b * ldrec;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + 1024 * e;
+        if (i < D) {
+            const double dmu = beta * ((sg[e] - dd[e]) - c * dd[e]);
+            rb[i] = dd[e];
+            rb[D + i] = dd[e] + dmu;
+            rb[2 * D + i] = dmu;
+        }
     }
 }
 
 // =====================================================================================
-// Symmetric rank-2B covariance update (gsm_numpy.py:21-23,50-53).
-// One workgroup = one 32x32 tile pair (I,J), I <= J, of the UPPER triangle; it reads S0[I,J]
-// once, computes W = S0[I,J] + (1/B) sum_b (d_b[I] d_b[J]^T - e_b[I] e_b[J]^T) with fp64 MFMA
-// (one 16x16 tile per wave, K = 2B), stores S[I,J] = W and, through an LDS transpose, the mirror
-// S[J,I] = W^T.  S0 must be symmetric (only its upper triangle is read); S is exactly symmetric.
+// Symmetric rank-2B covariance update (gsm_numpy.py:21-23,50-53) from the per-sample records.
+//   W = S0[I,J] + (1/B) ( Dm[:,I]^T Dm[:,J] - E[:,I]^T E[:,J] ),  S[I,J] = W,  S[J,I] = W^T
+// One 512-thread workgroup owns the row block I (32 rows) and TWO adjacent column blocks J0, J1 >= I
+// of the upper triangle (waves 0-3 compute tile 0, waves 4-7 tile 1: two waves per SIMD, where the
+// fp64 MFMA pipe delivers ~46 TF chip-wide instead of ~34 TF with one), so the I tiles are staged
+// once and every global load of the workgroup is issued in one batch.  Factor tiles are copied verbatim (16-B loads -> 16-B LDS writes, no arithmetic,
+// no transposition) into LDS as [k = sample][32 columns], row stride 48 doubles: the MFMA operand
+// reads (lane = column, k-slot = sample) are bank-conflict free for both operands.  The d-part and
+// the e-part run as two independent accumulator chains (acc_d - acc_e), which also hides the MFMA
+// latency.  S0 must be symmetric (only its upper triangle is read); S comes out exactly symmetric.
 // Bytes moved: 4 D^2 read + 8 D^2 written (algorithmic count of SURVEY 8(d): 16 D^2).
-// Factor tiles are built from X, SG, mu0 and coef while staging to LDS ([row][k], stride 2B+2
-// doubles: conflict-free ds_read_b64 for both MFMA operands).  Diagonal workgroups also write the
-// new mean mu = mu0 + mean_b dmu_b.
+// The workgroup whose first tile is diagonal also writes mu = mu0 + mean_b dmu_b.
 // =====================================================================================
 template <int SB>
-__global__ __launch_bounds__(256) void k_gsm_cov_sym(int D, const double* __restrict__ X, int ldx,
-                                                     const double* __restrict__ SG, int ldsg,
+__global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __restrict__ rec, int ldrec,
                                                      const double* __restrict__ mu0,
-                                                     const double* __restrict__ coef, int ldc,
                                                      const double* __restrict__ S0, int lds0,
                                                      double* __restrict__ S, int lds,
-                                                     double* __restrict__ mu_out, int dbg) {
-    constexpr int KF = 2 * SB;          // MFMA reduction length
-    constexpr int RS = KF + 2;          // LDS row stride (doubles)
-    constexpr int NIT = SB / 8;         // staging iterations (8 samples x 32 columns per pass)
-    __shared__ __attribute__((aligned(16))) double smem[2 * 32 * RS];   // >= 32*33 for every SB
-    double* FA = smem;
-    double* FB = smem + 32 * RS;
+                                                     double* __restrict__ mu_out, int dbg,
+                                                     unsigned long long* __restrict__ stamps) {
+#define STAMP(k)                                                                          \
+    do {                                                                                  \
+        if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+    STAMP(0);
+    constexpr int RS = 48;                       // LDS row stride (doubles): 32 columns + 16 pad
+    constexpr int TILE = SB * RS;                // one staged tile
+    constexpr int NU = SB * 16;                  // 16-B units per tile
+    constexpr int UPT = (6 * NU) / 512;          // units per thread over the six tiles
+    static_assert((6 * NU) % 512 == 0, "tile units must divide over 512 threads");
+    __shared__ __attribute__((aligned(16))) double smem[6 * TILE >= 2 * 32 * 33 ? 6 * TILE : 2 * 32 * 33];
+    // staged tiles, in this order: DI, EI, DJ0, EJ0, DJ1, EJ1
 
-    // upper-triangle tile pair from the linear block index
+    // ---- which tiles: row block ti, column blocks tj0, tj0+1 ------------------------------------
+    // Row ti of the upper triangle has m = nt - ti tiles: floor(m/2) two-tile workgroups and, for odd
+    // m, one single-tile workgroup (its last tile).  The two-tile workgroups come FIRST in the grid
+    // (exactly 256 of them at D = 1024: one per CU); the light single-tile ones are dispatched last
+    // and share a CU with a resident workgroup without stretching the kernel's tail.
     const int nt = D >> 5;
-    int ti, tj;
-    {
-        const int idx = blockIdx.x;
-        const double q = 2.0 * nt + 1.0;
-        int t = (int)((q - sqrt(q * q - 8.0 * (double)idx)) * 0.5);
-        if (t < 0) t = 0;
-        while (t > 0 && t * nt - (t * (t - 1)) / 2 > idx) --t;
-        while ((t + 1) * nt - ((t + 1) * t) / 2 <= idx) ++t;
-        ti = t;
-        tj = t + (idx - (t * nt - (t * (t - 1)) / 2));
+    const int n_two = ((nt >> 1) * ((nt + 1) >> 1));             // sum_m floor(m/2), m = 1..nt
+    int ti, tj0;
+    bool two;
+    if ((int)blockIdx.x < n_two) {
+        int rem = blockIdx.x;
+        ti = 0;
+        for (;;) {
+            const int inrow = (nt - ti) >> 1;
+            if (rem < inrow) break;
+            rem -= inrow;
+            ++ti;
+        }
+        tj0 = ti + 2 * rem;
+        two = true;
+    } else {
+        const int k = blockIdx.x - n_two;                        // k-th row with an odd tile count
+        ti = ((nt & 1) ? 0 : 1) + 2 * k;
+        tj0 = nt - 1;
+        two = false;
     }
-    const int I0 = ti * 32, J0 = tj * 32;
+    const bool diag = (tj0 == ti);
+    const int I0 = ti * 32, J0 = tj0 * 32;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
-    const int wr = w >> 1, wc = w & 1;
+    const int t = w >> 2;                        // which tile this wave computes (two waves per SIMD)
+    const int wr = (w >> 1) & 1, wc = w & 1;
     constexpr double invB = 1.0 / (double)SB;
+    const bool mine = (t == 0) || two;           // does this wave's tile exist
 
     // ---- every global load of this workgroup, in one batch --------------------------------
     double s0[4];
     const size_t srow = (size_t)(I0 + 16 * wr + ks);
-    const int scol = J0 + 16 * wc + c;
+    const int scol = J0 + 32 * ((t == 1 && two) ? 1 : 0) + 16 * wc + c;
 #pragma unroll
     for (int r = 0; r < 4; ++r) s0[r] = (dbg & 2) ? 1.0 : S0[(srow + 4 * r) * lds0 + scol];
-    __builtin_amdgcn_sched_barrier(0);   // keep the HBM loads of S0 ahead of the L2-resident staging loads
-
-    const int ii = tid & 31, bq = tid >> 5;
-    const double mI = mu0[I0 + ii], mJ = mu0[J0 + ii];
-    double xI[NIT], gI[NIT], xJ[NIT], gJ[NIT];
-    v2d ab[NIT];
-    double cc[NIT];
+    __builtin_amdgcn_sched_barrier(0);           // keep the HBM loads of S0 ahead of the L2-resident staging loads
+    v2d stg[UPT];
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-        const int b = bq + 8 * k;
-        if (dbg & 4) { xI[k] = gI[k] = xJ[k] = gJ[k] = 0.5; ab[k] = (v2d){0.5, 0.5}; cc[k] = 0.1; continue; }
-        xI[k] = X[(size_t)b * ldx + I0 + ii];
-        gI[k] = SG[(size_t)b * ldsg + I0 + ii];
-        xJ[k] = X[(size_t)b * ldx + J0 + ii];
-        gJ[k] = SG[(size_t)b * ldsg + J0 + ii];
-        ab[k] = *reinterpret_cast<const v2d*>(coef + (size_t)b * ldc);
-        cc[k] = coef[(size_t)b * ldc + 2];
+    for (int q = 0; q < UPT; ++q) {
+        const int g = q * 512 + tid;             // global unit over six tiles
+        const int tile = g / NU, u = g % NU;     // NU is a power of two
+        const int b = u >> 4, c2 = 2 * (u & 15);
+        // tile 0,1: I block (d, e); 2,3: J0 block; 4,5: J1 block (= J0 again when there is no second tile)
+        const int colbase = (tile < 2) ? I0 : (J0 + ((tile >= 4 && two) ? 32 : 0));
+        stg[q] = *reinterpret_cast<const v2d*>(rec + (size_t)b * ldrec + (tile & 1) * D + colbase + c2);
     }
-
-    // ---- factor tiles -> LDS ---------------------------------------------------------------
     double dmu_part = 0.0;
+    if (diag && tid < 256) {                     // dmu tile for the new mean: column = tid & 31, samples tid>>5 + 8k
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-        const int b = bq + 8 * k;
-        const double dI = mI - xI[k], dJ = mJ - xJ[k];
-        const double eI = ab[k].x * dI + ab[k].y * gI[k];
-        const double eJ = ab[k].x * dJ + ab[k].y * gJ[k];
-        FA[ii * RS + b] = dI;
-        FA[ii * RS + SB + b] = eI;
-        FB[ii * RS + b] = dJ * invB;
-        FB[ii * RS + SB + b] = -eJ * invB;
-        dmu_part += ab[k].y * ((gI[k] - dI) - cc[k] * dI);
+        for (int k = 0; k < SB / 8; ++k)
+            dmu_part += rec[(size_t)((tid >> 5) + 8 * k) * ldrec + 2 * D + I0 + (tid & 31)];
+    }
+    if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(1); }
+
+    // ---- factor tiles -> LDS, verbatim ---------------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < UPT; ++q) {
+        const int g = q * 512 + tid;
+        const int tile = g / NU, u = g % NU;
+        *reinterpret_cast<v2d*>(smem + tile * TILE + (u >> 4) * RS + 2 * (u & 15)) = stg[q];
     }
     __syncthreads();
+    STAMP(2);
 
-    // ---- MFMA: one 16x16 tile per wave, K = 2B ---------------------------------------------
-    const double* ap = FA + (16 * wr + c) * RS + ks;
-    const double* bp = FB + (16 * wc + c) * RS + ks;
-    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    // ---- MFMA: one 16x16 block per wave; chain 0 = d-part, chain 1 = e-part.  Operands go to
+    // registers first so the two chains issue back to back.
+    constexpr int NS = SB / 4;
+    double ad[NS], ae[NS], bd[NS], be[NS];
+    {
+        const double* adp = smem + ks * RS + 16 * wr + c;
+        const double* aep = adp + TILE;
+        const double* bdp = smem + (2 + 2 * t) * TILE + ks * RS + 16 * wc + c;
+        const double* bep = bdp + TILE;
 #pragma unroll
-    for (int s = 0; s < KF / 4; s += 2) {       // two independent chains hide the MFMA latency
-        if (dbg & 8) break;
-        acc0 = GSMVI_MFMA_F64(ap[4 * s], bp[4 * s], acc0);
-        acc1 = GSMVI_MFMA_F64(ap[4 * s + 4], bp[4 * s + 4], acc1);
+        for (int s = 0; s < NS; ++s) {
+            ad[s] = adp[4 * s * RS];
+            ae[s] = aep[4 * s * RS];
+            bd[s] = bdp[4 * s * RS];
+            be[s] = bep[4 * s * RS];
+        }
+    }
+    v4d accd = {0.0, 0.0, 0.0, 0.0}, acce = {0.0, 0.0, 0.0, 0.0};
+    if (!(dbg & 8)) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            accd = GSMVI_MFMA_F64(ad[s], bd[s], accd);
+            acce = GSMVI_MFMA_F64(ae[s], be[s], acce);
+        }
     }
     double wv[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) wv[r] = s0[r] + (acc0[r] + acc1[r]);
-
-    // ---- direct store S[I,J] ----------------------------------------------------------------
+    for (int r = 0; r < 4; ++r) wv[r] = s0[r] + (accd[r] - acce[r]) * invB;
+    if (mine) {                                  // direct store S[I, J_t]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) S[(srow + 4 * r) * lds + scol] = wv[r];
+        for (int r = 0; r < 4; ++r) S[(srow + 4 * r) * lds + scol] = wv[r];
+    }
+    if (stamps) { asm volatile("" :: "v"(wv[0]), "v"(wv[1]), "v"(wv[2]), "v"(wv[3])); STAMP(3); }
 
-    // ---- mirror store S[J,I] = W^T through LDS, and the new mean on the diagonal -------------
-    __syncthreads();                      // everyone is done reading FA / FB
-    double* LW = smem;                    // 32 x 33 transpose buffer (aliases the factor tiles)
-    if (ti != tj && !(dbg & 1)) {
+    // ---- mirror stores S[J_t, I] = W_t^T through LDS, and the new mean ---------------------------
+    __syncthreads();                             // everyone is done reading the factor tiles
+    double* LW = smem + t * 32 * 33;             // [2][32 x 33]
+    const bool need = mine && !(t == 0 && diag) && !(dbg & 1);
+    if (need) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) LW[(16 * wr + ks + 4 * r) * 33 + 16 * wc + c] = wv[r];
-    } else if (ti == tj) {
-        smem[bq * 32 + ii] = dmu_part;
     }
     __syncthreads();
-    if (ti != tj && !(dbg & 1)) {
-        // element (row j = 16 wr + ks + 4r of J, col i = 16 wc + c of I) = W[i][j]
+    if (need) {
+        // element (row j = 16 wr + ks + 4r of J_t, col i = 16 wc + c of I) = W_t[i][j]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const double v = LW[(16 * wc + c) * 33 + 16 * wr + ks + 4 * r];
-            S[(size_t)(J0 + 16 * wr + ks + 4 * r) * lds + I0 + 16 * wc + c] = v;
+            S[(size_t)(J0 + 32 * t + 16 * wr + ks + 4 * r) * lds + I0 + 16 * wc + c] = v;
         }
-    } else if (ti == tj && tid < 32) {
-        double s = 0.0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s += smem[q * 32 + tid];
-        mu_out[I0 + tid] = mu0[I0 + tid] + s * invB;
     }
+    if (diag) {
+        __syncthreads();
+        if (tid < 256) smem[tid] = dmu_part;     // [8][32]
+        __syncthreads();
+        if (tid < 32) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += smem[q * 32 + tid];
+            mu_out[I0 + tid] = mu0[I0 + tid] + s * invB;
+        }
+    }
+    STAMP(4);
+    if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(5); }
+#undef STAMP
 }
 
 // ---- launch helpers ------------------------------------------------------------------------
@@ -316,7 +368,7 @@ void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, 
                              int lda, const double* shift, double alpha, const double* M, int ldm, double* Pp,
                              int chunks_per_wg) {
 #define PF(MTV, HS)                                                                                         \
-    GSMVI_LAUNCH((k_panel_fast<MTV, HS>), grid, dim3(256), 0, st, ev, D, nrows, A, lda, shift, alpha, M, ldm, \
+    GSMVI_LAUNCH((k_panel_fast<MTV, HS>), grid, dim3(512), 0, st, ev, D, nrows, A, lda, shift, alpha, M, ldm, \
                  Pp, chunks_per_wg)
     if (shift) {
         if (MT == 1) PF(1, true); else if (MT == 2) PF(2, true); else PF(4, true);
@@ -328,12 +380,12 @@ void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, 
 
 // returns false when (D, KC) has no instantiation
 bool gsmvi_launch_gsm_scalars_fast(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, const double* X, int ldx,
-                                   const double* G, int ldg, const double* mu0, const double* Pp, double* SG,
-                                   int ldsg, double* coef, int ldc, double* Xout, int ldxo) {
+                                   const double* G, int ldg, const double* mu0, const double* Pp, double* rec,
+                                   int ldrec) {
     const int ept = (D + 1023) / 1024;
 #define SF(E, K)                                                                                              \
     GSMVI_LAUNCH((k_gsm_scalars_fast<E, K>), dim3(B), dim3(1024), 0, st, ev, D, B, KC, X, ldx, G, ldg, mu0, Pp, \
-                 SG, ldsg, coef, ldc, Xout, ldxo)
+                 rec, ldrec)
     if (KC > 8 || ept > 4) return false;
     const int kct = KC <= 1 ? 1 : (KC <= 2 ? 2 : (KC <= 4 ? 4 : 8));
     const int e = ept <= 1 ? 1 : (ept <= 2 ? 2 : 4);
@@ -344,16 +396,21 @@ bool gsmvi_launch_gsm_scalars_fast(hipStream_t st, hipEvent_t* ev, int D, int B,
     return true;
 }
 
-bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, const double* X, int ldx,
-                              const double* SG, int ldsg, const double* mu0, const double* coef, int ldc,
-                              const double* S0, int lds0, double* S, int lds, double* mu_out, int dbg) {
-    const int nt = D / 32;
-    const dim3 grid(nt * (nt + 1) / 2);
+// number of workgroups of k_gsm_cov_sym: row ti of the upper triangle holds ceil((nt - ti)/2)
+static int cov_sym_grid(int nt) {
+    int n = 0;
+    for (int ti = 0; ti < nt; ++ti) n += (nt - ti + 1) / 2;
+    return n;
+}
+
+bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, const double* rec, int ldrec,
+                              const double* mu0, const double* S0, int lds0, double* S, int lds, double* mu_out,
+                              int dbg, unsigned long long* stamps) {
+    const dim3 grid(cov_sym_grid(D / 32));
 #define CS(SBV)                                                                                             \
-    GSMVI_LAUNCH(k_gsm_cov_sym<SBV>, grid, dim3(256), 0, st, ev, D, X, ldx, SG, ldsg, mu0, coef, ldc, S0, lds0, \
-                 S, lds, mu_out, dbg)
+    GSMVI_LAUNCH(k_gsm_cov_sym<SBV>, grid, dim3(512), 0, st, ev, D, rec, ldrec, mu0, S0, lds0, S, lds, mu_out, dbg, \
+                 stamps)
     switch (B) {
-        case 8: CS(8); break;
         case 16: CS(16); break;
         case 32: CS(32); break;
         case 64: CS(64); break;

@@ -3,7 +3,7 @@
 // Reference being replaced: gsmvi/gsm_numpy.py:4-55 (per-sample update + batch mean).  The
 // algebra is the O(B D^2) form of SURVEY Appendix A.1:
 //     SG = G S0                               panel product   (k_panel_partial, fp64 MFMA)
-//     gSg_b, mv_b, rho_b, den_b               per-sample      (k_gsm_scalars, wave reductions)
+//     gSg_b, mv_b, rho_b, den_b, records       per-sample      (k_gsm_scalars, wave reductions)
 //     S  = S0 + (Dm^T Dm - E^T E)/B           rank-2B update  (k_gsm_cov_update, fp64 MFMA)
 // Layouts: everything row-major fp64 in HBM; S0 is streamed exactly once per pass.
 #include "gsmvi_common.h"
@@ -121,29 +121,32 @@ __global__ __launch_bounds__(256) void k_panel_finish(int D, int nrows, int KC, 
 }
 
 // =====================================================================================
-// Per-sample scalars of the GSM update (gsm_numpy.py:8-10,15; one workgroup per sample):
+// Per-sample stage of the GSM update (gsm_numpy.py:8-18; one workgroup per sample):
 //   SG_b = sum_kc Pp[kc][b]          gSg = g.SG   mv = (mu0-x).g
-//   rho = 0.5 sqrt(1+4(gSg+mv^2)) - 0.5,  den = 1+rho+mv,  c = (gSg-mv)/den
-//   coef[b] = {alpha = 1-(1+c)/(1+rho), beta = 1/(1+rho), c, rho}   (row stride ldc >= 4)
-// so that e_b = mu_b - x_b = alpha d_b + beta SG_b and dmu_b = beta((SG_b - d_b) - c d_b).
+//   rho = 0.5 sqrt(1+4(gSg+mv^2)) - 0.5,  den = 1+rho+mv,  c = (gSg-mv)/den,  beta = 1/(1+rho)
+//   dmu_b = beta ((SG_b - d_b) - c d_b)     (= mu_update of gsm_numpy.py:17)
+// and writes the sample's RECORD  rec[b] = [ d_b | e_b | dmu_b ]  (3D doubles, row stride ldrec) with
+// d_b = mu0 - x_b and e_b = d_b + dmu_b = mu_b - x_b, i.e. the two factor rows of
+// S_update_b = d d^T - e e^T (gsm_numpy.py:21-23).  Records are what the covariance kernel and the
+// batch-sharded exchange consume.
 // =====================================================================================
 __global__ __launch_bounds__(256) void k_gsm_scalars(int D, int B, int KC, const double* __restrict__ X,
                                                      int ldx, const double* __restrict__ G, int ldg,
                                                      const double* __restrict__ mu0,
-                                                     const double* __restrict__ Pp, double* __restrict__ SG,
-                                                     int ldsg, double* __restrict__ coef, int ldc,
-                                                     double* __restrict__ Xout, int ldxo) {
+                                                     const double* __restrict__ Pp, double* __restrict__ rec,
+                                                     int ldrec) {
     __shared__ double lds[8];
+    __shared__ double sh[2];
     const int b = blockIdx.x;
+    double* rb = rec + (size_t)b * ldrec;
     double p[2] = {0.0, 0.0};
     for (int i = threadIdx.x; i < D; i += 256) {
         double sg = 0.0;
         for (int kc = 0; kc < KC; ++kc) sg += Pp[((size_t)kc * B + b) * D + i];
-        SG[(size_t)b * ldsg + i] = sg;
         const double g = G[(size_t)b * ldg + i];
-        const double x = X[(size_t)b * ldx + i];
-        if (Xout) Xout[(size_t)b * ldxo + i] = x;
-        const double d = mu0[i] - x;
+        const double d = mu0[i] - X[(size_t)b * ldx + i];
+        rb[i] = d;
+        rb[D + i] = sg;                      // parked here until the scalars are known
         p[0] += g * sg;
         p[1] += d * g;
     }
@@ -152,30 +155,29 @@ __global__ __launch_bounds__(256) void k_gsm_scalars(int D, int B, int KC, const
         const double gSg = p[0], mv = p[1];
         const double rho = 0.5 * sqrt(1.0 + 4.0 * (gSg + mv * mv)) - 0.5;
         const double den = 1.0 + rho + mv;
-        const double c = (gSg - mv) / den;
-        const double beta = 1.0 / (1.0 + rho);
-        double* cb = coef + (size_t)b * ldc;
-        cb[0] = 1.0 - (1.0 + c) * beta;
-        cb[1] = beta;
-        cb[2] = c;
-        cb[3] = rho;
+        sh[0] = 1.0 / (1.0 + rho);
+        sh[1] = (gSg - mv) / den;
+    }
+    __syncthreads();
+    const double beta = sh[0], c = sh[1];
+    for (int i = threadIdx.x; i < D; i += 256) {       // same thread wrote these two entries
+        const double d = rb[i], sg = rb[D + i];
+        const double dmu = beta * ((sg - d) - c * d);
+        rb[D + i] = d + dmu;
+        rb[2 * D + i] = dmu;
     }
 }
 
 // =====================================================================================
-// Rank-2B covariance update (gsm_numpy.py:21-23,50-53):  S = S0 + (1/B) sum_b (d_b d_b^T - e_b e_b^T)
-// One workgroup = one 64x64 tile of S, 4 waves of 32x32 (2x2 MFMA tiles).  The factor tiles
-// [d;e] for the tile's rows (I) and columns (J) are built on the fly from X, SG, mu0 and the
-// per-sample coefficients and staged transposed in LDS ([row][k], padded so the MFMA operand
-// reads are bank-conflict free); S0 is prefetched into registers before staging and added to the
-// accumulators at the end, so its HBM latency hides under the staging + MFMA chain.
-// Column tile ct of lane c is column 2c+ct, i.e. every lane touches 16 contiguous bytes of S.
-// The diagonal workgroups also emit the new mean: mu = mu0 + mean_b dmu_b (gsm_numpy.py:50,52).
+// Rank-2B covariance update, guarded generic version (any D, B, ld, alignment):
+//   S = S0 + (1/B) sum_b (d_b d_b^T - e_b e_b^T),  mu = mu0 + (1/B) sum_b dmu_b     (gsm_numpy.py:50-53)
+// One workgroup = one 64x64 tile of S, 4 waves of 32x32 (2x2 MFMA tiles).  The factor rows come
+// from the records and are staged transposed in LDS ([row][k], padded so the MFMA operand reads
+// are bank-conflict free); S0 is prefetched into registers before staging and added to the
+// accumulators at the end.  Column tile ct of lane c is column 2c+ct (16 contiguous bytes per lane).
 // =====================================================================================
-__global__ __launch_bounds__(256) void k_gsm_cov_update(int D, int B, const double* __restrict__ X, int ldx,
-                                                        const double* __restrict__ SG, int ldsg,
+__global__ __launch_bounds__(256) void k_gsm_cov_update(int D, int B, const double* __restrict__ rec, int ldrec,
                                                         const double* __restrict__ mu0,
-                                                        const double* __restrict__ coef, int ldc,
                                                         const double* __restrict__ S0, int lds0,
                                                         double* __restrict__ S, int lds,
                                                         double* __restrict__ mu_out, int SB, int s_vec_ok) {
@@ -193,7 +195,6 @@ __global__ __launch_bounds__(256) void k_gsm_cov_update(int D, int B, const doub
     const int wr = w >> 1, wc = w & 1;
     const double invB = 1.0 / (double)B;
 
-    // prefetch the S0 sub-tile (2 row tiles x 4 regs, two adjacent columns per lane)
     v2d s0[2][4];
     const int col = J0 + 32 * wc + 2 * c;
 #pragma unroll
@@ -223,16 +224,10 @@ __global__ __launch_bounds__(256) void k_gsm_cov_update(int D, int B, const doub
             const int bl = idx >> 6, ii = idx & 63, b = b0 + bl;
             double dI = 0.0, eI = 0.0, dJ = 0.0, eJ = 0.0;
             if (bl < nb) {
-                const double al = coef[(size_t)b * ldc], be = coef[(size_t)b * ldc + 1];
+                const double* rb = rec + (size_t)b * ldrec;
                 const int gi = I0 + ii, gj = J0 + ii;
-                if (gi < D) {
-                    dI = mu0[gi] - X[(size_t)b * ldx + gi];
-                    eI = al * dI + be * SG[(size_t)b * ldsg + gi];
-                }
-                if (gj < D) {
-                    dJ = mu0[gj] - X[(size_t)b * ldx + gj];
-                    eJ = al * dJ + be * SG[(size_t)b * ldsg + gj];
-                }
+                if (gi < D) { dI = rb[gi]; eI = rb[D + gi]; }
+                if (gj < D) { dJ = rb[gj]; eJ = rb[D + gj]; }
             }
             FA[ii * RSA + bl] = dI;
             FA[ii * RSA + SB + bl] = eI;
@@ -245,7 +240,6 @@ __global__ __launch_bounds__(256) void k_gsm_cov_update(int D, int B, const doub
         const double* b0p = FB + (32 * wc + 2 * c) * RSB + ks;
         const double* b1p = b0p + RSB;
         const int nsteps = KCH >> 2;
-#pragma unroll 4
         for (int s = 0; s < nsteps; ++s) {
             const double a0 = a0p[4 * s], a1 = a1p[4 * s], bb0 = b0p[4 * s], bb1 = b1p[4 * s];
             acc[0][0] = GSMVI_MFMA_F64(a0, bb0, acc[0][0]);
@@ -256,7 +250,6 @@ __global__ __launch_bounds__(256) void k_gsm_cov_update(int D, int B, const doub
         __syncthreads();
     }
 
-    // S = S0 + update
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -273,18 +266,11 @@ __global__ __launch_bounds__(256) void k_gsm_cov_update(int D, int B, const doub
             }
         }
 
-    // new mean, by the diagonal workgroups
-    if (ti == tj) {
+    if (ti == tj) {                                // new mean, by the diagonal workgroups
         const int gi = I0 + l;
         double part = 0.0;
-        if (gi < D) {
-            const double m0 = mu0[gi];
-            for (int b = w; b < B; b += 4) {
-                const double d = m0 - X[(size_t)b * ldx + gi];
-                const double sg = SG[(size_t)b * ldsg + gi];
-                part += coef[(size_t)b * ldc + 1] * ((sg - d) - coef[(size_t)b * ldc + 2] * d);
-            }
-        }
+        if (gi < D)
+            for (int b = w; b < B; b += 4) part += rec[(size_t)b * ldrec + 2 * D + gi];
         smem[w * 64 + l] = part;
         __syncthreads();
         if (w == 0 && gi < D)
@@ -341,10 +327,9 @@ void gsmvi_launch_panel_finish(hipStream_t st, hipEvent_t* ev, int D, int nrows,
 }
 
 void gsmvi_launch_gsm_scalars(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, const double* X, int ldx,
-                              const double* G, int ldg, const double* mu0, const double* Pp, double* SG, int ldsg,
-                              double* coef, int ldc, double* Xout, int ldxo) {
-    GSMVI_LAUNCH(k_gsm_scalars, dim3(B), dim3(256), 0, st, ev, D, B, KC, X, ldx, G, ldg, mu0, Pp, SG, ldsg, coef,
-                 ldc, Xout, ldxo);
+                              const double* G, int ldg, const double* mu0, const double* Pp, double* rec,
+                              int ldrec) {
+    GSMVI_LAUNCH(k_gsm_scalars, dim3(B), dim3(256), 0, st, ev, D, B, KC, X, ldx, G, ldg, mu0, Pp, rec, ldrec);
 }
 
 size_t gsmvi_cov_update_lds_bytes(int SB) {
@@ -357,13 +342,12 @@ hipError_t gsmvi_cov_update_prepare() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-void gsmvi_launch_gsm_cov_update(hipStream_t st, hipEvent_t* ev, int D, int B, const double* X, int ldx,
-                                 const double* SG, int ldsg, const double* mu0, const double* coef, int ldc,
-                                 const double* S0, int lds0, double* S, int lds, double* mu_out, int SB,
-                                 int s_vec_ok) {
+void gsmvi_launch_gsm_cov_update(hipStream_t st, hipEvent_t* ev, int D, int B, const double* rec, int ldrec,
+                                 const double* mu0, const double* S0, int lds0, double* S, int lds, double* mu_out,
+                                 int SB, int s_vec_ok) {
     const int nt = (D + 63) / 64;
-    GSMVI_LAUNCH(k_gsm_cov_update, dim3(nt * nt), dim3(256), gsmvi_cov_update_lds_bytes(SB), st, ev, D, B, X, ldx,
-                 SG, ldsg, mu0, coef, ldc, S0, lds0, S, lds, mu_out, SB, s_vec_ok);
+    GSMVI_LAUNCH(k_gsm_cov_update, dim3(nt * nt), dim3(256), gsmvi_cov_update_lds_bytes(SB), st, ev, D, B, rec,
+                 ldrec, mu0, S0, lds0, S, lds, mu_out, SB, s_vec_ok);
 }
 
 void gsmvi_launch_commit(hipStream_t st, int D, const int* info, const double* mu_new, const double* S_new,

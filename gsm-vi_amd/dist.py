@@ -3,10 +3,11 @@
 The reference has no multi-device path; BASELINE.json's north_star asks for the batch of samples
 to be sharded across the GPUs of a node with an exchange "of the per-sample update contributions
 before the combined rank-B update is applied".  The contributions are low-rank, so ranks exchange
-per-sample RECORDS [x_b | S0 g_b | alpha, beta, c, rho] (2D+4 doubles each) -- never D x D
-matrices -- and every replica applies the identical combined update (fixed summation order =>
-replicas stay bit-identical).  Per update and rank: (B/P)(2D+4)*8 bytes sent; at D=1024, B=32,
-P=8 that is 64 KiB, i.e. latency-bound on xGMI.
+per-sample RECORDS [d_b | e_b | dmu_b] (3D doubles each: the two factor rows of the sample's
+rank-2 covariance increment and its mean increment) -- never D x D matrices -- and every replica
+applies the identical combined update (fixed summation order => replicas stay bit-identical).
+Per update and rank: (B/P) 3D * 8 bytes sent; at D=1024, B=32, P=8 that is 96 KiB, i.e.
+latency-bound on xGMI.
 """
 import numpy as np
 import torch

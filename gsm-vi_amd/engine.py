@@ -146,8 +146,8 @@ class HipEngine:
         return int(self.lib.gsmvi_gsm_record_len(int(D)))
 
     def gsm_local_stage(self, X, G, mu0, S0, out=None):
-        """Per-sample records [x | S0 g | alpha beta c rho] for this rank's samples (batch-sharded
-        path; gsmvi/gsm_numpy.py:7-11,15 for each local sample)."""
+        """Per-sample records [d | e | dmu] for this rank's samples (batch-sharded path;
+        gsmvi/gsm_numpy.py:7-18 for each local sample)."""
         Bl, D = X.shape
         self._ensure(D, Bl)
         rec = self.empty(Bl, self.record_len(D)) if out is None else out

@@ -78,8 +78,9 @@ int gsmvi_gsm_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
 /*
  * The same update in two stages, for the batch-sharded multi-GPU path (one process per GPU):
  *   local stage : for this rank's B_local samples, panel product + per-sample scalars; writes one
- *                 record per sample  rec[b] = [ x_b (D) | S0 g_b (D) | alpha, beta, c, rho ]  with row
- *                 stride ldrec >= gsmvi_gsm_record_len(D) = 2D+4.  Records of all ranks are
+ *                 record per sample  rec[b] = [ d_b (D) | e_b (D) | dmu_b (D) ]  (d_b = mu0 - x_b,
+ *                 dmu_b = mu_update of gsm_numpy.py:17, e_b = d_b + dmu_b) with row stride
+ *                 ldrec >= gsmvi_gsm_record_len(D) = 3D rounded up to even.  Records of all ranks are
  *                 all-gathered (RCCL) by the caller;
  *   apply       : every replica applies the combined rank-2B update from all B records.
  * gsmvi_gsm_update_f64 == local stage with B_local = B followed by apply.
@@ -100,6 +101,8 @@ int gsmvi_gsm_apply_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
  * scalars, ms[2] covariance update (-1 where a stage did not run).
  */
 int gsmvi_set_profiling(gsmvi_ctx* ctx, int on);
+/* Diagnostic builds only (tuning knob cov_dbg=16): read back in-kernel timeline stamps. */
+int gsmvi_debug_read_stamps(gsmvi_ctx* ctx, unsigned long long* out, int n);
 int gsmvi_get_profile(gsmvi_ctx* ctx, float* ms, int n);
 
 /*

@@ -55,13 +55,13 @@ class OracleEngine:
         return mu, S
 
     def record_len(self, D):
-        return 2 * D + 4
+        return 3 * D + (D & 1)
 
     def gsm_local_stage(self, X, G, mu0, S0, out=None):
         t = orc.gsm_per_sample_terms(X, G, mu0, S0)
-        beta = 1 / (1 + t["rho"])
-        c = (t["gSg"] - t["mv"]) / t["den"]
-        rec = np.concatenate([X, t["SG"], np.stack([1 - (1 + c) * beta, beta, c, t["rho"]], axis=1)], axis=1)
+        D = mu0.shape[0]
+        rec = np.zeros((X.shape[0], self.record_len(D)))
+        rec[:, :D], rec[:, D:2 * D], rec[:, 2 * D:3 * D] = t["dvec"], t["evec"], t["dmu"]
         if out is not None:
             out[...] = rec
             return out
@@ -70,10 +70,7 @@ class OracleEngine:
     def gsm_apply(self, rec, mu0, S0, out=None):
         D = mu0.shape[0]
         B = rec.shape[0]
-        X, SG, al, be, c = rec[:, :D], rec[:, D:2 * D], rec[:, 2 * D], rec[:, 2 * D + 1], rec[:, 2 * D + 2]
-        d = mu0[None, :] - X
-        e = al[:, None] * d + be[:, None] * SG
-        dmu = be[:, None] * ((SG - d) - c[:, None] * d)
+        d, e, dmu = rec[:, :D], rec[:, D:2 * D], rec[:, 2 * D:3 * D]
         mu = mu0 + dmu.mean(axis=0)
         S = S0 + (d.T @ d - e.T @ e) / B
         if out is not None:

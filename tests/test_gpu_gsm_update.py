@@ -156,10 +156,9 @@ def test_two_stage_equals_fused_and_profile(eng):
     assert np.array_equal(S_a.cpu().numpy(), S_b.cpu().numpy())
     t = orc.gsm_per_sample_terms(st["samples"], st["vs"], st["mu0"], st["S0"])
     r = rec.cpu().numpy()
-    assert np.array_equal(r[:, :320], st["samples"])
-    assert rel_err(r[:, 320:640], t["SG"]) < TOL
-    assert rel_err(r[:, 643], t["rho"]) < TOL
-    assert rel_err(r[:, 641], 1 / (1 + t["rho"])) < TOL
+    assert np.array_equal(r[:, :320], st["mu0"][None, :] - st["samples"])      # d_b = mu0 - x_b
+    assert rel_err(r[:, 320:640], t["evec"]) < TOL                               # e_b = mu_b - x_b
+    assert rel_err(r[:, 640:960], t["dmu"]) < TOL                                # per-sample mean increment
     eng.set_profiling(True)
     eng.gsm_update(X, G, mu0, S0)
     prof = eng.get_profile()
