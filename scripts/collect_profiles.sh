@@ -1,0 +1,34 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats and, in separate passes, the HBM
+# traffic counters for the bench workload.  Output: gpurun_out/prof_$1/ (copy summaries to profiles/).
+set -u
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="$ROOT/bench.py --steps 420 --warmup 42 --no-cpu-baseline"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS --no-graph > $OUT/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS --no-graph > $OUT/pmc_write.log 2>&1
+cd $ROOT
+python3 - "$OUT" <<'PY'
+import csv, glob, json, sys, collections
+out = sys.argv[1]
+res = {}
+st = glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True)
+if st:
+    rows = [r for r in csv.DictReader(open(st[0])) if r["Name"].lstrip("void ").startswith("k_")]
+    res["kernel_stats"] = {r["Name"].split("(")[0]: {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                                    "min_ns": int(r["MinNs"]), "max_ns": int(r["MaxNs"])} for r in rows}
+for name in ("FETCH_SIZE", "WRITE_SIZE"):
+    files = glob.glob(out + f"/pmc_{'fetch' if name=='FETCH_SIZE' else 'write'}/**/*counter_collection.csv", recursive=True)
+    acc = collections.defaultdict(list)
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == name:
+                acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    res[name] = {k: {"launches": len(v), "mean": sum(v) / len(v)} for k, v in acc.items() if "k_" in k}
+json.dump(res, open(out + "/summary.json", "w"), indent=1)
+print(json.dumps(res, indent=1)[:3000])
+PY

@@ -86,3 +86,14 @@ def test_bam_fit_example_config():
     mean_o, cov_o = borc.bam_fit(D, None, lambda x: orc.gaussian_score(x, m, P), 99,
                                  borc.Regularizers().custom(lambda i: 100 / (1 + i)), niter=100, batch_size=2)
     assert np.allclose(mean, mean_o, atol=1e-3) and np.allclose(cov, cov_o, atol=1e-3, rtol=1e-3)
+
+
+def test_config_c4_bam_d1024_b128():
+    """BASELINE configs[3] as a single-GPU parity case: BaM update, D=1024, B=128 (n = 129)."""
+    import gsmvi_amd
+    orc, borc = _o()
+    st = orc.make_update_state(1024, 128, seed=4)
+    for reg in (1.0, 100.0 / 3):
+        mu_o, S_o = borc.bam_lowrank_update_exact(st["samples"], st["vs"], st["mu0"], st["S0"], reg)
+        mu, S = gsmvi_amd.bam_lowrank_update(st["samples"], st["vs"], st["mu0"], st["S0"], reg)
+        assert rel_err(mu, mu_o) < 1e-6 and rel_err(S, 0.5 * (S_o + S_o.T)) < 1e-6, reg

@@ -229,3 +229,31 @@ def test_commit_and_revert(eng):
     flag.fill_(0)
     eng.commit(flag, mu_new, S_new, mu, S, nrev)
     assert torch.equal(mu, mu_new) and torch.equal(S, S_new) and eng.read_flag(nrev) == 1
+
+
+def test_config_c5_d4096_b64_ill_conditioned(eng):
+    """BASELINE configs[4] as a parity case: D=4096, B=64, target with cond(Sigma_t)=1e8, dense-covariance
+    update on one GPU against the batched oracle (fp64 GEMMs on the host, a few seconds)."""
+    import gsmvi_amd
+    orc = _oracle()
+    D, B = 4096, 64
+    rs = np.random.RandomState(5)
+    # ill-conditioned target: log-uniform spectrum in a random orthogonal basis (cond = 1e8)
+    Q, _ = np.linalg.qr(rs.standard_normal((D, D)))
+    w = np.logspace(-4, 4, D)
+    P = (Q / w) @ Q.T
+    P = 0.5 * (P + P.T)
+    m = rs.random_sample(D)
+    A = rs.standard_normal((D, D))
+    S0 = A @ A.T / D + 0.1 * np.eye(D)
+    S0 = 0.5 * (S0 + S0.T)
+    mu0 = rs.standard_normal(D)
+    X = mu0 + rs.standard_normal((B, D)) @ np.linalg.cholesky(S0).T
+    G = orc.gaussian_score(X, m, P)
+    mu_o, S_o = orc.gsm_update_batched(X, G, mu0, S0)
+    mu, S = gsmvi_amd.gsm_update(X, G, mu0, S0)
+    assert rel_err(mu, mu_o) < NORTH_STAR_TOL and rel_err(S, S_o) < NORTH_STAR_TOL
+    assert rel_err(mu, mu_o) < 1e-9 and rel_err(S, S_o) < 1e-9
+    assert np.array_equal(S, S.T)
+    Gd = eng.gaussian_score(eng.asarray(X), eng.asarray(m), eng.asarray(P))
+    assert rel_err(Gd.cpu().numpy(), G) < 1e-9
