@@ -9,8 +9,8 @@
 //   for k = 0 .. D/64-1:
 //     k_potrf_panel    : every workgroup factors the 64x64 diagonal block in LDS (redundantly,
 //                        it is 32 KB), workgroup 0 stores it; each workgroup then solves
-//                        R_kk^T X = S_k,cols for its 256 columns of the block row (one column per
-//                        thread, forward substitution in registers).
+//                        R_kk^T X = S_k,cols for its 64 columns of the block row (one column per
+//                        quad of lanes, forward substitution in registers).
 //     k_potrf_trailing : S_ij -= R_ki^T R_kj for the upper-triangle 64x64 tiles of the trailing
 //                        matrix, fp64 MFMA, K = 64.
 // The strictly lower triangle of R is zero on exit (the sampler's panel product reads all of R).
@@ -31,36 +31,110 @@ __global__ __launch_bounds__(256) void k_potrf_init(int D, const double* __restr
     if (blockIdx.x == 0 && threadIdx.x == 0) *info = 0;
 }
 
-// Factor the nb x nb (nb <= 64) upper block held in T[64][66] (LDS); rinv[p] = 1/R[p][p].  Returns
-// through sh_fail the 1-based local index of the first bad pivot (0 = ok).  256 threads = 16 x 16.
 #define TS 66
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)(u & 0xffffffffu), lane);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), lane);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// Factor the nb x nb (nb <= 64) upper block held in T[64][TS] (LDS, padded with identity beyond nb);
+// rinv[p] = 1/R[p][p].  *sh_fail = 1-based local index of the first bad pivot (0 = ok).
+// Blocked in four 16-column steps.  Per step: (1) wave 0 factors the 16x16 diagonal block entirely in
+// registers -- lane j holds column j, pivots and multipliers are broadcast with v_readlane, so the 16
+// sequential pivots cost no LDS round trip and no barrier; (2) the 16 x (rest) block row is solved
+// one column per thread; (3) the trailing block gets its rank-16 update.  Three barriers per step.
 __device__ __forceinline__ void chol64_lds(double* T, double* rinv, int nb, int* sh_fail) {
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) *sh_fail = 0;
     __syncthreads();
-    for (int p = 0; p < nb; ++p) {
-        if (tid == 0) {
-            const double piv = T[p * TS + p];
-            const bool ok = piv > 0.0 && piv < 1.7976931348623157e308;     // false for NaN, <= 0, inf
-            if (!ok && *sh_fail == 0) *sh_fail = p + 1;
-            const double r = ok ? sqrt(piv) : 1.0;
-            T[p * TS + p] = r;
-            rinv[p] = ok ? 1.0 / r : 0.0;
+    for (int kb = 0; kb < 4; ++kb) {
+        const int k0 = 16 * kb;
+        if (k0 >= nb) break;                                     // block-uniform
+        if (w == 0) {
+            const int j = lane & 15;
+            double col[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) col[i] = T[(k0 + i) * TS + k0 + j];
+            int fail = 0;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const double d = readlane_f64(col[p], p);
+                const bool ok = d > 0.0 && d < 1.7976931348623157e308;   // false for NaN, <= 0, inf
+                if (!ok && fail == 0) fail = k0 + p + 1;
+                // one rsqrt instead of sqrt + divide on the serial pivot chain: r = d * rsqrt(d) (<= 2 ulp)
+                const double ri = ok ? rsqrt(d) : 0.0;
+                const double r = ok ? d * ri : 1.0;
+                col[p] = (j == p) ? r : col[p] * ri;             // row p of the factor (entries j > p matter)
+                if (lane == p) rinv[k0 + p] = ri;
+#pragma unroll
+                for (int i = p + 1; i < 16; ++i) {
+                    const double tpi = readlane_f64(col[p], i);  // R[p][i]
+                    col[i] -= tpi * col[p];
+                }
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (i <= j) T[(k0 + i) * TS + k0 + j] = col[i];
+            }
+            if (lane == 0 && fail != 0 && k0 + 0 < nb && *sh_fail == 0 && fail <= nb) *sh_fail = fail;
         }
         __syncthreads();
-        const double ri = rinv[p];
-        if (tid > p && tid < nb) T[p * TS + tid] *= ri;
+        const int rest0 = k0 + 16;                               // first column to the right
+        // (2) block row: solve R_dd^T x = T[k0..k0+15][c] for every column c >= rest0
+        for (int cc = rest0 + tid; cc < 64; cc += 256) {
+            double x[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = T[(k0 + i) * TS + cc];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                x[p] *= rinv[k0 + p];
+#pragma unroll
+                for (int i = p + 1; i < 16; ++i) x[i] -= T[(k0 + p) * TS + k0 + i] * x[p];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) T[(k0 + i) * TS + cc] = x[i];
+        }
         __syncthreads();
-        for (int i = p + 1 + ty; i < nb; i += 16) {
-            const double tpi = T[p * TS + i];
-            for (int q = p + 1 + tx; q < nb; q += 16)
-                if (q >= i) T[i * TS + q] -= tpi * T[p * TS + q];
+        // (3) trailing update: T[i][q] -= sum_p T[k0+p][i] T[k0+p][q], rest0 <= i <= q < 64.
+        // 16 x 16 threads, each owns up to 3 x 3 elements (i = rest0+ty+16a, q = rest0+tx+16b); the
+        // operand values are read in one batch per p so the LDS latency is paid once, not per FMA.
+        {
+            const int ty = tid >> 4, tx = tid & 15;
+            double acc[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) acc[a][b] = 0.0;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                double ra[3], rb[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const int i = rest0 + ty + 16 * a, q = rest0 + tx + 16 * a;
+                    ra[a] = T[(k0 + p) * TS + (i < 64 ? i : 63)];
+                    rb[a] = T[(k0 + p) * TS + (q < 64 ? q : 63)];
+                }
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) acc[a][b] += ra[a] * rb[b];
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const int i = rest0 + ty + 16 * a, q = rest0 + tx + 16 * b;
+                    if (i < 64 && q < 64 && q >= i) T[i * TS + q] -= acc[a][b];
+                }
         }
         __syncthreads();
     }
 }
 
-// Block step k: diagonal factor + block-row solve.  grid.x = 1 + ceil(cols_right / 256).
+// Block step k: diagonal factor + block-row solve.  grid.x = 1 + ceil(cols_right / 64).
 // The factored diagonal block goes to diag_out (workspace), NOT into R: sibling workgroups of this
 // launch read the un-factored block from R with no ordering against workgroup 0.
 __global__ __launch_bounds__(256) void k_potrf_panel(int D, int k, double* __restrict__ R, int ldr,
@@ -83,26 +157,37 @@ __global__ __launch_bounds__(256) void k_potrf_panel(int D, int k, double* __res
         if (tid == 0 && sh_fail != 0 && *info == 0) *info = k0 + sh_fail;
         return;
     }
-    // Solve R_kk^T X = S_k,col, one column per thread, right-looking so that at pivot p only
-    // x[p..63] are live:  x[p] *= rinv[p];  x[t] -= R_kk[p][t] x[p]  (t > p).  Row p of the factor
-    // is the same LDS address for every lane (broadcast reads).  The scheduling fence per pivot
-    // stops the compiler from hoisting hundreds of LDS reads (which spilled to scratch).
-    const int col = k0 + NB + (blockIdx.x - 1) * 256 + tid;
+    // Solve R_kk^T X = S_k,cols for 64 columns per workgroup.  A column is shared by a QUAD of lanes:
+    // lane q of the quad owns rows q, q+4, ..., q+60 (16 registers), so the 2016 multiply-adds of a
+    // column are spread over four lanes and stay balanced as the pivot advances.  At pivot p the
+    // owning lane scales x[p] and broadcasts it inside the quad; every lane then updates its rows
+    // t > p:  x[t] -= R_kk[p][t] x[p].  (A workgroup with blockIdx.x > 0 exists only when columns remain
+    // to the right, i.e. nb == 64.)
+    const int colq = tid >> 2, q = tid & 3;
+    const int col = k0 + NB + (blockIdx.x - 1) * 64 + colq;
     const int colc = col < D ? col : D - 1;
-    // (a workgroup with blockIdx.x > 0 exists only when columns remain to the right, i.e. nb == 64)
-    double x[NB];
+    double x[16];
 #pragma unroll
-    for (int p = 0; p < NB; ++p) x[p] = R[(size_t)(k0 + p) * ldr + colc];
+    for (int r = 0; r < 16; ++r) x[r] = R[(size_t)(k0 + q + 4 * r) * ldr + colc];
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
-        x[p] *= rinv[p];
-        const double xp = x[p];
+        const int pr = p >> 2, pq = p & 3;                 // pivot row p lives in register pr of quad lane pq
+        const double mine = x[pr] * rinv[p];
+        if (q == pq) x[pr] = mine;
+        const double xp = __shfl(mine, (threadIdx.x & 60) | pq, 64);
 #pragma unroll
-        for (int t = p + 1; t < NB; ++t) x[t] -= T[p * TS + t] * xp;
+        for (int r = 0; r < 16; ++r) {
+            // rows q + 4r > p  (compile-time bound on r, lane-dependent part folded into a select)
+            if (4 * r + 3 > p) {
+                const int t = q + 4 * r;
+                const double rv = T[p * TS + t];
+                x[r] -= (t > p) ? rv * xp : 0.0;
+            }
+        }
     }
     if (col < D) {
 #pragma unroll
-        for (int p = 0; p < NB; ++p) R[(size_t)(k0 + p) * ldr + col] = x[p];
+        for (int r = 0; r < 16; ++r) R[(size_t)(k0 + q + 4 * r) * ldr + col] = x[r];
     }
 }
 
@@ -195,7 +280,7 @@ int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int
     const int nblk = (D + NB - 1) / NB;
     for (int k = 0; k < nblk; ++k) {
         const int right = D - (k + 1) * NB;
-        const int pg = 1 + (right > 0 ? (right + 255) / 256 : 0);
+        const int pg = 1 + (right > 0 ? (right + 63) / 64 : 0);
         hipLaunchKernelGGL(k_potrf_panel, dim3(pg), dim3(256), 0, st, D, k, R, ldr,
                            diag + (size_t)k * NB * NB, info_dev);
         if (right > 0) {
