@@ -115,9 +115,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("GSMVI_BENCH_FORCE_DIST"))   # the env knob exercises RCCL at N=1
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import gsmvi_amd
@@ -131,24 +135,24 @@ def main():
     n_inst = args.instances or max(2, int(np.ceil(320 * 2 ** 20 / per_inst)) + 1)
     inst, m, P = make_instances(eng, D, B, n_inst)
     lo, hi = shard_bounds(B, world, rank)
-    rec_all = eng.empty(B, eng.record_len(D)) if world > 1 else None
+    rec_all = eng.empty(B, eng.record_len(D)) if use_dist else None
 
     def step(k):
         it = inst[k % n_inst]
-        if world == 1:
+        if not use_dist:
             eng.gsm_update(it["X"], it["G"], it["mu0"], it["S0"], out=(it["mu"], it["S"]))
         else:
             sharded_gsm_update(eng, it["X"][lo:hi], it["G"][lo:hi], it["mu0"], it["S0"], rec_all=rec_all,
-                               out=(it["mu"], it["S"]))
+                               out=(it["mu"], it["S"]), force_collective=True)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     # ---- optional hipGraph of one trip round the ring (single GPU only) ------------------------
     graph, launch = None, "eager"
-    if world == 1 and not args.no_graph:
+    if not use_dist and not args.no_graph:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -181,7 +185,7 @@ def main():
     run(args.steps)
     barrier()
     el = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -190,7 +194,7 @@ def main():
 
     # ---- cache-resident rate: one instance, what a fit loop with a single covariance sees ------
     value_hot = None
-    if world == 1:
+    if not use_dist:
         it = inst[0]
         g1 = None
         try:
@@ -243,6 +247,22 @@ def main():
                 "avg_kernel_us": {k: v * 1e3 for k, v in avg_ms.items()},
                 "whole_update_algorithmic_GBs": alg_bytes_total * value / 1e9}
 
+    # ---- fit-iteration rate F: sample -> score -> update -> Cholesky PD check -> commit ----
+    fit_rate = None
+    if not use_dist:
+        try:
+            tgt = gsmvi_amd.GaussianTarget(m.cpu().numpy(), precision=P.cpu().numpy())
+            gsm = gsmvi_amd.GSM(D, tgt.lp, tgt.lp_g)
+            gsm.fit(1, niter=10, batch_size=B, verbose=False, rng="device")
+            torch.cuda.synchronize()
+            tf0 = time.perf_counter()
+            nf = 100
+            gsm.fit(1, niter=nf - 1, batch_size=B, verbose=False, rng="device")
+            torch.cuda.synchronize()
+            fit_rate = nf / (time.perf_counter() - tf0)
+        except Exception as e:      # reported, never hidden
+            fit_rate = f"failed: {type(e).__name__}: {e}"
+
     out = {"metric": "GSM updates/sec at D=%d,B=%d (dense-cov gsm_update, fp64)" % (D, B),
            "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -250,14 +270,20 @@ def main():
            "config": {"workload": f"BASELINE configs[2]: D={D} dense-cov Gaussian target, B={B}, one GSM update "
                                   f"per step", "D": D, "B": B, "instances": n_inst,
                       "ring_bytes": n_inst * per_inst, "launch": launch,
-                      "parallelism": "single GPU" if world == 1 else f"batch-sharded x{world} + RCCL all-gather"},
-           "value_cache_resident": value_hot, "roofline": roofline}
+                      "parallelism": "single GPU" if not use_dist else f"batch-sharded x{world} + RCCL all-gather"},
+           "value_cache_resident": value_hot, "fit_iterations_per_s": fit_rate, "roofline": roofline}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(D, B, args.cpu_seconds)
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        try:                                   # RCCL prints a banner through C stdio: get it out first
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)     # the ONE JSON line, last on stdout
 
 
 if __name__ == "__main__":

@@ -25,14 +25,14 @@ def shard_bounds(B, world, rank):
     return rank * per, (rank + 1) * per
 
 
-def sharded_gsm_update(eng, X_local, G_local, mu0, S0, group=None, rec_all=None, out=None):
+def sharded_gsm_update(eng, X_local, G_local, mu0, S0, group=None, rec_all=None, out=None, force_collective=False):
     """(mu, S) of gsm_update for the union of all ranks' samples (gsmvi/gsm_numpy.py:27-55).
 
     X_local, G_local: this rank's (B/P, D) samples and scores; mu0, S0 replicated.  ``rec_all``
     (B, 2D+4) may be passed to avoid allocating the gather buffer every call."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rec_local = eng.gsm_local_stage(X_local, G_local, mu0, S0)
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         rec = rec_local
     else:
         Bl, L = rec_local.shape
@@ -42,3 +42,23 @@ def sharded_gsm_update(eng, X_local, G_local, mu0, S0, group=None, rec_all=None,
         dist.all_gather_into_tensor(t_all, t_loc.contiguous(), group=group)
         rec = rec_all if isinstance(rec_all, torch.Tensor) else t_all.numpy()
     return eng.gsm_apply(rec, mu0, S0, out=out)
+
+
+def sharded_bam_update(eng, X_local, G_local, mu0, S0, reg, jitter=0.0, group=None, out=None, flag=None):
+    """(mu, S, flag) of the BaM update for the union of all ranks' samples (gsmvi/bam.py:72-114;
+    BASELINE config 4: B=128 sharded 16 per GPU).  BaM's statistics couple all samples (batch means
+    and the (B+1) x (B+1) matrix function), so ranks all-gather their (B/P, D) samples and scores
+    (2 (B/P) D doubles per rank: 256 KiB at D=1024, B=128, P=8 -- the part worth sharding is the
+    user's score evaluation) and every replica runs the identical update."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return eng.bam_update(X_local, G_local, mu0, S0, reg, jitter, out=out, flag=flag)
+    Bl, D = X_local.shape
+    packed = eng.empty(Bl, 2 * D)
+    packed[:, :D] = X_local
+    packed[:, D:] = G_local
+    allp = eng.empty(Bl * world, 2 * D)
+    dist.all_gather_into_tensor(_as_torch(allp), _as_torch(packed), group=group)
+    if not isinstance(allp, torch.Tensor):
+        allp = _as_torch(allp).numpy()
+    return eng.bam_update(allp[:, :D], allp[:, D:], mu0, S0, reg, jitter, out=out, flag=flag)

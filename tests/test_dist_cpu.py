@@ -34,6 +34,12 @@ def _worker(rank, world, port, q):
         gathered = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
         same = all(torch.equal(gathered[0], x) for x in gathered)
+        # BaM: all-gather of samples and scores, identical update on every replica
+        from oracle import bam_oracle as borc
+        from gsmvi_amd.dist import sharded_bam_update
+        mu_b, S_b, _ = sharded_bam_update(eng, st["samples"][lo:hi], st["vs"][lo:hi], st["mu0"], st["S0"], 2.0)
+        mu_bo, S_bo = borc.bam_lowrank_update_exact(st["samples"], st["vs"], st["mu0"], st["S0"], 2.0)
+        err = max(err, np.abs(mu_b - mu_bo).max(), np.abs(S_b - 0.5 * (S_bo + S_bo.T)).max())
         q.put((rank, float(err), bool(same)))
     finally:
         dist.destroy_process_group()
