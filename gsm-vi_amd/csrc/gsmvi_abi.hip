@@ -39,6 +39,9 @@ bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, cons
                               int dbg, unsigned long long* stamps);
 int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                      int* info_dev);
+int gsmvi_factor_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X,
+                      int ldx, const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double* mu,
+                      double* F, int ldf, int* info_dev);
 int gsmvi_bam_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X, int ldx,
                    const double* G, int ldg, const double* mu0, const double* S0, int lds0, double reg,
                    double jitter, double* mu, double* S, int lds, int* info_dev);
@@ -119,6 +122,9 @@ static void ws_sizes(int D, int B, size_t* n_pp, size_t* n_sg, size_t* n_small, 
     const int R = 2 * B + 8;                                   // BaM uses up to B+1 panel rows twice
     *rmax = R;
     *n_pp = (size_t)GSMVI_MAX_KC * R * D;
+    // potrf parks its factored 64x64 diagonal blocks here: one per block step of max(D, 2B+8)
+    const size_t potrf_scratch = (size_t)((((D > R ? D : R) + 63) / 64) * 64 * 64);
+    if (*n_pp < potrf_scratch) *n_pp = potrf_scratch;
     *n_sg = (size_t)R * D * 4;                                 // SG + BaM factor panels
     *n_small = (size_t)8 * R + (size_t)6 * R * R + 4096;
 }
@@ -207,6 +213,16 @@ int gsmvi_debug_read_stamps(gsmvi_ctx* ctx, unsigned long long* out, int n) {
     BAD_ARG(!ctx || !out || n < 1, "bad argument");
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, ctx->pp, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost));
+    return GSMVI_OK;
+}
+
+/* Diagnostic: copy n doubles from a workspace region (0 = panel slabs, 1 = finished panels, 2 = small
+ * matrices) starting at element `offset` to host memory.  Tests and debugging only. */
+int gsmvi_debug_read_workspace(gsmvi_ctx* ctx, int region, size_t offset, double* out, size_t n) {
+    BAD_ARG(!ctx || !out || region < 0 || region > 2, "bad argument");
+    const double* base = region == 0 ? ctx->pp : (region == 1 ? ctx->sg : ctx->small);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, base + offset, sizeof(double) * n, hipMemcpyDeviceToHost));
     return GSMVI_OK;
 }
 
@@ -400,6 +416,22 @@ int gsmvi_potrf_f64(gsmvi_ctx* ctx, void* stream, int D, const double* S, int ld
         return GSMVI_ERR_WORKSPACE;
     }
     return gsmvi_potrf_impl(ctx, reinterpret_cast<hipStream_t>(stream), D, S, lds, R, ldr, info_dev);
+}
+
+int gsmvi_gsm_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* Z, int ldz, const double* X,
+                                int ldx, const double* G, int ldg, const double* mu0, const double* F0, int ldf0,
+                                double* mu, double* F, int ldf, int* info_dev) {
+    int st = check_common(ctx, D, B, __func__);
+    if (st != GSMVI_OK) return st;
+    BAD_ARG(!Z || !X || !G || !mu0 || !F0 || !mu || !F || !info_dev, "NULL argument");
+    BAD_ARG(ldz < D || ldx < D || ldg < D || ldf0 < D || ldf < D, "leading dimension smaller than D");
+    BAD_ARG(F == F0 || mu == mu0, "outputs must not alias inputs");
+    if (2 * B > D || 2 * B > 128) {
+        gsmvi_set_error("%s: %s", __func__, "the factor form needs 2B <= D and 2B <= 128; use gsmvi_gsm_update_f64");
+        return GSMVI_ERR_UNSUPPORTED;
+    }
+    return gsmvi_factor_impl(ctx, reinterpret_cast<hipStream_t>(stream), D, B, Z, ldz, X, ldx, G, ldg, mu0, F0, ldf0,
+                             mu, F, ldf, info_dev);
 }
 
 int gsmvi_bam_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* X, int ldx, const double* G,

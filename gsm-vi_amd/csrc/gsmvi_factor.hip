@@ -1,0 +1,320 @@
+// Factor-form GSM update for gfx950 (fp64): the covariance is never formed or factorised.
+//
+// State: mu (D), Fm (D x D, any square factor with Sigma = Fm^T Fm); whitened draws Z (B x D), samples
+// X = mu + Z Fm, scores G = lp_g(X).  Algebra: SURVEY Appendix A.2 (derived from gsmvi/gsm_numpy.py:4-55,
+// verified against the imported reference; there is no reference implementation of this form), written
+// for row vectors:
+//   W = G Fm^T                               (transposed panel product, k_panel_t)
+//   ww = w.w, zw = z.w, rho = 0.5 sqrt(1+4(ww+zw^2)) - 0.5, den = 1+rho-zw
+//   u = ((w+z) + z (ww+zw)/den)/(1+rho)       dmu_b = u_b Fm,  mu' = mu + mean_b dmu_b
+//   Sigma' = Fm^T M Fm,  M = I + Rt^T J Rt,  Rt = [Z; U] (n = 2B rows),  J = (1/B) [[0, I], [I, -I]]
+// A factor of M:  Gamma = Rt Rt^T = Rg^T Rg (Cholesky),  I + Rg J Rg^T = T^T T (Cholesky; it exists iff
+// M is positive definite -- this IS the reference's accept/revert test, gsm_numpy.py:121-125,132-146,
+// on an n x n matrix instead of D x D),  C = I + Rt^T Rg^-1 (T - I) Rg^-T Rt,  C^T C = M, hence
+//   Fm' = C Fm = Fm + Rt^T Fs,   Fs = Rg^-1 (T - I) Rg^-T Tm,   Tm = Rt Fm = [X - mu; U Fm].
+// Per iteration Fm is read three times (W, U Fm, update) and written once; no O(D^3) work.
+// Requires n = 2B <= D (Gamma must be nonsingular) and n <= 128.
+#include "gsmvi_common.h"
+#include "gsmvi_ctx.h"
+#include "../../include/gsmvi_hip.h"
+
+// ---- transposed panel product partials: Pp[kc][r][j] = sum_{i in chunk(kc)} A[r][i] M[j][i] ----------
+// Workgroup = 16 rows j of M x CH-column chunks.  Both the A chunk (NR x CH) and the M tile (16 x CH)
+// are loaded with coalesced 16-B accesses along i and staged in LDS [row][CH+2]; MFMA A operand =
+// A rows, B operand = M rows (B[k][col j] = M[j][k]).  Guarded: any D, any alignment falls back to
+// 8-B loads.
+template <int MT, int CH>
+__global__ __launch_bounds__(256) void k_panel_t(int D, int nrows, const double* __restrict__ A, int lda,
+                                                 const double* __restrict__ M, int ldm, double* __restrict__ Pp,
+                                                 int chunks_per_wg) {
+    constexpr int LDG = CH + 2;
+    constexpr int NR = 16 * MT;
+    constexpr int KW = CH / 4;                    // columns of the chunk per wave
+    __shared__ double As[(NR + 16) * LDG];
+    double* Ms = As + NR * LDG;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+    const int j0 = blockIdx.x * 16, r0 = blockIdx.z * NR;
+    v4d acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int ch = 0; ch < chunks_per_wg; ++ch) {
+        const int cbase = (blockIdx.y * chunks_per_wg + ch) * CH;
+        if (cbase >= D) break;
+        if (ch > 0) __syncthreads();
+        for (int e = tid; e < (NR + 16) * CH; e += 256) {
+            const int row = e / CH, col = e % CH;
+            const int gc = cbase + col;
+            double v = 0.0;
+            if (gc < D) {
+                if (row < NR) {
+                    const int gr = r0 + row;
+                    if (gr < nrows) v = A[(size_t)gr * lda + gc];
+                } else {
+                    const int gj = j0 + row - NR;
+                    if (gj < D) v = M[(size_t)gj * ldm + gc];
+                }
+            }
+            As[row * LDG + col] = v;
+        }
+        __syncthreads();
+        const double* ap = As + c * LDG + KW * w + ks;
+        const double* bp = Ms + c * LDG + KW * w + ks;
+#pragma unroll 4
+        for (int s = 0; s < KW / 4; ++s) {
+            const double b = bp[4 * s];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = GSMVI_MFMA_F64(ap[mt * 16 * LDG + 4 * s], b, acc[mt]);
+        }
+    }
+    __syncthreads();
+    double* red = As;                              // [4][NR][17]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(w * NR + 16 * mt + ks + 4 * r) * 17 + c] = acc[mt][r];
+    __syncthreads();
+    for (int idx = tid; idx < NR * 16; idx += 256) {
+        const int rr = idx >> 4, cc = idx & 15;
+        const int row = r0 + rr, col = j0 + cc;
+        if (row < nrows && col < D) {
+            const double s = (red[(0 * NR + rr) * 17 + cc] + red[(1 * NR + rr) * 17 + cc]) +
+                             (red[(2 * NR + rr) * 17 + cc] + red[(3 * NR + rr) * 17 + cc]);
+            Pp[((size_t)blockIdx.y * nrows + row) * D + col] = s;
+        }
+    }
+}
+
+// ---- whitened per-sample stage: one workgroup per sample ----------------------------------------
+//   w_b = sum_kc Pp[kc][b];  scalars;  u_b;  writes Rt = [Z; U] (n x D), its transpose Rtt (D x nq) and the
+//   top half of Tm = Rt Fm, i.e. X - mu.
+__global__ __launch_bounds__(256) void k_gsmf_scalars(int D, int B, int KC, const double* __restrict__ Z, int ldz,
+                                                      const double* __restrict__ X, int ldx,
+                                                      const double* __restrict__ mu0,
+                                                      const double* __restrict__ Pp, double* __restrict__ Rt,
+                                                      double* __restrict__ Rtt, int nq, double* __restrict__ Tm) {
+    __shared__ double lds[8];
+    __shared__ double sh[2];
+    const int b = blockIdx.x;
+    double* urow = Rt + (size_t)(B + b) * D;
+    double p[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < D; i += 256) {
+        double wv = 0.0;
+        for (int kc = 0; kc < KC; ++kc) wv += Pp[((size_t)kc * B + b) * D + i];
+        const double z = Z[(size_t)b * ldz + i];
+        urow[i] = wv;                               // parked until the scalars are known
+        p[0] += wv * wv;
+        p[1] += z * wv;
+    }
+    block_sum<2>(p, lds);
+    if (threadIdx.x == 0) {
+        const double ww = p[0], zw = p[1];
+        const double rho = 0.5 * sqrt(1.0 + 4.0 * (ww + zw * zw)) - 0.5;
+        const double den = 1.0 + rho - zw;
+        sh[0] = 1.0 / (1.0 + rho);
+        sh[1] = (ww + zw) / den;
+    }
+    __syncthreads();
+    const double beta = sh[0], cz = sh[1];
+    for (int i = threadIdx.x; i < D; i += 256) {
+        const double z = Z[(size_t)b * ldz + i];
+        const double u = ((urow[i] + z) + z * cz) * beta;
+        Rt[(size_t)b * D + i] = z;
+        urow[i] = u;
+        Rtt[(size_t)i * nq + b] = z;
+        Rtt[(size_t)i * nq + B + b] = u;
+        Tm[(size_t)b * D + i] = X[(size_t)b * ldx + i] - mu0[i];
+    }
+}
+
+// ---- A' = I + Rg J Rg^T  (n x n),  J = (1/B) [[0, I], [I, -I]],  Rg upper triangular ------------------
+//   (Rg J)[i][k] = (1/B) * ( k <  B : Rg[i][B+k]
+//                            k >= B : Rg[i][k-B] - Rg[i][k] )
+__global__ __launch_bounds__(256) void k_gsmf_small_a(int n, int B, const double* __restrict__ Rg,
+                                                      const int* __restrict__ info_g, double* __restrict__ Ap) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * n) return;
+    const int i = idx / n, j = idx % n;
+    const double invB = 1.0 / (double)B;
+    double s = 0.0;
+    for (int k = 0; k < n; ++k) {
+        const double rj = (k < B) ? Rg[(size_t)i * n + B + k] : (Rg[(size_t)i * n + k - B] - Rg[(size_t)i * n + k]);
+        s += rj * Rg[(size_t)j * n + k];
+    }
+    double v = (i == j ? 1.0 : 0.0) + s * invB;
+    if (*info_g != 0) v = (i == j) ? -1.0 : 0.0;     // Gamma was singular: force the PD test to fail
+    Ap[idx] = v;
+}
+
+// ---- Fs = Rg^-1 (T - I) Rg^-T Tm  and the new mean, one column of D per thread --------------------------
+// 64 threads per block; the thread's n-vector lives in LDS ([k][64], conflict-free).  Rg, T are read with
+// wave-uniform indices (scalar loads, L2 hits).  bad = info_g | info_t is written for the update kernel.
+__global__ __launch_bounds__(64) void k_gsmf_colsolve(int D, int n, int B, const double* __restrict__ Rg,
+                                                      const double* __restrict__ T, const double* __restrict__ Tm,
+                                                      const double* __restrict__ mu0, double* __restrict__ Fs,
+                                                      double* __restrict__ mu, const int* __restrict__ info_g,
+                                                      const int* __restrict__ info_t, int* __restrict__ bad_out) {
+    extern __shared__ double v[];                  // [n][64]
+    const int t = threadIdx.x, j = blockIdx.x * 64 + t;
+    const int jc = j < D ? j : D - 1;
+    const int bad = (*info_g != 0) || (*info_t != 0);
+    if (blockIdx.x == 0 && t == 0) *bad_out = bad;
+    double dsum = 0.0;
+    for (int k = 0; k < n; ++k) {
+        const double x = Tm[(size_t)k * D + jc];
+        v[k * 64 + t] = x;
+        if (k >= B) dsum += x;                     // sum_b (U Fm)[b][j]
+    }
+    if (j < D) mu[j] = bad ? mu0[j] : mu0[j] + dsum / (double)B;
+    // v1 = Rg^-T t : forward substitution with the lower factor Rg^T
+    for (int r = 0; r < n; ++r) {
+        double a = v[r * 64 + t];
+        for (int k = 0; k < r; ++k) a -= Rg[(size_t)k * n + r] * v[k * 64 + t];
+        v[r * 64 + t] = a / Rg[(size_t)r * n + r];
+    }
+    // v2 = (T - I) v1 : upper-triangular mat-vec, in place from the top (row r needs entries >= r only)
+    for (int r = 0; r < n; ++r) {
+        double a = -v[r * 64 + t];
+        for (int k = r; k < n; ++k) a += T[(size_t)r * n + k] * v[k * 64 + t];
+        v[r * 64 + t] = a;
+    }
+    // v3 = Rg^-1 v2 : back substitution
+    for (int r = n - 1; r >= 0; --r) {
+        double a = v[r * 64 + t];
+        for (int k = r + 1; k < n; ++k) a -= Rg[(size_t)r * n + k] * v[k * 64 + t];
+        a /= Rg[(size_t)r * n + r];
+        v[r * 64 + t] = a;
+        if (j < D) Fs[(size_t)r * D + j] = a;
+    }
+}
+
+// ---- F = F0 + Rt^T Fs  (full, non-symmetric rank-n update; F = F0 when *bad) ---------------------------
+__global__ __launch_bounds__(256) void k_gsmf_update(int D, int KF, const double* __restrict__ Ft,
+                                                     const double* __restrict__ Fs, const double* __restrict__ F0,
+                                                     int ldf0, double* __restrict__ F, int ldf,
+                                                     const int* __restrict__ bad) {
+    constexpr int RS = 66;
+    __shared__ double FA[64 * RS];
+    __shared__ double FB[64 * RS];
+    const int ntiles = (D + 63) >> 6;
+    const int ti = blockIdx.x / ntiles, tj = blockIdx.x % ntiles;
+    const int I0 = ti * 64, J0 = tj * 64;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+    const int wr = w >> 1, wc = w & 1;
+    const int skip = *bad;
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int kb = 0; kb < KF && !skip; kb += 64) {
+        double va[16], vb[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int p = kb + (tid >> 6) + 4 * q, i = tid & 63;
+            const int pc = p < KF ? p : KF - 1;
+            const int gi = I0 + i, gj = J0 + i;
+            const double a = Ft[(size_t)pc * D + (gi < D ? gi : D - 1)];
+            const double b = Fs[(size_t)pc * D + (gj < D ? gj : D - 1)];
+            va[q] = (p < KF && gi < D) ? a : 0.0;
+            vb[q] = (p < KF && gj < D) ? b : 0.0;
+        }
+        if (kb > 0) __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int p = (tid >> 6) + 4 * q, i = tid & 63;
+            FA[i * RS + p] = va[q];
+            FB[i * RS + p] = vb[q];
+        }
+        __syncthreads();
+        const double* a0p = FA + (32 * wr + c) * RS + ks;
+        const double* a1p = a0p + 16 * RS;
+        const double* b0p = FB + (32 * wc + c) * RS + ks;
+        const double* b1p = b0p + 16 * RS;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const double a0 = a0p[4 * s], a1 = a1p[4 * s], b0 = b0p[4 * s], b1 = b1p[4 * s];
+            acc[0][0] = GSMVI_MFMA_F64(a0, b0, acc[0][0]);
+            acc[0][1] = GSMVI_MFMA_F64(a0, b1, acc[0][1]);
+            acc[1][0] = GSMVI_MFMA_F64(a1, b0, acc[1][0]);
+            acc[1][1] = GSMVI_MFMA_F64(a1, b1, acc[1][1]);
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = I0 + 32 * wr + 16 * rt + ks + 4 * r;
+                const int col = J0 + 32 * wc + 16 * ct + c;
+                if (row < D && col < D) F[(size_t)row * ldf + col] = F0[(size_t)row * ldf0 + col] + acc[rt][ct][r];
+            }
+}
+
+int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
+                     int* info_dev);
+
+static int chk(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        gsmvi_set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return GSMVI_ERR_HIP;
+    }
+    return GSMVI_OK;
+}
+
+int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
+                      const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double* mu, double* F,
+                      int ldf, int* info_dev) {
+    const int n = 2 * B, nq = n;                   // n is even
+    // workspace carve: ctx->sg holds 6*rmax*max_D doubles (rmax = 2B+8)
+    double* Rt = ctx->sg;                          // n x D   [Z; U]
+    double* Tm = Rt + (size_t)n * D;               // n x D   [X - mu; U Fm]
+    double* Fs = Tm + (size_t)n * D;               // n x D
+    double* Rtt = Fs + (size_t)n * D;              // D x n
+    double* Gam = ctx->small;                      // n x n
+    double* Rg = Gam + (size_t)n * n;
+    double* Ap = Rg + (size_t)n * n;
+    double* Tt = Ap + (size_t)n * n;
+    int* info_g = ctx->ints;
+    int* info_t = ctx->ints + 1;
+
+    // W = G Fm^T
+    const int MT = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+    const int CH = (MT == 4) ? 128 : 256;
+    const int strips = (D + 15) / 16, nchunks = (D + CH - 1) / CH, zb = (B + 16 * MT - 1) / (16 * MT);
+    int kc = (2 * ctx->num_cu + strips * zb - 1) / (strips * zb);
+    if (kc > nchunks) kc = nchunks;
+    if (kc > GSMVI_MAX_KC) kc = GSMVI_MAX_KC;
+    if (kc < 1) kc = 1;
+    const int cpw = (nchunks + kc - 1) / kc;
+    kc = (nchunks + cpw - 1) / cpw;
+    const dim3 grid(strips, kc, zb);
+    if (MT == 1) hipLaunchKernelGGL((k_panel_t<1, 256>), grid, dim3(256), 0, st, D, B, G, ldg, F0, ldf0, ctx->pp, cpw);
+    else if (MT == 2) hipLaunchKernelGGL((k_panel_t<2, 256>), grid, dim3(256), 0, st, D, B, G, ldg, F0, ldf0, ctx->pp, cpw);
+    else hipLaunchKernelGGL((k_panel_t<4, 128>), grid, dim3(256), 0, st, D, B, G, ldg, F0, ldf0, ctx->pp, cpw);
+    int rc = chk("k_panel_t");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gsmf_scalars, dim3(B), dim3(256), 0, st, D, B, kc, Z, ldz, X, ldx, mu0, ctx->pp, Rt, Rtt, nq,
+                       Tm);
+    if ((rc = chk("k_gsmf_scalars"))) return rc;
+    // bottom half of Tm: U Fm
+    int kc2 = 1;
+    if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, D, B, Rt + (size_t)B * D, D, nullptr, 1.0, F0, ldf0, ctx->pp,
+                                     &kc2)))
+        return rc;
+    if ((rc = gsmvi_panel_finish(st, D, B, kc2, ctx->pp, nullptr, Tm + (size_t)B * D, D))) return rc;
+    // Gamma = Rt Rt^T
+    if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, n, n, Rt, D, nullptr, 1.0, Rtt, nq, ctx->pp, &kc2))) return rc;
+    if ((rc = gsmvi_panel_finish(st, n, n, kc2, ctx->pp, nullptr, Gam, n))) return rc;
+    if ((rc = gsmvi_potrf_impl(ctx, st, n, Gam, n, Rg, n, info_g))) return rc;
+    hipLaunchKernelGGL(k_gsmf_small_a, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Rg, info_g, Ap);
+    if ((rc = chk("k_gsmf_small_a"))) return rc;
+    if ((rc = gsmvi_potrf_impl(ctx, st, n, Ap, n, Tt, n, info_t))) return rc;
+    hipLaunchKernelGGL(k_gsmf_colsolve, dim3((D + 63) / 64), dim3(64), sizeof(double) * n * 64, st, D, n, B, Rg, Tt, Tm,
+                       mu0, Fs, mu, info_g, info_t, info_dev);
+    if ((rc = chk("k_gsmf_colsolve"))) return rc;
+    const int nt = (D + 63) / 64;
+    hipLaunchKernelGGL(k_gsmf_update, dim3(nt * nt), dim3(256), 0, st, D, n, Rt, Fs, F0, ldf0, F, ldf, info_dev);
+    return chk("k_gsmf_update");
+}

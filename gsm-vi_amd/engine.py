@@ -173,6 +173,32 @@ class HipEngine:
             ps, lds))
         return mu, S
 
+    def gsm_factor_update(self, Z, X, G, mu0, F0, out=None, flag=None):
+        """Factor-form update: Sigma = F^T F, X = mu0 + Z F0.  Returns (mu, F, flag); flag != 0 means
+        the 2B x 2B positive-definite test failed and (mu, F) = (mu0, F0) (revert)."""
+        B, D = Z.shape
+        self._ensure(D, B)
+        mu, F = (self.empty(D), self.empty(D, D)) if out is None else out
+        flag = self.new_flag() if flag is None else flag
+        pz, ldz = self._mat(Z, "Z")
+        px, ldx = self._mat(X, "X")
+        pg, ldg = self._mat(G, "G")
+        pf0, ldf0 = self._mat(F0, "F0")
+        pf, ldf = self._mat(F, "F")
+        _lib.check("gsmvi_gsm_factor_update_f64", self.lib.gsmvi_gsm_factor_update_f64(
+            self._ctx, self._stream(), D, B, pz, ldz, px, ldx, pg, ldg, self._vec(mu0, "mu0"), pf0, ldf0,
+            self._vec(mu, "mu"), pf, ldf, C.c_void_p(flag.data_ptr())))
+        return mu, F, flag
+
+    def gram(self, F):
+        """cov = F^T F for the monitor / return value of the factor-form fit (one library GEMM per call;
+        not on the per-iteration path)."""
+        return (F.t() @ F).contiguous()
+
+    def count_flag(self, flag, counter):
+        """counter += (flag != 0), on the device, no host sync."""
+        counter.add_((flag != 0).to(counter.dtype))
+
     def set_profiling(self, on):
         self._ensure(max(self._max_D, 1), max(self._max_B, 1))
         _lib.check("gsmvi_set_profiling", self.lib.gsmvi_set_profiling(self._ctx, int(bool(on))))

@@ -60,7 +60,7 @@ class GSM:
     # ------------------------------------------------------------------------------
     def fit(self, key, mean=None, cov=None, batch_size=2, niter=5000, nprint=10, verbose=True,
             check_goodness=True, monitor=None, *, sampler="cholesky", rng="numpy", as_torch=False,
-            forced_samples=None):
+            forced_samples=None, method="dense"):
         """Fit N(mean, cov) to the target (gsmvi/gsm_numpy.py:77-129, gsmvi/gsm.py:79-133).
 
         Same arguments and return value as the reference.  Behaviour kept: ``niter + 1`` updates
@@ -78,7 +78,16 @@ class GSM:
                     the reference's legacy host sampler, bit-compatible sample stream (small D).
           rng     : "numpy" (host MT19937 z-stream, uploaded) or "device" (torch generator).
           forced_samples : (niter+1, B, D) teacher-forced samples replacing the sampler.
+          method  : "dense" (default) keeps Sigma and re-factorises it every iteration exactly like the
+                    reference (Cholesky = its _check_goodness).  "factor" keeps a square factor F with
+                    Sigma = F^T F instead (BASELINE config 5): samples are mean + z F, the
+                    update is a rank-2B correction of F and the positive-definite test is a Cholesky of
+                    a 2B x 2B matrix, so no O(D^3) work per iteration.  Same (mean, cov) up to round-off
+                    for the same samples; needs 2B <= min(D, 128) and the device sampler.
         """
+        if method == "factor":
+            return self._fit_factor(key, mean, cov, batch_size, niter, nprint, verbose, monitor, rng, as_torch)
+        assert method == "dense", "method must be 'dense' or 'factor'"
         eng = self._engine if self._engine is not None else get_engine()
         D, B = self.D, int(batch_size)
         mean_t = eng.zeros(D) if mean is None else eng.clone(mean).reshape(D)
@@ -142,6 +151,67 @@ class GSM:
             mc = [mean_t, cov_t] if mon_native else [eng.to_numpy(mean_t).copy(), eng.to_numpy(cov_t).copy()]
             monitor(i, mc, self.lp, key, nevals=nevals)
         self.n_reverts = eng.read_flag(n_rev)
+        if as_torch:
+            return mean_t, cov_t
+        return eng.to_numpy(mean_t), eng.to_numpy(cov_t)
+
+    # ------------------------------------------------------------------------------
+    def _fit_factor(self, key, mean, cov, batch_size, niter, nprint, verbose, monitor, rng, as_torch):
+        """Factor-form fit loop (see ``fit(method="factor")``): same driver logic as gsm_numpy.py:77-129,
+        state (mean, F) with cov = F^T F materialised only for the monitor and the return value."""
+        eng = self._engine if self._engine is not None else get_engine()
+        D, B = self.D, int(batch_size)
+        assert 2 * B <= min(D, 128), "method='factor' needs 2*batch_size <= min(D, 128)"
+        mean_t = eng.zeros(D) if mean is None else eng.clone(mean).reshape(D)
+        cov0 = eng.eye(D) if cov is None else eng.clone(cov).reshape(D, D)
+        flag, n_rev = eng.new_flag(), eng.new_flag()
+        F, _ = eng.potrf(cov0, flag=flag)                   # one factorisation for the whole fit
+        if eng.read_flag(flag) != 0:
+            raise ValueError("initial covariance is not positive definite")
+        rs = np.random.RandomState(key if not _is_torch(key) else int(key.flatten()[0]))
+        gen = None
+        if rng == "device":
+            gen = torch.Generator(device=eng.device)
+            gen.manual_seed(int(key) if not _is_torch(key) else int(key.flatten()[0]))
+        native = bool(getattr(self.lp_g, "device_native", False))
+        mon_native = bool(getattr(monitor, "device_native", False)) if monitor is not None else False
+        mean_new, F_new, Xbuf = eng.empty(D), eng.empty(D, D), eng.empty(B, D)
+
+        def state():
+            c = eng.gram(F)
+            return [mean_t, c] if mon_native else [eng.to_numpy(mean_t).copy(), eng.to_numpy(c).copy()]
+
+        nevals = 1
+        nprint = max(1, min(int(nprint), int(niter))) if niter > 0 else 1
+        every = max(1, niter // nprint) if niter > 0 else 1
+        reverts_seen = 0
+        i = 0
+        for i in range(niter + 1):
+            if verbose and i % every == 0:
+                print(f"Iteration {i} of {niter}")
+                r = eng.read_flag(n_rev)
+                if r > reverts_seen:
+                    print(f"Bad update for covariance matrix. Revert ({r - reverts_seen} since last print)")
+                    reverts_seen = r
+            if monitor is not None and i % monitor.checkpoint == 0:
+                monitor(i, state(), self.lp, key, nevals=nevals)
+                nevals = 0
+            Z = eng.normal(B, D, gen) if gen is not None else eng.normal_from_host(rs.standard_normal((B, D)))
+            X = eng.sample(Z, mean_t, F, out=Xbuf)
+            vs = self.lp_g(X) if native else eng.asarray(self.lp_g(eng.to_numpy(X)))
+            eng.gsm_factor_update(Z, X, vs, mean_t, F, out=(mean_new, F_new), flag=flag)
+            nevals += B
+            eng.count_flag(flag, n_rev)
+            mean_t, mean_new = mean_new, mean_t             # the kernel already returned the reverted state
+            F, F_new = F_new, F                             # when its PD test failed: accept = pointer swap
+        if verbose:
+            r = eng.read_flag(n_rev)
+            if r > reverts_seen:
+                print(f"Bad update for covariance matrix. Revert ({r - reverts_seen} since last print)")
+        if monitor is not None:
+            monitor(i, state(), self.lp, key, nevals=nevals)
+        self.n_reverts = eng.read_flag(n_rev)
+        cov_t = eng.gram(F)
         if as_torch:
             return mean_t, cov_t
         return eng.to_numpy(mean_t), eng.to_numpy(cov_t)

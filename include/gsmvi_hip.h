@@ -11,6 +11,7 @@
  *   examples/example_gsm_numpy.py:24-29  lp_g of the Gaussian target    ->  gsmvi_gaussian_score_f64
  *   gsmvi/gsm_numpy.py:116    np.random.multivariate_normal(mean,cov,B) ->  gsmvi_sample_f64 (+ gsmvi_potrf_f64)
  *   gsmvi/gsm_numpy.py:132-146 _check_goodness(cov)                     ->  gsmvi_potrf_f64 (info flag)
+ *   (no reference twin; gsm_numpy.py:4-55 in factor form)   ->  gsmvi_gsm_factor_update_f64
  *   gsmvi/bam.py:72-114       bam_lowrank_update(samples,vs,mu0,S0,reg) ->  gsmvi_bam_update_f64
  *   gsmvi/bam.py:31-69        bam_update(samples,vs,mu0,S0,reg)         ->  gsmvi_bam_update_f64 (same result, K6)
  *
@@ -95,6 +96,19 @@ int gsmvi_gsm_apply_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
                         const double* S0, int lds0, double* mu, double* S, int lds);
 
 /*
+ * Factor-form GSM update (BASELINE config 5): the state is a square factor Fm with
+ * Sigma = Fm^T Fm; Z (B x D) are the whitened draws behind the samples X = 1 mu0^T + Z F0, G = lp_g(X).
+ * Produces (mu, F) with F^T F equal to the covariance gsm_numpy.gsm_update would return for
+ * (X, G, mu0, F0^T F0) -- without forming or factorising any D x D covariance: the positive-definite
+ * test of gsm_numpy.py:121-125,132-146 becomes a Cholesky of a 2B x 2B matrix.  If that test fails,
+ * (mu, F) = (mu0, F0) and *info_dev = 1 (revert); else *info_dev = 0.  Needs 2B <= D and 2B <= 128.
+ */
+int gsmvi_gsm_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
+                                const double* Z, int ldz, const double* X, int ldx, const double* G, int ldg,
+                                const double* mu0, const double* F0, int ldf0,
+                                double* mu, double* F, int ldf, int* info_dev);
+
+/*
  * Profiling mode (used by bench.py for the roofline line): when on, the three kernels of the GSM
  * update are launched with dispatch-timestamp events; gsmvi_get_profile waits for the last call
  * and returns the kernel durations in milliseconds: ms[0] panel product, ms[1] per-sample
@@ -103,6 +117,9 @@ int gsmvi_gsm_apply_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
 int gsmvi_set_profiling(gsmvi_ctx* ctx, int on);
 /* Diagnostic builds only (tuning knob cov_dbg=16): read back in-kernel timeline stamps. */
 int gsmvi_debug_read_stamps(gsmvi_ctx* ctx, unsigned long long* out, int n);
+/* Diagnostic: read back a slice of the context workspace (region 0 panel slabs, 1 finished panels,
+ * 2 small matrices). */
+int gsmvi_debug_read_workspace(gsmvi_ctx* ctx, int region, size_t offset, double* out, size_t n);
 int gsmvi_get_profile(gsmvi_ctx* ctx, float* ms, int n);
 
 /*

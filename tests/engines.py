@@ -79,6 +79,25 @@ class OracleEngine:
             return out
         return mu, S
 
+    def gsm_factor_update(self, Z, X, G, mu0, F0, out=None, flag=None):
+        flag = Flag() if flag is None else flag
+        mu, Fo, ok = orc.gsm_factor_update(Z, G, mu0, F0.T)      # oracle convention: Sigma = F F^T
+        if ok and np.isfinite(Fo).all():
+            Fn, flag.v = Fo.T, 0
+        else:
+            mu, Fn, flag.v = mu0.copy(), F0.copy(), 1
+        if out is not None:
+            out[0][...] = mu
+            out[1][...] = Fn
+            return out[0], out[1], flag
+        return mu, Fn, flag
+
+    def gram(self, F):
+        return F.T @ F
+
+    def count_flag(self, flag, counter):
+        counter.v += int(flag.v != 0)
+
     def gaussian_score(self, X, m, P, out=None):
         return orc.gaussian_score(X, m, P)
 

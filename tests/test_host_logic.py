@@ -163,3 +163,25 @@ def test_regularizers_match_reference_semantics():
     assert [lin(0), lin(0), lin(5)] == [100.0, 50.0, 100.0 / 3]
     r.reset()
     assert r.custom(lambda i: 100 / (1 + i))(42) == 50.0
+
+
+def test_fit_factor_method_converges_and_keeps_cadence(golden):
+    """method='factor' (state = square factor, PD test on a 2B x 2B matrix): same driver logic -- converges
+    to the target like the dense method (K3) and keeps the monitor / nevals cadence (G5)."""
+    g = golden("g2_traj_D10.npz")
+    m, P = g["target_m"], g["target_P"]
+    calls = []
+
+    class Mon:
+        checkpoint = 100
+
+        def __call__(self, i, mc, lp, key, nevals=0):
+            assert mc[1].shape == (10, 10)
+            calls.append((i, nevals))
+
+    gsm = GSM(10, None, lambda x: orc.gaussian_score(x, m, P), engine=OracleEngine())
+    mean, cov = gsm.fit(99, niter=500, batch_size=2, verbose=False, monitor=Mon(), method="factor")
+    assert rel_err(mean, m) < 1e-9 and rel_err(cov, g["target_cov"]) < 1e-9 and gsm.n_reverts == 0
+    assert calls == [(0, 1), (100, 200), (200, 200), (300, 200), (400, 200), (500, 200), (500, 2)]
+    with pytest.raises(AssertionError):
+        GSM(4, None, lambda x: x, engine=OracleEngine()).fit(0, niter=1, batch_size=4, verbose=False, method="factor")
