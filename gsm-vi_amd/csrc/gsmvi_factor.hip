@@ -16,6 +16,7 @@
 // Requires n = 2B <= D (Gamma must be nonsingular) and n <= 128.
 #include "gsmvi_common.h"
 #include "gsmvi_ctx.h"
+#include "gsmvi_chol64.h"
 #include "../../include/gsmvi_hip.h"
 
 // ---- transposed panel product partials: Pp[kc][r][j] = sum_{i in chunk(kc)} A[r][i] M[j][i] ----------
@@ -251,6 +252,156 @@ __global__ __launch_bounds__(256) void k_gsmf_update(int D, int KF, const double
             }
 }
 
+// ---- everything small in ONE workgroup (n = 2B <= 64) ---------------------------------------------------
+//   Gamma -> Rg (Cholesky) -> A' = I + Rg J Rg^T -> T (Cholesky, the PD test) -> K = Rg^-1 (T - I) Rg^-T.
+// All matrices live in LDS ([64][TS], padded with the identity beyond n).  The three n-column triangular
+// operations that produce K are done one column per QUAD of lanes (lane q of the quad owns rows q, q+4, ..):
+// right-looking substitution with the pivot value broadcast inside the quad.  *bad = 1 if either Cholesky
+// fails (NaN, singular Gamma, or M not positive definite) and K is then irrelevant.
+__global__ __launch_bounds__(256) void k_gsmf_small(int n, int B, const double* __restrict__ Gam,
+                                                    double* __restrict__ Kmat, int* __restrict__ bad_out) {
+    __shared__ __attribute__((aligned(16))) double Rs[64 * TS];
+    __shared__ __attribute__((aligned(16))) double Ts[64 * TS];
+    __shared__ double rinv_g[64], rinv_t[64];
+    __shared__ int fail_g, fail_t;
+    const int tid = threadIdx.x;
+    {
+        double g[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {                 // unconditional (clamped) loads: one batch, one wait
+            const int e = tid + 256 * k, i = e >> 6, q = e & 63;
+            g[k] = Gam[(size_t)(i < n ? i : n - 1) * n + (q < n ? q : n - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int e = tid + 256 * k, i = e >> 6, q = e & 63;
+            Rs[i * TS + q] = (i < n && q < n && q >= i) ? g[k] : (i == q ? 1.0 : 0.0);
+        }
+    }
+    if (tid < 64) rinv_g[tid] = rinv_t[tid] = 1.0;
+    __syncthreads();
+    chol64_lds(Rs, rinv_g, n, &fail_g);                // Rs = Rg (upper); strictly-lower part is stale
+    for (int e = tid; e < 64 * 64; e += 256) {         // zero the strictly-lower part so Rs is a clean upper factor
+        const int i = e >> 6, q = e & 63;
+        if (q < i) Rs[i * TS + q] = 0.0;
+    }
+    __syncthreads();
+    // A' = I + (Rg J) Rg^T into Ts;  (Rg J)[i][k] = (1/B)(k < B ? Rg[i][B+k] : Rg[i][k-B] - Rg[i][k]).
+    // 16 x 16 threads, each a 4 x 4 register block (rows ty+16a, columns tx+16b): 8 LDS reads per 16 FMAs.
+    {
+        const double invB = 1.0 / (double)B;
+        const int ty = tid >> 4, tx = tid & 15;
+        double acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+        for (int k = 0; k < n; ++k) {
+            const int k1 = (k < B) ? B + k : k - B;    // (Rg J)[i][k] = Rg[i][k1] - (k >= B ? Rg[i][k] : 0)
+            const double sub = (k < B) ? 0.0 : 1.0;
+            double ra[4], rb[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int i = ty + 16 * a, j = tx + 16 * a;
+                ra[a] = Rs[i * TS + k1] - sub * Rs[i * TS + k];
+                rb[a] = Rs[j * TS + k];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] += ra[a] * rb[b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i = ty + 16 * a, j = tx + 16 * b;
+                const bool in = i < n && j < n;
+                Ts[i * TS + j] = (i == j ? 1.0 : 0.0) + (in ? acc[a][b] * invB : 0.0);
+            }
+    }
+    __syncthreads();
+    chol64_lds(Ts, rinv_t, n, &fail_t);                // Ts = T (upper): exists iff M is positive definite
+    const int bad = (fail_g != 0) || (fail_t != 0);
+    if (tid == 0) *bad_out = bad;
+    if (bad) return;                                   // block-uniform
+
+    // ---- K = Rg^-1 (T - I) Rg^-T, column c of the n x n result per quad ----
+    const int c = tid >> 2, q = tid & 3;               // 64 columns x 4 lanes
+    double x[16];
+    // phase 1: x = Rg^-T e_c  (forward substitution with the lower factor L = Rg^T, L[t][p] = Rg[p][t])
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = (q + 4 * r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int p = 0; p < 64; ++p) {
+        const int pr = p >> 2, pq = p & 3;
+        const double mine = x[pr] * rinv_g[p];
+        if (q == pq) x[pr] = mine;
+        const double xp = __shfl(mine, (threadIdx.x & 60) | pq, 64);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (4 * r + 3 > p) {
+                const int t = q + 4 * r;
+                const double rv = Rs[p * TS + t];
+                x[r] -= (t > p) ? rv * xp : 0.0;
+            }
+    }
+    // phase 2: y = (T - I) x  (upper-triangular mat-vec), column-oriented so it has the same shape as the
+    // substitutions: for p = 0..63 broadcast x[p] inside the quad, every lane adds T[t][p] x[p] to its rows t <= p.
+    {
+        double y[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = -x[r];
+#pragma unroll
+        for (int p = 0; p < 64; ++p) {
+            const int pr = p >> 2, pq = p & 3;
+            const double xp = __shfl(x[pr], (threadIdx.x & 60) | pq, 64);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (4 * r <= p) {
+                    const int t = q + 4 * r;
+                    const double tv = Ts[t * TS + p];
+                    y[r] += (t <= p) ? tv * xp : 0.0;
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = y[r];
+    }
+    // phase 3: z = Rg^-1 y  (back substitution, right-looking from the bottom): needs column p of Rg
+#pragma unroll
+    for (int p = 63; p >= 0; --p) {
+        const int pr = p >> 2, pq = p & 3;
+        const double mine = x[pr] * rinv_g[p];
+        if (q == pq) x[pr] = mine;
+        const double xp = __shfl(mine, (threadIdx.x & 60) | pq, 64);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (4 * r < p) {
+                const int t = q + 4 * r;
+                const double rv = Rs[t * TS + p];
+                x[r] -= (t < p) ? rv * xp : 0.0;
+            }
+    }
+    if (c < n) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = q + 4 * r;
+            if (t < n) Kmat[(size_t)t * n + c] = x[r];
+        }
+    }
+}
+
+// ---- new mean and the revert passthrough for the K-matrix path -----------------------------------------
+__global__ __launch_bounds__(256) void k_gsmf_mean(int D, int B, const double* __restrict__ Tm,
+                                                   const double* __restrict__ mu0, double* __restrict__ mu,
+                                                   const int* __restrict__ bad) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= D) return;
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) s += Tm[(size_t)(B + b) * D + j];
+    mu[j] = (*bad) ? mu0[j] : mu0[j] + s / (double)B;
+}
+
 int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                      int* info_dev);
 
@@ -307,13 +458,25 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
     // Gamma = Rt Rt^T
     if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, n, n, Rt, D, nullptr, 1.0, Rtt, nq, ctx->pp, &kc2))) return rc;
     if ((rc = gsmvi_panel_finish(st, n, n, kc2, ctx->pp, nullptr, Gam, n))) return rc;
-    if ((rc = gsmvi_potrf_impl(ctx, st, n, Gam, n, Rg, n, info_g))) return rc;
-    hipLaunchKernelGGL(k_gsmf_small_a, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Rg, info_g, Ap);
-    if ((rc = chk("k_gsmf_small_a"))) return rc;
-    if ((rc = gsmvi_potrf_impl(ctx, st, n, Ap, n, Tt, n, info_t))) return rc;
-    hipLaunchKernelGGL(k_gsmf_colsolve, dim3((D + 63) / 64), dim3(64), sizeof(double) * n * 64, st, D, n, B, Rg, Tt, Tm,
-                       mu0, Fs, mu, info_g, info_t, info_dev);
-    if ((rc = chk("k_gsmf_colsolve"))) return rc;
+    if (n <= 64) {
+        // everything small in one workgroup, then Fs = K Tm as one skinny GEMM (K = n)
+        double* Kmat = Rg;                         // reuse the n x n slot
+        hipLaunchKernelGGL(k_gsmf_small, dim3(1), dim3(256), 0, st, n, B, Gam, Kmat, info_dev);
+        if ((rc = chk("k_gsmf_small"))) return rc;
+        hipLaunchKernelGGL(k_gsmf_mean, dim3((D + 255) / 256), dim3(256), 0, st, D, B, Tm, mu0, mu, info_dev);
+        if ((rc = chk("k_gsmf_mean"))) return rc;
+        if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, ctx->pp, &kc2)))
+            return rc;
+        if ((rc = gsmvi_panel_finish(st, D, n, kc2, ctx->pp, nullptr, Fs, D))) return rc;
+    } else {
+        if ((rc = gsmvi_potrf_impl(ctx, st, n, Gam, n, Rg, n, info_g))) return rc;
+        hipLaunchKernelGGL(k_gsmf_small_a, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Rg, info_g, Ap);
+        if ((rc = chk("k_gsmf_small_a"))) return rc;
+        if ((rc = gsmvi_potrf_impl(ctx, st, n, Ap, n, Tt, n, info_t))) return rc;
+        hipLaunchKernelGGL(k_gsmf_colsolve, dim3((D + 63) / 64), dim3(64), sizeof(double) * n * 64, st, D, n, B, Rg, Tt,
+                           Tm, mu0, Fs, mu, info_g, info_t, info_dev);
+        if ((rc = chk("k_gsmf_colsolve"))) return rc;
+    }
     const int nt = (D + 63) / 64;
     hipLaunchKernelGGL(k_gsmf_update, dim3(nt * nt), dim3(256), 0, st, D, n, Rt, Fs, F0, ldf0, F, ldf, info_dev);
     return chk("k_gsmf_update");

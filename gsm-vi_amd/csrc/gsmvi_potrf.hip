@@ -31,108 +31,7 @@ __global__ __launch_bounds__(256) void k_potrf_init(int D, const double* __restr
     if (blockIdx.x == 0 && threadIdx.x == 0) *info = 0;
 }
 
-#define TS 66
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-    const unsigned long long u = __double_as_longlong(v);
-    const unsigned lo = __builtin_amdgcn_readlane((unsigned)(u & 0xffffffffu), lane);
-    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), lane);
-    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-
-// Factor the nb x nb (nb <= 64) upper block held in T[64][TS] (LDS, padded with identity beyond nb);
-// rinv[p] = 1/R[p][p].  *sh_fail = 1-based local index of the first bad pivot (0 = ok).
-// Blocked in four 16-column steps.  Per step: (1) wave 0 factors the 16x16 diagonal block entirely in
-// registers -- lane j holds column j, pivots and multipliers are broadcast with v_readlane, so the 16
-// sequential pivots cost no LDS round trip and no barrier; (2) the 16 x (rest) block row is solved
-// one column per thread; (3) the trailing block gets its rank-16 update.  Three barriers per step.
-__device__ __forceinline__ void chol64_lds(double* T, double* rinv, int nb, int* sh_fail) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) *sh_fail = 0;
-    __syncthreads();
-    for (int kb = 0; kb < 4; ++kb) {
-        const int k0 = 16 * kb;
-        if (k0 >= nb) break;                                     // block-uniform
-        if (w == 0) {
-            const int j = lane & 15;
-            double col[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) col[i] = T[(k0 + i) * TS + k0 + j];
-            int fail = 0;
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const double d = readlane_f64(col[p], p);
-                const bool ok = d > 0.0 && d < 1.7976931348623157e308;   // false for NaN, <= 0, inf
-                if (!ok && fail == 0) fail = k0 + p + 1;
-                // one rsqrt instead of sqrt + divide on the serial pivot chain: r = d * rsqrt(d) (<= 2 ulp)
-                const double ri = ok ? rsqrt(d) : 0.0;
-                const double r = ok ? d * ri : 1.0;
-                col[p] = (j == p) ? r : col[p] * ri;             // row p of the factor (entries j > p matter)
-                if (lane == p) rinv[k0 + p] = ri;
-#pragma unroll
-                for (int i = p + 1; i < 16; ++i) {
-                    const double tpi = readlane_f64(col[p], i);  // R[p][i]
-                    col[i] -= tpi * col[p];
-                }
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (i <= j) T[(k0 + i) * TS + k0 + j] = col[i];
-            }
-            if (lane == 0 && fail != 0 && k0 + 0 < nb && *sh_fail == 0 && fail <= nb) *sh_fail = fail;
-        }
-        __syncthreads();
-        const int rest0 = k0 + 16;                               // first column to the right
-        // (2) block row: solve R_dd^T x = T[k0..k0+15][c] for every column c >= rest0
-        for (int cc = rest0 + tid; cc < 64; cc += 256) {
-            double x[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) x[i] = T[(k0 + i) * TS + cc];
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                x[p] *= rinv[k0 + p];
-#pragma unroll
-                for (int i = p + 1; i < 16; ++i) x[i] -= T[(k0 + p) * TS + k0 + i] * x[p];
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) T[(k0 + i) * TS + cc] = x[i];
-        }
-        __syncthreads();
-        // (3) trailing update: T[i][q] -= sum_p T[k0+p][i] T[k0+p][q], rest0 <= i <= q < 64.
-        // 16 x 16 threads, each owns up to 3 x 3 elements (i = rest0+ty+16a, q = rest0+tx+16b); the
-        // operand values are read in one batch per p so the LDS latency is paid once, not per FMA.
-        {
-            const int ty = tid >> 4, tx = tid & 15;
-            double acc[3][3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) acc[a][b] = 0.0;
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                double ra[3], rb[3];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const int i = rest0 + ty + 16 * a, q = rest0 + tx + 16 * a;
-                    ra[a] = T[(k0 + p) * TS + (i < 64 ? i : 63)];
-                    rb[a] = T[(k0 + p) * TS + (q < 64 ? q : 63)];
-                }
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) acc[a][b] += ra[a] * rb[b];
-            }
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    const int i = rest0 + ty + 16 * a, q = rest0 + tx + 16 * b;
-                    if (i < 64 && q < 64 && q >= i) T[i * TS + q] -= acc[a][b];
-                }
-        }
-        __syncthreads();
-    }
-}
+#include "gsmvi_chol64.h"
 
 // Block step k: diagonal factor + block-row solve.  grid.x = 1 + ceil(cols_right / 64).
 // The factored diagonal block goes to diag_out (workspace), NOT into R: sibling workgroups of this
