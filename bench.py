@@ -250,18 +250,20 @@ def main():
     # ---- fit-iteration rate F: sample -> score -> update -> Cholesky PD check -> commit ----
     fit_rate = None
     if not use_dist:
-        try:
-            tgt = gsmvi_amd.GaussianTarget(m.cpu().numpy(), precision=P.cpu().numpy())
-            gsm = gsmvi_amd.GSM(D, tgt.lp, tgt.lp_g)
-            gsm.fit(1, niter=10, batch_size=B, verbose=False, rng="device")
-            torch.cuda.synchronize()
-            tf0 = time.perf_counter()
-            nf = 100
-            gsm.fit(1, niter=nf - 1, batch_size=B, verbose=False, rng="device")
-            torch.cuda.synchronize()
-            fit_rate = nf / (time.perf_counter() - tf0)
-        except Exception as e:      # reported, never hidden
-            fit_rate = f"failed: {type(e).__name__}: {e}"
+        fit_rate = {}
+        tgt = gsmvi_amd.GaussianTarget(m.cpu().numpy(), precision=P.cpu().numpy())
+        for method in ("dense", "factor"):
+            try:
+                gsm = gsmvi_amd.GSM(D, tgt.lp, tgt.lp_g)
+                gsm.fit(1, niter=10, batch_size=B, verbose=False, rng="device", method=method)
+                torch.cuda.synchronize()
+                tf0 = time.perf_counter()
+                nf = 150
+                gsm.fit(1, niter=nf - 1, batch_size=B, verbose=False, rng="device", method=method)
+                torch.cuda.synchronize()
+                fit_rate[method] = nf / (time.perf_counter() - tf0)
+            except Exception as e:      # reported, never hidden
+                fit_rate[method] = f"failed: {type(e).__name__}: {e}"
 
     out = {"metric": "GSM updates/sec at D=%d,B=%d (dense-cov gsm_update, fp64)" % (D, B),
            "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
