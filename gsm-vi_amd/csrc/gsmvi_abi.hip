@@ -426,7 +426,7 @@ int gsmvi_gsm_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, cons
     BAD_ARG(!Z || !X || !G || !mu0 || !F0 || !mu || !F || !info_dev, "NULL argument");
     BAD_ARG(ldz < D || ldx < D || ldg < D || ldf0 < D || ldf < D, "leading dimension smaller than D");
     BAD_ARG(F == F0 || mu == mu0, "outputs must not alias inputs");
-    if (2 * B > D || 2 * B > 128) {
+    if (2 * B > D || 2 * B > 128 || D > 16384) {
         gsmvi_set_error("%s: %s", __func__, "the factor form needs 2B <= D and 2B <= 128; use gsmvi_gsm_update_f64");
         return GSMVI_ERR_UNSUPPORTED;
     }

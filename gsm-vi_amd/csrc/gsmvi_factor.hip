@@ -85,45 +85,69 @@ __global__ __launch_bounds__(256) void k_panel_t(int D, int nrows, const double*
     }
 }
 
-// ---- whitened per-sample stage: one workgroup per sample ----------------------------------------
+// ---- whitened per-sample stage: one 1024-thread workgroup per sample (D <= 16384) -----------------
 //   w_b = sum_kc Pp[kc][b];  scalars;  u_b;  writes Rt = [Z; U] (n x D), its transpose Rtt (D x nq) and the
 //   top half of Tm = Rt Fm, i.e. X - mu.
-__global__ __launch_bounds__(256) void k_gsmf_scalars(int D, int B, int KC, const double* __restrict__ Z, int ldz,
-                                                      const double* __restrict__ X, int ldx,
-                                                      const double* __restrict__ mu0,
-                                                      const double* __restrict__ Pp, double* __restrict__ Rt,
-                                                      double* __restrict__ Rtt, int nq, double* __restrict__ Tm) {
-    __shared__ double lds[8];
-    __shared__ double sh[2];
-    const int b = blockIdx.x;
-    double* urow = Rt + (size_t)(B + b) * D;
-    double p[2] = {0.0, 0.0};
-    for (int i = threadIdx.x; i < D; i += 256) {
-        double wv = 0.0;
-        for (int kc = 0; kc < KC; ++kc) wv += Pp[((size_t)kc * B + b) * D + i];
-        const double z = Z[(size_t)b * ldz + i];
-        urow[i] = wv;                               // parked until the scalars are known
-        p[0] += wv * wv;
-        p[1] += z * wv;
+template <int EPT>
+__global__ __launch_bounds__(1024) void k_gsmf_scalars(int D, int B, int KC, const double* __restrict__ Z, int ldz,
+                                                       const double* __restrict__ X, int ldx,
+                                                       const double* __restrict__ mu0,
+                                                       const double* __restrict__ Pp, double* __restrict__ Rt,
+                                                       double* __restrict__ Rtt, int nq, double* __restrict__ Tm) {
+    __shared__ double lds[34];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double wv[EPT], zv[EPT], xv[EPT], mv[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {                 // all loads of the row in one batch
+        const int i = tid + 1024 * e;
+        const int ic = i < D ? i : D - 1;
+        double t = 0.0;
+        for (int kc = 0; kc < KC; ++kc) t += Pp[((size_t)kc * B + b) * D + ic];
+        wv[e] = t;
+        zv[e] = Z[(size_t)b * ldz + ic];
+        xv[e] = X[(size_t)b * ldx + ic];
+        mv[e] = mu0[ic];
     }
-    block_sum<2>(p, lds);
-    if (threadIdx.x == 0) {
-        const double ww = p[0], zw = p[1];
-        const double rho = 0.5 * sqrt(1.0 + 4.0 * (ww + zw * zw)) - 0.5;
-        const double den = 1.0 + rho - zw;
-        sh[0] = 1.0 / (1.0 + rho);
-        sh[1] = (ww + zw) / den;
+    double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+        if (tid + 1024 * e < D) {
+            p0 += wv[e] * wv[e];
+            p1 += zv[e] * wv[e];
+        }
+    p0 = wave_sum(p0);
+    p1 = wave_sum(p1);
+    if ((tid & 63) == 0) {
+        lds[2 * (tid >> 6)] = p0;
+        lds[2 * (tid >> 6) + 1] = p1;
     }
     __syncthreads();
-    const double beta = sh[0], cz = sh[1];
-    for (int i = threadIdx.x; i < D; i += 256) {
-        const double z = Z[(size_t)b * ldz + i];
-        const double u = ((urow[i] + z) + z * cz) * beta;
-        Rt[(size_t)b * D + i] = z;
-        urow[i] = u;
-        Rtt[(size_t)i * nq + b] = z;
-        Rtt[(size_t)i * nq + B + b] = u;
-        Tm[(size_t)b * D + i] = X[(size_t)b * ldx + i] - mu0[i];
+    if (tid == 0) {
+        double ww = 0.0, zw = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            ww += lds[2 * k];
+            zw += lds[2 * k + 1];
+        }
+        const double rho = 0.5 * sqrt(1.0 + 4.0 * (ww + zw * zw)) - 0.5;
+        const double den = 1.0 + rho - zw;
+        lds[32] = 1.0 / (1.0 + rho);
+        lds[33] = (ww + zw) / den;
+    }
+    __syncthreads();
+    const double beta = lds[32], cz = lds[33];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + 1024 * e;
+        if (i < D) {
+            const double z = zv[e];
+            const double u = ((wv[e] + z) + z * cz) * beta;
+            Rt[(size_t)b * D + i] = z;
+            Rt[(size_t)(B + b) * D + i] = u;
+            Rtt[(size_t)i * nq + b] = z;
+            Rtt[(size_t)i * nq + B + b] = u;
+            Tm[(size_t)b * D + i] = xv[e] - mv[e];
+        }
     }
 }
 
@@ -397,9 +421,19 @@ __global__ __launch_bounds__(256) void k_gsmf_mean(int D, int B, const double* _
                                                    const int* __restrict__ bad) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= D) return;
-    double s = 0.0;
-    for (int b = 0; b < B; ++b) s += Tm[(size_t)(B + b) * D + j];
-    mu[j] = (*bad) ? mu0[j] : mu0[j] + s / (double)B;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = 0;
+    for (; b + 8 <= B; b += 8) {                   // eight independent loads in flight per trip
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = Tm[(size_t)(B + b + k) * D + j];
+        s0 += v[0] + v[4];
+        s1 += v[1] + v[5];
+        s2 += v[2] + v[6];
+        s3 += v[3] + v[7];
+    }
+    for (; b < B; ++b) s0 += Tm[(size_t)(B + b) * D + j];
+    mu[j] = (*bad) ? mu0[j] : mu0[j] + ((s0 + s1) + (s2 + s3)) / (double)B;
 }
 
 int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
@@ -446,8 +480,12 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
     else hipLaunchKernelGGL((k_panel_t<4, 128>), grid, dim3(256), 0, st, D, B, G, ldg, F0, ldf0, ctx->pp, cpw);
     int rc = chk("k_panel_t");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gsmf_scalars, dim3(B), dim3(256), 0, st, D, B, kc, Z, ldz, X, ldx, mu0, ctx->pp, Rt, Rtt, nq,
-                       Tm);
+    {
+        const int ept = (D + 1023) / 1024;
+#define GS(E) hipLaunchKernelGGL(k_gsmf_scalars<E>, dim3(B), dim3(1024), 0, st, D, B, kc, Z, ldz, X, ldx, mu0, ctx->pp, Rt, Rtt, nq, Tm)
+        if (ept <= 1) GS(1); else if (ept <= 2) GS(2); else if (ept <= 4) GS(4); else if (ept <= 8) GS(8); else GS(16);
+#undef GS
+    }
     if ((rc = chk("k_gsmf_scalars"))) return rc;
     // bottom half of Tm: U Fm
     int kc2 = 1;
