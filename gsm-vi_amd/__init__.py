@@ -4,6 +4,7 @@ Mirrors the reference's public surface for the hot path (reference file:line):
     GSM, gsm_update                              gsmvi/gsm.py:31-133, gsmvi/gsm_numpy.py:27-129
     BaM, bam_update, bam_lowrank_update,
     Regularizers                                 gsmvi/bam.py:31-274
+    KLMonitor (diagnostics callback, host side)  gsmvi/monitors.py:43-125
 All numerics run in hand-written HIP kernels (libgsmvi_hip.so, C ABI in include/gsmvi_hip.h)
 called through ctypes; torch is used for device memory, streams and torch.distributed only.
 There is no CPU fallback: without the library or a GPU every compute entry point raises.
@@ -13,5 +14,6 @@ from .engine import HipEngine, get_engine                            # noqa: F40
 from .gsm import GSM, gsm_update                                     # noqa: F401
 from .bam import BaM, bam_update, bam_lowrank_update, Regularizers   # noqa: F401
 from .targets import GaussianTarget, device_score, score_from_logp   # noqa: F401
+from .monitors import KLMonitor                                      # noqa: F401
 
 __version__ = "0.1.0"
