@@ -33,7 +33,7 @@ void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, 
                              int chunks_per_wg);
 bool gsmvi_launch_gsm_scalars_fast(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, const double* X, int ldx,
                                    const double* G, int ldg, const double* mu0, const double* Pp, double* rec,
-                                   int ldrec);
+                                   int ldrec, int nt);
 bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, const double* rec, int ldrec,
                               const double* mu0, const double* S0, int lds0, double* S, int lds, double* mu_out,
                               int dbg, unsigned long long* stamps);
@@ -199,6 +199,7 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "panel_kc")) ctx->tune_panel_kc = value;
     else if (!strcmp(name, "update_sb")) ctx->tune_update_sb = value;
     else if (!strcmp(name, "no_fast")) ctx->tune_no_fast = value;
+    else if (!strcmp(name, "scalars_nt")) ctx->tune_scalars_nt = value;
     else if (!strcmp(name, "cov_dbg")) ctx->tune_cov_dbg = value;   // ablation bits, timing experiments only
     else {
         gsmvi_set_error("%s: unknown tuning knob %s", __func__, name);
@@ -310,8 +311,9 @@ static int gsm_local_stage(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, const d
     int kc = 1;
     int st = gsmvi_panel_product(ctx, hs, ctx->stage_events(0), D, B, G, ldg, nullptr, 1.0, S0, lds0, ctx->pp, &kc);
     if (st != GSMVI_OK) return st;
-    if (!ctx->tune_no_fast && D <= 4096 &&
-        gsmvi_launch_gsm_scalars_fast(hs, ctx->stage_events(1), D, B, kc, X, ldx, G, ldg, mu0, ctx->pp, rec, ldrec))
+    if (!ctx->tune_no_fast && D <= 8192 &&
+        gsmvi_launch_gsm_scalars_fast(hs, ctx->stage_events(1), D, B, kc, X, ldx, G, ldg, mu0, ctx->pp, rec, ldrec,
+                                      ctx->tune_scalars_nt))
         return check_launch("k_gsm_scalars_fast");
     gsmvi_launch_gsm_scalars(hs, ctx->stage_events(1), D, B, kc, X, ldx, G, ldg, mu0, ctx->pp, rec, ldrec);
     return check_launch("k_gsm_scalars");

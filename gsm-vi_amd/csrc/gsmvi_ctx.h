@@ -19,6 +19,7 @@ struct gsmvi_ctx {
     int tune_panel_kc = 0;
     int tune_update_sb = 0;
     int tune_cov_dbg = 0;      // ablation bits for k_gsm_cov_sym (wrong results; timing only)
+    int tune_scalars_nt = 0;   // threads per sample in k_gsm_scalars_fast (256/512/1024; 0 = default)
     int tune_no_fast = 0;      // 1 = force the guarded generic kernels (tests)
     int profiling = 0;         // when set, the update kernels are launched with dispatch-timestamp events
     hipEvent_t ev[8] = {};     // [2*stage], [2*stage+1]: panel, scalars, cov-update, spare

@@ -124,18 +124,19 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
 // EPT elements of the row; all loads first, one block reduction, then the record
 // rec[b] = [ d_b | e_b | dmu_b ] is written (see k_gsm_scalars for the algebra).
 // =====================================================================================
-template <int EPT, int KCT>
-__global__ __launch_bounds__(1024) void k_gsm_scalars_fast(int D, int B, int KC, const double* __restrict__ X,
-                                                           int ldx, const double* __restrict__ G, int ldg,
-                                                           const double* __restrict__ mu0,
-                                                           const double* __restrict__ Pp,
-                                                           double* __restrict__ rec, int ldrec) {
-    __shared__ double lds[34];
+template <int EPT, int KCT, int NT>
+__global__ __launch_bounds__(NT) void k_gsm_scalars_fast(int D, int B, int KC, const double* __restrict__ X,
+                                                         int ldx, const double* __restrict__ G, int ldg,
+                                                         const double* __restrict__ mu0,
+                                                         const double* __restrict__ Pp,
+                                                         double* __restrict__ rec, int ldrec) {
+    constexpr int NW = NT / 64;
+    __shared__ double lds[2 * NW];
     const int b = blockIdx.x, tid = threadIdx.x;
     double pp[EPT][KCT], xv[EPT], gv[EPT], mv0[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-        const int i = tid + 1024 * e;
+        const int i = tid + NT * e;
         const int ic = i < D ? i : D - 1;
 #pragma unroll
         for (int kc = 0; kc < KCT; ++kc)
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(1024) void k_gsm_scalars_fast(int D, int B, int KC,
     double p0 = 0.0, p1 = 0.0, sg[EPT], dd[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-        const int i = tid + 1024 * e;
+        const int i = tid + NT * e;
         double t = 0.0;
 #pragma unroll
         for (int kc = 0; kc < KCT; ++kc) t += (kc < KC) ? pp[e][kc] : 0.0;
@@ -166,24 +167,21 @@ __global__ __launch_bounds__(1024) void k_gsm_scalars_fast(int D, int B, int KC,
         lds[2 * w + 1] = p1;
     }
     __syncthreads();
-    if (tid == 0) {
-        double gSg = 0.0, mv = 0.0;
+    // every thread finishes the reduction and the scalar algebra itself (same operations, same order):
+    // cheaper than a second barrier around a one-thread section
+    double gSg = 0.0, mv = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            gSg += lds[2 * k];
-            mv += lds[2 * k + 1];
-        }
-        const double rho = 0.5 * sqrt(1.0 + 4.0 * (gSg + mv * mv)) - 0.5;
-        const double den = 1.0 + rho + mv;
-        lds[32] = 1.0 / (1.0 + rho);
-        lds[33] = (gSg - mv) / den;
+    for (int k = 0; k < NW; ++k) {
+        gSg += lds[2 * k];
+        mv += lds[2 * k + 1];
     }
-    __syncthreads();
-    const double beta = lds[32], c = lds[33];
+    const double rho = 0.5 * sqrt(1.0 + 4.0 * (gSg + mv * mv)) - 0.5;
+    const double den = 1.0 + rho + mv;
+    const double beta = 1.0 / (1.0 + rho), c = (gSg - mv) / den;
     double* rb = rec + (size_t)b * ldrec;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-        const int i = tid + 1024 * e;
+        const int i = tid + NT * e;
         if (i < D) {
             const double dmu = beta * ((sg[e] - dd[e]) - c * dd[e]);
             rb[i] = dd[e];
@@ -378,20 +376,23 @@ void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, 
 #undef PF
 }
 
-// returns false when (D, KC) has no instantiation
+// returns false when (D, KC) has no instantiation.  nt = threads per sample-workgroup (tuning knob scalars_nt)
 bool gsmvi_launch_gsm_scalars_fast(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, const double* X, int ldx,
                                    const double* G, int ldg, const double* mu0, const double* Pp, double* rec,
-                                   int ldrec) {
-    const int ept = (D + 1023) / 1024;
-#define SF(E, K)                                                                                              \
-    GSMVI_LAUNCH((k_gsm_scalars_fast<E, K>), dim3(B), dim3(1024), 0, st, ev, D, B, KC, X, ldx, G, ldg, mu0, Pp, \
-                 rec, ldrec)
-    if (KC > 8 || ept > 4) return false;
+                                   int ldrec, int nt) {
+    if (nt != 256 && nt != 512 && nt != 1024) nt = 512;   // 512 measured best at D=1024 (fewer waves to reduce)
+    const int ept = (D + nt - 1) / nt;
+#define SF(E, K, N)                                                                                              \
+    GSMVI_LAUNCH((k_gsm_scalars_fast<E, K, N>), dim3(B), dim3(N), 0, st, ev, D, B, KC, X, ldx, G, ldg, mu0, Pp, rec, \
+                 ldrec)
+#define SFK(E, N) do { if (kct == 1) SF(E, 1, N); else if (kct == 2) SF(E, 2, N); else if (kct == 4) SF(E, 4, N); else SF(E, 8, N); } while (0)
+#define SFE(N) do { if (e == 1) SFK(1, N); else if (e == 2) SFK(2, N); else if (e == 4) SFK(4, N); else SFK(8, N); } while (0)
+    if (KC > 8 || ept > 8) return false;
     const int kct = KC <= 1 ? 1 : (KC <= 2 ? 2 : (KC <= 4 ? 4 : 8));
-    const int e = ept <= 1 ? 1 : (ept <= 2 ? 2 : 4);
-    if (e == 1) { if (kct == 1) SF(1, 1); else if (kct == 2) SF(1, 2); else if (kct == 4) SF(1, 4); else SF(1, 8); }
-    else if (e == 2) { if (kct == 1) SF(2, 1); else if (kct == 2) SF(2, 2); else if (kct == 4) SF(2, 4); else SF(2, 8); }
-    else { if (kct == 1) SF(4, 1); else if (kct == 2) SF(4, 2); else if (kct == 4) SF(4, 4); else SF(4, 8); }
+    const int e = ept <= 1 ? 1 : (ept <= 2 ? 2 : (ept <= 4 ? 4 : 8));
+    if (nt == 256) SFE(256); else if (nt == 512) SFE(512); else SFE(1024);
+#undef SFE
+#undef SFK
 #undef SF
     return true;
 }

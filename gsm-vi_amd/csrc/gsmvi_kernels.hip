@@ -110,14 +110,20 @@ __global__ __launch_bounds__(256) void k_panel_partial(int D, int ncols, int nro
 }
 
 // Out[r][i] = addvec[i] + sum_kc Pp[kc][r][i]      (D here = number of columns of the panel)
+// The (at most GSMVI_MAX_KC = 8) slab loads are issued as one batch with clamped indices.
 __global__ __launch_bounds__(256) void k_panel_finish(int D, int nrows, int KC, const double* __restrict__ Pp,
                                                       const double* __restrict__ addvec,
                                                       double* __restrict__ Out, int ldo) {
     const int i = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
     if (i >= D) return;
+    double v[8];
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) v[kc] = Pp[((size_t)(kc < KC ? kc : KC - 1) * nrows + r) * D + i];
+    const double a = addvec ? addvec[i] : 0.0;
     double s = 0.0;
-    for (int kc = 0; kc < KC; ++kc) s += Pp[((size_t)kc * nrows + r) * D + i];
-    Out[(size_t)r * ldo + i] = s + (addvec ? addvec[i] : 0.0);
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) s += (kc < KC) ? v[kc] : 0.0;
+    Out[(size_t)r * ldo + i] = s + a;
 }
 
 // =====================================================================================
