@@ -150,9 +150,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- optional hipGraph of one trip round the ring (single GPU only) ------------------------
+    # ---- optional hipGraph of one trip round the ring (with RCCL: the all-gather is captured too) ----
     graph, launch = None, "eager"
-    if not use_dist and not args.no_graph:
+    if not args.no_graph:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -169,6 +169,11 @@ def main():
         except Exception as e:           # capture unsupported -> stay on eager launches of the same kernels
             graph, launch = None, f"eager (graph capture failed: {type(e).__name__})"
             torch.cuda.synchronize()
+        if use_dist:                     # every rank must take the same path
+            ok = torch.tensor([1 if graph is not None else 0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                graph, launch = None, "eager (graph capture failed on some rank)"
 
     def run(nsteps):
         done = 0
