@@ -1,6 +1,9 @@
 // In-LDS Cholesky of a 64 x 64 block (shared by gsmvi_potrf.hip and gsmvi_factor.hip).
 #pragma once
 #include "gsmvi_common.h"
+#ifndef CHOL_STAMP
+#define CHOL_STAMP(k) ((void)0)     // scripts/chol64bench.hip defines it to time the phases
+#endif
 
 #define TS 66
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
@@ -23,6 +26,7 @@ __device__ __forceinline__ void chol64_lds(double* T, double* rinv, int nb, int*
     for (int kb = 0; kb < 4; ++kb) {
         const int k0 = 16 * kb;
         if (k0 >= nb) break;                                     // block-uniform
+        CHOL_STAMP(1 + 4 * kb);
         if (w == 0) {
             const int j = lane & 15;
             double col[16];
@@ -34,11 +38,12 @@ __device__ __forceinline__ void chol64_lds(double* T, double* rinv, int nb, int*
                 const double d = readlane_f64(col[p], p);
                 const bool ok = d > 0.0 && d < 1.7976931348623157e308;   // false for NaN, <= 0, inf
                 if (!ok && fail == 0) fail = k0 + p + 1;
-                // serial pivot chain: hardware v_rsq_f64 estimate + two Newton steps (full fp64 accuracy,
+                // serial pivot chain: hardware v_rsq_f64 estimate + Newton steps (full fp64 accuracy,
                 // ~10 dependent ops instead of the library rsqrt's ~30), then r = d * rsqrt(d)
-                double y = __builtin_amdgcn_rsq(ok ? d : 1.0);
-                y = y * (1.5 - 0.5 * (ok ? d : 1.0) * y * y);
-                y = y * (1.5 - 0.5 * (ok ? d : 1.0) * y * y);
+                const double dd = ok ? d : 1.0;
+                double y = __builtin_amdgcn_rsq(dd);              // ~2^-26 relative error
+                y = y * (1.5 - 0.5 * dd * y * y);                 // Newton: error^2 -> fp64 precision
+                y = y * (1.5 - 0.5 * dd * y * y);                 // second step kept: v_rsq_f64 accuracy is not documented
                 const double ri = ok ? y : 0.0;
                 const double r = ok ? d * ri : 1.0;
                 col[p] = (j == p) ? r : col[p] * ri;             // row p of the factor (entries j > p matter)
@@ -57,6 +62,7 @@ __device__ __forceinline__ void chol64_lds(double* T, double* rinv, int nb, int*
             if (lane == 0 && fail != 0 && k0 + 0 < nb && *sh_fail == 0 && fail <= nb) *sh_fail = fail;
         }
         __syncthreads();
+        CHOL_STAMP(2 + 4 * kb);
         const int rest0 = k0 + 16;                               // first column to the right
         // (2) block row: solve R_dd^T x = T[k0..k0+15][c] for every column c >= rest0
         for (int cc = rest0 + tid; cc < 64; cc += 256) {
@@ -73,6 +79,8 @@ __device__ __forceinline__ void chol64_lds(double* T, double* rinv, int nb, int*
             for (int i = 0; i < 16; ++i) T[(k0 + i) * TS + cc] = x[i];
         }
         __syncthreads();
+        CHOL_STAMP(3 + 4 * kb);
+        if (rest0 >= 64) break;                                  // last block: no trailing matrix (block-uniform)
         // (3) trailing update: T[i][q] -= sum_p T[k0+p][i] T[k0+p][q], rest0 <= i <= q < 64.
         // 16 x 16 threads, each owns up to 3 x 3 elements (i = rest0+ty+16a, q = rest0+tx+16b); the
         // operand values are read in one batch per p so the LDS latency is paid once, not per FMA.
@@ -106,6 +114,7 @@ __device__ __forceinline__ void chol64_lds(double* T, double* rinv, int nb, int*
                 }
         }
         __syncthreads();
+        CHOL_STAMP(4 + 4 * kb);
     }
 }
 
