@@ -37,6 +37,7 @@ bool gsmvi_launch_gsm_scalars_fast(hipStream_t st, hipEvent_t* ev, int D, int B,
 bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, const double* rec, int ldrec,
                               const double* mu0, const double* S0, int lds0, double* S, int lds, double* mu_out,
                               int dbg, unsigned long long* stamps);
+int gsmvi_panel_fast_chunk(int MT);
 int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                      int* info_dev);
 int gsmvi_factor_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X,
@@ -254,9 +255,12 @@ int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D
                            const double* A, int lda, const double* shift, double alpha, const double* M, int ldm,
                            double* Pp, int* kc_out) {
     const int strips = (ncols + 15) / 16;
-    const int nchunks = (D + 255) / 256;
     const int MT = nrows <= 16 ? 1 : (nrows <= 32 ? 2 : 4);
     const int zblocks = (nrows + 16 * MT - 1) / (16 * MT);
+    const int a_vec_ok = (lda % 2 == 0) && aligned16(A);
+    const bool fast = !ctx->tune_no_fast && ncols == D && D % 64 == 0 && a_vec_ok && (!shift || aligned16(shift));
+    const int chw = fast ? gsmvi_panel_fast_chunk(MT) : 256;       // rows of M per chunk
+    const int nchunks = (D + chw - 1) / chw;
     int kc = ctx->tune_panel_kc > 0 ? ctx->tune_panel_kc
                                     : (2 * ctx->num_cu + strips * zblocks - 1) / (strips * zblocks);
     if (kc > nchunks) kc = nchunks;
@@ -264,9 +268,8 @@ int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D
     if (kc < 1) kc = 1;
     const int cpw = (nchunks + kc - 1) / kc;
     kc = (nchunks + cpw - 1) / cpw;
-    const int a_vec_ok = (lda % 2 == 0) && aligned16(A);
     *kc_out = kc;
-    if (!ctx->tune_no_fast && ncols == D && D % 64 == 0 && a_vec_ok && (!shift || aligned16(shift))) {
+    if (fast) {
         gsmvi_launch_panel_fast(st, ev, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm, Pp,
                                 cpw);
         return check_launch("k_panel_fast");

@@ -30,15 +30,19 @@
 // fragment-shaped loads of it touch 64 cache lines per instruction.
 // D % 64 == 0: a wave's 32 rows are all inside or all outside the matrix.
 // =====================================================================================
-template <int MT, bool HAS_SHIFT>
+template <int MT, bool HAS_SHIFT, int CHW>
 __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const double* __restrict__ A, int lda,
                                                     const double* __restrict__ shift, double alpha,
                                                     const double* __restrict__ M, int ldm,
                                                     double* __restrict__ Pp, int chunks_per_wg) {
-    constexpr int LDG = 258;                       // LDS row stride of the staged A chunk (doubles)
+    constexpr int LDG = CHW + 2;                   // LDS row stride of the staged A chunk (doubles)
     constexpr int NR = 16 * MT;
-    constexpr int UPT = 4 * MT;                    // 16-B staging units per thread: NR*128 / 512
-    __shared__ __attribute__((aligned(16))) double As[NR * LDG];   // also reused for the reduction
+    constexpr int RW = CHW / 8;                    // rows of the chunk per wave (8 waves)
+    constexpr int NST = RW / 4;                    // MFMA steps per wave and chunk
+    constexpr int U16 = CHW / 2;                   // 16-B units per staged row
+    constexpr int UPT = NR * U16 / 512;            // staging units per thread
+    constexpr int SMEM = (NR * LDG > 8 * NR * 17) ? NR * LDG : 8 * NR * 17;
+    __shared__ __attribute__((aligned(16))) double As[SMEM];       // staging buffer, reused for the reduction
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
     const int j = blockIdx.x * 16 + c;
     const int r0 = blockIdx.z * NR;
@@ -48,23 +52,23 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4d){0.0, 0.0, 0.0, 0.0};
 
     for (int ch = 0; ch < chunks_per_wg; ++ch) {
-        const int cbase = (blockIdx.y * chunks_per_wg + ch) * 256;          // block-uniform
+        const int cbase = (blockIdx.y * chunks_per_wg + ch) * CHW;          // block-uniform
         if (cbase >= D) break;
-        const int wbase = cbase + w * 32;                                   // wave-uniform: 8 waves x 32 rows
+        const int wbase = cbase + w * RW;                                   // wave-uniform: 8 waves x RW rows
         const bool wave_in = wbase < D;
         // ---- every global load of this chunk in one batch ----
-        double m[8];
+        double m[NST];
         {
             const double* mp = M + (size_t)((wave_in ? wbase : 0) + ks) * ldm + j;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) m[s] = mp[(size_t)(4 * s) * ldm];
+            for (int s = 0; s < NST; ++s) m[s] = mp[(size_t)(4 * s) * ldm];
         }
         v2d ga[UPT];
         v2d gs[UPT];
 #pragma unroll
         for (int q = 0; q < UPT; ++q) {
             const int u = q * 512 + tid;
-            const int row = u >> 7, c16 = u & 127;
+            const int row = u / U16, c16 = u % U16;
             const int grow = r0 + row;
             const int col = cbase + 2 * c16;
             const bool ok = grow < nrows && col < D;
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
 #pragma unroll
         for (int q = 0; q < UPT; ++q) {
             const int u = q * 512 + tid;
-            const int row = u >> 7, c16 = u & 127;
+            const int row = u / U16, c16 = u % U16;
             v2d v = ga[q];
             if (HAS_SHIFT) { v.x -= gs[q].x; v.y -= gs[q].y; }
             v.x *= alpha; v.y *= alpha;
@@ -85,14 +89,14 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
         }
         __syncthreads();
         if (wave_in) {
-            const double* ap = As + c * LDG + 32 * w + ks;
-            double av[MT][8];                       // operands to registers first: no LDS round trip per MFMA step
+            const double* ap = As + c * LDG + RW * w + ks;
+            double av[MT][NST];                     // operands to registers first: no LDS round trip per MFMA step
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int s = 0; s < 8; ++s) av[mt][s] = ap[mt * 16 * LDG + 4 * s];
+                for (int s = 0; s < NST; ++s) av[mt][s] = ap[mt * 16 * LDG + 4 * s];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
+            for (int s = 0; s < NST; ++s) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) acc[mt] = GSMVI_MFMA_F64(av[mt][s], m[s], acc[mt]);
             }
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
 
     // cross-wave reduction through LDS (fixed order => deterministic), red[w][row][17], w = 0..7
     __syncthreads();
-    double* red = As;                      // 8 * NR * 17 <= NR * 258
+    double* red = As;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -218,8 +222,10 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
     } while (0)
     STAMP(0);
     constexpr int RS = 48;                       // LDS row stride (doubles): 32 columns + 16 pad
-    constexpr int TILE = SB * RS;                // one staged tile
-    constexpr int NU = SB * 16;                  // 16-B units per tile
+    constexpr int NPASS = (SB > 32) ? SB / 32 : 1;   // samples are staged 32 at a time: <= 74 KB of LDS, so
+    constexpr int SBP = SB / NPASS;              //   two workgroups fit per CU also at B = 64
+    constexpr int TILE = SBP * RS;               // one staged tile (per pass)
+    constexpr int NU = SB * 16;                  // 16-B units per tile over all samples
     constexpr int UPT = (6 * NU) / 512;          // units per thread over the six tiles
     static_assert((6 * NU) % 512 == 0, "tile units must divide over 512 threads");
     __shared__ __attribute__((aligned(16))) double smem[6 * TILE >= 2 * 32 * 33 ? 6 * TILE : 2 * 32 * 33];
@@ -284,39 +290,43 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
     }
     if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(1); }
 
-    // ---- factor tiles -> LDS, verbatim ---------------------------------------------------------
-#pragma unroll
-    for (int q = 0; q < UPT; ++q) {
-        const int g = q * 512 + tid;
-        const int tile = g / NU, u = g % NU;
-        *reinterpret_cast<v2d*>(smem + tile * TILE + (u >> 4) * RS + 2 * (u & 15)) = stg[q];
-    }
-    __syncthreads();
-    STAMP(2);
-
-    // ---- MFMA: one 16x16 block per wave; chain 0 = d-part, chain 1 = e-part.  Operands go to
-    // registers first so the two chains issue back to back.
-    constexpr int NS = SB / 4;
-    double ad[NS], ae[NS], bd[NS], be[NS];
-    {
-        const double* adp = smem + ks * RS + 16 * wr + c;
-        const double* aep = adp + TILE;
-        const double* bdp = smem + (2 + 2 * t) * TILE + ks * RS + 16 * wc + c;
-        const double* bep = bdp + TILE;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            ad[s] = adp[4 * s * RS];
-            ae[s] = aep[4 * s * RS];
-            bd[s] = bdp[4 * s * RS];
-            be[s] = bep[4 * s * RS];
-        }
-    }
+    // ---- per pass of SBP samples: factor tiles -> LDS verbatim, then MFMA.  One 16x16 block per wave;
+    // chain 0 = d-part, chain 1 = e-part; operands go to registers first so the chains issue back to back.
+    constexpr int NS = SBP / 4;
     v4d accd = {0.0, 0.0, 0.0, 0.0}, acce = {0.0, 0.0, 0.0, 0.0};
-    if (!(dbg & 8)) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            accd = GSMVI_MFMA_F64(ad[s], bd[s], accd);
-            acce = GSMVI_MFMA_F64(ae[s], be[s], acce);
+    for (int pass = 0; pass < NPASS; ++pass) {
+        if (pass > 0) __syncthreads();           // the previous pass's operand reads are done
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) {
+            const int g = q * 512 + tid;
+            const int tile = g / NU, u = g % NU;
+            const int b = u >> 4;
+            if (b / SBP == pass)
+                *reinterpret_cast<v2d*>(smem + tile * TILE + (b % SBP) * RS + 2 * (u & 15)) = stg[q];
+        }
+        __syncthreads();
+        if (pass == 0) STAMP(2);
+        double ad[NS], ae[NS], bd[NS], be[NS];
+        {
+            const double* adp = smem + ks * RS + 16 * wr + c;
+            const double* aep = adp + TILE;
+            const double* bdp = smem + (2 + 2 * t) * TILE + ks * RS + 16 * wc + c;
+            const double* bep = bdp + TILE;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                ad[s] = adp[4 * s * RS];
+                ae[s] = aep[4 * s * RS];
+                bd[s] = bdp[4 * s * RS];
+                be[s] = bep[4 * s * RS];
+            }
+        }
+        if (!(dbg & 8)) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                accd = GSMVI_MFMA_F64(ad[s], bd[s], accd);
+                acce = GSMVI_MFMA_F64(ae[s], be[s], acce);
+            }
         }
     }
     double wv[4];
@@ -365,16 +375,19 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
 void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int nrows, const double* A,
                              int lda, const double* shift, double alpha, const double* M, int ldm, double* Pp,
                              int chunks_per_wg) {
-#define PF(MTV, HS)                                                                                         \
-    GSMVI_LAUNCH((k_panel_fast<MTV, HS>), grid, dim3(512), 0, st, ev, D, nrows, A, lda, shift, alpha, M, ldm, \
+#define PF(MTV, HS, CW)                                                                                          \
+    GSMVI_LAUNCH((k_panel_fast<MTV, HS, CW>), grid, dim3(512), 0, st, ev, D, nrows, A, lda, shift, alpha, M, ldm, \
                  Pp, chunks_per_wg)
     if (shift) {
-        if (MT == 1) PF(1, true); else if (MT == 2) PF(2, true); else PF(4, true);
+        if (MT == 1) PF(1, true, 256); else if (MT == 2) PF(2, true, 256); else PF(4, true, 128);
     } else {
-        if (MT == 1) PF(1, false); else if (MT == 2) PF(2, false); else PF(4, false);
+        if (MT == 1) PF(1, false, 256); else if (MT == 2) PF(2, false, 256); else PF(4, false, 128);
     }
 #undef PF
 }
+
+// column width of one staged chunk for a given MT (the ABI's chunk arithmetic must agree)
+int gsmvi_panel_fast_chunk(int MT) { return MT == 4 ? 128 : 256; }
 
 // returns false when (D, KC) has no instantiation.  nt = threads per sample-workgroup (tuning knob scalars_nt)
 bool gsmvi_launch_gsm_scalars_fast(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, const double* X, int ldx,
