@@ -60,7 +60,7 @@ class GSM:
     # ------------------------------------------------------------------------------
     def fit(self, key, mean=None, cov=None, batch_size=2, niter=5000, nprint=10, verbose=True,
             check_goodness=True, monitor=None, *, sampler="cholesky", rng="numpy", as_torch=False,
-            forced_samples=None, method="dense"):
+            forced_samples=None, method="dense", shard=False, group=None):
         """Fit N(mean, cov) to the target (gsmvi/gsm_numpy.py:77-129, gsmvi/gsm.py:79-133).
 
         Same arguments and return value as the reference.  Behaviour kept: ``niter + 1`` updates
@@ -78,6 +78,11 @@ class GSM:
                     the reference's legacy host sampler, bit-compatible sample stream (small D).
           rng     : "numpy" (host MT19937 z-stream, uploaded) or "device" (torch generator).
           forced_samples : (niter+1, B, D) teacher-forced samples replacing the sampler.
+          shard   : batch-sharded multi-GPU fit (one process per GPU, torch.distributed initialised; dense
+                    method only).  Every rank draws the same z-stream (same key), so samples are
+                    replicated; each rank evaluates ``lp_g`` only on its batch_size/world rows, the
+                    per-sample records are all-gathered (RCCL) and every replica applies the identical
+                    combined update (gsm-vi_amd/dist.py).  All ranks return the same (mean, cov).
           method  : "dense" (default) keeps Sigma and re-factorises it every iteration exactly like the
                     reference (Cholesky = its _check_goodness).  "factor" keeps a square factor F with
                     Sigma = F^T F instead (BASELINE config 5): samples are mean + z F, the
@@ -88,6 +93,7 @@ class GSM:
         if method == "factor":
             return self._fit_factor(key, mean, cov, batch_size, niter, nprint, verbose, monitor, rng, as_torch)
         assert method == "dense", "method must be 'dense' or 'factor'"
+        assert not (shard and rng == "device"), "shard=True needs the replicated host z-stream (rng='numpy')"
         eng = self._engine if self._engine is not None else get_engine()
         D, B = self.D, int(batch_size)
         mean_t = eng.zeros(D) if mean is None else eng.clone(mean).reshape(D)
@@ -135,8 +141,18 @@ class GSM:
             else:
                 Z = eng.normal(B, D, gen) if gen is not None else eng.normal_from_host(rs.standard_normal((B, D)))
                 X = eng.sample(Z, mean_t, R, out=Xbuf)
-            vs = self.lp_g(X) if native else eng.asarray(self.lp_g(eng.to_numpy(X)))
-            eng.gsm_update(X, vs, mean_t, cov_t, out=(mean_new, cov_new))
+            if shard:
+                from .dist import sharded_gsm_update, shard_bounds
+                import torch.distributed as _dist
+                world = _dist.get_world_size(group) if _dist.is_initialized() else 1
+                rank = _dist.get_rank(group) if _dist.is_initialized() else 0
+                lo, hi = shard_bounds(B, world, rank)
+                Xl = X[lo:hi]
+                vl = self.lp_g(Xl) if native else eng.asarray(self.lp_g(eng.to_numpy(Xl)))
+                sharded_gsm_update(eng, Xl, vl, mean_t, cov_t, group=group, out=(mean_new, cov_new))
+            else:
+                vs = self.lp_g(X) if native else eng.asarray(self.lp_g(eng.to_numpy(X)))
+                eng.gsm_update(X, vs, mean_t, cov_t, out=(mean_new, cov_new))
             nevals += B
             eng.potrf(cov_new, out=R_new, flag=flag)              # _check_goodness, :121,:132-146
             eng.commit(flag, mean_new, cov_new, mean_t, cov_t, n_rev)

@@ -40,6 +40,21 @@ def _worker(rank, world, port, q):
         mu_b, S_b, _ = sharded_bam_update(eng, st["samples"][lo:hi], st["vs"][lo:hi], st["mu0"], st["S0"], 2.0)
         mu_bo, S_bo = borc.bam_lowrank_update_exact(st["samples"], st["vs"], st["mu0"], st["S0"], 2.0)
         err = max(err, np.abs(mu_b - mu_bo).max(), np.abs(S_b - 0.5 * (S_bo + S_bo.T)).max())
+        # sharded FIT: same key on every rank, lp_g sees only the local rows, replicas end identical
+        from gsmvi_amd.gsm import GSM
+        m, cov_t, P = orc.make_gaussian_target(6, 4)
+        seen = []
+
+        def lp_g(x):
+            seen.append(x.shape[0])
+            return orc.gaussian_score(x, m, P)
+
+        mean_s, cov_s = GSM(6, None, lp_g, engine=OracleEngine()).fit(7, niter=30, batch_size=4, verbose=False,
+                                                                       shard=True)
+        mean_1, cov_1 = GSM(6, None, lambda x: orc.gaussian_score(x, m, P), engine=OracleEngine()).fit(
+            7, niter=30, batch_size=4, verbose=False)
+        assert set(seen) == {4 // world}
+        err = max(err, np.abs(mean_s - mean_1).max(), np.abs(cov_s - cov_1).max())
         q.put((rank, float(err), bool(same)))
     finally:
         dist.destroy_process_group()
