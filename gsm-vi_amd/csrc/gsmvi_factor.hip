@@ -85,6 +85,91 @@ __global__ __launch_bounds__(256) void k_panel_t(int D, int nrows, const double*
     }
 }
 
+// ---- fast transposed panel product (D % 64 == 0, even ld, 16-B aligned bases) ---------------------------
+// Same decomposition as k_panel_fast: 512 threads, 8 waves split the chunk's columns, every global load of a
+// chunk (A rows and the 16 M rows, both contiguous along i) issued in one batch as 16-B accesses, staged in
+// LDS [row][CHW+2], MFMA operands pulled to registers before the chain.
+template <int MT, int CHW>
+__global__ __launch_bounds__(512) void k_panel_t_fast(int D, int nrows, const double* __restrict__ A, int lda,
+                                                      const double* __restrict__ M, int ldm,
+                                                      double* __restrict__ Pp, int chunks_per_wg) {
+    constexpr int LDG = CHW + 2;
+    constexpr int NR = 16 * MT;
+    constexpr int RW = CHW / 8;                    // columns of the chunk per wave
+    constexpr int NST = RW / 4;
+    constexpr int U16 = CHW / 2;                   // 16-B units per staged row
+    constexpr int UPT = (NR + 16) * U16 / 512;
+    static_assert(((NR + 16) * U16) % 512 == 0, "staging units must divide over 512 threads");
+    constexpr int SMEM = ((NR + 16) * LDG > 8 * NR * 17) ? (NR + 16) * LDG : 8 * NR * 17;
+    __shared__ __attribute__((aligned(16))) double As[SMEM];
+    double* Ms = As + NR * LDG;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+    const int j0 = blockIdx.x * 16, r0 = blockIdx.z * NR;
+    v4d acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int ch = 0; ch < chunks_per_wg; ++ch) {
+        const int cbase = (blockIdx.y * chunks_per_wg + ch) * CHW;
+        if (cbase >= D) break;
+        v2d st[UPT];
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) {
+            const int u = q * 512 + tid;
+            const int row = u / U16, c16 = u % U16;
+            const int col = cbase + 2 * c16;
+            const int colc = col < D ? col : 0;
+            const double* src;
+            bool ok = col < D;
+            if (row < NR) {
+                const int gr = r0 + row;
+                ok = ok && gr < nrows;
+                src = A + (size_t)(gr < nrows ? gr : nrows - 1) * lda + colc;
+            } else {
+                src = M + (size_t)(j0 + row - NR) * ldm + colc;            // D % 16 == 0: all 16 rows exist
+            }
+            const v2d v = *reinterpret_cast<const v2d*>(src);
+            st[q] = ok ? v : (v2d){0.0, 0.0};
+        }
+        if (ch > 0) __syncthreads();
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) {
+            const int u = q * 512 + tid;
+            *reinterpret_cast<v2d*>(&As[(u / U16) * LDG + 2 * (u % U16)]) = st[q];
+        }
+        __syncthreads();
+        const double* ap = As + c * LDG + RW * w + ks;
+        const double* bp = Ms + c * LDG + RW * w + ks;
+        double av[MT][NST], bv[NST];
+#pragma unroll
+        for (int s = 0; s < NST; ++s) {
+            bv[s] = bp[4 * s];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt][s] = ap[mt * 16 * LDG + 4 * s];
+        }
+#pragma unroll
+        for (int s = 0; s < NST; ++s)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = GSMVI_MFMA_F64(av[mt][s], bv[s], acc[mt]);
+    }
+    __syncthreads();
+    double* red = As;                              // [8][NR][17]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(w * NR + 16 * mt + ks + 4 * r) * 17 + c] = acc[mt][r];
+    __syncthreads();
+    for (int idx = tid; idx < NR * 16; idx += 512) {
+        const int rr = idx >> 4, cc = idx & 15;
+        const int row = r0 + rr;
+        if (row < nrows) {
+            double s = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < 8; ww += 2) s += red[(ww * NR + rr) * 17 + cc] + red[((ww + 1) * NR + rr) * 17 + cc];
+            Pp[((size_t)blockIdx.y * nrows + row) * D + j0 + cc] = s;
+        }
+    }
+}
+
 // ---- whitened per-sample stage: one 1024-thread workgroup per sample (D <= 16384) -----------------
 //   w_b = sum_kc Pp[kc][b];  scalars;  u_b;  writes Rt = [Z; U] (n x D), its transpose Rtt (D x nq) and the
 //   top half of Tm = Rt Fm, i.e. X - mu.
@@ -415,6 +500,100 @@ __global__ __launch_bounds__(256) void k_gsmf_small(int n, int B, const double* 
     }
 }
 
+// ---- K = Rg^-1 (T - I) Rg^-T for 64 < n <= 128 -----------------------------------------------------------
+// One workgroup handles 16 columns of K, SIXTEEN lanes per column (lane q of the group owns rows q, q+16, ..).
+// The triangular matrix in use (Rg, then T, then Rg again) is resident in LDS ([128][130], padded with the
+// identity beyond n); each substitution step broadcasts the pivot value inside the 16-lane group.  Reading
+// a row of the matrix is a stride-1 LDS access, reading a column hits 16 distinct banks: both conflict-free.
+__device__ __forceinline__ void kmat_load_lds(double* Mt, double* rinv, const double* __restrict__ src, int n,
+                                              bool want_rinv) {
+    for (int e = threadIdx.x; e < 128 * 128; e += 256) {
+        const int i = e >> 7, j = e & 127;
+        Mt[i * 130 + j] = (i < n && j < n) ? (j >= i ? src[(size_t)i * n + j] : 0.0) : (i == j ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    if (want_rinv && threadIdx.x < 128) rinv[threadIdx.x] = 1.0 / Mt[threadIdx.x * 130 + threadIdx.x];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_gsmf_kmat_big(int n, const double* __restrict__ Rg,
+                                                       const double* __restrict__ T, double* __restrict__ Kmat,
+                                                       const int* __restrict__ info_g,
+                                                       const int* __restrict__ info_t, int* __restrict__ bad_out) {
+    __shared__ __attribute__((aligned(16))) double Mt[128 * 130];
+    __shared__ double rinv[128];
+    const int bad = (*info_g != 0) || (*info_t != 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *bad_out = bad;
+    if (bad) return;                                         // block-uniform
+    const int tid = threadIdx.x, c = tid >> 4, q = tid & 15, grp = tid & 48;   // grp: first lane of the group in the wave
+    const int cg = blockIdx.x * 16 + c;
+    double x[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[r] = (q + 16 * r == cg) ? 1.0 : 0.0;
+    // phase 1: x = Rg^-T e_c   (L = Rg^T, L[t][p] = Rg[p][t]: row p of Rg)
+    kmat_load_lds(Mt, rinv, Rg, n, true);
+#pragma unroll
+    for (int p = 0; p < 128; ++p) {
+        const int pr = p >> 4, pq = p & 15;
+        const double mine = x[pr] * rinv[p];
+        if (q == pq) x[pr] = mine;
+        const double xp = __shfl(mine, grp | pq, 64);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (16 * r + 15 > p) {
+                const int t = q + 16 * r;
+                const double rv = Mt[p * 130 + t];
+                x[r] -= (t > p) ? rv * xp : 0.0;
+            }
+    }
+    __syncthreads();
+    // phase 2: y = (T - I) x,  y[t] = sum_{p >= t} T[t][p] x[p] - x[t]
+    kmat_load_lds(Mt, rinv, T, n, false);
+    {
+        double y[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) y[r] = -x[r];
+#pragma unroll
+        for (int p = 0; p < 128; ++p) {
+            const int pr = p >> 4, pq = p & 15;
+            const double xp = __shfl(x[pr], grp | pq, 64);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (16 * r <= p) {
+                    const int t = q + 16 * r;
+                    const double tv = Mt[t * 130 + p];
+                    y[r] += (t <= p) ? tv * xp : 0.0;
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = y[r];
+    }
+    __syncthreads();
+    // phase 3: z = Rg^-1 y  (back substitution from the bottom; needs column p of Rg)
+    kmat_load_lds(Mt, rinv, Rg, n, true);
+#pragma unroll
+    for (int p = 127; p >= 0; --p) {
+        const int pr = p >> 4, pq = p & 15;
+        const double mine = x[pr] * rinv[p];
+        if (q == pq) x[pr] = mine;
+        const double xp = __shfl(mine, grp | pq, 64);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (16 * r < p) {
+                const int t = q + 16 * r;
+                const double rv = Mt[t * 130 + p];
+                x[r] -= (t < p) ? rv * xp : 0.0;
+            }
+    }
+    if (cg < n) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int t = q + 16 * r;
+            if (t < n) Kmat[(size_t)t * n + cg] = x[r];
+        }
+    }
+}
+
 // ---- new mean and the revert passthrough for the K-matrix path -----------------------------------------
 __global__ __launch_bounds__(256) void k_gsmf_mean(int D, int B, const double* __restrict__ Tm,
                                                    const double* __restrict__ mu0, double* __restrict__ mu,
@@ -467,6 +646,8 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
     // W = G Fm^T
     const int MT = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
     const int CH = (MT == 4) ? 128 : 256;
+    const bool fast_t = !ctx->tune_no_fast && D % 64 == 0 && ldg % 2 == 0 && ldf0 % 2 == 0 &&
+                        (reinterpret_cast<uintptr_t>(G) & 15u) == 0 && (reinterpret_cast<uintptr_t>(F0) & 15u) == 0;
     const int strips = (D + 15) / 16, nchunks = (D + CH - 1) / CH, zb = (B + 16 * MT - 1) / (16 * MT);
     int kc = (2 * ctx->num_cu + strips * zb - 1) / (strips * zb);
     if (kc > nchunks) kc = nchunks;
@@ -475,7 +656,11 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
     const int cpw = (nchunks + kc - 1) / kc;
     kc = (nchunks + cpw - 1) / cpw;
     const dim3 grid(strips, kc, zb);
-    if (MT == 1) hipLaunchKernelGGL((k_panel_t<1, 256>), grid, dim3(256), 0, st, D, B, G, ldg, F0, ldf0, ctx->pp, cpw);
+    if (fast_t) {
+        if (MT == 1) hipLaunchKernelGGL((k_panel_t_fast<1, 256>), grid, dim3(512), 0, st, D, B, G, ldg, F0, ldf0, ctx->pp, cpw);
+        else if (MT == 2) hipLaunchKernelGGL((k_panel_t_fast<2, 256>), grid, dim3(512), 0, st, D, B, G, ldg, F0, ldf0, ctx->pp, cpw);
+        else hipLaunchKernelGGL((k_panel_t_fast<4, 128>), grid, dim3(512), 0, st, D, B, G, ldg, F0, ldf0, ctx->pp, cpw);
+    } else if (MT == 1) hipLaunchKernelGGL((k_panel_t<1, 256>), grid, dim3(256), 0, st, D, B, G, ldg, F0, ldf0, ctx->pp, cpw);
     else if (MT == 2) hipLaunchKernelGGL((k_panel_t<2, 256>), grid, dim3(256), 0, st, D, B, G, ldg, F0, ldf0, ctx->pp, cpw);
     else hipLaunchKernelGGL((k_panel_t<4, 128>), grid, dim3(256), 0, st, D, B, G, ldg, F0, ldf0, ctx->pp, cpw);
     int rc = chk("k_panel_t");
@@ -507,13 +692,21 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
             return rc;
         if ((rc = gsmvi_panel_finish(st, D, n, kc2, ctx->pp, nullptr, Fs, D))) return rc;
     } else {
+        // 64 < n <= 128: the two n x n Choleskys through the blocked potrf, K in its own kernel, then the same
+        // skinny GEMM Fs = K Tm
+        double* Kmat = Gam;                        // Gamma is dead once Rg exists
         if ((rc = gsmvi_potrf_impl(ctx, st, n, Gam, n, Rg, n, info_g))) return rc;
         hipLaunchKernelGGL(k_gsmf_small_a, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Rg, info_g, Ap);
         if ((rc = chk("k_gsmf_small_a"))) return rc;
         if ((rc = gsmvi_potrf_impl(ctx, st, n, Ap, n, Tt, n, info_t))) return rc;
-        hipLaunchKernelGGL(k_gsmf_colsolve, dim3((D + 63) / 64), dim3(64), sizeof(double) * n * 64, st, D, n, B, Rg, Tt,
-                           Tm, mu0, Fs, mu, info_g, info_t, info_dev);
-        if ((rc = chk("k_gsmf_colsolve"))) return rc;
+        hipLaunchKernelGGL(k_gsmf_kmat_big, dim3((n + 15) / 16), dim3(256), 0, st, n, Rg, Tt, Kmat, info_g, info_t,
+                           info_dev);
+        if ((rc = chk("k_gsmf_kmat_big"))) return rc;
+        hipLaunchKernelGGL(k_gsmf_mean, dim3((D + 255) / 256), dim3(256), 0, st, D, B, Tm, mu0, mu, info_dev);
+        if ((rc = chk("k_gsmf_mean"))) return rc;
+        if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, ctx->pp, &kc2)))
+            return rc;
+        if ((rc = gsmvi_panel_finish(st, D, n, kc2, ctx->pp, nullptr, Fs, D))) return rc;
     }
     const int nt = (D + 63) / 64;
     hipLaunchKernelGGL(k_gsmf_update, dim3(nt * nt), dim3(256), 0, st, D, n, Rt, Fs, F0, ldf0, F, ldf, info_dev);
