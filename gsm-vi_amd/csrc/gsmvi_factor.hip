@@ -236,65 +236,139 @@ __global__ __launch_bounds__(1024) void k_gsmf_scalars(int D, int B, int KC, con
     }
 }
 
-// ---- A' = I + Rg J Rg^T  (n x n),  J = (1/B) [[0, I], [I, -I]],  Rg upper triangular ------------------
-//   (Rg J)[i][k] = (1/B) * ( k <  B : Rg[i][B+k]
-//                            k >= B : Rg[i][k-B] - Rg[i][k] )
-__global__ __launch_bounds__(256) void k_gsmf_small_a(int n, int B, const double* __restrict__ Rg,
-                                                      const int* __restrict__ info_g, double* __restrict__ Ap) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n * n) return;
-    const int i = idx / n, j = idx % n;
-    const double invB = 1.0 / (double)B;
-    double s = 0.0;
-    for (int k = 0; k < n; ++k) {
-        const double rj = (k < B) ? Rg[(size_t)i * n + B + k] : (Rg[(size_t)i * n + k - B] - Rg[(size_t)i * n + k]);
-        s += rj * Rg[(size_t)j * n + k];
+// LDS[128][130] <- upper triangle of the n x n matrix src (n <= 128), zero below, identity beyond n.
+// Clamped unconditional loads, 16 in flight per thread: a guarded load per iteration serialises 64 L2 round trips.
+__device__ __forceinline__ void load_upper128(double* Mt, const double* __restrict__ src, int n) {
+    const int j = threadIdx.x & 127, jc = j < n ? j : n - 1, ih = threadIdx.x >> 7;
+#pragma unroll
+    for (int it0 = 0; it0 < 64; it0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = ih + 2 * (it0 + u), ic = i < n ? i : n - 1;
+            v[u] = src[(size_t)ic * n + jc];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = ih + 2 * (it0 + u);
+            Mt[i * 130 + j] = (i < n && j < n) ? (j >= i ? v[u] : 0.0) : (i == j ? 1.0 : 0.0);
+        }
     }
-    double v = (i == j ? 1.0 : 0.0) + s * invB;
-    if (*info_g != 0) v = (i == j) ? -1.0 : 0.0;     // Gamma was singular: force the PD test to fail
-    Ap[idx] = v;
 }
 
-// ---- Fs = Rg^-1 (T - I) Rg^-T Tm  and the new mean, one column of D per thread --------------------------
-// 64 threads per block; the thread's n-vector lives in LDS ([k][64], conflict-free).  Rg, T are read with
-// wave-uniform indices (scalar loads, L2 hits).  bad = info_g | info_t is written for the update kernel.
-__global__ __launch_bounds__(64) void k_gsmf_colsolve(int D, int n, int B, const double* __restrict__ Rg,
-                                                      const double* __restrict__ T, const double* __restrict__ Tm,
-                                                      const double* __restrict__ mu0, double* __restrict__ Fs,
-                                                      double* __restrict__ mu, const int* __restrict__ info_g,
-                                                      const int* __restrict__ info_t, int* __restrict__ bad_out) {
-    extern __shared__ double v[];                  // [n][64]
-    const int t = threadIdx.x, j = blockIdx.x * 64 + t;
-    const int jc = j < D ? j : D - 1;
-    const int bad = (*info_g != 0) || (*info_t != 0);
-    if (blockIdx.x == 0 && t == 0) *bad_out = bad;
-    double dsum = 0.0;
-    for (int k = 0; k < n; ++k) {
-        const double x = Tm[(size_t)k * D + jc];
-        v[k * 64 + t] = x;
-        if (k >= B) dsum += x;                     // sum_b (U Fm)[b][j]
+// ---- A' = I + Rg J Rg^T  (n x n, 64 < n <= 128),  J = (1/B) [[0, I], [I, -I]],  Rg upper triangular ----
+//   (Rg J)[i][k] = (1/B) * ( k <  B : Rg[i][B+k]
+//                            k >= B : Rg[i][k-B] - Rg[i][k] )
+// 16 x 16 outputs per workgroup; the 16 rows of (Rg J) and the 16 rows of Rg it needs are staged in LDS
+// ([row][130]: reading one row per lane is conflict-free).
+__global__ __launch_bounds__(256) void k_gsmf_small_a(int n, int B, const double* __restrict__ Rg,
+                                                      const int* __restrict__ info_g, double* __restrict__ Ap) {
+    __shared__ double RJ[16 * 130];
+    __shared__ double RR[16 * 130];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+    for (int e = tid; e < 16 * 128; e += 256) {
+        const int r = e >> 7, k = e & 127;
+        const int gi = i0 + r, gj = j0 + r;
+        double vj = 0.0, vr = 0.0;
+        if (k < n) {
+            if (gi < n) vj = (k < B) ? Rg[(size_t)gi * n + B + k] : (Rg[(size_t)gi * n + k - B] - Rg[(size_t)gi * n + k]);
+            if (gj < n) vr = Rg[(size_t)gj * n + k];
+        }
+        RJ[r * 130 + k] = vj;
+        RR[r * 130 + k] = vr;
     }
-    if (j < D) mu[j] = bad ? mu0[j] : mu0[j] + dsum / (double)B;
-    // v1 = Rg^-T t : forward substitution with the lower factor Rg^T
-    for (int r = 0; r < n; ++r) {
-        double a = v[r * 64 + t];
-        for (int k = 0; k < r; ++k) a -= Rg[(size_t)k * n + r] * v[k * 64 + t];
-        v[r * 64 + t] = a / Rg[(size_t)r * n + r];
+    __syncthreads();
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < 128; k += 2) {
+        s0 += RJ[ty * 130 + k] * RR[tx * 130 + k];
+        s1 += RJ[ty * 130 + k + 1] * RR[tx * 130 + k + 1];
     }
-    // v2 = (T - I) v1 : upper-triangular mat-vec, in place from the top (row r needs entries >= r only)
-    for (int r = 0; r < n; ++r) {
-        double a = -v[r * 64 + t];
-        for (int k = r; k < n; ++k) a += T[(size_t)r * n + k] * v[k * 64 + t];
-        v[r * 64 + t] = a;
+    const int i = i0 + ty, j = j0 + tx;
+    if (i < n && j < n) {
+        double v = (i == j ? 1.0 : 0.0) + (s0 + s1) / (double)B;
+        if (*info_g != 0) v = (i == j) ? -1.0 : 0.0;     // Gamma was singular: force the PD test to fail
+        Ap[(size_t)i * n + j] = v;
     }
-    // v3 = Rg^-1 v2 : back substitution
-    for (int r = n - 1; r >= 0; --r) {
-        double a = v[r * 64 + t];
-        for (int k = r + 1; k < n; ++k) a -= Rg[(size_t)r * n + k] * v[k * 64 + t];
-        a /= Rg[(size_t)r * n + r];
-        v[r * 64 + t] = a;
-        if (j < D) Fs[(size_t)r * D + j] = a;
+}
+
+// ---- Cholesky A = R^T R of one n x n matrix, 64 < n <= 128, in ONE workgroup ----------------------------
+// The matrix lives in LDS ([128][130], identity beyond n).  2 x 2 blocks of 64: chol64 of A11, the block row
+// R12 = R11^-T A12 one column per quad of lanes (as k_potrf_panel), A22 -= R12^T R12 with a 4 x 4 register
+// tile per thread, chol64 of A22.  *info = 1-based index of the first bad pivot (0 = ok); R gets the upper
+// factor with a zero strictly-lower triangle.
+__global__ __launch_bounds__(256) void k_chol128(int n, const double* __restrict__ A, double* __restrict__ R,
+                                                 int* __restrict__ info) {
+    constexpr int MS = 130;
+    __shared__ __attribute__((aligned(16))) double M[128 * MS];
+    __shared__ double rinv[128];
+    __shared__ int sh_fail[2];
+    const int tid = threadIdx.x;
+    load_upper128(M, A, n);
+    if (tid < 128) rinv[tid] = 1.0;
+    __syncthreads();
+    chol64_rows_s<MS>(M, rinv, 64, &sh_fail[0]);
+    {
+        const int colq = tid >> 2, q = tid & 3;
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = M[(q + 4 * r) * MS + 64 + colq];
+#pragma unroll
+        for (int p = 0; p < 64; ++p) {
+            const int pr = p >> 2, pq = p & 3;
+            const double mine = x[pr] * rinv[p];
+            if (q == pq) x[pr] = mine;
+            const double xp = __shfl(mine, (tid & 60) | pq, 64);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (4 * r + 3 > p) {
+                    const int t = q + 4 * r;
+                    const double rv = M[p * MS + t];
+                    x[r] -= (t > p) ? rv * xp : 0.0;
+                }
+            }
+        }
+        __syncthreads();                                         // all reads of the A12 block are done
+#pragma unroll
+        for (int r = 0; r < 16; ++r) M[(q + 4 * r) * MS + 64 + colq] = x[r];
     }
+    __syncthreads();
+    {
+        const int ty = tid >> 4, tx = tid & 15;
+        double acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+#pragma unroll 4
+        for (int p = 0; p < 64; ++p) {
+            double ra[4], rb[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                ra[a] = M[p * MS + 64 + ty + 16 * a];
+                rb[a] = M[p * MS + 64 + tx + 16 * a];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] += ra[a] * rb[b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i = ty + 16 * a, j = tx + 16 * b;
+                if (j >= i) M[(64 + i) * MS + 64 + j] -= acc[a][b];
+            }
+    }
+    __syncthreads();
+    chol64_rows_s<MS>(M + 64 * MS + 64, rinv + 64, n - 64, &sh_fail[1]);
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, j = e % n;
+        R[e] = (j >= i) ? M[i * MS + j] : 0.0;
+    }
+    if (tid == 0) *info = sh_fail[0] != 0 ? sh_fail[0] : (sh_fail[1] != 0 ? 64 + sh_fail[1] : 0);
 }
 
 // ---- F = F0 + Rt^T Fs  (full, non-symmetric rank-n update; F = F0 when *bad) ---------------------------
@@ -507,10 +581,7 @@ __global__ __launch_bounds__(256) void k_gsmf_small(int n, int B, const double* 
 // a row of the matrix is a stride-1 LDS access, reading a column hits 16 distinct banks: both conflict-free.
 __device__ __forceinline__ void kmat_load_lds(double* Mt, double* rinv, const double* __restrict__ src, int n,
                                               bool want_rinv) {
-    for (int e = threadIdx.x; e < 128 * 128; e += 256) {
-        const int i = e >> 7, j = e & 127;
-        Mt[i * 130 + j] = (i < n && j < n) ? (j >= i ? src[(size_t)i * n + j] : 0.0) : (i == j ? 1.0 : 0.0);
-    }
+    load_upper128(Mt, src, n);
     __syncthreads();
     if (want_rinv && threadIdx.x < 128) rinv[threadIdx.x] = 1.0 / Mt[threadIdx.x * 130 + threadIdx.x];
     __syncthreads();
@@ -530,21 +601,23 @@ __global__ __launch_bounds__(256) void k_gsmf_kmat_big(int n, const double* __re
     double x[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) x[r] = (q + 16 * r == cg) ? 1.0 : 0.0;
+    // The pivot loops are blocked 8 x 16: the outer block index is unrolled (static register indices), the 16
+    // pivots inside a block stay a rolled loop -- fully unrolled, the scheduler hoists every LDS read and spills.
     // phase 1: x = Rg^-T e_c   (L = Rg^T, L[t][p] = Rg[p][t]: row p of Rg)
     kmat_load_lds(Mt, rinv, Rg, n, true);
 #pragma unroll
-    for (int p = 0; p < 128; ++p) {
-        const int pr = p >> 4, pq = p & 15;
-        const double mine = x[pr] * rinv[p];
-        if (q == pq) x[pr] = mine;
-        const double xp = __shfl(mine, grp | pq, 64);
+    for (int pb = 0; pb < 8; ++pb) {
+#pragma unroll 2
+        for (int pq = 0; pq < 16; ++pq) {
+            const int p = 16 * pb + pq;
+            const double mine = x[pb] * rinv[p];
+            if (q == pq) x[pb] = mine;
+            const double xp = __shfl(mine, grp | pq, 64);
+            const double* row = Mt + p * 130 + q;
+            x[pb] -= (q > pq) ? row[16 * pb] * xp : 0.0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-            if (16 * r + 15 > p) {
-                const int t = q + 16 * r;
-                const double rv = Mt[p * 130 + t];
-                x[r] -= (t > p) ? rv * xp : 0.0;
-            }
+            for (int r = pb + 1; r < 8; ++r) x[r] -= row[16 * r] * xp;
+        }
     }
     __syncthreads();
     // phase 2: y = (T - I) x,  y[t] = sum_{p >= t} T[t][p] x[p] - x[t]
@@ -554,16 +627,16 @@ __global__ __launch_bounds__(256) void k_gsmf_kmat_big(int n, const double* __re
 #pragma unroll
         for (int r = 0; r < 8; ++r) y[r] = -x[r];
 #pragma unroll
-        for (int p = 0; p < 128; ++p) {
-            const int pr = p >> 4, pq = p & 15;
-            const double xp = __shfl(x[pr], grp | pq, 64);
+        for (int pb = 0; pb < 8; ++pb) {
+#pragma unroll 2
+            for (int pq = 0; pq < 16; ++pq) {
+                const int p = 16 * pb + pq;
+                const double xp = __shfl(x[pb], grp | pq, 64);
+                const double* colp = Mt + q * 130 + p;
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-                if (16 * r <= p) {
-                    const int t = q + 16 * r;
-                    const double tv = Mt[t * 130 + p];
-                    y[r] += (t <= p) ? tv * xp : 0.0;
-                }
+                for (int r = 0; r < pb; ++r) y[r] += colp[16 * r * 130] * xp;
+                y[pb] += (q <= pq) ? colp[16 * pb * 130] * xp : 0.0;
+            }
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) x[r] = y[r];
@@ -572,18 +645,18 @@ __global__ __launch_bounds__(256) void k_gsmf_kmat_big(int n, const double* __re
     // phase 3: z = Rg^-1 y  (back substitution from the bottom; needs column p of Rg)
     kmat_load_lds(Mt, rinv, Rg, n, true);
 #pragma unroll
-    for (int p = 127; p >= 0; --p) {
-        const int pr = p >> 4, pq = p & 15;
-        const double mine = x[pr] * rinv[p];
-        if (q == pq) x[pr] = mine;
-        const double xp = __shfl(mine, grp | pq, 64);
+    for (int pb = 7; pb >= 0; --pb) {
+#pragma unroll 2
+        for (int pq = 15; pq >= 0; --pq) {
+            const int p = 16 * pb + pq;
+            const double mine = x[pb] * rinv[p];
+            if (q == pq) x[pb] = mine;
+            const double xp = __shfl(mine, grp | pq, 64);
+            const double* colp = Mt + q * 130 + p;
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-            if (16 * r < p) {
-                const int t = q + 16 * r;
-                const double rv = Mt[t * 130 + p];
-                x[r] -= (t < p) ? rv * xp : 0.0;
-            }
+            for (int r = 0; r < pb; ++r) x[r] -= colp[16 * r * 130] * xp;
+            x[pb] -= (q < pq) ? colp[16 * pb * 130] * xp : 0.0;
+        }
     }
     if (cg < n) {
 #pragma unroll
@@ -692,13 +765,13 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
             return rc;
         if ((rc = gsmvi_panel_finish(st, D, n, kc2, ctx->pp, nullptr, Fs, D))) return rc;
     } else {
-        // 64 < n <= 128: the two n x n Choleskys through the blocked potrf, K in its own kernel, then the same
-        // skinny GEMM Fs = K Tm
+        // 64 < n <= 128: the two n x n Choleskys one workgroup each, K in its own kernel, then the same skinny
+        // GEMM Fs = K Tm
         double* Kmat = Gam;                        // Gamma is dead once Rg exists
-        if ((rc = gsmvi_potrf_impl(ctx, st, n, Gam, n, Rg, n, info_g))) return rc;
-        hipLaunchKernelGGL(k_gsmf_small_a, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Rg, info_g, Ap);
-        if ((rc = chk("k_gsmf_small_a"))) return rc;
-        if ((rc = gsmvi_potrf_impl(ctx, st, n, Ap, n, Tt, n, info_t))) return rc;
+        hipLaunchKernelGGL(k_chol128, dim3(1), dim3(256), 0, st, n, Gam, Rg, info_g);
+        hipLaunchKernelGGL(k_gsmf_small_a, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, st, n, B, Rg, info_g, Ap);
+        hipLaunchKernelGGL(k_chol128, dim3(1), dim3(256), 0, st, n, Ap, Tt, info_t);
+        if ((rc = chk("k_chol128"))) return rc;
         hipLaunchKernelGGL(k_gsmf_kmat_big, dim3((n + 15) / 16), dim3(256), 0, st, n, Rg, Tt, Kmat, info_g, info_t,
                            info_dev);
         if ((rc = chk("k_gsmf_kmat_big"))) return rc;
