@@ -36,6 +36,12 @@ _SIGS = {
                                             C.c_int, _c_dp, _c_dp, C.c_int, _c_dp, C.c_int]),
     "gsmvi_gsm_apply_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, _c_dp,
                                       C.c_int, _c_dp, _c_dp, C.c_int]),
+    "gsmvi_gsm_rows_stage_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp,
+                                           C.c_int, _c_dp, C.c_int]),
+    "gsmvi_gsm_records_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int,
+                                        _c_dp, _c_dp, _c_dp, C.c_int]),
+    "gsmvi_gsm_apply_rows_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _c_dp,
+                                           C.c_int, _c_dp, _c_dp, C.c_int, _c_dp, _c_dp, C.c_int]),
     "gsmvi_gsm_factor_update_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int,
                                               _c_dp, C.c_int, _c_dp, _c_dp, C.c_int, _c_dp, _c_dp, C.c_int, _c_dp]),
     "gsmvi_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),

@@ -24,7 +24,9 @@ hipError_t gsmvi_cov_update_prepare();
 hipError_t gsmvi_bam_prepare();
 void gsmvi_launch_gsm_cov_update(hipStream_t st, hipEvent_t* ev, int D, int B, const double* rec, int ldrec,
                                  const double* mu0, const double* S0, int lds0, double* S, int lds, double* mu_out,
-                                 int SB, int s_vec_ok);
+                                 int SB, int s_vec_ok, int row0, int nrows);
+int gsmvi_panel_t_product(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* A, int lda,
+                          const double* M, int ldm, int mrows, double* Pp, int* kc_out);
 void gsmvi_launch_commit(hipStream_t st, int D, const int* info, const double* mu_new, const double* S_new,
                          int lds_new, double* mu, double* S, int lds, int* n_reverts);
 // fast paths (gsmvi_fast.hip)
@@ -309,17 +311,15 @@ static int check_common(gsmvi_ctx* ctx, int D, int B, const char* fn) {
 
 extern "C" {
 
+static int gsm_records(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, int kc, const double* X, int ldx,
+                       const double* G, int ldg, const double* mu0, const double* Pp, double* rec, int ldrec);
+
 static int gsm_local_stage(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, const double* X, int ldx, const double* G,
                            int ldg, const double* mu0, const double* S0, int lds0, double* rec, int ldrec) {
     int kc = 1;
     int st = gsmvi_panel_product(ctx, hs, ctx->stage_events(0), D, B, G, ldg, nullptr, 1.0, S0, lds0, ctx->pp, &kc);
     if (st != GSMVI_OK) return st;
-    if (!ctx->tune_no_fast && D <= 8192 &&
-        gsmvi_launch_gsm_scalars_fast(hs, ctx->stage_events(1), D, B, kc, X, ldx, G, ldg, mu0, ctx->pp, rec, ldrec,
-                                      ctx->tune_scalars_nt))
-        return check_launch("k_gsm_scalars_fast");
-    gsmvi_launch_gsm_scalars(hs, ctx->stage_events(1), D, B, kc, X, ldx, G, ldg, mu0, ctx->pp, rec, ldrec);
-    return check_launch("k_gsm_scalars");
+    return gsm_records(ctx, hs, D, B, kc, X, ldx, G, ldg, mu0, ctx->pp, rec, ldrec);
 }
 
 static int gsm_apply(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, const double* rec, int ldrec, const double* mu0,
@@ -333,8 +333,19 @@ static int gsm_apply(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, const double*
     if (SB > 64) SB = 64;
     SB = (SB + 1) & ~1;
     const int s_vec_ok = (lds0 % 2 == 0) && (lds % 2 == 0) && aligned16(S0) && aligned16(S);
-    gsmvi_launch_gsm_cov_update(hs, ctx->stage_events(2), D, B, rec, ldrec, mu0, S0, lds0, S, lds, mu, SB, s_vec_ok);
+    gsmvi_launch_gsm_cov_update(hs, ctx->stage_events(2), D, B, rec, ldrec, mu0, S0, lds0, S, lds, mu, SB, s_vec_ok,
+                                0, D);
     return check_launch("k_gsm_cov_update");
+}
+
+static int gsm_records(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, int kc, const double* X, int ldx,
+                       const double* G, int ldg, const double* mu0, const double* Pp, double* rec, int ldrec) {
+    if (!ctx->tune_no_fast && D <= 8192 &&
+        gsmvi_launch_gsm_scalars_fast(hs, ctx->stage_events(1), D, B, kc, X, ldx, G, ldg, mu0, Pp, rec, ldrec,
+                                      ctx->tune_scalars_nt))
+        return check_launch("k_gsm_scalars_fast");
+    gsmvi_launch_gsm_scalars(hs, ctx->stage_events(1), D, B, kc, X, ldx, G, ldg, mu0, Pp, rec, ldrec);
+    return check_launch("k_gsm_scalars");
 }
 
 int gsmvi_gsm_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* X, int ldx, const double* G,
@@ -373,6 +384,51 @@ int gsmvi_gsm_apply_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double
     BAD_ARG(S == S0 || mu == mu0, "outputs must not alias inputs");
     hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
     return gsm_apply(ctx, hs, D, B, rec, ldrec, mu0, S0, lds0, mu, S, lds);
+}
+
+int gsmvi_gsm_rows_stage_f64(gsmvi_ctx* ctx, void* stream, int D, int B, int nrows, const double* G, int ldg,
+                             const double* S0rows, int lds0, double* SGcols, int ldsg) {
+    int st = check_common(ctx, D, B, __func__);
+    if (st != GSMVI_OK) return st;
+    BAD_ARG(!G || !S0rows || !SGcols, "NULL array");
+    BAD_ARG(nrows <= 0 || nrows > D, "nrows out of range");
+    BAD_ARG(ldg < D || lds0 < D || ldsg < nrows, "leading dimension too small");
+    hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    int kc = 1;
+    st = gsmvi_panel_t_product(ctx, hs, D, B, G, ldg, S0rows, lds0, nrows, ctx->pp, &kc);
+    if (st != GSMVI_OK) return st;
+    return gsmvi_panel_finish(hs, nrows, B, kc, ctx->pp, nullptr, SGcols, ldsg);
+}
+
+int gsmvi_gsm_records_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* X, int ldx, const double* G,
+                          int ldg, const double* mu0, const double* SG, double* rec, int ldrec) {
+    int st = check_common(ctx, D, B, __func__);
+    if (st != GSMVI_OK) return st;
+    BAD_ARG(!X || !G || !mu0 || !SG || !rec, "NULL array");
+    BAD_ARG(ldx < D || ldg < D, "leading dimension smaller than D");
+    BAD_ARG(ldrec < gsmvi_gsm_record_len(D), "ldrec smaller than gsmvi_gsm_record_len(D)");
+    // the gathered SG (B x D, contiguous) is exactly one partial slab
+    return gsm_records(ctx, reinterpret_cast<hipStream_t>(stream), D, B, 1, X, ldx, G, ldg, mu0, SG, rec, ldrec);
+}
+
+int gsmvi_gsm_apply_rows_f64(gsmvi_ctx* ctx, void* stream, int D, int B, int row0, int nrows, const double* rec,
+                             int ldrec, const double* mu0, const double* S0rows, int lds0, double* mu,
+                             double* Srows, int lds) {
+    int st = check_common(ctx, D, B, __func__);
+    if (st != GSMVI_OK) return st;
+    BAD_ARG(!rec || !mu0 || !S0rows || !Srows, "NULL array");
+    BAD_ARG(row0 < 0 || nrows <= 0 || row0 + nrows > D, "row block out of range");
+    BAD_ARG(lds0 < D || lds < D, "leading dimension smaller than D");
+    BAD_ARG(ldrec < gsmvi_gsm_record_len(D), "ldrec smaller than gsmvi_gsm_record_len(D)");
+    BAD_ARG(Srows == S0rows || (mu && mu == mu0), "outputs must not alias inputs");
+    hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    int SB = ctx->tune_update_sb > 0 ? ctx->tune_update_sb : ((B + 1) & ~1);
+    if (SB > 64) SB = 64;
+    SB = (SB + 1) & ~1;
+    const int s_vec_ok = (lds0 % 2 == 0) && (lds % 2 == 0) && aligned16(S0rows) && aligned16(Srows);
+    gsmvi_launch_gsm_cov_update(hs, ctx->stage_events(2), D, B, rec, ldrec, mu0, S0rows, lds0, Srows, lds, mu, SB,
+                                s_vec_ok, row0, nrows);
+    return check_launch("k_gsm_cov_update(rows)");
 }
 
 int gsmvi_gaussian_score_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* X, int ldx,

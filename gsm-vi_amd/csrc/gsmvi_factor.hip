@@ -20,6 +20,8 @@
 #include "../../include/gsmvi_hip.h"
 
 // ---- transposed panel product partials: Pp[kc][r][j] = sum_{i in chunk(kc)} A[r][i] M[j][i] ----------
+// M has mrows rows of length D (mrows = D for the square factor; a row block of a sharded matrix otherwise);
+// the slabs are nrows x mrows.
 // Workgroup = 16 rows j of M x CH-column chunks.  Both the A chunk (NR x CH) and the M tile (16 x CH)
 // are loaded with coalesced 16-B accesses along i and staged in LDS [row][CH+2]; MFMA A operand =
 // A rows, B operand = M rows (B[k][col j] = M[j][k]).  Guarded: any D, any alignment falls back to
@@ -27,7 +29,7 @@
 template <int MT, int CH>
 __global__ __launch_bounds__(256) void k_panel_t(int D, int nrows, const double* __restrict__ A, int lda,
                                                  const double* __restrict__ M, int ldm, double* __restrict__ Pp,
-                                                 int chunks_per_wg) {
+                                                 int chunks_per_wg, int mrows) {
     constexpr int LDG = CH + 2;
     constexpr int NR = 16 * MT;
     constexpr int KW = CH / 4;                    // columns of the chunk per wave
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void k_panel_t(int D, int nrows, const double*
                     if (gr < nrows) v = A[(size_t)gr * lda + gc];
                 } else {
                     const int gj = j0 + row - NR;
-                    if (gj < D) v = M[(size_t)gj * ldm + gc];
+                    if (gj < mrows) v = M[(size_t)gj * ldm + gc];
                 }
             }
             As[row * LDG + col] = v;
@@ -77,10 +79,10 @@ __global__ __launch_bounds__(256) void k_panel_t(int D, int nrows, const double*
     for (int idx = tid; idx < NR * 16; idx += 256) {
         const int rr = idx >> 4, cc = idx & 15;
         const int row = r0 + rr, col = j0 + cc;
-        if (row < nrows && col < D) {
+        if (row < nrows && col < mrows) {
             const double s = (red[(0 * NR + rr) * 17 + cc] + red[(1 * NR + rr) * 17 + cc]) +
                              (red[(2 * NR + rr) * 17 + cc] + red[(3 * NR + rr) * 17 + cc]);
-            Pp[((size_t)blockIdx.y * nrows + row) * D + col] = s;
+            Pp[((size_t)blockIdx.y * nrows + row) * mrows + col] = s;
         }
     }
 }
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void k_panel_t(int D, int nrows, const double*
 template <int MT, int CHW>
 __global__ __launch_bounds__(512) void k_panel_t_fast(int D, int nrows, const double* __restrict__ A, int lda,
                                                       const double* __restrict__ M, int ldm,
-                                                      double* __restrict__ Pp, int chunks_per_wg) {
+                                                      double* __restrict__ Pp, int chunks_per_wg, int mrows) {
     constexpr int LDG = CHW + 2;
     constexpr int NR = 16 * MT;
     constexpr int RW = CHW / 8;                    // columns of the chunk per wave
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(512) void k_panel_t_fast(int D, int nrows, const do
                 ok = ok && gr < nrows;
                 src = A + (size_t)(gr < nrows ? gr : nrows - 1) * lda + colc;
             } else {
-                src = M + (size_t)(j0 + row - NR) * ldm + colc;            // D % 16 == 0: all 16 rows exist
+                src = M + (size_t)(j0 + row - NR) * ldm + colc;            // mrows % 16 == 0: all 16 rows exist
             }
             const v2d v = *reinterpret_cast<const v2d*>(src);
             st[q] = ok ? v : (v2d){0.0, 0.0};
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(512) void k_panel_t_fast(int D, int nrows, const do
             double s = 0.0;
 #pragma unroll
             for (int ww = 0; ww < 8; ww += 2) s += red[(ww * NR + rr) * 17 + cc] + red[((ww + 1) * NR + rr) * 17 + cc];
-            Pp[((size_t)blockIdx.y * nrows + row) * D + j0 + cc] = s;
+            Pp[((size_t)blockIdx.y * nrows + row) * mrows + j0 + cc] = s;
         }
     }
 }
@@ -700,6 +702,32 @@ static int chk(const char* what) {
     return GSMVI_OK;
 }
 
+// Pp[kc][B][mrows] partial slabs of A M^T (A: B x D, M: mrows x D); *kc_out slabs.
+int gsmvi_panel_t_product(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* A, int lda, const double* M,
+                          int ldm, int mrows, double* Pp, int* kc_out) {
+    const int MT = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+    const int CH = (MT == 4) ? 128 : 256;
+    const bool fast_t = !ctx->tune_no_fast && D % 64 == 0 && mrows % 16 == 0 && lda % 2 == 0 && ldm % 2 == 0 &&
+                        (reinterpret_cast<uintptr_t>(A) & 15u) == 0 && (reinterpret_cast<uintptr_t>(M) & 15u) == 0;
+    const int strips = (mrows + 15) / 16, nchunks = (D + CH - 1) / CH, zb = (B + 16 * MT - 1) / (16 * MT);
+    int kc = (2 * ctx->num_cu + strips * zb - 1) / (strips * zb);
+    if (kc > nchunks) kc = nchunks;
+    if (kc > GSMVI_MAX_KC) kc = GSMVI_MAX_KC;
+    if (kc < 1) kc = 1;
+    const int cpw = (nchunks + kc - 1) / kc;
+    kc = (nchunks + cpw - 1) / cpw;
+    *kc_out = kc;
+    const dim3 grid(strips, kc, zb);
+    if (fast_t) {
+        if (MT == 1) hipLaunchKernelGGL((k_panel_t_fast<1, 256>), grid, dim3(512), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
+        else if (MT == 2) hipLaunchKernelGGL((k_panel_t_fast<2, 256>), grid, dim3(512), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
+        else hipLaunchKernelGGL((k_panel_t_fast<4, 128>), grid, dim3(512), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
+    } else if (MT == 1) hipLaunchKernelGGL((k_panel_t<1, 256>), grid, dim3(256), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
+    else if (MT == 2) hipLaunchKernelGGL((k_panel_t<2, 256>), grid, dim3(256), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
+    else hipLaunchKernelGGL((k_panel_t<4, 128>), grid, dim3(256), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
+    return chk("k_panel_t");
+}
+
 int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
                       const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double* mu, double* F,
                       int ldf, int* info_dev) {
@@ -717,26 +745,8 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
     int* info_t = ctx->ints + 1;
 
     // W = G Fm^T
-    const int MT = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
-    const int CH = (MT == 4) ? 128 : 256;
-    const bool fast_t = !ctx->tune_no_fast && D % 64 == 0 && ldg % 2 == 0 && ldf0 % 2 == 0 &&
-                        (reinterpret_cast<uintptr_t>(G) & 15u) == 0 && (reinterpret_cast<uintptr_t>(F0) & 15u) == 0;
-    const int strips = (D + 15) / 16, nchunks = (D + CH - 1) / CH, zb = (B + 16 * MT - 1) / (16 * MT);
-    int kc = (2 * ctx->num_cu + strips * zb - 1) / (strips * zb);
-    if (kc > nchunks) kc = nchunks;
-    if (kc > GSMVI_MAX_KC) kc = GSMVI_MAX_KC;
-    if (kc < 1) kc = 1;
-    const int cpw = (nchunks + kc - 1) / kc;
-    kc = (nchunks + cpw - 1) / cpw;
-    const dim3 grid(strips, kc, zb);
-    if (fast_t) {
-        if (MT == 1) hipLaunchKernelGGL((k_panel_t_fast<1, 256>), grid, dim3(512), 0, st, D, B, G, ldg, F0, ldf0, ctx->pp, cpw);
-        else if (MT == 2) hipLaunchKernelGGL((k_panel_t_fast<2, 256>), grid, dim3(512), 0, st, D, B, G, ldg, F0, ldf0, ctx->pp, cpw);
-        else hipLaunchKernelGGL((k_panel_t_fast<4, 128>), grid, dim3(512), 0, st, D, B, G, ldg, F0, ldf0, ctx->pp, cpw);
-    } else if (MT == 1) hipLaunchKernelGGL((k_panel_t<1, 256>), grid, dim3(256), 0, st, D, B, G, ldg, F0, ldf0, ctx->pp, cpw);
-    else if (MT == 2) hipLaunchKernelGGL((k_panel_t<2, 256>), grid, dim3(256), 0, st, D, B, G, ldg, F0, ldf0, ctx->pp, cpw);
-    else hipLaunchKernelGGL((k_panel_t<4, 128>), grid, dim3(256), 0, st, D, B, G, ldg, F0, ldf0, ctx->pp, cpw);
-    int rc = chk("k_panel_t");
+    int kc = 1;
+    int rc = gsmvi_panel_t_product(ctx, st, D, B, G, ldg, F0, ldf0, D, ctx->pp, &kc);
     if (rc) return rc;
     {
         const int ept = (D + 1023) / 1024;

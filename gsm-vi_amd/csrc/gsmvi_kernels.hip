@@ -186,7 +186,10 @@ __global__ __launch_bounds__(256) void k_gsm_cov_update(int D, int B, const doub
                                                         const double* __restrict__ mu0,
                                                         const double* __restrict__ S0, int lds0,
                                                         double* __restrict__ S, int lds,
-                                                        double* __restrict__ mu_out, int SB, int s_vec_ok) {
+                                                        double* __restrict__ mu_out, int SB, int s_vec_ok,
+                                                        int row0, int nrows) {
+    // Row-block form: S0/S point at rows [row0, row0+nrows) of the matrix (the full matrix is row0 = 0,
+    // nrows = D); tiles cover nrows x D, the records are indexed with global rows.
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int KCH = 2 * SB;
     const int KR = (KCH + 31) & ~31;
@@ -208,12 +211,12 @@ __global__ __launch_bounds__(256) void k_gsm_cov_update(int D, int B, const doub
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = I0 + 32 * wr + 16 * rt + ks + 4 * r;
-            if (s_vec_ok && row < D && col + 1 < D) {
+            if (s_vec_ok && row < nrows && col + 1 < D) {
                 s0[rt][r] = *reinterpret_cast<const v2d*>(S0 + (size_t)row * lds0 + col);
             } else {
                 v2d t = {0.0, 0.0};
-                if (row < D && col < D) t.x = S0[(size_t)row * lds0 + col];
-                if (row < D && col + 1 < D) t.y = S0[(size_t)row * lds0 + col + 1];
+                if (row < nrows && col < D) t.x = S0[(size_t)row * lds0 + col];
+                if (row < nrows && col + 1 < D) t.y = S0[(size_t)row * lds0 + col + 1];
                 s0[rt][r] = t;
             }
         }
@@ -231,8 +234,8 @@ __global__ __launch_bounds__(256) void k_gsm_cov_update(int D, int B, const doub
             double dI = 0.0, eI = 0.0, dJ = 0.0, eJ = 0.0;
             if (bl < nb) {
                 const double* rb = rec + (size_t)b * ldrec;
-                const int gi = I0 + ii, gj = J0 + ii;
-                if (gi < D) { dI = rb[gi]; eI = rb[D + gi]; }
+                const int gi = row0 + I0 + ii, gj = J0 + ii;
+                if (I0 + ii < nrows) { dI = rb[gi]; eI = rb[D + gi]; }
                 if (gj < D) { dJ = rb[gj]; eJ = rb[D + gj]; }
             }
             FA[ii * RSA + bl] = dI;
@@ -264,16 +267,16 @@ __global__ __launch_bounds__(256) void k_gsm_cov_update(int D, int B, const doub
             v2d o;
             o.x = s0[rt][r].x + acc[rt][0][r];
             o.y = s0[rt][r].y + acc[rt][1][r];
-            if (s_vec_ok && row < D && col + 1 < D) {
+            if (s_vec_ok && row < nrows && col + 1 < D) {
                 *reinterpret_cast<v2d*>(S + (size_t)row * lds + col) = o;
             } else {
-                if (row < D && col < D) S[(size_t)row * lds + col] = o.x;
-                if (row < D && col + 1 < D) S[(size_t)row * lds + col + 1] = o.y;
+                if (row < nrows && col < D) S[(size_t)row * lds + col] = o.x;
+                if (row < nrows && col + 1 < D) S[(size_t)row * lds + col + 1] = o.y;
             }
         }
 
-    if (ti == tj) {                                // new mean, by the diagonal workgroups
-        const int gi = I0 + l;
+    if (ti == 0 && mu_out != nullptr) {            // new mean (all D entries), by the first row of workgroups
+        const int gi = J0 + l;
         double part = 0.0;
         if (gi < D)
             for (int b = w; b < B; b += 4) part += rec[(size_t)b * ldrec + 2 * D + gi];
@@ -350,10 +353,10 @@ hipError_t gsmvi_cov_update_prepare() {
 
 void gsmvi_launch_gsm_cov_update(hipStream_t st, hipEvent_t* ev, int D, int B, const double* rec, int ldrec,
                                  const double* mu0, const double* S0, int lds0, double* S, int lds, double* mu_out,
-                                 int SB, int s_vec_ok) {
-    const int nt = (D + 63) / 64;
-    GSMVI_LAUNCH(k_gsm_cov_update, dim3(nt * nt), dim3(256), gsmvi_cov_update_lds_bytes(SB), st, ev, D, B, rec,
-                 ldrec, mu0, S0, lds0, S, lds, mu_out, SB, s_vec_ok);
+                                 int SB, int s_vec_ok, int row0, int nrows) {
+    const int nt = (D + 63) / 64, ntr = (nrows + 63) / 64;
+    GSMVI_LAUNCH(k_gsm_cov_update, dim3(ntr * nt), dim3(256), gsmvi_cov_update_lds_bytes(SB), st, ev, D, B, rec,
+                 ldrec, mu0, S0, lds0, S, lds, mu_out, SB, s_vec_ok, row0, nrows);
 }
 
 void gsmvi_launch_commit(hipStream_t st, int D, const int* info, const double* mu_new, const double* S_new,

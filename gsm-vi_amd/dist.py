@@ -44,6 +44,43 @@ def sharded_gsm_update(eng, X_local, G_local, mu0, S0, group=None, rec_all=None,
     return eng.gsm_apply(rec, mu0, S0, out=out)
 
 
+def row_bounds(D, world, rank):
+    """Rows [lo, hi) of the covariance owned by ``rank``: blocks of ceil(D / world) rows, the last one ragged
+    (possibly empty ranks are not supported: D >= world)."""
+    per = -(-D // world)
+    lo = min(rank * per, D)
+    return lo, min(lo + per, D)
+
+
+def row_sharded_gsm_update(eng, X, G, mu0, S0_rows, group=None, out=None):
+    """gsm_update with the covariance sharded by ROW BLOCKS.
+
+    Every rank holds rows ``row_bounds(D, P, r)`` of S0 and gets back (mu, S_rows): the full new mean and the
+    same rows of the new covariance.  X, G, mu0 are replicated.  The only exchange is an all-gather of the
+    owned COLUMNS of SG = G S0 (B x D/P doubles per rank: 256 KiB at D=4096, B=64, P=8); the D^2-sized reads
+    and writes -- the HBM-bound part -- are divided by P, unlike the batch-sharded form above."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B, D = X.shape
+    lo, hi = row_bounds(D, world, rank)
+    assert S0_rows.shape == (hi - lo, D), f"rank {rank} must hold rows [{lo}, {hi}) of S0"
+    SGc = eng.gsm_rows_stage(G, S0_rows)
+    if world == 1:
+        SG = SGc
+    else:
+        per = -(-D // world)
+        send = eng.zeros(B, per)
+        send[:, :hi - lo] = SGc
+        recv = eng.empty(world * B, per)
+        dist.all_gather_into_tensor(_as_torch(recv), _as_torch(send), group=group)
+        SG = eng.empty(B, D)
+        for p in range(world):
+            plo, phi = row_bounds(D, world, p)
+            SG[:, plo:phi] = recv[p * B:(p + 1) * B, :phi - plo]
+    rec = eng.gsm_records(X, G, mu0, SG)
+    return eng.gsm_apply_rows(rec, mu0, S0_rows, lo, out=out)
+
+
 def sharded_bam_update(eng, X_local, G_local, mu0, S0, reg, jitter=0.0, group=None, out=None, flag=None):
     """(mu, S, flag) of the BaM update for the union of all ranks' samples (gsmvi/bam.py:72-114;
     BASELINE config 4: B=128 sharded 16 per GPU).  BaM's statistics couple all samples (batch means

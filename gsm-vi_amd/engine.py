@@ -173,6 +173,50 @@ class HipEngine:
             ps, lds))
         return mu, S
 
+    # ---- row-block sharded covariance ---------------------------------
+    def gsm_rows_stage(self, G, S0_rows, out=None):
+        """Columns [row0, row0+nrows) of G S0 from the owned row block of the symmetric S0 (gsm_numpy.py:7)."""
+        B, D = G.shape
+        nr = S0_rows.shape[0]
+        assert S0_rows.shape == (nr, D)
+        self._ensure(D, B)
+        SGc = self.empty(B, nr) if out is None else out
+        pg, ldg = self._mat(G, "vs")
+        ps0, lds0 = self._mat(S0_rows, "S0_rows")
+        po, ldo = self._mat(SGc, "SGcols")
+        _lib.check("gsmvi_gsm_rows_stage_f64", self.lib.gsmvi_gsm_rows_stage_f64(
+            self._ctx, self._stream(), D, B, nr, pg, ldg, ps0, lds0, po, ldo))
+        return SGc
+
+    def gsm_records(self, X, G, mu0, SG, out=None):
+        """Records [d | e | dmu] of all samples from the gathered SG = G S0 (gsm_numpy.py:8-17)."""
+        B, D = X.shape
+        assert SG.shape == (B, D) and SG.is_contiguous()
+        self._ensure(D, B)
+        rec = self.empty(B, self.record_len(D)) if out is None else out
+        px, ldx = self._mat(X, "samples")
+        pg, ldg = self._mat(G, "vs")
+        pr, ldr = self._mat(rec, "rec")
+        _lib.check("gsmvi_gsm_records_f64", self.lib.gsmvi_gsm_records_f64(
+            self._ctx, self._stream(), D, B, px, ldx, pg, ldg, self._vec(mu0, "mu0"), C.c_void_p(SG.data_ptr()),
+            pr, ldr))
+        return rec
+
+    def gsm_apply_rows(self, rec, mu0, S0_rows, row0, out=None):
+        """(mu, S_rows): the rank-2B update restricted to the owned rows, and the full new mean."""
+        B = rec.shape[0]
+        D = mu0.shape[0]
+        nr = S0_rows.shape[0]
+        self._ensure(D, B)
+        mu, S = (self.empty(D), self.empty(nr, D)) if out is None else out
+        pr, ldr = self._mat(rec, "rec")
+        ps0, lds0 = self._mat(S0_rows, "S0_rows")
+        ps, lds = self._mat(S, "S_rows")
+        _lib.check("gsmvi_gsm_apply_rows_f64", self.lib.gsmvi_gsm_apply_rows_f64(
+            self._ctx, self._stream(), D, B, int(row0), nr, pr, ldr, self._vec(mu0, "mu0"), ps0, lds0,
+            self._vec(mu, "mu"), ps, lds))
+        return mu, S
+
     def gsm_factor_update(self, Z, X, G, mu0, F0, out=None, flag=None):
         """Factor-form update: Sigma = F^T F, X = mu0 + Z F0.  Returns (mu, F, flag); flag != 0 means
         the 2B x 2B positive-definite test failed and (mu, F) = (mu0, F0) (revert)."""

@@ -97,6 +97,26 @@ int gsmvi_gsm_apply_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
                         const double* S0, int lds0, double* mu, double* S, int lds);
 
 /*
+ * The same update with the covariance sharded by ROW BLOCKS (the decomposition that divides
+ * the HBM-bound passes by the number of GPUs).  A rank owns rows [row0, row0 + nrows) of S0 as an
+ * nrows x D row-major block; X, G, mu0 are replicated.
+ *   rows stage : SGcols (B x nrows, ldsg) = G S0rows^T, i.e. columns [row0, row0+nrows) of G S0 (S0 symmetric,
+ *                gsm_numpy.py:7).  The caller all-gathers the column slices into SG (B x D, contiguous);
+ *   records    : per-sample scalars of gsm_numpy.py:8-17 from the gathered SG -> records as above (replicated);
+ *   apply rows : Srows = S0rows + (1/B) sum_b (d_b d_b^T - e_b e_b^T)[row0 : row0+nrows, :], and the full new
+ *                mean when mu != NULL.
+ */
+int gsmvi_gsm_rows_stage_f64(gsmvi_ctx* ctx, void* stream, int D, int B, int nrows,
+                             const double* G, int ldg, const double* S0rows, int lds0,
+                             double* SGcols, int ldsg);
+int gsmvi_gsm_records_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
+                          const double* X, int ldx, const double* G, int ldg, const double* mu0,
+                          const double* SG, double* rec, int ldrec);
+int gsmvi_gsm_apply_rows_f64(gsmvi_ctx* ctx, void* stream, int D, int B, int row0, int nrows,
+                             const double* rec, int ldrec, const double* mu0,
+                             const double* S0rows, int lds0, double* mu, double* Srows, int lds);
+
+/*
  * Factor-form GSM update (BASELINE config 5): the state is a square factor Fm with
  * Sigma = Fm^T Fm; Z (B x D) are the whitened draws behind the samples X = 1 mu0^T + Z F0, G = lp_g(X).
  * Produces (mu, F) with F^T F equal to the covariance gsm_numpy.gsm_update would return for

@@ -79,6 +79,41 @@ class OracleEngine:
             return out
         return mu, S
 
+    def gsm_rows_stage(self, G, S0_rows, out=None):
+        SGc = G @ S0_rows.T
+        if out is not None:
+            out[...] = SGc
+            return out
+        return SGc
+
+    def gsm_records(self, X, G, mu0, SG, out=None):
+        D = mu0.shape[0]
+        d = mu0[None, :] - X
+        gSg = np.einsum("bi,bi->b", G, SG)
+        mv = np.einsum("bi,bi->b", d, G)
+        rho = 0.5 * np.sqrt(1.0 + 4.0 * (gSg + mv * mv)) - 0.5
+        den = 1.0 + rho + mv
+        dmu = ((SG - d) - d * ((gSg - mv) / den)[:, None]) / (1.0 + rho)[:, None]
+        rec = np.zeros((X.shape[0], self.record_len(D)))
+        rec[:, :D], rec[:, D:2 * D], rec[:, 2 * D:3 * D] = d, d + dmu, dmu
+        if out is not None:
+            out[...] = rec
+            return out
+        return rec
+
+    def gsm_apply_rows(self, rec, mu0, S0_rows, row0, out=None):
+        D = mu0.shape[0]
+        B = rec.shape[0]
+        nr = S0_rows.shape[0]
+        d, e, dmu = rec[:, :D], rec[:, D:2 * D], rec[:, 2 * D:3 * D]
+        mu = mu0 + dmu.mean(axis=0)
+        S = S0_rows + (d[:, row0:row0 + nr].T @ d - e[:, row0:row0 + nr].T @ e) / B
+        if out is not None:
+            out[0][...] = mu
+            out[1][...] = S
+            return out
+        return mu, S
+
     def gsm_factor_update(self, Z, X, G, mu0, F0, out=None, flag=None):
         flag = Flag() if flag is None else flag
         mu, Fo, ok = orc.gsm_factor_update(Z, G, mu0, F0.T)      # oracle convention: Sigma = F F^T

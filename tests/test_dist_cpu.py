@@ -55,6 +55,14 @@ def _worker(rank, world, port, q):
             7, niter=30, batch_size=4, verbose=False)
         assert set(seen) == {4 // world}
         err = max(err, np.abs(mean_s - mean_1).max(), np.abs(cov_s - cov_1).max())
+        # row-block sharded covariance (ragged: D = 25 rows over 2 ranks = 13 + 12)
+        from gsmvi_amd.dist import row_sharded_gsm_update, row_bounds
+        st = orc.make_update_state(25, 6, 5)
+        rlo, rhi = row_bounds(25, world, rank)
+        mu_r, S_r = row_sharded_gsm_update(eng, st["samples"], st["vs"], st["mu0"], st["S0"][rlo:rhi].copy())
+        mu_o, S_o = orc.gsm_update_faithful(st["samples"], st["vs"], st["mu0"], st["S0"])
+        assert S_r.shape == (rhi - rlo, 25)
+        err = max(err, np.abs(mu_r - mu_o).max(), np.abs(S_r - S_o[rlo:rhi]).max())
         q.put((rank, float(err), bool(same)))
     finally:
         dist.destroy_process_group()
@@ -74,6 +82,27 @@ def test_sharded_update_world2_gloo():
         assert p.exitcode == 0
     for rank, err, same in res:
         assert err < 1e-12 and same, (rank, err, same)
+
+
+def test_row_bounds_cover_and_are_ragged_at_the_end():
+    from gsmvi_amd.dist import row_bounds
+    for D, P in ((25, 2), (1024, 8), (10, 3), (4096, 8), (7, 7)):
+        b = [row_bounds(D, P, r) for r in range(P)]
+        assert b[0][0] == 0 and b[-1][1] == D
+        assert all(b[i][1] == b[i + 1][0] for i in range(P - 1))
+        assert all(hi - lo == -(-D // P) for lo, hi in b[:-1])
+
+
+def test_row_sharded_update_single_process_equals_oracle():
+    """world = 1 (no process group): the three row-block stages with the oracle-backed engine."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import gsm_oracle as orc
+    from engines import OracleEngine
+    from gsmvi_amd.dist import row_sharded_gsm_update
+    st = orc.make_update_state(17, 4, 2)
+    mu, S = row_sharded_gsm_update(OracleEngine(), st["samples"], st["vs"], st["mu0"], st["S0"])
+    mu_o, S_o = orc.gsm_update_faithful(st["samples"], st["vs"], st["mu0"], st["S0"])
+    assert np.abs(mu - mu_o).max() < 1e-12 and np.abs(S - S_o).max() < 1e-12
 
 
 def test_shard_bounds():
