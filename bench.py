@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--tune", action="append", default=[], help="name=value launch knob (experiments)")
+    ap.add_argument("--shard", choices=("batch", "rows"), default="batch",
+                    help="N>1 decomposition: batch (north_star; records all-gathered) or covariance row blocks "
+                         "(SURVEY 8(f)3; SG column slices all-gathered, D^2 passes divided by N)")
     return ap.parse_args()
 
 
@@ -125,7 +128,7 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import gsmvi_amd
-    from gsmvi_amd.dist import sharded_gsm_update, shard_bounds
+    from gsmvi_amd.dist import sharded_gsm_update, shard_bounds, row_sharded_gsm_update, row_bounds
     eng = gsmvi_amd.get_engine(local_rank)
     for kv in args.tune:
         k, v = kv.split("=")
@@ -136,11 +139,19 @@ def main():
     inst, m, P = make_instances(eng, D, B, n_inst)
     lo, hi = shard_bounds(B, world, rank)
     rec_all = eng.empty(B, eng.record_len(D)) if use_dist else None
+    rows = use_dist and args.shard == "rows"
+    if rows:                                 # every rank keeps only its row block of each covariance
+        rlo, rhi = row_bounds(D, world, rank)
+        for it in inst:
+            it["S0r"] = it["S0"][rlo:rhi].contiguous()
+            it["Sr"] = eng.empty(rhi - rlo, D)
 
     def step(k):
         it = inst[k % n_inst]
         if not use_dist:
             eng.gsm_update(it["X"], it["G"], it["mu0"], it["S0"], out=(it["mu"], it["S"]))
+        elif rows:
+            row_sharded_gsm_update(eng, it["X"], it["G"], it["mu0"], it["S0r"], out=(it["mu"], it["Sr"]))
         else:
             sharded_gsm_update(eng, it["X"][lo:hi], it["G"][lo:hi], it["mu0"], it["S0"], rec_all=rec_all,
                                out=(it["mu"], it["S"]), force_collective=True)
@@ -277,7 +288,9 @@ def main():
            "config": {"workload": f"BASELINE configs[2]: D={D} dense-cov Gaussian target, B={B}, one GSM update "
                                   f"per step", "D": D, "B": B, "instances": n_inst,
                       "ring_bytes": n_inst * per_inst, "launch": launch,
-                      "parallelism": "single GPU" if not use_dist else f"batch-sharded x{world} + RCCL all-gather"},
+                      "parallelism": "single GPU" if not use_dist else
+                      (f"covariance row blocks x{world} + RCCL all-gather of SG column slices" if rows else
+                       f"batch-sharded x{world} + RCCL all-gather")},
            "value_cache_resident": value_hot, "fit_iterations_per_s": fit_rate, "roofline": roofline}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(D, B, args.cpu_seconds)

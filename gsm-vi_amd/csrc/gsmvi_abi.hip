@@ -188,6 +188,7 @@ int gsmvi_destroy(gsmvi_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (int k = 0; k < 8; ++k)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     hipError_t e = hipFree(ctx->ws);
     delete ctx;
     if (e != hipSuccess) {

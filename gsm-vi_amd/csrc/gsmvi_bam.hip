@@ -16,7 +16,11 @@
 // eigen-solve (N itself enters BB exactly) and BB^-1 is applied by triangular substitution, never
 // as an explicit inverse: with cond(N) ~ 1e7 the explicit-inverse form loses 3 digits.
 // Everything of size D runs in HIP kernels; S0 is read twice and S written once.
+#include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "gsmvi_common.h"
@@ -93,6 +97,126 @@ __global__ __launch_bounds__(64) void k_bam_forward(int D, int n, const double* 
         const double r1 = reg / (1.0 + reg);
         const double s0g = P[(size_t)(n - 1) * D + i] / sqrt(r1);        // (S0 gbar)_i = P[n-1][i]/sqrt(r1)
         mu[i] = mu0[i] / (1.0 + reg) + r1 * (s0g + dot_v - dot_z + xbar[i]);
+    }
+}
+
+// ---- N = M1^T M1 + sym(N0) and M1^T (n x n), on the device ---------------------------------------
+__global__ __launch_bounds__(256) void k_bam_nmat(int n, const double* __restrict__ M1,
+                                                  const double* __restrict__ N0, double* __restrict__ Nm,
+                                                  double* __restrict__ M1T) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * n) return;
+    const int i = idx / n, j = idx % n;
+    double s0 = 0.0, s1 = 0.0;
+    int k = 0;
+    for (; k + 1 < n; k += 2) {
+        s0 += M1[(size_t)k * n + i] * M1[(size_t)k * n + j];
+        s1 += M1[(size_t)(k + 1) * n + i] * M1[(size_t)(k + 1) * n + j];
+    }
+    if (k < n) s0 += M1[(size_t)k * n + i] * M1[(size_t)k * n + j];
+    Nm[idx] = (s0 + s1) + 0.5 * (N0[(size_t)i * n + j] + N0[(size_t)j * n + i]);
+    M1T[idx] = M1[(size_t)j * n + i];
+}
+
+// ---- Z = L^-1 (P + T1), T1 = M1^T Vf precomputed by the panel product, n <= 144 -----------------------
+// Sixteen lanes per column of D, 16 columns per workgroup.  Lane q of a column group owns rows q, q+16, ...
+// (9 registers).  U = L^T is staged in LDS in packed upper form (row p holds L[p..n-1][p], contiguous, so the
+// lanes of a group read consecutive words); pivot p is broadcast inside the group with one shuffle.
+// T1 arrives in rows n..2n-1 of Fs and is overwritten there with -Z by the lane that read it.
+#define BAMF_NMAX 144
+__global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const double* __restrict__ P,
+                                                       const double* __restrict__ Upk,
+                                                       const double* __restrict__ Ldinv,
+                                                       const double* __restrict__ zg, const double* __restrict__ vg,
+                                                       const double* __restrict__ mu0,
+                                                       const double* __restrict__ xbar, double reg,
+                                                       double* __restrict__ Ft, double* __restrict__ Fs,
+                                                       double* __restrict__ mu) {
+    __shared__ __attribute__((aligned(16))) double U[BAMF_NMAX * (BAMF_NMAX + 1) / 2];
+    __shared__ double sdi[BAMF_NMAX], szg[BAMF_NMAX], svg[BAMF_NMAX];
+    const int tid = threadIdx.x, c = tid >> 4, q = tid & 15, grp = tid & 48;
+    const int j = blockIdx.x * 16 + c, jc = j < D ? j : D - 1;
+    const int npk = n * (n + 1) / 2;
+    {
+        constexpr int PER = (BAMF_NMAX * (BAMF_NMAX + 1) / 2 + 255) / 256;       // 41
+#pragma unroll
+        for (int it0 = 0; it0 < PER; it0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * (it0 + u);
+                v[u] = Upk[e < npk ? e : npk - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + 256 * (it0 + u);
+                if (e < npk) U[e] = v[u];
+            }
+        }
+        if (tid < BAMF_NMAX) {
+            const int r = tid < n ? tid : n - 1;
+            sdi[tid] = Ldinv[r];
+            szg[tid] = tid < n ? zg[r] : 0.0;
+            svg[tid] = tid < n ? vg[r] : 0.0;
+        }
+    }
+    double x[9], vf[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int r = q + 16 * i, rc = r < n ? r : n - 1;
+        const double a = P[(size_t)rc * D + jc] + Fs[(size_t)(n + rc) * D + jc];
+        x[i] = r < n ? a : 0.0;
+        vf[i] = r < n ? Ft[(size_t)rc * D + jc] : 0.0;
+    }
+    __syncthreads();
+    // forward substitution; the 16 pivots of a block stay a rolled loop (static register index = block)
+#pragma unroll
+    for (int pb = 0; pb < 9; ++pb) {
+        if (16 * pb >= n) break;                                  // uniform
+#pragma unroll 2
+        for (int pq = 0; pq < 16; ++pq) {
+            const int p = 16 * pb + pq;
+            if (p >= n) break;                                    // uniform
+            const double mine = x[pb] * sdi[p];
+            if (q == pq) x[pb] = mine;
+            const double xp = __shfl(mine, grp | pq, 64);
+            // row p of U starts at p*n - p(p-1)/2 and holds columns p..n-1
+            const double* row = U + (p * n - (p * (p - 1)) / 2) - p + q;
+            {
+                const int t = q + 16 * pb;
+                const double uv = row[16 * pb < n - q ? 16 * pb : 0];
+                x[pb] -= (t > p && t < n) ? uv * xp : 0.0;
+            }
+#pragma unroll
+            for (int i = pb + 1; i < 9; ++i) {
+                const int t = q + 16 * i;
+                const double uv = row[t < n ? 16 * i : 0];
+                x[i] -= (t < n) ? uv * xp : 0.0;
+            }
+        }
+    }
+    double dot_z = 0.0, dot_v = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int r = q + 16 * i;
+        if (r < n) {
+            dot_z += x[i] * szg[r];
+            dot_v += vf[i] * svg[r];
+            if (j < D) {
+                Ft[(size_t)(n + r) * D + j] = x[i];
+                Fs[(size_t)(n + r) * D + j] = -x[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+        dot_z += __shfl_xor(dot_z, m, 64);
+        dot_v += __shfl_xor(dot_v, m, 64);
+    }
+    if (q == 0 && j < D) {
+        const double r1 = reg / (1.0 + reg);
+        const double s0g = P[(size_t)(n - 1) * D + j] / sqrt(r1);        // (S0 gbar)_j = P[n-1][j]/sqrt(r1)
+        mu[j] = mu0[j] / (1.0 + reg) + r1 * (s0g + dot_v - dot_z + xbar[j]);
     }
 }
 
@@ -196,14 +320,17 @@ __global__ __launch_bounds__(256) void k_lowrank_update(int D, int KF, const dou
 // ---- host: eigen-decomposition of a symmetric n x n matrix (row-major) -------------------------------
 // Householder tridiagonalisation followed by the implicit-shift QL iteration (the classic EISPACK
 // tred2 / tql2 pair; O(n^3) with a small constant: ~10x fewer flops than cyclic Jacobi at n = 129).
-// A is destroyed; on return w = eigenvalues (ascending), E = eigenvectors in COLUMNS (row-major n x n).
+// A is destroyed; on return w = eigenvalues (ascending), E = eigenvectors in ROWS (row-major n x n).
+// The work matrix is addressed column-major (the input is symmetric, so that is free): every O(n^3) loop of
+// tred2 then runs down a contiguous column, and its result is already the row-per-eigenvector layout the
+// QL rotations want.
 static bool sym_eigh(int n, std::vector<double>& A, std::vector<double>& w, std::vector<double>& E) {
     for (size_t k = 0; k < (size_t)n * n; ++k)
         if (!(A[k] == A[k]) || std::fabs(A[k]) > 1.7e308) return false;          // NaN / inf
     std::vector<double>& V = E;
     V = A;
     std::vector<double> d(n), e(n);
-#define Vij(i, j) V[(size_t)(i) * n + (j)]
+#define Vij(i, j) V[(size_t)(j) * n + (i)]
     // ---- tred2 ----
     for (int j = 0; j < n; ++j) d[j] = Vij(n - 1, j);
     for (int i = n - 1; i > 0; --i) {
@@ -275,10 +402,8 @@ static bool sym_eigh(int n, std::vector<double>& A, std::vector<double>& w, std:
     }
     Vij(n - 1, n - 1) = 1.0;
     e[0] = 0.0;
-    // ---- tql2 (eigenvectors kept TRANSPOSED while rotating: a rotation touches two contiguous rows) ----
-    std::vector<double> Vt((size_t)n * n);
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) Vt[(size_t)j * n + i] = Vij(i, j);
+    // ---- tql2 (row j of the storage = column j of V: a rotation touches two contiguous rows) ----
+    std::vector<double>& Vt = V;
     for (int i = 1; i < n; ++i) e[i - 1] = e[i];
     e[n - 1] = 0.0;
     double f = 0.0, tst1 = 0.0;
@@ -337,8 +462,6 @@ static bool sym_eigh(int n, std::vector<double>& A, std::vector<double>& w, std:
         d[l] = d[l] + f;
         e[l] = 0.0;
     }
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) Vij(i, j) = Vt[(size_t)j * n + i];
 #undef Vij
     w = d;
     return true;
@@ -374,6 +497,7 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
                    int ldg, const double* mu0, const double* S0, int lds0, double reg, double jitter, double* mu,
                    double* S, int lds, int* info_dev) {
     const int n = B + 1, n2 = 2 * n, nq = (n + 1) & ~1;
+    const auto t_entry = std::chrono::steady_clock::now();
     // workspace carve (ctx->sg holds 4*rmax*max_D doubles, rmax = 2B+8 >= 2n+6)
     double* Qt = ctx->sg;                          // n x D
     double* P = Qt + (size_t)n * D;                // n x D
@@ -396,31 +520,58 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, n, n, P, D, nullptr, 1.0, Qm, nq, ctx->pp, &kc))) return rc;
     if ((rc = gsmvi_panel_finish(st, n, n, kc, ctx->pp, nullptr, N0, n))) return rc;
 
+    // N = M1^T M1 + sym(N0) and M1^T on the device; then the three n x n blocks go to the host
+    double* Nd = Ld + (size_t)n * n + 3 * n;       // n x n
+    double* M1T = Nd + (size_t)n * n;              // n x n
+    double* Upk = M1T + (size_t)n * n;             // n(n+1)/2: packed rows of L^T
+    hipLaunchKernelGGL(k_bam_nmat, dim3((n * n + 255) / 256), dim3(256), 0, st, n, M1, N0, Nd, M1T);
+    static const bool timing = getenv("GSMVI_BAM_TIMING") != nullptr;     // diagnostic: host phase times on stderr
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t_0 = tnow();
     // ---- host: the (B+1) x (B+1) matrix function (bam.py:108-110) ----
-    std::vector<double> h((size_t)2 * n * n);
-    HIPCHK(hipMemcpyAsync(h.data(), M1, sizeof(double) * 2 * n * n, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    const double* hM1 = h.data();
-    const double* hN0 = h.data() + (size_t)n * n;
+    // pinned staging: [M1 | N0 | N] down, [L | Ldinv | zg | vg | packed L^T] up.  (Pageable buffers make the
+    // copies take the runtime's blocking staging path: 2.2 ms per call became 5+ ms when calls were queued
+    // back to back.)
+    const size_t npk = (size_t)n * (n + 1) / 2;
+    const size_t n_down = (size_t)3 * n * n, n_up = (size_t)n * n + 3 * n + npk;
+    if (ctx->h_pin_doubles < n_down + n_up + 2) {
+        if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+        ctx->h_pin = nullptr;
+        ctx->h_pin_doubles = 0;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), (n_down + n_up + 2) * sizeof(double), hipHostMallocDefault));
+        ctx->h_pin_doubles = n_down + n_up + 2;
+    }
+    double* h = ctx->h_pin;
+    if (ctx->h_pin_busy) {                         // previous call's uploads may have been queued on another stream
+        HIPCHK(hipEventSynchronize(ctx->ev[7]));
+        ctx->h_pin_busy = 0;
+    }
     std::vector<double> N((size_t)n * n), w, E;
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
-            double s = 0.0;
-            for (int k = 0; k < n; ++k) s += hM1[(size_t)k * n + i] * hM1[(size_t)k * n + j];
-            N[(size_t)i * n + j] = s + 0.5 * (hN0[(size_t)i * n + j] + hN0[(size_t)j * n + i]);
-        }
+    HIPCHK(hipMemcpyAsync(h, M1, sizeof(double) * 2 * n * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h + (size_t)2 * n * n, Nd, sizeof(double) * n * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::copy(h + (size_t)2 * n * n, h + (size_t)3 * n * n, N.begin());
+    const double* hM1 = h;
+    const double* hN0 = h + (size_t)n * n;
+    const auto t_1 = tnow();
     int bad = 0;
     std::vector<double> Nc = N;
     if (!sym_eigh(n, Nc, w, E)) bad = 1;
+    const auto t_2 = tnow();
     // BB = N + I/2 + E sqrt(w + 1/4) E^T
     std::vector<double> BBm = N;
     if (!bad) {
         for (int i = 0; i < n; ++i) BBm[(size_t)i * n + i] += 0.5;
         for (int k = 0; k < n; ++k) {
             const double sq = sqrt((w[k] > 0.0 ? w[k] : 0.0) + 0.25);
+            const double* ek = &E[(size_t)k * n];
             for (int i = 0; i < n; ++i) {
-                const double eik = E[(size_t)i * n + k] * sq;
-                for (int j = 0; j < n; ++j) BBm[(size_t)i * n + j] += eik * E[(size_t)j * n + k];
+                const double eik = ek[i] * sq;
+                double* bi = &BBm[(size_t)i * n];
+                for (int j = 0; j < n; ++j) bi[j] += eik * ek[j];
             }
         }
         for (int i = 0; i < n; ++i)
@@ -430,10 +581,13 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
             }
         if (!host_cholesky(n, BBm)) bad = 1;
     }
-    std::vector<double> up((size_t)n * n + 3 * n, 0.0);      // L, Ldinv, zg, vg
+    const bool lanes16 = n <= BAMF_NMAX;
+    double* up = h + n_down;                                  // L, Ldinv, zg, vg
+    double* upk = up + (size_t)n * n + 3 * n;                 // rows of L^T, packed (k_bam_forward16)
+    std::fill(up, up + n_up, 0.0);
     if (!bad) {
         const double r1s = sqrt(reg / (1.0 + reg));
-        double* hL = up.data();
+        double* hL = up;
         double* hDi = hL + (size_t)n * n;
         double* hzg = hDi + n;
         double* hvg = hzg + n;
@@ -451,19 +605,43 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
             if (!(hzg[r] == hzg[r])) bad = 1;
         }
     }
-    if (bad) {                                       // poison the outputs' inputs so nothing stale is applied
-        for (auto& v : up) v = std::nan("");
+    if (!bad && lanes16) {
+        size_t o = 0;
+        for (int pp = 0; pp < n; ++pp)
+            for (int t = pp; t < n; ++t) upk[o++] = up[(size_t)t * n + pp];
     }
-    HIPCHK(hipMemcpyAsync(Ld, up.data(), sizeof(double) * up.size(), hipMemcpyHostToDevice, st));
-    if (info_dev) HIPCHK(hipMemcpyAsync(info_dev, &bad, sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));             // `up` / `bad` live on this stack frame
+    if (bad) {                                       // poison the outputs' inputs so nothing stale is applied
+        std::fill(up, up + n_up, std::nan(""));
+    }
+    const auto t_3 = tnow();
+    HIPCHK(hipMemcpyAsync(Ld, up, sizeof(double) * ((size_t)n * n + 3 * n), hipMemcpyHostToDevice, st));
+    if (lanes16) HIPCHK(hipMemcpyAsync(Upk, upk, sizeof(double) * npk, hipMemcpyHostToDevice, st));
+    int* h_bad = reinterpret_cast<int*>(h + n_down + n_up);
+    *h_bad = bad;
+    if (info_dev) HIPCHK(hipMemcpyAsync(info_dev, h_bad, sizeof(int), hipMemcpyHostToDevice, st));
+    // no stream synchronisation here: the staging buffer is pinned; the next call waits on this event before
+    // it touches the buffer again
+    HIPCHK(hipEventRecord(ctx->ev[7], st));
+    ctx->h_pin_busy = 1;
+    if (timing)
+        fprintf(stderr, "[gsmvi bam n=%d] device+download %.3f  eigen %.3f  BB+chol+zg %.3f  upload %.3f ms\n", n,
+                tms(t_0, t_1), tms(t_1, t_2), tms(t_2, t_3), tms(t_3, tnow()));
 
     const double* Ldinv = Ld + (size_t)n * n;
-    hipLaunchKernelGGL(k_bam_forward, dim3((D + 63) / 64), dim3(64), sizeof(double) * 2 * n * 64, st, D, n, P, M1, Ld,
-                       Ldinv, Ldinv + n, Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu);
+    if (lanes16) {
+        // T1 = M1^T Vf into rows n..2n-1 of Fs, then the 16-lanes-per-column substitution
+        if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, M1T, n, nullptr, 1.0, Ft, D, ctx->pp, &kc))) return rc;
+        if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, Fs + (size_t)n * D, D))) return rc;
+        hipLaunchKernelGGL(k_bam_forward16, dim3((D + 15) / 16), dim3(256), 0, st, D, n, P, Upk, Ldinv, Ldinv + n,
+                           Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu);
+    } else {
+        hipLaunchKernelGGL(k_bam_forward, dim3((D + 63) / 64), dim3(64), sizeof(double) * 2 * n * 64, st, D, n, P, M1,
+                           Ld, Ldinv, Ldinv + n, Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu);
+    }
     const int nt = (D + 63) / 64;
     hipLaunchKernelGGL(k_lowrank_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds,
                        jitter);
+    if (timing) fprintf(stderr, "[gsmvi bam] entry->t0 %.3f  whole call %.3f ms\n", tms(t_entry, t_0), tms(t_entry, tnow()));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         gsmvi_set_error("BaM launch failed: %s%s", hipGetErrorString(e), "");

@@ -22,6 +22,9 @@ struct gsmvi_ctx {
     int tune_scalars_nt = 0;   // threads per sample in k_gsm_scalars_fast (256/512/1024; 0 = default)
     int tune_no_fast = 0;      // 1 = force the guarded generic kernels (tests)
     int profiling = 0;         // when set, the update kernels are launched with dispatch-timestamp events
+    double* h_pin = nullptr;   // pinned host staging for BaM's small matrices (grown on demand)
+    size_t h_pin_doubles = 0;
+    int h_pin_busy = 0;        // ev[7] marks the end of the last upload from h_pin
     hipEvent_t ev[8] = {};     // [2*stage], [2*stage+1]: panel, scalars, cov-update, spare
     int ev_valid[4] = {};
 

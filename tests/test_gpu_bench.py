@@ -41,3 +41,8 @@ def test_bench_json_contract():
 def test_bench_rccl_path_world1():
     d = _run({"GSMVI_BENCH_FORCE_DIST": "1"}, "--steps", "42", "--warmup", "21", "--no-cpu-baseline")
     assert d["n_gpus"] == 1 and "RCCL" in d["config"]["parallelism"] and d["value"] > 0
+
+
+def test_bench_row_block_path_world1():
+    d = _run({"GSMVI_BENCH_FORCE_DIST": "1"}, "--steps", "42", "--warmup", "21", "--no-cpu-baseline", "--shard", "rows")
+    assert d["n_gpus"] == 1 and "row blocks" in d["config"]["parallelism"] and d["value"] > 0
