@@ -86,10 +86,10 @@ class BaM:
         cov_t = eng.eye(D) if cov is None else eng.clone(cov).reshape(D, D)
         seed = int(np.asarray(key.cpu() if _is_torch(key) else key).flatten()[-1])
         rs = np.random.RandomState(seed)
-        gen = None
-        if rng == "device":
-            gen = torch.Generator(device=eng.device)
-            gen.manual_seed(seed)
+        assert rng in ("numpy", "device"), "rng must be 'numpy' or 'device'"
+        dev_rng = rng == "device"
+        Zbuf = eng.empty(B, D) if dev_rng else None
+        ndraw = 0                       # counter-based stream: one `call` per draw, retries included
         native = bool(getattr(self.lp_g, "device_native", False))
         mon_native = bool(getattr(monitor, "device_native", False)) if monitor is not None else False
 
@@ -128,8 +128,11 @@ class BaM:
                     elif sampler == "svd":
                         X = eng.asarray(_legacy_mvn(rs, eng.to_numpy(mean_t), eng.to_numpy(cov_t), B))
                     else:
-                        Z = eng.normal(B, D, gen) if gen is not None else \
-                            eng.normal_from_host(rs.standard_normal((B, D)))
+                        if dev_rng:
+                            Z = eng.normal(B, D, seed, ndraw, out=Zbuf)
+                            ndraw += 1
+                        else:
+                            Z = eng.normal_from_host(rs.standard_normal((B, D)))
                         X = eng.sample(Z, mean_t, R, out=Xbuf)
                     vs = self.lp_g(X) if native else eng.asarray(self.lp_g(eng.to_numpy(X)))
                     nevals += B

@@ -44,7 +44,7 @@ int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double*
                      int* info_dev);
 int gsmvi_factor_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X,
                       int ldx, const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double* mu,
-                      double* F, int ldf, int* info_dev);
+                      double* F, int ldf, int* info_dev, int* n_reverts_dev);
 int gsmvi_bam_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X, int ldx,
                    const double* G, int ldg, const double* mu0, const double* S0, int lds0, double reg,
                    double jitter, double* mu, double* S, int lds, int* info_dev);
@@ -482,7 +482,7 @@ int gsmvi_potrf_f64(gsmvi_ctx* ctx, void* stream, int D, const double* S, int ld
 
 int gsmvi_gsm_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* Z, int ldz, const double* X,
                                 int ldx, const double* G, int ldg, const double* mu0, const double* F0, int ldf0,
-                                double* mu, double* F, int ldf, int* info_dev) {
+                                double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev) {
     int st = check_common(ctx, D, B, __func__);
     if (st != GSMVI_OK) return st;
     BAD_ARG(!Z || !X || !G || !mu0 || !F0 || !mu || !F || !info_dev, "NULL argument");
@@ -493,7 +493,7 @@ int gsmvi_gsm_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, cons
         return GSMVI_ERR_UNSUPPORTED;
     }
     return gsmvi_factor_impl(ctx, reinterpret_cast<hipStream_t>(stream), D, B, Z, ldz, X, ldx, G, ldg, mu0, F0, ldf0,
-                             mu, F, ldf, info_dev);
+                             mu, F, ldf, info_dev, n_reverts_dev);
 }
 
 int gsmvi_bam_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* X, int ldx, const double* G,

@@ -672,9 +672,10 @@ __global__ __launch_bounds__(256) void k_gsmf_kmat_big(int n, const double* __re
 // ---- new mean and the revert passthrough for the K-matrix path -----------------------------------------
 __global__ __launch_bounds__(256) void k_gsmf_mean(int D, int B, const double* __restrict__ Tm,
                                                    const double* __restrict__ mu0, double* __restrict__ mu,
-                                                   const int* __restrict__ bad) {
+                                                   const int* __restrict__ bad, int* __restrict__ n_reverts) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= D) return;
+    if (j == 0 && n_reverts && *bad) *n_reverts += 1;      // one launch per update on the stream: no race
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int b = 0;
     for (; b + 8 <= B; b += 8) {                   // eight independent loads in flight per trip
@@ -730,7 +731,7 @@ int gsmvi_panel_t_product(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
 
 int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
                       const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double* mu, double* F,
-                      int ldf, int* info_dev) {
+                      int ldf, int* info_dev, int* n_reverts_dev) {
     const int n = 2 * B, nq = n;                   // n is even
     // workspace carve: ctx->sg holds 6*rmax*max_D doubles (rmax = 2B+8)
     double* Rt = ctx->sg;                          // n x D   [Z; U]
@@ -769,7 +770,7 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
         double* Kmat = Rg;                         // reuse the n x n slot
         hipLaunchKernelGGL(k_gsmf_small, dim3(1), dim3(256), 0, st, n, B, Gam, Kmat, info_dev);
         if ((rc = chk("k_gsmf_small"))) return rc;
-        hipLaunchKernelGGL(k_gsmf_mean, dim3((D + 255) / 256), dim3(256), 0, st, D, B, Tm, mu0, mu, info_dev);
+        hipLaunchKernelGGL(k_gsmf_mean, dim3((D + 255) / 256), dim3(256), 0, st, D, B, Tm, mu0, mu, info_dev, n_reverts_dev);
         if ((rc = chk("k_gsmf_mean"))) return rc;
         if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, ctx->pp, &kc2)))
             return rc;
@@ -785,7 +786,7 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
         hipLaunchKernelGGL(k_gsmf_kmat_big, dim3((n + 15) / 16), dim3(256), 0, st, n, Rg, Tt, Kmat, info_g, info_t,
                            info_dev);
         if ((rc = chk("k_gsmf_kmat_big"))) return rc;
-        hipLaunchKernelGGL(k_gsmf_mean, dim3((D + 255) / 256), dim3(256), 0, st, D, B, Tm, mu0, mu, info_dev);
+        hipLaunchKernelGGL(k_gsmf_mean, dim3((D + 255) / 256), dim3(256), 0, st, D, B, Tm, mu0, mu, info_dev, n_reverts_dev);
         if ((rc = chk("k_gsmf_mean"))) return rc;
         if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, ctx->pp, &kc2)))
             return rc;

@@ -106,8 +106,17 @@ class HipEngine:
         """Upload a host (B,D) array of standard normals (parity mode: numpy MT19937 stream)."""
         return torch.as_tensor(z_host, dtype=torch.float64).to(self.device, non_blocking=False)
 
-    def normal(self, B, D, generator=None):
-        return torch.randn(B, D, dtype=torch.float64, device=self.device, generator=generator)
+    def normal(self, B, D, seed, call=0, out=None, raw=None):
+        """(B, D) standard normals from the counter-based device stream (csrc/gsmvi_rng.hip): a pure function of
+        (seed, call, element index).  Replaces the z-stream of np.random.multivariate_normal
+        (gsmvi/gsm_numpy.py:105,116); ``call`` is the fit iteration."""
+        self._ensure(max(self._max_D, 1), max(self._max_B, 1))
+        Z = self.empty(B, D) if out is None else out
+        assert Z.is_contiguous() and Z.numel() == B * D
+        _lib.check("gsmvi_randn_f64", self.lib.gsmvi_randn_f64(
+            self._ctx, self._stream(), int(seed) & (2 ** 64 - 1), int(call), B * D, C.c_void_p(Z.data_ptr()),
+            C.c_void_p(raw.data_ptr()) if raw is not None else None))
+        return Z
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -217,9 +226,9 @@ class HipEngine:
             self._vec(mu, "mu"), ps, lds))
         return mu, S
 
-    def gsm_factor_update(self, Z, X, G, mu0, F0, out=None, flag=None):
+    def gsm_factor_update(self, Z, X, G, mu0, F0, out=None, flag=None, n_reverts=None):
         """Factor-form update: Sigma = F^T F, X = mu0 + Z F0.  Returns (mu, F, flag); flag != 0 means
-        the 2B x 2B positive-definite test failed and (mu, F) = (mu0, F0) (revert)."""
+        the 2B x 2B positive-definite test failed and (mu, F) = (mu0, F0) (revert; counted in n_reverts)."""
         B, D = Z.shape
         self._ensure(D, B)
         mu, F = (self.empty(D), self.empty(D, D)) if out is None else out
@@ -231,17 +240,14 @@ class HipEngine:
         pf, ldf = self._mat(F, "F")
         _lib.check("gsmvi_gsm_factor_update_f64", self.lib.gsmvi_gsm_factor_update_f64(
             self._ctx, self._stream(), D, B, pz, ldz, px, ldx, pg, ldg, self._vec(mu0, "mu0"), pf0, ldf0,
-            self._vec(mu, "mu"), pf, ldf, C.c_void_p(flag.data_ptr())))
+            self._vec(mu, "mu"), pf, ldf, C.c_void_p(flag.data_ptr()),
+            C.c_void_p(n_reverts.data_ptr()) if n_reverts is not None else None))
         return mu, F, flag
 
     def gram(self, F):
         """cov = F^T F for the monitor / return value of the factor-form fit (one library GEMM per call;
         not on the per-iteration path)."""
         return (F.t() @ F).contiguous()
-
-    def count_flag(self, flag, counter):
-        """counter += (flag != 0), on the device, no host sync."""
-        counter.add_((flag != 0).to(counter.dtype))
 
     def set_profiling(self, on):
         self._ensure(max(self._max_D, 1), max(self._max_B, 1))

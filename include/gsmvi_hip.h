@@ -10,6 +10,7 @@
  *   gsmvi/gsm.py:31-58        gsm_update (JAX twin)                     ->  gsmvi_gsm_update_f64
  *   examples/example_gsm_numpy.py:24-29  lp_g of the Gaussian target    ->  gsmvi_gaussian_score_f64
  *   gsmvi/gsm_numpy.py:116    np.random.multivariate_normal(mean,cov,B) ->  gsmvi_sample_f64 (+ gsmvi_potrf_f64)
+ *   gsmvi/gsm_numpy.py:105,116 np.random.seed + standard-normal stream  ->  gsmvi_randn_f64 (counter-based)
  *   gsmvi/gsm_numpy.py:132-146 _check_goodness(cov)                     ->  gsmvi_potrf_f64 (info flag)
  *   (no reference twin; gsm_numpy.py:4-55 in factor form)   ->  gsmvi_gsm_factor_update_f64
  *   gsmvi/bam.py:72-114       bam_lowrank_update(samples,vs,mu0,S0,reg) ->  gsmvi_bam_update_f64
@@ -123,11 +124,12 @@ int gsmvi_gsm_apply_rows_f64(gsmvi_ctx* ctx, void* stream, int D, int B, int row
  * (X, G, mu0, F0^T F0) -- without forming or factorising any D x D covariance: the positive-definite
  * test of gsm_numpy.py:121-125,132-146 becomes a Cholesky of a 2B x 2B matrix.  If that test fails,
  * (mu, F) = (mu0, F0) and *info_dev = 1 (revert); else *info_dev = 0.  Needs 2B <= D and 2B <= 128.
+ * n_reverts_dev (device int, may be NULL) is incremented on a revert, like gsmvi_commit_f64 does.
  */
 int gsmvi_gsm_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
                                 const double* Z, int ldz, const double* X, int ldx, const double* G, int ldg,
                                 const double* mu0, const double* F0, int ldf0,
-                                double* mu, double* F, int ldf, int* info_dev);
+                                double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev);
 
 /*
  * Profiling mode (used by bench.py for the roofline line): when on, the three kernels of the GSM
@@ -168,6 +170,17 @@ int gsmvi_potrf_f64(gsmvi_ctx* ctx, void* stream, int D, const double* S, int ld
 int gsmvi_sample_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
                      const double* Z, int ldz, const double* mu, const double* R, int ldr,
                      double* X, int ldx);
+
+/*
+ * Whitened draws: out[0..n) ~ N(0, 1), a pure function of (seed, call, element index) -- counter-based
+ * Philox4x32-10 (key = seed, counter = (pair index, call)) + Box-Muller in fp64; see csrc/gsmvi_rng.hip.
+ * Replaces the standard-normal stream behind np.random.multivariate_normal (gsm_numpy.py:105,116) in
+ * throughput mode; `call` is the fit iteration (the JAX twins likewise derive a fresh sub-key per iteration,
+ * gsm.py:117-119).  Stateless, so sharded ranks draw identical Z from the same key.  raw (device uint32,
+ * 4 words per element pair, may be NULL) receives the Philox words (tests pin them to Random123 vectors).
+ */
+int gsmvi_randn_f64(gsmvi_ctx* ctx, void* stream, uint64_t seed, uint64_t call, int64_t n, double* out,
+                    uint32_t* raw);
 
 /*
  * Commit-or-revert (gsm_numpy.py:121-125): if *info_dev == 0 copy (mu_new, S_new) over (mu, S),

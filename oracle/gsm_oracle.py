@@ -24,7 +24,7 @@ import numpy as np
 __all__ = [
     "gsm_single_faithful", "gsm_update_faithful", "gsm_per_sample_terms", "gsm_update_batched",
     "gsm_factor_terms", "gsm_factor_update", "cov_is_good", "svd_sampler", "gaussian_score", "make_gaussian_target",
-    "make_update_state", "gsm_fit",
+    "make_update_state", "gsm_fit", "philox4x32_10", "philox_randn",
 ]
 
 
@@ -157,6 +157,42 @@ def svd_sampler(rs, mean, cov, size):
 # --------------------------------------------------------------------------------------
 # a4/a7: the synthetic Gaussian target  reference: examples/example_gsm_numpy.py:8-31
 # --------------------------------------------------------------------------------------
+def philox4x32_10(counter, key):
+    """Philox4x32-10 (Salmon, Moraes, Dror & Shaw, "Parallel random numbers: as easy as 1, 2, 3", SC'11;
+    the Random123 library).  ``counter``: (n, 4) uint32, ``key``: (2,) uint32 -> (n, 4) uint32.  Not part of
+    the reference (its z-stream is numpy's MT19937, gsm_numpy.py:105; the JAX twins use threefry,
+    gsm.py:117): this restates the device generator of csrc/gsmvi_rng.hip and is pinned to the Random123
+    known-answer vectors in tests/test_oracle_golden.py."""
+    c = np.array(counter, dtype=np.uint64).reshape(-1, 4).copy()
+    k0, k1 = (np.uint64(int(key[0])), np.uint64(int(key[1])))
+    M0, M1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    sh = np.uint64(32)
+    for _ in range(10):
+        p0, p1 = M0 * c[:, 0], M1 * c[:, 2]
+        c = np.stack([(p1 >> sh) ^ c[:, 1] ^ k0, p1 & mask, (p0 >> sh) ^ c[:, 3] ^ k1, p0 & mask], axis=1)
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return c.astype(np.uint32)
+
+
+def philox_randn(seed, call, n, return_raw=False):
+    """n standard normals of the device stream (csrc/gsmvi_rng.hip): element pair p of ``call`` is the Philox
+    block with counter (p lo, p hi, call lo, call hi) and key (seed lo, seed hi); two 53-bit uniforms
+    ((a >> 5) 2^26 + (b >> 6) + 1/2) 2^-53 and Box-Muller give z[2p], z[2p+1]."""
+    seed, call, n = int(seed) & (2 ** 64 - 1), int(call), int(n)
+    p = np.arange((n + 1) // 2, dtype=np.uint64)
+    lo = np.uint64(0xFFFFFFFF)
+    ctr = np.stack([p & lo, p >> np.uint64(32), np.full_like(p, call & 0xFFFFFFFF), np.full_like(p, call >> 32)], axis=1)
+    w = philox4x32_10(ctr, (seed & 0xFFFFFFFF, seed >> 32)).astype(np.uint64)
+    u1 = (((w[:, 0] >> np.uint64(5)) << np.uint64(26)) | (w[:, 1] >> np.uint64(6))).astype(np.float64)
+    u2 = (((w[:, 2] >> np.uint64(5)) << np.uint64(26)) | (w[:, 3] >> np.uint64(6))).astype(np.float64)
+    u1 = (u1 + 0.5) / 9007199254740992.0
+    u2 = (u2 + 0.5) / 9007199254740992.0
+    r = np.sqrt(-2.0 * np.log(u1))
+    z = np.stack([r * np.cos(2.0 * np.pi * u2), r * np.sin(2.0 * np.pi * u2)], axis=1).reshape(-1)[:n]
+    return (z, w.astype(np.uint32)) if return_raw else z
+
+
 def make_gaussian_target(D, seed, cond=None):
     """Seeded version of example_gsm_numpy.py:11-14: m = U(0,1)^D, Sig_t = L L^T + 1e-3 I.
     With ``cond`` the spectrum is rescaled log-uniformly to that condition number (config 5)."""

@@ -43,8 +43,12 @@ class OracleEngine:
     def normal_from_host(self, z):
         return np.asarray(z, dtype=np.float64)
 
-    def normal(self, B, D, generator=None):
-        raise NotImplementedError
+    def normal(self, B, D, seed, call=0, out=None, raw=None):
+        z = orc.philox_randn(seed, call, B * D).reshape(B, D)
+        if out is not None:
+            out[...] = z
+            return out
+        return z
 
     def gsm_update(self, X, G, mu0, S0, out=None):
         mu, S = orc.gsm_update_batched(X, G, mu0, S0)
@@ -114,13 +118,15 @@ class OracleEngine:
             return out
         return mu, S
 
-    def gsm_factor_update(self, Z, X, G, mu0, F0, out=None, flag=None):
+    def gsm_factor_update(self, Z, X, G, mu0, F0, out=None, flag=None, n_reverts=None):
         flag = Flag() if flag is None else flag
         mu, Fo, ok = orc.gsm_factor_update(Z, G, mu0, F0.T)      # oracle convention: Sigma = F F^T
         if ok and np.isfinite(Fo).all():
             Fn, flag.v = Fo.T, 0
         else:
             mu, Fn, flag.v = mu0.copy(), F0.copy(), 1
+            if n_reverts is not None:
+                n_reverts.v += 1
         if out is not None:
             out[0][...] = mu
             out[1][...] = Fn
@@ -129,9 +135,6 @@ class OracleEngine:
 
     def gram(self, F):
         return F.T @ F
-
-    def count_flag(self, flag, counter):
-        counter.v += int(flag.v != 0)
 
     def gaussian_score(self, X, m, P, out=None):
         return orc.gaussian_score(X, m, P)
