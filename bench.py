@@ -105,10 +105,21 @@ def cpu_baseline(D, B, seconds):
         orc.gsm_update_batched(st["samples"], st["vs"], st["mu0"], st["S0"])
         nb += 1
     tb = time.perf_counter() - tb0
+    one_core = None
+    try:                                         # the same port pinned to one BLAS thread
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            n1, t1 = 0, time.perf_counter()
+            while time.perf_counter() - t1 < min(4.0, seconds / 3) or n1 < 2:
+                orc.gsm_update_faithful(st["samples"], st["vs"], st["mu0"], st["S0"])
+                n1 += 1
+            one_core = n1 / (time.perf_counter() - t1)
+    except Exception:
+        one_core = None
     return {"value": n / el, "unit": "updates/s", "cores": int(threads), "kind": "port",
             "sample": f"{n} updates of D={D},B={B} (oracle/gsm_oracle.py:gsm_update_faithful, numpy fp64, "
                       f"{os.cpu_count()} host cpus)",
-            "best_effort_blas3_value": nb / tb}
+            "value_1_core": one_core, "best_effort_blas3_value": nb / tb}
 
 
 def main():
@@ -257,11 +268,48 @@ def main():
             traffic = json.load(open(tpath)).get("k_gsm_cov_update_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_gsm_cov_update", "achieved": achieved, "peak": HBM_PEAK_GBS,
+    roofline = {"bound": "hbm", "kernel": "k_gsm_cov_sym" if (D % 32 == 0 and B in (16, 32, 64)) else "k_gsm_cov_update",
+                "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes_update,
                 "avg_kernel_us": {k: v * 1e3 for k, v in avg_ms.items()},
                 "whole_update_algorithmic_GBs": alg_bytes_total * value / 1e9}
+    # ---- calibration: the attainable HBM rate on this box (device copy of 1 GiB, read + write
+    # bytes) and what a plain copy of one covariance costs in the same cold ring (it moves 16 D^2 bytes, the
+    # covariance kernel's algorithmic count) -- torch's copy kernel, plumbing, not the product path.
+    if rank == 0:
+        try:
+            big = torch.empty(2, 2 ** 27, dtype=torch.float64, device=eng.device)
+            big[0].fill_(1.0)
+            for _ in range(2):
+                big[1].copy_(big[0])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                big[1].copy_(big[0])
+            e1.record()
+            e1.synchronize()
+            attain = 5 * 2.0 * big[0].numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del big
+            gcp = torch.cuda.CUDAGraph()
+            for it in inst:
+                it["S"].copy_(it["S0"])
+            torch.cuda.synchronize()
+            with torch.cuda.graph(gcp):
+                for it in inst:
+                    it["S"].copy_(it["S0"])
+            gcp.replay()
+            torch.cuda.synchronize()
+            tc0 = time.perf_counter()
+            for _ in range(20):
+                gcp.replay()
+            torch.cuda.synchronize()
+            copy_us = (time.perf_counter() - tc0) / (20 * n_inst) * 1e6
+            roofline["attainable_peak"] = attain
+            roofline["frac_of_attainable"] = achieved / attain
+            roofline["plain_copy_same_size_us"] = copy_us
+        except Exception as e:                  # calibration only
+            roofline["attainable_peak"] = f"failed: {type(e).__name__}"
 
     # ---- fit-iteration rate F: sample -> score -> update -> Cholesky PD check -> commit ----
     fit_rate = None
