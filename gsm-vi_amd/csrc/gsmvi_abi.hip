@@ -32,7 +32,7 @@ void gsmvi_launch_commit(hipStream_t st, int D, const int* info, const double* m
 // fast paths (gsmvi_fast.hip)
 void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int nrows, const double* A,
                              int lda, const double* shift, double alpha, const double* M, int ldm, double* Pp,
-                             int chunks_per_wg);
+                             int chunks_per_wg, int ncols);
 bool gsmvi_launch_gsm_scalars_fast(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, const double* X, int ldx,
                                    const double* G, int ldg, const double* mu0, const double* Pp, double* rec,
                                    int ldrec, int nt);
@@ -261,7 +261,7 @@ int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D
     const int MT = nrows <= 16 ? 1 : (nrows <= 32 ? 2 : 4);
     const int zblocks = (nrows + 16 * MT - 1) / (16 * MT);
     const int a_vec_ok = (lda % 2 == 0) && aligned16(A);
-    const bool fast = !ctx->tune_no_fast && ncols == D && D % 64 == 0 && a_vec_ok && (!shift || aligned16(shift));
+    const bool fast = !ctx->tune_no_fast && ncols % 16 == 0 && D % 64 == 0 && a_vec_ok && (!shift || aligned16(shift));
     const int chw = fast ? gsmvi_panel_fast_chunk(MT) : 256;       // rows of M per chunk
     const int nchunks = (D + chw - 1) / chw;
     int kc = ctx->tune_panel_kc > 0 ? ctx->tune_panel_kc
@@ -274,7 +274,7 @@ int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D
     *kc_out = kc;
     if (fast) {
         gsmvi_launch_panel_fast(st, ev, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm, Pp,
-                                cpw);
+                                cpw, ncols);
         return check_launch("k_panel_fast");
     }
     gsmvi_launch_panel_partial(st, ev, MT, dim3(strips, kc, zblocks), D, ncols, nrows, A, lda, shift, alpha, M,

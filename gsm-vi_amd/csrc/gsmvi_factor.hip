@@ -437,6 +437,96 @@ __global__ __launch_bounds__(256) void k_gsmf_update(int D, int KF, const double
             }
 }
 
+// ---- fast rank-n update (D % 64 == 0, n = 32 NP): F = F0 + Rt^T Fs, the new mean, the revert passthrough ---
+// One 512-thread workgroup per 64 x 64 tile (two waves per SIMD for the fp64 MFMA rate); wave w owns the
+// 16-row block w >> 1 and the two 16-column blocks of half w & 1.  Every global load of the workgroup -- the F0
+// tile in accumulator layout and all n rows of both operand tiles -- is issued in one batch; the operand rows
+// then pass through LDS 32 at a time, [k][80] (64 columns + 16 pad: both MFMA operand reads conflict-free).
+// Tile row 0 also writes mu = mu0 + mean_b (U Fm)_b (rows B..2B-1 of Tm) for its 64 columns, and workgroup 0
+// counts the revert.  When *bad (the 2B x 2B positive-definite test failed) F = F0 and mu = mu0.
+template <int NP>
+__global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const double* __restrict__ Rt,
+                                                          const double* __restrict__ Fs,
+                                                          const double* __restrict__ F0, int ldf0,
+                                                          double* __restrict__ F, int ldf,
+                                                          const double* __restrict__ Tm,
+                                                          const double* __restrict__ mu0, double* __restrict__ mu,
+                                                          const int* __restrict__ bad, int* __restrict__ n_reverts) {
+    constexpr int RS = 80, KP = 32;
+    __shared__ __attribute__((aligned(16))) double sm[2 * KP * RS];
+    const int nt = D >> 6;
+    const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
+    const int I0 = ti * 64, J0 = tj * 64;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+    const int wr = w >> 1, wc = w & 1;
+    // ---- all global loads ----
+    double f0[2][4];
+    const size_t frow = (size_t)(I0 + 16 * wr + ks);
+    const int fcol = J0 + 32 * wc + c;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f0[blk][r] = F0[(frow + 4 * r) * ldf0 + fcol + 16 * blk];
+    v2d ga[NP][2], gb[NP][2];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int u = q * 512 + tid, row = u >> 5, c2 = 2 * (u & 31);
+            ga[p][q] = *reinterpret_cast<const v2d*>(Rt + (size_t)(KP * p + row) * D + I0 + c2);
+            gb[p][q] = *reinterpret_cast<const v2d*>(Fs + (size_t)(KP * p + row) * D + J0 + c2);
+        }
+    const int skip = *bad;
+    double msum = 0.0;
+    if (ti == 0) {                               // partial column sums of rows B + g, B + g + 8, ... of Tm
+        const int g = tid >> 6, col = J0 + (tid & 63);
+        for (int b = g; b < B; b += 8) msum += Tm[(size_t)(B + b) * D + col];
+    }
+    if (blockIdx.x == 0 && tid == 0 && skip && n_reverts) *n_reverts += 1;
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (p > 0) __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int u = q * 512 + tid, row = u >> 5, c2 = 2 * (u & 31);
+            *reinterpret_cast<v2d*>(sm + row * RS + c2) = ga[p][q];
+            *reinterpret_cast<v2d*>(sm + (KP + row) * RS + c2) = gb[p][q];
+        }
+        __syncthreads();
+        double a[8], b0[8], b1[8];
+        const double* ap = sm + ks * RS + 16 * wr + c;
+        const double* bp = sm + (KP + ks) * RS + 32 * wc + c;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            a[s] = ap[4 * s * RS];
+            b0[s] = bp[4 * s * RS];
+            b1[s] = bp[4 * s * RS + 16];
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            acc0 = GSMVI_MFMA_F64(a[s], b0[s], acc0);
+            acc1 = GSMVI_MFMA_F64(a[s], b1[s], acc1);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        F[(frow + 4 * r) * ldf + fcol] = skip ? f0[0][r] : f0[0][r] + acc0[r];
+        F[(frow + 4 * r) * ldf + fcol + 16] = skip ? f0[1][r] : f0[1][r] + acc1[r];
+    }
+    if (ti == 0) {
+        __syncthreads();
+        sm[tid] = msum;                          // [8][64]
+        __syncthreads();
+        if (tid < 64) {
+            double s = 0.0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += sm[g * 64 + tid];
+            mu[J0 + tid] = skip ? mu0[J0 + tid] : mu0[J0 + tid] + s / (double)B;
+        }
+    }
+}
+
 // ---- everything small in ONE workgroup (n = 2B <= 64) ---------------------------------------------------
 //   Gamma -> Rg (Cholesky) -> A' = I + Rg J Rg^T -> T (Cholesky, the PD test) -> K = Rg^-1 (T - I) Rg^-T.
 // All matrices live in LDS ([64][TS], padded with the identity beyond n).  The three n-column triangular
@@ -770,11 +860,13 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
         double* Kmat = Rg;                         // reuse the n x n slot
         hipLaunchKernelGGL(k_gsmf_small, dim3(1), dim3(256), 0, st, n, B, Gam, Kmat, info_dev);
         if ((rc = chk("k_gsmf_small"))) return rc;
-        hipLaunchKernelGGL(k_gsmf_mean, dim3((D + 255) / 256), dim3(256), 0, st, D, B, Tm, mu0, mu, info_dev, n_reverts_dev);
-        if ((rc = chk("k_gsmf_mean"))) return rc;
-        if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, ctx->pp, &kc2)))
+        // inner dimension n <= one chunk, so there is exactly one slab: it is written straight into Fs
+        if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, Fs, &kc2)))
             return rc;
-        if ((rc = gsmvi_panel_finish(st, D, n, kc2, ctx->pp, nullptr, Fs, D))) return rc;
+        if (kc2 != 1) {
+            gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "K Tm product was split (internal error)");
+            return GSMVI_ERR_UNSUPPORTED;
+        }
     } else {
         // 64 < n <= 128: the two n x n Choleskys one workgroup each, K in its own kernel, then the same skinny
         // GEMM Fs = K Tm
@@ -786,13 +878,24 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
         hipLaunchKernelGGL(k_gsmf_kmat_big, dim3((n + 15) / 16), dim3(256), 0, st, n, Rg, Tt, Kmat, info_g, info_t,
                            info_dev);
         if ((rc = chk("k_gsmf_kmat_big"))) return rc;
-        hipLaunchKernelGGL(k_gsmf_mean, dim3((D + 255) / 256), dim3(256), 0, st, D, B, Tm, mu0, mu, info_dev, n_reverts_dev);
-        if ((rc = chk("k_gsmf_mean"))) return rc;
-        if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, ctx->pp, &kc2)))
+        // inner dimension n <= one chunk, so there is exactly one slab: it is written straight into Fs
+        if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, Fs, &kc2)))
             return rc;
-        if ((rc = gsmvi_panel_finish(st, D, n, kc2, ctx->pp, nullptr, Fs, D))) return rc;
+        if (kc2 != 1) {
+            gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "K Tm product was split (internal error)");
+            return GSMVI_ERR_UNSUPPORTED;
+        }
     }
     const int nt = (D + 63) / 64;
+    if (!ctx->tune_no_fast && D % 64 == 0 && (n == 32 || n == 64 || n == 128)) {
+        // the fast kernel also writes the mean and counts the revert
+#define UF(NPV) hipLaunchKernelGGL(k_gsmf_update_fast<NPV>, dim3(nt * nt), dim3(512), 0, st, D, B, Rt, Fs, F0, ldf0, F, ldf, Tm, mu0, mu, info_dev, n_reverts_dev)
+        if (n == 32) UF(1); else if (n == 64) UF(2); else UF(4);
+#undef UF
+        return chk("k_gsmf_update_fast");
+    }
+    hipLaunchKernelGGL(k_gsmf_mean, dim3((D + 255) / 256), dim3(256), 0, st, D, B, Tm, mu0, mu, info_dev, n_reverts_dev);
+    if ((rc = chk("k_gsmf_mean"))) return rc;
     hipLaunchKernelGGL(k_gsmf_update, dim3(nt * nt), dim3(256), 0, st, D, n, Rt, Fs, F0, ldf0, F, ldf, info_dev);
     return chk("k_gsmf_update");
 }

@@ -28,13 +28,14 @@
 // A[:, 256 rows] (16*MT x 256 doubles) is loaded by the whole workgroup with fully coalesced 16-B
 // accesses and staged in LDS ([row][258]: conflict-free ds_read_b64 for the MFMA A operand), because
 // fragment-shaped loads of it touch 64 cache lines per instruction.
-// D % 64 == 0: a wave's 32 rows are all inside or all outside the matrix.
+// D % 64 == 0: a wave's 32 rows are all inside or all outside the matrix.  M has ncols columns (a multiple of
+// 16; ncols = D for the square matrices, 2B for the factor path's Gram product); slabs are nrows x ncols.
 // =====================================================================================
 template <int MT, bool HAS_SHIFT, int CHW>
 __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const double* __restrict__ A, int lda,
                                                     const double* __restrict__ shift, double alpha,
                                                     const double* __restrict__ M, int ldm,
-                                                    double* __restrict__ Pp, int chunks_per_wg) {
+                                                    double* __restrict__ Pp, int chunks_per_wg, int ncols) {
     constexpr int LDG = CHW + 2;                   // LDS row stride of the staged A chunk (doubles)
     constexpr int NR = 16 * MT;
     constexpr int RW = CHW / 8;                    // rows of the chunk per wave (8 waves)
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
             double s = 0.0;
 #pragma unroll
             for (int ww = 0; ww < 8; ww += 2) s += red[(ww * NR + rr) * 17 + cc] + red[((ww + 1) * NR + rr) * 17 + cc];
-            Pp[((size_t)blockIdx.y * nrows + row) * D + blockIdx.x * 16 + cc] = s;
+            Pp[((size_t)blockIdx.y * nrows + row) * ncols + blockIdx.x * 16 + cc] = s;
         }
     }
 }
@@ -374,10 +375,10 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
 // ---- launch helpers ------------------------------------------------------------------------
 void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int nrows, const double* A,
                              int lda, const double* shift, double alpha, const double* M, int ldm, double* Pp,
-                             int chunks_per_wg) {
+                             int chunks_per_wg, int ncols) {
 #define PF(MTV, HS, CW)                                                                                          \
     GSMVI_LAUNCH((k_panel_fast<MTV, HS, CW>), grid, dim3(512), 0, st, ev, D, nrows, A, lda, shift, alpha, M, ldm, \
-                 Pp, chunks_per_wg)
+                 Pp, chunks_per_wg, ncols)
     if (shift) {
         if (MT == 1) PF(1, true, 256); else if (MT == 2) PF(2, true, 256); else PF(4, true, 128);
     } else {
