@@ -529,14 +529,21 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const do
 
 // ---- everything small in ONE workgroup (n = 2B <= 64) ---------------------------------------------------
 //   Gamma -> Rg (Cholesky) -> A' = I + Rg J Rg^T -> T (Cholesky, the PD test) -> K = Rg^-1 (T - I) Rg^-T.
-// All matrices live in LDS ([64][TS], padded with the identity beyond n).  The three n-column triangular
-// operations that produce K are done one column per QUAD of lanes (lane q of the quad owns rows q, q+4, ..):
-// right-looking substitution with the pivot value broadcast inside the quad.  *bad = 1 if either Cholesky
+// All matrices live in LDS ([64][TS], padded with the identity beyond n).  W = Rg^-T comes from one n-column
+// forward substitution, one column per QUAD of lanes (lane q of the quad owns rows q, q+4, ..; the pivot
+// value is broadcast inside the quad); K = W^T (T - I) W is then two 64^3 products on the MFMA pipe.  *bad = 1 if either Cholesky
 // fails (NaN, singular Gamma, or M not positive definite) and K is then irrelevant.
 __global__ __launch_bounds__(256) void k_gsmf_small(int n, int B, const double* __restrict__ Gam,
-                                                    double* __restrict__ Kmat, int* __restrict__ bad_out) {
+                                                    double* __restrict__ Kmat, int* __restrict__ bad_out,
+                                                    unsigned long long* __restrict__ stamps) {
+#define SMALL_STAMP(k)                                                                      \
+    do {                                                                                    \
+        if (stamps && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memrealtime();        \
+    } while (0)
+    SMALL_STAMP(0);
     __shared__ __attribute__((aligned(16))) double Rs[64 * TS];
     __shared__ __attribute__((aligned(16))) double Ts[64 * TS];
+    __shared__ __attribute__((aligned(16))) double Ps[64 * TS];
     __shared__ double rinv_g[64], rinv_t[64];
     __shared__ int fail_g, fail_t;
     const int tid = threadIdx.x;
@@ -555,48 +562,59 @@ __global__ __launch_bounds__(256) void k_gsmf_small(int n, int B, const double* 
     }
     if (tid < 64) rinv_g[tid] = rinv_t[tid] = 1.0;
     __syncthreads();
+    SMALL_STAMP(1);
     chol64_lds(Rs, rinv_g, n, &fail_g);                // Rs = Rg (upper); strictly-lower part is stale
+    SMALL_STAMP(2);
     for (int e = tid; e < 64 * 64; e += 256) {         // zero the strictly-lower part so Rs is a clean upper factor
         const int i = e >> 6, q = e & 63;
         if (q < i) Rs[i * TS + q] = 0.0;
     }
     __syncthreads();
-    // A' = I + (Rg J) Rg^T into Ts;  (Rg J)[i][k] = (1/B)(k < B ? Rg[i][B+k] : Rg[i][k-B] - Rg[i][k]).
-    // 16 x 16 threads, each a 4 x 4 register block (rows ty+16a, columns tx+16b): 8 LDS reads per 16 FMAs.
+    // A' = I + (Rg J) Rg^T into Ts;  (Rg J)[i][k] = (1/B)(k < B ? Rg[i][B+k] : Rg[i][k-B] - Rg[i][k]), on the
+    // MFMA pipe.  Wave w owns the 16-column block j = w and computes the blocks (i, j), i <= j (A' is
+    // symmetric; the mirror is written too).  Rg is upper triangular, so Rg[j][k] = 0 for k < 16 j: only the
+    // k-blocks j..3 contribute -- 80 MFMAs in all instead of a 64^3 VALU product.
     {
         const double invB = 1.0 / (double)B;
-        const int ty = tid >> 4, tx = tid & 15;
-        double acc[4][4];
+        const int w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
+        v4d acc[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int ib = 0; ib < 4; ++ib) acc[ib] = (v4d){0.0, 0.0, 0.0, 0.0};
+        const double* brow = Rs + (16 * w + cc) * TS;
+        for (int kb = w; kb < 4; ++kb) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-        for (int k = 0; k < n; ++k) {
-            const int k1 = (k < B) ? B + k : k - B;    // (Rg J)[i][k] = Rg[i][k1] - (k >= B ? Rg[i][k] : 0)
-            const double sub = (k < B) ? 0.0 : 1.0;
-            double ra[4], rb[4];
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int k = 16 * kb + 4 * s4 + ks;
+                const int k1 = (k < B) ? B + k : k - B;
+                const double bv = brow[k];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int i = ty + 16 * a, j = tx + 16 * a;
-                ra[a] = Rs[i * TS + k1] - sub * Rs[i * TS + k];
-                rb[a] = Rs[j * TS + k];
+                for (int ib = 0; ib < 4; ++ib) {       // independent accumulator chains; ib <= w is wave-uniform
+                    if (ib <= w) {
+                        const double* arow = Rs + (16 * ib + cc) * TS;
+                        const double a1 = arow[k1 < 64 ? k1 : 63], a0 = arow[k];
+                        const double a = (k < n) ? ((k < B) ? a1 : a1 - a0) : 0.0;
+                        acc[ib] = GSMVI_MFMA_F64(a, bv, acc[ib]);
+                    }
+                }
             }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] += ra[a] * rb[b];
         }
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int ib = 0; ib < 4; ++ib) {
+            if (ib <= w) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int i = ty + 16 * a, j = tx + 16 * b;
-                const bool in = i < n && j < n;
-                Ts[i * TS + j] = (i == j ? 1.0 : 0.0) + (in ? acc[a][b] * invB : 0.0);
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * ib + ks + 4 * r, j = 16 * w + cc;
+                    const double v = (i == j ? 1.0 : 0.0) + ((i < n && j < n) ? acc[ib][r] * invB : 0.0);
+                    Ts[i * TS + j] = v;
+                    if (ib != w) Ts[j * TS + i] = v;
+                }
             }
+        }
     }
     __syncthreads();
+    SMALL_STAMP(3);
     chol64_lds(Ts, rinv_t, n, &fail_t);                // Ts = T (upper): exists iff M is positive definite
+    SMALL_STAMP(4);
     const int bad = (fail_g != 0) || (fail_t != 0);
     if (tid == 0) *bad_out = bad;
     if (bad) return;                                   // block-uniform
@@ -621,49 +639,64 @@ __global__ __launch_bounds__(256) void k_gsmf_small(int n, int B, const double* 
                 x[r] -= (t > p) ? rv * xp : 0.0;
             }
     }
-    // phase 2: y = (T - I) x  (upper-triangular mat-vec), column-oriented so it has the same shape as the
-    // substitutions: for p = 0..63 broadcast x[p] inside the quad, every lane adds T[t][p] x[p] to its rows t <= p.
+    // Column c of W = Rg^-T (lower triangular) is now in the quad's registers.  K = W^T (T - I) W is two
+    // 64 x 64 x 64 products on the MFMA pipe instead of a second and a third 64-step substitution:
+    //   P = (T - I) W   then   K = W^T P.
+    __syncthreads();                                   // every quad is done reading Rg
+    SMALL_STAMP(5);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Rs[(q + 4 * r) * TS + c] = x[r];       // Rs <- W
+    for (int e = tid; e < 64 * 64; e += 256) {         // Ts <- T - I, strictly-lower part cleared
+        const int i = e >> 6, j = e & 63;
+        if (j < i) Ts[i * TS + j] = 0.0;
+        else if (j == i) Ts[i * TS + j] -= 1.0;
+    }
+    __syncthreads();
     {
-        double y[16];
+        const int w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
+        // Wave w owns the 16-column block j = w of both products; the four row blocks are independent chains.
+        // P[i][j] = sum_k (T - I)[i][k] W[k][j]: T - I is upper (k >= i), W lower (k >= j): k-blocks max(i, j)..3.
+        v4d acc[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) y[r] = -x[r];
+        for (int ib = 0; ib < 4; ++ib) acc[ib] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int kb = w; kb < 4; ++kb) {
 #pragma unroll
-        for (int p = 0; p < 64; ++p) {
-            const int pr = p >> 2, pq = p & 3;
-            const double xp = __shfl(x[pr], (threadIdx.x & 60) | pq, 64);
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int k = 16 * kb + 4 * s4 + ks;
+                const double bv = Rs[k * TS + 16 * w + cc];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (4 * r <= p) {
-                    const int t = q + 4 * r;
-                    const double tv = Ts[t * TS + p];
-                    y[r] += (t <= p) ? tv * xp : 0.0;
-                }
+                for (int ib = 0; ib < 4; ++ib)
+                    if (ib <= kb) acc[ib] = GSMVI_MFMA_F64(Ts[(16 * ib + cc) * TS + k], bv, acc[ib]);
+            }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = y[r];
-    }
-    // phase 3: z = Rg^-1 y  (back substitution, right-looking from the bottom): needs column p of Rg
+        for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
-    for (int p = 63; p >= 0; --p) {
-        const int pr = p >> 2, pq = p & 3;
-        const double mine = x[pr] * rinv_g[p];
-        if (q == pq) x[pr] = mine;
-        const double xp = __shfl(mine, (threadIdx.x & 60) | pq, 64);
+            for (int r = 0; r < 4; ++r) Ps[(16 * ib + ks + 4 * r) * TS + 16 * w + cc] = acc[ib][r];
+        __syncthreads();
+        // K[i][j] = sum_k W[k][i] P[k][j]: W[k][i] = 0 for k < i: k-blocks i..3.
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (4 * r < p) {
-                const int t = q + 4 * r;
-                const double rv = Rs[t * TS + p];
-                x[r] -= (t < p) ? rv * xp : 0.0;
+        for (int ib = 0; ib < 4; ++ib) acc[ib] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int k = 16 * kb + 4 * s4 + ks;
+                const double bv = Ps[k * TS + 16 * w + cc];
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib)
+                    if (ib <= kb) acc[ib] = GSMVI_MFMA_F64(Rs[k * TS + 16 * ib + cc], bv, acc[ib]);
+            }
+        }
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ib + ks + 4 * r, j = 16 * w + cc;
+                if (i < n && j < n) Kmat[(size_t)i * n + j] = acc[ib][r];
             }
     }
-    if (c < n) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int t = q + 4 * r;
-            if (t < n) Kmat[(size_t)t * n + c] = x[r];
-        }
-    }
+    SMALL_STAMP(6);
+#undef SMALL_STAMP
 }
 
 // ---- K = Rg^-1 (T - I) Rg^-T for 64 < n <= 128 -----------------------------------------------------------
@@ -858,7 +891,8 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
     if (n <= 64) {
         // everything small in one workgroup, then Fs = K Tm as one skinny GEMM (K = n)
         double* Kmat = Rg;                         // reuse the n x n slot
-        hipLaunchKernelGGL(k_gsmf_small, dim3(1), dim3(256), 0, st, n, B, Gam, Kmat, info_dev);
+        hipLaunchKernelGGL(k_gsmf_small, dim3(1), dim3(256), 0, st, n, B, Gam, Kmat, info_dev,
+                           (ctx->tune_cov_dbg & 128) ? reinterpret_cast<unsigned long long*>(ctx->pp) : nullptr);
         if ((rc = chk("k_gsmf_small"))) return rc;
         // inner dimension n <= one chunk, so there is exactly one slab: it is written straight into Fs
         if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, Fs, &kc2)))

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Diagnostic: phase times of k_gsmf_small (the 2B x 2B chain of the factor update) from s_memrealtime stamps."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, gsmvi_amd
+from oracle import gsm_oracle as orc
+D, B = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1024, 32)
+eng = gsmvi_amd.get_engine()
+g = torch.Generator(device="cuda"); g.manual_seed(0)
+kw = dict(dtype=torch.float64, device="cuda", generator=g)
+A = torch.randn(D, D, **kw); S0 = A @ A.T / D + 0.1 * torch.eye(D, dtype=torch.float64, device="cuda")
+F0 = torch.linalg.cholesky(S0).T.contiguous(); mu0 = torch.randn(D, **kw); Z = torch.randn(B, D, **kw)
+X = (mu0 + Z @ F0).contiguous(); G = -(X - 0.5)
+eng.set_tuning("cov_dbg", 128)
+names = ["load", "chol(Gamma)", "A'", "chol(A')", "W=Rg^-T", "K=W^T(T-I)W"]
+for trial in range(3):
+    for _ in range(20):
+        eng.gsm_factor_update(Z, X, G, mu0, F0)
+    buf = (C.c_ulonglong * 8)()
+    eng.lib.gsmvi_debug_read_stamps(eng._ctx, buf, 8)
+    st = np.array(buf, dtype=np.int64)[:7]
+    print("  ".join(f"{n} {d / 100.0:.2f}us" for n, d in zip(names, np.diff(st))), f" total {(st[6] - st[0]) / 100.0:.2f}us")
