@@ -699,11 +699,11 @@ __global__ __launch_bounds__(256) void k_gsmf_small(int n, int B, const double* 
 #undef SMALL_STAMP
 }
 
-// ---- K = Rg^-1 (T - I) Rg^-T for 64 < n <= 128 -----------------------------------------------------------
-// One workgroup handles 16 columns of K, SIXTEEN lanes per column (lane q of the group owns rows q, q+16, ..).
-// The triangular matrix in use (Rg, then T, then Rg again) is resident in LDS ([128][130], padded with the
-// identity beyond n); each substitution step broadcasts the pivot value inside the 16-lane group.  Reading
-// a row of the matrix is a stride-1 LDS access, reading a column hits 16 distinct banks: both conflict-free.
+// ---- K = Rg^-1 (T - I) Rg^-T = W^T (T - I) W, W = Rg^-T, for 64 < n <= 128 -----------------------------------
+// k_gsmf_kmat_big: W by forward substitution.  One workgroup handles 16 columns, SIXTEEN lanes per column (lane
+// q of the group owns rows q, q+16, ..); Rg is resident in LDS ([128][130], padded with the identity beyond
+// n); each substitution step broadcasts the pivot value inside the 16-lane group.  The two products then run
+// on the MFMA pipe (k_gsmf_gemm128), instead of a second and a third 128-step substitution.
 __device__ __forceinline__ void kmat_load_lds(double* Mt, double* rinv, const double* __restrict__ src, int n,
                                               bool want_rinv) {
     load_upper128(Mt, src, n);
@@ -713,7 +713,7 @@ __device__ __forceinline__ void kmat_load_lds(double* Mt, double* rinv, const do
 }
 
 __global__ __launch_bounds__(256) void k_gsmf_kmat_big(int n, const double* __restrict__ Rg,
-                                                       const double* __restrict__ T, double* __restrict__ Kmat,
+                                                       double* __restrict__ Wout,
                                                        const int* __restrict__ info_g,
                                                        const int* __restrict__ info_t, int* __restrict__ bad_out) {
     __shared__ __attribute__((aligned(16))) double Mt[128 * 130];
@@ -744,51 +744,51 @@ __global__ __launch_bounds__(256) void k_gsmf_kmat_big(int n, const double* __re
             for (int r = pb + 1; r < 8; ++r) x[r] -= row[16 * r] * xp;
         }
     }
-    __syncthreads();
-    // phase 2: y = (T - I) x,  y[t] = sum_{p >= t} T[t][p] x[p] - x[t]
-    kmat_load_lds(Mt, rinv, T, n, false);
-    {
-        double y[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) y[r] = -x[r];
-#pragma unroll
-        for (int pb = 0; pb < 8; ++pb) {
-#pragma unroll 2
-            for (int pq = 0; pq < 16; ++pq) {
-                const int p = 16 * pb + pq;
-                const double xp = __shfl(x[pb], grp | pq, 64);
-                const double* colp = Mt + q * 130 + p;
-#pragma unroll
-                for (int r = 0; r < pb; ++r) y[r] += colp[16 * r * 130] * xp;
-                y[pb] += (q <= pq) ? colp[16 * pb * 130] * xp : 0.0;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) x[r] = y[r];
-    }
-    __syncthreads();
-    // phase 3: z = Rg^-1 y  (back substitution from the bottom; needs column p of Rg)
-    kmat_load_lds(Mt, rinv, Rg, n, true);
-#pragma unroll
-    for (int pb = 7; pb >= 0; --pb) {
-#pragma unroll 2
-        for (int pq = 15; pq >= 0; --pq) {
-            const int p = 16 * pb + pq;
-            const double mine = x[pb] * rinv[p];
-            if (q == pq) x[pb] = mine;
-            const double xp = __shfl(mine, grp | pq, 64);
-            const double* colp = Mt + q * 130 + p;
-#pragma unroll
-            for (int r = 0; r < pb; ++r) x[r] -= colp[16 * r * 130] * xp;
-            x[pb] -= (q < pq) ? colp[16 * pb * 130] * xp : 0.0;
-        }
-    }
+    // W = Rg^-T (lower triangular), column cg in this group's registers
     if (cg < n) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int t = q + 16 * r;
-            if (t < n) Kmat[(size_t)t * n + cg] = x[r];
+            if (t < n) Wout[(size_t)t * n + cg] = x[r];
         }
+    }
+}
+
+// ---- C = op(A) B for n x n matrices (n <= 128), one 16 x 16 block per wave -------------------------------
+//   MODE 0:  C = (A - I) B     (A = T upper triangular: P = (T - I) W)
+//   MODE 1:  C = A^T B         (A = W lower triangular: K = W^T P)
+// All operand fragments of a block are loaded from L2 in one batch, then one MFMA chain of n/4 steps.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_gsmf_gemm128(int n, const double* __restrict__ A,
+                                                      const double* __restrict__ Bm, double* __restrict__ Cm,
+                                                      const int* __restrict__ bad) {
+    if (*bad) return;
+    const int nb = (n + 15) >> 4;
+    const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blk >= nb * nb) return;                                  // wave-uniform
+    const int i0 = (blk / nb) * 16, j0 = (blk % nb) * 16;
+    const int l = threadIdx.x & 63, cc = l & 15, ks = l >> 4;
+    double a[32], b[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const int k = 4 * s + ks;
+        const int kc = k < n ? k : n - 1, ic = (i0 + cc) < n ? i0 + cc : n - 1, jc = (j0 + cc) < n ? j0 + cc : n - 1;
+        const double av = MODE == 0 ? A[(size_t)ic * n + kc] - (ic == kc ? 1.0 : 0.0) : A[(size_t)kc * n + ic];
+        const double bv = Bm[(size_t)kc * n + jc];
+        const bool in = k < n && (i0 + cc) < n;
+        a[s] = in ? av : 0.0;
+        b[s] = (k < n && (j0 + cc) < n) ? bv : 0.0;
+    }
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 32; s += 2) {
+        acc0 = GSMVI_MFMA_F64(a[s], b[s], acc0);
+        acc1 = GSMVI_MFMA_F64(a[s + 1], b[s + 1], acc1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ks + 4 * r, j = j0 + cc;
+        if (i < n && j < n) Cm[(size_t)i * n + j] = acc0[r] + acc1[r];
     }
 }
 
@@ -905,13 +905,21 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
         // 64 < n <= 128: the two n x n Choleskys one workgroup each, K in its own kernel, then the same skinny
         // GEMM Fs = K Tm
         double* Kmat = Gam;                        // Gamma is dead once Rg exists
+        double* Wm = Ap;                           // A' is dead once T exists
+        double* Pm = Tt + (size_t)n * n;           // fifth n x n slot of the small-matrix workspace
         hipLaunchKernelGGL(k_chol128, dim3(1), dim3(256), 0, st, n, Gam, Rg, info_g);
         hipLaunchKernelGGL(k_gsmf_small_a, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, st, n, B, Rg, info_g, Ap);
         hipLaunchKernelGGL(k_chol128, dim3(1), dim3(256), 0, st, n, Ap, Tt, info_t);
         if ((rc = chk("k_chol128"))) return rc;
-        hipLaunchKernelGGL(k_gsmf_kmat_big, dim3((n + 15) / 16), dim3(256), 0, st, n, Rg, Tt, Kmat, info_g, info_t,
+        hipLaunchKernelGGL(k_gsmf_kmat_big, dim3((n + 15) / 16), dim3(256), 0, st, n, Rg, Wm, info_g, info_t,
                            info_dev);
         if ((rc = chk("k_gsmf_kmat_big"))) return rc;
+        {
+            const int nb = (n + 15) / 16, gw = (nb * nb + 3) / 4;
+            hipLaunchKernelGGL(k_gsmf_gemm128<0>, dim3(gw), dim3(256), 0, st, n, Tt, Wm, Pm, info_dev);   // P = (T - I) W
+            hipLaunchKernelGGL(k_gsmf_gemm128<1>, dim3(gw), dim3(256), 0, st, n, Wm, Pm, Kmat, info_dev); // K = W^T P
+            if ((rc = chk("k_gsmf_gemm128"))) return rc;
+        }
         // inner dimension n <= one chunk, so there is exactly one slab: it is written straight into Fs
         if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, Fs, &kc2)))
             return rc;
