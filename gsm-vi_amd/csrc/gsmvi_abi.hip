@@ -45,6 +45,12 @@ int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double*
 int gsmvi_factor_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X,
                       int ldx, const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double* mu,
                       double* F, int ldf, int* info_dev, int* n_reverts_dev);
+int gsmvi_factor_local_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int Bl, const double* Z, int ldz,
+                            const double* X, int ldx, const double* G, int ldg, const double* mu0, const double* F0,
+                            int ldf0, double* rec, int ldrec);
+int gsmvi_factor_apply_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz,
+                            const double* rec, int ldrec, const double* mu0, const double* F0, int ldf0, double* mu,
+                            double* F, int ldf, int* info_dev, int* n_reverts_dev);
 int gsmvi_bam_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X, int ldx,
                    const double* G, int ldg, const double* mu0, const double* S0, int lds0, double reg,
                    double jitter, double* mu, double* S, int lds, int* info_dev);
@@ -494,6 +500,39 @@ int gsmvi_gsm_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, cons
     }
     return gsmvi_factor_impl(ctx, reinterpret_cast<hipStream_t>(stream), D, B, Z, ldz, X, ldx, G, ldg, mu0, F0, ldf0,
                              mu, F, ldf, info_dev, n_reverts_dev);
+}
+
+int gsmvi_gsm_factor_local_stage_f64(gsmvi_ctx* ctx, void* stream, int D, int B_local, const double* Z, int ldz,
+                                     const double* X, int ldx, const double* G, int ldg, const double* mu0,
+                                     const double* F0, int ldf0, double* rec, int ldrec) {
+    int st = check_common(ctx, D, B_local, __func__);
+    if (st != GSMVI_OK) return st;
+    BAD_ARG(!Z || !X || !G || !mu0 || !F0 || !rec, "NULL argument");
+    BAD_ARG(ldz < D || ldx < D || ldg < D || ldf0 < D, "leading dimension smaller than D");
+    BAD_ARG(ldrec < gsmvi_gsm_record_len(D), "ldrec smaller than gsmvi_gsm_record_len(D)");
+    if (D > 16384) {
+        gsmvi_set_error("%s: %s", __func__, "the factor form supports D <= 16384");
+        return GSMVI_ERR_UNSUPPORTED;
+    }
+    return gsmvi_factor_local_impl(ctx, reinterpret_cast<hipStream_t>(stream), D, B_local, Z, ldz, X, ldx, G, ldg, mu0,
+                                   F0, ldf0, rec, ldrec);
+}
+
+int gsmvi_gsm_factor_apply_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* Z, int ldz,
+                               const double* rec, int ldrec, const double* mu0, const double* F0, int ldf0,
+                               double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev) {
+    int st = check_common(ctx, D, B, __func__);
+    if (st != GSMVI_OK) return st;
+    BAD_ARG(!Z || !rec || !mu0 || !F0 || !mu || !F || !info_dev, "NULL argument");
+    BAD_ARG(ldz < D || ldf0 < D || ldf < D, "leading dimension smaller than D");
+    BAD_ARG(ldrec < gsmvi_gsm_record_len(D), "ldrec smaller than gsmvi_gsm_record_len(D)");
+    BAD_ARG(F == F0 || mu == mu0, "outputs must not alias inputs");
+    if (2 * B > D || 2 * B > 128 || D > 16384) {
+        gsmvi_set_error("%s: %s", __func__, "the factor form needs 2B <= D and 2B <= 128; use gsmvi_gsm_update_f64");
+        return GSMVI_ERR_UNSUPPORTED;
+    }
+    return gsmvi_factor_apply_impl(ctx, reinterpret_cast<hipStream_t>(stream), D, B, Z, ldz, rec, ldrec, mu0, F0, ldf0,
+                                   mu, F, ldf, info_dev, n_reverts_dev);
 }
 
 int gsmvi_bam_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* X, int ldx, const double* G,

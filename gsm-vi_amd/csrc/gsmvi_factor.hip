@@ -852,22 +852,44 @@ int gsmvi_panel_t_product(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     return chk("k_panel_t");
 }
 
-int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
-                      const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double* mu, double* F,
-                      int ldf, int* info_dev, int* n_reverts_dev) {
-    const int n = 2 * B, nq = n;                   // n is even
-    // workspace carve: ctx->sg holds 6*rmax*max_D doubles (rmax = 2B+8)
+// ---- records of the batch-sharded factor path: rec[b] = [ x_b - mu (D) | u_b (D) | (u Fm)_b (D) ] ------------
+__global__ __launch_bounds__(256) void k_gsmf_pack(int D, int Bl, const double* __restrict__ Rt,
+                                                   const double* __restrict__ Tm, double* __restrict__ rec,
+                                                   int ldrec) {
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= D) return;
+    double* rb = rec + (size_t)b * ldrec;
+    rb[i] = Tm[(size_t)b * D + i];
+    rb[D + i] = Rt[(size_t)(Bl + b) * D + i];
+    rb[2 * D + i] = Tm[(size_t)(Bl + b) * D + i];
+}
+
+// Rt = [Z; U], its transpose Rtt (D x n), Tm = [X - mu; U Fm] from the replicated draws and ALL records
+__global__ __launch_bounds__(256) void k_gsmf_unpack(int D, int B, const double* __restrict__ Z, int ldz,
+                                                     const double* __restrict__ rec, int ldrec,
+                                                     double* __restrict__ Rt, double* __restrict__ Rtt, int nq,
+                                                     double* __restrict__ Tm) {
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= D) return;
+    const double* rb = rec + (size_t)b * ldrec;
+    const double z = Z[(size_t)b * ldz + i], u = rb[D + i];
+    Rt[(size_t)b * D + i] = z;
+    Rt[(size_t)(B + b) * D + i] = u;
+    Rtt[(size_t)i * nq + b] = z;
+    Rtt[(size_t)i * nq + B + b] = u;
+    Tm[(size_t)b * D + i] = rb[i];
+    Tm[(size_t)(B + b) * D + i] = rb[2 * D + i];
+}
+
+// Front half: per-sample stage for B samples.  Fills Rt = [Z; U] (2B x D), Rtt (D x 2B) and Tm = [X - mu; U Fm]
+// in the workspace (layout for n = 2B rows).
+static int factor_front(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
+                        const double* G, int ldg, const double* mu0, const double* F0, int ldf0) {
+    const int n = 2 * B, nq = n;
     double* Rt = ctx->sg;                          // n x D   [Z; U]
     double* Tm = Rt + (size_t)n * D;               // n x D   [X - mu; U Fm]
     double* Fs = Tm + (size_t)n * D;               // n x D
     double* Rtt = Fs + (size_t)n * D;              // D x n
-    double* Gam = ctx->small;                      // n x n
-    double* Rg = Gam + (size_t)n * n;
-    double* Ap = Rg + (size_t)n * n;
-    double* Tt = Ap + (size_t)n * n;
-    int* info_g = ctx->ints;
-    int* info_t = ctx->ints + 1;
-
     // W = G Fm^T
     int kc = 1;
     int rc = gsmvi_panel_t_product(ctx, st, D, B, G, ldg, F0, ldf0, D, ctx->pp, &kc);
@@ -884,7 +906,63 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
     if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, D, B, Rt + (size_t)B * D, D, nullptr, 1.0, F0, ldf0, ctx->pp,
                                      &kc2)))
         return rc;
-    if ((rc = gsmvi_panel_finish(st, D, B, kc2, ctx->pp, nullptr, Tm + (size_t)B * D, D))) return rc;
+    return gsmvi_panel_finish(st, D, B, kc2, ctx->pp, nullptr, Tm + (size_t)B * D, D);
+}
+
+static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
+                       double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev);
+
+int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
+                      const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double* mu, double* F,
+                      int ldf, int* info_dev, int* n_reverts_dev) {
+    int rc = factor_front(ctx, st, D, B, Z, ldz, X, ldx, G, ldg, mu0, F0, ldf0);
+    if (rc) return rc;
+    return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev);
+}
+
+// Batch-sharded form, stage 1: this rank's B_local samples -> records.
+int gsmvi_factor_local_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int Bl, const double* Z, int ldz, const double* X,
+                            int ldx, const double* G, int ldg, const double* mu0, const double* F0, int ldf0,
+                            double* rec, int ldrec) {
+    int rc = factor_front(ctx, st, D, Bl, Z, ldz, X, ldx, G, ldg, mu0, F0, ldf0);
+    if (rc) return rc;
+    const double* Rt = ctx->sg;
+    const double* Tm = Rt + (size_t)2 * Bl * D;
+    hipLaunchKernelGGL(k_gsmf_pack, dim3((D + 255) / 256, Bl), dim3(256), 0, st, D, Bl, Rt, Tm, rec, ldrec);
+    return chk("k_gsmf_pack");
+}
+
+// Batch-sharded form, stage 2: every replica applies the combined update from ALL B records and the replicated Z.
+int gsmvi_factor_apply_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* rec,
+                            int ldrec, const double* mu0, const double* F0, int ldf0, double* mu, double* F, int ldf,
+                            int* info_dev, int* n_reverts_dev) {
+    const int n = 2 * B;
+    double* Rt = ctx->sg;
+    double* Tm = Rt + (size_t)n * D;
+    double* Fs = Tm + (size_t)n * D;
+    double* Rtt = Fs + (size_t)n * D;
+    hipLaunchKernelGGL(k_gsmf_unpack, dim3((D + 255) / 256, B), dim3(256), 0, st, D, B, Z, ldz, rec, ldrec, Rt, Rtt, n, Tm);
+    int rc = chk("k_gsmf_unpack");
+    if (rc) return rc;
+    return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev);
+}
+
+// Back half: from Rt, Rtt, Tm (n = 2B rows) to (mu, F).
+static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
+                       double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev) {
+    const int n = 2 * B, nq = n;                   // n is even
+    // workspace carve: ctx->sg holds 6*rmax*max_D doubles (rmax = 2B+8)
+    double* Rt = ctx->sg;                          // n x D   [Z; U]
+    double* Tm = Rt + (size_t)n * D;               // n x D   [X - mu; U Fm]
+    double* Fs = Tm + (size_t)n * D;               // n x D
+    double* Rtt = Fs + (size_t)n * D;              // D x n
+    double* Gam = ctx->small;                      // n x n
+    double* Rg = Gam + (size_t)n * n;
+    double* Ap = Rg + (size_t)n * n;
+    double* Tt = Ap + (size_t)n * n;
+    int* info_g = ctx->ints;
+    int* info_t = ctx->ints + 1;
+    int rc, kc2 = 1;
     // Gamma = Rt Rt^T
     if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, n, n, Rt, D, nullptr, 1.0, Rtt, nq, ctx->pp, &kc2))) return rc;
     if ((rc = gsmvi_panel_finish(st, n, n, kc2, ctx->pp, nullptr, Gam, n))) return rc;

@@ -44,6 +44,27 @@ def sharded_gsm_update(eng, X_local, G_local, mu0, S0, group=None, rec_all=None,
     return eng.gsm_apply(rec, mu0, S0, out=out)
 
 
+def sharded_gsm_factor_update(eng, Z, X_local, G_local, mu0, F0, lo, group=None, rec_all=None, out=None, flag=None,
+                              n_reverts=None, force_collective=False):
+    """Batch-sharded factor-form update (BASELINE config 5 on several GPUs): (mu, F, flag).
+
+    Z (B, D): the whitened draws of ALL samples, replicated (same key on every rank); X_local, G_local: samples
+    and scores of this rank's rows [lo, lo + B/P).  Each rank runs the per-sample stage for its rows (two of
+    the three passes over F0 divided by P), records [x - mu0 | u | u F0] are all-gathered (3D doubles per
+    sample, like the dense path) and every replica applies the identical rank-2B factor update."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    Bl = X_local.shape[0]
+    rec_local = eng.gsm_factor_local_stage(Z[lo:lo + Bl], X_local, G_local, mu0, F0)
+    if world == 1 and not (force_collective and dist.is_initialized()):
+        rec = rec_local
+    else:
+        if rec_all is None:
+            rec_all = eng.empty(Bl * world, rec_local.shape[1])
+        dist.all_gather_into_tensor(_as_torch(rec_all), _as_torch(rec_local).contiguous(), group=group)
+        rec = rec_all if isinstance(rec_all, torch.Tensor) else _as_torch(rec_all).numpy()
+    return eng.gsm_factor_apply(Z, rec, mu0, F0, out=out, flag=flag, n_reverts=n_reverts)
+
+
 def row_bounds(D, world, rank):
     """Rows [lo, hi) of the covariance owned by ``rank``: blocks of ceil(D / world) rows, the last one ragged
     (possibly empty ranks are not supported: D >= world)."""

@@ -244,6 +244,37 @@ class HipEngine:
             C.c_void_p(n_reverts.data_ptr()) if n_reverts is not None else None))
         return mu, F, flag
 
+    def gsm_factor_local_stage(self, Z_l, X_l, G_l, mu0, F0, out=None):
+        """Records [x - mu0 | u | u F0] of this rank's samples (batch-sharded factor path)."""
+        Bl, D = Z_l.shape
+        self._ensure(D, Bl)
+        rec = self.empty(Bl, self.record_len(D)) if out is None else out
+        pz, ldz = self._mat(Z_l, "Z")
+        px, ldx = self._mat(X_l, "X")
+        pg, ldg = self._mat(G_l, "G")
+        pf0, ldf0 = self._mat(F0, "F0")
+        pr, ldr = self._mat(rec, "rec")
+        _lib.check("gsmvi_gsm_factor_local_stage_f64", self.lib.gsmvi_gsm_factor_local_stage_f64(
+            self._ctx, self._stream(), D, Bl, pz, ldz, px, ldx, pg, ldg, self._vec(mu0, "mu0"), pf0, ldf0, pr, ldr))
+        return rec
+
+    def gsm_factor_apply(self, Z, rec, mu0, F0, out=None, flag=None, n_reverts=None):
+        """(mu, F, flag) from the replicated draws Z and ALL samples' records (batch-sharded factor path)."""
+        B, D = Z.shape
+        assert rec.shape[0] == B
+        self._ensure(D, B)
+        mu, F = (self.empty(D), self.empty(D, D)) if out is None else out
+        flag = self.new_flag() if flag is None else flag
+        pz, ldz = self._mat(Z, "Z")
+        pr, ldr = self._mat(rec, "rec")
+        pf0, ldf0 = self._mat(F0, "F0")
+        pf, ldf = self._mat(F, "F")
+        _lib.check("gsmvi_gsm_factor_apply_f64", self.lib.gsmvi_gsm_factor_apply_f64(
+            self._ctx, self._stream(), D, B, pz, ldz, pr, ldr, self._vec(mu0, "mu0"), pf0, ldf0,
+            self._vec(mu, "mu"), pf, ldf, C.c_void_p(flag.data_ptr()),
+            C.c_void_p(n_reverts.data_ptr()) if n_reverts is not None else None))
+        return mu, F, flag
+
     def gram(self, F):
         """cov = F^T F for the monitor / return value of the factor-form fit (one library GEMM per call;
         not on the per-iteration path)."""

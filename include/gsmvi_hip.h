@@ -132,6 +132,26 @@ int gsmvi_gsm_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
                                 double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev);
 
 /*
+ * The factor-form update in two stages, for the batch-sharded multi-GPU path (BASELINE config 5 on several GPUs;
+ * same decomposition as gsmvi_gsm_local_stage_f64 / gsmvi_gsm_apply_f64):
+ *   local stage : for this rank's B_local samples (rows of Z, X, G): W = G F0^T, the whitened scalars, u_b and
+ *                 u_b F0; one record per sample  rec[b] = [ x_b - mu0 (D) | u_b (D) | u_b F0 (D) ], row stride
+ *                 ldrec >= gsmvi_gsm_record_len(D).  Two of the three passes over F0 are divided by the number of
+ *                 ranks.  Records of all ranks are all-gathered (RCCL) by the caller;
+ *   apply       : every replica holds the same Z (B x D: the draw stream is replicated, gsmvi_randn_f64 is
+ *                 counter-based) and all B records, and runs the 2B x 2B positive-definite test and the rank-2B
+ *                 factor update.  Same outputs and revert semantics as gsmvi_gsm_factor_update_f64.
+ * gsmvi_gsm_factor_update_f64 == local stage with B_local = B followed by apply.
+ */
+int gsmvi_gsm_factor_local_stage_f64(gsmvi_ctx* ctx, void* stream, int D, int B_local,
+                                     const double* Z, int ldz, const double* X, int ldx, const double* G, int ldg,
+                                     const double* mu0, const double* F0, int ldf0, double* rec, int ldrec);
+int gsmvi_gsm_factor_apply_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
+                               const double* Z, int ldz, const double* rec, int ldrec,
+                               const double* mu0, const double* F0, int ldf0,
+                               double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev);
+
+/*
  * Profiling mode (used by bench.py for the roofline line): when on, the three kernels of the GSM
  * update are launched with dispatch-timestamp events; gsmvi_get_profile waits for the last call
  * and returns the kernel durations in milliseconds: ms[0] panel product, ms[1] per-sample

@@ -133,6 +133,40 @@ class OracleEngine:
             return out[0], out[1], flag
         return mu, Fn, flag
 
+    def gsm_factor_local_stage(self, Z_l, X_l, G_l, mu0, F0, out=None):
+        D = mu0.shape[0]
+        t = orc.gsm_factor_terms(Z_l, G_l, F0.T)                 # oracle convention: Sigma = F F^T
+        rec = np.zeros((Z_l.shape[0], self.record_len(D)))
+        rec[:, :D], rec[:, D:2 * D], rec[:, 2 * D:3 * D] = X_l - mu0[None, :], t["U"], t["U"] @ F0
+        if out is not None:
+            out[...] = rec
+            return out
+        return rec
+
+    def gsm_factor_apply(self, Z, rec, mu0, F0, out=None, flag=None, n_reverts=None):
+        flag = Flag() if flag is None else flag
+        B, D = Z.shape
+        U = rec[:, D:2 * D]
+        Y = U - Z
+        M = np.eye(D) + (Z.T @ Z - Y.T @ Y) / B
+        mu = mu0 + rec[:, 2 * D:3 * D].mean(axis=0)
+        try:
+            Cm = np.linalg.cholesky(0.5 * (M + M.T))
+            ok = bool(np.isfinite(Cm).all())
+        except np.linalg.LinAlgError:
+            ok = False
+        if ok:
+            Fn, flag.v = Cm.T @ F0, 0                            # (C^T F0)^T (C^T F0) = F0^T M F0
+        else:
+            mu, Fn, flag.v = mu0.copy(), F0.copy(), 1
+            if n_reverts is not None:
+                n_reverts.v += 1
+        if out is not None:
+            out[0][...] = mu
+            out[1][...] = Fn
+            return out[0], out[1], flag
+        return mu, Fn, flag
+
     def gram(self, F):
         return F.T @ F
 

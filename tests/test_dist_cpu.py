@@ -55,6 +55,29 @@ def _worker(rank, world, port, q):
             7, niter=30, batch_size=4, verbose=False)
         assert set(seen) == {4 // world}
         err = max(err, np.abs(mean_s - mean_1).max(), np.abs(cov_s - cov_1).max())
+        # batch-sharded FACTOR path (BASELINE config 5 on several GPUs): update and fit
+        from gsmvi_amd.dist import sharded_gsm_factor_update
+        stf = orc.make_update_state(12, 4, 9)
+        F0 = stf["L"].T.copy()                                    # engine convention: Sigma = F0^T F0
+        flo, fhi = shard_bounds(4, world, rank)
+        mu_f, F_f, fl = sharded_gsm_factor_update(eng, stf["Z"], stf["samples"][flo:fhi], stf["vs"][flo:fhi],
+                                                   stf["mu0"], F0, flo)
+        mu_o, S_o = orc.gsm_update_faithful(stf["samples"], stf["vs"], stf["mu0"], stf["S0"])
+        assert fl.v == 0
+        err = max(err, np.abs(mu_f - mu_o).max(), np.abs(F_f.T @ F_f - S_o).max())
+        m2, cov_t2, P2 = orc.make_gaussian_target(10, 4)          # factor form needs 2B <= D
+        seen2 = []
+
+        def lp_g2(x):
+            seen2.append(x.shape[0])
+            return orc.gaussian_score(x, m2, P2)
+
+        mean_fs, cov_fs = GSM(10, None, lp_g2, engine=OracleEngine()).fit(7, niter=30, batch_size=4, verbose=False,
+                                                                           shard=True, method="factor")
+        mean_f1, cov_f1 = GSM(10, None, lambda x: orc.gaussian_score(x, m2, P2), engine=OracleEngine()).fit(
+            7, niter=30, batch_size=4, verbose=False, method="factor")
+        assert set(seen2) == {4 // world}
+        err = max(err, np.abs(mean_fs - mean_f1).max(), np.abs(cov_fs - cov_f1).max())
         # row-block sharded covariance (ragged: D = 25 rows over 2 ranks = 13 + 12)
         from gsmvi_amd.dist import row_sharded_gsm_update, row_bounds
         st = orc.make_update_state(25, 6, 5)

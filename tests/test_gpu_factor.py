@@ -114,3 +114,30 @@ def test_fit_factor_equals_dense_fit_same_z_stream():
     b0 = gsmvi_amd.GSM(D, tgt.lp, tgt.lp_g).fit(3, niter=0, batch_size=4, verbose=False, method="factor")
     assert rel_err(b0[0], a0[0]) < 1e-11 and rel_err(b0[1], a0[1]) < 1e-11
     assert np.isfinite(a[1]).all() and np.isfinite(b[1]).all()
+
+
+@pytest.mark.parametrize("D,B,P", [(12, 4, 2), (100, 16, 4), (256, 32, 8), (1024, 32, 2), (320, 64, 8)])
+def test_sharded_two_stage_factor_update_equals_fused(D, B, P):
+    """gsmvi_gsm_factor_local_stage_f64 on P row shards + gsmvi_gsm_factor_apply_f64 on the concatenated records
+    (what P ranks and one all-gather do, gsm-vi_amd/dist.py) equals the fused update and the dense oracle."""
+    import torch
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    orc, st, F0 = _setup(D, B, 3 * D + B)
+    Z, X, G, mu0, F0d = (eng.asarray(a) for a in (st["Z"], st["samples"], st["vs"], st["mu0"], F0))
+    per = B // P
+    rec = torch.cat([eng.gsm_factor_local_stage(Z[r * per:(r + 1) * per], X[r * per:(r + 1) * per],
+                                                G[r * per:(r + 1) * per], mu0, F0d) for r in range(P)])
+    n_rev = eng.new_flag()
+    mu, F, flag = eng.gsm_factor_apply(Z, rec, mu0, F0d, n_reverts=n_rev)
+    mu_1, F_1, flag_1 = eng.gsm_factor_update(Z, X, G, mu0, F0d)
+    assert eng.read_flag(flag) == 0 and eng.read_flag(flag_1) == 0 and eng.read_flag(n_rev) == 0
+    Fn, F1 = F.cpu().numpy(), F_1.cpu().numpy()
+    assert rel_err(mu.cpu().numpy(), mu_1.cpu().numpy()) < 1e-12 and rel_err(Fn.T @ Fn, F1.T @ F1) < 1e-11
+    mu_o, S_o = orc.gsm_update_batched(st["samples"], st["vs"], st["mu0"], st["S0"])
+    assert rel_err(mu.cpu().numpy(), mu_o) < 1e-10 and rel_err(Fn.T @ Fn, S_o) < 1e-10
+    # the revert passthrough of the apply stage: NaN in a record's u-part (a NaN score) -> old state, counted
+    rec[0, D] = float("nan")
+    mu_b, F_b, flag_b = eng.gsm_factor_apply(Z, rec, mu0, F0d, n_reverts=n_rev)
+    assert eng.read_flag(flag_b) != 0 and eng.read_flag(n_rev) == 1
+    assert torch.equal(mu_b, mu0) and torch.equal(F_b, F0d)
