@@ -126,3 +126,17 @@ def test_autograd_score_helper_and_medium_fit():
     mean, cov = gsmvi_amd.GSM(D, None, lp_g).fit(7, niter=400, batch_size=16, verbose=False)
     e0 = max(rel_err(np.zeros(D), m), rel_err(np.eye(D), cov_t))
     assert rel_err(mean, m) < 0.05 and rel_err(cov, cov_t) < 0.05 < e0      # well on its way after 400 its
+
+
+def test_example_scripts_run():
+    """examples/*.py: the reference's example workflows through the drop-in API (numpy callback and device-native)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    for script, args in (("gsm_gaussian.py", ["5", "2", "500", "dense"]), ("gsm_gaussian.py", ["16", "4", "600", "factor"]),
+                         ("bam_gaussian.py", ["5", "2", "100"])):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script)] + args, capture_output=True,
+                           text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert "differs" not in p.stdout and "mean ok" in p.stdout, p.stdout
