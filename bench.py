@@ -127,6 +127,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before the first HIP call: dmabuf IPC for RCCL
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or bool(os.environ.get("GSMVI_BENCH_FORCE_DIST"))   # the env knob exercises RCCL at N=1
