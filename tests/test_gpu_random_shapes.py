@@ -1,0 +1,56 @@
+"""Randomised parity of the dense update through the public API (gsm_numpy.py:27-55): hypothesis draws D, B, the
+input dtype, the memory layout (row strides, offsets) and the container (numpy / torch device tensors); every
+draw is checked against the pinned oracle, for purity of the inputs and for the reference's dtype contract
+(float32 in -> float64 out, gsm_numpy.py:47)."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st, HealthCheck
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(D=st.integers(1, 200), B=st.integers(1, 40), seed=st.integers(0, 10_000), f32=st.booleans(),
+       pad=st.integers(0, 3), off=st.integers(0, 2), as_torch=st.booleans())
+def test_random_shapes_layouts_dtypes(D, B, seed, f32, pad, off, as_torch):
+    import torch
+    import gsmvi_amd
+    from oracle import gsm_oracle as orc
+    s = orc.make_update_state(D, B, seed)
+    dt = np.float32 if f32 else np.float64
+    X, G, mu0, S0 = (np.asarray(s[k], dtype=dt) for k in ("samples", "vs", "mu0", "S0"))
+    S0 = 0.5 * (S0 + S0.T)                                     # exactly symmetric also after the float32 cast
+    mu_o, S_o = orc.gsm_update_batched(X.astype(np.float64), G.astype(np.float64), mu0.astype(np.float64),
+                                       S0.astype(np.float64))
+
+    def laid_out(a):                                           # a view into a larger buffer: row stride D + pad, offset
+        if a.ndim == 1:
+            return a
+        buf = np.zeros((a.shape[0], a.shape[1] + pad + off), dtype=a.dtype)
+        buf[:, off:off + a.shape[1]] = a
+        return buf[:, off:off + a.shape[1]]
+
+    args = [laid_out(X), laid_out(G), mu0, laid_out(S0)]
+    keep = [a.copy() for a in args]
+    if as_torch:
+        dev = [torch.as_tensor(np.ascontiguousarray(a)).cuda() for a in args]
+        if pad + off:                                          # strided device views as well
+            big = [torch.zeros(a.shape[0], a.shape[1] + pad + off, dtype=a.dtype, device="cuda") if a.dim() == 2 else a
+                   for a in dev]
+            for b_, a in zip(big, dev):
+                if a.dim() == 2:
+                    b_[:, off:off + a.shape[1]] = a
+            dev = [b_[:, off:off + a.shape[1]] if a.dim() == 2 else a for b_, a in zip(big, dev)]
+        mu, S = gsmvi_amd.gsm_update(*dev)
+        assert isinstance(mu, torch.Tensor) and mu.dtype == torch.float64 and S.dtype == torch.float64
+        mu, S = mu.cpu().numpy(), S.cpu().numpy()
+    else:
+        mu, S = gsmvi_amd.gsm_update(*args)
+        assert mu.dtype == np.float64 and S.dtype == np.float64           # gsm_numpy.py:47
+        for a, k in zip(args, keep):
+            assert np.array_equal(a, k)                                   # inputs untouched
+    assert mu.shape == (D,) and S.shape == (D, D)
+    tol = 1e-10
+    assert rel_err(mu, mu_o) < tol and rel_err(S, S_o) < tol, (D, B, seed, f32, pad, off, as_torch)
