@@ -73,13 +73,16 @@ class BaM:
 
     def fit(self, key, regf, mean=None, cov=None, batch_size=2, niter=5000, nprint=10, verbose=True,
             check_goodness=True, monitor=None, retries=10, jitter=1e-6, *, sampler="cholesky", rng="numpy",
-            as_torch=False, forced_samples=None):
+            as_torch=False, forced_samples=None, shard=False, group=None):
         """gsmvi/bam.py:140-216.  Kept: niter+1 iterations (:178); nprint clamp (:177); reg = regf(i)
         per attempt (:196); jitter on the diagonal and symmetrisation (:198-199, done in-kernel);
         retry on any exception up to ``retries`` then re-raise (:189-206); Cholesky accept/revert of
         both mean and cov (:208-212); monitor cadence (:182-185,:214-215).
         Deviation: the JAX threefry key split + per-iteration numpy re-seed (:191-192) is replaced by
-        one private RandomState(key) stream (JAX is not a dependency)."""
+        one private RandomState(key) stream (JAX is not a dependency).
+        ``shard=True`` (BASELINE config 4: B=128 sharded 16 per GPU; one process per GPU, torch.distributed
+        initialised): every rank draws the same Z, samples and scores only its batch_size/world rows, the
+        (x_b, g_b) rows are all-gathered (dist.sharded_bam_update) and every replica runs the identical update."""
         eng = self._engine if self._engine is not None else get_engine()
         D, B = self.D, int(batch_size)
         mean_t = eng.zeros(D) if mean is None else eng.clone(mean).reshape(D)
@@ -93,9 +96,17 @@ class BaM:
         native = bool(getattr(self.lp_g, "device_native", False))
         mon_native = bool(getattr(monitor, "device_native", False)) if monitor is not None else False
 
+        lo, hi = 0, B
+        if shard:
+            assert sampler == "cholesky" and forced_samples is None, "shard=True needs the replicated z-stream"
+            from .dist import sharded_bam_update, shard_bounds
+            import torch.distributed as _dist
+            world = _dist.get_world_size(group) if _dist.is_initialized() else 1
+            rank = _dist.get_rank(group) if _dist.is_initialized() else 0
+            lo, hi = shard_bounds(B, world, rank)
         mean_new, cov_new = eng.empty(D), eng.empty(D, D)
         R, R_new = eng.empty(D, D), eng.empty(D, D)
-        Xbuf = eng.empty(B, D)
+        Xbuf = eng.empty(hi - lo, D)
         flag, uflag, n_rev = eng.new_flag(), eng.new_flag(), eng.new_flag()
         use_factor = sampler == "cholesky" and forced_samples is None
         if use_factor:                      # the sampling factor of the initial covariance
@@ -133,11 +144,15 @@ class BaM:
                             ndraw += 1
                         else:
                             Z = eng.normal_from_host(rs.standard_normal((B, D)))
-                        X = eng.sample(Z, mean_t, R, out=Xbuf)
+                        X = eng.sample(Z[lo:hi], mean_t, R, out=Xbuf)     # only this rank's rows when sharded
                     vs = self.lp_g(X) if native else eng.asarray(self.lp_g(eng.to_numpy(X)))
                     nevals += B
                     reg = regf(i)
-                    eng.bam_update(X, vs, mean_t, cov_t, reg, jitter, out=(mean_new, cov_new), flag=uflag)
+                    if shard:
+                        sharded_bam_update(eng, X, vs, mean_t, cov_t, reg, jitter, group=group,
+                                           out=(mean_new, cov_new), flag=uflag)
+                    else:
+                        eng.bam_update(X, vs, mean_t, cov_t, reg, jitter, out=(mean_new, cov_new), flag=uflag)
                     break
                 except Exception as e:                      # noqa: BLE001 -- reference behaviour
                     if j < retries:

@@ -78,6 +78,20 @@ def _worker(rank, world, port, q):
             7, niter=30, batch_size=4, verbose=False, method="factor")
         assert set(seen2) == {4 // world}
         err = max(err, np.abs(mean_fs - mean_f1).max(), np.abs(cov_fs - cov_f1).max())
+        # sharded BaM FIT (BASELINE config 4 in miniature): same key everywhere, local rows scored, replicas identical
+        from gsmvi_amd.bam import BaM, Regularizers
+        seen3 = []
+
+        def lp_g3(x):
+            seen3.append(x.shape[0])
+            return orc.gaussian_score(x, m, P)
+
+        mean_bs, cov_bs = BaM(6, None, lp_g3, engine=OracleEngine()).fit(7, Regularizers().constant(5.0), niter=20,
+                                                                         batch_size=4, verbose=False, shard=True)
+        mean_b1, cov_b1 = BaM(6, None, lambda x: orc.gaussian_score(x, m, P), engine=OracleEngine()).fit(
+            7, Regularizers().constant(5.0), niter=20, batch_size=4, verbose=False)
+        assert set(seen3) == {4 // world}
+        err = max(err, np.abs(mean_bs - mean_b1).max(), np.abs(cov_bs - cov_b1).max())
         # row-block sharded covariance (ragged: D = 25 rows over 2 ranks = 13 + 12)
         from gsmvi_amd.dist import row_sharded_gsm_update, row_bounds
         st = orc.make_update_state(25, 6, 5)
