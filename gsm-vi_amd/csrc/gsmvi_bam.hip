@@ -324,6 +324,28 @@ __global__ __launch_bounds__(256) void k_lowrank_update(int D, int KF, const dou
 // The work matrix is addressed column-major (the input is symmetric, so that is free): every O(n^3) loop of
 // tred2 then runs down a contiguous column, and its result is already the row-per-eigenvector layout the
 // QL rotations want.
+// sqrt(a^2 + b^2); the library's hypot (overflow-safe, ~3x the cost) only outside the range where squaring is safe
+static inline double fast_hypot(double a, double b) {
+    const double x = std::fabs(a), y = std::fabs(b), mx = x > y ? x : y;
+    if (mx > 1e150 || (mx < 1e-150 && mx > 0.0)) return std::hypot(a, b);
+    return std::sqrt(x * x + y * y);
+}
+
+// dot product with four independent partial sums in a fixed order (lets the host compiler vectorise it without
+// reassociating: the order is part of the source, so results are reproducible)
+static inline double dot4(const double* __restrict__ a, const double* __restrict__ b, int n) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+    for (; k + 4 <= n; k += 4) {
+        s0 += a[k] * b[k];
+        s1 += a[k + 1] * b[k + 1];
+        s2 += a[k + 2] * b[k + 2];
+        s3 += a[k + 3] * b[k + 3];
+    }
+    for (; k < n; ++k) s0 += a[k] * b[k];
+    return (s0 + s1) + (s2 + s3);
+}
+
 static bool sym_eigh(int n, std::vector<double>& A, std::vector<double>& w, std::vector<double>& E) {
     for (size_t k = 0; k < (size_t)n * n; ++k)
         if (!(A[k] == A[k]) || std::fabs(A[k]) > 1.7e308) return false;          // NaN / inf
@@ -358,11 +380,12 @@ static bool sym_eigh(int n, std::vector<double>& A, std::vector<double>& w, std:
             for (int j = 0; j < i; ++j) {
                 f = d[j];
                 Vij(j, i) = f;
-                g = e[j] + Vij(j, j) * f;
-                for (int k = j + 1; k <= i - 1; ++k) {
-                    g += Vij(k, j) * d[k];
-                    e[k] += Vij(k, j) * f;
-                }
+                // column j of the work matrix is contiguous (column-major addressing): one dot, one axpy
+                const double* __restrict__ cj = &Vij(j + 1, j);
+                const int len = i - 1 - j;
+                g = e[j] + Vij(j, j) * f + (len > 0 ? dot4(cj, &d[j + 1], len) : 0.0);
+                double* __restrict__ ek = &e[j + 1];
+                for (int k = 0; k < len; ++k) ek[k] += cj[k] * f;
                 e[j] = g;
             }
             f = 0.0;
@@ -375,7 +398,12 @@ static bool sym_eigh(int n, std::vector<double>& A, std::vector<double>& w, std:
             for (int j = 0; j < i; ++j) {
                 f = d[j];
                 g = e[j];
-                for (int k = j; k <= i - 1; ++k) Vij(k, j) -= (f * e[k] + g * d[k]);
+                {
+                    double* __restrict__ cj = &Vij(j, j);
+                    const double* __restrict__ ek = &e[j];
+                    const double* __restrict__ dk = &d[j];
+                    for (int k = 0; k < i - j; ++k) cj[k] -= (f * ek[k] + g * dk[k]);
+                }
                 d[j] = Vij(i - 1, j);
                 Vij(i, j) = 0.0;
             }
@@ -389,9 +417,10 @@ static bool sym_eigh(int n, std::vector<double>& A, std::vector<double>& w, std:
         if (h != 0.0) {
             for (int k = 0; k <= i; ++k) d[k] = Vij(k, i + 1) / h;
             for (int j = 0; j <= i; ++j) {
-                double g = 0.0;
-                for (int k = 0; k <= i; ++k) g += Vij(k, i + 1) * Vij(k, j);
-                for (int k = 0; k <= i; ++k) Vij(k, j) -= g * d[k];
+                double* __restrict__ cj = &Vij(0, j);
+                const double g = dot4(&Vij(0, i + 1), cj, i + 1);
+                const double* __restrict__ dk = d.data();
+                for (int k = 0; k <= i; ++k) cj[k] -= g * dk[k];
             }
         }
         for (int k = 0; k <= i; ++k) Vij(k, i + 1) = 0.0;
@@ -422,7 +451,7 @@ static bool sym_eigh(int n, std::vector<double>& A, std::vector<double>& w, std:
                 if (++iter > 200) return false;
                 double g = d[l];
                 double p = (d[l + 1] - g) / (2.0 * e[l]);
-                double r = std::hypot(p, 1.0);
+                double r = fast_hypot(p, 1.0);
                 if (p < 0) r = -r;
                 d[l] = e[l] / (p + r);
                 d[l + 1] = e[l] * (p + r);
@@ -440,14 +469,14 @@ static bool sym_eigh(int n, std::vector<double>& A, std::vector<double>& w, std:
                     s2 = s;
                     g = c * e[i];
                     h = c * p;
-                    r = std::hypot(p, e[i]);
+                    r = fast_hypot(p, e[i]);
                     e[i + 1] = s * r;
                     s = e[i] / r;
                     c = p / r;
                     p = c * d[i] - s * g;
                     d[i + 1] = h + s * (c * g + s * d[i]);
-                    double* vi = &Vt[(size_t)i * n];
-                    double* vi1 = vi + n;
+                    double* __restrict__ vi = &Vt[(size_t)i * n];
+                    double* __restrict__ vi1 = &Vt[(size_t)(i + 1) * n];      // distinct rows: vectorised
                     for (int k = 0; k < n; ++k) {
                         const double hk = vi1[k];
                         vi1[k] = s * vi[k] + c * hk;
@@ -479,14 +508,13 @@ static bool sym_eigh(int n, std::vector<double>& A, std::vector<double>& w, std:
 // host Cholesky of an SPD n x n matrix (row-major, lower factor written in place); false if not PD
 static bool host_cholesky(int n, std::vector<double>& A) {
     for (int j = 0; j < n; ++j) {
-        double d = A[(size_t)j * n + j];
-        for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+        const double* rj = &A[(size_t)j * n];
+        double d = rj[j] - dot4(rj, rj, j);
         if (!(d > 0.0)) return false;
         d = sqrt(d);
         A[(size_t)j * n + j] = d;
         for (int i = j + 1; i < n; ++i) {
-            double s = A[(size_t)i * n + j];
-            for (int k = 0; k < j; ++k) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+            const double s = A[(size_t)i * n + j] - dot4(&A[(size_t)i * n], rj, j);
             A[(size_t)i * n + j] = s / d;
         }
     }
