@@ -11,6 +11,9 @@ ARGS="$ROOT/bench.py --steps 420 --warmup 42 --no-cpu-baseline"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS --no-graph > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS --no-graph > $OUT/pmc_write.log 2>&1
+# MFMA pipe occupancy (north_star: "MFMA utilisation against gfx950 peak"): busy cycles of the matrix pipe and the
+# fp64 MFMA op count, against the time the GPU was active during the dispatch
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $ARGS --no-graph > $OUT/pmc_mfma.log 2>&1
 cd $ROOT
 python3 - "$OUT" <<'PY'
 import csv, glob, json, sys, collections
@@ -21,8 +24,10 @@ if st:
     rows = [r for r in csv.DictReader(open(st[0])) if r["Name"].lstrip("void ").startswith("k_")]
     res["kernel_stats"] = {r["Name"].split("(")[0]: {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                                                     "min_ns": int(r["MinNs"]), "max_ns": int(r["MaxNs"])} for r in rows}
-for name in ("FETCH_SIZE", "WRITE_SIZE"):
-    files = glob.glob(out + f"/pmc_{'fetch' if name=='FETCH_SIZE' else 'write'}/**/*counter_collection.csv", recursive=True)
+for name in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F64",
+             "GRBM_GUI_ACTIVE"):
+    sub = 'fetch' if name == 'FETCH_SIZE' else ('write' if name == 'WRITE_SIZE' else 'mfma')
+    files = glob.glob(out + f"/pmc_{sub}/**/*counter_collection.csv", recursive=True)
     acc = collections.defaultdict(list)
     for f in files:
         for r in csv.DictReader(open(f)):
@@ -35,6 +40,18 @@ def per_launch(kern):
     f = next((v["mean"] for k, v in res.get("FETCH_SIZE", {}).items() if kern in k), None)
     w = next((v["mean"] for k, v in res.get("WRITE_SIZE", {}).items() if kern in k), None)
     return None if f is None or w is None else {"fetch_KiB_raw": f, "write_KiB": w, "bytes": (2.0 * f + w) * 1024.0}
+# MFMA pipe utilisation per kernel.  SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all 1024 matrix pipes (64 per
+# v_mfma_f64_16x16x4_f64: checked against the op count); GRBM_GUI_ACTIVE is useless under per-dispatch counter
+# collection (it spans the collection overhead), so the busy time per SIMD at the 2.4 GHz peak clock is set against the
+# kernel's average duration from the kernel-trace pass.
+mf = {}
+for k, v in res.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).items():
+    dur = next((d["avg_ns"] for n_, d in res.get("kernel_stats", {}).items() if n_ == k), None)
+    busy_us = v["mean"] / 1024.0 / 2400.0
+    mf[k] = {"mfma_busy_cycles_all_simds": v["mean"], "mfma_busy_us_per_simd_at_2.4GHz": busy_us,
+             "kernel_avg_us": dur / 1e3 if dur else None, "mfma_util": busy_us / (dur / 1e3) if dur else None,
+             "mfma_f64_flop": 512.0 * res.get("SQ_INSTS_VALU_MFMA_MOPS_F64", {}).get(k, {}).get("mean", 0.0)}
+res["mfma_util"] = {k: v for k, v in mf.items() if v["mfma_busy_cycles_all_simds"] > 0}
 cov, pan, sca = per_launch("k_gsm_cov_sym"), per_launch("k_panel_fast"), per_launch("k_gsm_scalars_fast")
 if cov:
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 420 "

@@ -71,3 +71,37 @@ def test_product_package_never_imports_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("oracle-backed", "").replace("oracle(test", ""), \
                     f"{f} mentions the oracle"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,B", [(64, 8), (1024, 32), (37, 5)])
+def test_plain_c_program_drives_the_abi(tmp_path, D, B):
+    """tests/abi_c/abi_smoke.c: a C99 program (gcc, no C++, no torch) links libgsmvi_hip.so, passes raw HIP device
+    pointers, and reproduces the oracle -- the drop-in boundary is a C ABI, not a Python extension."""
+    import subprocess
+    import numpy as np
+    from oracle import gsm_oracle as orc
+    from gsmvi_amd import _lib
+    from conftest import rel_err
+    libdir = os.path.dirname(_lib.library_path())
+    exe = str(tmp_path / "abi_smoke")
+    cmd = ["gcc", "-std=c99", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "abi_c", "abi_smoke.c"), "-o", exe, "-L" + libdir, "-lgsmvi_hip",
+           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    st = orc.make_update_state(D, B, 7)
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(np.array([D, B], dtype=np.int32).tobytes())
+        for k in ("samples", "vs", "mu0", "S0"):
+            f.write(np.ascontiguousarray(st[k], dtype=np.float64).tobytes())
+    p = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True,
+                       timeout=120)
+    assert p.returncode == 0, (p.returncode, p.stderr[-2000:])
+    raw = open(tmp_path / "out.bin", "rb").read()
+    out = np.frombuffer(raw[:8 * (D + 2 * D * D)], dtype=np.float64)
+    info = int(np.frombuffer(raw[8 * (D + 2 * D * D):], dtype=np.int32)[0])
+    mu, S, R = out[:D], out[D:D + D * D].reshape(D, D), out[D + D * D:].reshape(D, D)
+    mu_o, S_o = orc.gsm_update_faithful(st["samples"], st["vs"], st["mu0"], st["S0"])
+    assert rel_err(mu, mu_o) < 1e-11 and rel_err(S, S_o) < 1e-11 and info == 0
+    assert rel_err(R.T @ R, S_o) < 1e-11 and np.array_equal(np.tril(R, -1), np.zeros_like(R))
