@@ -262,11 +262,13 @@ def main():
     alg_bytes_update = 16.0 * D * D + 16.0 * B * D                     # pass B
     alg_bytes_total = 24.0 * D * D + 72.0 * B * D                      # whole update
     achieved = alg_bytes_update / (avg_ms["cov_update"] * 1e-3) / 1e9
-    traffic = None
+    traffic, mfma_util = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("k_gsm_cov_update_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("k_gsm_cov_update_bytes_per_launch")
+            mfma_util = next((v.get("util") for k, v in (tj.get("mfma_util") or {}).items() if "k_gsm_cov_sym" in k), None)
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": "k_gsm_cov_sym" if (D % 32 == 0 and B in (16, 32, 64)) else "k_gsm_cov_update",
@@ -274,7 +276,8 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes_update,
                 "avg_kernel_us": {k: v * 1e3 for k, v in avg_ms.items()},
-                "whole_update_algorithmic_GBs": alg_bytes_total * value / 1e9}
+                "whole_update_algorithmic_GBs": alg_bytes_total * value / 1e9,
+                "mfma_pipe_util_profiled": mfma_util}     # SQ_VALU_MFMA_BUSY_CYCLES pass, profiles/traffic.json
     # ---- calibration: the attainable HBM rate on this box (device copy of 1 GiB, read + write
     # bytes) and what a plain copy of one covariance costs in the same cold ring (it moves 16 D^2 bytes, the
     # covariance kernel's algorithmic count) -- torch's copy kernel, plumbing, not the product path.

@@ -61,7 +61,12 @@ if cov:
                "k_gsm_cov_update_fetch_KiB_raw": cov["fetch_KiB_raw"], "k_gsm_cov_update_write_KiB": cov["write_KiB"],
                "k_gsm_cov_update_bytes_per_launch": cov["bytes"],
                "k_panel_fast_bytes_per_launch": pan["bytes"] if pan else None,
-               "k_gsm_scalars_bytes_per_launch": sca["bytes"] if sca else None},
+               "k_gsm_scalars_bytes_per_launch": sca["bytes"] if sca else None,
+               "mfma_util": {k.replace("void ", ""): {"busy_us_per_simd_at_2.4GHz": v["mfma_busy_us_per_simd_at_2.4GHz"],
+                                                       "kernel_avg_us": v["kernel_avg_us"], "util": v["mfma_util"],
+                                                       "f64_flop": v["mfma_f64_flop"]}
+                             for k, v in res.get("mfma_util", {}).items()
+                             if any(t in k for t in ("k_gsm_cov_sym", "k_panel_fast<2, false", "k_gsmf_update_fast"))}},
               open(out + "/traffic.json", "w"), indent=1)
 json.dump(res, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])
