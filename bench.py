@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--tune", action="append", default=[], help="name=value launch knob (experiments)")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="also measure the throughput with this many independent updates in flight (one HIP stream "
+                         "and one engine context each; compute of one overlaps the collective of another). Reported "
+                         "as value_in_flight beside the sequential `value`; opt-in")
     ap.add_argument("--shard", choices=("batch", "rows"), default="batch",
                     help="N>1 decomposition: batch (north_star; records all-gathered) or covariance row blocks "
                          "(SURVEY 8(f)3; SG column slices all-gathered, D^2 passes divided by N)")
@@ -220,6 +224,67 @@ def main():
     ms_per_step = el / args.steps * 1e3
     value = args.steps / el
 
+    # ---- opt-in: several independent updates in flight (throughput of independent chains, not of one fit) -----
+    value_in_flight = None
+    if args.in_flight > 1:
+        from gsmvi_amd.engine import HipEngine
+        nl = args.in_flight
+        engs = [eng] + [HipEngine(local_rank) for _ in range(nl - 1)]        # one context (workspace) per stream
+        recs = [rec_all] + [eng.empty(B, eng.record_len(D)) if use_dist else None for _ in range(nl - 1)]
+        lanes = [torch.cuda.Stream() for _ in range(nl)]
+
+        def lane_step(k, ln):
+            it = inst[k % n_inst]
+            if not use_dist:
+                engs[ln].gsm_update(it["X"], it["G"], it["mu0"], it["S0"], out=(it["mu"], it["S"]))
+            elif rows:
+                row_sharded_gsm_update(engs[ln], it["X"], it["G"], it["mu0"], it["S0r"], out=(it["mu"], it["Sr"]))
+            else:
+                sharded_gsm_update(engs[ln], it["X"][lo:hi], it["G"][lo:hi], it["mu0"], it["S0"], rec_all=recs[ln],
+                                   out=(it["mu"], it["S"]), force_collective=True)
+
+        def issue():
+            cur = torch.cuda.current_stream()
+            for sl in lanes:
+                sl.wait_stream(cur)
+            for k in range(n_inst):
+                with torch.cuda.stream(lanes[k % nl]):
+                    lane_step(k, k % nl)
+            for sl in lanes:
+                cur.wait_stream(sl)
+
+        issue()
+        torch.cuda.synchronize()
+        gfl = None
+        if not args.no_graph:
+            try:
+                gfl = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gfl):
+                    issue()
+            except Exception:
+                gfl = None
+                torch.cuda.synchronize()
+        if use_dist:
+            okf = torch.tensor([1 if gfl is not None else 0], device="cuda")
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if int(okf.item()) == 0:
+                gfl = None
+        reps = max(1, args.steps // n_inst)
+        for _ in range(2):
+            gfl.replay() if gfl is not None else issue()
+        barrier()
+        tf0 = time.perf_counter()
+        for _ in range(reps):
+            gfl.replay() if gfl is not None else issue()
+        barrier()
+        elf = time.perf_counter() - tf0
+        if use_dist:
+            tt = torch.tensor([elf], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elf = float(tt.item())
+        value_in_flight = {"updates_per_s": reps * n_inst / elf, "in_flight": nl,
+                           "launch": "hipGraph" if gfl is not None else "eager"}
+
     # ---- cache-resident rate: one instance, what a fit loop with a single covariance sees ------
     value_hot = None
     if not use_dist:
@@ -344,6 +409,8 @@ def main():
                       (f"covariance row blocks x{world} + RCCL all-gather of SG column slices" if rows else
                        f"batch-sharded x{world} + RCCL all-gather")},
            "value_cache_resident": value_hot, "fit_iterations_per_s": fit_rate, "roofline": roofline}
+    if value_in_flight is not None:
+        out["value_in_flight"] = value_in_flight
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(D, B, args.cpu_seconds)
     if use_dist:

@@ -46,3 +46,9 @@ def test_bench_rccl_path_world1():
 def test_bench_row_block_path_world1():
     d = _run({"GSMVI_BENCH_FORCE_DIST": "1"}, "--steps", "42", "--warmup", "21", "--no-cpu-baseline", "--shard", "rows")
     assert d["n_gpus"] == 1 and "row blocks" in d["config"]["parallelism"] and d["value"] > 0
+
+
+def test_bench_in_flight_option():
+    """--in-flight 2: two independent updates on two streams / two engine contexts (opt-in secondary figure)."""
+    d = _run({}, "--steps", "42", "--warmup", "21", "--no-cpu-baseline", "--in-flight", "2")
+    assert d["value"] > 0 and d["value_in_flight"]["in_flight"] == 2 and d["value_in_flight"]["updates_per_s"] > 0
