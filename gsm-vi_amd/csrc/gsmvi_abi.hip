@@ -135,7 +135,8 @@ static void ws_sizes(int D, int B, size_t* n_pp, size_t* n_sg, size_t* n_small, 
     const size_t potrf_scratch = (size_t)((((D > R ? D : R) + 63) / 64) * 64 * 64);
     if (*n_pp < potrf_scratch) *n_pp = potrf_scratch;
     *n_sg = (size_t)R * D * 4;                                 // SG + BaM factor panels
-    *n_small = (size_t)8 * R + (size_t)6 * R * R + 4096;
+    // + the device chain of BaM's small matrix function: five padded 144 x 144 iterates, coefficients, BB (n <= 129)
+    *n_small = (size_t)8 * R + (size_t)6 * R * R + 4096 + (size_t)5 * 144 * 144 + 64 + (size_t)129 * 129 + 64;
 }
 
 size_t gsmvi_workspace_bytes(int max_D, int max_B) {
@@ -209,6 +210,7 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "panel_kc")) ctx->tune_panel_kc = value;
     else if (!strcmp(name, "update_sb")) ctx->tune_update_sb = value;
     else if (!strcmp(name, "no_fast")) ctx->tune_no_fast = value;
+    else if (!strcmp(name, "bam_host")) ctx->tune_bam_host = value;
     else if (!strcmp(name, "scalars_nt")) ctx->tune_scalars_nt = value;
     else if (!strcmp(name, "cov_dbg")) ctx->tune_cov_dbg = value;   // ablation bits, timing experiments only
     else {

@@ -521,6 +521,11 @@ static bool host_cholesky(int n, std::vector<double>& A) {
     return true;
 }
 
+int gsmvi_bam_small_device(hipStream_t st, int n, double reg, const double* Nd, const double* M1, const double* N0,
+                           double* scratch, double* Ld, double* Upk, int* info_dev);
+int gsmvi_bam_small_nmax();
+size_t gsmvi_bam_small_scratch_doubles(int n);
+
 int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X, int ldx, const double* G,
                    int ldg, const double* mu0, const double* S0, int lds0, double reg, double jitter, double* mu,
                    double* S, int lds, int* info_dev) {
@@ -553,13 +558,23 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     double* M1T = Nd + (size_t)n * n;              // n x n
     double* Upk = M1T + (size_t)n * n;             // n(n+1)/2: packed rows of L^T
     hipLaunchKernelGGL(k_bam_nmat, dim3((n * n + 255) / 256), dim3(256), 0, st, n, M1, N0, Nd, M1T);
+    const double* Ldinv = Ld + (size_t)n * n;
+    const bool on_device = n <= gsmvi_bam_small_nmax() && !ctx->tune_bam_host;
+    if (on_device) {
+        // the whole (B+1) x (B+1) matrix function on the device (gsmvi_bam_small.hip): no copy, no synchronisation
+        double* scratch = Upk + (size_t)n * (n + 1) / 2 + 2;
+        if ((rc = gsmvi_bam_small_device(st, n, reg, Nd, M1, N0, scratch, Ld, Upk, info_dev ? info_dev : ctx->ints + 8)))
+            return rc;
+    }
     static const bool timing = getenv("GSMVI_BAM_TIMING") != nullptr;     // diagnostic: host phase times on stderr
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
     };
     const auto t_0 = tnow();
-    // ---- host: the (B+1) x (B+1) matrix function (bam.py:108-110) ----
+    const bool lanes16 = n <= BAMF_NMAX;
+    if (!on_device) {
+    // ---- host fallback (B > 128, or tuning knob bam_host): the (B+1) x (B+1) matrix function (bam.py:108-110) ----
     // pinned staging: [M1 | N0 | N] down, [L | Ldinv | zg | vg | packed L^T] up.  (Pageable buffers make the
     // copies take the runtime's blocking staging path: 2.2 ms per call became 5+ ms when calls were queued
     // back to back.)
@@ -609,7 +624,6 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
             }
         if (!host_cholesky(n, BBm)) bad = 1;
     }
-    const bool lanes16 = n <= BAMF_NMAX;
     double* up = h + n_down;                                  // L, Ldinv, zg, vg
     double* upk = up + (size_t)n * n + 3 * n;                 // rows of L^T, packed (k_bam_forward16)
     std::fill(up, up + n_up, 0.0);
@@ -654,8 +668,8 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     if (timing)
         fprintf(stderr, "[gsmvi bam n=%d] device+download %.3f  eigen %.3f  BB+chol+zg %.3f  upload %.3f ms\n", n,
                 tms(t_0, t_1), tms(t_1, t_2), tms(t_2, t_3), tms(t_3, tnow()));
+    }   // host fallback
 
-    const double* Ldinv = Ld + (size_t)n * n;
     if (lanes16) {
         // T1 = M1^T Vf into rows n..2n-1 of Fs, then the 16-lanes-per-column substitution
         if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, M1T, n, nullptr, 1.0, Ft, D, ctx->pp, &kc))) return rc;

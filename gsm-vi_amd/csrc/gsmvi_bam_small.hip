@@ -1,0 +1,354 @@
+// BaM's (B+1) x (B+1) matrix function on the DEVICE (gsmvi/bam.py:108-110; the reference evaluates it on the host
+// through jax.pure_callback + scipy sqrtm, bam.py:15-22).  n = B + 1 <= 129.
+//
+//   BB = ((N + I/4)^(1/2) + I/2)^2 = N + I/2 + (N + I/4)^(1/2),   BB = L L^T,   zg = L^-1 (P gbar + M1^T Vf gbar)
+//
+// The square root comes from the coupled Newton-Schulz iteration in product form (Higham, Functions of Matrices,
+// (6.35); stable, multiplication-only):  with A = N + I/4, s = trace(A),  Y_0 = A / s,  Z_0 = I,
+//     M = c^2 Z Y,   T = (3 I - M) / 2,   Y <- c Y T,   Z <- c T Z          =>  Y -> (A/s)^(1/2),  Z -> (A/s)^(-1/2)
+// (s = trace(A) >= lambda_max is used as the scale: every workgroup can sum a diagonal by itself)
+// Every iterate is a polynomial in A (symmetric, commuting), but the products are taken exactly in the order above:
+// that is what makes the iteration stable in floating point.  The eigenvalues mu of Z Y start
+// in [1/(4s), 1] (A >= I/4 because N is a Gram matrix) and obey mu <- f(c^2 mu), f(x) = x (3 - x)^2 / 4.  Because
+// the lower bound is KNOWN, the scaling c^2 = 3 / (1 + sqrt(l) + l) (Chen & Chow's scaled Newton-Schulz, written
+// for mu = sigma^2) is computed from a scalar recurrence alone: small eigenvalues grow ~6.75x per step instead of
+// 2.25x, 12-15 steps instead of ~27 at cond(A) ~ 1e7.  The recurrence (and hence the number of steps k*) depends
+// on s, which lives on the device: k_bam_ns_prep runs it once and stores c_k^2 and k*; the host enqueues the
+// launches of BAMS_KMAX steps and the ones beyond k* return at once.  Two launches per step on many workgroups:
+// M = Z Y, then Y' and Z' together (one 16 x 16 block per wave, fp64 MFMA, operands straight from L2).  Then BB
+// (symmetrised), its Cholesky factor in ONE workgroup
+// (two 64 x 64 blocks as in the factor path, plus one bordered column for n = 129) and the small outputs that
+// k_bam_forward16 consumes.  No host synchronisation, no host arithmetic.
+#include "gsmvi_common.h"
+#include "gsmvi_ctx.h"
+#include "gsmvi_chol64.h"
+#include "../../include/gsmvi_hip.h"
+
+#define BAMS_NMAX 129
+#define BAMS_LD 144                  // padded leading dimension of the iteration matrices (9 blocks of 16)
+#define BAMS_KMAX 24                 // launches enqueued; k* <= BAMS_KMAX is checked on the device (else flagged)
+// coef layout (doubles): [0..KMAX) c_k^2, [32] k*, [33] s, [34] 1 if s is not finite or the bound did not close
+
+// ---- s = trace(N + I/4) >= lambda_max, Y0 = (N + I/4)/s, Z0 = I (padded to BAMS_LD), the scaling recurrence -------
+// Every workgroup sums the diagonal itself (n loads) and fills its share of Y0 / Z0; workgroup 0 also runs the scalar
+// recurrence.  A NaN / inf anywhere in N needs no flag of its own: it propagates through the products into BB, where
+// k_bam_chol_out rejects it.
+__global__ __launch_bounds__(256) void k_bam_ns_prep(int n, const double* __restrict__ Nm, double* __restrict__ Y,
+                                                     double* __restrict__ Z, double* __restrict__ coef) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    double tr = 0.0;
+    for (int i = tid; i < n; i += 256) tr += Nm[(size_t)i * n + i] + 0.25;
+    tr = wave_sum(tr);
+    if ((tid & 63) == 0) red[tid >> 6] = tr;
+    __syncthreads();
+    const double s = (red[0] + red[1]) + (red[2] + red[3]);
+    const double sinv = 1.0 / s;
+    for (int e = blockIdx.x * 256 + tid; e < BAMS_LD * BAMS_LD; e += gridDim.x * 256) {
+        const int i = e / BAMS_LD, j = e % BAMS_LD;
+        const bool in = i < n && j < n;
+        const double v = in ? Nm[(size_t)i * n + j] + (i == j ? 0.25 : 0.0) : 0.0;
+        Y[e] = v * sinv;
+        Z[e] = (in && i == j) ? 1.0 : 0.0;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        double l = 0.25 * sinv;                              // lower bound of the eigenvalues of Z Y (A >= I/4)
+        const bool s_ok = (s == s) && s > 0.0 && s < 1e300;
+        if (!(l > 0.0) || l > 1.0) l = 1.0;
+        int kstar = BAMS_KMAX + 1;
+        for (int k = 0; k < BAMS_KMAX; ++k) {
+            const double c2 = (l < 0.25) ? 3.0 / (1.0 + sqrt(l) + l) : 1.0;      // scale only while it pays
+            coef[k] = c2;
+            const double x = c2 * l;
+            l = x * (3.0 - x) * (3.0 - x) * 0.25;
+            if (l > 1.0) l = 1.0;
+            if (1.0 - l < 1e-15 && kstar > BAMS_KMAX) kstar = k + 2;             // one more step after the bound closes
+        }
+        if (kstar > BAMS_KMAX) kstar = BAMS_KMAX;            // cond(A) beyond ~1e12: flagged below
+        coef[32] = (double)kstar;
+        coef[33] = s;
+        coef[34] = (!s_ok || !(1.0 - l < 1e-15)) ? 1.0 : 0.0;
+    }
+}
+
+// ---- one 16 x 16 block per wave of  C = op(A) op(B)  on BAMS_LD x BAMS_LD matrices ----------------------------------
+//   MODE 0: C = A B      MODE 1: C = A T(B)      MODE 2: C = T(A) B,     T(M) = 1.5 I - 0.5 c2 M  applied on the fly.
+// No symmetry is assumed: the stability of the coupled iteration depends on the exact products Y T and T Z (with the
+// order swapped -- Z T, equal in exact arithmetic -- rounding errors grow and the iteration diverges at
+// cond(A) ~ 1e6: checked in numpy and on the device).  A is read by rows (16 rows x 4 consecutive k per k-step:
+// 32-B segments, the matrices are L2-resident), B by rows of 16 consecutive columns (128-B segments).
+template <int MODE>
+__device__ __forceinline__ void bams_block(const double* __restrict__ A, const double* __restrict__ Bm,
+                                           double* __restrict__ Out, int blk, int nb, int nk, double c2, double scale) {
+    // one WORKGROUP per 16 x 16 block; wave w takes the k-steps w, w + 4, ... (at most 9), every load of the wave in one
+    // batch; the four partial blocks are summed through LDS in a fixed order
+    __shared__ double red[4 * 256];
+    const int i0 = (blk / nb) * 16, j0 = (blk % nb) * 16;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, cc = l & 15, ks = l >> 4;
+    double a[9], b[9];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+        const int st = w + 4 * u;
+        const int k = 4 * st + ks;
+        const int kc = k < BAMS_LD ? k : BAMS_LD - 1;
+        const double av = A[(size_t)(i0 + cc) * BAMS_LD + kc];
+        const double bv = Bm[(size_t)kc * BAMS_LD + j0 + cc];
+        a[u] = MODE == 2 ? ((kc == i0 + cc ? 1.5 : 0.0) - 0.5 * c2 * av) : av;
+        b[u] = MODE == 1 ? ((kc == j0 + cc ? 1.5 : 0.0) - 0.5 * c2 * bv) : bv;
+        if (st >= nk) { a[u] = 0.0; b[u] = 0.0; }
+    }
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u + 1 < 9; u += 2) {
+        acc0 = GSMVI_MFMA_F64(a[u], b[u], acc0);
+        acc1 = GSMVI_MFMA_F64(a[u + 1], b[u + 1], acc1);
+    }
+    acc0 = GSMVI_MFMA_F64(a[8], b[8], acc0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w * 256 + (ks + 4 * r) * 16 + cc] = acc0[r] + acc1[r];
+    __syncthreads();
+    const int t = threadIdx.x;                               // element (t >> 4, t & 15) of the block
+    const double v = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
+    Out[(size_t)(i0 + (t >> 4)) * BAMS_LD + j0 + (t & 15)] = scale * v;
+}
+
+// M = Z Y (the scaling enters through T in the step kernel)
+__global__ __launch_bounds__(256) void k_bam_ns_zy(int n, int k, const double* __restrict__ Ya,
+                                                   const double* __restrict__ Za, const double* __restrict__ Yb,
+                                                   const double* __restrict__ Zb, double* __restrict__ Mm,
+                                                   const double* __restrict__ coef) {
+    if ((double)k >= coef[32] || coef[34] != 0.0) return;
+    const double* Y = (k & 1) ? Yb : Ya;
+    const double* Z = (k & 1) ? Zb : Za;
+    const int nb = (n + 15) >> 4, nk = (n + 3) >> 2;
+    bams_block<0>(Z, Y, Mm, blockIdx.x, nb, nk, 0.0, 1.0);
+}
+
+// Y' = c Y T and Z' = c T Z (in THIS order), T = 1.5 I - 0.5 c^2 M.  Blocks [0, nb^2) -> Y', the rest -> Z'.
+__global__ __launch_bounds__(256) void k_bam_ns_step(int n, int k, double* __restrict__ Ya, double* __restrict__ Za,
+                                                     double* __restrict__ Yb, double* __restrict__ Zb,
+                                                     const double* __restrict__ Mm, const double* __restrict__ coef) {
+    if ((double)k >= coef[32] || coef[34] != 0.0) return;
+    const double c2 = coef[k], c = sqrt(c2);
+    const double* Yi = (k & 1) ? Yb : Ya;
+    const double* Zi = (k & 1) ? Zb : Za;
+    double* Yo = (k & 1) ? Ya : Yb;
+    double* Zo = (k & 1) ? Za : Zb;
+    const int nb = (n + 15) >> 4, nk = (n + 3) >> 2;
+    if ((int)blockIdx.x < nb * nb) bams_block<1>(Yi, Mm, Yo, blockIdx.x, nb, nk, c2, c);             // Y' = c Y T
+    else bams_block<2>(Mm, Zi, Zo, blockIdx.x - nb * nb, nb, nk, c2, c);                            // Z' = c T Z
+}
+
+// BB = N + I/2 + sqrt(s) sym(Y_final)   (n x n, row-major, ld n)
+__global__ __launch_bounds__(256) void k_bam_ns_bb(int n, const double* __restrict__ Nm, const double* __restrict__ Ya,
+                                                   const double* __restrict__ Yb, const double* __restrict__ coef,
+                                                   double* __restrict__ BBg) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * n) return;
+    const int i = e / n, j = e % n;
+    const int kstar = (int)coef[32];
+    const double* Y = (kstar & 1) ? Yb : Ya;                 // iterate k* lives in buffer k* & 1
+    const double rs = sqrt(coef[33]);
+    const double y = 0.5 * (Y[(size_t)i * BAMS_LD + j] + Y[(size_t)j * BAMS_LD + i]);
+    BBg[e] = (coef[34] != 0.0) ? __longlong_as_double(0x7ff8000000000000LL) : Nm[e] + (i == j ? 0.5 : 0.0) + rs * y;
+}
+
+// ---- Cholesky of BB (n <= 129) in ONE workgroup and the small outputs ---------------------------------------------
+// The leading min(n, 128) rows/columns: two 64 x 64 diagonal blocks (chol64), the 64-column block row by the quad
+// substitution, the rank-64 update of the second block on the VALU (as k_chol128 in the factor path).  n = 129: the
+// last column is bordered on: r = R11^-T a by one wave, rho = sqrt(alpha - r.r).
+// Outputs: Ld (n x n, lower L = R^T), Ldinv (n), zg (n), vg (n) behind it, Upk (packed rows of R from the diagonal).
+__global__ __launch_bounds__(256) void k_bam_chol_out(int n, double reg, const double* __restrict__ BBg,
+                                                      const double* __restrict__ M1, const double* __restrict__ N0,
+                                                      double* __restrict__ Ld, double* __restrict__ Upk,
+                                                      int* __restrict__ info) {
+    constexpr int MS = 130;
+    __shared__ __attribute__((aligned(16))) double M[128 * MS];
+    __shared__ double rinv[128], sc[BAMS_NMAX + 3], av[BAMS_NMAX + 3];
+    __shared__ double rho_s;
+    __shared__ int sh_fail[2], sh_bad;
+    const int tid = threadIdx.x;
+    const int n1 = n < 128 ? n : 128;                        // size of the blocked part
+    double* Ldinv = Ld + (size_t)n * n;
+    double* zg = Ldinv + n;
+    double* vg = zg + n;
+    // load the upper triangle of the leading block (identity beyond n1) and, for n = 129, the border column
+    int nan_in = 0;
+    for (int e = tid; e < 128 * 128; e += 256) {
+        const int i = e >> 7, j = e & 127;
+        double v = (i == j) ? 1.0 : 0.0;
+        if (i < n1 && j < n1) {
+            const double b = BBg[(size_t)i * n + j];
+            if (!(b == b)) nan_in = 1;
+            v = (j >= i) ? b : 0.0;
+        }
+        M[i * MS + j] = v;
+    }
+    if (n > 128 && tid < 128) M[tid * MS + 128] = BBg[(size_t)tid * n + 128];
+    if (tid < 128) rinv[tid] = 1.0;
+    if (tid == 0) { sh_bad = 0; sh_fail[0] = sh_fail[1] = 0; rho_s = 1.0; }
+    __syncthreads();
+    if (nan_in) sh_bad = 1;
+    __syncthreads();
+    chol64_rows_s<MS>(M, rinv, n1 < 64 ? n1 : 64, &sh_fail[0]);
+    if (n1 > 64) {
+        // block row R12 = R11^-T A12 (64 columns, one per quad of lanes), A22 -= R12^T R12, factor A22
+        const int colq = tid >> 2, q = tid & 3;
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = M[(q + 4 * r) * MS + 64 + colq];
+#pragma unroll
+        for (int p = 0; p < 64; ++p) {
+            const int pr = p >> 2, pq = p & 3;
+            const double mine = x[pr] * rinv[p];
+            if (q == pq) x[pr] = mine;
+            const double xp = __shfl(mine, (tid & 60) | pq, 64);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (4 * r + 3 > p) {
+                    const int t = q + 4 * r;
+                    const double rv = M[p * MS + t];
+                    x[r] -= (t > p) ? rv * xp : 0.0;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) M[(q + 4 * r) * MS + 64 + colq] = x[r];
+        __syncthreads();
+        {
+            const int ty = tid >> 4, tx = tid & 15;
+            double acc[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+#pragma unroll 4
+            for (int p = 0; p < 64; ++p) {
+                double ra[4], rb[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    ra[a] = M[p * MS + 64 + ty + 16 * a];
+                    rb[a] = M[p * MS + 64 + tx + 16 * a];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] += ra[a] * rb[b];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int i = ty + 16 * a, j = tx + 16 * b;
+                    if (j >= i) M[(64 + i) * MS + 64 + j] -= acc[a][b];
+                }
+        }
+        __syncthreads();
+        chol64_rows_s<MS>(M + 64 * MS + 64, rinv + 64, n1 - 64, &sh_fail[1]);
+    }
+    __syncthreads();
+    // border column (n = 129): r = R11^-T a, column-oriented forward substitution in one wave
+    if (n > 128) {
+        if (tid < 64) {
+            double a0 = M[tid * MS + 128], a1 = M[(tid + 64) * MS + 128];
+            for (int p = 0; p < 128; ++p) {
+                const double cur = (p < 64) ? a0 : a1;
+                const double rp = __shfl(cur, p & 63, 64) * rinv[p];
+                if (tid == (p & 63)) { if (p < 64) a0 = rp; else a1 = rp; }
+                const double r0 = M[p * MS + tid], r1 = M[p * MS + tid + 64];
+                if (tid > p) a0 -= r0 * rp;
+                if (tid + 64 > p) a1 -= r1 * rp;
+            }
+            M[tid * MS + 128] = a0;
+            M[(tid + 64) * MS + 128] = a1;
+            double ss = wave_sum(a0 * a0 + a1 * a1);
+            if (tid == 0) {
+                const double d = BBg[(size_t)128 * n + 128] - ss;
+                if (!(d > 0.0) || !(d < 1.7976931348623157e308)) sh_bad = 1;
+                rho_s = sqrt(d > 0.0 ? d : 1.0);
+            }
+        }
+        __syncthreads();
+    }
+    const int bad = sh_bad || sh_fail[0] != 0 || sh_fail[1] != 0;
+    if (tid == 0) *info = bad;
+    const size_t npk = (size_t)n * (n + 1) / 2;
+    if (bad) {                                               // poison: nothing stale may be applied
+        const double qn = __longlong_as_double(0x7ff8000000000000LL);
+        for (size_t e = tid; e < (size_t)n * n + 3 * n; e += 256) Ld[e] = qn;
+        for (size_t e = tid; e < npk; e += 256) Upk[e] = qn;
+        return;
+    }
+    // R(i, j), i <= j
+    auto Rel = [&](int i, int j) -> double { return (j < 128) ? M[i * MS + j] : (i < 128 ? M[i * MS + 128] : rho_s); };
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, j = e % n;                      // L[i][j] = R[j][i], j <= i
+        Ld[e] = (j <= i) ? Rel(j, i) : 0.0;
+        if (j >= i) Upk[(size_t)i * n - ((size_t)i * (i - 1)) / 2 - i + j] = Rel(i, j);
+    }
+    for (int p = tid; p < n; p += 256) Ldinv[p] = 1.0 / Rel(p, p);
+    // vg = Vf gbar = M1[:, n-1] / r1s;  a = P gbar + M1^T vg;  zg = L^-1 a   (bam.py:107,110 applied to gbar)
+    const double r1s = sqrt(reg / (1.0 + reg));
+    for (int p = tid; p < n; p += 256) sc[p] = M1[(size_t)p * n + (n - 1)] / r1s;
+    __syncthreads();
+    for (int p = tid; p < n; p += 256) {
+        double a = N0[(size_t)p * n + (n - 1)] / r1s;
+        for (int kk = 0; kk < n; ++kk) a += M1[(size_t)kk * n + p] * sc[kk];
+        av[p] = a;
+        vg[p] = sc[p];
+    }
+    __syncthreads();
+    if (tid < 64) {                                          // forward substitution with L = R^T, one wave, 3 rows per lane
+        double a[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) a[u] = (tid + 64 * u < n) ? av[tid + 64 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            for (int pl = 0; pl < 64; ++pl) {
+                const int pp = 64 * u + pl;
+                if (pp >= n) break;                          // wave-uniform
+                const double zk = __shfl(a[u], pl, 64) / Rel(pp, pp);
+                if (tid == pl) a[u] = zk;
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    const int r = tid + 64 * v;
+                    if (v >= u && r > pp && r < n) a[v] -= Rel(pp, r) * zk;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (tid + 64 * u < n) zg[tid + 64 * u] = a[u];
+    }
+}
+
+// Host side: enqueue the whole chain on `st`.  scratch: >= 5 * BAMS_LD^2 + 64 + n^2 doubles.
+int gsmvi_bam_small_device(hipStream_t st, int n, double reg, const double* Nd, const double* M1, const double* N0,
+                           double* scratch, double* Ld, double* Upk, int* info_dev) {
+    const size_t LL = (size_t)BAMS_LD * BAMS_LD;
+    double* Ya = scratch;
+    double* Za = Ya + LL;
+    double* Yb = Za + LL;
+    double* Zb = Yb + LL;
+    double* Mm = Zb + LL;
+    double* coef = Mm + LL;
+    double* BBg = coef + 64;
+    hipLaunchKernelGGL(k_bam_ns_prep, dim3(27), dim3(256), 0, st, n, Nd, Ya, Za, coef);
+    const int nb = (n + 15) / 16;
+    for (int k = 0; k < BAMS_KMAX; ++k) {
+        hipLaunchKernelGGL(k_bam_ns_zy, dim3(nb * nb), dim3(256), 0, st, n, k, Ya, Za, Yb, Zb, Mm, coef);
+        hipLaunchKernelGGL(k_bam_ns_step, dim3(2 * nb * nb), dim3(256), 0, st, n, k, Ya, Za, Yb, Zb, Mm, coef);
+    }
+    hipLaunchKernelGGL(k_bam_ns_bb, dim3((n * n + 255) / 256), dim3(256), 0, st, n, Nd, Ya, Yb, coef, BBg);
+    hipLaunchKernelGGL(k_bam_chol_out, dim3(1), dim3(256), 0, st, n, reg, BBg, M1, N0, Ld, Upk, info_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        gsmvi_set_error("BaM small-matrix launch failed: %s%s", hipGetErrorString(e), "");
+        return GSMVI_ERR_HIP;
+    }
+    return GSMVI_OK;
+}
+
+int gsmvi_bam_small_nmax() { return BAMS_NMAX; }
+size_t gsmvi_bam_small_scratch_doubles(int n) { return (size_t)5 * BAMS_LD * BAMS_LD + 64 + (size_t)n * n; }

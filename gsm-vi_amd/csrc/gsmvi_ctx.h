@@ -21,6 +21,7 @@ struct gsmvi_ctx {
     int tune_cov_dbg = 0;      // ablation bits for k_gsm_cov_sym (wrong results; timing only)
     int tune_scalars_nt = 0;   // threads per sample in k_gsm_scalars_fast (256/512/1024; 0 = default)
     int tune_no_fast = 0;      // 1 = force the guarded generic kernels (tests)
+    int tune_bam_host = 0;     // 1 = BaM's small matrix function on the host even when the device chain applies (tests)
     int profiling = 0;         // when set, the update kernels are launched with dispatch-timestamp events
     double* h_pin = nullptr;   // pinned host staging for BaM's small matrices (grown on demand)
     size_t h_pin_doubles = 0;

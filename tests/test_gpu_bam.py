@@ -97,3 +97,47 @@ def test_config_c4_bam_d1024_b128():
         mu_o, S_o = borc.bam_lowrank_update_exact(st["samples"], st["vs"], st["mu0"], st["S0"], reg)
         mu, S = gsmvi_amd.bam_lowrank_update(st["samples"], st["vs"], st["mu0"], st["S0"], reg)
         assert rel_err(mu, mu_o) < 1e-6 and rel_err(S, 0.5 * (S_o + S_o.T)) < 1e-6, reg
+
+
+@pytest.mark.parametrize("D,B,reg", [(3, 1, 1.0), (7, 2, 0.01), (64, 8, 100.0), (40, 50, 2.0), (256, 63, 10.0),
+                                     (200, 64, 1.0), (300, 100, 0.3), (1024, 127, 1.0), (1024, 128, 1.0)])
+def test_device_matrix_function_equals_host_fallback(D, B, reg):
+    """The (B+1) x (B+1) matrix function of bam.py:108-110 runs on the device (scaled Newton-Schulz square root +
+    Cholesky, csrc/gsmvi_bam_small.hip: no host synchronisation, no host arithmetic) for B <= 128; the host
+    eigen-solve kept for larger B (tuning knob bam_host) must agree."""
+    import gsmvi_amd
+    orc, borc = _o()
+    eng = gsmvi_amd.get_engine()
+    st = orc.make_update_state(D, B, seed=D + B)
+    X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
+    mu_d, S_d, f_d = eng.bam_update(X, G, mu0, S0, reg, 1e-6)
+    eng.set_tuning("bam_host", 1)
+    try:
+        mu_h, S_h, f_h = eng.bam_update(X, G, mu0, S0, reg, 1e-6)
+    finally:
+        eng.set_tuning("bam_host", 0)
+    assert eng.read_flag(f_d) == 0 and eng.read_flag(f_h) == 0
+    assert rel_err(mu_d.cpu().numpy(), mu_h.cpu().numpy()) < 1e-9
+    assert rel_err(S_d.cpu().numpy(), S_h.cpu().numpy()) < 1e-9
+
+
+def test_bam_update_is_graph_capturable():
+    """No host synchronisation inside gsmvi_bam_update_f64 for B <= 128: the call can be captured and replayed."""
+    import torch
+    import gsmvi_amd
+    orc, borc = _o()
+    eng = gsmvi_amd.get_engine()
+    st = orc.make_update_state(96, 12, seed=3)
+    X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
+    out = (eng.empty(96), eng.empty(96, 96))
+    flag = eng.new_flag()
+    eng.bam_update(X, G, mu0, S0, 2.0, 0.0, out=out, flag=flag)
+    ref = (out[0].clone(), out[1].clone())
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.bam_update(X, G, mu0, S0, 2.0, 0.0, out=out, flag=flag)
+    out[0].zero_(); out[1].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]) and eng.read_flag(flag) == 0
