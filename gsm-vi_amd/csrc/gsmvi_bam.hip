@@ -28,36 +28,76 @@
 #include "../../include/gsmvi_hip.h"
 
 // ---- column means and the factor panels -----------------------------------------------------
-// thread i = column; Qt, Vf row-major n x D (ld D); Qm = Qt^T as D x n (ld nq).
+// Workgroup = 64 columns x 4 sample groups (thread (g, c): samples g, g + 4, ...; eight independent loads in
+// flight); the four partial column sums are combined through LDS in a fixed order.  Qt, Vf row-major n x D (ld D);
+// Qm = Qt^T as D x n (ld nq), written through an LDS transpose so that both layouts are stored coalesced.
 __global__ __launch_bounds__(256) void k_bam_stats(int D, int B, const double* __restrict__ X, int ldx,
                                                    const double* __restrict__ G, int ldg,
                                                    const double* __restrict__ mu0, double reg,
                                                    double* __restrict__ xbar, double* __restrict__ gbar,
                                                    double* __restrict__ Qt, double* __restrict__ Vf,
                                                    double* __restrict__ Vf2, double* __restrict__ Qm, int nq) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= D) return;
+    __shared__ double red[2][4][64];
+    __shared__ double tq[64][33];                  // transpose buffer: 64 columns x 32 samples (+1 pad)
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + c, ic = i < D ? i : D - 1;
     double sx = 0.0, sg = 0.0;
-    for (int b = 0; b < B; ++b) {
-        sx += X[(size_t)b * ldx + i];
-        sg += G[(size_t)b * ldg + i];
+    int b = g;
+    for (; b + 28 < B; b += 32) {
+        double vx[8], vg[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            vx[u] = X[(size_t)(b + 4 * u) * ldx + ic];
+            vg[u] = G[(size_t)(b + 4 * u) * ldg + ic];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { sx += vx[u]; sg += vg[u]; }
     }
-    const double xb = sx / B, gb = sg / B;
-    xbar[i] = xb;
-    gbar[i] = gb;
+    for (; b < B; b += 4) { sx += X[(size_t)b * ldx + ic]; sg += G[(size_t)b * ldg + ic]; }
+    red[0][g][c] = sx;
+    red[1][g][c] = sg;
+    __syncthreads();
+    const double xb = ((red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c])) / B;
+    const double gb = ((red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c])) / B;
     const double a = sqrt(reg / B), r1s = sqrt(reg / (1.0 + reg));
-    for (int b = 0; b < B; ++b) {
-        const double q = a * (G[(size_t)b * ldg + i] - gb);
-        Qt[(size_t)b * D + i] = q;
-        Qm[(size_t)i * nq + b] = q;
-        const double v = a * (X[(size_t)b * ldx + i] - xb);
-        Vf[(size_t)b * D + i] = v;
-        Vf2[(size_t)b * D + i] = v;
+    if (g == 0 && i < D) {
+        xbar[i] = xb;
+        gbar[i] = gb;
+        Qt[(size_t)B * D + i] = r1s * gb;
+        Qm[(size_t)i * nq + B] = r1s * gb;
+        Vf[(size_t)B * D + i] = r1s * (mu0[i] - xb);
+        Vf2[(size_t)B * D + i] = r1s * (mu0[i] - xb);
     }
-    Qt[(size_t)B * D + i] = r1s * gb;
-    Qm[(size_t)i * nq + B] = r1s * gb;
-    Vf[(size_t)B * D + i] = r1s * (mu0[i] - xb);
-    Vf2[(size_t)B * D + i] = r1s * (mu0[i] - xb);
+    // rows of Qt / Vf, 32 samples per pass; Qm through the transpose buffer
+    for (int b0 = 0; b0 < B; b0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int bb = b0 + g + 4 * u;
+            double q = 0.0;
+            if (bb < B) {
+                q = a * (G[(size_t)bb * ldg + ic] - gb);
+                const double v = a * (X[(size_t)bb * ldx + ic] - xb);
+                if (i < D) {
+                    Qt[(size_t)bb * D + i] = q;
+                    Vf[(size_t)bb * D + i] = v;
+                    Vf2[(size_t)bb * D + i] = v;
+                }
+            }
+            tq[c][g + 4 * u] = q;
+        }
+        __syncthreads();
+        // 64 columns x 32 samples -> Qm[i][b0 .. b0+31]: thread (row = tid >> 2, 8 samples each)
+        {
+            const int cr = threadIdx.x >> 2, s0 = (threadIdx.x & 3) * 8;
+            const int gi = blockIdx.x * 64 + cr;
+            if (gi < D) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (b0 + s0 + u < B) Qm[(size_t)gi * nq + b0 + s0 + u] = tq[cr][s0 + u];
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // ---- Z = L^-1 (P + M1^T Vf), the new mean, and the signed factor panel -------------------------
@@ -543,7 +583,7 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     double* N0 = M1 + (size_t)n * n;               // n x n
     double* Ld = N0 + (size_t)n * n;               // n x n, then Ldinv (n), zg (n), vg (n)
 
-    hipLaunchKernelGGL(k_bam_stats, dim3((D + 255) / 256), dim3(256), 0, st, D, B, X, ldx, G, ldg, mu0, reg, xbar,
+    hipLaunchKernelGGL(k_bam_stats, dim3((D + 63) / 64), dim3(256), 0, st, D, B, X, ldx, G, ldg, mu0, reg, xbar,
                        gbar, Qt, Ft, Fs, Qm, nq);
     int kc = 1, rc;
     if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, D, n, Qt, D, nullptr, 1.0, S0, lds0, ctx->pp, &kc))) return rc;

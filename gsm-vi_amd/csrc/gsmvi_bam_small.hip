@@ -139,6 +139,96 @@ __global__ __launch_bounds__(256) void k_bam_ns_step(int n, int k, double* __res
     else bams_block<2>(Mm, Zi, Zo, blockIdx.x - nb * nb, nb, nk, c2, c);                            // Z' = c T Z
 }
 
+// ---- n <= 48: the whole iteration in ONE workgroup, matrices in LDS, exactly k* steps --------------------------------
+// Nine waves, wave (bi, bj) owns the 16 x 16 block (bi, bj) of every product; Y, Z ping-pong between two LDS buffers.
+// Same arithmetic as the multi-workgroup chain (same scaling recurrence, same product order); writes BB directly.
+#define BAMS_SN 48
+#define BAMS_SLD 50
+__global__ __launch_bounds__(576) void k_bam_ns_small(int n, const double* __restrict__ Nm, double* __restrict__ BBg) {
+    __shared__ double Yb_[2][BAMS_SN * BAMS_SLD], Zb_[2][BAMS_SN * BAMS_SLD], Ms[BAMS_SN * BAMS_SLD];
+    __shared__ double coefs[BAMS_KMAX + 4];
+    __shared__ double red[9];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
+    const int bi = w / 3, bj = w % 3, i0 = 16 * bi, j0 = 16 * bj;
+    double tr = 0.0;
+    for (int i = tid; i < n; i += 576) tr += Nm[(size_t)i * n + i] + 0.25;
+    tr = wave_sum(tr);
+    if (l == 0) red[w] = tr;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int u = 0; u < 9; ++u) s += red[u];
+    const double sinv = 1.0 / s;
+    for (int e = tid; e < BAMS_SN * BAMS_SN; e += 576) {
+        const int i = e / BAMS_SN, j = e % BAMS_SN;
+        const bool in = i < n && j < n;
+        Yb_[0][i * BAMS_SLD + j] = in ? (Nm[(size_t)i * n + j] + (i == j ? 0.25 : 0.0)) * sinv : 0.0;
+        Zb_[0][i * BAMS_SLD + j] = (in && i == j) ? 1.0 : 0.0;
+    }
+    if (tid == 0) {
+        double lb = 0.25 * sinv;
+        const bool s_ok = (s == s) && s > 0.0 && s < 1e300;
+        if (!(lb > 0.0) || lb > 1.0) lb = 1.0;
+        int kstar = BAMS_KMAX + 1;
+        for (int k = 0; k < BAMS_KMAX; ++k) {
+            const double c2 = (lb < 0.25) ? 3.0 / (1.0 + sqrt(lb) + lb) : 1.0;
+            coefs[k] = c2;
+            const double x = c2 * lb;
+            lb = x * (3.0 - x) * (3.0 - x) * 0.25;
+            if (lb > 1.0) lb = 1.0;
+            if (1.0 - lb < 1e-15 && kstar > BAMS_KMAX) kstar = k + 2;
+        }
+        if (kstar > BAMS_KMAX) kstar = BAMS_KMAX;
+        coefs[BAMS_KMAX] = (double)kstar;
+        coefs[BAMS_KMAX + 1] = (!s_ok || !(1.0 - lb < 1e-15)) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const int kstar = (int)coefs[BAMS_KMAX];
+    const bool failed = coefs[BAMS_KMAX + 1] != 0.0;
+    for (int k = 0; k < kstar && !failed; ++k) {
+        const double* Y = Yb_[k & 1];
+        const double* Z = Zb_[k & 1];
+        double* Yo = Yb_[(k & 1) ^ 1];
+        double* Zo = Zb_[(k & 1) ^ 1];
+        const double c2 = coefs[k], c = sqrt(c2);
+        {   // M = Z Y
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int st = 0; st < BAMS_SN / 4; ++st) {
+                const int kk = 4 * st + ks;
+                acc = GSMVI_MFMA_F64(Z[(i0 + cc) * BAMS_SLD + kk], Y[kk * BAMS_SLD + j0 + cc], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ms[(i0 + ks + 4 * r) * BAMS_SLD + j0 + cc] = acc[r];
+        }
+        __syncthreads();
+        {   // Y' = c Y T,  Z' = c T Z,  T = 1.5 I - 0.5 c2 M
+            v4d ay = {0.0, 0.0, 0.0, 0.0}, az = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int st = 0; st < BAMS_SN / 4; ++st) {
+                const int kk = 4 * st + ks;
+                const double tb = (kk == j0 + cc ? 1.5 : 0.0) - 0.5 * c2 * Ms[kk * BAMS_SLD + j0 + cc];     // T[kk][j]
+                const double ta = (kk == i0 + cc ? 1.5 : 0.0) - 0.5 * c2 * Ms[(i0 + cc) * BAMS_SLD + kk];     // T[i][kk]
+                ay = GSMVI_MFMA_F64(Y[(i0 + cc) * BAMS_SLD + kk], tb, ay);
+                az = GSMVI_MFMA_F64(ta, Z[kk * BAMS_SLD + j0 + cc], az);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Yo[(i0 + ks + 4 * r) * BAMS_SLD + j0 + cc] = c * ay[r];
+                Zo[(i0 + ks + 4 * r) * BAMS_SLD + j0 + cc] = c * az[r];
+            }
+        }
+        __syncthreads();
+    }
+    const double* Yf = Yb_[kstar & 1];
+    const double rs = sqrt(s);
+    for (int e = tid; e < n * n; e += 576) {
+        const int i = e / n, j = e % n;
+        const double y = 0.5 * (Yf[i * BAMS_SLD + j] + Yf[j * BAMS_SLD + i]);
+        BBg[e] = failed ? __longlong_as_double(0x7ff8000000000000LL) : Nm[e] + (i == j ? 0.5 : 0.0) + rs * y;
+    }
+}
+
 // BB = N + I/2 + sqrt(s) sym(Y_final)   (n x n, row-major, ld n)
 __global__ __launch_bounds__(256) void k_bam_ns_bb(int n, const double* __restrict__ Nm, const double* __restrict__ Ya,
                                                    const double* __restrict__ Yb, const double* __restrict__ coef,
@@ -334,13 +424,18 @@ int gsmvi_bam_small_device(hipStream_t st, int n, double reg, const double* Nd, 
     double* Mm = Zb + LL;
     double* coef = Mm + LL;
     double* BBg = coef + 64;
-    hipLaunchKernelGGL(k_bam_ns_prep, dim3(27), dim3(256), 0, st, n, Nd, Ya, Za, coef);
-    const int nb = (n + 15) / 16;
-    for (int k = 0; k < BAMS_KMAX; ++k) {
-        hipLaunchKernelGGL(k_bam_ns_zy, dim3(nb * nb), dim3(256), 0, st, n, k, Ya, Za, Yb, Zb, Mm, coef);
-        hipLaunchKernelGGL(k_bam_ns_step, dim3(2 * nb * nb), dim3(256), 0, st, n, k, Ya, Za, Yb, Zb, Mm, coef);
+    if (n <= BAMS_SN) {
+        // small problems: the whole iteration in one workgroup, exactly k* steps, no skipped launches
+        hipLaunchKernelGGL(k_bam_ns_small, dim3(1), dim3(576), 0, st, n, Nd, BBg);
+    } else {
+        hipLaunchKernelGGL(k_bam_ns_prep, dim3(27), dim3(256), 0, st, n, Nd, Ya, Za, coef);
+        const int nb = (n + 15) / 16;
+        for (int k = 0; k < BAMS_KMAX; ++k) {
+            hipLaunchKernelGGL(k_bam_ns_zy, dim3(nb * nb), dim3(256), 0, st, n, k, Ya, Za, Yb, Zb, Mm, coef);
+            hipLaunchKernelGGL(k_bam_ns_step, dim3(2 * nb * nb), dim3(256), 0, st, n, k, Ya, Za, Yb, Zb, Mm, coef);
+        }
+        hipLaunchKernelGGL(k_bam_ns_bb, dim3((n * n + 255) / 256), dim3(256), 0, st, n, Nd, Ya, Yb, coef, BBg);
     }
-    hipLaunchKernelGGL(k_bam_ns_bb, dim3((n * n + 255) / 256), dim3(256), 0, st, n, Nd, Ya, Yb, coef, BBg);
     hipLaunchKernelGGL(k_bam_chol_out, dim3(1), dim3(256), 0, st, n, reg, BBg, M1, N0, Ld, Upk, info_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
