@@ -10,11 +10,12 @@
 //   BB = L L^T;  Z = L^-1 A^T (n x D)  =>  A BB^-1 A^T = Z^T Z                              (bam.py:110)
 //   S  = V - Z^T Z = S0 + Vf^T Vf - Z^T Z     rank-2n symmetric update, fp64 MFMA           (bam.py:111)
 //   mu = mu0/(1+reg) + reg/(1+reg) (S gbar + xbar)                                         (bam.py:112)
-// The n x n symmetric eigen-problem behind the matrix square root and the n x n Cholesky are done
-// on the HOST inside this call (Householder + implicit QL; one stream synchronisation) -- the reference does the same step as
-// a host callback (jax.pure_callback, bam.py:15-22).  Only the square-root term goes through the
-// eigen-solve (N itself enters BB exactly) and BB^-1 is applied by triangular substitution, never
-// as an explicit inverse: with cond(N) ~ 1e7 the explicit-inverse form loses 3 digits.
+// The n x n matrix square root and the n x n Cholesky run on the DEVICE for n <= 129 (gsmvi_bam_small.hip: scaled
+// coupled Newton-Schulz iteration + one-workgroup Cholesky; the reference does this step as a host callback,
+// jax.pure_callback, bam.py:15-22).  For larger n a host fallback remains in this file (Householder + implicit QL
+// eigen-solve, one stream synchronisation).  Only the square-root term goes through the iteration / eigen-solve
+// (N itself enters BB exactly) and BB^-1 is applied by triangular substitution, never as an explicit inverse:
+// with cond(N) ~ 1e7 the explicit-inverse form loses 3 digits.
 // Everything of size D runs in HIP kernels; S0 is read twice and S written once.
 #include <algorithm>
 #include <chrono>

@@ -62,12 +62,12 @@ __global__ __launch_bounds__(256) void k_bam_ns_prep(int n, const double* __rest
             const double x = c2 * l;
             l = x * (3.0 - x) * (3.0 - x) * 0.25;
             if (l > 1.0) l = 1.0;
-            if (1.0 - l < 1e-15 && kstar > BAMS_KMAX) kstar = k + 2;             // one more step after the bound closes
+            if (1.0 - l < 5e-9 && kstar > BAMS_KMAX) kstar = k + 2;              // e -> 0.75 e^2: one more step gives < 1e-16
         }
-        if (kstar > BAMS_KMAX) kstar = BAMS_KMAX;            // cond(A) beyond ~1e12: flagged below
+        coef[34] = (!s_ok || kstar > BAMS_KMAX) ? 1.0 : 0.0;  // cond(A) beyond ~1e12: not reachable in BAMS_KMAX steps
+        if (kstar > BAMS_KMAX) kstar = BAMS_KMAX;
         coef[32] = (double)kstar;
         coef[33] = s;
-        coef[34] = (!s_ok || !(1.0 - l < 1e-15)) ? 1.0 : 0.0;
     }
 }
 
@@ -176,46 +176,67 @@ __global__ __launch_bounds__(576) void k_bam_ns_small(int n, const double* __res
             const double x = c2 * lb;
             lb = x * (3.0 - x) * (3.0 - x) * 0.25;
             if (lb > 1.0) lb = 1.0;
-            if (1.0 - lb < 1e-15 && kstar > BAMS_KMAX) kstar = k + 2;
+            if (1.0 - lb < 5e-9 && kstar > BAMS_KMAX) kstar = k + 2;
         }
+        coefs[BAMS_KMAX + 1] = (!s_ok || kstar > BAMS_KMAX) ? 1.0 : 0.0;
         if (kstar > BAMS_KMAX) kstar = BAMS_KMAX;
         coefs[BAMS_KMAX] = (double)kstar;
-        coefs[BAMS_KMAX + 1] = (!s_ok || !(1.0 - lb < 1e-15)) ? 1.0 : 0.0;
     }
     __syncthreads();
     const int kstar = (int)coefs[BAMS_KMAX];
     const bool failed = coefs[BAMS_KMAX + 1] != 0.0;
+    const int nk = (n + 3) >> 2;
     for (int k = 0; k < kstar && !failed; ++k) {
         const double* Y = Yb_[k & 1];
         const double* Z = Zb_[k & 1];
         double* Yo = Yb_[(k & 1) ^ 1];
         double* Zo = Zb_[(k & 1) ^ 1];
         const double c2 = coefs[k], c = sqrt(c2);
+        constexpr int NST = BAMS_SN / 4;                     // up to 12 k-steps (nk = ceil(n / 4) of them are non-zero)
         {   // M = Z Y
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            double a[NST], b[NST];
 #pragma unroll
-            for (int st = 0; st < BAMS_SN / 4; ++st) {
+            for (int st = 0; st < NST; ++st) {
                 const int kk = 4 * st + ks;
-                acc = GSMVI_MFMA_F64(Z[(i0 + cc) * BAMS_SLD + kk], Y[kk * BAMS_SLD + j0 + cc], acc);
+                a[st] = Z[(i0 + cc) * BAMS_SLD + kk];
+                b[st] = Y[kk * BAMS_SLD + j0 + cc];
+            }
+            v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int st = 0; st < NST; st += 2) {
+                if (st < nk) {                               // block-uniform: the padded k-steps are skipped
+                    acc0 = GSMVI_MFMA_F64(a[st], b[st], acc0);
+                    acc1 = GSMVI_MFMA_F64(a[st + 1], b[st + 1], acc1);
+                }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Ms[(i0 + ks + 4 * r) * BAMS_SLD + j0 + cc] = acc[r];
+            for (int r = 0; r < 4; ++r) Ms[(i0 + ks + 4 * r) * BAMS_SLD + j0 + cc] = acc0[r] + acc1[r];
         }
         __syncthreads();
         {   // Y' = c Y T,  Z' = c T Z,  T = 1.5 I - 0.5 c2 M
-            v4d ay = {0.0, 0.0, 0.0, 0.0}, az = {0.0, 0.0, 0.0, 0.0};
+            double ya[NST], tb[NST], ta[NST], zb[NST];
 #pragma unroll
-            for (int st = 0; st < BAMS_SN / 4; ++st) {
+            for (int st = 0; st < NST; ++st) {
                 const int kk = 4 * st + ks;
-                const double tb = (kk == j0 + cc ? 1.5 : 0.0) - 0.5 * c2 * Ms[kk * BAMS_SLD + j0 + cc];     // T[kk][j]
-                const double ta = (kk == i0 + cc ? 1.5 : 0.0) - 0.5 * c2 * Ms[(i0 + cc) * BAMS_SLD + kk];     // T[i][kk]
-                ay = GSMVI_MFMA_F64(Y[(i0 + cc) * BAMS_SLD + kk], tb, ay);
-                az = GSMVI_MFMA_F64(ta, Z[kk * BAMS_SLD + j0 + cc], az);
+                tb[st] = (kk == j0 + cc ? 1.5 : 0.0) - 0.5 * c2 * Ms[kk * BAMS_SLD + j0 + cc];      // T[kk][j]
+                ta[st] = (kk == i0 + cc ? 1.5 : 0.0) - 0.5 * c2 * Ms[(i0 + cc) * BAMS_SLD + kk];    // T[i][kk]
+                ya[st] = Y[(i0 + cc) * BAMS_SLD + kk];
+                zb[st] = Z[kk * BAMS_SLD + j0 + cc];
+            }
+            v4d ay0 = {0.0, 0.0, 0.0, 0.0}, ay1 = ay0, az0 = ay0, az1 = ay0;
+#pragma unroll
+            for (int st = 0; st < NST; st += 2) {
+                if (st < nk) {
+                    ay0 = GSMVI_MFMA_F64(ya[st], tb[st], ay0);
+                    az0 = GSMVI_MFMA_F64(ta[st], zb[st], az0);
+                    ay1 = GSMVI_MFMA_F64(ya[st + 1], tb[st + 1], ay1);
+                    az1 = GSMVI_MFMA_F64(ta[st + 1], zb[st + 1], az1);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                Yo[(i0 + ks + 4 * r) * BAMS_SLD + j0 + cc] = c * ay[r];
-                Zo[(i0 + ks + 4 * r) * BAMS_SLD + j0 + cc] = c * az[r];
+                Yo[(i0 + ks + 4 * r) * BAMS_SLD + j0 + cc] = c * (ay0[r] + ay1[r]);
+                Zo[(i0 + ks + 4 * r) * BAMS_SLD + j0 + cc] = c * (az0[r] + az1[r]);
             }
         }
         __syncthreads();

@@ -19,7 +19,7 @@
  * Conventions
  *   - All matrices are row-major float64 in DEVICE memory; `ld*` are leading dimensions in elements.
  *   - Calls are asynchronous on `stream` (a hipStream_t passed as void*); nothing synchronises (sole
- *     exception: gsmvi_bam_update_f64, see there), so call sequences can be captured into a hipGraph.
+ *     exception: gsmvi_bam_update_f64 with B > 128, see there), so call sequences can be captured into a hipGraph.
  *   - Inputs are never modified; outputs must not alias inputs (reference updates are pure,
  *     gsm_numpy.py:47-55) unless an entry point says otherwise.
  *   - S0 must be symmetric (it is a covariance); the kernels read it once, by rows.
@@ -213,10 +213,12 @@ int gsmvi_commit_f64(gsmvi_ctx* ctx, void* stream, int D, const int* info_dev,
 /*
  * BaM update (gsmvi/bam.py:72-114 with the exact rank-(B+1) factor of U; equals bam.py:31-69).
  * Symmetrised output (bam.py:199 does this in fit); jitter is added to the diagonal (bam.py:198).
- * NOTE: unlike every other entry point this call synchronises `stream` twice (the (B+1) x (B+1) matrix
- * function is evaluated on the host, as the reference does through jax.pure_callback, bam.py:15-22) and
- * therefore cannot be captured into a hipGraph.  *info_dev = 1 if that small problem was not finite /
- * not positive definite (then mu, S are NaN-poisoned and the caller's accept/revert must reject them).
+ * The (B+1) x (B+1) matrix function of bam.py:108-110 -- which the reference evaluates on the host through
+ * jax.pure_callback (bam.py:15-22) -- runs on the device for B <= 128 (scaled coupled Newton-Schulz square root on
+ * the MFMA pipe + a one-workgroup Cholesky, csrc/gsmvi_bam_small.hip): no synchronisation, graph-capturable.  For
+ * B > 128 the call falls back to a host eigen-solve and synchronises `stream` (then it cannot be captured).
+ * *info_dev = 1 if that small problem was not finite / not positive definite (then mu, S are NaN-poisoned and the
+ * caller's accept/revert must reject them).
  */
 int gsmvi_bam_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
                          const double* X, int ldx, const double* G, int ldg,

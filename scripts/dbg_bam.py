@@ -29,3 +29,4 @@ print("Y err", np.abs(Y * np.sqrt(coef[33]) - (V * np.sqrt(w)) @ V.T).max())
 print("mu nan", torch.isnan(mu).any().item(), "S nan", torch.isnan(S).any().item())
 Ld = rd(2 * n * n, n * n).reshape(n, n)
 print("L nan", np.isnan(Ld).any(), "L err", np.abs(Ld @ Ld.T - BBref).max())
+
