@@ -26,8 +26,9 @@
 
 #define BAMS_NMAX 129
 #define BAMS_LD 144                  // padded leading dimension of the iteration matrices (9 blocks of 16)
-#define BAMS_KMAX 24                 // launches enqueued; k* <= BAMS_KMAX is checked on the device (else flagged)
-// coef layout (doubles): [0..KMAX) c_k^2, [32] k*, [33] s, [34] 1 if s is not finite or the bound did not close
+#define BAMS_KMAX 32                 // launches enqueued; k* <= BAMS_KMAX is checked on the device (else flagged)
+// coef layout (doubles): [0..KMAX) c_k^2, [40] k*, [41] s, [42] 1 if s is not finite or the bound did not close in KMAX steps
+// (KMAX = 32 scaled steps cover cond(A) up to ~1e20, beyond what fp64 can represent in N + I/4)
 
 // ---- s = trace(N + I/4) >= lambda_max, Y0 = (N + I/4)/s, Z0 = I (padded to BAMS_LD), the scaling recurrence -------
 // Every workgroup sums the diagonal itself (n loads) and fills its share of Y0 / Z0; workgroup 0 also runs the scalar
@@ -64,10 +65,10 @@ __global__ __launch_bounds__(256) void k_bam_ns_prep(int n, const double* __rest
             if (l > 1.0) l = 1.0;
             if (1.0 - l < 5e-9 && kstar > BAMS_KMAX) kstar = k + 2;              // e -> 0.75 e^2: one more step gives < 1e-16
         }
-        coef[34] = (!s_ok || kstar > BAMS_KMAX) ? 1.0 : 0.0;  // cond(A) beyond ~1e12: not reachable in BAMS_KMAX steps
+        coef[42] = (!s_ok || kstar > BAMS_KMAX) ? 1.0 : 0.0;  // cond(A) beyond ~1e12: not reachable in BAMS_KMAX steps
         if (kstar > BAMS_KMAX) kstar = BAMS_KMAX;
-        coef[32] = (double)kstar;
-        coef[33] = s;
+        coef[40] = (double)kstar;
+        coef[41] = s;
     }
 }
 
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void k_bam_ns_zy(int n, int k, const double* _
                                                    const double* __restrict__ Za, const double* __restrict__ Yb,
                                                    const double* __restrict__ Zb, double* __restrict__ Mm,
                                                    const double* __restrict__ coef) {
-    if ((double)k >= coef[32] || coef[34] != 0.0) return;
+    if ((double)k >= coef[40] || coef[42] != 0.0) return;
     const double* Y = (k & 1) ? Yb : Ya;
     const double* Z = (k & 1) ? Zb : Za;
     const int nb = (n + 15) >> 4, nk = (n + 3) >> 2;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void k_bam_ns_zy(int n, int k, const double* _
 __global__ __launch_bounds__(256) void k_bam_ns_step(int n, int k, double* __restrict__ Ya, double* __restrict__ Za,
                                                      double* __restrict__ Yb, double* __restrict__ Zb,
                                                      const double* __restrict__ Mm, const double* __restrict__ coef) {
-    if ((double)k >= coef[32] || coef[34] != 0.0) return;
+    if ((double)k >= coef[40] || coef[42] != 0.0) return;
     const double c2 = coef[k], c = sqrt(c2);
     const double* Yi = (k & 1) ? Yb : Ya;
     const double* Zi = (k & 1) ? Zb : Za;
@@ -257,11 +258,11 @@ __global__ __launch_bounds__(256) void k_bam_ns_bb(int n, const double* __restri
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= n * n) return;
     const int i = e / n, j = e % n;
-    const int kstar = (int)coef[32];
+    const int kstar = (int)coef[40];
     const double* Y = (kstar & 1) ? Yb : Ya;                 // iterate k* lives in buffer k* & 1
-    const double rs = sqrt(coef[33]);
+    const double rs = sqrt(coef[41]);
     const double y = 0.5 * (Y[(size_t)i * BAMS_LD + j] + Y[(size_t)j * BAMS_LD + i]);
-    BBg[e] = (coef[34] != 0.0) ? __longlong_as_double(0x7ff8000000000000LL) : Nm[e] + (i == j ? 0.5 : 0.0) + rs * y;
+    BBg[e] = (coef[42] != 0.0) ? __longlong_as_double(0x7ff8000000000000LL) : Nm[e] + (i == j ? 0.5 : 0.0) + rs * y;
 }
 
 // ---- Cholesky of BB (n <= 129) in ONE workgroup and the small outputs ---------------------------------------------

@@ -15,17 +15,17 @@ def rd(off, cnt):
     buf = (C.c_double * cnt)()
     eng.lib.gsmvi_debug_read_workspace(eng._ctx, 2, off, buf, cnt)
     return np.array(buf)
-coef = rd(off_scr + 5 * LL, 40)
-print("flag", eng.read_flag(f), "kstar", coef[32], "s", coef[33], "bad", coef[34], "c2", coef[:int(coef[32])])
+coef = rd(off_scr + 5 * LL, 48)
+print("flag", eng.read_flag(f), "kstar", coef[40], "s", coef[41], "bad", coef[42], "c2", coef[:int(coef[40])])
 Nd = rd(3 * n * n + 3 * n, n * n).reshape(n, n)
 BB = rd(off_scr + 5 * LL + 64, n * n).reshape(n, n)
 w, V = np.linalg.eigh(Nd + 0.25 * np.eye(n))
 print("eig(A) min/max", w.min(), w.max())
 BBref = Nd + 0.5 * np.eye(n) + (V * np.sqrt(w)) @ V.T
 print("BB err", np.abs(BB - BBref).max() / np.abs(BBref).max(), "nan in BB", np.isnan(BB).any())
-ks = int(coef[32])
+ks = int(coef[40])
 Y = rd(off_scr + (2 * LL if ks & 1 else 0), LL).reshape(144, 144)[:n, :n]
-print("Y err", np.abs(Y * np.sqrt(coef[33]) - (V * np.sqrt(w)) @ V.T).max())
+print("Y err", np.abs(Y * np.sqrt(coef[41]) - (V * np.sqrt(w)) @ V.T).max())
 print("mu nan", torch.isnan(mu).any().item(), "S nan", torch.isnan(S).any().item())
 Ld = rd(2 * n * n, n * n).reshape(n, n)
 print("L nan", np.isnan(Ld).any(), "L err", np.abs(Ld @ Ld.T - BBref).max())

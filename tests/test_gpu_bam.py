@@ -141,3 +141,29 @@ def test_bam_update_is_graph_capturable():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]) and eng.read_flag(flag) == 0
+
+
+@pytest.mark.parametrize("B,scale,reg", [(4, 1e2, 1e3), (4, 1e3, 1e3), (16, 1e5, 1e3), (32, 30.0, 100.0), (60, 3e3, 1e3)])
+def test_device_matrix_function_at_extreme_scales_is_as_accurate_as_the_host_path(B, scale, reg):
+    """Huge score magnitudes and reg (|N| up to ~1e15: the BaM update itself is ill-conditioned there and both paths
+    lose digits against the scipy restatement): the device Newton-Schulz chain still closes within its enqueued
+    steps and is as close to the restatement as the host eigen-solve path is."""
+    import gsmvi_amd
+    orc, borc = _o()
+    eng = gsmvi_amd.get_engine()
+    D = 160
+    st = orc.make_update_state(D, B, seed=B)
+    Gs = st["vs"] * scale
+    X, G, mu0, S0 = (eng.asarray(a) for a in (st["samples"], Gs, st["mu0"], st["S0"]))
+    mu_d, S_d, f_d = eng.bam_update(X, G, mu0, S0, reg, 0.0)
+    eng.set_tuning("bam_host", 1)
+    try:
+        mu_h, S_h, f_h = eng.bam_update(X, G, mu0, S0, reg, 0.0)
+    finally:
+        eng.set_tuning("bam_host", 0)
+    assert eng.read_flag(f_d) == 0 and eng.read_flag(f_h) == 0
+    mu_o, S_o = borc.bam_lowrank_update_exact(st["samples"], Gs, st["mu0"], st["S0"], reg)
+    S_o = 0.5 * (S_o + S_o.T)
+    e_dev = max(rel_err(mu_d.cpu().numpy(), mu_o), rel_err(S_d.cpu().numpy(), S_o))
+    e_host = max(rel_err(mu_h.cpu().numpy(), mu_o), rel_err(S_h.cpu().numpy(), S_o))
+    assert e_dev < max(10.0 * e_host, 1e-8), (e_dev, e_host)
