@@ -286,15 +286,21 @@ __global__ __launch_bounds__(256) void k_bam_chol_out(int n, double reg, const d
     double* vg = zg + n;
     // load the upper triangle of the leading block (identity beyond n1) and, for n = 129, the border column
     int nan_in = 0;
-    for (int e = tid; e < 128 * 128; e += 256) {
-        const int i = e >> 7, j = e & 127;
-        double v = (i == j) ? 1.0 : 0.0;
-        if (i < n1 && j < n1) {
-            const double b = BBg[(size_t)i * n + j];
-            if (!(b == b)) nan_in = 1;
-            v = (j >= i) ? b : 0.0;
+#pragma unroll 1
+    for (int e0 = 0; e0 < 128 * 128; e0 += 256 * 16) {      // sixteen clamped loads in flight per thread
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = e0 + 256 * u + tid, i = e >> 7, j = e & 127;
+            v[u] = BBg[(size_t)(i < n1 ? i : n1 - 1) * n + (j < n1 ? j : n1 - 1)];
         }
-        M[i * MS + j] = v;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = e0 + 256 * u + tid, i = e >> 7, j = e & 127;
+            const bool in = i < n1 && j < n1;
+            if (in && !(v[u] == v[u])) nan_in = 1;
+            M[i * MS + j] = in ? (j >= i ? v[u] : 0.0) : (i == j ? 1.0 : 0.0);
+        }
     }
     if (n > 128 && tid < 128) M[tid * MS + 128] = BBg[(size_t)tid * n + 128];
     if (tid < 128) rinv[tid] = 1.0;
@@ -360,29 +366,51 @@ __global__ __launch_bounds__(256) void k_bam_chol_out(int n, double reg, const d
         chol64_rows_s<MS>(M + 64 * MS + 64, rinv + 64, n1 - 64, &sh_fail[1]);
     }
     __syncthreads();
-    // border column (n = 129): r = R11^-T a, column-oriented forward substitution in one wave
-    if (n > 128) {
-        if (tid < 64) {
-            double a0 = M[tid * MS + 128], a1 = M[(tid + 64) * MS + 128];
-            for (int p = 0; p < 128; ++p) {
-                const double cur = (p < 64) ? a0 : a1;
-                const double rp = __shfl(cur, p & 63, 64) * rinv[p];
-                if (tid == (p & 63)) { if (p < 64) a0 = rp; else a1 = rp; }
-                const double r0 = M[p * MS + tid], r1 = M[p * MS + tid + 64];
-                if (tid > p) a0 -= r0 * rp;
-                if (tid + 64 > p) a1 -= r1 * rp;
-            }
-            M[tid * MS + 128] = a0;
-            M[(tid + 64) * MS + 128] = a1;
-            double ss = wave_sum(a0 * a0 + a1 * a1);
-            if (tid == 0) {
-                const double d = BBg[(size_t)128 * n + 128] - ss;
-                if (!(d > 0.0) || !(d < 1.7976931348623157e308)) sh_bad = 1;
-                rho_s = sqrt(d > 0.0 ? d : 1.0);
-            }
+
+    // vg = Vf gbar = M1[:, n-1] / r1s and a = P gbar + M1^T vg (bam.py:107 applied to gbar) do not depend on the factor:
+    // they are computed by waves 1-3 while wave 0 runs the border substitution (n = 129), eight loads in flight
+    const double r1s = sqrt(reg / (1.0 + reg));
+    for (int p = tid; p < n; p += 256) sc[p] = M1[(size_t)p * n + (n - 1)] / r1s;
+    __syncthreads();
+    const bool border = n > 128;
+    if (border && tid < 64) {
+        // border column: r = R11^-T a, column-oriented forward substitution in one wave
+        double a0 = M[tid * MS + 128], a1 = M[(tid + 64) * MS + 128];
+        for (int p = 0; p < 128; ++p) {
+            const double cur = (p < 64) ? a0 : a1;
+            const double rp = __shfl(cur, p & 63, 64) * rinv[p];
+            if (tid == (p & 63)) { if (p < 64) a0 = rp; else a1 = rp; }
+            const double r0 = M[p * MS + tid], r1 = M[p * MS + tid + 64];
+            if (tid > p) a0 -= r0 * rp;
+            if (tid + 64 > p) a1 -= r1 * rp;
         }
-        __syncthreads();
+        M[tid * MS + 128] = a0;
+        M[(tid + 64) * MS + 128] = a1;
+        double ss = wave_sum(a0 * a0 + a1 * a1);
+        if (tid == 0) {
+            const double d = BBg[(size_t)128 * n + 128] - ss;
+            if (!(d > 0.0) || !(d < 1.7976931348623157e308)) sh_bad = 1;
+            rho_s = sqrt(d > 0.0 ? d : 1.0);
+        }
+    } else {
+        const int t0 = border ? tid - 64 : tid, nt = border ? 192 : 256;
+        for (int p = t0; p < n; p += nt) {
+            double a0 = N0[(size_t)p * n + (n - 1)] / r1s, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int kk = 0;
+            for (; kk + 8 <= n; kk += 8) {
+                double m[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) m[u] = M1[(size_t)(kk + u) * n + p];
+                a0 += m[0] * sc[kk] + m[4] * sc[kk + 4];
+                a1 += m[1] * sc[kk + 1] + m[5] * sc[kk + 5];
+                a2 += m[2] * sc[kk + 2] + m[6] * sc[kk + 6];
+                a3 += m[3] * sc[kk + 3] + m[7] * sc[kk + 7];
+            }
+            for (; kk < n; ++kk) a0 += M1[(size_t)kk * n + p] * sc[kk];
+            av[p] = (a0 + a1) + (a2 + a3);
+        }
     }
+    __syncthreads();
     const int bad = sh_bad || sh_fail[0] != 0 || sh_fail[1] != 0;
     if (tid == 0) *info = bad;
     const size_t npk = (size_t)n * (n + 1) / 2;
@@ -400,42 +428,27 @@ __global__ __launch_bounds__(256) void k_bam_chol_out(int n, double reg, const d
         if (j >= i) Upk[(size_t)i * n - ((size_t)i * (i - 1)) / 2 - i + j] = Rel(i, j);
     }
     for (int p = tid; p < n; p += 256) Ldinv[p] = 1.0 / Rel(p, p);
-    // vg = Vf gbar = M1[:, n-1] / r1s;  a = P gbar + M1^T vg;  zg = L^-1 a   (bam.py:107,110 applied to gbar)
-    const double r1s = sqrt(reg / (1.0 + reg));
-    for (int p = tid; p < n; p += 256) sc[p] = M1[(size_t)p * n + (n - 1)] / r1s;
-    __syncthreads();
-    for (int p = tid; p < n; p += 256) {
-        double a = N0[(size_t)p * n + (n - 1)] / r1s;
-        for (int kk = 0; kk < n; ++kk) a += M1[(size_t)kk * n + p] * sc[kk];
-        av[p] = a;
-        vg[p] = sc[p];
-    }
-    __syncthreads();
+    // zg = L^-1 a   (bam.py:110 applied to gbar)
+    for (int p = tid; p < n; p += 256) vg[p] = sc[p];
     if (tid < 64) {                                          // forward substitution with L = R^T, one wave, 3 rows per lane
-        double a[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) a[u] = (tid + 64 * u < n) ? av[tid + 64 * u] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            for (int pl = 0; pl < 64; ++pl) {
-                const int pp = 64 * u + pl;
-                if (pp >= n) break;                          // wave-uniform
-                const double zk = __shfl(a[u], pl, 64) / Rel(pp, pp);
-                if (tid == pl) a[u] = zk;
-#pragma unroll
-                for (int v = 0; v < 3; ++v) {
-                    const int r = tid + 64 * v;
-                    if (v >= u && r > pp && r < n) a[v] -= Rel(pp, r) * zk;
-                }
-            }
+        double a0 = (tid < n) ? av[tid] : 0.0, a1 = (tid + 64 < n) ? av[tid + 64] : 0.0;
+        double a2 = (tid == 0 && n > 128) ? av[128] : 0.0;   // row 128 lives in lane 0
+        const int nlead = n < 128 ? n : 128;
+        for (int pp = 0; pp < nlead; ++pp) {
+            const double cur = (pp < 64) ? a0 : a1;
+            const double zk = __shfl(cur, pp & 63, 64) * rinv[pp];
+            if (tid == (pp & 63)) { if (pp < 64) a0 = zk; else a1 = zk; }
+            const double r0 = M[pp * MS + tid], r1 = M[pp * MS + tid + 64], r2 = M[pp * MS + 128];
+            if (tid > pp) a0 -= r0 * zk;
+            if (tid + 64 > pp && tid + 64 < 128) a1 -= r1 * zk;
+            if (tid == 0) a2 -= r2 * zk;                     // R[pp][128]: the border column (unused when n <= 128)
         }
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-            if (tid + 64 * u < n) zg[tid + 64 * u] = a[u];
+        if (tid < n) zg[tid] = a0;
+        if (tid + 64 < nlead) zg[tid + 64] = a1;
+        if (tid == 0 && n > 128) zg[128] = a2 / rho_s;
     }
 }
 
-// Host side: enqueue the whole chain on `st`.  scratch: >= 5 * BAMS_LD^2 + 64 + n^2 doubles.
 int gsmvi_bam_small_device(hipStream_t st, int n, double reg, const double* Nd, const double* M1, const double* N0,
                            double* scratch, double* Ld, double* Upk, int* info_dev) {
     const size_t LL = (size_t)BAMS_LD * BAMS_LD;

@@ -30,3 +30,4 @@ print("mu nan", torch.isnan(mu).any().item(), "S nan", torch.isnan(S).any().item
 Ld = rd(2 * n * n, n * n).reshape(n, n)
 print("L nan", np.isnan(Ld).any(), "L err", np.abs(Ld @ Ld.T - BBref).max())
 
+
