@@ -49,6 +49,15 @@ __global__ __launch_bounds__(256) void k_potrf_panel(int D, int k, double* __res
         T[i * TS + q] = (i < nb && q < nb && q >= i) ? R[(size_t)(k0 + i) * ldr + k0 + q] : (i == q ? 1.0 : 0.0);
     }
     if (tid < 64) rinv[tid] = 1.0;
+    // this workgroup's 64 columns of the block row: loaded BEFORE the factorisation so that their latency hides behind it
+    const int colq = tid >> 2, q = tid & 3;
+    const int col = k0 + NB + ((int)blockIdx.x - 1) * 64 + colq;
+    const int colc = col < D ? col : D - 1;
+    double x[16];
+    if (blockIdx.x > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = R[(size_t)(k0 + q + 4 * r) * ldr + colc];
+    }
     __syncthreads();
     chol64_lds(T, rinv, nb, &sh_fail);
     if (blockIdx.x == 0) {
@@ -62,12 +71,6 @@ __global__ __launch_bounds__(256) void k_potrf_panel(int D, int k, double* __res
     // owning lane scales x[p] and broadcasts it inside the quad; every lane then updates its rows
     // t > p:  x[t] -= R_kk[p][t] x[p].  (A workgroup with blockIdx.x > 0 exists only when columns remain
     // to the right, i.e. nb == 64.)
-    const int colq = tid >> 2, q = tid & 3;
-    const int col = k0 + NB + (blockIdx.x - 1) * 64 + colq;
-    const int colc = col < D ? col : D - 1;
-    double x[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = R[(size_t)(k0 + q + 4 * r) * ldr + colc];
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
         const int pr = p >> 2, pq = p & 3;                 // pivot row p lives in register pr of quad lane pq
