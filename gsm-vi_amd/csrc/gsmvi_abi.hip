@@ -196,6 +196,7 @@ int gsmvi_destroy(gsmvi_ctx* ctx) {
     for (int k = 0; k < 8; ++k)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->bam_hint_host) (void)hipHostFree(ctx->bam_hint_host);
     hipError_t e = hipFree(ctx->ws);
     delete ctx;
     if (e != hipSuccess) {
@@ -211,6 +212,8 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     else if (!strcmp(name, "update_sb")) ctx->tune_update_sb = value;
     else if (!strcmp(name, "no_fast")) ctx->tune_no_fast = value;
     else if (!strcmp(name, "bam_host")) ctx->tune_bam_host = value;
+    else if (!strcmp(name, "bam_full")) ctx->tune_bam_full = value;
+    else if (!strcmp(name, "bam_kenq")) ctx->tune_bam_kenq = value;
     else if (!strcmp(name, "scalars_nt")) ctx->tune_scalars_nt = value;
     else if (!strcmp(name, "cov_dbg")) ctx->tune_cov_dbg = value;   // ablation bits, timing experiments only
     else {

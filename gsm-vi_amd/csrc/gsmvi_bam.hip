@@ -563,7 +563,7 @@ static bool host_cholesky(int n, std::vector<double>& A) {
 }
 
 int gsmvi_bam_small_device(hipStream_t st, int n, double reg, const double* Nd, const double* M1, const double* N0,
-                           double* scratch, double* Ld, double* Upk, int* info_dev);
+                           double* scratch, double* Ld, double* Upk, int* info_dev, int* hint_host, int force_kenq);
 int gsmvi_bam_small_nmax();
 size_t gsmvi_bam_small_scratch_doubles(int n);
 
@@ -604,7 +604,14 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     if (on_device) {
         // the whole (B+1) x (B+1) matrix function on the device (gsmvi_bam_small.hip): no copy, no synchronisation
         double* scratch = Upk + (size_t)n * (n + 1) / 2 + 2;
-        if ((rc = gsmvi_bam_small_device(st, n, reg, Nd, M1, N0, scratch, Ld, Upk, info_dev ? info_dev : ctx->ints + 8)))
+        if (!ctx->bam_hint_host) {                 // pinned, device-visible word for the step-count hint
+            if (hipHostMalloc(reinterpret_cast<void**>(&ctx->bam_hint_host), 64, hipHostMallocMapped) == hipSuccess)
+                *ctx->bam_hint_host = 0;
+            else
+                ctx->bam_hint_host = nullptr;
+        }
+        if ((rc = gsmvi_bam_small_device(st, n, reg, Nd, M1, N0, scratch, Ld, Upk, info_dev ? info_dev : ctx->ints + 8,
+                                         ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq)))
             return rc;
     }
     static const bool timing = getenv("GSMVI_BAM_TIMING") != nullptr;     // diagnostic: host phase times on stderr

@@ -35,7 +35,8 @@
 // recurrence.  A NaN / inf anywhere in N needs no flag of its own: it propagates through the products into BB, where
 // k_bam_chol_out rejects it.
 __global__ __launch_bounds__(256) void k_bam_ns_prep(int n, const double* __restrict__ Nm, double* __restrict__ Y,
-                                                     double* __restrict__ Z, double* __restrict__ coef) {
+                                                     double* __restrict__ Z, double* __restrict__ coef,
+                                                     int* __restrict__ hint_host) {
     __shared__ double red[4];
     const int tid = threadIdx.x;
     double tr = 0.0;
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(256) void k_bam_ns_prep(int n, const double* __rest
         if (kstar > BAMS_KMAX) kstar = BAMS_KMAX;
         coef[40] = (double)kstar;
         coef[41] = s;
+        if (hint_host) *hint_host = kstar;                   // pinned host word: how many steps the NEXT call should enqueue
     }
 }
 
@@ -248,6 +250,62 @@ __global__ __launch_bounds__(576) void k_bam_ns_small(int n, const double* __res
         const int i = e / n, j = e % n;
         const double y = 0.5 * (Yf[i * BAMS_SLD + j] + Yf[j * BAMS_SLD + i]);
         BBg[e] = failed ? __longlong_as_double(0x7ff8000000000000LL) : Nm[e] + (i == j ? 0.5 : 0.0) + rs * y;
+    }
+}
+
+// ---- safety net behind the enqueued steps --------------------------------------------------------------------------
+// The host enqueues kenq <= BAMS_KMAX multi-workgroup steps, guessed from the k* of the previous call (a pinned host
+// word written by k_bam_ns_prep: no synchronisation, possibly stale).  If this call's k* turns out larger, the missing
+// steps kenq .. k*-1 are executed HERE by one workgroup -- slow (one CU) but exact, so a stale guess costs time, never
+// correctness; normally the kernel returns at once.  Same products, same order, same ping-pong parity.
+template <int MODE>
+__device__ __forceinline__ void bams_block_wave(const double* A, const double* Bm, double* Out, int blk, int nb, int nk,
+                                                double c2, double scale) {
+    const int i0 = (blk / nb) * 16, j0 = (blk % nb) * 16;
+    const int l = threadIdx.x & 63, cc = l & 15, ks = l >> 4;
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int s0 = 0; s0 < nk; s0 += 12) {
+        double a[12], b[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int k = 4 * (s0 + u) + ks;
+            const int kc = k < BAMS_LD ? k : BAMS_LD - 1;
+            const double av = A[(size_t)(i0 + cc) * BAMS_LD + kc];
+            const double bv = Bm[(size_t)kc * BAMS_LD + j0 + cc];
+            a[u] = MODE == 2 ? ((kc == i0 + cc ? 1.5 : 0.0) - 0.5 * c2 * av) : av;
+            b[u] = MODE == 1 ? ((kc == j0 + cc ? 1.5 : 0.0) - 0.5 * c2 * bv) : bv;
+            if (s0 + u >= nk) { a[u] = 0.0; b[u] = 0.0; }
+        }
+#pragma unroll
+        for (int u = 0; u < 12; u += 2) {
+            acc0 = GSMVI_MFMA_F64(a[u], b[u], acc0);
+            acc1 = GSMVI_MFMA_F64(a[u + 1], b[u + 1], acc1);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Out[(size_t)(i0 + ks + 4 * r) * BAMS_LD + j0 + cc] = scale * (acc0[r] + acc1[r]);
+}
+
+__global__ __launch_bounds__(1024) void k_bam_ns_tail(int n, int kenq, double* Ya, double* Za, double* Yb, double* Zb,
+                                                      double* Mm, const double* coef) {
+    const int kstar = (int)coef[40];
+    if (kenq >= kstar || coef[42] != 0.0) return;            // the usual case: nothing left to do
+    const int nb = (n + 15) >> 4, nk = (n + 3) >> 2, w = threadIdx.x >> 6;
+    for (int k = kenq; k < kstar; ++k) {
+        const double c2 = coef[k], c = sqrt(c2);
+        double* Yi = (k & 1) ? Yb : Ya;
+        double* Zi = (k & 1) ? Zb : Za;
+        double* Yo = (k & 1) ? Ya : Yb;
+        double* Zo = (k & 1) ? Za : Zb;
+        for (int blk = w; blk < nb * nb; blk += 16) bams_block_wave<0>(Zi, Yi, Mm, blk, nb, nk, 0.0, 1.0);
+        __threadfence_block();
+        __syncthreads();
+        for (int blk = w; blk < 2 * nb * nb; blk += 16) {
+            if (blk < nb * nb) bams_block_wave<1>(Yi, Mm, Yo, blk, nb, nk, c2, c);
+            else bams_block_wave<2>(Mm, Zi, Zo, blk - nb * nb, nb, nk, c2, c);
+        }
+        __threadfence_block();
+        __syncthreads();
     }
 }
 
@@ -450,7 +508,7 @@ __global__ __launch_bounds__(256) void k_bam_chol_out(int n, double reg, const d
 }
 
 int gsmvi_bam_small_device(hipStream_t st, int n, double reg, const double* Nd, const double* M1, const double* N0,
-                           double* scratch, double* Ld, double* Upk, int* info_dev) {
+                           double* scratch, double* Ld, double* Upk, int* info_dev, int* hint_host, int force_kenq) {
     const size_t LL = (size_t)BAMS_LD * BAMS_LD;
     double* Ya = scratch;
     double* Za = Ya + LL;
@@ -463,12 +521,22 @@ int gsmvi_bam_small_device(hipStream_t st, int n, double reg, const double* Nd, 
         // small problems: the whole iteration in one workgroup, exactly k* steps, no skipped launches
         hipLaunchKernelGGL(k_bam_ns_small, dim3(1), dim3(576), 0, st, n, Nd, BBg);
     } else {
-        hipLaunchKernelGGL(k_bam_ns_prep, dim3(27), dim3(256), 0, st, n, Nd, Ya, Za, coef);
+        // steps to enqueue: the previous call's k* + 2 when known (pinned host word, read without synchronising),
+        // everything otherwise; k_bam_ns_tail makes up for a guess that turns out too small
+        int kenq = BAMS_KMAX;
+        if (hint_host) {
+            const int h = *reinterpret_cast<volatile int*>(hint_host);
+            if (h > 0 && h + 2 < BAMS_KMAX) kenq = h + 2;
+        }
+        if (force_kenq > 0 && force_kenq < BAMS_KMAX) kenq = force_kenq;       // tests: exercise the safety net
+        hipLaunchKernelGGL(k_bam_ns_prep, dim3(27), dim3(256), 0, st, n, Nd, Ya, Za, coef, hint_host);
         const int nb = (n + 15) / 16;
-        for (int k = 0; k < BAMS_KMAX; ++k) {
+        for (int k = 0; k < kenq; ++k) {
             hipLaunchKernelGGL(k_bam_ns_zy, dim3(nb * nb), dim3(256), 0, st, n, k, Ya, Za, Yb, Zb, Mm, coef);
             hipLaunchKernelGGL(k_bam_ns_step, dim3(2 * nb * nb), dim3(256), 0, st, n, k, Ya, Za, Yb, Zb, Mm, coef);
         }
+        if (kenq < BAMS_KMAX)
+            hipLaunchKernelGGL(k_bam_ns_tail, dim3(1), dim3(1024), 0, st, n, kenq, Ya, Za, Yb, Zb, Mm, coef);
         hipLaunchKernelGGL(k_bam_ns_bb, dim3((n * n + 255) / 256), dim3(256), 0, st, n, Nd, Ya, Yb, coef, BBg);
     }
     hipLaunchKernelGGL(k_bam_chol_out, dim3(1), dim3(256), 0, st, n, reg, BBg, M1, N0, Ld, Upk, info_dev);

@@ -21,6 +21,9 @@ struct gsmvi_ctx {
     int tune_cov_dbg = 0;      // ablation bits for k_gsm_cov_sym (wrong results; timing only)
     int tune_scalars_nt = 0;   // threads per sample in k_gsm_scalars_fast (256/512/1024; 0 = default)
     int tune_no_fast = 0;      // 1 = force the guarded generic kernels (tests)
+    int* bam_hint_host = nullptr;       // pinned word: k* of the last device BaM chain (step-count hint, never synchronised on)
+    int tune_bam_kenq = 0;     // > 0: enqueue exactly this many multi-workgroup steps (tests of the tail kernel)
+    int tune_bam_full = 0;     // 1 = always enqueue every Newton-Schulz step (ignore the hint; tests)
     int tune_bam_host = 0;     // 1 = BaM's small matrix function on the host even when the device chain applies (tests)
     int profiling = 0;         // when set, the update kernels are launched with dispatch-timestamp events
     double* h_pin = nullptr;   // pinned host staging for BaM's small matrices (grown on demand)

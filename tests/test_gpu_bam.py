@@ -167,3 +167,28 @@ def test_device_matrix_function_at_extreme_scales_is_as_accurate_as_the_host_pat
     e_dev = max(rel_err(mu_d.cpu().numpy(), mu_o), rel_err(S_d.cpu().numpy(), S_o))
     e_host = max(rel_err(mu_h.cpu().numpy(), mu_o), rel_err(S_h.cpu().numpy(), S_o))
     assert e_dev < max(10.0 * e_host, 1e-8), (e_dev, e_host)
+
+
+@pytest.mark.parametrize("D,B,kenq", [(200, 64, 3), (1024, 128, 5), (300, 100, 1)])
+def test_step_count_hint_and_tail_kernel(D, B, kenq):
+    """The multi-workgroup Newton-Schulz chain enqueues as many steps as the previous call needed (+2); when that
+    guess is too small the single-workgroup tail kernel runs the missing steps: same result as the full chain."""
+    import gsmvi_amd
+    orc, borc = _o()
+    eng = gsmvi_amd.get_engine()
+    st = orc.make_update_state(D, B, seed=D)
+    X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
+    eng.set_tuning("bam_full", 1)
+    mu_f, S_f, f_f = eng.bam_update(X, G, mu0, S0, 2.0, 0.0)
+    eng.set_tuning("bam_full", 0)
+    eng.set_tuning("bam_kenq", kenq)                     # far too few enqueued steps: the tail does the rest
+    try:
+        mu_t, S_t, f_t = eng.bam_update(X, G, mu0, S0, 2.0, 0.0)
+    finally:
+        eng.set_tuning("bam_kenq", 0)
+    mu_h, S_h, f_h = eng.bam_update(X, G, mu0, S0, 2.0, 0.0)       # hinted by the calls above
+    mu_h2, S_h2, _ = eng.bam_update(X, G, mu0, S0, 2.0, 0.0)
+    assert eng.read_flag(f_f) == 0 and eng.read_flag(f_t) == 0 and eng.read_flag(f_h) == 0
+    for mu, S in ((mu_t, S_t), (mu_h, S_h), (mu_h2, S_h2)):
+        assert rel_err(mu.cpu().numpy(), mu_f.cpu().numpy()) < 1e-11
+        assert rel_err(S.cpu().numpy(), S_f.cpu().numpy()) < 1e-11
