@@ -580,19 +580,19 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     double* Qm = Fs + (size_t)n2 * D;              // D x nq
     double* xbar = Qm + (size_t)D * nq;
     double* gbar = xbar + D;
-    double* M1 = ctx->small;                       // n x n
-    double* N0 = M1 + (size_t)n * n;               // n x n
-    double* Ld = N0 + (size_t)n * n;               // n x n, then Ldinv (n), zg (n), vg (n)
+    double* N0 = ctx->small;                       // n x n   } stacked [N0; M1] = [P; Vf] Q: ONE panel product
+    double* M1 = N0 + (size_t)n * n;               // n x n   }
+    double* Ld = M1 + (size_t)n * n;               // n x n, then Ldinv (n), zg (n), vg (n)
 
     hipLaunchKernelGGL(k_bam_stats, dim3((D + 63) / 64), dim3(256), 0, st, D, B, X, ldx, G, ldg, mu0, reg, xbar,
                        gbar, Qt, Ft, Fs, Qm, nq);
     int kc = 1, rc;
     if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, D, n, Qt, D, nullptr, 1.0, S0, lds0, ctx->pp, &kc))) return rc;
     if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, P, D))) return rc;
-    if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, n, n, Ft, D, nullptr, 1.0, Qm, nq, ctx->pp, &kc))) return rc;
-    if ((rc = gsmvi_panel_finish(st, n, n, kc, ctx->pp, nullptr, M1, n))) return rc;
-    if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, n, n, P, D, nullptr, 1.0, Qm, nq, ctx->pp, &kc))) return rc;
-    if ((rc = gsmvi_panel_finish(st, n, n, kc, ctx->pp, nullptr, N0, n))) return rc;
+    // M1 = Vf Q and N0 = P Q share the right operand; P and Vf (the first n rows of Ft) are adjacent in the workspace,
+    // so both Gram matrices come from one 2n-row panel product, finished into the adjacent [N0; M1]
+    if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, n, n2, P, D, nullptr, 1.0, Qm, nq, ctx->pp, &kc))) return rc;
+    if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
 
     // N = M1^T M1 + sym(N0) and M1^T on the device; then the three n x n blocks go to the host
     double* Nd = Ld + (size_t)n * n + 3 * n;       // n x n
@@ -641,12 +641,12 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
         ctx->h_pin_busy = 0;
     }
     std::vector<double> N((size_t)n * n), w, E;
-    HIPCHK(hipMemcpyAsync(h, M1, sizeof(double) * 2 * n * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h, N0, sizeof(double) * 2 * n * n, hipMemcpyDeviceToHost, st));     // [N0 | M1]
     HIPCHK(hipMemcpyAsync(h + (size_t)2 * n * n, Nd, sizeof(double) * n * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     std::copy(h + (size_t)2 * n * n, h + (size_t)3 * n * n, N.begin());
-    const double* hM1 = h;
-    const double* hN0 = h + (size_t)n * n;
+    const double* hN0 = h;
+    const double* hM1 = h + (size_t)n * n;
     const auto t_1 = tnow();
     int bad = 0;
     std::vector<double> Nc = N;
