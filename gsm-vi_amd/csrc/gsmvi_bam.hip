@@ -358,6 +358,84 @@ __global__ __launch_bounds__(256) void k_lowrank_update(int D, int KF, const dou
             }
 }
 
+// ---- fast form of the same update for D % 64 == 0 and KF <= 288 ---------------------------------------------------
+// The product Ft^T Fs = Vf^T Vf - Z^T Z is symmetric term by term (row p < n contributes Vf[p][i] Vf[p][j], row
+// p >= n contributes -Z[i] Z[j]), so computing EVERY 64 x 64 tile with the same k order gives a bitwise symmetric S
+// without the mirror pass -- twice the (small) MFMA work, but 256 workgroups instead of 136 at D = 1024, two waves per
+// SIMD, no transposes.  512 threads per tile; wave w owns the 16-row block w >> 1 and two 16-column blocks; every
+// global load of the workgroup is issued first (S0 tile in accumulator layout, then all KF rows of both operand
+// tiles, rows beyond KF as zeros); operands pass through LDS 32 rows at a time ([k][80], conflict-free for both MFMA
+// operands).  Same structure as k_gsmf_update_fast in the factor path.
+template <int NPMAX>
+__global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, const double* __restrict__ Ft,
+                                                             const double* __restrict__ Fs,
+                                                             const double* __restrict__ S0, int lds0,
+                                                             double* __restrict__ S, int lds, double jitter) {
+    constexpr int RS = 80, KP = 32;
+    __shared__ __attribute__((aligned(16))) double sm[2 * KP * RS];
+    const int nt = D >> 6, np = (KF + KP - 1) / KP;
+    const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
+    const int I0 = ti * 64, J0 = tj * 64;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+    const int wr = w >> 1, wc = w & 1;
+    double s0[2][4];
+    const size_t frow = (size_t)(I0 + 16 * wr + ks);
+    const int fcol = J0 + 32 * wc + c;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s0[blk][r] = S0[(frow + 4 * r) * lds0 + fcol + 16 * blk];
+    v2d ga[NPMAX][2], gb[NPMAX][2];
+#pragma unroll
+    for (int p = 0; p < NPMAX; ++p) {
+        if (p < np) {                                        // block-uniform
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int u = q * 512 + tid, row = KP * p + (u >> 5), c2 = 2 * (u & 31);
+                const int rc = row < KF ? row : KF - 1;
+                const v2d a = *reinterpret_cast<const v2d*>(Ft + (size_t)rc * D + I0 + c2);
+                const v2d b = *reinterpret_cast<const v2d*>(Fs + (size_t)rc * D + J0 + c2);
+                ga[p][q] = row < KF ? a : (v2d){0.0, 0.0};
+                gb[p][q] = row < KF ? b : (v2d){0.0, 0.0};
+            }
+        }
+    }
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int p = 0; p < NPMAX; ++p) {
+        if (p < np) {
+            if (p > 0) __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int u = q * 512 + tid, row = u >> 5, c2 = 2 * (u & 31);
+                *reinterpret_cast<v2d*>(sm + row * RS + c2) = ga[p][q];
+                *reinterpret_cast<v2d*>(sm + (KP + row) * RS + c2) = gb[p][q];
+            }
+            __syncthreads();
+            double a[8], b0[8], b1[8];
+            const double* ap = sm + ks * RS + 16 * wr + c;
+            const double* bp = sm + (KP + ks) * RS + 32 * wc + c;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                a[s] = ap[4 * s * RS];
+                b0[s] = bp[4 * s * RS];
+                b1[s] = bp[4 * s * RS + 16];
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                acc0 = GSMVI_MFMA_F64(a[s], b0[s], acc0);
+                acc1 = GSMVI_MFMA_F64(a[s], b1[s], acc1);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const size_t row = frow + 4 * r;
+        S[row * lds + fcol] = s0[0][r] + acc0[r] + ((int)row == fcol ? jitter : 0.0);
+        S[row * lds + fcol + 16] = s0[1][r] + acc1[r] + ((int)row == fcol + 16 ? jitter : 0.0);
+    }
+}
+
 // ---- host: eigen-decomposition of a symmetric n x n matrix (row-major) -------------------------------
 // Householder tridiagonalisation followed by the implicit-shift QL iteration (the classic EISPACK
 // tred2 / tql2 pair; O(n^3) with a small constant: ~10x fewer flops than cyclic Jacobi at n = 129).
@@ -729,8 +807,15 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
                            Ld, Ldinv, Ldinv + n, Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu);
     }
     const int nt = (D + 63) / 64;
-    hipLaunchKernelGGL(k_lowrank_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds,
-                       jitter);
+    if (!ctx->tune_no_fast && D % 64 == 0 && n2 <= 288) {
+        if (n2 <= 96)
+            hipLaunchKernelGGL(k_lowrank_update_fast<3>, dim3(nt * nt), dim3(512), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds, jitter);
+        else
+            hipLaunchKernelGGL(k_lowrank_update_fast<9>, dim3(nt * nt), dim3(512), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds, jitter);
+    } else {
+        hipLaunchKernelGGL(k_lowrank_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds,
+                           jitter);
+    }
     if (timing) fprintf(stderr, "[gsmvi bam] entry->t0 %.3f  whole call %.3f ms\n", tms(t_entry, t_0), tms(t_entry, tnow()));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
