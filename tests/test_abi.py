@@ -105,3 +105,15 @@ def test_plain_c_program_drives_the_abi(tmp_path, D, B):
     mu_o, S_o = orc.gsm_update_faithful(st["samples"], st["vs"], st["mu0"], st["S0"])
     assert rel_err(mu, mu_o) < 1e-11 and rel_err(S, S_o) < 1e-11 and info == 0
     assert rel_err(R.T @ R, S_o) < 1e-11 and np.array_equal(np.tril(R, -1), np.zeros_like(R))
+
+
+def test_new_entry_points_reject_bad_arguments_without_a_gpu():
+    """Argument validation of the entry points added for the sharded factor path and the draw stream runs before any
+    HIP call, so it is checkable on a machine without a GPU."""
+    from gsmvi_amd import _lib
+    lib = _lib.load_library()
+    assert lib.gsmvi_gsm_factor_local_stage_f64(None, None, 8, 2, None, 8, None, 8, None, 8, None, None, 8, None, 24) == 1
+    assert b"ctx" in lib.gsmvi_last_error()
+    assert lib.gsmvi_gsm_factor_apply_f64(None, None, 8, 2, None, 8, None, 24, None, None, 8, None, None, 8, None, None) == 1
+    assert lib.gsmvi_randn_f64(None, None, 1, 0, 16, None, None) == 1
+    assert lib.gsmvi_gsm_record_len(5) == 16 and lib.gsmvi_gsm_record_len(4) == 12
