@@ -15,7 +15,7 @@ void gsmvi_launch_panel_partial(hipStream_t st, hipEvent_t* ev, int MT, dim3 gri
                                 const double* A, int lda, const double* shift, double alpha, const double* M,
                                 int ldm, double* Pp, int chunks_per_wg, int a_vec_ok);
 void gsmvi_launch_panel_finish(hipStream_t st, hipEvent_t* ev, int D, int nrows, int KC, const double* Pp,
-                               const double* addvec, double* Out, int ldo);
+                               const double* addvec, double* Out, int ldo, int ncols_out);
 void gsmvi_launch_gsm_scalars(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, const double* X, int ldx,
                               const double* G, int ldg, const double* mu0, const double* Pp, double* rec,
                               int ldrec);
@@ -301,7 +301,14 @@ int gsmvi_panel_product(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D, i
 // Out (nrows x ncols, ldo) = addvec + sum of the kc slabs
 int gsmvi_panel_finish(hipStream_t st, int ncols, int nrows, int kc, const double* Pp, const double* addvec,
                        double* Out, int ldo) {
-    gsmvi_launch_panel_finish(st, nullptr, ncols, nrows, kc, Pp, addvec, Out, ldo);
+    gsmvi_launch_panel_finish(st, nullptr, ncols, nrows, kc, Pp, addvec, Out, ldo, ncols);
+    return check_launch("k_panel_finish");
+}
+
+// slabs with ncols_in columns (padded), only the first ncols_out are summed into Out
+int gsmvi_panel_finish_cols(hipStream_t st, int ncols_in, int ncols_out, int nrows, int kc, const double* Pp,
+                            double* Out, int ldo) {
+    gsmvi_launch_panel_finish(st, nullptr, ncols_in, nrows, kc, Pp, nullptr, Out, ldo, ncols_out);
     return check_launch("k_panel_finish");
 }
 
@@ -453,7 +460,7 @@ int gsmvi_gaussian_score_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const d
     int kc = 1;
     st = gsmvi_panel_product(ctx, hs, nullptr, D, B, X, ldx, m, -1.0, P, ldp, ctx->pp, &kc);
     if (st != GSMVI_OK) return st;
-    gsmvi_launch_panel_finish(hs, nullptr, D, B, kc, ctx->pp, nullptr, G, ldg);
+    gsmvi_launch_panel_finish(hs, nullptr, D, B, kc, ctx->pp, nullptr, G, ldg, D);
     return check_launch("k_panel_finish");
 }
 
@@ -467,7 +474,7 @@ int gsmvi_sample_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* Z
     int kc = 1;
     st = gsmvi_panel_product(ctx, hs, nullptr, D, B, Z, ldz, nullptr, 1.0, R, ldr, ctx->pp, &kc);
     if (st != GSMVI_OK) return st;
-    gsmvi_launch_panel_finish(hs, nullptr, D, B, kc, ctx->pp, mu, X, ldx);
+    gsmvi_launch_panel_finish(hs, nullptr, D, B, kc, ctx->pp, mu, X, ldx, D);
     return check_launch("k_panel_finish");
 }
 

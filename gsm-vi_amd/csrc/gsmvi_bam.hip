@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void k_bam_stats(int D, int B, const double* _
         gbar[i] = gb;
         Qt[(size_t)B * D + i] = r1s * gb;
         Qm[(size_t)i * nq + B] = r1s * gb;
+        for (int cz = B + 1; cz < nq; ++cz) Qm[(size_t)i * nq + cz] = 0.0;      // padding columns of the 16-wide strips
         Vf[(size_t)B * D + i] = r1s * (mu0[i] - xb);
         Vf2[(size_t)B * D + i] = r1s * (mu0[i] - xb);
     }
@@ -648,7 +649,7 @@ size_t gsmvi_bam_small_scratch_doubles(int n);
 int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X, int ldx, const double* G,
                    int ldg, const double* mu0, const double* S0, int lds0, double reg, double jitter, double* mu,
                    double* S, int lds, int* info_dev) {
-    const int n = B + 1, n2 = 2 * n, nq = (n + 1) & ~1;
+    const int n = B + 1, n2 = 2 * n, nq = (n + 15) & ~15;      // Q^T padded to whole 16-column strips (zeros)
     const auto t_entry = std::chrono::steady_clock::now();
     // workspace carve (ctx->sg holds 4*rmax*max_D doubles, rmax = 2B+8 >= 2n+6)
     double* Qt = ctx->sg;                          // n x D
@@ -669,8 +670,8 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, P, D))) return rc;
     // M1 = Vf Q and N0 = P Q share the right operand; P and Vf (the first n rows of Ft) are adjacent in the workspace,
     // so both Gram matrices come from one 2n-row panel product, finished into the adjacent [N0; M1]
-    if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, n, n2, P, D, nullptr, 1.0, Qm, nq, ctx->pp, &kc))) return rc;
-    if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
+    if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, nq, n2, P, D, nullptr, 1.0, Qm, nq, ctx->pp, &kc))) return rc;
+    if ((rc = gsmvi_panel_finish_cols(st, nq, n, n2, kc, ctx->pp, N0, n))) return rc;
 
     // N = M1^T M1 + sym(N0) and M1^T on the device; then the three n x n blocks go to the host
     double* Nd = Ld + (size_t)n * n + 3 * n;       // n x n

@@ -44,6 +44,8 @@ int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D
                            double* Pp, int* kc_out);
 int gsmvi_panel_finish(hipStream_t st, int ncols, int nrows, int kc, const double* Pp, const double* addvec,
                        double* Out, int ldo);
+int gsmvi_panel_finish_cols(hipStream_t st, int ncols_in, int ncols_out, int nrows, int kc, const double* Pp,
+                            double* Out, int ldo);
 void gsmvi_set_error(const char* fmt, const char* a, const char* b);
 int gsmvi_panel_product(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D, int nrows, const double* A, int lda,
                         const double* shift, double alpha, const double* M, int ldm, double* Pp, int* kc_out);

@@ -111,11 +111,12 @@ __global__ __launch_bounds__(256) void k_panel_partial(int D, int ncols, int nro
 
 // Out[r][i] = addvec[i] + sum_kc Pp[kc][r][i]      (D here = number of columns of the panel)
 // The (at most GSMVI_MAX_KC = 8) slab loads are issued as one batch with clamped indices.
+// ncols_out <= D: only the first ncols_out columns are written (slabs whose column count was padded to 16).
 __global__ __launch_bounds__(256) void k_panel_finish(int D, int nrows, int KC, const double* __restrict__ Pp,
                                                       const double* __restrict__ addvec,
-                                                      double* __restrict__ Out, int ldo) {
+                                                      double* __restrict__ Out, int ldo, int ncols_out) {
     const int i = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
-    if (i >= D) return;
+    if (i >= ncols_out) return;
     double v[8];
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc) v[kc] = Pp[((size_t)(kc < KC ? kc : KC - 1) * nrows + r) * D + i];
@@ -330,9 +331,9 @@ void gsmvi_launch_panel_partial(hipStream_t st, hipEvent_t* ev, int MT, dim3 gri
 }
 
 void gsmvi_launch_panel_finish(hipStream_t st, hipEvent_t* ev, int D, int nrows, int KC, const double* Pp,
-                               const double* addvec, double* Out, int ldo) {
-    GSMVI_LAUNCH(k_panel_finish, dim3((D + 255) / 256, nrows), dim3(256), 0, st, ev, D, nrows, KC, Pp, addvec, Out,
-                 ldo);
+                               const double* addvec, double* Out, int ldo, int ncols_out) {
+    GSMVI_LAUNCH(k_panel_finish, dim3((ncols_out + 255) / 256, nrows), dim3(256), 0, st, ev, D, nrows, KC, Pp, addvec,
+                 Out, ldo, ncols_out);
 }
 
 void gsmvi_launch_gsm_scalars(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, const double* X, int ldx,
