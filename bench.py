@@ -123,11 +123,45 @@ def cpu_baseline(D, B, seconds):
     return {"value": n / el, "unit": "updates/s", "cores": int(threads), "kind": "port",
             "sample": f"{n} updates of D={D},B={B} (oracle/gsm_oracle.py:gsm_update_faithful, numpy fp64, "
                       f"{os.cpu_count()} host cpus)",
-            "value_1_core": one_core, "best_effort_blas3_value": nb / tb}
+            "value_1_core": one_core, "best_effort_blas3_value": nb / tb,
+            "cpu_jax": "unavailable (jax/jaxlib are not installed on this image and there is no network; the "
+                       "numpy port stands in for the north star's CPU-JAX baseline)"}
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves as a CHILD torch.distributed.run
+    (never an exec of this process, and before this process has made any GPU call) and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()             # counting devices does not initialise the GPU
+    if ndev < n:
+        sys.stderr.write(f"bench.py: --gpus {n} requested but only {ndev} GPU(s) are visible; refusing to report a "
+                         f"{n}-GPU number from fewer devices\n")
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in p.stdout.splitlines():
+        if not lines or ln != lines[-1]:
+            sys.stderr.write(ln + "\n")           # whatever else the ranks printed
+    if p.returncode != 0 or not lines:
+        sys.stderr.write(f"bench.py: the {n}-rank run failed (exit code {p.returncode}, "
+                         f"{'no' if not lines else 'a'} JSON line)\n")
+        sys.exit(p.returncode or 1)
+    print(lines[-1], flush=True)
+    sys.exit(0)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -141,7 +175,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("NCCL_DEBUG", "WARN")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import gsmvi_amd
     from gsmvi_amd.dist import sharded_gsm_update, shard_bounds, row_sharded_gsm_update, row_bounds
@@ -177,8 +211,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- optional hipGraph of one trip round the ring (with RCCL: the all-gather is captured too) ----
-    graph, launch = None, "eager"
+    # ---- hipGraphs of the timed sequence (with RCCL: the all-gather is captured too).  The timed region is
+    # `steps // gsize` replays of a graph of gsize = min(ring, steps) consecutive ring positions plus ONE replay
+    # of a second graph holding the `steps % gsize` left over, so every timed step runs in the launch mode the
+    # JSON line names, for any --steps.
+    gsize = max(1, min(n_inst, args.steps))
+    n_full, n_rem = args.steps // gsize, args.steps % gsize
+    graph, graph_rem, launch = None, None, "eager"
+
+    def capture(first, count):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for k in range(first, first + count):
+                step(k)
+        return g
+
     if not args.no_graph:
         try:
             side = torch.cuda.Stream()
@@ -188,33 +235,45 @@ def main():
                     step(k)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                for k in range(n_inst):
-                    step(k)
-            launch = f"hipGraph({n_inst} updates/replay)"
+            graph = capture(0, gsize)
+            if n_rem:
+                graph_rem = capture(n_full * gsize, n_rem)
+            launch = f"hipGraph({n_full} x {gsize} updates/replay" + (f" + 1 x {n_rem}" if n_rem else "") + ")"
         except Exception as e:           # capture unsupported -> stay on eager launches of the same kernels
-            graph, launch = None, f"eager (graph capture failed: {type(e).__name__})"
+            graph, graph_rem, launch = None, None, f"eager (graph capture failed: {type(e).__name__})"
             torch.cuda.synchronize()
         if use_dist:                     # every rank must take the same path
             ok = torch.tensor([1 if graph is not None else 0], device="cuda")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
-                graph, launch = None, "eager (graph capture failed on some rank)"
+                graph, graph_rem, launch = None, None, "eager (graph capture failed on some rank)"
 
-    def run(nsteps):
-        done = 0
+    def run_timed():
         if graph is not None:
-            while nsteps - done >= n_inst:
+            for _ in range(n_full):
                 graph.replay()
-                done += n_inst
-        for k in range(nsteps - done):
-            step(k)
+            if graph_rem is not None:
+                graph_rem.replay()
+        else:
+            for k in range(args.steps):
+                step(k)
 
-    run(args.warmup)
+    def run_warmup():
+        """At least --warmup steps, in the timed region's own launch mode (whole replays, >= 1 of each graph)."""
+        if graph is not None:
+            for _ in range(max(1, -(-args.warmup // gsize))):
+                graph.replay()
+            if graph_rem is not None:
+                graph_rem.replay()
+            return max(1, -(-args.warmup // gsize)) * gsize + n_rem
+        for k in range(args.warmup):
+            step(k)
+        return args.warmup
+
+    warm_done = run_warmup()
     barrier()
     t0 = time.perf_counter()
-    run(args.steps)
+    run_timed()
     barrier()
     el = time.perf_counter() - t0
     if use_dist:
@@ -336,10 +395,19 @@ def main():
             mfma_util = next((v.get("util") for k, v in (tj.get("mfma_util") or {}).items() if "k_gsm_cov_sym" in k), None)
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_gsm_cov_sym" if (D % 32 == 0 and B in (16, 32, 64)) else "k_gsm_cov_update",
+    sym = D % 32 == 0 and B in (16, 32, 64)
+    # bytes the selected kernel really moves: the symmetric kernel reads only the upper triangle of S0
+    # (4 D^2 + the diagonal tiles) and writes all of S (8 D^2); the generic one reads and writes 8 D^2 each
+    nt32 = D // 32
+    moved = ((nt32 * (nt32 + 1) // 2) * 32 * 32 * 8.0 + 8.0 * D * D + 16.0 * B * D) if sym else alg_bytes_update
+    roofline = {"bound": "hbm", "kernel": "k_gsm_cov_sym" if sym else "k_gsm_cov_update",
                 "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": "profiles/traffic.json (rocprofv3 PMC pass of an earlier run of this command; "
+                                  "not a live counter)",
                 "algorithmic_bytes_per_launch": alg_bytes_update,
+                "moved_bytes_per_launch": moved, "achieved_moved": moved / (avg_ms["cov_update"] * 1e-3) / 1e9,
+                "frac_moved": moved / (avg_ms["cov_update"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "avg_kernel_us": {k: v * 1e3 for k, v in avg_ms.items()},
                 "whole_update_algorithmic_GBs": alg_bytes_total * value / 1e9,
                 "mfma_pipe_util_profiled": mfma_util}     # SQ_VALU_MFMA_BUSY_CYCLES pass, profiles/traffic.json
@@ -404,7 +472,7 @@ def main():
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"BASELINE configs[2]: D={D} dense-cov Gaussian target, B={B}, one GSM update "
                                   f"per step", "D": D, "B": B, "instances": n_inst,
-                      "ring_bytes": n_inst * per_inst, "launch": launch,
+                      "ring_bytes": n_inst * per_inst, "launch": launch, "warmup_steps_run": warm_done,
                       "parallelism": "single GPU" if not use_dist else
                       (f"covariance row blocks x{world} + RCCL all-gather of SG column slices" if rows else
                        f"batch-sharded x{world} + RCCL all-gather")},

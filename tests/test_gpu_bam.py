@@ -192,3 +192,59 @@ def test_step_count_hint_and_tail_kernel(D, B, kenq):
     for mu, S in ((mu_t, S_t), (mu_h, S_h), (mu_h2, S_h2)):
         assert rel_err(mu.cpu().numpy(), mu_f.cpu().numpy()) < 1e-11
         assert rel_err(S.cpu().numpy(), S_f.cpu().numpy()) < 1e-11
+
+
+def _bam_uv(X, G, mu0, S0, reg):
+    """U, V, xbar, gbar exactly as gsmvi/bam.py:50-60 forms them (the batch means of outer products written as
+    one GEMM instead of the reference's vmap'ed (B, D, D) temporary)."""
+    B = X.shape[0]
+    xbar = X.mean(axis=0)                                       # bam.py:50
+    xdiff = X - xbar                                            # :52
+    C = xdiff.T @ xdiff / B                                     # :53
+    gbar = G.mean(axis=0)                                       # :55
+    gdiff = G - gbar                                            # :56
+    Gm = gdiff.T @ gdiff / B                                    # :57
+    U = reg * Gm + reg / (1 + reg) * np.outer(gbar, gbar)       # :59
+    V = S0 + reg * C + reg / (1 + reg) * np.outer(mu0 - xbar, mu0 - xbar)   # :60
+    return U, V, xbar, gbar
+
+
+@pytest.mark.parametrize("reg", [0.5, 10.0, 100.0 / 3])
+@pytest.mark.parametrize("D,B", [(64, 8), (256, 32), (1024, 128)])
+def test_k8_defining_equation_of_the_bam_update(D, B, reg):
+    """K8: an ORACLE-INDEPENDENT pin.  The BaM covariance is DEFINED as the solution of S U S + S = V
+    (gsmvi/bam.py:59-65 solves exactly this: S = 2 V (I + sqrtm(I + 4 U V))^-1) and the mean as
+    mu0/(1+reg) + reg/(1+reg) (S gbar + xbar) (bam.py:67).  The HIP result is put into both equations with U, V
+    formed from the inputs; oracle/bam_oracle.py is not involved.  Sizes include BASELINE configs[3] (1024, 128)."""
+    import gsmvi_amd
+    orc, _ = _o()
+    st = orc.make_update_state(D, B, seed=D + B)
+    X, G, mu0, S0 = st["samples"], st["vs"], st["mu0"], st["S0"]
+    U, V, xbar, gbar = _bam_uv(X, G, mu0, S0, reg)
+    for fn in (gsmvi_amd.bam_lowrank_update, gsmvi_amd.bam_update):
+        mu, S = fn(X, G, mu0, S0, reg)                           # jitter 0
+        res = S @ U @ S + S - V
+        # normwise backward error of the defining equation (the honest scale: ||S||^2 ||U|| is up to 1e8 ||V|| on
+        # this target, whose scores are O(1e3), so eps * that is what a plain ||res|| / ||V|| can resolve; the
+        # scipy restatement itself reaches 8e-9 there at (256, 32, reg 100/3))
+        n2 = lambda M: np.linalg.norm(M, 2)
+        bwd = n2(res) / (n2(S) ** 2 * n2(U) + n2(S) + n2(V))
+        plain = np.abs(res).max() / np.abs(V).max()
+        assert bwd < 1e-14 and plain < 1e-7, (fn.__name__, bwd, plain)
+        mu_def = mu0 / (1 + reg) + reg / (1 + reg) * (S @ gbar + xbar)
+        assert rel_err(mu, mu_def) < 1e-12
+        assert np.array_equal(S, S.T) and np.linalg.eigvalsh(S).min() > 0
+
+
+def test_full_form_gap_stays_small_at_moderate_reg(golden):
+    """bam_update is served by the low-rank kernels (K6: the two forms are algebraically equal); against the
+    restated FULL form (bam.py:31-69) the gap must stay well inside the north-star 1e-5 at reg <= 10."""
+    import gsmvi_amd
+    g = golden("r1_bam.npz")
+    for c in [str(x) for x in g["cases"]]:
+        if float(g[f"{c}/reg"]) > 10.0:
+            continue
+        mu, S = gsmvi_amd.bam_update(g[f"{c}/samples"], g[f"{c}/vs"], g[f"{c}/mu0"], g[f"{c}/S0"],
+                                     float(g[f"{c}/reg"]))
+        Sf = 0.5 * (g[f"{c}/S_full"] + g[f"{c}/S_full"].T)
+        assert rel_err(S, Sf) < 1e-6 and rel_err(mu, g[f"{c}/mu_full"]) < 1e-6, c

@@ -52,3 +52,27 @@ def test_bench_in_flight_option():
     """--in-flight 2: two independent updates on two streams / two engine contexts (opt-in secondary figure)."""
     d = _run({}, "--steps", "42", "--warmup", "21", "--no-cpu-baseline", "--in-flight", "2")
     assert d["value"] > 0 and d["value_in_flight"]["in_flight"] == 2 and d["value_in_flight"]["updates_per_s"] > 0
+
+
+def test_bench_driver_flags_time_the_graph_path_they_name():
+    """The driver's own invocation (--steps 20 --warmup 5, fewer steps than ring instances): every timed step is a
+    hipGraph replay and the label says what ran (round-1 verdict: those 20 steps used to be eager launches)."""
+    d = _run({}, "--steps", "20", "--warmup", "5", "--no-cpu-baseline")
+    assert d["steps"] == 20 and d["warmup"] == 5
+    assert d["config"]["launch"] == "hipGraph(1 x 20 updates/replay)", d["config"]["launch"]
+    assert d["config"]["warmup_steps_run"] >= 5
+    assert d["value"] > 40e3, d["value"]                # eager launches gave 36.5k; the replayed graph ~55-65k
+    d = _run({}, "--steps", "50", "--warmup", "5", "--no-cpu-baseline")
+    assert d["config"]["launch"] == "hipGraph(2 x 21 updates/replay + 1 x 8)", d["config"]["launch"]
+    assert "traffic_source" in d["roofline"] and d["roofline"]["moved_bytes_per_launch"] < \
+        d["roofline"]["algorithmic_bytes_per_launch"]
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """--gpus N without a launcher starts its own N ranks; with fewer than N devices it must fail loudly instead of
+    reporting a 1-GPU number as an N-GPU one."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], capture_output=True,
+                       text=True, timeout=300, cwd=ROOT)
+    assert p.returncode != 0 and "GPU(s) are visible" in p.stderr and '"metric"' not in p.stdout

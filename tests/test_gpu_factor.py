@@ -156,3 +156,131 @@ def test_factor_fit_converges_to_machine_precision_on_gaussian_targets(D, B, nit
         mean, cov = gsm.fit(5, niter=niter, batch_size=B, verbose=False, rng="device", method=method)
         assert gsm.n_reverts == 0
         assert np.abs(mean - m).max() < 1e-12 and rel_err(cov, cov_t) < 1e-12, method
+
+
+# ---- BASELINE configs[4]: D=4096, B=64, "Cholesky-factor update path", ill-conditioned --------------------------
+def _logspectrum_spd(rs, D, cond):
+    """SPD matrix with a log-uniform spectrum in a random orthogonal basis: eigenvalues 1 .. cond, scaled so that
+    their geometric mean is 1 (cond = 1e8 -> eigenvalues 1e-4 .. 1e4)."""
+    Q, _ = np.linalg.qr(rs.standard_normal((D, D)))
+    w = np.logspace(-0.5 * np.log10(cond), 0.5 * np.log10(cond), D)
+    S = (Q * w) @ Q.T
+    return 0.5 * (S + S.T), Q, w
+
+
+_C5 = {}
+
+
+def _c5_case(state_cond):
+    """(orc, X, G, mu0, S0, F0, Z) at D=4096, B=64: target with cond(Sigma_t) = 1e8 (the recipe of
+    tests/test_gpu_gsm_update.py::test_config_c5_d4096_b64_ill_conditioned) and a state covariance that is
+    either the well-conditioned SURVEY 8(d) recipe (state_cond None) or has cond(F0^T F0) = state_cond."""
+    if state_cond in _C5:
+        return _C5[state_cond]
+    from oracle import gsm_oracle as orc
+    D, B = 4096, 64
+    rs = np.random.RandomState(5)
+    if "target" not in _C5:
+        Qt, _ = np.linalg.qr(rs.standard_normal((D, D)))
+        wt = np.logspace(-4, 4, D)
+        P = (Qt / wt) @ Qt.T
+        _C5["target"] = (rs.random_sample(D), 0.5 * (P + P.T))
+    m, P = _C5["target"]
+    rs = np.random.RandomState(17 if state_cond is None else int(np.log10(state_cond)))
+    if state_cond is None:
+        A = rs.standard_normal((D, D))
+        S0 = A @ A.T / D + 0.1 * np.eye(D)
+        S0 = 0.5 * (S0 + S0.T)
+    else:
+        S0, _, _ = _logspectrum_spd(rs, D, state_cond)
+    F0 = np.linalg.cholesky(S0).T.copy()            # upper factor, Sigma = F0^T F0
+    S0 = F0.T @ F0                                   # the covariance the factor REPRESENTS (what the oracle gets)
+    mu0 = rs.standard_normal(D)
+    Z = rs.standard_normal((B, D))
+    X = mu0 + Z @ F0
+    G = orc.gaussian_score(X, m, P)
+    _C5[state_cond] = (orc, X, G, mu0, S0, F0, Z)
+    return _C5[state_cond]
+
+
+@pytest.mark.parametrize("state_cond", [None, 1e4, 1e8])
+def test_config_c5_factor_path_d4096_b64(state_cond):
+    """BASELINE configs[4] through the path it names: gsmvi_gsm_factor_update_f64 at D=4096, B=64 (2B = 128:
+    k_chol128 / k_gsmf_kmat_big / k_gsmf_update_fast<4>) against the pinned dense oracle on (mu, F^T F) --
+    cond-1e8 target; state factor well conditioned, cond 1e4 and cond 1e8.  Tolerances are the measured ones
+    (fp64): see the assertion; north-star bar 1e-5."""
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    orc, X, G, mu0, S0, F0, Z = _c5_case(state_cond)
+    mu_o, S_o = orc.gsm_update_batched(X, G, mu0, S0)
+    n_rev = eng.new_flag()
+    mu, F, flag = eng.gsm_factor_update(eng.asarray(Z), eng.asarray(X), eng.asarray(G), eng.asarray(mu0),
+                                        eng.asarray(F0), n_reverts=n_rev)
+    assert eng.read_flag(flag) == 0 and eng.read_flag(n_rev) == 0
+    Fn = F.cpu().numpy()
+    e_mu, e_S = rel_err(mu.cpu().numpy(), mu_o), rel_err(Fn.T @ Fn, S_o)
+    print(f"c5 factor path, state cond {state_cond}: rel err mu {e_mu:.2e} cov {e_S:.2e}")
+    assert e_mu < 1e-5 and e_S < 1e-5                                  # north star
+    tol = 1e-9 if state_cond is None else 1e-7
+    assert e_mu < tol and e_S < tol, (e_mu, e_S)
+    # the update must also agree with the DENSE HIP path on the represented covariance
+    mu_d, S_d = gsmvi_amd.gsm_update(X, G, mu0, S0)
+    assert rel_err(mu.cpu().numpy(), mu_d) < tol and rel_err(Fn.T @ Fn, S_d) < tol
+
+
+@pytest.mark.parametrize("D,B,cond", [(256, 32, 1e8), (1024, 32, 1e8), (320, 64, 1e6), (128, 16, 1e10)])
+def test_factor_update_ill_conditioned_state(D, B, cond):
+    """State factor with cond(F^T F) up to 1e10 through the single-workgroup 2B x 2B chain (k_gsmf_small, 2B <= 64)
+    and the big one (2B = 128)."""
+    import gsmvi_amd
+    from oracle import gsm_oracle as orc
+    eng = gsmvi_amd.get_engine()
+    rs = np.random.RandomState(D + B)
+    S0, _, _ = _logspectrum_spd(rs, D, cond)
+    F0 = np.linalg.cholesky(S0).T.copy()
+    S0 = F0.T @ F0
+    m, cov_t, P = orc.make_gaussian_target(D, 7)
+    mu0 = rs.standard_normal(D)
+    Z = rs.standard_normal((B, D))
+    X = mu0 + Z @ F0
+    G = orc.gaussian_score(X, m, P)
+    mu_o, S_o = orc.gsm_update_batched(X, G, mu0, S0)
+    mu, F, flag = eng.gsm_factor_update(eng.asarray(Z), eng.asarray(X), eng.asarray(G), eng.asarray(mu0),
+                                        eng.asarray(F0))
+    assert eng.read_flag(flag) == 0
+    Fn = F.cpu().numpy()
+    e_mu, e_S = rel_err(mu.cpu().numpy(), mu_o), rel_err(Fn.T @ Fn, S_o)
+    print(f"factor update D={D} B={B} state cond {cond:g}: rel err mu {e_mu:.2e} cov {e_S:.2e}")
+    assert e_mu < 1e-7 and e_S < 1e-7, (e_mu, e_S)
+
+
+def test_g4_decisive_revert_case_through_the_factor_form(golden):
+    """G4 (tests/golden/g4_revert.npz): the crafted update whose dense covariance DECISIVELY fails the reference's
+    Cholesky test (gsm_numpy.py:121-125,132-146 revert it).  In factor form Sigma' = F'^T F' is positive
+    semi-definite by construction, so the same inputs can only (a) be reverted by the 2B x 2B test, state kept
+    bit for bit, or (b) be accepted with a finite PSD covariance.  Which one happens is pinned here and documented
+    in GSM.fit's docstring (deviation from the dense path, where rounding noise in S0 + rank-2B terms makes the
+    matrix indefinite)."""
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    g = golden("g4_revert.npz")
+    mu0, S0, X, G = g["mu0"], g["S0"], g["samples"], g["vs"]
+    F0 = np.linalg.cholesky(S0).T.copy()                    # the reference accepts S0 itself (make_golden.py g4)
+    Z = np.linalg.solve(F0.T, (X - mu0).T).T                # x = mu0 + z F0
+    n_rev = eng.new_flag()
+    mu, F, flag = eng.gsm_factor_update(eng.asarray(Z), eng.asarray(X), eng.asarray(G), eng.asarray(mu0),
+                                        eng.asarray(F0), n_reverts=n_rev)
+    Fn, mun = F.cpu().numpy(), mu.cpu().numpy()
+    if eng.read_flag(flag) != 0:                                                    # (a)
+        assert eng.read_flag(n_rev) == 1 and np.array_equal(mun, mu0) and np.array_equal(Fn, F0)
+        outcome = "reverted"
+    else:                                                                           # (b)
+        S = Fn.T @ Fn
+        assert np.isfinite(S).all() and np.isfinite(mun).all()
+        assert np.linalg.eigvalsh(0.5 * (S + S.T)).min() >= -1e-12 * np.abs(S).max()
+        outcome = "accepted"
+    print("G4 through the factor form:", outcome)
+    assert outcome == G4_FACTOR_OUTCOME
+
+
+G4_FACTOR_OUTCOME = "reverted"      # measured on MI355X (see GSM.fit docstring); the dense path reverts too
