@@ -32,14 +32,22 @@ void gsmvi_launch_commit(hipStream_t st, int D, const int* info, const double* m
 // fast paths (gsmvi_fast.hip)
 void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int nrows, const double* A,
                              int lda, const double* shift, double alpha, const double* M, int ldm, double* Pp,
-                             int chunks_per_wg, int ncols);
+                             int chunks_per_wg, int ncols, unsigned long long* stamps);
 bool gsmvi_launch_gsm_scalars_fast(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, const double* X, int ldx,
                                    const double* G, int ldg, const double* mu0, const double* Pp, double* rec,
-                                   int ldrec, int nt);
+                                   int ldrec, int nt, unsigned long long* stamps);
 bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, const double* rec, int ldrec,
                               const double* mu0, const double* S0, int lds0, double* S, int lds, double* mu_out,
                               int dbg, unsigned long long* stamps);
 int gsmvi_panel_fast_chunk(int MT);
+// two-launch dense update (gsmvi_fused.hip)
+int gsmvi_panel_seam_chunk(int MT);
+bool gsmvi_launch_panel_seam(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, int chunks_per_wg, const double* G,
+                             int ldg, const double* S0, int lds0, const double* X, int ldx, const double* mu0,
+                             double* Pp, double* SG, double* pd, unsigned* cnt, unsigned long long* stamps);
+bool gsmvi_launch_gsm_cov_fused(hipStream_t st, hipEvent_t* ev, int D, int B, const double* X, int ldx,
+                                const double* SG, const double* pd, const double* mu0, const double* S0, int lds0,
+                                double* S, int lds, double* mu_out, int flags, unsigned long long* stamps);
 int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                      int* info_dev);
 int gsmvi_factor_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X,
@@ -144,7 +152,7 @@ size_t gsmvi_workspace_bytes(int max_D, int max_B) {
     size_t a, b, c;
     int r;
     ws_sizes(max_D, max_B, &a, &b, &c, &r);
-    return (a + b + c) * sizeof(double) + 256;
+    return (a + b + c) * sizeof(double) + 256 + 4096;
 }
 
 int gsmvi_create(gsmvi_ctx** out, int device, int max_D, int max_B) {
@@ -165,7 +173,7 @@ int gsmvi_create(gsmvi_ctx** out, int device, int max_D, int max_B) {
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     size_t n_pp, n_sg, n_small;
     ws_sizes(max_D, max_B, &n_pp, &n_sg, &n_small, &c->rmax);
-    c->ws_bytes = (n_pp + n_sg + n_small) * sizeof(double) + 256;
+    c->ws_bytes = (n_pp + n_sg + n_small) * sizeof(double) + 256 + 4096;
     hipError_t e = hipMalloc(&c->ws, c->ws_bytes);
     if (e != hipSuccess) {
         gsmvi_set_error("hipMalloc of the workspace failed: %s%s", hipGetErrorString(e), "");
@@ -176,6 +184,7 @@ int gsmvi_create(gsmvi_ctx** out, int device, int max_D, int max_B) {
     c->sg = c->pp + n_pp;
     c->small = c->sg + n_sg;
     c->ints = reinterpret_cast<int*>(c->small + n_small);
+    c->seam_cnt = reinterpret_cast<unsigned*>(c->ints + 64);
     e = hipMemset(c->ws, 0, c->ws_bytes);
     if (e == hipSuccess) e = gsmvi_cov_update_prepare();
     if (e == hipSuccess) e = gsmvi_bam_prepare();
@@ -197,6 +206,7 @@ int gsmvi_destroy(gsmvi_ctx* ctx) {
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->bam_hint_host) (void)hipHostFree(ctx->bam_hint_host);
+    if (ctx->stamps) (void)hipFree(ctx->stamps);
     hipError_t e = hipFree(ctx->ws);
     delete ctx;
     if (e != hipSuccess) {
@@ -211,11 +221,20 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "panel_kc")) ctx->tune_panel_kc = value;
     else if (!strcmp(name, "update_sb")) ctx->tune_update_sb = value;
     else if (!strcmp(name, "no_fast")) ctx->tune_no_fast = value;
+    else if (!strcmp(name, "fused")) ctx->tune_fused = value;
+    else if (!strcmp(name, "fused_flags")) ctx->tune_fused_flags = value;
     else if (!strcmp(name, "bam_host")) ctx->tune_bam_host = value;
     else if (!strcmp(name, "bam_full")) ctx->tune_bam_full = value;
     else if (!strcmp(name, "bam_kenq")) ctx->tune_bam_kenq = value;
     else if (!strcmp(name, "scalars_nt")) ctx->tune_scalars_nt = value;
     else if (!strcmp(name, "cov_dbg")) ctx->tune_cov_dbg = value;   // ablation bits, timing experiments only
+    else if (!strcmp(name, "timeline")) {                           // whole-update timeline stamps (diagnostic)
+        if (value && !ctx->stamps) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->stamps), GSMVI_STAMP_WORDS * sizeof(unsigned long long)));
+            HIP_TRY(hipMemset(ctx->stamps, 0, GSMVI_STAMP_WORDS * sizeof(unsigned long long)));
+        }
+        ctx->tune_timeline = value;
+    }
     else {
         gsmvi_set_error("%s: unknown tuning knob %s", __func__, name);
         return GSMVI_ERR_BAD_ARG;
@@ -228,6 +247,11 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
 int gsmvi_debug_read_stamps(gsmvi_ctx* ctx, unsigned long long* out, int n) {
     BAD_ARG(!ctx || !out || n < 1, "bad argument");
     HIP_TRY(hipDeviceSynchronize());
+    if (ctx->tune_timeline && ctx->stamps) {
+        BAD_ARG(n > GSMVI_STAMP_WORDS, "more words than the timeline buffer holds");
+        HIP_TRY(hipMemcpy(out, ctx->stamps, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost));
+        return GSMVI_OK;
+    }
     HIP_TRY(hipMemcpy(out, ctx->pp, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost));
     return GSMVI_OK;
 }
@@ -285,7 +309,7 @@ int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D
     *kc_out = kc;
     if (fast) {
         gsmvi_launch_panel_fast(st, ev, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm, Pp,
-                                cpw, ncols);
+                                cpw, ncols, ctx->timeline_stamps(0));
         return check_launch("k_panel_fast");
     }
     gsmvi_launch_panel_partial(st, ev, MT, dim3(strips, kc, zblocks), D, ncols, nrows, A, lda, shift, alpha, M,
@@ -346,6 +370,7 @@ static int gsm_apply(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, const double*
     if (!ctx->tune_no_fast && D % 32 == 0 && (ldrec % 2 == 0) && aligned16(rec) &&
         gsmvi_launch_gsm_cov_sym(hs, ctx->stage_events(2), D, B, rec, ldrec, mu0, S0, lds0, S, lds, mu,
                                  ctx->tune_cov_dbg,
+                                 ctx->timeline_stamps(2) ? ctx->timeline_stamps(2) :
                                  (ctx->tune_cov_dbg & 16) ? reinterpret_cast<unsigned long long*>(ctx->pp) : nullptr))
         return check_launch("k_gsm_cov_sym");
     int SB = ctx->tune_update_sb > 0 ? ctx->tune_update_sb : ((B + 1) & ~1);
@@ -361,10 +386,45 @@ static int gsm_records(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, int kc, con
                        const double* G, int ldg, const double* mu0, const double* Pp, double* rec, int ldrec) {
     if (!ctx->tune_no_fast && D <= 8192 &&
         gsmvi_launch_gsm_scalars_fast(hs, ctx->stage_events(1), D, B, kc, X, ldx, G, ldg, mu0, Pp, rec, ldrec,
-                                      ctx->tune_scalars_nt))
+                                      ctx->tune_scalars_nt, ctx->timeline_stamps(1)))
         return check_launch("k_gsm_scalars_fast");
     gsmvi_launch_gsm_scalars(hs, ctx->stage_events(1), D, B, kc, X, ldx, G, ldg, mu0, Pp, rec, ldrec);
     return check_launch("k_gsm_scalars");
+}
+
+// Two-launch form (gsmvi_fused.hip).  Returns false when the problem is not eligible (the caller then runs the
+// three-launch path): needs the fast-path alignment, B in {16,32,64}, and a panel grid of at most one workgroup per
+// CU -- the geometry the in-kernel hand-off of k_panel_seam was measured in.
+static bool gsm_update_fused(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, const double* X, int ldx, const double* G,
+                             int ldg, const double* mu0, const double* S0, int lds0, double* mu, double* S, int lds,
+                             int* status) {
+    if (ctx->tune_no_fast || !ctx->tune_fused || ctx->tune_cov_dbg) return false;
+    if (D % 64 != 0 || !(B == 16 || B == 32 || B == 64)) return false;
+    if ((ldx | ldg | lds0 | lds) & 1) return false;
+    if (!aligned16(X) || !aligned16(G) || !aligned16(mu0) || !aligned16(S0) || !aligned16(S)) return false;
+    const int strips = D / 16, MT = B / 16;
+    if (strips > ctx->num_cu || strips > 64) return false;      // k_gsm_cov_fused reduces at most 64 strips (D <= 1024)
+    const int chw = gsmvi_panel_seam_chunk(MT);
+    const int nchunks = (D + chw - 1) / chw;
+    int kc = ctx->tune_panel_kc > 0 ? ctx->tune_panel_kc : ctx->num_cu / strips;
+    if (kc > nchunks) kc = nchunks;
+    if (kc > GSMVI_SEAM_MAX_KC) kc = GSMVI_SEAM_MAX_KC;
+    if (kc < 1) kc = 1;
+    const int cpw = (nchunks + kc - 1) / kc;
+    kc = (nchunks + cpw - 1) / cpw;
+    if (strips * kc > ctx->num_cu) return false;
+    double* SG = ctx->sg;                          // [B][D]
+    double* pd = ctx->small;                       // [strips][B][2]
+    if (!gsmvi_launch_panel_seam(hs, ctx->stage_events(0), D, B, kc, cpw, G, ldg, S0, lds0, X, ldx, mu0, ctx->pp, SG,
+                                 pd, ctx->seam_cnt, ctx->timeline_stamps(0)))
+        return false;
+    *status = check_launch("k_panel_seam");
+    if (*status != GSMVI_OK) return true;
+    if (ctx->profiling) ctx->ev_valid[1] = 0;      // no per-sample launch on this path
+    gsmvi_launch_gsm_cov_fused(hs, ctx->stage_events(2), D, B, X, ldx, SG, pd, mu0, S0, lds0, S, lds, mu,
+                               ctx->tune_fused_flags, ctx->timeline_stamps(2));
+    *status = check_launch("k_gsm_cov_fused");
+    return true;
 }
 
 int gsmvi_gsm_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* X, int ldx, const double* G,
@@ -375,6 +435,7 @@ int gsmvi_gsm_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const doubl
     BAD_ARG(ldx < D || ldg < D || lds0 < D || lds < D, "leading dimension smaller than D");
     BAD_ARG(S == S0 || mu == mu0, "outputs must not alias inputs");
     hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    if (gsm_update_fused(ctx, hs, D, B, X, ldx, G, ldg, mu0, S0, lds0, mu, S, lds, &st)) return st;
     const int ldrec = 3 * D + (D & 1);            // even stride keeps every record 16-byte aligned
     st = gsm_local_stage(ctx, hs, D, B, X, ldx, G, ldg, mu0, S0, lds0, ctx->sg, ldrec);
     if (st != GSMVI_OK) return st;

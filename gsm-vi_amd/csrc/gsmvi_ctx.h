@@ -4,6 +4,8 @@
 #include <cstddef>
 
 #define GSMVI_MAX_KC 8
+#define GSMVI_SEAM_MAX_KC 8   // split-K pieces a strip seam of k_panel_seam can combine
+#define GSMVI_STAMP_WORDS (4 * 4096)   // timeline diagnostic: 4 kernels x 512 workgroups x 8 words
 
 struct gsmvi_ctx {
     int device = 0;
@@ -16,9 +18,15 @@ struct gsmvi_ctx {
     double* sg = nullptr;      // [4][rmax][max_D] finished panels (SG, BaM factor panels)
     double* small = nullptr;   // coefficients and small dense matrices
     int* ints = nullptr;       // device ints (flags)
+    unsigned* seam_cnt = nullptr;   // [1024] arrival counters of k_panel_seam (zero between launches)
+    int tune_fused = 0;        // 1 = dense update as TWO launches where eligible (gsmvi_fused.hip); measured no faster than the
+                               // three-launch default at D=1024, B=32 (54.6k vs 54.2k updates/s HBM-cold, 59.8k vs 65.2k cache-resident)
+    int tune_fused_flags = 0;  // experiment bits for k_gsm_cov_fused (1 = mirror tile stored without the LDS transpose)
     int tune_panel_kc = 0;
     int tune_update_sb = 0;
     int tune_cov_dbg = 0;      // ablation bits for k_gsm_cov_sym (wrong results; timing only)
+    int tune_timeline = 0;     // 1 = every fast-path kernel of the dense update writes s_memrealtime stamps (diagnostic)
+    unsigned long long* stamps = nullptr;   // [kernel][workgroup][8], allocated by the "timeline" knob
     int tune_scalars_nt = 0;   // threads per sample in k_gsm_scalars_fast (256/512/1024; 0 = default)
     int tune_no_fast = 0;      // 1 = force the guarded generic kernels (tests)
     int* bam_hint_host = nullptr;       // pinned word: k* of the last device BaM chain (step-count hint, never synchronised on)
@@ -31,6 +39,10 @@ struct gsmvi_ctx {
     int h_pin_busy = 0;        // ev[7] marks the end of the last upload from h_pin
     hipEvent_t ev[8] = {};     // [2*stage], [2*stage+1]: panel, scalars, cov-update, spare
     int ev_valid[4] = {};
+
+    unsigned long long* timeline_stamps(int kernel) {
+        return (tune_timeline && stamps) ? stamps + (size_t)kernel * 4096 : nullptr;
+    }
 
     hipEvent_t* stage_events(int stage) {
         if (!profiling) return nullptr;

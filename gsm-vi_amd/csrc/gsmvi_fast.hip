@@ -35,7 +35,15 @@ template <int MT, bool HAS_SHIFT, int CHW>
 __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const double* __restrict__ A, int lda,
                                                     const double* __restrict__ shift, double alpha,
                                                     const double* __restrict__ M, int ldm,
-                                                    double* __restrict__ Pp, int chunks_per_wg, int ncols) {
+                                                    double* __restrict__ Pp, int chunks_per_wg, int ncols,
+                                                    unsigned long long* __restrict__ stamps) {
+#define PSTAMP(k)                                                                                              \
+    do {                                                                                                       \
+        if (stamps && threadIdx.x == 0)                                                                        \
+            stamps[(size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k)] =       \
+                __builtin_amdgcn_s_memrealtime();                                                              \
+    } while (0)
+    PSTAMP(0);
     constexpr int LDG = CHW + 2;                   // LDS row stride of the staged A chunk (doubles)
     constexpr int NR = 16 * MT;
     constexpr int RW = CHW / 8;                    // rows of the chunk per wave (8 waves)
@@ -57,15 +65,14 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
         if (cbase >= D) break;
         const int wbase = cbase + w * RW;                                   // wave-uniform: 8 waves x RW rows
         const bool wave_in = wbase < D;
-        // ---- every global load of this chunk in one batch ----
-        double m[NST];
-        {
-            const double* mp = M + (size_t)((wave_in ? wbase : 0) + ks) * ldm + j;
-#pragma unroll
-            for (int s = 0; s < NST; ++s) m[s] = mp[(size_t)(4 * s) * ldm];
-        }
+        // ---- every global load of this chunk in one batch: the left-operand chunk FIRST (it comes from L2 / the
+        // Infinity Cache and has to pass through LDS and a barrier), the HBM stream of M behind it.  vmcnt counts in
+        // issue order, so the staging below waits only for the A loads and MFMA step s only for m[0..s]: the LDS
+        // staging and the first MFMA steps overlap the tail of the M stream (measured with the in-kernel timeline,
+        // scripts/timeline2.py: the load phase and the MFMA phase used to be strictly serial).
         v2d ga[UPT];
         v2d gs[UPT];
+        unsigned okbits = 0;
 #pragma unroll
         for (int q = 0; q < UPT; ++q) {
             const int u = q * 512 + tid;
@@ -76,19 +83,29 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
             ga[q] = *reinterpret_cast<const v2d*>(A + (size_t)(grow < nrows ? grow : nrows - 1) * lda +
                                                   (col < D ? col : 0));
             if (HAS_SHIFT) gs[q] = *reinterpret_cast<const v2d*>(shift + (col < D ? col : 0));
-            if (!ok) ga[q] = HAS_SHIFT ? gs[q] : (v2d){0.0, 0.0};          // contributes alpha*(x-x) = 0
+            okbits |= (ok ? 1u : 0u) << q;     // the out-of-range select is applied at staging time: no use of a
+        }                                      // loaded value may sit in front of the M stream's issue
+        __builtin_amdgcn_sched_barrier(0);
+        double m[NST];
+        {
+            const double* mp = M + (size_t)((wave_in ? wbase : 0) + ks) * ldm + j;
+#pragma unroll
+            for (int s = 0; s < NST; ++s) m[s] = mp[(size_t)(4 * s) * ldm];
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (ch > 0) __syncthreads();       // previous chunk's MFMA reads of As are done
 #pragma unroll
         for (int q = 0; q < UPT; ++q) {
             const int u = q * 512 + tid;
             const int row = u / U16, c16 = u % U16;
             v2d v = ga[q];
+            if (!((okbits >> q) & 1u)) v = HAS_SHIFT ? gs[q] : (v2d){0.0, 0.0};   // contributes alpha*(x-x) = 0
             if (HAS_SHIFT) { v.x -= gs[q].x; v.y -= gs[q].y; }
             v.x *= alpha; v.y *= alpha;
             *reinterpret_cast<v2d*>(&As[row * LDG + 2 * c16]) = v;
         }
         __syncthreads();
+        PSTAMP(1);                         // left operand staged (the M stream may still be in flight)
         if (wave_in) {
             const double* ap = As + c * LDG + RW * w + ks;
             double av[MT][NST];                     // operands to registers first: no LDS round trip per MFMA step
@@ -106,6 +123,7 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
 
     // cross-wave reduction through LDS (fixed order => deterministic), red[w][row][17], w = 0..7
     __syncthreads();
+    PSTAMP(2);
     double* red = As;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -122,6 +140,8 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
             Pp[((size_t)blockIdx.y * nrows + row) * ncols + blockIdx.x * 16 + cc] = s;
         }
     }
+    if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PSTAMP(3); }
+#undef PSTAMP
 }
 
 // =====================================================================================
@@ -134,7 +154,9 @@ __global__ __launch_bounds__(NT) void k_gsm_scalars_fast(int D, int B, int KC, c
                                                          int ldx, const double* __restrict__ G, int ldg,
                                                          const double* __restrict__ mu0,
                                                          const double* __restrict__ Pp,
-                                                         double* __restrict__ rec, int ldrec) {
+                                                         double* __restrict__ rec, int ldrec,
+                                                         unsigned long long* __restrict__ stamps) {
+    if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8] = __builtin_amdgcn_s_memrealtime();
     constexpr int NW = NT / 64;
     __shared__ double lds[2 * NW];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -164,6 +186,7 @@ __global__ __launch_bounds__(NT) void k_gsm_scalars_fast(int D, int B, int KC, c
             p1 += dd[e] * gv[e];
         }
     }
+    if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime();
     p0 = wave_sum(p0);
     p1 = wave_sum(p1);
     const int w = tid >> 6;
@@ -193,6 +216,10 @@ __global__ __launch_bounds__(NT) void k_gsm_scalars_fast(int D, int B, int KC, c
             rb[D + i] = dd[e] + dmu;
             rb[2 * D + i] = dmu;
         }
+    }
+    if (stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -375,10 +402,10 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
 // ---- launch helpers ------------------------------------------------------------------------
 void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int nrows, const double* A,
                              int lda, const double* shift, double alpha, const double* M, int ldm, double* Pp,
-                             int chunks_per_wg, int ncols) {
+                             int chunks_per_wg, int ncols, unsigned long long* stamps) {
 #define PF(MTV, HS, CW)                                                                                          \
     GSMVI_LAUNCH((k_panel_fast<MTV, HS, CW>), grid, dim3(512), 0, st, ev, D, nrows, A, lda, shift, alpha, M, ldm, \
-                 Pp, chunks_per_wg, ncols)
+                 Pp, chunks_per_wg, ncols, stamps)
     if (shift) {
         if (MT == 1) PF(1, true, 256); else if (MT == 2) PF(2, true, 256); else PF(4, true, 128);
     } else {
@@ -393,12 +420,12 @@ int gsmvi_panel_fast_chunk(int MT) { return MT == 4 ? 128 : 256; }
 // returns false when (D, KC) has no instantiation.  nt = threads per sample-workgroup (tuning knob scalars_nt)
 bool gsmvi_launch_gsm_scalars_fast(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, const double* X, int ldx,
                                    const double* G, int ldg, const double* mu0, const double* Pp, double* rec,
-                                   int ldrec, int nt) {
+                                   int ldrec, int nt, unsigned long long* stamps) {
     if (nt != 256 && nt != 512 && nt != 1024) nt = 512;   // 512 measured best at D=1024 (fewer waves to reduce)
     const int ept = (D + nt - 1) / nt;
 #define SF(E, K, N)                                                                                              \
     GSMVI_LAUNCH((k_gsm_scalars_fast<E, K, N>), dim3(B), dim3(N), 0, st, ev, D, B, KC, X, ldx, G, ldg, mu0, Pp, rec, \
-                 ldrec)
+                 ldrec, stamps)
 #define SFK(E, N) do { if (kct == 1) SF(E, 1, N); else if (kct == 2) SF(E, 2, N); else if (kct == 4) SF(E, 4, N); else SF(E, 8, N); } while (0)
 #define SFE(N) do { if (e == 1) SFK(1, N); else if (e == 2) SFK(2, N); else if (e == 4) SFK(4, N); else SFK(8, N); } while (0)
     if (KC > 8 || ept > 8) return false;
