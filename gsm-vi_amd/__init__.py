@@ -4,7 +4,8 @@ Mirrors the reference's public surface for the hot path (reference file:line):
     GSM, gsm_update                              gsmvi/gsm.py:31-133, gsmvi/gsm_numpy.py:27-129
     BaM, bam_update, bam_lowrank_update,
     Regularizers                                 gsmvi/bam.py:31-274
-    KLMonitor (diagnostics callback, host side)  gsmvi/monitors.py:43-125
+    KLMonitor (diagnostics callback, host side),
+    DeviceKLMonitor (same protocol, on the GPU)  gsmvi/monitors.py:43-125
     lbfgs_init, ADVI (initialiser and the ELBO
     baseline of the examples; off the hot path)  gsmvi/initializers.py:5-17, gsmvi/advi.py:8-112
 All GSM / BaM numerics run in hand-written HIP kernels (libgsmvi_hip.so, C ABI in include/gsmvi_hip.h)
@@ -17,7 +18,7 @@ from .engine import HipEngine, get_engine                            # noqa: F40
 from .gsm import GSM, gsm_update                                     # noqa: F401
 from .bam import BaM, bam_update, bam_lowrank_update, Regularizers   # noqa: F401
 from .targets import GaussianTarget, device_score, score_from_logp   # noqa: F401
-from .monitors import KLMonitor                                      # noqa: F401
+from .monitors import KLMonitor, DeviceKLMonitor                     # noqa: F401
 from .initializers import lbfgs_init                                 # noqa: F401
 from .advi import ADVI                                               # noqa: F401
 

@@ -36,6 +36,8 @@ _SIGS = {
                                             C.c_int, _c_dp, _c_dp, C.c_int, _c_dp, C.c_int]),
     "gsmvi_gsm_apply_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, _c_dp,
                                       C.c_int, _c_dp, _c_dp, C.c_int]),
+    "gsmvi_gsm_update_sharded_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int,
+                                               _c_dp, C.c_int, _c_dp, _c_dp, C.c_int, _c_dp, _c_dp, _c_dp, C.c_int]),
     "gsmvi_gsm_rows_stage_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp,
                                            C.c_int, _c_dp, C.c_int]),
     "gsmvi_gsm_records_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int,
@@ -57,6 +59,9 @@ _SIGS = {
     "gsmvi_gaussian_score_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp,
                                            _c_dp, C.c_int, _c_dp, C.c_int]),
     "gsmvi_potrf_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int, _c_dp]),
+    "gsmvi_gram_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int]),
+    "gsmvi_whiten_rows_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int,
+                                        _c_dp, _c_dp, C.c_int, _c_dp]),
     "gsmvi_sample_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, _c_dp,
                                    C.c_int, _c_dp, C.c_int]),
     "gsmvi_commit_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, C.c_int, _c_dp, _c_dp,

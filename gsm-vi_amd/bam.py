@@ -73,7 +73,7 @@ class BaM:
 
     def fit(self, key, regf, mean=None, cov=None, batch_size=2, niter=5000, nprint=10, verbose=True,
             check_goodness=True, monitor=None, retries=10, jitter=1e-6, *, sampler="cholesky", rng="numpy",
-            as_torch=False, forced_samples=None, shard=False, group=None):
+            as_torch=False, forced_samples=None, shard=False, group=None, check_update_flag=False):
         """gsmvi/bam.py:140-216.  Kept: niter+1 iterations (:178); nprint clamp (:177); reg = regf(i)
         per attempt (:196); jitter on the diagonal and symmetrisation (:198-199, done in-kernel);
         retry on any exception up to ``retries`` then re-raise (:189-206); Cholesky accept/revert of
@@ -82,7 +82,17 @@ class BaM:
         one private RandomState(key) stream (JAX is not a dependency).
         ``shard=True`` (BASELINE config 4: B=128 sharded 16 per GPU; one process per GPU, torch.distributed
         initialised): every rank draws the same Z, samples and scores only its batch_size/world rows, the
-        (x_b, g_b) rows are all-gathered (dist.sharded_bam_update) and every replica runs the identical update."""
+        (x_b, g_b) rows are all-gathered (dist.sharded_bam_update) and every replica runs the identical update.
+        Retries when sharded are COLLECTIVE: after the score call every rank contributes a fail bit to one
+        all-reduce (MAX), so either all ranks retry -- redrawing and advancing the regulariser together -- or
+        none does; a rank never re-enters a collective its peers have left (one host synchronisation per
+        iteration, small beside the Cholesky of the accept test).
+        Deviation (documented): the reference retries on ANY exception inside sample/score/update (:189-206),
+        which on its JAX path includes numerical failures surfacing as exceptions from the host callbacks.  The
+        device update never raises: a numerical failure poisons the outputs with NaN, the Cholesky accept test
+        rejects them and the iteration is a revert (counted in ``n_reverts``), not a retry.
+        ``check_update_flag=True`` restores the retry: the update's device flag is read every iteration (one host
+        synchronisation) and a non-zero flag raises FloatingPointError into the retry loop."""
         eng = self._engine if self._engine is not None else get_engine()
         D, B = self.D, int(batch_size)
         mean_t = eng.zeros(D) if mean is None else eng.clone(mean).reshape(D)
@@ -97,6 +107,7 @@ class BaM:
         mon_native = bool(getattr(monitor, "device_native", False)) if monitor is not None else False
 
         lo, hi = 0, B
+        world = 1
         if shard:
             assert sampler == "cholesky" and forced_samples is None, "shard=True needs the replicated z-stream"
             from .dist import sharded_bam_update, shard_bounds
@@ -145,7 +156,20 @@ class BaM:
                         else:
                             Z = eng.normal_from_host(rs.standard_normal((B, D)))
                         X = eng.sample(Z[lo:hi], mean_t, R, out=Xbuf)     # only this rank's rows when sharded
-                    vs = self.lp_g(X) if native else eng.asarray(self.lp_g(eng.to_numpy(X)))
+                    err = None
+                    try:
+                        vs = self.lp_g(X) if native else eng.asarray(self.lp_g(eng.to_numpy(X)))
+                    except Exception as e_score:            # noqa: BLE001
+                        if not (shard and world > 1):
+                            raise
+                        err, vs = e_score, None
+                    if shard and world > 1:                 # agree on failure BEFORE anybody enters the gather
+                        import torch
+                        fb = torch.tensor([0 if err is None else 1], dtype=torch.int32,
+                                          device=X.device if _is_torch(X) else "cpu")
+                        _dist.all_reduce(fb, op=_dist.ReduceOp.MAX, group=group)
+                        if int(fb.item()) != 0:             # nobody has called regf yet (bam.py:194-196 order)
+                            raise err if err is not None else RuntimeError("score evaluation failed on another rank")
                     nevals += B
                     reg = regf(i)
                     if shard:
@@ -153,6 +177,8 @@ class BaM:
                                            out=(mean_new, cov_new), flag=uflag)
                     else:
                         eng.bam_update(X, vs, mean_t, cov_t, reg, jitter, out=(mean_new, cov_new), flag=uflag)
+                    if check_update_flag and eng.read_flag(uflag) != 0:
+                        raise FloatingPointError("BaM update flagged a numerical failure (device flag != 0)")
                     break
                 except Exception as e:                      # noqa: BLE001 -- reference behaviour
                     if j < retries:

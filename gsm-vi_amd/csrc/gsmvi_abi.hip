@@ -50,6 +50,9 @@ bool gsmvi_launch_gsm_cov_fused(hipStream_t st, hipEvent_t* ev, int D, int B, co
                                 double* S, int lds, double* mu_out, int flags, unsigned long long* stamps);
 int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                      int* info_dev);
+int gsmvi_gram_impl(hipStream_t st, int D, const double* F, int ldf, double* C, int ldc);
+int gsmvi_whiten_impl(hipStream_t st, int D, int nrows, const double* R, int ldr, const double* X, int ldx,
+                      const double* mu, double* Z, int ldz, double* logdiag);
 int gsmvi_factor_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X,
                       int ldx, const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double* mu,
                       double* F, int ldf, int* info_dev, int* n_reverts_dev);
@@ -557,6 +560,21 @@ int gsmvi_potrf_f64(gsmvi_ctx* ctx, void* stream, int D, const double* S, int ld
         return GSMVI_ERR_WORKSPACE;
     }
     return gsmvi_potrf_impl(ctx, reinterpret_cast<hipStream_t>(stream), D, S, lds, R, ldr, info_dev);
+}
+
+int gsmvi_gram_f64(gsmvi_ctx* ctx, void* stream, int D, const double* F, int ldf, double* C, int ldc) {
+    BAD_ARG(!ctx || !F || !C, "NULL argument");
+    BAD_ARG(D <= 0 || ldf < D || ldc < D, "bad size");
+    BAD_ARG(F == C, "output must not alias the input");
+    return gsmvi_gram_impl(reinterpret_cast<hipStream_t>(stream), D, F, ldf, C, ldc);
+}
+
+int gsmvi_whiten_rows_f64(gsmvi_ctx* ctx, void* stream, int D, int nrows, const double* R, int ldr, const double* X,
+                          int ldx, const double* mu, double* Z, int ldz, double* logdiag_dev) {
+    BAD_ARG(!ctx || !R || !X || !Z, "NULL argument");
+    BAD_ARG(D <= 0 || nrows <= 0 || ldr < D || ldx < D || ldz < D, "bad size");
+    BAD_ARG(D > 8192, "D > 8192 not supported (the residual row lives in LDS)");
+    return gsmvi_whiten_impl(reinterpret_cast<hipStream_t>(stream), D, nrows, R, ldr, X, ldx, mu, Z, ldz, logdiag_dev);
 }
 
 int gsmvi_gsm_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* Z, int ldz, const double* X,

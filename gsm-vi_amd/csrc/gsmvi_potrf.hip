@@ -173,6 +173,135 @@ __global__ __launch_bounds__(256) void k_potrf_finish(int D, const double* __res
     }
 }
 
+// =====================================================================================
+// C = F^T F (Gram matrix of the columns; the covariance a square factor represents).  One workgroup per 64x64 tile
+// of the upper triangle, K = D in chunks of 64 staged transposed in LDS exactly like k_potrf_trailing; the mirror
+// tile is written from the same accumulators, so C is exactly symmetric.  Used once per fit (return value of the
+// factor-form fit) and per monitor checkpoint: not on the per-iteration path.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_gram(int D, const double* __restrict__ F, int ldf, double* __restrict__ C,
+                                              int ldc) {
+    constexpr int RS = 66;
+    __shared__ double FA[64 * RS];
+    __shared__ double FB[64 * RS];
+    const int ntr = (D + 63) >> 6;
+    int ti, tj;
+    {
+        const int idx = blockIdx.x;
+        int t = 0, base = 0;
+        while (base + (ntr - t) <= idx) { base += ntr - t; ++t; }
+        ti = t;
+        tj = t + (idx - base);
+    }
+    const int I0 = ti * 64, J0 = tj * 64;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+    const int wr = w >> 1, wc = w & 1;
+    v4d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < D; k0 += 64) {
+        double va[16], vb[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int p = (tid >> 6) + 4 * q, i = tid & 63;
+            const int gi = I0 + i, gj = J0 + i, gk = k0 + p;
+            va[q] = (gi < D && gk < D) ? F[(size_t)gk * ldf + gi] : 0.0;
+            vb[q] = (gj < D && gk < D) ? F[(size_t)gk * ldf + gj] : 0.0;
+        }
+        if (k0 > 0) __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int p = (tid >> 6) + 4 * q, i = tid & 63;
+            FA[i * RS + p] = va[q];
+            FB[i * RS + p] = vb[q];
+        }
+        __syncthreads();
+        const double* a0p = FA + (32 * wr + c) * RS + ks;
+        const double* a1p = a0p + 16 * RS;
+        const double* b0p = FB + (32 * wc + c) * RS + ks;
+        const double* b1p = b0p + 16 * RS;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const double a0 = a0p[4 * s], a1 = a1p[4 * s], b0 = b0p[4 * s], b1 = b1p[4 * s];
+            acc[0][0] = GSMVI_MFMA_F64(a0, b0, acc[0][0]);
+            acc[0][1] = GSMVI_MFMA_F64(a0, b1, acc[0][1]);
+            acc[1][0] = GSMVI_MFMA_F64(a1, b0, acc[1][0]);
+            acc[1][1] = GSMVI_MFMA_F64(a1, b1, acc[1][1]);
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = I0 + 32 * wr + 16 * rt + ks + 4 * r;
+                const int col = J0 + 32 * wc + 16 * ct + c;
+                if (row < D && col < D) {
+                    if (col >= row) C[(size_t)row * ldc + col] = acc[rt][ct][r];
+                    if (col > row) C[(size_t)col * ldc + row] = acc[rt][ct][r];
+                }
+            }
+}
+
+// =====================================================================================
+// Z = (X - mu) R^-1 for a few rows (R upper triangular, R^T R = Sigma): the whitened residuals whose squared
+// norm gives log N(x; mu, Sigma) together with sum_i log R_ii (the monitor's log q, gsmvi/monitors.py:107).
+// One workgroup per row, residual row in LDS, column-by-column forward substitution (row j of R is contiguous).
+// Also returns logdiag[0] = sum_i log R_ii from workgroup 0.  O(D^2) per row with D barriers: monitor use only.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_whiten_rows(int D, const double* __restrict__ R, int ldr,
+                                                     const double* __restrict__ X, int ldx,
+                                                     const double* __restrict__ mu, double* __restrict__ Z, int ldz,
+                                                     double* __restrict__ logdiag) {
+    extern __shared__ double rres[];             // D doubles
+    __shared__ double red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < D; i += 256) rres[i] = X[(size_t)b * ldx + i] - (mu ? mu[i] : 0.0);
+    __syncthreads();
+    for (int j = 0; j < D; ++j) {
+        const double zj = rres[j] / R[(size_t)j * ldr + j];      // every thread: same value
+        __syncthreads();                                          // all reads of rres[j] done before it is rewritten
+        if (tid == 0) rres[j] = zj;
+        for (int t = j + 1 + tid; t < D; t += 256) rres[t] -= zj * R[(size_t)j * ldr + t];
+        __syncthreads();
+    }
+    for (int i = tid; i < D; i += 256) Z[(size_t)b * ldz + i] = rres[i];
+    if (b == 0 && logdiag) {
+        double s = 0.0;
+        for (int i = tid; i < D; i += 256) s += log(R[(size_t)i * ldr + i]);
+        s = wave_sum(s);
+        if ((tid & 63) == 0) red[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) logdiag[0] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+int gsmvi_gram_impl(hipStream_t st, int D, const double* F, int ldf, double* C, int ldc) {
+    const int ntr = (D + 63) / 64;
+    hipLaunchKernelGGL(k_gram, dim3(ntr * (ntr + 1) / 2), dim3(256), 0, st, D, F, ldf, C, ldc);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        gsmvi_set_error("gram launch failed: %s%s", hipGetErrorString(e), "");
+        return GSMVI_ERR_HIP;
+    }
+    return GSMVI_OK;
+}
+
+int gsmvi_whiten_impl(hipStream_t st, int D, int nrows, const double* R, int ldr, const double* X, int ldx,
+                      const double* mu, double* Z, int ldz, double* logdiag) {
+    hipLaunchKernelGGL(k_whiten_rows, dim3(nrows), dim3(256), (size_t)D * sizeof(double), st, D, R, ldr, X, ldx, mu, Z,
+                       ldz, logdiag);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        gsmvi_set_error("whiten launch failed: %s%s", hipGetErrorString(e), "");
+        return GSMVI_ERR_HIP;
+    }
+    return GSMVI_OK;
+}
+
 int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                      int* info_dev) {
     double* diag = ctx->pp;                       // nblk x 64 x 64 doubles; the panel-partial slab is idle here

@@ -18,6 +18,18 @@ def _as_torch(a):
     return a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
 
 
+def _all_gather(t_all, t_loc, group=None):
+    """all_gather_into_tensor on the group's backend.  RCCL ("nccl") takes device tensors as they are; a gloo group
+    (CPU rendezvous, used by the tests that run two HIP-backed ranks on ONE GPU -- RCCL refuses two ranks per
+    device) gets the device tensors staged through the host."""
+    if t_all.is_cuda and dist.get_backend(group) == "gloo":
+        h_all = torch.empty(t_all.shape, dtype=t_all.dtype)
+        dist.all_gather_into_tensor(h_all, t_loc.contiguous().cpu(), group=group)
+        t_all.copy_(h_all)
+        return
+    dist.all_gather_into_tensor(t_all, t_loc.contiguous(), group=group)
+
+
 def shard_bounds(B, world, rank):
     """Contiguous equal shards; B must be divisible by the world size (one fixed-size all-gather)."""
     assert B % world == 0, f"batch size {B} must be divisible by the number of ranks {world}"
@@ -39,7 +51,7 @@ def sharded_gsm_update(eng, X_local, G_local, mu0, S0, group=None, rec_all=None,
         if rec_all is None:
             rec_all = eng.empty(Bl * world, L)
         t_all, t_loc = _as_torch(rec_all), _as_torch(rec_local)
-        dist.all_gather_into_tensor(t_all, t_loc.contiguous(), group=group)
+        _all_gather(t_all, t_loc, group)
         rec = rec_all if isinstance(rec_all, torch.Tensor) else t_all.numpy()
     return eng.gsm_apply(rec, mu0, S0, out=out)
 
@@ -60,7 +72,7 @@ def sharded_gsm_factor_update(eng, Z, X_local, G_local, mu0, F0, lo, group=None,
     else:
         if rec_all is None:
             rec_all = eng.empty(Bl * world, rec_local.shape[1])
-        dist.all_gather_into_tensor(_as_torch(rec_all), _as_torch(rec_local).contiguous(), group=group)
+        _all_gather(_as_torch(rec_all), _as_torch(rec_local), group)
         rec = rec_all if isinstance(rec_all, torch.Tensor) else _as_torch(rec_all).numpy()
     return eng.gsm_factor_apply(Z, rec, mu0, F0, out=out, flag=flag, n_reverts=n_reverts)
 
@@ -93,7 +105,7 @@ def row_sharded_gsm_update(eng, X, G, mu0, S0_rows, group=None, out=None):
         send = eng.zeros(B, per)
         send[:, :hi - lo] = SGc
         recv = eng.empty(world * B, per)
-        dist.all_gather_into_tensor(_as_torch(recv), _as_torch(send), group=group)
+        _all_gather(_as_torch(recv), _as_torch(send), group)
         SG = eng.empty(B, D)
         for p in range(world):
             plo, phi = row_bounds(D, world, p)
@@ -116,7 +128,7 @@ def sharded_bam_update(eng, X_local, G_local, mu0, S0, reg, jitter=0.0, group=No
     packed[:, :D] = X_local
     packed[:, D:] = G_local
     allp = eng.empty(Bl * world, 2 * D)
-    dist.all_gather_into_tensor(_as_torch(allp), _as_torch(packed), group=group)
+    _all_gather(_as_torch(allp), _as_torch(packed), group)
     if not isinstance(allp, torch.Tensor):
         allp = _as_torch(allp).numpy()
     return eng.bam_update(allp[:, :D], allp[:, D:], mu0, S0, reg, jitter, out=out, flag=flag)

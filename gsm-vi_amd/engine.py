@@ -275,10 +275,32 @@ class HipEngine:
             C.c_void_p(n_reverts.data_ptr()) if n_reverts is not None else None))
         return mu, F, flag
 
-    def gram(self, F):
-        """cov = F^T F for the monitor / return value of the factor-form fit (one library GEMM per call;
-        not on the per-iteration path)."""
-        return (F.t() @ F).contiguous()
+    def gram(self, F, out=None):
+        """cov = F^T F (gsmvi_gram_f64): the covariance a square factor represents -- return value of the
+        factor-form fit and what its monitor sees (gsm_numpy.py:129).  Not on the per-iteration path."""
+        D = F.shape[0]
+        assert F.shape == (D, D)
+        self._ensure(D, max(self._max_B, 1))
+        Cm = self.empty(D, D) if out is None else out
+        pf, ldf = self._mat(F, "F")
+        pc, ldc = self._mat(Cm, "C")
+        _lib.check("gsmvi_gram_f64", self.lib.gsmvi_gram_f64(self._ctx, self._stream(), D, pf, ldf, pc, ldc))
+        return Cm
+
+    def whiten_rows(self, X, mu, R):
+        """(Z, logdiag): Z = (X - mu) R^-1 for the rows of X and logdiag = sum_i log R_ii (a 1-element device
+        tensor); log N(x_b; mu, R^T R) = -|z_b|^2/2 - logdiag - D/2 log(2 pi)   [gsmvi/monitors.py:107]."""
+        n, D = X.shape
+        self._ensure(D, max(self._max_B, 1))
+        Z = self.empty(n, D)
+        ld = self.empty(1)
+        px, ldx = self._mat(X, "X")
+        pr, ldr = self._mat(R, "R")
+        pz, ldz = self._mat(Z, "Z")
+        _lib.check("gsmvi_whiten_rows_f64", self.lib.gsmvi_whiten_rows_f64(
+            self._ctx, self._stream(), D, n, pr, ldr, px, ldx, self._vec(mu, "mu") if mu is not None else None,
+            pz, ldz, C.c_void_p(ld.data_ptr())))
+        return Z, ld
 
     def set_profiling(self, on):
         self._ensure(max(self._max_D, 1), max(self._max_B, 1))

@@ -98,3 +98,72 @@ class KLMonitor:
         self.nevals.append(self.offset_evals + nevals)
         self.offset_evals = self.nevals[-1]
         return key
+
+
+@dataclass
+class DeviceKLMonitor(KLMonitor):
+    """KLMonitor (gsmvi/monitors.py:43-125) whose sampling and Gaussian log density run on the GPU.
+
+    ``device_native = True`` makes the fit drivers hand over the device tensors ``[mean, cov]`` (no D x D copy to
+    the host, no numpy SVD sampler).  Per call: ``gsmvi_potrf_f64`` (upper factor R of cov), q-samples
+    x = mean + z R from the counter-based draw stream (``gsmvi_randn_f64`` + ``gsmvi_sample_f64``), log q from the
+    whitened residuals and the factor's diagonal (``gsmvi_whiten_rows_f64``); only ``batch_size_kl`` x D numbers
+    come back to the host for the final sums.  ``lp`` gets the device tensor first and numpy if it refuses it.
+    Same fields, bookkeeping and NaN-on-exception behaviour as the reference's monitor.
+    """
+    engine: object = None
+    device_native = True
+    _CHUNK = 128
+
+    def _sum_lp(self, lp, x_dev, eng):
+        try:
+            return float(np.sum(_to_numpy(lp(x_dev))))
+        except (TypeError, AttributeError, RuntimeError, ValueError):
+            return float(np.sum(_to_numpy(lp(eng.to_numpy(x_dev)))))
+
+    def _sum_logq(self, eng, X, mu, R):
+        Z, logdiag = eng.whiten_rows(X, mu, R)
+        Zh = eng.to_numpy(Z)
+        n, D = Zh.shape
+        return -0.5 * float(np.sum(Zh * Zh)) - n * float(eng.to_numpy(logdiag).reshape(-1)[0]) \
+            - 0.5 * n * D * np.log(2 * np.pi)
+
+    def __call__(self, i, params, lp, key, nevals=1):
+        if self.engine is None:
+            from .engine import get_engine
+            self.engine = get_engine()
+        eng = self.engine
+        if self._rs is None:
+            self._seed = int(np.asarray(_to_numpy(key)).flatten()[-1]) % (2 ** 32)
+            self._rs = np.random.RandomState(self._seed)
+            self._calls = 0
+        try:
+            mu, cov = eng.asarray(params[0]), eng.asarray(params[1])
+            D, n = int(mu.shape[0]), int(self.batch_size_kl)
+            R, flag = eng.potrf(cov)
+            if eng.read_flag(flag) != 0:
+                raise ValueError("covariance is not positive definite")
+            Z = eng.normal(n, D, self._seed ^ 0x5DEECE66D, self._calls)
+            self._calls += 1
+            acc = 0.0
+            for s0 in range(0, n, self._CHUNK):              # bounded engine workspace whatever batch_size_kl is
+                X = eng.sample(Z[s0:s0 + self._CHUNK], mu, R)
+                acc += self._sum_logq(eng, X, mu, R) - self._sum_lp(lp, X, eng)
+            self.rkl.append(acc / n)
+            if self.ref_samples is not None:
+                ref = _to_numpy(self.ref_samples)
+                idx = self._rs.permutation(ref.shape[0])[:n]
+                acc = 0.0
+                for s0 in range(0, len(idx), self._CHUNK):
+                    Xp = eng.asarray(np.ascontiguousarray(ref[idx[s0:s0 + self._CHUNK]]))
+                    acc += self._sum_lp(lp, Xp, eng) - self._sum_logq(eng, Xp, mu, R)
+                self.fkl.append(acc / len(idx))
+            else:
+                self.fkl.append(float("nan"))
+        except Exception as e:                                         # noqa: BLE001 (reference behaviour)
+            print(f"Exception occured in monitor : {e}.\nAppending NaN")
+            self.rkl.append(float("nan"))
+            self.fkl.append(float("nan"))
+        self.nevals.append(self.offset_evals + nevals)
+        self.offset_evals = self.nevals[-1]
+        return key

@@ -98,6 +98,21 @@ int gsmvi_gsm_apply_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
                         const double* S0, int lds0, double* mu, double* S, int lds);
 
 /*
+ * Batch-sharded update over RCCL in ONE call (one process per GPU; SURVEY 8(b): "RCCL-sharded variants taking an
+ * ncclComm_t"): local stage on this rank's B_local samples -> ncclAllGather of the records (B_local *
+ * gsmvi_gsm_record_len(D) doubles per rank, in place in rec_all) on `stream` -> combined rank-2B update applied by
+ * every replica; replicas end bit-identical.  nccl_comm is an ncclComm_t (passed as void* so that this header does
+ * not need rccl.h) created by the caller with the RCCL library loaded in its process; this library resolves
+ * ncclAllGather from that instance at first use and does not link RCCL itself.  rec_all: caller-owned device buffer
+ * of (B_local * nranks) x gsmvi_gsm_record_len(D) doubles.  B_local * nranks must fit the context's max_B.
+ * Python callers use torch.distributed instead (gsm-vi_amd/dist.py::sharded_gsm_update), same two stage calls.
+ */
+int gsmvi_gsm_update_sharded_f64(gsmvi_ctx* ctx, void* stream, void* nccl_comm, int D, int B_local,
+                                 const double* X_local, int ldx, const double* G_local, int ldg,
+                                 const double* mu0, const double* S0, int lds0, double* rec_all,
+                                 double* mu, double* S, int lds);
+
+/*
  * The same update with the covariance sharded by ROW BLOCKS (the decomposition that divides
  * the HBM-bound passes by the number of GPUs).  A rank owns rows [row0, row0 + nrows) of S0 as an
  * nrows x D row-major block; X, G, mu0 are replicated.
@@ -181,6 +196,23 @@ int gsmvi_gaussian_score_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
  */
 int gsmvi_potrf_f64(gsmvi_ctx* ctx, void* stream, int D, const double* S, int lds,
                     double* R, int ldr, int* info_dev);
+
+/*
+ * C = F^T F for a square factor F (D x D, any square factor with F^T F = cov): the covariance a factor-form fit
+ * returns and hands to its monitor (the reference's fit returns cov, gsm_numpy.py:129; monitors.py:99).  C is
+ * exactly symmetric.  Once per fit / per monitor checkpoint, not per iteration.
+ */
+int gsmvi_gram_f64(gsmvi_ctx* ctx, void* stream, int D, const double* F, int ldf, double* C, int ldc);
+
+/*
+ * Whitened residuals Z = (X - 1 mu^T) R^-1 for nrows rows of X and an upper Cholesky factor R (R^T R = cov), and
+ * (if logdiag_dev != NULL) logdiag_dev[0] = sum_i log R_ii.  Together they give the row-wise Gaussian log density
+ * log N(x; mu, cov) = -1/2 |z|^2 - sum_i log R_ii - D/2 log(2 pi) that the reference's KLMonitor evaluates through
+ * numpyro's MultivariateNormal.log_prob (gsmvi/monitors.py:107-113).  mu may be NULL (zero mean).  Monitor use
+ * only (D dependent steps per row).  D <= 8192.
+ */
+int gsmvi_whiten_rows_f64(gsmvi_ctx* ctx, void* stream, int D, int nrows, const double* R, int ldr,
+                          const double* X, int ldx, const double* mu, double* Z, int ldz, double* logdiag_dev);
 
 /*
  * Draw samples X = 1 mu^T + Z R for whitened draws Z (B x D) and an upper factor R (R^T R = cov).

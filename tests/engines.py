@@ -167,8 +167,16 @@ class OracleEngine:
             return out[0], out[1], flag
         return mu, Fn, flag
 
-    def gram(self, F):
+    def gram(self, F, out=None):
+        if out is not None:
+            out[...] = F.T @ F
+            return out
         return F.T @ F
+
+    def whiten_rows(self, X, mu, R):
+        r = X - (mu[None, :] if mu is not None else 0.0)
+        Z = np.linalg.solve(R.T, r.T).T                 # z R = r
+        return Z, np.array([np.sum(np.log(np.diag(R)))])
 
     def gaussian_score(self, X, m, P, out=None):
         return orc.gaussian_score(X, m, P)

@@ -107,6 +107,48 @@ def test_plain_c_program_drives_the_abi(tmp_path, D, B):
     assert rel_err(R.T @ R, S_o) < 1e-11 and np.array_equal(np.tril(R, -1), np.zeros_like(R))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,B", [(1024, 32), (100, 6)])
+def test_rccl_taking_entry_point_from_plain_c(tmp_path, D, B):
+    """tests/abi_c/rccl_sharded.c: a C program owning the ncclComm_t drives gsmvi_gsm_update_sharded_f64 (local
+    stage -> ncclAllGather on the caller's stream -> combined update).  One rank per visible GPU, at most 2 (the GPU
+    box has one; RCCL does not allow two ranks on one device)."""
+    import subprocess
+    import numpy as np
+    import torch
+    from oracle import gsm_oracle as orc
+    from gsmvi_amd import _lib
+    from conftest import rel_err
+    libdir = os.path.dirname(_lib.library_path())
+    exe = str(tmp_path / "rccl_sharded")
+    cmd = ["gcc", "-std=gnu99", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "abi_c", "rccl_sharded.c"), "-o", exe, "-L" + libdir, "-lgsmvi_hip",
+           "-L/opt/rocm/lib", "-lamdhip64", "-lrccl", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    st = orc.make_update_state(D, B, 7)
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(np.array([D, B], dtype=np.int32).tobytes())
+        for k in ("samples", "vs", "mu0", "S0"):
+            f.write(np.ascontiguousarray(st[k], dtype=np.float64).tobytes())
+    nranks = min(2, torch.cuda.device_count())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+    procs = [subprocess.Popen([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(nranks), str(r),
+                               str(tmp_path / "nccl.id")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=env) for r in range(nranks)]
+    outs = [q.communicate(timeout=300) for q in procs]
+    for q, (so, se) in zip(procs, outs):
+        assert q.returncode == 0, (q.returncode, se[-2000:])
+    mu_o, S_o = orc.gsm_update_faithful(st["samples"], st["vs"], st["mu0"], st["S0"])
+    res = []
+    for r in range(nranks):
+        out = np.frombuffer(open(str(tmp_path / "out.bin") + f".{r}", "rb").read(), dtype=np.float64)
+        mu, S = out[:D], out[D:].reshape(D, D)
+        assert rel_err(mu, mu_o) < 1e-11 and rel_err(S, S_o) < 1e-11
+        res.append(out)
+    assert all(np.array_equal(res[0], x) for x in res)          # replicas bit-identical
+
+
 def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     """Argument validation of the entry points added for the sharded factor path and the draw stream runs before any
     HIP call, so it is checkable on a machine without a GPU."""
@@ -117,3 +159,6 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.gsmvi_gsm_factor_apply_f64(None, None, 8, 2, None, 8, None, 24, None, None, 8, None, None, 8, None, None) == 1
     assert lib.gsmvi_randn_f64(None, None, 1, 0, 16, None, None) == 1
     assert lib.gsmvi_gsm_record_len(5) == 16 and lib.gsmvi_gsm_record_len(4) == 12
+    assert lib.gsmvi_gsm_update_sharded_f64(None, None, None, 8, 2, None, 8, None, 8, None, None, 8, None, None, None, 8) == 1
+    assert lib.gsmvi_gram_f64(None, None, 8, None, 8, None, 8) == 1
+    assert lib.gsmvi_whiten_rows_f64(None, None, 8, 2, None, 8, None, 8, None, None, 8, None) == 1

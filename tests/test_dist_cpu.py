@@ -157,3 +157,55 @@ def test_world1_no_process_group():
     mu, S = sharded_gsm_update(OracleEngine(), st["samples"], st["vs"], st["mu0"], st["S0"])
     mu_o, S_o = orc.gsm_update_batched(st["samples"], st["vs"], st["mu0"], st["S0"])
     assert np.abs(mu - mu_o).max() < 1e-12 and np.abs(S - S_o).max() < 1e-12
+
+
+def _retry_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import gsm_oracle as orc
+        from engines import OracleEngine
+        from gsmvi_amd.bam import BaM, Regularizers
+        D, B = 6, 4
+        m, cov_t, P = orc.make_gaussian_target(D, 4)
+        calls = [0]
+
+        def lp_g(x):
+            calls[0] += 1
+            if rank == 1 and calls[0] in (3, 4, 9):          # fails on ONE rank only, twice in a row once
+                raise FloatingPointError("synthetic score failure")
+            return orc.gaussian_score(x, m, P)
+
+        reg = Regularizers()
+        mean, cov = BaM(D, None, lp_g, engine=OracleEngine()).fit(5, reg.linear(10.0), niter=12, batch_size=B,
+                                                                   verbose=False, shard=True, retries=3)
+        t = torch.from_numpy(np.concatenate([mean, cov.ravel(), [float(reg.counter), float(calls[0])]]))
+        gathered = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        same = all(torch.equal(gathered[0], x) for x in gathered)
+        q.put((rank, same, reg.counter, calls[0], bool(np.isfinite(cov).all())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_bam_retries_are_collective():
+    """A score failure on ONE rank must make EVERY rank retry (fail bit all-reduced before the gather): replicas
+    stay identical, the regulariser advances equally, nobody re-enters a collective alone (round-1 advice)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_retry_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, counter, ncalls, finite in res:
+        assert same and finite, (rank, same, finite)
+        assert counter == 13                # niter + 1 successful updates; failed attempts never reached regf
+        assert ncalls == 13 + 3             # three collective retries: every rank redrew and re-scored

@@ -1,0 +1,123 @@
+"""The real multi-rank code path as far as ONE GPU allows: two processes (gloo rendezvous; RCCL refuses two ranks on one
+device) each with its own HipEngine on cuda:0 run gsm-vi_amd/dist.py's sharded updates and sharded fits through the
+HIP stage kernels.  What this does not cover -- the RCCL transport itself at world size > 1 -- is exercised at world
+size 1 by tests/test_gpu_bench.py and tests/test_abi.py::test_rccl_taking_entry_point_from_plain_c."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    try:
+        import gsmvi_amd
+        from oracle import gsm_oracle as orc
+        from oracle import bam_oracle as borc
+        from gsmvi_amd.dist import (sharded_gsm_update, sharded_gsm_factor_update, sharded_bam_update,
+                                    row_sharded_gsm_update, shard_bounds, row_bounds)
+        torch.cuda.set_device(0)
+        eng = gsmvi_amd.HipEngine(0)                       # one context per process
+        err = 0.0
+        for D, B in ((1024, 32), (96, 8)):
+            st = orc.make_update_state(D, B, 3)
+            X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
+            lo, hi = shard_bounds(B, world, rank)
+            mu, S = sharded_gsm_update(eng, X[lo:hi], G[lo:hi], mu0, S0)
+            mu_o, S_o = orc.gsm_update_batched(st["samples"], st["vs"], st["mu0"], st["S0"])
+            err = max(err, np.abs(mu.cpu().numpy() - mu_o).max() / np.abs(mu_o).max(),
+                      np.abs(S.cpu().numpy() - S_o).max() / np.abs(S_o).max())
+            # replicas bit-identical
+            t = torch.cat([mu, S.reshape(-1)]).cpu()
+            gathered = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(gathered, t)
+            out[f"same_{D}"] = all(torch.equal(gathered[0], x) for x in gathered)
+            # factor form
+            F0 = eng.asarray(st["L"].T.copy())
+            Z = eng.asarray(st["Z"])
+            mu_f, F_f, flag = sharded_gsm_factor_update(eng, Z, X[lo:hi], G[lo:hi], mu0, F0, lo)
+            Fn = F_f.cpu().numpy()
+            err = max(err, np.abs(Fn.T @ Fn - S_o).max() / np.abs(S_o).max())
+            assert eng.read_flag(flag) == 0
+            # row-block sharded covariance
+            rlo, rhi = row_bounds(D, world, rank)
+            mu_r, S_r = row_sharded_gsm_update(eng, X, G, mu0, S0[rlo:rhi].contiguous())
+            err = max(err, np.abs(S_r.cpu().numpy() - S_o[rlo:rhi]).max() / np.abs(S_o).max(),
+                      np.abs(mu_r.cpu().numpy() - mu_o).max() / np.abs(mu_o).max())
+            # BaM (all-gather of the samples and scores)
+            mu_b, S_b, _ = sharded_bam_update(eng, X[lo:hi], G[lo:hi], mu0, S0, 2.0)
+            mu_bo, S_bo = borc.bam_lowrank_update_exact(st["samples"], st["vs"], st["mu0"], st["S0"], 2.0)
+            err = max(err, np.abs(S_b.cpu().numpy() - 0.5 * (S_bo + S_bo.T)).max() / np.abs(S_bo).max())
+        out["err"] = err
+        # sharded FITS through the HIP kernels: same key on every rank, lp_g sees only the local rows
+        D, B = 24, 8
+        m, cov_t, P = orc.make_gaussian_target(D, 4)
+        tgt = gsmvi_amd.GaussianTarget(m, precision=P, engine=eng)
+        rows = []
+
+        def lp_g(x):
+            rows.append(x.shape[0])
+            return tgt.lp_g(x)
+        lp_g.device_native = True
+        g = gsmvi_amd.GSM(D, None, lp_g, engine=eng)
+        mean_s, cov_s = g.fit(7, niter=40, batch_size=B, verbose=False, shard=True, rng="device")
+        out["method"] = g.method_used
+        mean_1, cov_1 = gsmvi_amd.GSM(D, None, tgt.lp_g, engine=eng).fit(7, niter=40, batch_size=B, verbose=False,
+                                                                         rng="device")
+        out["rows"] = sorted(set(rows))
+        out["fit_err"] = max(np.abs(mean_s - mean_1).max(), np.abs(cov_s - cov_1).max())
+        mean_d, cov_d = gsmvi_amd.GSM(D, None, lp_g, engine=eng).fit(7, niter=15, batch_size=B, verbose=False,
+                                                                     shard=True, method="dense")
+        mean_d1, cov_d1 = gsmvi_amd.GSM(D, None, tgt.lp_g, engine=eng).fit(7, niter=15, batch_size=B, verbose=False,
+                                                                           method="dense")
+        out["fit_err_dense"] = max(np.abs(mean_d - mean_d1).max(), np.abs(cov_d - cov_d1).max())
+        reg = gsmvi_amd.Regularizers()
+        bm, bc = gsmvi_amd.BaM(D, None, lp_g, engine=eng).fit(7, reg.constant(1.0), niter=15, batch_size=B,
+                                                              verbose=False, shard=True)
+        reg1 = gsmvi_amd.Regularizers()
+        bm1, bc1 = gsmvi_amd.BaM(D, None, tgt.lp_g, engine=eng).fit(7, reg1.constant(1.0), niter=15, batch_size=B,
+                                                                    verbose=False)
+        out["bam_err"] = max(np.abs(bm - bm1).max(), np.abs(bc - bc1).max())
+        out["ok"] = True
+    except Exception as e:                                   # noqa: BLE001
+        import traceback
+        out["ok"] = False
+        out["exc"] = traceback.format_exc()
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_two_hip_backed_ranks_share_one_gpu():
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    for r in range(world):
+        o = res[r]
+        assert o["ok"], o.get("exc")
+        assert o["err"] < 1e-10, o["err"]
+        assert o["same_1024"] and o["same_96"]
+        assert o["method"] == "factor" and o["rows"] == [4]
+        assert o["fit_err"] < 1e-9 and o["fit_err_dense"] < 1e-9 and o["bam_err"] < 1e-8, o

@@ -47,3 +47,25 @@ def test_monitor_protocol_and_bookkeeping():
     bad = KLMonitor(batch_size_kl=4, checkpoint=1)
     bad(0, [np.zeros(2), -np.eye(2)], lp, 5, nevals=3)                   # non-PD covariance -> NaN, not an exception
     assert np.isnan(bad.rkl[0]) and np.isnan(bad.fkl[0]) and bad.nevals == [3]
+
+
+def test_device_monitor_host_logic_with_the_oracle_engine():
+    """DeviceKLMonitor's bookkeeping and estimators with the oracle-backed test engine (the HIP kernels behind
+    potrf / randn / sample / whiten_rows are checked on the GPU in tests/test_gpu_aux.py)."""
+    from gsmvi_amd.monitors import DeviceKLMonitor
+    D = 4
+    m, cov_t, P = orc.make_gaussian_target(D, 1)
+    mq, Sq = m + 0.3, cov_t * 1.5 + 0.1 * np.eye(D)
+    lp = lambda x: mvn_logpdf(np.asarray(x), m, cov_t)
+    ref = np.random.RandomState(3).multivariate_normal(m, cov_t, size=200000)
+    mon = DeviceKLMonitor(batch_size_kl=100000, checkpoint=1, offset_evals=2, ref_samples=ref, engine=OracleEngine())
+    mon(0, [mq, Sq], lp, 11, nevals=5)
+    assert abs(mon.rkl[0] - _kl_gauss(mq, Sq, m, cov_t)) < 3e-2
+    assert abs(mon.fkl[0] - _kl_gauss(m, cov_t, mq, Sq)) < 3e-2
+    assert mon.nevals == [7] and mon.offset_evals == 7
+    mon(1, [mq, -np.eye(D)], lp, 11, nevals=1)
+    assert np.isnan(mon.rkl[1]) and mon.nevals == [7, 8]
+    gsm = GSM(D, lp, lambda x: orc.gaussian_score(x, m, P), engine=OracleEngine())
+    mon2 = DeviceKLMonitor(batch_size_kl=32, checkpoint=50, engine=OracleEngine())
+    gsm.fit(99, niter=200, batch_size=2, verbose=False, monitor=mon2)
+    assert len(mon2.rkl) == 6 and abs(mon2.rkl[-1]) < 1e-6 and np.isnan(mon2.fkl[-1])
