@@ -166,6 +166,12 @@ int gsmvi_create(gsmvi_ctx** out, int device, int max_D, int max_B) {
     int st = gsmvi_device_count(&n);
     if (st != GSMVI_OK) return st;
     BAD_ARG(device < 0 || device >= n, "device index out of range");
+    int prev_device = 0;                                   // the caller's current device is restored on return
+    HIP_TRY(hipGetDevice(&prev_device));
+    struct device_guard {
+        int prev;
+        ~device_guard() { (void)hipSetDevice(prev); }
+    } guard{prev_device};
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -204,6 +210,12 @@ int gsmvi_create(gsmvi_ctx** out, int device, int max_D, int max_B) {
 
 int gsmvi_destroy(gsmvi_ctx* ctx) {
     if (!ctx) return GSMVI_OK;
+    int prev_device = 0;
+    (void)hipGetDevice(&prev_device);
+    struct device_guard {
+        int prev;
+        ~device_guard() { (void)hipSetDevice(prev); }
+    } guard{prev_device};
     (void)hipSetDevice(ctx->device);
     for (int k = 0; k < 8; ++k)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
@@ -224,6 +236,7 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "panel_kc")) ctx->tune_panel_kc = value;
     else if (!strcmp(name, "update_sb")) ctx->tune_update_sb = value;
     else if (!strcmp(name, "no_fast")) ctx->tune_no_fast = value;
+    else if (!strcmp(name, "small_v")) ctx->tune_small_v = value;
     else if (!strcmp(name, "fused")) ctx->tune_fused = value;
     else if (!strcmp(name, "fused_flags")) ctx->tune_fused_flags = value;
     else if (!strcmp(name, "bam_host")) ctx->tune_bam_host = value;

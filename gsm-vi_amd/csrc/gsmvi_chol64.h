@@ -131,8 +131,20 @@ __device__ __forceinline__ void chol64_lds_s(double* T, double* rinv, int nb, in
 // (Measured on MI355X, one workgroup: 12 us against 23 us for the blocked variant above; taking four pivots per
 // barrier with a redundant 4 x 4 factor in every thread was no faster -- the chain is instruction latency:
 // dropping the barrier altogether only takes 11.2 -> 9.1 us, the Newton steps cost nothing.)
-template <int STR>
-__device__ __forceinline__ void chol64_rows_s(double* T, double* rinv, int nb, int* sh_fail) {
+// SEMIDEF = true factors a positive SEMI-definite matrix (a Gram matrix G = Rt Rt^T whose rows may be linearly
+// dependent).  A pivot that is not above the rounding floor of its row, d_p <= GSMVI_DEP_TOL * G_pp with G_pp the ORIGINAL
+// diagonal entry (diag0[p] = |row p|^2; the test is scale-free per row, so rows of tiny norm are fine), cannot be told
+// from zero in fp64 -- and a tiny POSITIVE noise pivot is as harmful as a negative one (1 / sqrt(1e-34) in the factor:
+// scripts/dbg_dep128.py).  Such a row is DEPENDENT: its row of the factor and its diagonal come out as ZERO, rinv[p] = 0,
+// the pivot is skipped in the elimination, no failure is reported (R^T R still equals G to rounding).  allow_dep
+// (block-uniform) = false turns the dependent verdict into a FAILURE instead: the callers pass "every diagonal entry is
+// of moderate size" (max_p G_pp < 2^32), because dropping a row perturbs the represented matrix by up to
+// sqrt(GSMVI_DEP_TOL) |row| -- harmless for whitened draws (|z|^2 ~ D), meaningless for |z| ~ 1e10 (fixture G4).
+// NaN / inf pivots fail in every mode.  SEMIDEF = false is the plain positive-definite test (pivot <= 0 fails).
+#define GSMVI_DEP_TOL 1.4210854715202004e-14        /* 64 eps */
+template <int STR, bool SEMIDEF = false>
+__device__ __forceinline__ void chol64_rows_s(double* T, double* rinv, int nb, int* sh_fail, bool allow_dep = true,
+                                              const double* diag0 = nullptr) {
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     double s[4][4];
 #pragma unroll
@@ -156,8 +168,10 @@ __device__ __forceinline__ void chol64_rows_s(double* T, double* rinv, int nb, i
             for (int a = pb; a < 4; ++a) ri[a] = row[ty + 16 * a];
 #pragma unroll
             for (int b = pb; b < 4; ++b) rj[b] = row[tx + 16 * b];
-            const bool ok = d > 0.0 && d < 1.7976931348623157e308;   // false for NaN, <= 0, inf
-            if (!ok && fail == 0) fail = p + 1;
+            const double floor_p = SEMIDEF ? GSMVI_DEP_TOL * diag0[p] : 0.0;
+            const bool ok = d > floor_p && d < 1.7976931348623157e308;   // false for NaN, inf, pivots at the rounding floor
+            const bool dep = SEMIDEF && allow_dep && d <= floor_p && d > -1.7976931348623157e308;   // dependent row
+            if (!ok && !dep && fail == 0) fail = p + 1;
             const double dd = ok ? d : 1.0;
             double y = __builtin_amdgcn_rcp(dd);
             y = __builtin_fma(y, __builtin_fma(-dd, y, 1.0), y);
@@ -188,7 +202,7 @@ __device__ __forceinline__ void chol64_rows_s(double* T, double* rinv, int nb, i
     CHOL_STAMP(2);
     if (tid < 64) {
         const double d = T[tid * STR + tid];
-        const bool ok = d > 0.0 && d < 1.7976931348623157e308;
+        const bool ok = d > (SEMIDEF ? GSMVI_DEP_TOL * diag0[tid] : 0.0) && d < 1.7976931348623157e308;
         const double dd = ok ? d : 1.0;
         double y = __builtin_amdgcn_rsq(dd);
         y = y * (1.5 - 0.5 * dd * y * y);
@@ -205,7 +219,7 @@ __device__ __forceinline__ void chol64_rows_s(double* T, double* rinv, int nb, i
             if (j >= i) {
                 const double r = rinv[i];
                 const double v = T[i * STR + j];
-                T[i * STR + j] = (j == i) ? (r != 0.0 ? v * r : 1.0) : v * r;
+                T[i * STR + j] = (j == i) ? (r != 0.0 ? v * r : (SEMIDEF ? 0.0 : 1.0)) : v * r;
             }
         }
     __syncthreads();

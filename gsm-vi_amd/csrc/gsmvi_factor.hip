@@ -300,17 +300,31 @@ __global__ __launch_bounds__(256) void k_gsmf_small_a(int n, int B, const double
 // R12 = R11^-T A12 one column per quad of lanes (as k_potrf_panel), A22 -= R12^T R12 with a 4 x 4 register
 // tile per thread, chol64 of A22.  *info = 1-based index of the first bad pivot (0 = ok); R gets the upper
 // factor with a zero strictly-lower triangle.
+template <bool SEMIDEF>
 __global__ __launch_bounds__(256) void k_chol128(int n, const double* __restrict__ A, double* __restrict__ R,
                                                  int* __restrict__ info) {
     constexpr int MS = 130;
     __shared__ __attribute__((aligned(16))) double M[128 * MS];
-    __shared__ double rinv[128];
+    __shared__ double rinv[128], diag0[128];
     __shared__ int sh_fail[2];
     const int tid = threadIdx.x;
     load_upper128(M, A, n);
     if (tid < 128) rinv[tid] = 1.0;
     __syncthreads();
-    chol64_rows_s<MS>(M, rinv, 64, &sh_fail[0]);
+    bool moderate = true;
+    if (SEMIDEF) {                                  // original diagonal (= |row|^2 of [Z; U]) and the magnitude guard
+        if (tid == 0) sh_fail[1] = 1;
+        __syncthreads();
+        if (tid < 128) {
+            const double d = M[tid * MS + tid];
+            diag0[tid] = d;
+            if (!(d < 4294967296.0)) sh_fail[1] = 0;
+        }
+        __syncthreads();
+        moderate = sh_fail[1] != 0;
+        __syncthreads();
+    }
+    chol64_rows_s<MS, SEMIDEF>(M, rinv, 64, &sh_fail[0], moderate, diag0);
     {
         const int colq = tid >> 2, q = tid & 3;
         double x[16];
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(256) void k_chol128(int n, const double* __restrict
             }
     }
     __syncthreads();
-    chol64_rows_s<MS>(M + 64 * MS + 64, rinv + 64, n - 64, &sh_fail[1]);
+    chol64_rows_s<MS, SEMIDEF>(M + 64 * MS + 64, rinv + 64, n - 64, &sh_fail[1], moderate, diag0 + 64);
     for (int e = tid; e < n * n; e += 256) {
         const int i = e / n, j = e % n;
         R[e] = (j >= i) ? M[i * MS + j] : 0.0;
@@ -527,6 +541,21 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const do
     }
 }
 
+// Captures the original diagonal of the 64 x 64 LDS matrix M (row stride STR) into diag0[64] and returns (block-uniform)
+// whether every entry is below 2^32 and not NaN -- the two inputs of the semi-definite rule of chol64_rows_s.
+template <int STR>
+__device__ __forceinline__ bool diag_capture(const double* M, double* diag0, int* sh_flag) {
+    if (threadIdx.x == 0) *sh_flag = 1;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const double d = M[threadIdx.x * STR + threadIdx.x];
+        diag0[threadIdx.x] = d;
+        if (!(d < 4294967296.0)) *sh_flag = 0;
+    }
+    __syncthreads();
+    return *sh_flag != 0;
+}
+
 // ---- everything small in ONE workgroup (n = 2B <= 64) ---------------------------------------------------
 //   Gamma -> Rg (Cholesky) -> A' = I + Rg J Rg^T -> T (Cholesky, the PD test) -> K = Rg^-1 (T - I) Rg^-T.
 // All matrices live in LDS ([64][TS], padded with the identity beyond n).  W = Rg^-T comes from one n-column
@@ -544,7 +573,7 @@ __global__ __launch_bounds__(256) void k_gsmf_small(int n, int B, const double* 
     __shared__ __attribute__((aligned(16))) double Rs[64 * TS];
     __shared__ __attribute__((aligned(16))) double Ts[64 * TS];
     __shared__ __attribute__((aligned(16))) double Ps[64 * TS];
-    __shared__ double rinv_g[64], rinv_t[64];
+    __shared__ double rinv_g[64], rinv_t[64], diag0[64];
     __shared__ int fail_g, fail_t;
     const int tid = threadIdx.x;
     {
@@ -563,12 +592,14 @@ __global__ __launch_bounds__(256) void k_gsmf_small(int n, int B, const double* 
     if (tid < 64) rinv_g[tid] = rinv_t[tid] = 1.0;
     __syncthreads();
     SMALL_STAMP(1);
-    chol64_lds(Rs, rinv_g, n, &fail_g);                // Rs = Rg (upper); strictly-lower part is stale
+    const bool moderate = diag_capture<TS>(Rs, diag0, &fail_t);
+    chol64_rows_s<TS, true>(Rs, rinv_g, n, &fail_g, moderate, diag0);   // Rs = Rg (upper, semi-definite rule); strictly-lower part is stale
     SMALL_STAMP(2);
     for (int e = tid; e < 64 * 64; e += 256) {         // zero the strictly-lower part so Rs is a clean upper factor
         const int i = e >> 6, q = e & 63;
         if (q < i) Rs[i * TS + q] = 0.0;
     }
+    if (tid < 64 && rinv_g[tid] == 0.0) rinv_g[tid] = 1.0;      // dependent rows: unit diagonal in the substitution
     __syncthreads();
     // A' = I + (Rg J) Rg^T into Ts;  (Rg J)[i][k] = (1/B)(k < B ? Rg[i][B+k] : Rg[i][k-B] - Rg[i][k]), on the
     // MFMA pipe.  Wave w owns the 16-column block j = w and computes the blocks (i, j), i <= j (A' is
@@ -699,6 +730,219 @@ __global__ __launch_bounds__(256) void k_gsmf_small(int n, int B, const double* 
 #undef SMALL_STAMP
 }
 
+// ---- the same chain with EIGHT waves (n = 2B <= 64): waves 0-3 are the Cholesky team, waves 4-7 helpers ---------------
+// What changes against k_gsmf_small (kept as the reference, tuning knob small_v=1):
+//   * W = Rg^-T (64 substitution steps, 7.4 us, no barrier of its own) runs on the helper waves WHILE the Cholesky
+//     team factors A' (14.4 us, one barrier per pivot): the helpers execute one barrier per substitution step so that
+//     the workgroup barrier counts match (s_barrier counts waves, not program counters), and stay ahead of the
+//     factorisation (115 ns per step against 190 ns per pivot);
+//   * the three MFMA phases (A', P = (T - I) W, K = W^T P) use all eight waves (two per SIMD: the fp64 MFMA pipe
+//     delivers 46 TF chip-wide there against 34 TF with one), row blocks split by parity between the two teams.
+template <int STR>
+__device__ __forceinline__ void chol64_helper_idle(int nb) {
+#pragma unroll 1
+    for (int pb = 0; pb < 4; ++pb) {
+        if (16 * pb >= nb) break;
+#pragma unroll 1
+        for (int pq = 0; pq < 16; ++pq) __syncthreads();
+    }
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+}
+
+// NP forward-substitution steps of W = Rg^-T for the calling quad's column, ONE workgroup barrier per step (matches the
+// per-pivot barrier of chol64_rows_s running on the other four waves)
+template <int NP>
+__device__ __forceinline__ void wsubst_steps(double (&x)[16], int sq, const double* Rs, const double* rinv_g) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        __syncthreads();
+        const int pr = p >> 2, pq = p & 3;
+        const double mine = x[pr] * rinv_g[p];
+        if (sq == pq) x[pr] = mine;
+        const double xp = __shfl(mine, (threadIdx.x & 60) | pq, 64);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (4 * r + 3 > p) {
+                const int t = sq + 4 * r;
+                const double rv = Rs[p * TS + t];
+                x[r] -= (t > p) ? rv * xp : 0.0;
+            }
+    }
+}
+
+__global__ __launch_bounds__(512) void k_gsmf_small8(int n, int B, const double* __restrict__ Gam,
+                                                     double* __restrict__ Kmat, int* __restrict__ bad_out,
+                                                     unsigned long long* __restrict__ stamps) {
+#define SMALL_STAMP(k)                                                                      \
+    do {                                                                                    \
+        if (stamps && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memrealtime();        \
+    } while (0)
+    SMALL_STAMP(0);
+    __shared__ __attribute__((aligned(16))) double Rs[64 * TS];
+    __shared__ __attribute__((aligned(16))) double Ts[64 * TS];
+    __shared__ __attribute__((aligned(16))) double Ps[64 * TS];
+    __shared__ double rinv_g[64], rinv_t[64], diag0[64];
+    __shared__ int fail_g, fail_t;
+    const int tid = threadIdx.x;
+    const bool team = tid < 256;                       // Cholesky team (waves 0-3) / helpers (waves 4-7)
+    {
+        double g[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = tid + 512 * k, i = e >> 6, q = e & 63;
+            g[k] = Gam[(size_t)(i < n ? i : n - 1) * n + (q < n ? q : n - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = tid + 512 * k, i = e >> 6, q = e & 63;
+            Rs[i * TS + q] = (i < n && q < n && q >= i) ? g[k] : (i == q ? 1.0 : 0.0);
+        }
+    }
+    if (tid < 64) rinv_g[tid] = rinv_t[tid] = 1.0;
+    __syncthreads();
+    SMALL_STAMP(1);
+    // Gamma = Rt Rt^T is only positive SEMI-definite when rows of [Z; U] are linearly dependent (an isotropic state on
+    // an isotropic target makes every u_b - a_b z_b parallel to mu - m; the exact fixed point makes U = -Z ...): the
+    // dependent rows drop out of Rg (zero row, zero diagonal) and get a unit diagonal in the substitution below, which
+    // leaves C^T C = I + Rt^T J Rt intact (factor form).
+    const bool moderate = diag_capture<TS>(Rs, diag0, &fail_t);
+    if (team) chol64_rows_s<TS, true>(Rs, rinv_g, n, &fail_g, moderate, diag0);
+    else chol64_helper_idle<TS>(n);
+    SMALL_STAMP(2);
+    for (int e = tid; e < 64 * 64; e += 512) {
+        const int i = e >> 6, q = e & 63;
+        if (q < i) Rs[i * TS + q] = 0.0;
+    }
+    if (tid < 64 && rinv_g[tid] == 0.0) rinv_g[tid] = 1.0;
+    __syncthreads();
+    const int w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
+    const int wj = w & 3, g2 = w >> 2;                 // column block of this wave, team index (row-block parity)
+    {   // A' = I + (Rg J) Rg^T into Ts (see k_gsmf_small); wave (wj, g2) computes the blocks (ib, wj), ib <= wj, ib % 2 == g2
+        const double invB = 1.0 / (double)B;
+        v4d acc[2];
+        acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+        const double* brow = Rs + (16 * wj + cc) * TS;
+        for (int kb = wj; kb < 4; ++kb) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int k = 16 * kb + 4 * s4 + ks;
+                const int k1 = (k < B) ? B + k : k - B;
+                const double bv = brow[k];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int ib = 2 * h + g2;
+                    if (ib <= wj) {
+                        const double* arow = Rs + (16 * ib + cc) * TS;
+                        const double a1 = arow[k1 < 64 ? k1 : 63], a0 = arow[k];
+                        const double a = (k < n) ? ((k < B) ? a1 : a1 - a0) : 0.0;
+                        acc[h] = GSMVI_MFMA_F64(a, bv, acc[h]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ib = 2 * h + g2;
+            if (ib <= wj) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * ib + ks + 4 * r, j = 16 * wj + cc;
+                    const double v = (i == j ? 1.0 : 0.0) + ((i < n && j < n) ? acc[h][r] * invB : 0.0);
+                    Ts[i * TS + j] = v;
+                    if (ib != wj) Ts[j * TS + i] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    SMALL_STAMP(3);
+    // ---- Cholesky of A' (the positive-definite test) || W = Rg^-T by substitution ----
+    double x[16];
+    const int sc = (tid & 255) >> 2, sq = tid & 3;     // helper thread: column sc of W, quad lane sq (rows sq, sq+4, ..)
+    if (team) {
+        chol64_rows_s<TS>(Ts, rinv_t, n, &fail_t);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = (sq + 4 * r == sc) ? 1.0 : 0.0;
+        // one instantiation per pivot count of the factorisation running beside us (16 ceil(n/16)): the loop must be
+        // fully unrolled (x[] is indexed with compile-time constants) and free of per-step branches (a predicated
+        // body measured 22 us for the pair at n = 64 against 16.6 us straight-line); rows beyond n are identity.
+        switch ((n + 15) >> 4) {
+            case 1: wsubst_steps<16>(x, sq, Rs, rinv_g); break;
+            case 2: wsubst_steps<32>(x, sq, Rs, rinv_g); break;
+            case 3: wsubst_steps<48>(x, sq, Rs, rinv_g); break;
+            default: wsubst_steps<64>(x, sq, Rs, rinv_g); break;
+        }
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+    }
+    SMALL_STAMP(4);
+    const int bad = (fail_g != 0) || (fail_t != 0);
+    if (tid == 0) *bad_out = bad;
+    if (bad) return;                                   // block-uniform
+    // every helper has finished reading Rg (its 64 steps precede the last three barriers): Rs <- W, Ts <- T - I
+    if (!team) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Rs[(sq + 4 * r) * TS + sc] = x[r];
+    } else {
+        for (int e = tid; e < 64 * 64; e += 256) {
+            const int i = e >> 6, j = e & 63;
+            if (j < i) Ts[i * TS + j] = 0.0;
+            else if (j == i) Ts[i * TS + j] -= 1.0;
+        }
+    }
+    __syncthreads();
+    SMALL_STAMP(5);
+    {
+        // P[i][j] = sum_k (T - I)[i][k] W[k][j]: k-blocks max(i, j)..3; wave (wj, g2): column block wj, row blocks ib % 2 == g2
+        v4d acc[2];
+        acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int kb = wj; kb < 4; ++kb) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int k = 16 * kb + 4 * s4 + ks;
+                const double bv = Rs[k * TS + 16 * wj + cc];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int ib = 2 * h + g2;
+                    if (ib <= kb) acc[h] = GSMVI_MFMA_F64(Ts[(16 * ib + cc) * TS + k], bv, acc[h]);
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ps[(16 * (2 * h + g2) + ks + 4 * r) * TS + 16 * wj + cc] = acc[h][r];
+        __syncthreads();
+        // K[i][j] = sum_k W[k][i] P[k][j]: k-blocks i..3
+        acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int k = 16 * kb + 4 * s4 + ks;
+                const double bv = Ps[k * TS + 16 * wj + cc];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int ib = 2 * h + g2;
+                    if (ib <= kb) acc[h] = GSMVI_MFMA_F64(Rs[k * TS + 16 * ib + cc], bv, acc[h]);
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * (2 * h + g2) + ks + 4 * r, j = 16 * wj + cc;
+                if (i < n && j < n) Kmat[(size_t)i * n + j] = acc[h][r];
+            }
+    }
+    SMALL_STAMP(6);
+#undef SMALL_STAMP
+}
+
 // ---- K = Rg^-1 (T - I) Rg^-T = W^T (T - I) W, W = Rg^-T, for 64 < n <= 128 -----------------------------------
 // k_gsmf_kmat_big: W by forward substitution.  One workgroup handles 16 columns, SIXTEEN lanes per column (lane
 // q of the group owns rows q, q+16, ..); Rg is resident in LDS ([128][130], padded with the identity beyond
@@ -708,7 +952,10 @@ __device__ __forceinline__ void kmat_load_lds(double* Mt, double* rinv, const do
                                               bool want_rinv) {
     load_upper128(Mt, src, n);
     __syncthreads();
-    if (want_rinv && threadIdx.x < 128) rinv[threadIdx.x] = 1.0 / Mt[threadIdx.x * 130 + threadIdx.x];
+    if (want_rinv && threadIdx.x < 128) {              // a zero diagonal marks a dependent row of [Z; U]: unit pivot
+        const double dg = Mt[threadIdx.x * 130 + threadIdx.x];
+        rinv[threadIdx.x] = dg == 0.0 ? 1.0 : 1.0 / dg;
+    }
     __syncthreads();
 }
 
@@ -951,7 +1198,7 @@ int gsmvi_factor_apply_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const 
 static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
                        double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev) {
     const int n = 2 * B, nq = n;                   // n is even
-    // workspace carve: ctx->sg holds 6*rmax*max_D doubles (rmax = 2B+8)
+    // workspace carve: ctx->sg holds 4*rmax*max_D doubles (rmax = 2B+8; ws_sizes in gsmvi_abi.hip)
     double* Rt = ctx->sg;                          // n x D   [Z; U]
     double* Tm = Rt + (size_t)n * D;               // n x D   [X - mu; U Fm]
     double* Fs = Tm + (size_t)n * D;               // n x D
@@ -969,8 +1216,12 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
     if (n <= 64) {
         // everything small in one workgroup, then Fs = K Tm as one skinny GEMM (K = n)
         double* Kmat = Rg;                         // reuse the n x n slot
-        hipLaunchKernelGGL(k_gsmf_small, dim3(1), dim3(256), 0, st, n, B, Gam, Kmat, info_dev,
-                           (ctx->tune_cov_dbg & 128) ? reinterpret_cast<unsigned long long*>(ctx->pp) : nullptr);
+        if (ctx->tune_small_v == 1)
+            hipLaunchKernelGGL(k_gsmf_small, dim3(1), dim3(256), 0, st, n, B, Gam, Kmat, info_dev,
+                               (ctx->tune_cov_dbg & 128) ? reinterpret_cast<unsigned long long*>(ctx->pp) : nullptr);
+        else
+            hipLaunchKernelGGL(k_gsmf_small8, dim3(1), dim3(512), 0, st, n, B, Gam, Kmat, info_dev,
+                               (ctx->tune_cov_dbg & 128) ? reinterpret_cast<unsigned long long*>(ctx->pp) : nullptr);
         if ((rc = chk("k_gsmf_small"))) return rc;
         // inner dimension n <= one chunk, so there is exactly one slab: it is written straight into Fs
         if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, Fs, &kc2)))
@@ -985,9 +1236,9 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         double* Kmat = Gam;                        // Gamma is dead once Rg exists
         double* Wm = Ap;                           // A' is dead once T exists
         double* Pm = Tt + (size_t)n * n;           // fifth n x n slot of the small-matrix workspace
-        hipLaunchKernelGGL(k_chol128, dim3(1), dim3(256), 0, st, n, Gam, Rg, info_g);
+        hipLaunchKernelGGL(k_chol128<true>, dim3(1), dim3(256), 0, st, n, Gam, Rg, info_g);   // Gram matrix: semi-definite rule
         hipLaunchKernelGGL(k_gsmf_small_a, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, st, n, B, Rg, info_g, Ap);
-        hipLaunchKernelGGL(k_chol128, dim3(1), dim3(256), 0, st, n, Ap, Tt, info_t);
+        hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(256), 0, st, n, Ap, Tt, info_t);
         if ((rc = chk("k_chol128"))) return rc;
         hipLaunchKernelGGL(k_gsmf_kmat_big, dim3((n + 15) / 16), dim3(256), 0, st, n, Rg, Wm, info_g, info_t,
                            info_dev);

@@ -64,7 +64,6 @@ extern "C" int gsmvi_randn_f64(gsmvi_ctx* ctx, void* stream, uint64_t seed, uint
         return GSMVI_ERR_BAD_ARG;
     }
     if (n == 0) return GSMVI_OK;
-    (void)hipSetDevice(ctx->device);
     const long long pairs = (n + 1) / 2;
     hipLaunchKernelGGL(k_randn, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        (unsigned long long)seed, (unsigned long long)call, (long long)n, out, raw);

@@ -379,7 +379,9 @@ _ENGINES = {}
 
 
 def get_engine(device=None):
-    """Process-wide engine per device (created on first use; raises if the library or GPU is missing)."""
+    """Process-wide engine per device (created on first use; raises if the library or GPU is missing).
+    ONE context = ONE workspace: calls through the shared engine must not run concurrently on two streams or two
+    threads; give every extra stream / thread its own ``HipEngine(device)`` (as bench.py --in-flight does)."""
     _lib.load_library()
     _require_gpu()
     idx = torch.cuda.current_device() if device is None else (device if isinstance(device, int)

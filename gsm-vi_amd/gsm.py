@@ -25,7 +25,24 @@ def gsm_update(samples, vs, mu0, S0, engine=None):
     assert len(vs.shape) == 2
     eng = engine if engine is not None else get_engine()
     want_torch = _is_torch(samples)
-    mu, S = eng.gsm_update(eng.asarray(samples), eng.asarray(vs), eng.asarray(mu0), eng.asarray(S0))
+    S0d = eng.asarray(S0)
+    # The fast update kernel reads only the upper triangle of S0 (a covariance is symmetric).  This user-facing
+    # one-off call keeps the reference's semantics (S = S0 + mean, gsm_numpy.py:50-53) for ANY S0: a non-symmetric
+    # S0 is routed to the generic kernels, which read all of it.  The fit loops call the engine directly.
+    symmetric = bool((S0d == S0d.T).all()) if _is_torch(S0d) else bool(np.array_equal(S0d, S0d.T))
+    Xd, Gd, m0 = eng.asarray(samples), eng.asarray(vs), eng.asarray(mu0)
+    if symmetric or not hasattr(eng, "set_tuning"):
+        mu, S = eng.gsm_update(Xd, Gd, m0, S0d)
+    else:
+        # row b of the panel stage is g_b^T S0; the reference forms S0 g_b (gsm_numpy.py:7): hand the panel stage
+        # S0^T, and let the generic update kernel read all of S0
+        eng.set_tuning("no_fast", 1)
+        try:
+            S0t = S0d.T.contiguous() if _is_torch(S0d) else np.ascontiguousarray(S0d.T)
+            rec = eng.gsm_local_stage(Xd, Gd, m0, S0t)
+            mu, S = eng.gsm_apply(rec, m0, S0d)
+        finally:
+            eng.set_tuning("no_fast", 0)
     return (mu, S) if want_torch else (eng.to_numpy(mu), eng.to_numpy(S))
 
 
@@ -97,18 +114,20 @@ class GSM:
                     update is a rank-2B correction of F and the positive-definite test is a Cholesky of
                     a 2B x 2B matrix, so no O(D^3) work per iteration.  Same (mean, cov) up to round-off
                     for the same samples; needs 2B <= min(D, 128) and the device sampler.  It converges to
-                    machine precision on Gaussian targets like the dense form (tests/test_gpu_factor.py); the one
-                    case it treats differently is a state that is EXACTLY the fixed point (score == -(x - mean) to
-                    the last bit): the 2B rows [Z; U] are then linearly dependent, their Gram matrix is singular and
-                    the iteration is counted as a revert -- the state is left unchanged, which is also what the
-                    dense update would produce there.
+                    machine precision on Gaussian targets like the dense form (tests/test_gpu_factor.py).
+                    Linearly dependent rows of [Z; U] -- an isotropic state on an isotropic target (every
+                    u_b - a_b z_b is parallel to mean - m), or a state that is EXACTLY the fixed point (U = 0) --
+                    make the 2B x 2B Gram matrix singular; they are handled by a rank-revealing rule (a pivot at the
+                    rounding floor of its row drops the row; csrc/gsmvi_chol64.h, SEMIDEF), agree with the dense
+                    update to 1e-15 (test_factor_update_with_linearly_dependent_rows) and are not reverts.
                     Accept/revert in factor form: Sigma' = F'^T F' is positive semi-definite by construction, so
                     the ROUNDING failures that make the dense Sigma' indefinite (the reference's only source of
                     reverts on finite inputs, gsm_numpy.py:121-125) cannot occur; what the 2B x 2B test rejects
-                    are NaN/inf inputs, rank-deficient [Z; U] (the fixed point above) and updates whose small
-                    matrix is numerically indefinite.  The reference's decisive revert fixture G4
-                    (tests/golden/g4_revert.npz: eigenvalues 1e-14 next to O(1e3) displacements) is ALSO reverted
-                    in factor form (tests/test_gpu_factor.py::test_g4_...), state kept bit for bit.
+                    are NaN/inf inputs, updates whose small matrix is numerically indefinite, and whitened rows
+                    of absurd size (|z|^2 >= 2^32) that are dependent to rounding.  The reference's decisive revert
+                    fixture G4 (tests/golden/g4_revert.npz: eigenvalues 1e-14 next to O(1e3) displacements, |z| ~
+                    1e10) is ALSO reverted in factor form (tests/test_gpu_factor.py::test_g4_...), state kept bit
+                    for bit.
         """
         D_, B_ = self.D, int(batch_size)
         if method == "auto":

@@ -60,6 +60,9 @@ int gsmvi_device_count(int* n);
 /* Workspace bytes a context allocates for problems up to (max_D, max_B). */
 size_t gsmvi_workspace_bytes(int max_D, int max_B);
 /* Creates a context on `device` with workspace for D <= max_D, B <= max_B. */
+/* gsmvi_create / gsmvi_destroy leave the caller's current HIP device as they found it.  The compute entry points
+ * never change the current device either: `stream` must belong to the context's device and that device must be
+ * current when they are called (what torch.cuda.set_device / hipSetDevice in the calling loop guarantees). */
 int gsmvi_create(gsmvi_ctx** out, int device, int max_D, int max_B);
 int gsmvi_destroy(gsmvi_ctx* ctx);
 /* Launch-heuristic knob for experiments: name in {"panel_kc","update_tile", ...}; value<=0 = auto */
@@ -72,6 +75,11 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value);
  *   mu  (D)          new mean           S  (D x D, lds)  new covariance
  * mu = mu0 + mean_b dmu_b ; S = S0 + mean_b (d_b d_b^T - e_b e_b^T), d_b = mu0 - x_b, e_b = d_b + dmu_b.
  * Three kernels: panel product SG = G S0 (fp64 MFMA), per-sample scalars, rank-2B update (fp64 MFMA).
+ * PRECONDITION: S0 is symmetric (a covariance).  For D % 32 == 0 and B in {16, 32, 64} the update kernel reads only
+ * the UPPER triangle of S0 and mirrors the result, so S comes out exactly symmetric; for other shapes the generic
+ * kernel reads all of S0.  A non-symmetric S0 therefore gives shape-dependent results that differ from
+ * gsm_numpy.py:50-53 (S0 + mean); the Python drop-in gsm_update() symmetry-checks host inputs for that reason.
+ * One context per stream: calls on one gsmvi_ctx share its workspace and must not run concurrently.
  */
 int gsmvi_gsm_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
                          const double* X, int ldx, const double* G, int ldg,

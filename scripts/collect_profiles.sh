@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats and, in separate passes, the HBM
 # traffic counters for the bench workload.  Output: gpurun_out/prof_$1/ (copy summaries to profiles/).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -14,6 +14,16 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- 
 # MFMA pipe occupancy (north_star: "MFMA utilisation against gfx950 peak"): busy cycles of the matrix pipe and the
 # fp64 MFMA op count, against the time the GPU was active during the dispatch
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $ARGS --no-graph > $OUT/pmc_mfma.log 2>&1
+# the >= 0.50 HBM-roofline point of the covariance kernel (D=4096, B=32) and the fit-iteration kernel tables
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_d4096 -- python3 $ROOT/bench.py --D 4096 --B 32 --steps 60 --warmup 12 --no-cpu-baseline > $OUT/trace_d4096.log 2>&1
+for cfg in "1024 32 factor" "1024 32 dense" "4096 64 factor" "256 8 factor"; do
+  tag=$(echo $cfg | tr ' ' '_')
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fit_$tag -- python3 $ROOT/scripts/factor_prof.py $cfg > $OUT/fit_$tag.log 2>&1
+  echo "== fit iteration kernels, D B method = $cfg (41 iterations; name, calls, avg ns, % of GPU time)" >> $OUT/fit_iteration_kernels.txt
+  python3 $ROOT/scripts/prof_top.py $OUT/fit_$tag 18 >> $OUT/fit_iteration_kernels.txt 2>&1
+done
+echo "== bench.py --D 4096 --B 32 (kernel-trace stats)" > $OUT/d4096_b32_kernels.txt
+python3 $ROOT/scripts/prof_top.py $OUT/trace_d4096 8 >> $OUT/d4096_b32_kernels.txt 2>&1
 cd $ROOT
 python3 - "$OUT" <<'PY'
 import csv, glob, json, sys, collections
@@ -57,7 +67,11 @@ if cov:
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 420 "
                          "--warmup 42 --no-cpu-baseline --no-graph` (scripts/collect_profiles.sh), D=1024 B=32",
                "units": "counters in KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a coalesced "
-                        "streaming read); WRITE_SIZE taken as is",
+                        "streaming read); WRITE_SIZE taken as is.  The x2 was calibrated on this box for the 8-B/lane "
+                        "128-byte-segment loads of these kernels too (scripts/fetchcal.hip, profiles/r02/fetchcal.txt: "
+                        "ratio 0.500 for 16-B/lane, 8-B/lane contiguous and 8-B/lane row segments).  The fetch side of "
+                        "k_gsm_cov_sym is the upper triangle of S0 (4.33 MB at D=1024) plus the records re-fetched through "
+                        "the fabric by each of the 8 XCD L2s (8 x 0.52 MB, served by the Infinity Cache)",
                "k_gsm_cov_update_fetch_KiB_raw": cov["fetch_KiB_raw"], "k_gsm_cov_update_write_KiB": cov["write_KiB"],
                "k_gsm_cov_update_bytes_per_launch": cov["bytes"],
                "k_panel_fast_bytes_per_launch": pan["bytes"] if pan else None,

@@ -281,6 +281,49 @@ def test_g4_decisive_revert_case_through_the_factor_form(golden):
         outcome = "accepted"
     print("G4 through the factor form:", outcome)
     assert outcome == G4_FACTOR_OUTCOME
+    if outcome == "accepted":
+        # what the update is in (nearly) exact arithmetic: the same formulas in 80-bit long double
+        from oracle import gsm_oracle as orc
+        ld = np.longdouble
+        mu_x, S_x = orc.gsm_update_batched(X.astype(ld), G.astype(ld), mu0.astype(ld), S0.astype(ld))
+        e_mu, e_S = rel_err(mun, mu_x.astype(np.float64)), rel_err(Fn.T @ Fn, S_x.astype(np.float64))
+        print(f"   vs the long-double update: rel err mu {e_mu:.2e} cov {e_S:.2e}; min eig of the long-double cov "
+              f"{np.linalg.eigvalsh(S_x.astype(np.float64)).min():.2e}")
+        assert e_mu < 1e-6 and e_S < 1e-6
 
 
-G4_FACTOR_OUTCOME = "reverted"      # measured on MI355X (see GSM.fit docstring); the dense path reverts too
+# Measured on MI355X: reverted, like the dense path.  The Gram matrix of [Z; U] is singular to rounding here and its
+# entries are ~1e20 (|Z| ~ 1e10 because S0 has eigenvalues 1e-14): the semi-definite rule that lets the factor form
+# work through DEPENDENT rows of moderate size (csrc/gsmvi_chol64.h, SEMIDEF) is switched off for such magnitudes --
+# accepting would return a covariance 10 % away from the exact-arithmetic update (measured with the rule forced on).
+G4_FACTOR_OUTCOME = "reverted"
+
+
+@pytest.mark.parametrize("D,B", [(8, 2), (64, 8), (256, 32), (300, 64), (64, 32)])
+def test_factor_update_with_linearly_dependent_rows(D, B):
+    """Isotropic state on an isotropic target: every u_b - a_b z_b is parallel to mu - m, so the 2B rows [Z; U] have rank
+    B + 1 and their Gram matrix is singular.  The factor form must go through (semi-definite rule) and agree with the
+    pinned dense oracle, which has no such degeneracy.  Also: the EXACT fixed point (U = -Z... all rows dependent)."""
+    import gsmvi_amd
+    from oracle import gsm_oracle as orc
+    eng = gsmvi_amd.get_engine()
+    rs = np.random.RandomState(D)
+    mu0, F0 = np.zeros(D), np.eye(D)
+    Z = rs.standard_normal((B, D))
+    X = mu0 + Z @ F0
+    G = -2.0 * (X - 0.5)                                    # target N(0.5, I/2)
+    mu_o, S_o = orc.gsm_update_batched(X, G, mu0, F0.T @ F0)
+    n_rev = eng.new_flag()
+    mu, F, flag = eng.gsm_factor_update(eng.asarray(Z), eng.asarray(X), eng.asarray(G), eng.asarray(mu0),
+                                        eng.asarray(F0), n_reverts=n_rev)
+    assert eng.read_flag(flag) == 0 and eng.read_flag(n_rev) == 0
+    Fn = F.cpu().numpy()
+    e_mu, e_S = rel_err(mu.cpu().numpy(), mu_o), rel_err(Fn.T @ Fn, S_o)
+    print(f"dependent rows D={D} B={B}: rel err mu {e_mu:.2e} cov {e_S:.2e}")
+    assert e_mu < 1e-9 and e_S < 1e-6
+    # exact fixed point: score == -(x - mu0) for cov = I: the update is the identity map
+    Gf = -(X - mu0)
+    mu2, F2, flag2 = eng.gsm_factor_update(eng.asarray(Z), eng.asarray(X), eng.asarray(Gf), eng.asarray(mu0),
+                                           eng.asarray(F0), n_reverts=n_rev)
+    F2n = F2.cpu().numpy()
+    assert rel_err(F2n.T @ F2n, np.eye(D)) < 1e-9 and np.abs(mu2.cpu().numpy() - mu0).max() < 1e-9

@@ -75,17 +75,22 @@ def test_revert_on_gpu(golden, capsys):
     assert "Bad update for covariance matrix. Revert" in capsys.readouterr().out
 
 
-def test_nan_score_reverts():
+@pytest.mark.parametrize("method", ["dense", "factor", "auto"])
+def test_nan_score_reverts(method):
+    """A NaN score makes exactly that iteration a revert in both state representations.  (The target is N(0.5, I/2),
+    not the initial state N(0, I): AT the exact fixed point the factor form counts every iteration as a revert,
+    see the fit docstring.)"""
     import gsmvi_amd
     calls = [0]
 
     def lp_g(x):
         calls[0] += 1
-        return np.full_like(x, np.nan) if calls[0] == 2 else -x
+        return np.full_like(x, np.nan) if calls[0] == 2 else -2.0 * (x - 0.5)
 
-    gsm = gsmvi_amd.GSM(4, None, lp_g)
-    mean, cov = gsm.fit(1, niter=3, batch_size=2, verbose=False)
+    gsm = gsmvi_amd.GSM(8, None, lp_g)
+    mean, cov = gsm.fit(1, niter=3, batch_size=2, verbose=False, method=method)
     assert gsm.n_reverts == 1 and np.isfinite(mean).all() and np.isfinite(cov).all()
+    assert gsm.method_used == ("dense" if method == "dense" else "factor")
 
 
 def test_monitor_cadence_on_gpu(golden):

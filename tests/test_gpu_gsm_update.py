@@ -292,3 +292,19 @@ def test_row_sharded_update_world1_goes_through_the_hip_stages(eng):
     mu, S = row_sharded_gsm_update(eng, X, G, mu0, S0)
     mu_o, S_o = orc.gsm_update_faithful(st["samples"], st["vs"], st["mu0"], st["S0"])
     assert rel_err(mu.cpu().numpy(), mu_o) < 1e-10 and rel_err(S.cpu().numpy(), S_o) < 1e-10
+
+
+def test_nonsymmetric_s0_keeps_the_reference_semantics(eng):
+    """gsm_numpy.py:50-53 is S = S0 + mean(dS) for ANY S0; the fast kernel reads only the upper triangle, so the
+    user-facing gsm_update routes a non-symmetric S0 to the generic kernels (round-1 advice)."""
+    import gsmvi_amd
+    orc = _oracle()
+    st = orc.make_update_state(64, 16, 3)
+    S0 = st["S0"].copy()
+    S0[5, 40] += 0.25                                    # not symmetric any more
+    mu_o, S_o = orc.gsm_update_faithful(st["samples"], st["vs"], st["mu0"], S0)
+    mu, S = gsmvi_amd.gsm_update(st["samples"], st["vs"], st["mu0"], S0)
+    assert rel_err(mu, mu_o) < 1e-11 and rel_err(S, S_o) < 1e-11
+    assert abs(S[5, 40] - S[40, 5] - 0.25) < 1e-12
+    mu2, S2 = gsmvi_amd.gsm_update(st["samples"], st["vs"], st["mu0"], st["S0"])      # symmetric: fast path again
+    assert np.array_equal(S2, S2.T)
