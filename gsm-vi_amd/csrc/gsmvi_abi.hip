@@ -143,7 +143,9 @@ static void ws_sizes(int D, int B, size_t* n_pp, size_t* n_sg, size_t* n_small, 
     *rmax = R;
     *n_pp = (size_t)GSMVI_MAX_KC * R * D;
     // potrf parks its factored 64x64 diagonal blocks here: one per block step of max(D, 2B+8)
-    const size_t potrf_scratch = (size_t)((((D > R ? D : R) + 63) / 64) * 64 * 64);
+    const size_t dpad = (size_t)(((D > R ? D : R) + 63) / 64) * 64;
+    size_t potrf_scratch = dpad * 64;                          // v1: one factored 64 x 64 block per step
+    if (potrf_scratch < 2 * 64 * dpad + 2 * 64 * 64) potrf_scratch = 2 * 64 * dpad + 2 * 64 * 64;   // v2: row buffers + W
     if (*n_pp < potrf_scratch) *n_pp = potrf_scratch;
     *n_sg = (size_t)R * D * 4;                                 // SG + BaM factor panels
     // + the device chain of BaM's small matrix function: five padded 144 x 144 iterates, coefficients, BB (n <= 129)
@@ -237,6 +239,7 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     else if (!strcmp(name, "update_sb")) ctx->tune_update_sb = value;
     else if (!strcmp(name, "no_fast")) ctx->tune_no_fast = value;
     else if (!strcmp(name, "small_v")) ctx->tune_small_v = value;
+    else if (!strcmp(name, "potrf_v")) ctx->tune_potrf_v = value;
     else if (!strcmp(name, "fused")) ctx->tune_fused = value;
     else if (!strcmp(name, "fused_flags")) ctx->tune_fused_flags = value;
     else if (!strcmp(name, "bam_host")) ctx->tune_bam_host = value;
@@ -568,6 +571,7 @@ int gsmvi_potrf_f64(gsmvi_ctx* ctx, void* stream, int D, const double* S, int ld
                     int* info_dev) {
     BAD_ARG(!ctx || !S || !R || !info_dev, "NULL argument");
     BAD_ARG(D <= 0 || lds < D || ldr < D, "bad size");
+    BAD_ARG(S == R, "the factor must not alias the matrix (tiles of S are read while R is written)");
     if (D > ctx->max_D) {
         gsmvi_set_error("%s: %s", __func__, "D exceeds the context's workspace");
         return GSMVI_ERR_WORKSPACE;

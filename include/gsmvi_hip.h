@@ -200,7 +200,8 @@ int gsmvi_gaussian_score_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
  * Upper Cholesky factor R (R^T R = S, R upper triangular, strictly-lower part zeroed) of a
  * symmetric matrix; *info_dev (device int) = 0 if S is positive definite, else 1 + index of the
  * first failing pivot (also set when a NaN is met).  Replaces np.linalg.cholesky inside
- * _check_goodness (gsm_numpy.py:132-146) and supplies the sampling factor.
+ * _check_goodness (gsm_numpy.py:132-146) and supplies the sampling factor.  R must not alias S; only the upper
+ * triangle of S is read (plus the full diagonal blocks).  ceil(D/64) launches.
  */
 int gsmvi_potrf_f64(gsmvi_ctx* ctx, void* stream, int D, const double* S, int lds,
                     double* R, int ldr, int* info_dev);
