@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--instances", type=int, default=0, help="ring size (0 = enough to exceed the Infinity Cache)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large-point", action="store_true", help="skip the D=4096 roofline point of the covariance kernel")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--tune", action="append", default=[], help="name=value launch knob (experiments)")
     ap.add_argument("--in-flight", type=int, default=1,
@@ -410,6 +411,9 @@ def main():
                 "frac_moved": moved / (avg_ms["cov_update"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "avg_kernel_us": {k: v * 1e3 for k, v in avg_ms.items()},
                 "whole_update_algorithmic_GBs": alg_bytes_total * value / 1e9,
+                "whole_update_frac": alg_bytes_total * value / 1e9 / HBM_PEAK_GBS,   # all launches of one update
+                "whole_update_frac_cache_resident": (alg_bytes_total * value_hot / 1e9 / HBM_PEAK_GBS)
+                if value_hot else None,
                 "mfma_pipe_util_profiled": mfma_util}     # SQ_VALU_MFMA_BUSY_CYCLES pass, profiles/traffic.json
     # ---- calibration: the attainable HBM rate on this box (device copy of 1 GiB, read + write
     # bytes) and what a plain copy of one covariance costs in the same cold ring (it moves 16 D^2 bytes, the
@@ -448,12 +452,36 @@ def main():
         except Exception as e:                  # calibration only
             roofline["attainable_peak"] = f"failed: {type(e).__name__}"
 
+    # ---- the same kernel where it is bandwidth- rather than latency-bound: D=4096, B=32, measured live (two cold
+    # instances, hipExt dispatch events; rocprofv3 evidence: profiles/r02/d4096_b32_kernel_stats.csv) ----
+    if rank == 0 and not use_dist and D == 1024 and not args.no_large_point:
+        try:
+            DL, BL = 4096, 32
+            li, _, _ = make_instances(eng, DL, BL, 3, seed0=7)
+            eng.set_profiling(True)
+            tl = []
+            for kk in range(12):
+                it = li[kk % 3]
+                eng.gsm_update(it["X"], it["G"], it["mu0"], it["S0"], out=(it["mu"], it["S"]))
+                if kk >= 3:
+                    tl.append(eng.get_profile()["cov_update"])
+            eng.set_profiling(False)
+            tms = float(np.mean(tl))
+            bl = 16.0 * DL * DL + 16.0 * BL * DL
+            roofline["large_D_point"] = {"D": DL, "B": BL, "kernel": "k_gsm_cov_sym", "avg_kernel_us": tms * 1e3,
+                                         "algorithmic_bytes_per_launch": bl, "achieved": bl / (tms * 1e-3) / 1e9,
+                                         "frac": bl / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            del li
+            torch.cuda.empty_cache()
+        except Exception as e:                  # secondary figure only
+            roofline["large_D_point"] = f"failed: {type(e).__name__}: {e}"
+
     # ---- fit-iteration rate F: sample -> score -> update -> Cholesky PD check -> commit ----
     fit_rate = None
     if not use_dist:
         fit_rate = {}
         tgt = gsmvi_amd.GaussianTarget(m.cpu().numpy(), precision=P.cpu().numpy())
-        for method in ("dense", "factor"):
+        for method in ("dense", "factor", "auto"):
             try:
                 gsm = gsmvi_amd.GSM(D, tgt.lp, tgt.lp_g)
                 gsm.fit(1, niter=10, batch_size=B, verbose=False, rng="device", method=method)
