@@ -149,6 +149,31 @@ def test_rccl_taking_entry_point_from_plain_c(tmp_path, D, B):
     assert all(np.array_equal(res[0], x) for x in res)          # replicas bit-identical
 
 
+def test_host_code_under_asan_ubsan(tmp_path):
+    """the host side of the ABI (validation, workspace arithmetic, error strings, launch
+    geometry code paths reachable without a device) built with AddressSanitizer + UBSan (`make -C gsm-vi_amd/csrc asan`)
+    and walked by a plain-C driver; any sanitizer report aborts the driver.  (GPU sanitizers are unavailable on the
+    pool; the device code of that build is the ordinary one.)"""
+    import subprocess
+    csrc = os.path.join(ROOT, "gsm-vi_amd", "csrc")
+    p = subprocess.run(["make", "-C", csrc, "-j4", "asan"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    libdir = os.path.join(ROOT, "gsm-vi_amd")
+    exe = str(tmp_path / "abi_hostcheck")
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    cmd = [clang, "-std=c99", "-O1", "-g", "-fsanitize=address,undefined", "-shared-libsan",
+           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi_c", "abi_hostcheck.c"), "-o", exe,
+           "-L" + libdir, "-lgsmvi_hip_asan", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rt = subprocess.run([clang, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               LD_LIBRARY_PATH=os.path.dirname(rt) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    p = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0 and "abi_hostcheck ok" in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-3000:])
+    assert "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr, p.stderr[-3000:]
+
+
 def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     """Argument validation of the entry points added for the sharded factor path and the draw stream runs before any
     HIP call, so it is checkable on a machine without a GPU."""
