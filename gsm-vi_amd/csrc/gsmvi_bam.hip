@@ -680,6 +680,14 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     hipLaunchKernelGGL(k_bam_nmat, dim3((n * n + 255) / 256), dim3(256), 0, st, n, M1, N0, Nd, M1T);
     const double* Ldinv = Ld + (size_t)n * n;
     const bool on_device = n <= gsmvi_bam_small_nmax() && !ctx->tune_bam_host;
+    if (!on_device && !ctx->tune_bam_host) {
+        // No silent host compute in the product path: the device chain covers B <= 128 (n <= 129).  The host eigen-solve
+        // below stays as the tests' reference and is reachable only through the explicit tuning knob bam_host = 1.
+        gsmvi_set_error("%s: %s", "gsmvi_bam_update_f64",
+                        "B > 128 is beyond the device matrix-function chain; set the tuning knob bam_host=1 to use the "
+                        "synchronising host eigen-solve path");
+        return GSMVI_ERR_UNSUPPORTED;
+    }
     if (on_device) {
         // the whole (B+1) x (B+1) matrix function on the device (gsmvi_bam_small.hip): no copy, no synchronisation
         double* scratch = Upk + (size_t)n * (n + 1) / 2 + 2;

@@ -308,7 +308,11 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
         const int b = u >> 4, c2 = 2 * (u & 15);
         // tile 0,1: I block (d, e); 2,3: J0 block; 4,5: J1 block (= J0 again when there is no second tile)
         const int colbase = (tile < 2) ? I0 : (J0 + ((tile >= 4 && two) ? 32 : 0));
-        stg[q] = *reinterpret_cast<const v2d*>(rec + (size_t)b * ldrec + (tile & 1) * D + colbase + c2);
+        // the 16 single-tile workgroups (they share a CU with a two-tile one) neither load nor stage a second column
+        // block, and their waves 4-7 issue no MFMA: 32 instead of 64 MFMAs per SIMD on those CUs (they were the
+        // kernel's 0.9 us tail: profiles/r02/timeline_cold_three_launch.txt).  tile is wave-uniform.
+        stg[q] = (two || tile < 4) ? *reinterpret_cast<const v2d*>(rec + (size_t)b * ldrec + (tile & 1) * D + colbase + c2)
+                                   : (v2d){0.0, 0.0};
     }
     double dmu_part = 0.0;
     if (diag && tid < 256) {                     // dmu tile for the new mean: column = tid & 31, samples tid>>5 + 8k
@@ -330,13 +334,13 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
             const int g = q * 512 + tid;
             const int tile = g / NU, u = g % NU;
             const int b = u >> 4;
-            if (b / SBP == pass)
+            if (b / SBP == pass && (two || tile < 4))
                 *reinterpret_cast<v2d*>(smem + tile * TILE + (b % SBP) * RS + 2 * (u & 15)) = stg[q];
         }
         __syncthreads();
         if (pass == 0) STAMP(2);
         double ad[NS], ae[NS], bd[NS], be[NS];
-        {
+        if (mine) {
             const double* adp = smem + ks * RS + 16 * wr + c;
             const double* aep = adp + TILE;
             const double* bdp = smem + (2 + 2 * t) * TILE + ks * RS + 16 * wc + c;
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
                 be[s] = bep[4 * s * RS];
             }
         }
-        if (!(dbg & 8)) {
+        if (mine && !(dbg & 8)) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 accd = GSMVI_MFMA_F64(ad[s], bd[s], accd);

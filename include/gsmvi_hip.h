@@ -19,7 +19,7 @@
  * Conventions
  *   - All matrices are row-major float64 in DEVICE memory; `ld*` are leading dimensions in elements.
  *   - Calls are asynchronous on `stream` (a hipStream_t passed as void*); nothing synchronises (sole
- *     exception: gsmvi_bam_update_f64 with B > 128, see there), so call sequences can be captured into a hipGraph.
+ *     exception: the opt-in bam_host test knob of gsmvi_bam_update_f64), so call sequences can be captured into a hipGraph.
  *   - Inputs are never modified; outputs must not alias inputs (reference updates are pure,
  *     gsm_numpy.py:47-55) unless an entry point says otherwise.
  *   - S0 must be symmetric (it is a covariance); the kernels read it once, by rows.
@@ -257,7 +257,9 @@ int gsmvi_commit_f64(gsmvi_ctx* ctx, void* stream, int D, const int* info_dev,
  * The (B+1) x (B+1) matrix function of bam.py:108-110 -- which the reference evaluates on the host through
  * jax.pure_callback (bam.py:15-22) -- runs on the device for B <= 128 (scaled coupled Newton-Schulz square root on
  * the MFMA pipe + a one-workgroup Cholesky, csrc/gsmvi_bam_small.hip): no synchronisation, graph-capturable.  For
- * B > 128 the call falls back to a host eigen-solve and synchronises `stream` (then it cannot be captured).
+ * B > 128 the call returns GSMVI_ERR_UNSUPPORTED: there is no silent host computation in this library.  (A host
+ * eigen-solve of the small problem exists as the tests' reference behind gsmvi_set_tuning(ctx, "bam_host", 1); it
+ * synchronises `stream` and cannot be captured.)
  * *info_dev = 1 if that small problem was not finite / not positive definite (then mu, S are NaN-poisoned and the
  * caller's accept/revert must reject them).
  */

@@ -252,3 +252,24 @@ def test_full_form_gap_stays_small_at_moderate_reg(golden):
                                      float(g[f"{c}/reg"]))
         Sf = 0.5 * (g[f"{c}/S_full"] + g[f"{c}/S_full"].T)
         assert rel_err(S, Sf) < 1e-6 and rel_err(mu, g[f"{c}/mu_full"]) < 1e-6, c
+
+
+def test_no_silent_host_path_for_large_batches():
+    """B > 128 is beyond the device chain of the (B+1) x (B+1) matrix function: the call must say so
+    (GSMVI_ERR_UNSUPPORTED) instead of computing on the host; the host eigen-solve stays reachable for the tests
+    through the explicit bam_host knob and agrees with the restatement."""
+    import gsmvi_amd
+    orc, borc = _o()
+    eng = gsmvi_amd.get_engine()
+    st = orc.make_update_state(300, 130, seed=2)
+    X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
+    with pytest.raises(gsmvi_amd.GsmviError) as ei:
+        eng.bam_update(X, G, mu0, S0, 1.0)
+    assert ei.value.status == 5 and "bam_host" in str(ei.value)      # GSMVI_ERR_UNSUPPORTED
+    eng.set_tuning("bam_host", 1)
+    try:
+        mu, S, flag = eng.bam_update(X, G, mu0, S0, 1.0)
+    finally:
+        eng.set_tuning("bam_host", 0)
+    mu_o, S_o = borc.bam_lowrank_update_exact(st["samples"], st["vs"], st["mu0"], st["S0"], 1.0)
+    assert eng.read_flag(flag) == 0 and rel_err(S.cpu().numpy(), 0.5 * (S_o + S_o.T)) < 1e-8
