@@ -249,10 +249,16 @@ def main():
             if int(ok.item()) == 0:
                 graph, graph_rem, launch = None, None, "eager (graph capture failed on some rank)"
 
+    replay_ev = []                       # one torch event pair per full replay: median / min per step
+
     def run_timed():
         if graph is not None:
             for _ in range(n_full):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 graph.replay()
+                e1.record()
+                replay_ev.append((e0, e1))
             if graph_rem is not None:
                 graph_rem.replay()
         else:
@@ -283,6 +289,11 @@ def main():
         el = float(t.item())
     ms_per_step = el / args.steps * 1e3
     value = args.steps / el
+    per_replay_us = sorted(e0.elapsed_time(e1) * 1e3 / gsize for e0, e1 in replay_ev) if replay_ev else []
+    step_us_stats = ({"median": per_replay_us[len(per_replay_us) // 2], "min": per_replay_us[0], "max": per_replay_us[-1],
+                      "replays": len(per_replay_us), "note": "device time of each full graph replay / updates per replay "
+                      "(torch events on the replay stream); `value` itself is wall clock over all steps"}
+                     if per_replay_us else None)
 
     # ---- opt-in: several independent updates in flight (throughput of independent chains, not of one fit) -----
     value_in_flight = None
@@ -504,7 +515,7 @@ def main():
                       "parallelism": "single GPU" if not use_dist else
                       (f"covariance row blocks x{world} + RCCL all-gather of SG column slices" if rows else
                        f"batch-sharded x{world} + RCCL all-gather")},
-           "value_cache_resident": value_hot, "fit_iterations_per_s": fit_rate, "roofline": roofline}
+           "step_us": step_us_stats, "value_cache_resident": value_hot, "fit_iterations_per_s": fit_rate, "roofline": roofline}
     if value_in_flight is not None:
         out["value_in_flight"] = value_in_flight
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

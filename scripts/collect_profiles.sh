@@ -5,9 +5,10 @@ set -u
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$ROOT/bench.py --steps 420 --warmup 42 --no-cpu-baseline"
+ARGS="$ROOT/bench.py --steps 420 --warmup 42 --no-cpu-baseline --no-large-point"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS --no-graph > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS --no-graph > $OUT/pmc_write.log 2>&1
