@@ -226,6 +226,22 @@ __device__ __forceinline__ void chol64_rows_s(double* T, double* rinv, int nb, i
     CHOL_STAMP(3);
 }
 
+// Waves of the workgroup that do NOT take part in chol64_rows_s (which needs exactly 256 threads) execute this instead:
+// the same number of workgroup barriers (one per pivot, 16 ceil(nb/16), plus the three trailing ones) -- s_barrier counts
+// waves, not program counters.  A helper that has work to do between the barriers replaces this loop with its own.
+template <int STR>
+__device__ __forceinline__ void chol64_helper_idle(int nb) {
+#pragma unroll 1
+    for (int pb = 0; pb < 4; ++pb) {
+        if (16 * pb >= nb) break;
+#pragma unroll 1
+        for (int pq = 0; pq < 16; ++pq) __syncthreads();
+    }
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+}
+
 __device__ __forceinline__ void chol64_lds(double* T, double* rinv, int nb, int* sh_fail) {
 #ifdef GSMVI_CHOL64_BLOCKED
     chol64_lds_s<TS>(T, rinv, nb, sh_fail);

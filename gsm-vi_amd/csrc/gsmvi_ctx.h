@@ -27,7 +27,8 @@ struct gsmvi_ctx {
     int tune_cov_dbg = 0;      // ablation bits for k_gsm_cov_sym (wrong results; timing only)
     int tune_timeline = 0;     // 1 = every fast-path kernel of the dense update writes s_memrealtime stamps (diagnostic)
     unsigned long long* stamps = nullptr;   // [kernel][workgroup][8], allocated by the "timeline" knob
-    int tune_potrf_v = 2;      // 1 = two launches per block step (round 1), 2 = one fused launch per step (k_potrf_step)
+    int tune_potrf_v = 3;      // 1 = two launches per block step (round 1), 2 = one fused launch per step (k_potrf_step),
+                               // 3 = the same with eight waves: W substitution beside the Cholesky (k_potrf_step8)
     int tune_small_v = 2;      // 1 = four-wave k_gsmf_small (reference), 2 = eight-wave k_gsmf_small8 (W beside the Cholesky)
     int tune_scalars_nt = 0;   // threads per sample in k_gsm_scalars_fast (256/512/1024; 0 = default)
     int tune_no_fast = 0;      // 1 = force the guarded generic kernels (tests)

@@ -738,19 +738,6 @@ __global__ __launch_bounds__(256) void k_gsmf_small(int n, int B, const double* 
 //     factorisation (115 ns per step against 190 ns per pivot);
 //   * the three MFMA phases (A', P = (T - I) W, K = W^T P) use all eight waves (two per SIMD: the fp64 MFMA pipe
 //     delivers 46 TF chip-wide there against 34 TF with one), row blocks split by parity between the two teams.
-template <int STR>
-__device__ __forceinline__ void chol64_helper_idle(int nb) {
-#pragma unroll 1
-    for (int pb = 0; pb < 4; ++pb) {
-        if (16 * pb >= nb) break;
-#pragma unroll 1
-        for (int pq = 0; pq < 16; ++pq) __syncthreads();
-    }
-    __syncthreads();
-    __syncthreads();
-    __syncthreads();
-}
-
 // NP forward-substitution steps of W = Rg^-T for the calling quad's column, ONE workgroup barrier per step (matches the
 // per-pivot barrier of chol64_rows_s running on the other four waves)
 template <int NP>

@@ -526,6 +526,234 @@ __global__ __launch_bounds__(256) void k_potrf_step(int D, int k, const double* 
     }
 }
 
+// =====================================================================================
+// Version 3 = version 2 with EIGHT waves per tile workgroup:
+//   * the three 64^3 products run two waves per SIMD (wave w: rows 32 wr + 16 rr .., columns 32 wc .., one 16 x 32 strip
+//     of accumulators; the fp64 MFMA pipe delivers 46 TF chip-wide there against 34 TF with one wave per SIMD);
+//   * in the diagonal tile, W_k = R_kk^-T is built by waves 4-7 WHILE waves 0-3 factor the tile: substitution step p needs
+//     row p of the factor and its pivot only, and chol64_rows_s has published both (unscaled, in LDS) by the barrier that
+//     opens pivot p.  The helpers execute one barrier per step (matching the factorisation's per-pivot barrier) and
+//     derive 1/sqrt(d_p) themselves.  Version 2 ran the 64 substitution steps (7.4 us) after the factorisation.
+// =====================================================================================
+__device__ __forceinline__ void potrf_mma64x8(const double* FA, const double* FB, v4d (&acc)[2], int wr, int rr, int wc,
+                                              int c, int ks) {
+    constexpr int RS = 66;
+    const double* ap = FA + (32 * wr + 16 * rr + c) * RS + ks;
+    const double* b0p = FB + (32 * wc + c) * RS + ks;
+    const double* b1p = b0p + 16 * RS;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const double a = ap[4 * s], b0 = b0p[4 * s], b1 = b1p[4 * s];
+        acc[0] = GSMVI_MFMA_F64(a, b0, acc[0]);
+        acc[1] = GSMVI_MFMA_F64(a, b1, acc[1]);
+    }
+}
+
+__global__ __launch_bounds__(512) void k_potrf_step8(int D, int k, const double* S, int lds, double* R, int ldr,
+                                                     double* rowbuf, int ldrow, double* wbuf, int* __restrict__ info,
+                                                     unsigned long long* __restrict__ stamps) {
+#define PSTAMP(i)                                                                                                  \
+    do {                                                                                                           \
+        if (stamps && blockIdx.x == 0 && threadIdx.x == 0 && k < 64) stamps[k * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+    PSTAMP(0);
+    constexpr int RS = 66;
+    static_assert(RS == TS, "chol64 runs in the staging buffer");
+    __shared__ __attribute__((aligned(16))) double L0[64 * RS];
+    __shared__ __attribute__((aligned(16))) double L1[64 * RS];
+    __shared__ __attribute__((aligned(16))) double L2[64 * RS];
+    __shared__ double rinv[64];
+    __shared__ int sh_fail;
+    const int nblk = (D + NB - 1) / NB, m = nblk - k;
+    int ti, tj;
+    {
+        const int idx = blockIdx.x;
+        int t = 0, base = 0;
+        while (base + (m - t) <= idx) { base += m - t; ++t; }
+        ti = t;
+        tj = t + (idx - base);
+    }
+    const int I0 = (k + ti) * NB, J0 = (k + tj) * NB;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+    const int wr = (w >> 1) & 1, wc = w & 1, rr = w >> 2;
+    const bool first_row = (ti == 0), diag = (ti == 0 && tj == 0), same = (ti == tj);
+    const double* Asrc = (k <= 1) ? S : R;
+    const int lda = (k <= 1) ? lds : ldr;
+    const double* Bsrc = (k == 1) ? S : rowbuf + (size_t)((k - 1) & 1) * NB * ldrow;
+    const int ldb = (k == 1) ? lds : ldrow;
+    const int lrow0 = 32 * wr + 16 * rr + ks;                     // local row of accumulator register r: lrow0 + 4 r
+
+    double tv[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = I0 + lrow0 + 4 * r, col = J0 + 32 * wc + 16 * ct + c;
+            tv[ct][r] = (row < D && col < D) ? Asrc[(size_t)row * lda + col] : ((row == col) ? 1.0 : 0.0);
+        }
+    v4d acc[2];
+    if (k > 0) {
+        const double* Wk = wbuf + (size_t)((k - 1) & 1) * NB * NB;
+        double vw[8], vi[8], vj[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) vw[q] = Wk[tid + 512 * q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int p = (tid >> 6) + 8 * q, i = tid & 63;
+            const int gi = I0 + i, gj = J0 + i;
+            vi[q] = (gi < D) ? Bsrc[(size_t)p * ldb + gi] : 0.0;
+            vj[q] = (!same && gj < D) ? Bsrc[(size_t)p * ldb + gj] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 512 * q;
+            L0[(e >> 6) * RS + (e & 63)] = vw[q];
+            const int p = (tid >> 6) + 8 * q, i = tid & 63;
+            L1[i * RS + p] = vi[q];
+        }
+        __syncthreads();
+        PSTAMP(1);
+        acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+        potrf_mma64x8(L0, L1, acc, wr, rr, wc, c, ks);            // X_I = W B_I
+        __syncthreads();
+        PSTAMP(2);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = lrow0 + 4 * r, col = 32 * wc + 16 * ct + c;
+                L2[col * RS + row] = acc[ct][r];
+                if (first_row && same) {
+                    const int gc = J0 + col;
+                    if (gc < D) R[(size_t)((k - 1) * NB + row) * ldr + gc] = acc[ct][r];
+                }
+            }
+        if (!same) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int p = (tid >> 6) + 8 * q, i = tid & 63;
+                L1[i * RS + p] = vj[q];
+            }
+            __syncthreads();
+            acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+            potrf_mma64x8(L0, L1, acc, wr, rr, wc, c, ks);        // X_J = W B_J
+            __syncthreads();
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = lrow0 + 4 * r, col = 32 * wc + 16 * ct + c;
+                    L1[col * RS + row] = acc[ct][r];
+                    if (first_row) {
+                        const int gc = J0 + col;
+                        if (gc < D) R[(size_t)((k - 1) * NB + row) * ldr + gc] = acc[ct][r];
+                    }
+                }
+        }
+        __syncthreads();
+        acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+        potrf_mma64x8(L2, same ? L2 : L1, acc, wr, rr, wc, c, ks);    // T -= X_I^T X_J
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tv[ct][r] -= acc[ct][r];
+        if (first_row) {
+            for (int e = tid; e < NB * NB; e += 512) {
+                const int jr = e >> 6, p = e & 63;
+                if (J0 + jr < D) R[(size_t)(J0 + jr) * ldr + (k - 1) * NB + p] = 0.0;
+            }
+        }
+    }
+    if (!diag) {
+        double* dst = first_row ? rowbuf + (size_t)(k & 1) * NB * ldrow : R;
+        const int ldd = first_row ? ldrow : ldr;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lrow = lrow0 + 4 * r, col = J0 + 32 * wc + 16 * ct + c;
+                const int row = first_row ? lrow : I0 + lrow;
+                if (I0 + lrow < D && col < D) dst[(size_t)row * ldd + col] = tv[ct][r];
+            }
+        return;
+    }
+    // ---- the diagonal tile (k, k): waves 0-3 factor it, waves 4-7 build W_k = R_kk^-T one pivot behind ----
+    const int nb = (D - I0) < NB ? (D - I0) : NB;
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = lrow0 + 4 * r, j = 32 * wc + 16 * ct + c;
+            L0[i * RS + j] = (i < nb && j < nb) ? tv[ct][r] : (i == j ? 1.0 : 0.0);
+        }
+    if (tid < 64) rinv[tid] = 1.0;
+    __syncthreads();
+    PSTAMP(3);
+    if (tid < 256) {
+        chol64_rows_s<TS>(L0, rinv, nb, &sh_fail);     // (raising this team's wave priority with s_setprio changed nothing)
+        PSTAMP(4);
+        if (tid == 0 && sh_fail != 0 && *info == 0) *info = I0 + sh_fail;
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int i = e >> 6, j = e & 63;
+            if (i < nb && j < nb) R[(size_t)(I0 + i) * ldr + I0 + j] = (j >= i) ? L0[i * RS + j] : 0.0;
+        }
+        if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PSTAMP(5); }
+        return;
+    }
+    if (m == 1) {                                                 // last step: nobody needs W; only match the barriers
+        chol64_helper_idle<TS>(nb);
+        return;
+    }
+    {
+        // nb == 64 here (only the last block can be ragged).  Column cq of the lower-triangular W per quad of lanes; step p:
+        // x_p *= 1/sqrt(d_p), x_t -= R[p][t] x_p (t > p) with R[p][t] = T[p][t] / sqrt(d_p), T = the published unscaled row.
+        const int st = tid - 256, cq = st >> 2, q = st & 3;
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = (q + 4 * r == cq) ? 1.0 : 0.0;
+        // software-pipelined by one more pivot: behind barrier p the helper starts 1/sqrt(d_p) (a dependent chain of ~10
+        // instructions) and meanwhile runs the arithmetic of step p - 1, whose scale it already holds
+        double ri_prev = 0.0;
+#pragma unroll
+        for (int p = 0; p <= 64; ++p) {
+            double ri = 0.0;
+            if (p < 64) {
+                __syncthreads();                                  // = the barrier that opens pivot p: row p and d_p are final
+                const double d = L0[p * RS + p];
+                const bool ok = d > 0.0 && d < 1.7976931348623157e308;
+                const double dd = ok ? d : 1.0;
+                double y = __builtin_amdgcn_rsq(dd);
+                y = y * (1.5 - 0.5 * dd * y * y);
+                y = y * (1.5 - 0.5 * dd * y * y);
+                ri = ok ? y : 0.0;                                // the rinv[p] the factorisation will publish at its end
+            }
+            if (p > 0) {
+                const int ps = p - 1, pr = ps >> 2, pq = ps & 3;
+                const double mine = x[pr] * ri_prev;
+                if (q == pq) x[pr] = mine;
+                const double xp = __shfl(mine, (threadIdx.x & 60) | pq, 64) * ri_prev;   // x_p / sqrt(d_p): scales the unscaled row
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (4 * r + 3 > ps) {
+                        const int t = q + 4 * r;
+                        const double rv = L0[ps * RS + t];
+                        x[r] -= (t > ps) ? rv * xp : 0.0;
+                    }
+            }
+            ri_prev = ri;
+        }
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+        double* Wk = wbuf + (size_t)(k & 1) * NB * NB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Wk[(q + 4 * r) * NB + cq] = x[r];
+    }
+}
+
+#undef PSTAMP
+
 static int potrf_v1(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                     int* info_dev) {
     double* diag = ctx->pp;                       // nblk x 64 x 64 doubles; the panel-partial slab is idle here
@@ -561,8 +789,12 @@ int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int
         hipLaunchKernelGGL(k_potrf_clear_info, dim3(1), dim3(1), 0, st, info_dev);
         for (int k = 0; k < nblk; ++k) {
             const int m = nblk - k;
-            hipLaunchKernelGGL(k_potrf_step, dim3(m * (m + 1) / 2), dim3(256), 0, st, D, k, S, lds, R, ldr, rowbuf, ldrow,
-                               wbuf, info_dev);
+            if (ctx->tune_potrf_v == 2)
+                hipLaunchKernelGGL(k_potrf_step, dim3(m * (m + 1) / 2), dim3(256), 0, st, D, k, S, lds, R, ldr, rowbuf,
+                                   ldrow, wbuf, info_dev);
+            else
+                hipLaunchKernelGGL(k_potrf_step8, dim3(m * (m + 1) / 2), dim3(512), 0, st, D, k, S, lds, R, ldr, rowbuf,
+                                   ldrow, wbuf, info_dev, ctx->timeline_stamps(3));
         }
     }
     hipError_t e = hipGetLastError();
