@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void k_bam_chol_out(int n, double reg, const d
             const int pr = p >> 2, pq = p & 3;
             const double mine = x[pr] * rinv[p];
             if (q == pq) x[pr] = mine;
-            const double xp = __shfl(mine, (tid & 60) | pq, 64);
+            const double xp = quad_bcast_rt<0>(mine, pq);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (4 * r + 3 > p) {

@@ -132,19 +132,20 @@ __device__ __forceinline__ void chol64_lds_s(double* T, double* rinv, int nb, in
 // barrier with a redundant 4 x 4 factor in every thread was no faster -- the chain is instruction latency:
 // dropping the barrier altogether only takes 11.2 -> 9.1 us, the Newton steps cost nothing.)
 // SEMIDEF = true factors a positive SEMI-definite matrix (a Gram matrix G = Rt Rt^T whose rows may be linearly
-// dependent).  A pivot that is not above the rounding floor of its row, d_p <= GSMVI_DEP_TOL * G_pp with G_pp the ORIGINAL
-// diagonal entry (diag0[p] = |row p|^2; the test is scale-free per row, so rows of tiny norm are fine), cannot be told
-// from zero in fp64 -- and a tiny POSITIVE noise pivot is as harmful as a negative one (1 / sqrt(1e-34) in the factor:
-// scripts/dbg_dep128.py).  Such a row is DEPENDENT: its row of the factor and its diagonal come out as ZERO, rinv[p] = 0,
-// the pivot is skipped in the elimination, no failure is reported (R^T R still equals G to rounding).  allow_dep
-// (block-uniform) = false turns the dependent verdict into a FAILURE instead: the callers pass "every diagonal entry is
-// of moderate size" (max_p G_pp < 2^32), because dropping a row perturbs the represented matrix by up to
-// sqrt(GSMVI_DEP_TOL) |row| -- harmless for whitened draws (|z|^2 ~ D), meaningless for |z| ~ 1e10 (fixture G4).
-// NaN / inf pivots fail in every mode.  SEMIDEF = false is the plain positive-definite test (pivot <= 0 fails).
+// dependent).  The CALLER has lowered every diagonal entry by its rounding floor, G_pp <- G_pp (1 - GSMVI_DEP_TOL)
+// (a relative perturbation of 64 eps, scale-free per row, so rows of tiny norm are fine); a pivot <= 0 then means
+// "not above the rounding floor of its row": it cannot be told from zero in fp64 -- and a tiny POSITIVE noise pivot is
+// as harmful as a negative one (1 / sqrt(1e-34) in the factor: scripts/dbg_dep128.py), hence the shift instead of a
+// plain sign test.  (Comparing against a per-pivot floor read from LDS inside the loop put that read on the pivot chain:
+// 12.2 -> 14.8 us per 64 x 64 block.)  Such a row is DEPENDENT: its row of the factor and its diagonal come out as
+// ZERO, rinv[p] = 0, the pivot is skipped in the elimination, no failure is reported (R^T R still equals G to
+// rounding).  allow_dep (block-uniform) = false turns the dependent verdict into a FAILURE instead: the callers pass
+// "every diagonal entry is of moderate size" (max_p G_pp < 2^32), because dropping a row perturbs the represented matrix
+// by up to sqrt(GSMVI_DEP_TOL) |row| -- harmless for whitened draws (|z|^2 ~ D), meaningless for |z| ~ 1e10 (fixture
+// G4).  NaN / inf pivots fail in every mode.  SEMIDEF = false is the plain positive-definite test (pivot <= 0 fails).
 #define GSMVI_DEP_TOL 1.4210854715202004e-14        /* 64 eps */
 template <int STR, bool SEMIDEF = false>
-__device__ __forceinline__ void chol64_rows_s(double* T, double* rinv, int nb, int* sh_fail, bool allow_dep = true,
-                                              const double* diag0 = nullptr) {
+__device__ __forceinline__ void chol64_rows_s(double* T, double* rinv, int nb, int* sh_fail, bool allow_dep = true) {
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     double s[4][4];
 #pragma unroll
@@ -168,9 +169,8 @@ __device__ __forceinline__ void chol64_rows_s(double* T, double* rinv, int nb, i
             for (int a = pb; a < 4; ++a) ri[a] = row[ty + 16 * a];
 #pragma unroll
             for (int b = pb; b < 4; ++b) rj[b] = row[tx + 16 * b];
-            const double floor_p = SEMIDEF ? GSMVI_DEP_TOL * diag0[p] : 0.0;
-            const bool ok = d > floor_p && d < 1.7976931348623157e308;   // false for NaN, inf, pivots at the rounding floor
-            const bool dep = SEMIDEF && allow_dep && d <= floor_p && d > -1.7976931348623157e308;   // dependent row
+            const bool ok = d > 0.0 && d < 1.7976931348623157e308;   // false for NaN, <= 0, inf
+            const bool dep = SEMIDEF && allow_dep && d <= 0.0 && d > -1.7976931348623157e308;   // dependent row
             if (!ok && !dep && fail == 0) fail = p + 1;
             const double dd = ok ? d : 1.0;
             double y = __builtin_amdgcn_rcp(dd);
@@ -202,7 +202,7 @@ __device__ __forceinline__ void chol64_rows_s(double* T, double* rinv, int nb, i
     CHOL_STAMP(2);
     if (tid < 64) {
         const double d = T[tid * STR + tid];
-        const bool ok = d > (SEMIDEF ? GSMVI_DEP_TOL * diag0[tid] : 0.0) && d < 1.7976931348623157e308;
+        const bool ok = d > 0.0 && d < 1.7976931348623157e308;
         const double dd = ok ? d : 1.0;
         double y = __builtin_amdgcn_rsq(dd);
         y = y * (1.5 - 0.5 * dd * y * y);

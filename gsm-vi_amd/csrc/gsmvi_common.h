@@ -12,6 +12,22 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 #define GSMVI_WAVE 64
 #define GSMVI_WG 256
 
+// Broadcast of lane Q (0..3, compile-time) of every quad of lanes to the whole quad: two DPP moves (quad_perm), pure VALU --
+// __shfl compiles to ds_bpermute_b32, an LDS-pipeline instruction with ~100 cycles of latency on a dependent chain.
+template <int Q>
+__device__ __forceinline__ double quad_bcast(double v) {
+    constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);      // DPP quad_perm: [Q, Q, Q, Q]
+    const unsigned long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffu), ctrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), ctrl, 0xf, 0xf, false);
+    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+template <int>
+__device__ __forceinline__ double quad_bcast_rt(double v, int q) {  // run-time lane (still DPP: four-way select)
+    const double a = quad_bcast<0>(v), b = quad_bcast<1>(v), c = quad_bcast<2>(v), d = quad_bcast<3>(v);
+    return q == 0 ? a : (q == 1 ? b : (q == 2 ? c : d));
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

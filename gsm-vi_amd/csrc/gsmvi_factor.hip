@@ -305,26 +305,26 @@ __global__ __launch_bounds__(256) void k_chol128(int n, const double* __restrict
                                                  int* __restrict__ info) {
     constexpr int MS = 130;
     __shared__ __attribute__((aligned(16))) double M[128 * MS];
-    __shared__ double rinv[128], diag0[128];
+    __shared__ double rinv[128];
     __shared__ int sh_fail[2];
     const int tid = threadIdx.x;
     load_upper128(M, A, n);
     if (tid < 128) rinv[tid] = 1.0;
     __syncthreads();
     bool moderate = true;
-    if (SEMIDEF) {                                  // original diagonal (= |row|^2 of [Z; U]) and the magnitude guard
+    if (SEMIDEF) {                                  // rounding-floor shift of the diagonal and the magnitude guard
         if (tid == 0) sh_fail[1] = 1;
         __syncthreads();
         if (tid < 128) {
             const double d = M[tid * MS + tid];
-            diag0[tid] = d;
+            M[tid * MS + tid] = d - GSMVI_DEP_TOL * d;           // rounding floor of the row, see chol64_rows_s
             if (!(d < 4294967296.0)) sh_fail[1] = 0;
         }
         __syncthreads();
         moderate = sh_fail[1] != 0;
         __syncthreads();
     }
-    chol64_rows_s<MS, SEMIDEF>(M, rinv, 64, &sh_fail[0], moderate, diag0);
+    chol64_rows_s<MS, SEMIDEF>(M, rinv, 64, &sh_fail[0], moderate);
     {
         const int colq = tid >> 2, q = tid & 3;
         double x[16];
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void k_chol128(int n, const double* __restrict
             const int pr = p >> 2, pq = p & 3;
             const double mine = x[pr] * rinv[p];
             if (q == pq) x[pr] = mine;
-            const double xp = __shfl(mine, (tid & 60) | pq, 64);
+            const double xp = quad_bcast_rt<0>(mine, pq);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (4 * r + 3 > p) {
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void k_chol128(int n, const double* __restrict
             }
     }
     __syncthreads();
-    chol64_rows_s<MS, SEMIDEF>(M + 64 * MS + 64, rinv + 64, n - 64, &sh_fail[1], moderate, diag0 + 64);
+    chol64_rows_s<MS, SEMIDEF>(M + 64 * MS + 64, rinv + 64, n - 64, &sh_fail[1], moderate);
     for (int e = tid; e < n * n; e += 256) {
         const int i = e / n, j = e % n;
         R[e] = (j >= i) ? M[i * MS + j] : 0.0;
@@ -541,15 +541,16 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const do
     }
 }
 
-// Captures the original diagonal of the 64 x 64 LDS matrix M (row stride STR) into diag0[64] and returns (block-uniform)
-// whether every entry is below 2^32 and not NaN -- the two inputs of the semi-definite rule of chol64_rows_s.
+// Prepares the 64 x 64 LDS Gram matrix M (row stride STR) for the semi-definite rule of chol64_rows_s: lowers every diagonal
+// entry by its rounding floor, M_pp <- M_pp (1 - GSMVI_DEP_TOL), and returns (block-uniform) whether every entry is below
+// 2^32 and not NaN.
 template <int STR>
-__device__ __forceinline__ bool diag_capture(const double* M, double* diag0, int* sh_flag) {
+__device__ __forceinline__ bool diag_prepare(double* M, int* sh_flag) {
     if (threadIdx.x == 0) *sh_flag = 1;
     __syncthreads();
     if (threadIdx.x < 64) {
         const double d = M[threadIdx.x * STR + threadIdx.x];
-        diag0[threadIdx.x] = d;
+        M[threadIdx.x * STR + threadIdx.x] = d - GSMVI_DEP_TOL * d;
         if (!(d < 4294967296.0)) *sh_flag = 0;
     }
     __syncthreads();
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(256) void k_gsmf_small(int n, int B, const double* 
     __shared__ __attribute__((aligned(16))) double Rs[64 * TS];
     __shared__ __attribute__((aligned(16))) double Ts[64 * TS];
     __shared__ __attribute__((aligned(16))) double Ps[64 * TS];
-    __shared__ double rinv_g[64], rinv_t[64], diag0[64];
+    __shared__ double rinv_g[64], rinv_t[64];
     __shared__ int fail_g, fail_t;
     const int tid = threadIdx.x;
     {
@@ -592,8 +593,8 @@ __global__ __launch_bounds__(256) void k_gsmf_small(int n, int B, const double* 
     if (tid < 64) rinv_g[tid] = rinv_t[tid] = 1.0;
     __syncthreads();
     SMALL_STAMP(1);
-    const bool moderate = diag_capture<TS>(Rs, diag0, &fail_t);
-    chol64_rows_s<TS, true>(Rs, rinv_g, n, &fail_g, moderate, diag0);   // Rs = Rg (upper, semi-definite rule); strictly-lower part is stale
+    const bool moderate = diag_prepare<TS>(Rs, &fail_t);
+    chol64_rows_s<TS, true>(Rs, rinv_g, n, &fail_g, moderate);   // Rs = Rg (upper, semi-definite rule); strictly-lower part is stale
     SMALL_STAMP(2);
     for (int e = tid; e < 64 * 64; e += 256) {         // zero the strictly-lower part so Rs is a clean upper factor
         const int i = e >> 6, q = e & 63;
@@ -661,7 +662,7 @@ __global__ __launch_bounds__(256) void k_gsmf_small(int n, int B, const double* 
         const int pr = p >> 2, pq = p & 3;
         const double mine = x[pr] * rinv_g[p];
         if (q == pq) x[pr] = mine;
-        const double xp = __shfl(mine, (threadIdx.x & 60) | pq, 64);
+        const double xp = quad_bcast_rt<0>(mine, pq);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             if (4 * r + 3 > p) {
@@ -748,7 +749,7 @@ __device__ __forceinline__ void wsubst_steps(double (&x)[16], int sq, const doub
         const int pr = p >> 2, pq = p & 3;
         const double mine = x[pr] * rinv_g[p];
         if (sq == pq) x[pr] = mine;
-        const double xp = __shfl(mine, (threadIdx.x & 60) | pq, 64);
+        const double xp = quad_bcast_rt<0>(mine, pq);       // DPP, not ds_bpermute: the chain stays off the LDS pipeline
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             if (4 * r + 3 > p) {
@@ -770,7 +771,7 @@ __global__ __launch_bounds__(512) void k_gsmf_small8(int n, int B, const double*
     __shared__ __attribute__((aligned(16))) double Rs[64 * TS];
     __shared__ __attribute__((aligned(16))) double Ts[64 * TS];
     __shared__ __attribute__((aligned(16))) double Ps[64 * TS];
-    __shared__ double rinv_g[64], rinv_t[64], diag0[64];
+    __shared__ double rinv_g[64], rinv_t[64];
     __shared__ int fail_g, fail_t;
     const int tid = threadIdx.x;
     const bool team = tid < 256;                       // Cholesky team (waves 0-3) / helpers (waves 4-7)
@@ -794,8 +795,8 @@ __global__ __launch_bounds__(512) void k_gsmf_small8(int n, int B, const double*
     // an isotropic target makes every u_b - a_b z_b parallel to mu - m; the exact fixed point makes U = -Z ...): the
     // dependent rows drop out of Rg (zero row, zero diagonal) and get a unit diagonal in the substitution below, which
     // leaves C^T C = I + Rt^T J Rt intact (factor form).
-    const bool moderate = diag_capture<TS>(Rs, diag0, &fail_t);
-    if (team) chol64_rows_s<TS, true>(Rs, rinv_g, n, &fail_g, moderate, diag0);
+    const bool moderate = diag_prepare<TS>(Rs, &fail_t);
+    if (team) chol64_rows_s<TS, true>(Rs, rinv_g, n, &fail_g, moderate);
     else chol64_helper_idle<TS>(n);
     SMALL_STAMP(2);
     for (int e = tid; e < 64 * 64; e += 512) {

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_potrf_panel(int D, int k, double* __res
         const int pr = p >> 2, pq = p & 3;                 // pivot row p lives in register pr of quad lane pq
         const double mine = x[pr] * rinv[p];
         if (q == pq) x[pr] = mine;
-        const double xp = __shfl(mine, (threadIdx.x & 60) | pq, 64);
+        const double xp = quad_bcast_rt<0>(mine, pq);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             // rows q + 4r > p  (compile-time bound on r, lane-dependent part folded into a select)
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void k_potrf_step(int D, int k, const double* 
             const int pr = p >> 2, pq = p & 3;
             const double mine = x[pr] * rinv[p];
             if (q == pq) x[pr] = mine;
-            const double xp = __shfl(mine, (threadIdx.x & 60) | pq, 64);
+            const double xp = quad_bcast_rt<0>(mine, pq);
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (4 * r + 3 > p) {
@@ -708,10 +708,16 @@ __global__ __launch_bounds__(512) void k_potrf_step8(int D, int k, const double*
     {
         // nb == 64 here (only the last block can be ragged).  Column cq of the lower-triangular W per quad of lanes; step p:
         // x_p *= 1/sqrt(d_p), x_t -= R[p][t] x_p (t > p) with R[p][t] = T[p][t] / sqrt(d_p), T = the published unscaled row.
+        // Row ownership inside the quad: lane q owns the row PAIRS {8r + 2q, 8r + 2q + 1}, r = 0..7 (x[2r], x[2r+1]), so a
+        // step reads the published row with 8 ds_read_b128 per lane instead of 16 ds_read_b64: the helpers' LDS traffic
+        // is what slows the factorisation beside them (scripts/potrf_timeline.py: 12.5 us alone, 18.4 us with b64 reads).
         const int st = tid - 256, cq = st >> 2, q = st & 3;
         double x[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = (q + 4 * r == cq) ? 1.0 : 0.0;
+        for (int r = 0; r < 8; ++r) {
+            x[2 * r] = (8 * r + 2 * q == cq) ? 1.0 : 0.0;
+            x[2 * r + 1] = (8 * r + 2 * q + 1 == cq) ? 1.0 : 0.0;
+        }
         // software-pipelined by one more pivot: behind barrier p the helper starts 1/sqrt(d_p) (a dependent chain of ~10
         // instructions) and meanwhile runs the arithmetic of step p - 1, whose scale it already holds
         double ri_prev = 0.0;
@@ -729,16 +735,19 @@ __global__ __launch_bounds__(512) void k_potrf_step8(int D, int k, const double*
                 ri = ok ? y : 0.0;                                // the rinv[p] the factorisation will publish at its end
             }
             if (p > 0) {
-                const int ps = p - 1, pr = ps >> 2, pq = ps & 3;
+                const int ps = p - 1;
+                const int pr = 2 * (ps >> 3) + (ps & 1), pq = (ps >> 1) & 3;     // register and quad lane that hold x_ps
                 const double mine = x[pr] * ri_prev;
                 if (q == pq) x[pr] = mine;
-                const double xp = __shfl(mine, (threadIdx.x & 60) | pq, 64) * ri_prev;   // x_p / sqrt(d_p): scales the unscaled row
+                const double xp = quad_bcast_rt<0>(mine, pq) * ri_prev;   // x_p / sqrt(d_p): scales the unscaled row (pq is a
+                                                                            // compile-time constant after unrolling)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (4 * r + 3 > ps) {
-                        const int t = q + 4 * r;
-                        const double rv = L0[ps * RS + t];
-                        x[r] -= (t > ps) ? rv * xp : 0.0;
+                for (int r = 0; r < 8; ++r)
+                    if (8 * r + 7 > ps) {
+                        const int t = 8 * r + 2 * q;
+                        const v2d rv = *reinterpret_cast<const v2d*>(&L0[ps * RS + t]);   // RS and t even: 16-byte aligned
+                        x[2 * r] -= (t > ps) ? rv.x * xp : 0.0;
+                        x[2 * r + 1] -= (t + 1 > ps) ? rv.y * xp : 0.0;
                     }
             }
             ri_prev = ri;
@@ -748,7 +757,10 @@ __global__ __launch_bounds__(512) void k_potrf_step8(int D, int k, const double*
         __syncthreads();
         double* Wk = wbuf + (size_t)(k & 1) * NB * NB;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Wk[(q + 4 * r) * NB + cq] = x[r];
+        for (int r = 0; r < 8; ++r) {
+            Wk[(8 * r + 2 * q) * NB + cq] = x[2 * r];
+            Wk[(8 * r + 2 * q + 1) * NB + cq] = x[2 * r + 1];
+        }
     }
 }
 
