@@ -535,14 +535,16 @@ __global__ __launch_bounds__(256) void k_potrf_step(int D, int k, const double* 
 //     opens pivot p.  The helpers execute one barrier per step (matching the factorisation's per-pivot barrier) and
 //     derive 1/sqrt(d_p) themselves.  Version 2 ran the 64 substitution steps (7.4 us) after the factorisation.
 // =====================================================================================
+// nsteps (wave-uniform, <= 16): k-steps of 4 to run -- the solve's left operand W is lower triangular, so the row block
+// 16 rb .. 16 rb + 15 of X = W B needs k < 16 (rb + 1) only
 __device__ __forceinline__ void potrf_mma64x8(const double* FA, const double* FB, v4d (&acc)[2], int wr, int rr, int wc,
-                                              int c, int ks) {
+                                              int c, int ks, int nsteps = 16) {
     constexpr int RS = 66;
     const double* ap = FA + (32 * wr + 16 * rr + c) * RS + ks;
     const double* b0p = FB + (32 * wc + c) * RS + ks;
     const double* b1p = b0p + 16 * RS;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
+#pragma unroll 4
+    for (int s = 0; s < nsteps; ++s) {
         const double a = ap[4 * s], b0 = b0p[4 * s], b1 = b1p[4 * s];
         acc[0] = GSMVI_MFMA_F64(a, b0, acc[0]);
         acc[1] = GSMVI_MFMA_F64(a, b1, acc[1]);
@@ -614,7 +616,8 @@ __global__ __launch_bounds__(512) void k_potrf_step8(int D, int k, const double*
         __syncthreads();
         PSTAMP(1);
         acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
-        potrf_mma64x8(L0, L1, acc, wr, rr, wc, c, ks);            // X_I = W B_I
+        const int tri_steps = 4 * (2 * wr + rr + 1);                 // W[i][p] = 0 for p > i
+        potrf_mma64x8(L0, L1, acc, wr, rr, wc, c, ks, tri_steps);   // X_I = W B_I
         __syncthreads();
         PSTAMP(2);
 #pragma unroll
@@ -636,7 +639,7 @@ __global__ __launch_bounds__(512) void k_potrf_step8(int D, int k, const double*
             }
             __syncthreads();
             acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
-            potrf_mma64x8(L0, L1, acc, wr, rr, wc, c, ks);        // X_J = W B_J
+            potrf_mma64x8(L0, L1, acc, wr, rr, wc, c, ks, tri_steps);   // X_J = W B_J
             __syncthreads();
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
