@@ -32,7 +32,8 @@ void gsmvi_launch_commit(hipStream_t st, int D, const int* info, const double* m
 // fast paths (gsmvi_fast.hip)
 void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int nrows, const double* A,
                              int lda, const double* shift, double alpha, const double* M, int ldm, double* Pp,
-                             int chunks_per_wg, int ncols, unsigned long long* stamps);
+                             int chunks_per_wg, int ncols, unsigned long long* stamps, double* Out, int ldo,
+                             const double* addvec, unsigned* cnt);
 bool gsmvi_launch_gsm_scalars_fast(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, const double* X, int ldx,
                                    const double* G, int ldg, const double* mu0, const double* Pp, double* rec,
                                    int ldrec, int nt, unsigned long long* stamps);
@@ -238,6 +239,7 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "panel_kc")) ctx->tune_panel_kc = value;
     else if (!strcmp(name, "update_sb")) ctx->tune_update_sb = value;
     else if (!strcmp(name, "no_fast")) ctx->tune_no_fast = value;
+    else if (!strcmp(name, "seam_finish")) ctx->tune_seam_finish = value;
     else if (!strcmp(name, "small_v")) ctx->tune_small_v = value;
     else if (!strcmp(name, "potrf_v")) ctx->tune_potrf_v = value;
     else if (!strcmp(name, "fused")) ctx->tune_fused = value;
@@ -310,6 +312,45 @@ int gsmvi_get_profile(gsmvi_ctx* ctx, float* ms, int n) {
 // A: nrows x D, M: D x ncols (row-major, ldm).  Returns the number of slabs through *kc_out.
 int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D, int ncols, int nrows,
                            const double* A, int lda, const double* shift, double alpha, const double* M, int ldm,
+                           double* Pp, int* kc_out);
+
+// Product with a FINISHED output Out (nrows x ncols, ldo) = addvec + alpha (A - shift) M.  On the fast path with at most
+// one workgroup per CU the split-K slabs are combined inside the product launch (per-strip seam of k_panel_fast);
+// otherwise product + k_panel_finish.  Same numbers either way (same summation order).
+int gsmvi_panel_product_out(gsmvi_ctx* ctx, hipStream_t st, int D, int ncols, int nrows, const double* A, int lda,
+                            const double* shift, double alpha, const double* M, int ldm, const double* addvec, double* Out,
+                            int ldo) {
+    const int strips = (ncols + 15) / 16;
+    const int MT = nrows <= 16 ? 1 : (nrows <= 32 ? 2 : 4);
+    const int zblocks = (nrows + 16 * MT - 1) / (16 * MT);
+    const int a_vec_ok = (lda % 2 == 0) && aligned16(A);
+    const bool fast = !ctx->tune_no_fast && ctx->tune_seam_finish && ncols % 16 == 0 && D % 64 == 0 && a_vec_ok &&
+                      (!shift || aligned16(shift));
+    if (fast) {
+        const int chw = gsmvi_panel_fast_chunk(MT);
+        const int nchunks = (D + chw - 1) / chw;
+        int kc = ctx->tune_panel_kc > 0 ? ctx->tune_panel_kc : ctx->num_cu / (strips * zblocks);
+        if (kc > nchunks) kc = nchunks;
+        if (kc > GSMVI_MAX_KC) kc = GSMVI_MAX_KC;
+        if (kc >= 1) {
+            const int cpw = (nchunks + kc - 1) / kc;
+            kc = (nchunks + cpw - 1) / cpw;
+            if (strips * zblocks * kc <= ctx->num_cu && strips * zblocks <= 1024) {
+                gsmvi_launch_panel_fast(st, nullptr, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm,
+                                        ctx->pp, cpw, ncols, ctx->timeline_stamps(0), Out, ldo, addvec, ctx->seam_cnt);
+                return check_launch("k_panel_fast(seam)");
+            }
+        }
+    }
+    int kc = 1;
+    int rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, ncols, nrows, A, lda, shift, alpha, M, ldm, ctx->pp, &kc);
+    if (rc != GSMVI_OK) return rc;
+    gsmvi_launch_panel_finish(st, nullptr, ncols, nrows, kc, ctx->pp, addvec, Out, ldo, ncols);
+    return check_launch("k_panel_finish");
+}
+
+int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D, int ncols, int nrows,
+                           const double* A, int lda, const double* shift, double alpha, const double* M, int ldm,
                            double* Pp, int* kc_out) {
     const int strips = (ncols + 15) / 16;
     const int MT = nrows <= 16 ? 1 : (nrows <= 32 ? 2 : 4);
@@ -328,7 +369,7 @@ int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D
     *kc_out = kc;
     if (fast) {
         gsmvi_launch_panel_fast(st, ev, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm, Pp,
-                                cpw, ncols, ctx->timeline_stamps(0));
+                                cpw, ncols, ctx->timeline_stamps(0), nullptr, 0, nullptr, nullptr);
         return check_launch("k_panel_fast");
     }
     gsmvi_launch_panel_partial(st, ev, MT, dim3(strips, kc, zblocks), D, ncols, nrows, A, lda, shift, alpha, M,
@@ -537,11 +578,7 @@ int gsmvi_gaussian_score_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const d
     BAD_ARG(!X || !m || !P || !G, "NULL array");
     BAD_ARG(ldx < D || ldp < D || ldg < D, "leading dimension smaller than D");
     hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
-    int kc = 1;
-    st = gsmvi_panel_product(ctx, hs, nullptr, D, B, X, ldx, m, -1.0, P, ldp, ctx->pp, &kc);
-    if (st != GSMVI_OK) return st;
-    gsmvi_launch_panel_finish(hs, nullptr, D, B, kc, ctx->pp, nullptr, G, ldg, D);
-    return check_launch("k_panel_finish");
+    return gsmvi_panel_product_out(ctx, hs, D, D, B, X, ldx, m, -1.0, P, ldp, nullptr, G, ldg);
 }
 
 int gsmvi_sample_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* Z, int ldz, const double* mu,
@@ -551,11 +588,7 @@ int gsmvi_sample_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* Z
     BAD_ARG(!Z || !mu || !R || !X, "NULL array");
     BAD_ARG(ldz < D || ldr < D || ldx < D, "leading dimension smaller than D");
     hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
-    int kc = 1;
-    st = gsmvi_panel_product(ctx, hs, nullptr, D, B, Z, ldz, nullptr, 1.0, R, ldr, ctx->pp, &kc);
-    if (st != GSMVI_OK) return st;
-    gsmvi_launch_panel_finish(hs, nullptr, D, B, kc, ctx->pp, mu, X, ldx, D);
-    return check_launch("k_panel_finish");
+    return gsmvi_panel_product_out(ctx, hs, D, D, B, Z, ldz, nullptr, 1.0, R, ldr, mu, X, ldx);
 }
 
 int gsmvi_commit_f64(gsmvi_ctx* ctx, void* stream, int D, const int* info_dev, const double* mu_new,

@@ -29,6 +29,8 @@ struct gsmvi_ctx {
     unsigned long long* stamps = nullptr;   // [kernel][workgroup][8], allocated by the "timeline" knob
     int tune_potrf_v = 3;      // 1 = two launches per block step (round 1), 2 = one fused launch per step (k_potrf_step),
                                // 3 = the same with eight waves: W substitution beside the Cholesky (k_potrf_step8)
+    int tune_seam_finish = 1;  // 1 = split-K slabs of sample / score / U F / Gram products combined inside the product launch
+                               // (per-strip seam) where the grid fits one workgroup per CU; 0 = product + k_panel_finish
     int tune_small_v = 2;      // 1 = four-wave k_gsmf_small (reference), 2 = eight-wave k_gsmf_small8 (W beside the Cholesky)
     int tune_scalars_nt = 0;   // threads per sample in k_gsm_scalars_fast (256/512/1024; 0 = default)
     int tune_no_fast = 0;      // 1 = force the guarded generic kernels (tests)
@@ -57,6 +59,9 @@ struct gsmvi_ctx {
 int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D, int ncols, int nrows,
                            const double* A, int lda, const double* shift, double alpha, const double* M, int ldm,
                            double* Pp, int* kc_out);
+int gsmvi_panel_product_out(gsmvi_ctx* ctx, hipStream_t st, int D, int ncols, int nrows, const double* A, int lda,
+                            const double* shift, double alpha, const double* M, int ldm, const double* addvec, double* Out,
+                            int ldo);
 int gsmvi_panel_finish(hipStream_t st, int ncols, int nrows, int kc, const double* Pp, const double* addvec,
                        double* Out, int ldo);
 int gsmvi_panel_finish_cols(hipStream_t st, int ncols_in, int ncols_out, int nrows, int kc, const double* Pp,

@@ -1137,11 +1137,8 @@ static int factor_front(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doub
     }
     if ((rc = chk("k_gsmf_scalars"))) return rc;
     // bottom half of Tm: U Fm
-    int kc2 = 1;
-    if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, D, B, Rt + (size_t)B * D, D, nullptr, 1.0, F0, ldf0, ctx->pp,
-                                     &kc2)))
-        return rc;
-    return gsmvi_panel_finish(st, D, B, kc2, ctx->pp, nullptr, Tm + (size_t)B * D, D);
+    return gsmvi_panel_product_out(ctx, st, D, D, B, Rt + (size_t)B * D, D, nullptr, 1.0, F0, ldf0, nullptr,
+                                   Tm + (size_t)B * D, D);
 }
 
 static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
@@ -1199,8 +1196,7 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
     int* info_t = ctx->ints + 1;
     int rc, kc2 = 1;
     // Gamma = Rt Rt^T
-    if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, n, n, Rt, D, nullptr, 1.0, Rtt, nq, ctx->pp, &kc2))) return rc;
-    if ((rc = gsmvi_panel_finish(st, n, n, kc2, ctx->pp, nullptr, Gam, n))) return rc;
+    if ((rc = gsmvi_panel_product_out(ctx, st, D, n, n, Rt, D, nullptr, 1.0, Rtt, nq, nullptr, Gam, n))) return rc;
     if (n <= 64) {
         // everything small in one workgroup, then Fs = K Tm as one skinny GEMM (K = n)
         double* Kmat = Rg;                         // reuse the n x n slot

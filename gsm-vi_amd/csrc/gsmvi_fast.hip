@@ -35,8 +35,9 @@ template <int MT, bool HAS_SHIFT, int CHW>
 __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const double* __restrict__ A, int lda,
                                                     const double* __restrict__ shift, double alpha,
                                                     const double* __restrict__ M, int ldm,
-                                                    double* __restrict__ Pp, int chunks_per_wg, int ncols,
-                                                    unsigned long long* __restrict__ stamps) {
+                                                    double* Pp, int chunks_per_wg, int ncols,
+                                                    unsigned long long* __restrict__ stamps, double* __restrict__ Out,
+                                                    int ldo, const double* __restrict__ addvec, unsigned* cnt) {
 #define PSTAMP(k)                                                                                              \
     do {                                                                                                       \
         if (stamps && threadIdx.x == 0)                                                                        \
@@ -130,6 +131,13 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[(w * NR + 16 * mt + ks + 4 * r) * 17 + c] = acc[mt][r];
     __syncthreads();
+    // Out == nullptr: the slab Pp[kc] is the result (a finish pass or a consumer sums the KC slabs).
+    // Out != nullptr: FINISHED output Out = addvec + sum_kc slab[kc] from this launch -- for KC == 1 directly; otherwise through
+    // the per-strip seam of gsmvi_fused.hip (pieces stored write-through, one agent-scope ticket per workgroup, the last of
+    // the strip's KC workgroups sums the pieces in the order of k_panel_finish: results are bit-identical to product +
+    // finish).  The ABI takes this form only while the grid has at most one workgroup per CU.
+    const int KC = gridDim.y;
+    const bool seam = Out != nullptr && KC > 1;
     for (int idx = tid; idx < NR * 16; idx += 512) {
         const int rr = idx >> 4, cc = idx & 15;
         const int row = r0 + rr;
@@ -137,7 +145,36 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
             double s = 0.0;
 #pragma unroll
             for (int ww = 0; ww < 8; ww += 2) s += red[(ww * NR + rr) * 17 + cc] + red[((ww + 1) * NR + rr) * 17 + cc];
-            Pp[((size_t)blockIdx.y * nrows + row) * ncols + blockIdx.x * 16 + cc] = s;
+            double* dst = &Pp[((size_t)blockIdx.y * nrows + row) * ncols + blockIdx.x * 16 + cc];
+            if (Out == nullptr) *dst = s;
+            else if (!seam) Out[(size_t)row * ldo + blockIdx.x * 16 + cc] = s + (addvec ? addvec[blockIdx.x * 16 + cc] : 0.0);
+            else __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1: write-through
+        }
+    }
+    if (seam) {
+        __shared__ unsigned s_ticket;
+        unsigned* my_cnt = cnt + (size_t)blockIdx.z * gridDim.x + blockIdx.x;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) s_ticket = __hip_atomic_fetch_add(my_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_ticket == (unsigned)(KC - 1)) {
+            if (tid == 0) __hip_atomic_store(my_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int idx = tid; idx < NR * 16; idx += 512) {
+                const int rr = idx >> 4, cc = idx & 15;
+                const int row = r0 + rr;
+                if (row < nrows) {
+                    double pv[8];
+#pragma unroll
+                    for (int kc = 0; kc < 8; ++kc)
+                        pv[kc] = __hip_atomic_load(&Pp[((size_t)(kc < KC ? kc : KC - 1) * nrows + row) * ncols +
+                                                       blockIdx.x * 16 + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    double t = 0.0;
+#pragma unroll
+                    for (int kc = 0; kc < 8; ++kc) t += (kc < KC) ? pv[kc] : 0.0;
+                    Out[(size_t)row * ldo + blockIdx.x * 16 + cc] = t + (addvec ? addvec[blockIdx.x * 16 + cc] : 0.0);
+                }
+            }
         }
     }
     if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PSTAMP(3); }
@@ -406,10 +443,11 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
 // ---- launch helpers ------------------------------------------------------------------------
 void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int nrows, const double* A,
                              int lda, const double* shift, double alpha, const double* M, int ldm, double* Pp,
-                             int chunks_per_wg, int ncols, unsigned long long* stamps) {
+                             int chunks_per_wg, int ncols, unsigned long long* stamps, double* Out, int ldo,
+                             const double* addvec, unsigned* cnt) {
 #define PF(MTV, HS, CW)                                                                                          \
     GSMVI_LAUNCH((k_panel_fast<MTV, HS, CW>), grid, dim3(512), 0, st, ev, D, nrows, A, lda, shift, alpha, M, ldm, \
-                 Pp, chunks_per_wg, ncols, stamps)
+                 Pp, chunks_per_wg, ncols, stamps, Out, ldo, addvec, cnt)
     if (shift) {
         if (MT == 1) PF(1, true, 256); else if (MT == 2) PF(2, true, 256); else PF(4, true, 128);
     } else {

@@ -24,6 +24,7 @@ def eng():
     e.set_tuning("fused", 1)            # opt-in path (default off: measured no faster than three launches)
     yield e
     e.set_tuning("fused", 0)
+    e.set_tuning("seam_finish", 1)
     e.set_tuning("fused_flags", 0)
     e.set_tuning("timeline", 0)
 
@@ -143,3 +144,42 @@ def test_chained_fused_updates_follow_the_oracle(eng):
         mu_o, S_o = orc.gsm_update_batched(X, Gs, mu_o, S_o)
         mu_d, S_d = eng.gsm_update(eng.asarray(X), eng.asarray(Gs), mu_d, S_d)
         assert rel_err(mu_d.cpu().numpy(), mu_o) < 1e-9 and rel_err(S_d.cpu().numpy(), S_o) < 1e-9, it
+
+
+def test_seam_finished_panel_products_equal_product_plus_finish(eng):
+    """sample / score / U F / Gram products with the split-K slabs combined inside the product launch (per-strip seam of
+    k_panel_fast) against the same products followed by k_panel_finish (knob seam_finish=0): bit-identical, also under
+    uneven load and in a tight loop (the hand-off is the one of k_panel_seam)."""
+    import torch
+    from oracle import gsm_oracle as orc
+    for D, B in ((1024, 32), (1024, 16), (512, 64), (256, 8), (1024, 4)):
+        st = orc.make_update_state(D, B, D + B)
+        X, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "mu0", "S0"))
+        Z = eng.asarray(st["Z"])
+        m, P = eng.asarray(st["m"]), eng.asarray(st["P"])
+        R, _ = eng.potrf(S0)
+        eng.set_tuning("seam_finish", 0)
+        Xr, Gr = eng.sample(Z, mu0, R).clone(), eng.gaussian_score(X, m, P).clone()
+        eng.set_tuning("seam_finish", 1)
+        side = torch.cuda.Stream()
+        A = torch.randn(2048, 2048, device=eng.device)
+        bad = 0
+        for rep in range(25):
+            with torch.cuda.stream(side):
+                n = 256 * (1 + rep % 8)
+                (A[:n, :n] @ A[:n, :n]).sum()
+            outs = [(eng.sample(Z, mu0, R), eng.gaussian_score(X, m, P)) for _ in range(4)]
+            torch.cuda.synchronize()
+            bad += sum(0 if (torch.equal(a, Xr) and torch.equal(b, Gr)) else 1 for a, b in outs)
+        assert bad == 0, (D, B, bad)
+        assert rel_err(Gr.cpu().numpy(), orc.gaussian_score(st["samples"], st["m"], st["P"])) < 1e-9
+    # the factor update (U F and Gram products through the seam) against its finish-kernel form
+    st = orc.make_update_state(1024, 32, 5)
+    F0 = eng.asarray(st["L"].T.copy())
+    args = (eng.asarray(st["Z"]), eng.asarray(st["samples"]), eng.asarray(st["vs"]), eng.asarray(st["mu0"]), F0)
+    eng.set_tuning("seam_finish", 0)
+    mu_r, F_r, _ = eng.gsm_factor_update(*args)
+    eng.set_tuning("seam_finish", 1)
+    for _ in range(20):
+        mu_s, F_s, fl = eng.gsm_factor_update(*args)
+        assert torch.equal(mu_s, mu_r) and torch.equal(F_s, F_r) and eng.read_flag(fl) == 0
