@@ -72,7 +72,7 @@ class BaM:
         self._engine = engine
 
     def fit(self, key, regf, mean=None, cov=None, batch_size=2, niter=5000, nprint=10, verbose=True,
-            check_goodness=True, monitor=None, retries=10, jitter=1e-6, *, sampler="cholesky", rng="numpy",
+            check_goodness=True, monitor=None, retries=10, jitter=1e-6, *, sampler="cholesky", rng="auto",
             as_torch=False, forced_samples=None, shard=False, group=None, check_update_flag=False):
         """gsmvi/bam.py:140-216.  Kept: niter+1 iterations (:178); nprint clamp (:177); reg = regf(i)
         per attempt (:196); jitter on the diagonal and symmetrisation (:198-199, done in-kernel);
@@ -99,8 +99,8 @@ class BaM:
         cov_t = eng.eye(D) if cov is None else eng.clone(cov).reshape(D, D)
         seed = int(np.asarray(key.cpu() if _is_torch(key) else key).flatten()[-1])
         rs = np.random.RandomState(seed)
-        assert rng in ("numpy", "device"), "rng must be 'numpy' or 'device'"
-        dev_rng = rng == "device"
+        assert rng in ("auto", "numpy", "device"), "rng must be 'auto', 'numpy' or 'device'"
+        dev_rng = rng == "device" or (rng == "auto" and sampler == "cholesky")   # as GSM.fit: see its docstring
         Zbuf = eng.empty(B, D) if dev_rng else None
         ndraw = 0                       # counter-based stream: one `call` per draw, retries included
         native = bool(getattr(self.lp_g, "device_native", False))

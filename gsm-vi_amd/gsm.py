@@ -76,7 +76,7 @@ class GSM:
 
     # ------------------------------------------------------------------------------
     def fit(self, key, mean=None, cov=None, batch_size=2, niter=5000, nprint=10, verbose=True,
-            check_goodness=True, monitor=None, *, sampler="cholesky", rng="numpy", as_torch=False,
+            check_goodness=True, monitor=None, *, sampler="cholesky", rng="auto", as_torch=False,
             forced_samples=None, method="auto", shard=False, group=None):
         """Fit N(mean, cov) to the target (gsmvi/gsm_numpy.py:77-129, gsmvi/gsm.py:79-133).
 
@@ -93,7 +93,11 @@ class GSM:
         Extra keyword-only arguments (not in the reference):
           sampler : "cholesky" (default) x = mean + R^T z from the device Cholesky factor, or "svd":
                     the reference's legacy host sampler, bit-compatible sample stream (small D).
-          rng     : "numpy" (host MT19937 z-stream, uploaded: the reference's stream, gsm_numpy.py:105) or
+          rng     : "auto" (default) = "device" with the Cholesky sampler, "numpy" with sampler="svd".  With the
+                    Cholesky sampler the samples differ from the reference's (SVD factor) whatever the z-stream is,
+                    so the default takes the stream that keeps the iteration on the GPU (a host MT19937 draw of
+                    B x D normals plus its upload costs more than the whole device iteration).
+                    "numpy" (host MT19937 z-stream, uploaded: the reference's stream, gsm_numpy.py:105) or
                     "device" (counter-based Philox stream generated by gsmvi_randn_f64 from (key, iteration):
                     nothing crosses PCIe, and sharded ranks draw identical Z).
           forced_samples : (niter+1, B, D) teacher-forced samples replacing the sampler.
@@ -145,8 +149,8 @@ class GSM:
         nevals = 1
         seed = int(key) if not _is_torch(key) else int(key.flatten()[0])
         rs = np.random.RandomState(seed)
-        assert rng in ("numpy", "device"), "rng must be 'numpy' or 'device'"
-        dev_rng = rng == "device"
+        assert rng in ("auto", "numpy", "device"), "rng must be 'auto', 'numpy' or 'device'"
+        dev_rng = rng == "device" or (rng == "auto" and sampler == "cholesky")
         Zbuf = eng.empty(B, D) if dev_rng else None
         native = bool(getattr(self.lp_g, "device_native", False))
         mon_native = bool(getattr(monitor, "device_native", False)) if monitor is not None else False
@@ -233,8 +237,8 @@ class GSM:
             raise ValueError("initial covariance is not positive definite")
         seed = int(key) if not _is_torch(key) else int(key.flatten()[0])
         rs = np.random.RandomState(seed)
-        assert rng in ("numpy", "device"), "rng must be 'numpy' or 'device'"
-        dev_rng = rng == "device"
+        assert rng in ("auto", "numpy", "device"), "rng must be 'auto', 'numpy' or 'device'"
+        dev_rng = rng != "numpy"                            # the factor form always samples with its own factor
         Zbuf = eng.empty(B, D) if dev_rng else None
         native = bool(getattr(self.lp_g, "device_native", False))
         mon_native = bool(getattr(monitor, "device_native", False)) if monitor is not None else False
