@@ -329,13 +329,17 @@ int gsmvi_panel_product_out(gsmvi_ctx* ctx, hipStream_t st, int D, int ncols, in
     if (fast) {
         const int chw = gsmvi_panel_fast_chunk(MT);
         const int nchunks = (D + chw - 1) / chw;
-        int kc = ctx->tune_panel_kc > 0 ? ctx->tune_panel_kc : ctx->num_cu / (strips * zblocks);
+        // the split the plain product would take (two workgroups per CU wanted); the one-launch form is used only when
+        // that split needs no seam (kc == 1) or fits one workgroup per CU -- never at the price of fewer workgroups
+        // (D = 4096: kc = 2, 512 workgroups; forcing kc = 1 there cost 20 % of the product's speed)
+        int kc = ctx->tune_panel_kc > 0 ? ctx->tune_panel_kc
+                                        : (2 * ctx->num_cu + strips * zblocks - 1) / (strips * zblocks);
         if (kc > nchunks) kc = nchunks;
         if (kc > GSMVI_MAX_KC) kc = GSMVI_MAX_KC;
         if (kc >= 1) {
             const int cpw = (nchunks + kc - 1) / kc;
             kc = (nchunks + cpw - 1) / cpw;
-            if (strips * zblocks * kc <= ctx->num_cu && strips * zblocks <= 1024) {
+            if ((kc == 1 || strips * zblocks * kc <= ctx->num_cu) && strips * zblocks <= 1024) {
                 gsmvi_launch_panel_fast(st, nullptr, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm,
                                         ctx->pp, cpw, ncols, ctx->timeline_stamps(0), Out, ldo, addvec, ctx->seam_cnt);
                 return check_launch("k_panel_fast(seam)");

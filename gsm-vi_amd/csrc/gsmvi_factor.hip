@@ -301,14 +301,20 @@ __global__ __launch_bounds__(256) void k_gsmf_small_a(int n, int B, const double
 // tile per thread, chol64 of A22.  *info = 1-based index of the first bad pivot (0 = ok); R gets the upper
 // factor with a zero strictly-lower triangle.
 template <bool SEMIDEF>
-__global__ __launch_bounds__(256) void k_chol128(int n, const double* __restrict__ A, double* __restrict__ R,
+__global__ __launch_bounds__(512) void k_chol128(int n, const double* __restrict__ A, double* __restrict__ R,
                                                  int* __restrict__ info) {
+    // Eight waves (round 2).  Waves 0-3 factor A11 (chol64_rows_s needs exactly 256 threads) while waves 4-7 solve the block
+    // row R12 = R11^-T A12 ONE PIVOT BEHIND: substitution step p needs row p of the factor and its pivot only, both published
+    // (unscaled, in LDS) by the barrier that opens pivot p; the helpers execute one barrier per step, as in k_potrf_step8.
+    // A22 -= R12^T R12 then runs on the MFMA pipe with all eight waves (it was a VALU loop of 64 x 16 FMAs per thread), and
+    // the second block is factored by waves 0-3 with the helpers matching its barriers.  55 -> ~37 us per call.
     constexpr int MS = 130;
     __shared__ __attribute__((aligned(16))) double M[128 * MS];
     __shared__ double rinv[128];
     __shared__ int sh_fail[2];
     const int tid = threadIdx.x;
-    load_upper128(M, A, n);
+    const bool team = tid < 256;
+    if (team) load_upper128(M, A, n);
     if (tid < 128) rinv[tid] = 1.0;
     __syncthreads();
     bool moderate = true;
@@ -324,63 +330,85 @@ __global__ __launch_bounds__(256) void k_chol128(int n, const double* __restrict
         moderate = sh_fail[1] != 0;
         __syncthreads();
     }
-    chol64_rows_s<MS, SEMIDEF>(M, rinv, 64, &sh_fail[0], moderate);
-    {
-        const int colq = tid >> 2, q = tid & 3;
+    if (team) {
+        chol64_rows_s<MS, SEMIDEF>(M, rinv, 64, &sh_fail[0], moderate);
+    } else {
+        // column colq of A12 per quad of helper lanes; lane q owns the row pairs {8r + 2q, 8r + 2q + 1}
+        const int st = tid - 256, colq = st >> 2, q = st & 3;
         double x[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = M[(q + 4 * r) * MS + 64 + colq];
-#pragma unroll
-        for (int p = 0; p < 64; ++p) {
-            const int pr = p >> 2, pq = p & 3;
-            const double mine = x[pr] * rinv[p];
-            if (q == pq) x[pr] = mine;
-            const double xp = quad_bcast_rt<0>(mine, pq);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (4 * r + 3 > p) {
-                    const int t = q + 4 * r;
-                    const double rv = M[p * MS + t];
-                    x[r] -= (t > p) ? rv * xp : 0.0;
-                }
-            }
+        for (int r = 0; r < 8; ++r) {
+            x[2 * r] = M[(8 * r + 2 * q) * MS + 64 + colq];
+            x[2 * r + 1] = M[(8 * r + 2 * q + 1) * MS + 64 + colq];
         }
-        __syncthreads();                                         // all reads of the A12 block are done
+        double ri_prev = 0.0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) M[(q + 4 * r) * MS + 64 + colq] = x[r];
+        for (int p = 0; p <= 64; ++p) {
+            double ri = 0.0;
+            if (p < 64) {
+                __syncthreads();                                  // opens pivot p: row p and d_p are final
+                const double d = M[p * MS + p];
+                // the verdict chol64_rows_s reaches for this pivot: usable, or dropped / failed (then its row of R is zero)
+                const bool ok = d > 0.0 && d < 1.7976931348623157e308;
+                const double dd = ok ? d : 1.0;
+                double y = __builtin_amdgcn_rsq(dd);
+                y = y * (1.5 - 0.5 * dd * y * y);
+                y = y * (1.5 - 0.5 * dd * y * y);
+                ri = ok ? y : 0.0;
+            }
+            if (p > 0) {
+                const int ps = p - 1;
+                const int pr = 2 * (ps >> 3) + (ps & 1), pq = (ps >> 1) & 3;
+                const double mine = x[pr] * ri_prev;
+                if (q == pq) x[pr] = mine;
+                const double xp = quad_bcast_rt<0>(mine, pq) * ri_prev;
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (8 * r + 7 > ps) {
+                        const int t = 8 * r + 2 * q;
+                        const v2d rv = *reinterpret_cast<const v2d*>(&M[ps * MS + t]);
+                        x[2 * r] -= (t > ps) ? rv.x * xp : 0.0;
+                        x[2 * r + 1] -= (t + 1 > ps) ? rv.y * xp : 0.0;
+                    }
+            }
+            ri_prev = ri;
+        }
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+        // every helper is past its last read of the A12 block (all 64 steps precede the trailing barriers); rows of a
+        // dropped / failed pivot carry x_p * 0 = 0, as the sequential solve produced through rinv[p] = 0
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            M[(8 * r + 2 * q) * MS + 64 + colq] = x[2 * r];
+            M[(8 * r + 2 * q + 1) * MS + 64 + colq] = x[2 * r + 1];
+        }
     }
     __syncthreads();
     {
-        const int ty = tid >> 4, tx = tid & 15;
-        double acc[4][4];
+        // A22 -= R12^T R12 on the MFMA pipe: the 10 upper 16 x 16 blocks (bi <= bj) over eight waves, operands straight from
+        // M (A[k][i] = M[k][64 + i]: lanes of one k-slot read 16 consecutive doubles)
+        const int w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+        for (int blk = w; blk < 10; blk += 8) {
+            int bi = 0, rem = blk;
+            while (rem >= 4 - bi) { rem -= 4 - bi; ++bi; }
+            const int bj = bi + rem;
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            const double* ap = M + ks * MS + 64 + 16 * bi + c;
+            const double* bp = M + ks * MS + 64 + 16 * bj + c;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+            for (int s = 0; s < 16; ++s) acc = GSMVI_MFMA_F64(ap[4 * s * MS], bp[4 * s * MS], acc);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-#pragma unroll 4
-        for (int p = 0; p < 64; ++p) {
-            double ra[4], rb[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                ra[a] = M[p * MS + 64 + ty + 16 * a];
-                rb[a] = M[p * MS + 64 + tx + 16 * a];
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * bi + ks + 4 * r, j = 16 * bj + c;
+                if (j >= i) M[(64 + i) * MS + 64 + j] -= acc[r];
             }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] += ra[a] * rb[b];
         }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int i = ty + 16 * a, j = tx + 16 * b;
-                if (j >= i) M[(64 + i) * MS + 64 + j] -= acc[a][b];
-            }
     }
     __syncthreads();
-    chol64_rows_s<MS, SEMIDEF>(M + 64 * MS + 64, rinv + 64, n - 64, &sh_fail[1], moderate);
-    for (int e = tid; e < n * n; e += 256) {
+    if (team) chol64_rows_s<MS, SEMIDEF>(M + 64 * MS + 64, rinv + 64, n - 64, &sh_fail[1], moderate);
+    else chol64_helper_idle<MS>(n - 64);
+    for (int e = tid; e < n * n; e += 512) {
         const int i = e / n, j = e % n;
         R[e] = (j >= i) ? M[i * MS + j] : 0.0;
     }
@@ -1220,9 +1248,9 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         double* Kmat = Gam;                        // Gamma is dead once Rg exists
         double* Wm = Ap;                           // A' is dead once T exists
         double* Pm = Tt + (size_t)n * n;           // fifth n x n slot of the small-matrix workspace
-        hipLaunchKernelGGL(k_chol128<true>, dim3(1), dim3(256), 0, st, n, Gam, Rg, info_g);   // Gram matrix: semi-definite rule
+        hipLaunchKernelGGL(k_chol128<true>, dim3(1), dim3(512), 0, st, n, Gam, Rg, info_g);   // Gram matrix: semi-definite rule
         hipLaunchKernelGGL(k_gsmf_small_a, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, st, n, B, Rg, info_g, Ap);
-        hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(256), 0, st, n, Ap, Tt, info_t);
+        hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n, Ap, Tt, info_t);
         if ((rc = chk("k_chol128"))) return rc;
         hipLaunchKernelGGL(k_gsmf_kmat_big, dim3((n + 15) / 16), dim3(256), 0, st, n, Rg, Wm, info_g, info_t,
                            info_dev);
