@@ -28,10 +28,36 @@ __device__ __forceinline__ double quad_bcast_rt(double v, int q) {  // run-time 
     return q == 0 ? a : (q == 1 ? b : (q == 2 ? c : d));
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+// One DPP-permuted copy of a double (two 32-bit DPP moves; CTRL is a DPP control word: quad_perm 0x00-0xFF,
+// row_half_mirror 0x141, row_mirror 0x140).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffu), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// Sum over the 16 lanes of each DPP row (lanes 16k .. 16k+15), result in every lane of the row; fixed order.
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_f64<0xB1>(v);            // quad_perm [1,0,3,2]: neighbour
+    v += dpp_f64<0x4E>(v);            // quad_perm [2,3,0,1]: other pair of the quad
+    v += dpp_f64<0x141>(v);           // row_half_mirror: the other quad of the half row
+    v += dpp_f64<0x140>(v);           // row_mirror: the other half row
     return v;
+}
+// Sum over the 64 lanes of the wave, result in every lane; fixed order (rows 0..3 added left to right).  Pure VALU + four
+// v_readlane pairs: the ds_bpermute butterfly this replaces put six LDS-pipeline round trips on the dependent chain.
+__device__ __forceinline__ double wave_sum(double v) {
+    v = row16_sum(v);
+    const unsigned long long u = __double_as_longlong(v);
+    double r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)(u & 0xffffffffu), 16 * k);
+        const unsigned hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), 16 * k);
+        r[k] = __longlong_as_double(((unsigned long long)hi << 32) | lo);
+    }
+    return ((r[0] + r[1]) + r[2]) + r[3];
 }
 
 // Deterministic block sum of up to NV values per thread for a 256-thread block.

@@ -36,13 +36,7 @@ __device__ __forceinline__ double ld_sc1(const double* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // sum over the 16 lanes that share l >> 4 (fixed butterfly order; every lane gets the result)
-__device__ __forceinline__ double sum16(double v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    return v;
-}
+__device__ __forceinline__ double sum16(double v) { return row16_sum(v); }
 
 // =====================================================================================
 // SG = G S0 with the per-strip seam.  Grid (D/16 strips, KC, 1), 512 threads; B = 16 MT samples, D % 64 == 0,
