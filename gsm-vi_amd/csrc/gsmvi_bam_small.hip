@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void k_bam_ns_bb(int n, const double* __restri
 // substitution, the rank-64 update of the second block on the VALU (as k_chol128 in the factor path).  n = 129: the
 // last column is bordered on: r = R11^-T a by one wave, rho = sqrt(alpha - r.r).
 // Outputs: Ld (n x n, lower L = R^T), Ldinv (n), zg (n), vg (n) behind it, Upk (packed rows of R from the diagonal).
-__global__ __launch_bounds__(256) void k_bam_chol_out(int n, double reg, const double* __restrict__ BBg,
+__global__ __launch_bounds__(512) void k_bam_chol_out(int n, double reg, const double* __restrict__ BBg,
                                                       const double* __restrict__ M1, const double* __restrict__ N0,
                                                       double* __restrict__ Ld, double* __restrict__ Upk,
                                                       int* __restrict__ info) {
@@ -342,22 +342,29 @@ __global__ __launch_bounds__(256) void k_bam_chol_out(int n, double reg, const d
     double* Ldinv = Ld + (size_t)n * n;
     double* zg = Ldinv + n;
     double* vg = zg + n;
+    // Eight waves since round 2: waves 0-3 ("team") run everything written for 256 threads; waves 4-7 only help in the
+    // blocked part -- the block row R12 one pivot behind the factorisation of A11 and the MFMA rank-64 update (the shared
+    // pieces of gsmvi_chol64.h, as k_chol128 of the factor path) -- match the barriers of the second factorisation and
+    // leave (a finished wave no longer takes part in the workgroup's barriers).
+    const bool team = tid < 256;
     // load the upper triangle of the leading block (identity beyond n1) and, for n = 129, the border column
     int nan_in = 0;
+    if (team) {
 #pragma unroll 1
-    for (int e0 = 0; e0 < 128 * 128; e0 += 256 * 16) {      // sixteen clamped loads in flight per thread
-        double v[16];
+        for (int e0 = 0; e0 < 128 * 128; e0 += 256 * 16) {      // sixteen clamped loads in flight per thread
+            double v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int e = e0 + 256 * u + tid, i = e >> 7, j = e & 127;
-            v[u] = BBg[(size_t)(i < n1 ? i : n1 - 1) * n + (j < n1 ? j : n1 - 1)];
-        }
+            for (int u = 0; u < 16; ++u) {
+                const int e = e0 + 256 * u + tid, i = e >> 7, j = e & 127;
+                v[u] = BBg[(size_t)(i < n1 ? i : n1 - 1) * n + (j < n1 ? j : n1 - 1)];
+            }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int e = e0 + 256 * u + tid, i = e >> 7, j = e & 127;
-            const bool in = i < n1 && j < n1;
-            if (in && !(v[u] == v[u])) nan_in = 1;
-            M[i * MS + j] = in ? (j >= i ? v[u] : 0.0) : (i == j ? 1.0 : 0.0);
+            for (int u = 0; u < 16; ++u) {
+                const int e = e0 + 256 * u + tid, i = e >> 7, j = e & 127;
+                const bool in = i < n1 && j < n1;
+                if (in && !(v[u] == v[u])) nan_in = 1;
+                M[i * MS + j] = in ? (j >= i ? v[u] : 0.0) : (i == j ? 1.0 : 0.0);
+            }
         }
     }
     if (n > 128 && tid < 128) M[tid * MS + 128] = BBg[(size_t)tid * n + 128];
@@ -366,63 +373,19 @@ __global__ __launch_bounds__(256) void k_bam_chol_out(int n, double reg, const d
     __syncthreads();
     if (nan_in) sh_bad = 1;
     __syncthreads();
-    chol64_rows_s<MS>(M, rinv, n1 < 64 ? n1 : 64, &sh_fail[0]);
     if (n1 > 64) {
-        // block row R12 = R11^-T A12 (64 columns, one per quad of lanes), A22 -= R12^T R12, factor A22
-        const int colq = tid >> 2, q = tid & 3;
-        double x[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = M[(q + 4 * r) * MS + 64 + colq];
-#pragma unroll
-        for (int p = 0; p < 64; ++p) {
-            const int pr = p >> 2, pq = p & 3;
-            const double mine = x[pr] * rinv[p];
-            if (q == pq) x[pr] = mine;
-            const double xp = quad_bcast_rt<0>(mine, pq);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (4 * r + 3 > p) {
-                    const int t = q + 4 * r;
-                    const double rv = M[p * MS + t];
-                    x[r] -= (t > p) ? rv * xp : 0.0;
-                }
-            }
-        }
+        if (team) chol64_rows_s<MS>(M, rinv, 64, &sh_fail[0]);
+        else chol128_helper_rowsolve<MS>(M);            // R12 = R11^-T A12 (64 columns), one pivot behind
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) M[(q + 4 * r) * MS + 64 + colq] = x[r];
+        chol128_rank64_update<MS>(M);                    // A22 -= R12^T R12 on the MFMA pipe
         __syncthreads();
-        {
-            const int ty = tid >> 4, tx = tid & 15;
-            double acc[4][4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-#pragma unroll 4
-            for (int p = 0; p < 64; ++p) {
-                double ra[4], rb[4];
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    ra[a] = M[p * MS + 64 + ty + 16 * a];
-                    rb[a] = M[p * MS + 64 + tx + 16 * a];
-                }
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) acc[a][b] += ra[a] * rb[b];
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int i = ty + 16 * a, j = tx + 16 * b;
-                    if (j >= i) M[(64 + i) * MS + 64 + j] -= acc[a][b];
-                }
-        }
-        __syncthreads();
-        chol64_rows_s<MS>(M + 64 * MS + 64, rinv + 64, n1 - 64, &sh_fail[1]);
+        if (team) chol64_rows_s<MS>(M + 64 * MS + 64, rinv + 64, n1 - 64, &sh_fail[1]);
+        else chol64_helper_idle<MS>(n1 - 64);
+    } else {
+        if (team) chol64_rows_s<MS>(M, rinv, n1, &sh_fail[0]);
+        else chol64_helper_idle<MS>(n1);
     }
+    if (!team) return;
     __syncthreads();
 
     // vg = Vf gbar = M1[:, n-1] / r1s and a = P gbar + M1^T vg (bam.py:107 applied to gbar) do not depend on the factor:
@@ -539,7 +502,7 @@ int gsmvi_bam_small_device(hipStream_t st, int n, double reg, const double* Nd, 
             hipLaunchKernelGGL(k_bam_ns_tail, dim3(1), dim3(1024), 0, st, n, kenq, Ya, Za, Yb, Zb, Mm, coef);
         hipLaunchKernelGGL(k_bam_ns_bb, dim3((n * n + 255) / 256), dim3(256), 0, st, n, Nd, Ya, Yb, coef, BBg);
     }
-    hipLaunchKernelGGL(k_bam_chol_out, dim3(1), dim3(256), 0, st, n, reg, BBg, M1, N0, Ld, Upk, info_dev);
+    hipLaunchKernelGGL(k_bam_chol_out, dim3(1), dim3(512), 0, st, n, reg, BBg, M1, N0, Ld, Upk, info_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         gsmvi_set_error("BaM small-matrix launch failed: %s%s", hipGetErrorString(e), "");

@@ -242,6 +242,86 @@ __device__ __forceinline__ void chol64_helper_idle(int nb) {
     __syncthreads();
 }
 
+// ---- shared pieces of the 2 x 2-block Cholesky of an n x n matrix, 64 < n <= 128, held in LDS as M[128][MS] -------------
+// (k_chol128 of the factor path, k_bam_chol_out of BaM; both run eight waves: waves 0-3 call chol64_rows_s.)
+// Helper waves (threads 256..511) while waves 0-3 factor A11 = M[0:64][0:64]: the block row R12 = R11^-T A12 ONE PIVOT
+// BEHIND the factorisation.  Substitution step p needs row p of the factor and its pivot only; chol64_rows_s has published
+// both (unscaled) by the barrier that opens pivot p.  One workgroup barrier per step + the three trailing ones = the barrier
+// count of chol64_rows_s with nb = 64.  Column colq of A12 per quad of lanes; lane q owns the row pairs {8r + 2q, 8r + 2q + 1}
+// (ds_read_b128 of the published row); pivot broadcast by DPP.  A dropped / failed pivot (d <= 0, NaN) contributes a zero row,
+// as the sequential solve did through rinv[p] = 0.
+template <int MS>
+__device__ __forceinline__ void chol128_helper_rowsolve(double* M) {
+    const int st = threadIdx.x - 256, colq = st >> 2, q = st & 3;
+    double x[16];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        x[2 * r] = M[(8 * r + 2 * q) * MS + 64 + colq];
+        x[2 * r + 1] = M[(8 * r + 2 * q + 1) * MS + 64 + colq];
+    }
+    double ri_prev = 0.0;
+#pragma unroll
+    for (int p = 0; p <= 64; ++p) {
+        double ri = 0.0;
+        if (p < 64) {
+            __syncthreads();                                      // opens pivot p: row p and d_p are final
+            const double d = M[p * MS + p];
+            const bool ok = d > 0.0 && d < 1.7976931348623157e308;
+            const double dd = ok ? d : 1.0;
+            double y = __builtin_amdgcn_rsq(dd);
+            y = y * (1.5 - 0.5 * dd * y * y);
+            y = y * (1.5 - 0.5 * dd * y * y);
+            ri = ok ? y : 0.0;
+        }
+        if (p > 0) {
+            const int ps = p - 1;
+            const int pr = 2 * (ps >> 3) + (ps & 1), pq = (ps >> 1) & 3;
+            const double mine = x[pr] * ri_prev;
+            if (q == pq) x[pr] = mine;
+            const double xp = quad_bcast_rt<0>(mine, pq) * ri_prev;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (8 * r + 7 > ps) {
+                    const int t = 8 * r + 2 * q;
+                    const v2d rv = *reinterpret_cast<const v2d*>(&M[ps * MS + t]);
+                    x[2 * r] -= (t > ps) ? rv.x * xp : 0.0;
+                    x[2 * r + 1] -= (t + 1 > ps) ? rv.y * xp : 0.0;
+                }
+        }
+        ri_prev = ri;
+    }
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {                                 // every helper is past its last read of the A12 block
+        M[(8 * r + 2 * q) * MS + 64 + colq] = x[2 * r];
+        M[(8 * r + 2 * q + 1) * MS + 64 + colq] = x[2 * r + 1];
+    }
+}
+
+// A22 -= R12^T R12 on the MFMA pipe, all eight waves: the 10 upper 16 x 16 blocks (bi <= bj), operands straight from M
+// (A[k][i] = M[k][64 + i]: the lanes of one k-slot read 16 consecutive doubles).  Call between two workgroup barriers.
+template <int MS>
+__device__ __forceinline__ void chol128_rank64_update(double* M) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 15, ks = l >> 4;
+    for (int blk = w; blk < 10; blk += 8) {
+        int bi = 0, rem = blk;
+        while (rem >= 4 - bi) { rem -= 4 - bi; ++bi; }
+        const int bj = bi + rem;
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        const double* ap = M + ks * MS + 64 + 16 * bi + c;
+        const double* bp = M + ks * MS + 64 + 16 * bj + c;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = GSMVI_MFMA_F64(ap[4 * s * MS], bp[4 * s * MS], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * bi + ks + 4 * r, j = 16 * bj + c;
+            if (j >= i) M[(64 + i) * MS + 64 + j] -= acc[r];
+        }
+    }
+}
+
 __device__ __forceinline__ void chol64_lds(double* T, double* rinv, int nb, int* sh_fail) {
 #ifdef GSMVI_CHOL64_BLOCKED
     chol64_lds_s<TS>(T, rinv, nb, sh_fail);

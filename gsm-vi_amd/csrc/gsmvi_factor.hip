@@ -330,81 +330,10 @@ __global__ __launch_bounds__(512) void k_chol128(int n, const double* __restrict
         moderate = sh_fail[1] != 0;
         __syncthreads();
     }
-    if (team) {
-        chol64_rows_s<MS, SEMIDEF>(M, rinv, 64, &sh_fail[0], moderate);
-    } else {
-        // column colq of A12 per quad of helper lanes; lane q owns the row pairs {8r + 2q, 8r + 2q + 1}
-        const int st = tid - 256, colq = st >> 2, q = st & 3;
-        double x[16];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            x[2 * r] = M[(8 * r + 2 * q) * MS + 64 + colq];
-            x[2 * r + 1] = M[(8 * r + 2 * q + 1) * MS + 64 + colq];
-        }
-        double ri_prev = 0.0;
-#pragma unroll
-        for (int p = 0; p <= 64; ++p) {
-            double ri = 0.0;
-            if (p < 64) {
-                __syncthreads();                                  // opens pivot p: row p and d_p are final
-                const double d = M[p * MS + p];
-                // the verdict chol64_rows_s reaches for this pivot: usable, or dropped / failed (then its row of R is zero)
-                const bool ok = d > 0.0 && d < 1.7976931348623157e308;
-                const double dd = ok ? d : 1.0;
-                double y = __builtin_amdgcn_rsq(dd);
-                y = y * (1.5 - 0.5 * dd * y * y);
-                y = y * (1.5 - 0.5 * dd * y * y);
-                ri = ok ? y : 0.0;
-            }
-            if (p > 0) {
-                const int ps = p - 1;
-                const int pr = 2 * (ps >> 3) + (ps & 1), pq = (ps >> 1) & 3;
-                const double mine = x[pr] * ri_prev;
-                if (q == pq) x[pr] = mine;
-                const double xp = quad_bcast_rt<0>(mine, pq) * ri_prev;
-#pragma unroll
-                for (int r = 0; r < 8; ++r)
-                    if (8 * r + 7 > ps) {
-                        const int t = 8 * r + 2 * q;
-                        const v2d rv = *reinterpret_cast<const v2d*>(&M[ps * MS + t]);
-                        x[2 * r] -= (t > ps) ? rv.x * xp : 0.0;
-                        x[2 * r + 1] -= (t + 1 > ps) ? rv.y * xp : 0.0;
-                    }
-            }
-            ri_prev = ri;
-        }
-        __syncthreads();
-        __syncthreads();
-        __syncthreads();
-        // every helper is past its last read of the A12 block (all 64 steps precede the trailing barriers); rows of a
-        // dropped / failed pivot carry x_p * 0 = 0, as the sequential solve produced through rinv[p] = 0
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            M[(8 * r + 2 * q) * MS + 64 + colq] = x[2 * r];
-            M[(8 * r + 2 * q + 1) * MS + 64 + colq] = x[2 * r + 1];
-        }
-    }
+    if (team) chol64_rows_s<MS, SEMIDEF>(M, rinv, 64, &sh_fail[0], moderate);
+    else chol128_helper_rowsolve<MS>(M);               // R12 = R11^-T A12, one pivot behind (gsmvi_chol64.h)
     __syncthreads();
-    {
-        // A22 -= R12^T R12 on the MFMA pipe: the 10 upper 16 x 16 blocks (bi <= bj) over eight waves, operands straight from
-        // M (A[k][i] = M[k][64 + i]: lanes of one k-slot read 16 consecutive doubles)
-        const int w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
-        for (int blk = w; blk < 10; blk += 8) {
-            int bi = 0, rem = blk;
-            while (rem >= 4 - bi) { rem -= 4 - bi; ++bi; }
-            const int bj = bi + rem;
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
-            const double* ap = M + ks * MS + 64 + 16 * bi + c;
-            const double* bp = M + ks * MS + 64 + 16 * bj + c;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) acc = GSMVI_MFMA_F64(ap[4 * s * MS], bp[4 * s * MS], acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * bi + ks + 4 * r, j = 16 * bj + c;
-                if (j >= i) M[(64 + i) * MS + 64 + j] -= acc[r];
-            }
-        }
-    }
+    chol128_rank64_update<MS>(M);                       // A22 -= R12^T R12 on the MFMA pipe
     __syncthreads();
     if (team) chol64_rows_s<MS, SEMIDEF>(M + 64 * MS + 64, rinv + 64, n - 64, &sh_fail[1], moderate);
     else chol64_helper_idle<MS>(n - 64);
