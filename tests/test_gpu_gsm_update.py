@@ -308,3 +308,21 @@ def test_nonsymmetric_s0_keeps_the_reference_semantics(eng):
     assert abs(S[5, 40] - S[40, 5] - 0.25) < 1e-12
     mu2, S2 = gsmvi_amd.gsm_update(st["samples"], st["vs"], st["mu0"], st["S0"])      # symmetric: fast path again
     assert np.array_equal(S2, S2.T)
+
+
+@pytest.mark.parametrize("D", [100, 256, 1024])
+def test_potrf_versions_agree(eng, D):
+    """The reference forms kept behind the potrf_v knob (1 = round-1 two-launch step, 2 = fused step with four waves)
+    against the default eight-wave step: same factor to round-off, same flag."""
+    orc = _oracle()
+    st = orc.make_update_state(D, 2, D)
+    S = eng.asarray(st["S0"])
+    R3, f3 = eng.potrf(S)
+    try:
+        for v in (1, 2):
+            eng.set_tuning("potrf_v", v)
+            Rv, fv = eng.potrf(S)
+            assert eng.read_flag(fv) == eng.read_flag(f3) == 0
+            assert rel_err(Rv.cpu().numpy(), R3.cpu().numpy()) < 1e-11, v
+    finally:
+        eng.set_tuning("potrf_v", 3)
