@@ -339,7 +339,11 @@ int gsmvi_panel_product_out(gsmvi_ctx* ctx, hipStream_t st, int D, int ncols, in
         if (kc >= 1) {
             const int cpw = (nchunks + kc - 1) / kc;
             kc = (nchunks + cpw - 1) / cpw;
-            if ((kc == 1 || strips * zblocks * kc <= ctx->num_cu) && strips * zblocks <= 1024) {
+            // seam_finish = 1 (default): only the hand-off-free case (kc == 1: the product writes the finished output
+            // itself); = 2 also the per-strip seam (an in-kernel cross-workgroup hand-off: +2 % fit rate at D = 1024,
+            // bit-identical in every test including uneven load, kept opt-in like the two-launch dense update)
+            if ((kc == 1 || (ctx->tune_seam_finish >= 2 && strips * zblocks * kc <= ctx->num_cu)) &&
+                strips * zblocks <= 1024) {
                 gsmvi_launch_panel_fast(st, nullptr, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm,
                                         ctx->pp, cpw, ncols, ctx->timeline_stamps(0), Out, ldo, addvec, ctx->seam_cnt);
                 return check_launch("k_panel_fast(seam)");

@@ -29,8 +29,9 @@ struct gsmvi_ctx {
     unsigned long long* stamps = nullptr;   // [kernel][workgroup][8], allocated by the "timeline" knob
     int tune_potrf_v = 3;      // 1 = two launches per block step (round 1), 2 = one fused launch per step (k_potrf_step),
                                // 3 = the same with eight waves: W substitution beside the Cholesky (k_potrf_step8)
-    int tune_seam_finish = 1;  // 1 = split-K slabs of sample / score / U F / Gram products combined inside the product launch
-                               // (per-strip seam) where the grid fits one workgroup per CU; 0 = product + k_panel_finish
+    int tune_seam_finish = 1;  // finished outputs of sample / score / U F / Gram products from the product launch: 0 = never
+                               // (product + k_panel_finish), 1 = when the split-K count is 1 (no hand-off involved; default),
+                               // 2 = also through the per-strip seam where the grid fits one workgroup per CU
     int tune_small_v = 2;      // 1 = four-wave k_gsmf_small (reference), 2 = eight-wave k_gsmf_small8 (W beside the Cholesky)
     int tune_scalars_nt = 0;   // threads per sample in k_gsm_scalars_fast (256/512/1024; 0 = default)
     int tune_no_fast = 0;      // 1 = force the guarded generic kernels (tests)

@@ -160,7 +160,7 @@ def test_seam_finished_panel_products_equal_product_plus_finish(eng):
         R, _ = eng.potrf(S0)
         eng.set_tuning("seam_finish", 0)
         Xr, Gr = eng.sample(Z, mu0, R).clone(), eng.gaussian_score(X, m, P).clone()
-        eng.set_tuning("seam_finish", 1)
+        eng.set_tuning("seam_finish", 2)
         side = torch.cuda.Stream()
         A = torch.randn(2048, 2048, device=eng.device)
         bad = 0
@@ -179,7 +179,7 @@ def test_seam_finished_panel_products_equal_product_plus_finish(eng):
     args = (eng.asarray(st["Z"]), eng.asarray(st["samples"]), eng.asarray(st["vs"]), eng.asarray(st["mu0"]), F0)
     eng.set_tuning("seam_finish", 0)
     mu_r, F_r, _ = eng.gsm_factor_update(*args)
-    eng.set_tuning("seam_finish", 1)
+    eng.set_tuning("seam_finish", 2)
     for _ in range(20):
         mu_s, F_s, fl = eng.gsm_factor_update(*args)
         assert torch.equal(mu_s, mu_r) and torch.equal(F_s, F_r) and eng.read_flag(fl) == 0
