@@ -201,6 +201,9 @@ int gsmvi_create(gsmvi_ctx** out, int device, int max_D, int max_B) {
     if (e == hipSuccess) e = gsmvi_cov_update_prepare();
     if (e == hipSuccess) e = gsmvi_bam_prepare();
     for (int k = 0; k < 8 && e == hipSuccess; ++k) e = hipEventCreate(&c->ev[k]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) {
         gsmvi_set_error("context initialisation failed: %s%s", hipGetErrorString(e), "");
         (void)hipFree(c->ws);
@@ -222,6 +225,9 @@ int gsmvi_destroy(gsmvi_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (int k = 0; k < 8; ++k)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->bam_hint_host) (void)hipHostFree(ctx->bam_hint_host);
     if (ctx->stamps) (void)hipFree(ctx->stamps);
@@ -240,6 +246,7 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     else if (!strcmp(name, "update_sb")) ctx->tune_update_sb = value;
     else if (!strcmp(name, "no_fast")) ctx->tune_no_fast = value;
     else if (!strcmp(name, "seam_finish")) ctx->tune_seam_finish = value;
+    else if (!strcmp(name, "fork")) ctx->tune_fork = value;
     else if (!strcmp(name, "small_v")) ctx->tune_small_v = value;
     else if (!strcmp(name, "potrf_v")) ctx->tune_potrf_v = value;
     else if (!strcmp(name, "fused")) ctx->tune_fused = value;

@@ -43,6 +43,11 @@ struct gsmvi_ctx {
     double* h_pin = nullptr;   // pinned host staging for BaM's small matrices (grown on demand)
     size_t h_pin_doubles = 0;
     int h_pin_busy = 0;        // ev[7] marks the end of the last upload from h_pin
+    hipStream_t side = nullptr;      // second stream of the factor update: U F runs beside the Gram product and the 2B x 2B chain
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int tune_fork = 0;         // 1 = U F of the factor update on the second stream beside the Gram product and the 2B x 2B chain.
+                               // Measured SLOWER (scripts/ab_fork.py: 79 -> 92 us per update in a graph at D=1024, B=32; 53 -> 74 us
+                               // at D=256; +1 % at D=4096): the two cross-stream event edges cost more than the 12 us they hide
     hipEvent_t ev[8] = {};     // [2*stage], [2*stage+1]: panel, scalars, cov-update, spare
     int ev_valid[4] = {};
 

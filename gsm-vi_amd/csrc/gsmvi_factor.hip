@@ -1076,7 +1076,7 @@ __global__ __launch_bounds__(256) void k_gsmf_unpack(int D, int B, const double*
 // Front half: per-sample stage for B samples.  Fills Rt = [Z; U] (2B x D), Rtt (D x 2B) and Tm = [X - mu; U Fm]
 // in the workspace (layout for n = 2B rows).
 static int factor_front(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
-                        const double* G, int ldg, const double* mu0, const double* F0, int ldf0) {
+                        const double* G, int ldg, const double* mu0, const double* F0, int ldf0, bool with_uf = true) {
     const int n = 2 * B, nq = n;
     double* Rt = ctx->sg;                          // n x D   [Z; U]
     double* Tm = Rt + (size_t)n * D;               // n x D   [X - mu; U Fm]
@@ -1093,20 +1093,43 @@ static int factor_front(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doub
 #undef GS
     }
     if ((rc = chk("k_gsmf_scalars"))) return rc;
+    if (!with_uf) return GSMVI_OK;
     // bottom half of Tm: U Fm
     return gsmvi_panel_product_out(ctx, st, D, D, B, Rt + (size_t)B * D, D, nullptr, 1.0, F0, ldf0, nullptr,
                                    Tm + (size_t)B * D, D);
 }
 
 static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
-                       double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev);
+                       double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, hipEvent_t join = nullptr);
 
 int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
                       const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double* mu, double* F,
                       int ldf, int* info_dev, int* n_reverts_dev) {
-    int rc = factor_front(ctx, st, D, B, Z, ldz, X, ldx, G, ldg, mu0, F0, ldf0);
+    // U F (a pass over the factor, needed only by Fs = K Tm at the very end) is independent of the Gram product and
+    // the one-workgroup 2B x 2B chain: it runs on the context's second stream beside them, forked and joined with
+    // events (graph-capturable: a capture of the caller's stream pulls the second stream in through the event wait).
+    // The two concurrent panel products get disjoint slab regions of the workspace.
+    const int n = 2 * B;
+    const size_t gram_slabs = (size_t)GSMVI_MAX_KC * n * n;
+    const bool fork = ctx->tune_fork && ctx->side && ctx->tune_seam_finish < 2 &&
+                      gram_slabs + (size_t)GSMVI_MAX_KC * B * D <= (size_t)GSMVI_MAX_KC * ctx->rmax * ctx->max_D;
+    int rc = factor_front(ctx, st, D, B, Z, ldz, X, ldx, G, ldg, mu0, F0, ldf0, !fork);
     if (rc) return rc;
-    return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev);
+    if (!fork) return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev);
+    if (hipEventRecord(ctx->ev_fork, st) != hipSuccess || hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0) != hipSuccess)
+        return chk("fork of the factor update");
+    {
+        double* Rt = ctx->sg;
+        double* Tm = Rt + (size_t)n * D;
+        double* pp_main = ctx->pp;
+        ctx->pp = pp_main + gram_slabs;                 // slabs of the side product behind those of the Gram product
+        rc = gsmvi_panel_product_out(ctx, ctx->side, D, D, B, Rt + (size_t)B * D, D, nullptr, 1.0, F0, ldf0, nullptr,
+                                     Tm + (size_t)B * D, D);
+        ctx->pp = pp_main;
+        if (rc) return rc;
+    }
+    if (hipEventRecord(ctx->ev_join, ctx->side) != hipSuccess) return chk("join of the factor update");
+    return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, ctx->ev_join);
 }
 
 // Batch-sharded form, stage 1: this rank's B_local samples -> records.
@@ -1138,7 +1161,7 @@ int gsmvi_factor_apply_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const 
 
 // Back half: from Rt, Rtt, Tm (n = 2B rows) to (mu, F).
 static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
-                       double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev) {
+                       double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, hipEvent_t join) {
     const int n = 2 * B, nq = n;                   // n is even
     // workspace carve: ctx->sg holds 4*rmax*max_D doubles (rmax = 2B+8; ws_sizes in gsmvi_abi.hip)
     double* Rt = ctx->sg;                          // n x D   [Z; U]
@@ -1164,6 +1187,8 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
             hipLaunchKernelGGL(k_gsmf_small8, dim3(1), dim3(512), 0, st, n, B, Gam, Kmat, info_dev,
                                (ctx->tune_cov_dbg & 128) ? reinterpret_cast<unsigned long long*>(ctx->pp) : nullptr);
         if ((rc = chk("k_gsmf_small"))) return rc;
+        // (the bottom half of Tm comes from the second stream when the update was forked)
+        if (join && hipStreamWaitEvent(st, join, 0) != hipSuccess) return chk("join of the factor update");
         // inner dimension n <= one chunk, so there is exactly one slab: it is written straight into Fs
         if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, Fs, &kc2)))
             return rc;
@@ -1190,6 +1215,8 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
             hipLaunchKernelGGL(k_gsmf_gemm128<1>, dim3(gw), dim3(256), 0, st, n, Wm, Pm, Kmat, info_dev); // K = W^T P
             if ((rc = chk("k_gsmf_gemm128"))) return rc;
         }
+        // (the bottom half of Tm comes from the second stream when the update was forked)
+        if (join && hipStreamWaitEvent(st, join, 0) != hipSuccess) return chk("join of the factor update");
         // inner dimension n <= one chunk, so there is exactly one slab: it is written straight into Fs
         if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, Fs, &kc2)))
             return rc;

@@ -346,3 +346,20 @@ def test_small_chain_versions_agree():
         assert rel_err(mu4.cpu().numpy(), mu8.cpu().numpy()) < 1e-12
         a, b = F4.cpu().numpy(), F8.cpu().numpy()
         assert rel_err(a.T @ a, b.T @ b) < 1e-12
+
+
+def test_forked_factor_update_equals_the_single_stream_form():
+    """Knob fork=1 (U F on the context's second stream; measured slower, kept as an experiment): same numbers."""
+    import torch
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    orc, st, F0 = _setup(256, 32, 9)
+    args = tuple(eng.asarray(a) for a in (st["Z"], st["samples"], st["vs"], st["mu0"], F0))
+    mu0_, F0_, _ = eng.gsm_factor_update(*args)
+    eng.set_tuning("fork", 1)
+    try:
+        for _ in range(5):
+            mu1, F1, fl = eng.gsm_factor_update(*args)
+            assert torch.equal(mu1, mu0_) and torch.equal(F1, F0_) and eng.read_flag(fl) == 0
+    finally:
+        eng.set_tuning("fork", 0)
