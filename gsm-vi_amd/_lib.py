@@ -31,6 +31,8 @@ _SIGS = {
     "gsmvi_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "gsmvi_gsm_update_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int,
                                        _c_dp, _c_dp, C.c_int, _c_dp, _c_dp, C.c_int]),
+    "gsmvi_gsm_update_general_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int,
+                                               _c_dp, _c_dp, C.c_int, _c_dp, _c_dp, C.c_int]),
     "gsmvi_gsm_record_len": (C.c_int, [C.c_int]),
     "gsmvi_gsm_local_stage_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp,
                                             C.c_int, _c_dp, _c_dp, C.c_int, _c_dp, C.c_int]),
@@ -73,7 +75,7 @@ _SIGS = {
 
 
 def exported_symbols():
-    """Names every build of the library must export (kept in sync with include/gsmvi_hip.h)."""
+    """Names every build of the library must export (kept in sync with include/gsmvi_hip.h and gsmvi_hip_debug.h)."""
     return sorted(_SIGS)
 
 

@@ -95,6 +95,9 @@ class BaM:
         synchronisation) and a non-zero flag raises FloatingPointError into the retry loop."""
         eng = self._engine if self._engine is not None else get_engine()
         D, B = self.D, int(batch_size)
+        bmax = getattr(eng, "bam_max_batch", None)
+        if bmax is not None and B > bmax:               # deterministic: raised here, not inside the retry loop
+            raise ValueError(f"BaM.fit: batch_size {B} exceeds the device update's limit of {bmax}")
         mean_t = eng.zeros(D) if mean is None else eng.clone(mean).reshape(D)
         cov_t = eng.eye(D) if cov is None else eng.clone(cov).reshape(D, D)
         seed = int(np.asarray(key.cpu() if _is_torch(key) else key).flatten()[-1])

@@ -9,6 +9,7 @@
 #include <string>
 
 #include "../../include/gsmvi_hip.h"
+#include "../../include/gsmvi_hip_debug.h"
 
 // ---- kernels (gsmvi_kernels.hip / gsmvi_potrf.hip / gsmvi_bam.hip) -------------------------
 void gsmvi_launch_panel_partial(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int ncols, int nrows,
@@ -33,7 +34,7 @@ void gsmvi_launch_commit(hipStream_t st, int D, const int* info, const double* m
 void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int nrows, const double* A,
                              int lda, const double* shift, double alpha, const double* M, int ldm, double* Pp,
                              int chunks_per_wg, int ncols, unsigned long long* stamps, double* Out, int ldo,
-                             const double* addvec, unsigned* cnt);
+                             const double* addvec);
 bool gsmvi_launch_gsm_scalars_fast(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, const double* X, int ldx,
                                    const double* G, int ldg, const double* mu0, const double* Pp, double* rec,
                                    int ldrec, int nt, unsigned long long* stamps);
@@ -41,14 +42,6 @@ bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, cons
                               const double* mu0, const double* S0, int lds0, double* S, int lds, double* mu_out,
                               int dbg, unsigned long long* stamps);
 int gsmvi_panel_fast_chunk(int MT);
-// two-launch dense update (gsmvi_fused.hip)
-int gsmvi_panel_seam_chunk(int MT);
-bool gsmvi_launch_panel_seam(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, int chunks_per_wg, const double* G,
-                             int ldg, const double* S0, int lds0, const double* X, int ldx, const double* mu0,
-                             double* Pp, double* SG, double* pd, unsigned* cnt, unsigned long long* stamps);
-bool gsmvi_launch_gsm_cov_fused(hipStream_t st, hipEvent_t* ev, int D, int B, const double* X, int ldx,
-                                const double* SG, const double* pd, const double* mu0, const double* S0, int lds0,
-                                double* S, int lds, double* mu_out, int flags, unsigned long long* stamps);
 int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                      int* info_dev);
 int gsmvi_gram_impl(hipStream_t st, int D, const double* F, int ldf, double* C, int ldc);
@@ -196,14 +189,10 @@ int gsmvi_create(gsmvi_ctx** out, int device, int max_D, int max_B) {
     c->sg = c->pp + n_pp;
     c->small = c->sg + n_sg;
     c->ints = reinterpret_cast<int*>(c->small + n_small);
-    c->seam_cnt = reinterpret_cast<unsigned*>(c->ints + 64);
     e = hipMemset(c->ws, 0, c->ws_bytes);
     if (e == hipSuccess) e = gsmvi_cov_update_prepare();
     if (e == hipSuccess) e = gsmvi_bam_prepare();
     for (int k = 0; k < 8 && e == hipSuccess; ++k) e = hipEventCreate(&c->ev[k]);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) {
         gsmvi_set_error("context initialisation failed: %s%s", hipGetErrorString(e), "");
         (void)hipFree(c->ws);
@@ -225,10 +214,6 @@ int gsmvi_destroy(gsmvi_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (int k = 0; k < 8; ++k)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    if (ctx->side) (void)hipStreamDestroy(ctx->side);
-    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->bam_hint_host) (void)hipHostFree(ctx->bam_hint_host);
     if (ctx->stamps) (void)hipFree(ctx->stamps);
     hipError_t e = hipFree(ctx->ws);
@@ -245,13 +230,7 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     if (!strcmp(name, "panel_kc")) ctx->tune_panel_kc = value;
     else if (!strcmp(name, "update_sb")) ctx->tune_update_sb = value;
     else if (!strcmp(name, "no_fast")) ctx->tune_no_fast = value;
-    else if (!strcmp(name, "seam_finish")) ctx->tune_seam_finish = value;
-    else if (!strcmp(name, "fork")) ctx->tune_fork = value;
-    else if (!strcmp(name, "small_v")) ctx->tune_small_v = value;
-    else if (!strcmp(name, "potrf_v")) ctx->tune_potrf_v = value;
-    else if (!strcmp(name, "fused")) ctx->tune_fused = value;
-    else if (!strcmp(name, "fused_flags")) ctx->tune_fused_flags = value;
-    else if (!strcmp(name, "bam_host")) ctx->tune_bam_host = value;
+    else if (!strcmp(name, "direct_out")) ctx->tune_direct_out = value;
     else if (!strcmp(name, "bam_full")) ctx->tune_bam_full = value;
     else if (!strcmp(name, "bam_kenq")) ctx->tune_bam_kenq = value;
     else if (!strcmp(name, "scalars_nt")) ctx->tune_scalars_nt = value;
@@ -321,9 +300,8 @@ int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D
                            const double* A, int lda, const double* shift, double alpha, const double* M, int ldm,
                            double* Pp, int* kc_out);
 
-// Product with a FINISHED output Out (nrows x ncols, ldo) = addvec + alpha (A - shift) M.  On the fast path with at most
-// one workgroup per CU the split-K slabs are combined inside the product launch (per-strip seam of k_panel_fast);
-// otherwise product + k_panel_finish.  Same numbers either way (same summation order).
+// Product with a FINISHED output Out (nrows x ncols, ldo) = addvec + alpha (A - shift) M.  On the fast path with a split-K
+// count of 1 the product launch writes Out itself; otherwise product + k_panel_finish.  Same numbers either way.
 int gsmvi_panel_product_out(gsmvi_ctx* ctx, hipStream_t st, int D, int ncols, int nrows, const double* A, int lda,
                             const double* shift, double alpha, const double* M, int ldm, const double* addvec, double* Out,
                             int ldo) {
@@ -331,14 +309,14 @@ int gsmvi_panel_product_out(gsmvi_ctx* ctx, hipStream_t st, int D, int ncols, in
     const int MT = nrows <= 16 ? 1 : (nrows <= 32 ? 2 : 4);
     const int zblocks = (nrows + 16 * MT - 1) / (16 * MT);
     const int a_vec_ok = (lda % 2 == 0) && aligned16(A);
-    const bool fast = !ctx->tune_no_fast && ctx->tune_seam_finish && ncols % 16 == 0 && D % 64 == 0 && a_vec_ok &&
+    const bool fast = !ctx->tune_no_fast && ctx->tune_direct_out && ncols % 16 == 0 && D % 64 == 0 && a_vec_ok &&
                       (!shift || aligned16(shift));
     if (fast) {
         const int chw = gsmvi_panel_fast_chunk(MT);
         const int nchunks = (D + chw - 1) / chw;
         // the split the plain product would take (two workgroups per CU wanted); the one-launch form is used only when
-        // that split needs no seam (kc == 1) or fits one workgroup per CU -- never at the price of fewer workgroups
-        // (D = 4096: kc = 2, 512 workgroups; forcing kc = 1 there cost 20 % of the product's speed)
+        // that split is kc == 1 -- never at the price of fewer workgroups (D = 4096: kc = 2, 512 workgroups; forcing
+        // kc = 1 there cost 20 % of the product's speed)
         int kc = ctx->tune_panel_kc > 0 ? ctx->tune_panel_kc
                                         : (2 * ctx->num_cu + strips * zblocks - 1) / (strips * zblocks);
         if (kc > nchunks) kc = nchunks;
@@ -346,14 +324,11 @@ int gsmvi_panel_product_out(gsmvi_ctx* ctx, hipStream_t st, int D, int ncols, in
         if (kc >= 1) {
             const int cpw = (nchunks + kc - 1) / kc;
             kc = (nchunks + cpw - 1) / cpw;
-            // seam_finish = 1 (default): only the hand-off-free case (kc == 1: the product writes the finished output
-            // itself); = 2 also the per-strip seam (an in-kernel cross-workgroup hand-off: +2 % fit rate at D = 1024,
-            // bit-identical in every test including uneven load, kept opt-in like the two-launch dense update)
-            if ((kc == 1 || (ctx->tune_seam_finish >= 2 && strips * zblocks * kc <= ctx->num_cu)) &&
-                strips * zblocks <= 1024) {
+            // only the hand-off-free case (kc == 1): the product writes the finished output itself
+            if (kc == 1 && strips * zblocks <= 1024) {
                 gsmvi_launch_panel_fast(st, nullptr, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm,
-                                        ctx->pp, cpw, ncols, ctx->timeline_stamps(0), Out, ldo, addvec, ctx->seam_cnt);
-                return check_launch("k_panel_fast(seam)");
+                                        ctx->pp, cpw, ncols, ctx->timeline_stamps(0), Out, ldo, addvec);
+                return check_launch("k_panel_fast(out)");
             }
         }
     }
@@ -384,7 +359,7 @@ int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D
     *kc_out = kc;
     if (fast) {
         gsmvi_launch_panel_fast(st, ev, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm, Pp,
-                                cpw, ncols, ctx->timeline_stamps(0), nullptr, 0, nullptr, nullptr);
+                                cpw, ncols, ctx->timeline_stamps(0), nullptr, 0, nullptr);
         return check_launch("k_panel_fast");
     }
     gsmvi_launch_panel_partial(st, ev, MT, dim3(strips, kc, zblocks), D, ncols, nrows, A, lda, shift, alpha, M,
@@ -467,41 +442,6 @@ static int gsm_records(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, int kc, con
     return check_launch("k_gsm_scalars");
 }
 
-// Two-launch form (gsmvi_fused.hip).  Returns false when the problem is not eligible (the caller then runs the
-// three-launch path): needs the fast-path alignment, B in {16,32,64}, and a panel grid of at most one workgroup per
-// CU -- the geometry the in-kernel hand-off of k_panel_seam was measured in.
-static bool gsm_update_fused(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, const double* X, int ldx, const double* G,
-                             int ldg, const double* mu0, const double* S0, int lds0, double* mu, double* S, int lds,
-                             int* status) {
-    if (ctx->tune_no_fast || !ctx->tune_fused || ctx->tune_cov_dbg) return false;
-    if (D % 64 != 0 || !(B == 16 || B == 32 || B == 64)) return false;
-    if ((ldx | ldg | lds0 | lds) & 1) return false;
-    if (!aligned16(X) || !aligned16(G) || !aligned16(mu0) || !aligned16(S0) || !aligned16(S)) return false;
-    const int strips = D / 16, MT = B / 16;
-    if (strips > ctx->num_cu || strips > 64) return false;      // k_gsm_cov_fused reduces at most 64 strips (D <= 1024)
-    const int chw = gsmvi_panel_seam_chunk(MT);
-    const int nchunks = (D + chw - 1) / chw;
-    int kc = ctx->tune_panel_kc > 0 ? ctx->tune_panel_kc : ctx->num_cu / strips;
-    if (kc > nchunks) kc = nchunks;
-    if (kc > GSMVI_SEAM_MAX_KC) kc = GSMVI_SEAM_MAX_KC;
-    if (kc < 1) kc = 1;
-    const int cpw = (nchunks + kc - 1) / kc;
-    kc = (nchunks + cpw - 1) / cpw;
-    if (strips * kc > ctx->num_cu) return false;
-    double* SG = ctx->sg;                          // [B][D]
-    double* pd = ctx->small;                       // [strips][B][2]
-    if (!gsmvi_launch_panel_seam(hs, ctx->stage_events(0), D, B, kc, cpw, G, ldg, S0, lds0, X, ldx, mu0, ctx->pp, SG,
-                                 pd, ctx->seam_cnt, ctx->timeline_stamps(0)))
-        return false;
-    *status = check_launch("k_panel_seam");
-    if (*status != GSMVI_OK) return true;
-    if (ctx->profiling) ctx->ev_valid[1] = 0;      // no per-sample launch on this path
-    gsmvi_launch_gsm_cov_fused(hs, ctx->stage_events(2), D, B, X, ldx, SG, pd, mu0, S0, lds0, S, lds, mu,
-                               ctx->tune_fused_flags, ctx->timeline_stamps(2));
-    *status = check_launch("k_gsm_cov_fused");
-    return true;
-}
-
 int gsmvi_gsm_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* X, int ldx, const double* G,
                          int ldg, const double* mu0, const double* S0, int lds0, double* mu, double* S, int lds) {
     int st = check_common(ctx, D, B, __func__);
@@ -510,7 +450,6 @@ int gsmvi_gsm_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const doubl
     BAD_ARG(ldx < D || ldg < D || lds0 < D || lds < D, "leading dimension smaller than D");
     BAD_ARG(S == S0 || mu == mu0, "outputs must not alias inputs");
     hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
-    if (gsm_update_fused(ctx, hs, D, B, X, ldx, G, ldg, mu0, S0, lds0, mu, S, lds, &st)) return st;
     const int ldrec = 3 * D + (D & 1);            // even stride keeps every record 16-byte aligned
     st = gsm_local_stage(ctx, hs, D, B, X, ldx, G, ldg, mu0, S0, lds0, ctx->sg, ldrec);
     if (st != GSMVI_OK) return st;
@@ -518,6 +457,30 @@ int gsmvi_gsm_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const doubl
 }
 
 int gsmvi_gsm_record_len(int D) { return 3 * D + (D & 1); }
+
+// The same update for an S0 that is NOT symmetric: keeps the reference's literal semantics S = S0 + mean_b(...) with
+// S0 g_b in the per-sample stage (gsm_numpy.py:7,50-53).  Row b of the panel stage is g_b^T S0^T (the transposed panel
+// product), and the guarded update kernel reads all of S0 instead of its upper triangle.
+int gsmvi_gsm_update_general_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* X, int ldx, const double* G,
+                                 int ldg, const double* mu0, const double* S0, int lds0, double* mu, double* S, int lds) {
+    int st = check_common(ctx, D, B, __func__);
+    if (st != GSMVI_OK) return st;
+    BAD_ARG(!X || !G || !mu0 || !S0 || !mu || !S, "NULL array");
+    BAD_ARG(ldx < D || ldg < D || lds0 < D || lds < D, "leading dimension smaller than D");
+    BAD_ARG(S == S0 || mu == mu0, "outputs must not alias inputs");
+    hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    const int ldrec = 3 * D + (D & 1);
+    int kc = 1;
+    st = gsmvi_panel_t_product(ctx, hs, D, B, G, ldg, S0, lds0, D, ctx->pp, &kc);
+    if (st != GSMVI_OK) return st;
+    st = gsm_records(ctx, hs, D, B, kc, X, ldx, G, ldg, mu0, ctx->pp, ctx->sg, ldrec);
+    if (st != GSMVI_OK) return st;
+    int SB = (B + 1) & ~1;
+    if (SB > 64) SB = 64;
+    const int s_vec_ok = (lds0 % 2 == 0) && (lds % 2 == 0) && aligned16(S0) && aligned16(S);
+    gsmvi_launch_gsm_cov_update(hs, nullptr, D, B, ctx->sg, ldrec, mu0, S0, lds0, S, lds, mu, SB, s_vec_ok, 0, D);
+    return check_launch("k_gsm_cov_update(general)");
+}
 
 int gsmvi_gsm_local_stage_f64(gsmvi_ctx* ctx, void* stream, int D, int B_local, const double* X, int ldx,
                               const double* G, int ldg, const double* mu0, const double* S0, int lds0, double* rec,

@@ -10,6 +10,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 #define GSMVI_MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 #define GSMVI_WAVE 64
+#define GSMVI_STAMP_WG 512            // workgroups per kernel slot of the timeline diagnostic (8 words each)
 #define GSMVI_WG 256
 
 // Broadcast of lane Q (0..3, compile-time) of every quad of lanes to the whole quad: two DPP moves (quad_perm), pure VALU --

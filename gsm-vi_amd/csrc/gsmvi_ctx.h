@@ -4,7 +4,6 @@
 #include <cstddef>
 
 #define GSMVI_MAX_KC 8
-#define GSMVI_SEAM_MAX_KC 8   // split-K pieces a strip seam of k_panel_seam can combine
 #define GSMVI_STAMP_WORDS (4 * 4096)   // timeline diagnostic: 4 kernels x 512 workgroups x 8 words
 
 struct gsmvi_ctx {
@@ -18,36 +17,19 @@ struct gsmvi_ctx {
     double* sg = nullptr;      // [4][rmax][max_D] finished panels (SG, BaM factor panels)
     double* small = nullptr;   // coefficients and small dense matrices
     int* ints = nullptr;       // device ints (flags)
-    unsigned* seam_cnt = nullptr;   // [1024] arrival counters of k_panel_seam (zero between launches)
-    int tune_fused = 0;        // 1 = dense update as TWO launches where eligible (gsmvi_fused.hip); measured no faster than the
-                               // three-launch default at D=1024, B=32 (54.6k vs 54.2k updates/s HBM-cold, 59.8k vs 65.2k cache-resident)
-    int tune_fused_flags = 0;  // experiment bits for k_gsm_cov_fused (1 = mirror tile stored without the LDS transpose)
     int tune_panel_kc = 0;
     int tune_update_sb = 0;
     int tune_cov_dbg = 0;      // ablation bits for k_gsm_cov_sym (wrong results; timing only)
     int tune_timeline = 0;     // 1 = every fast-path kernel of the dense update writes s_memrealtime stamps (diagnostic)
     unsigned long long* stamps = nullptr;   // [kernel][workgroup][8], allocated by the "timeline" knob
-    int tune_potrf_v = 3;      // 1 = two launches per block step (round 1), 2 = one fused launch per step (k_potrf_step),
-                               // 3 = the same with eight waves: W substitution beside the Cholesky (k_potrf_step8)
-    int tune_seam_finish = 1;  // finished outputs of sample / score / U F / Gram products from the product launch: 0 = never
-                               // (product + k_panel_finish), 1 = when the split-K count is 1 (no hand-off involved; default),
-                               // 2 = also through the per-strip seam where the grid fits one workgroup per CU
-    int tune_small_v = 2;      // 1 = four-wave k_gsmf_small (reference), 2 = eight-wave k_gsmf_small8 (W beside the Cholesky)
+    int tune_direct_out = 1;   // finished outputs of sample / score / U F / Gram products from the product launch when the split-K
+                               // count is 1 (no hand-off involved); 0 = always product + k_panel_finish (A/B tests)
     int tune_scalars_nt = 0;   // threads per sample in k_gsm_scalars_fast (256/512/1024; 0 = default)
     int tune_no_fast = 0;      // 1 = force the guarded generic kernels (tests)
     int* bam_hint_host = nullptr;       // pinned word: k* of the last device BaM chain (step-count hint, never synchronised on)
     int tune_bam_kenq = 0;     // > 0: enqueue exactly this many multi-workgroup steps (tests of the tail kernel)
     int tune_bam_full = 0;     // 1 = always enqueue every Newton-Schulz step (ignore the hint; tests)
-    int tune_bam_host = 0;     // 1 = BaM's small matrix function on the host even when the device chain applies (tests)
     int profiling = 0;         // when set, the update kernels are launched with dispatch-timestamp events
-    double* h_pin = nullptr;   // pinned host staging for BaM's small matrices (grown on demand)
-    size_t h_pin_doubles = 0;
-    int h_pin_busy = 0;        // ev[7] marks the end of the last upload from h_pin
-    hipStream_t side = nullptr;      // second stream of the factor update: U F runs beside the Gram product and the 2B x 2B chain
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int tune_fork = 0;         // 1 = U F of the factor update on the second stream beside the Gram product and the 2B x 2B chain.
-                               // Measured SLOWER (scripts/ab_fork.py: 79 -> 92 us per update in a graph at D=1024, B=32; 53 -> 74 us
-                               // at D=256; +1 % at D=4096): the two cross-stream event edges cost more than the 12 us they hide
     hipEvent_t ev[8] = {};     // [2*stage], [2*stage+1]: panel, scalars, cov-update, spare
     int ev_valid[4] = {};
 

@@ -514,188 +514,15 @@ __device__ __forceinline__ bool diag_prepare(double* M, int* sh_flag) {
     return *sh_flag != 0;
 }
 
-// ---- everything small in ONE workgroup (n = 2B <= 64) ---------------------------------------------------
+// ---- everything small in ONE workgroup (n = 2B <= 64), eight waves ---------------------------------------------------
 //   Gamma -> Rg (Cholesky) -> A' = I + Rg J Rg^T -> T (Cholesky, the PD test) -> K = Rg^-1 (T - I) Rg^-T.
-// All matrices live in LDS ([64][TS], padded with the identity beyond n).  W = Rg^-T comes from one n-column
-// forward substitution, one column per QUAD of lanes (lane q of the quad owns rows q, q+4, ..; the pivot
-// value is broadcast inside the quad); K = W^T (T - I) W is then two 64^3 products on the MFMA pipe.  *bad = 1 if either Cholesky
-// fails (NaN, singular Gamma, or M not positive definite) and K is then irrelevant.
-__global__ __launch_bounds__(256) void k_gsmf_small(int n, int B, const double* __restrict__ Gam,
-                                                    double* __restrict__ Kmat, int* __restrict__ bad_out,
-                                                    unsigned long long* __restrict__ stamps) {
-#define SMALL_STAMP(k)                                                                      \
-    do {                                                                                    \
-        if (stamps && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memrealtime();        \
-    } while (0)
-    SMALL_STAMP(0);
-    __shared__ __attribute__((aligned(16))) double Rs[64 * TS];
-    __shared__ __attribute__((aligned(16))) double Ts[64 * TS];
-    __shared__ __attribute__((aligned(16))) double Ps[64 * TS];
-    __shared__ double rinv_g[64], rinv_t[64];
-    __shared__ int fail_g, fail_t;
-    const int tid = threadIdx.x;
-    {
-        double g[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {                 // unconditional (clamped) loads: one batch, one wait
-            const int e = tid + 256 * k, i = e >> 6, q = e & 63;
-            g[k] = Gam[(size_t)(i < n ? i : n - 1) * n + (q < n ? q : n - 1)];
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int e = tid + 256 * k, i = e >> 6, q = e & 63;
-            Rs[i * TS + q] = (i < n && q < n && q >= i) ? g[k] : (i == q ? 1.0 : 0.0);
-        }
-    }
-    if (tid < 64) rinv_g[tid] = rinv_t[tid] = 1.0;
-    __syncthreads();
-    SMALL_STAMP(1);
-    const bool moderate = diag_prepare<TS>(Rs, &fail_t);
-    chol64_rows_s<TS, true>(Rs, rinv_g, n, &fail_g, moderate);   // Rs = Rg (upper, semi-definite rule); strictly-lower part is stale
-    SMALL_STAMP(2);
-    for (int e = tid; e < 64 * 64; e += 256) {         // zero the strictly-lower part so Rs is a clean upper factor
-        const int i = e >> 6, q = e & 63;
-        if (q < i) Rs[i * TS + q] = 0.0;
-    }
-    if (tid < 64 && rinv_g[tid] == 0.0) rinv_g[tid] = 1.0;      // dependent rows: unit diagonal in the substitution
-    __syncthreads();
-    // A' = I + (Rg J) Rg^T into Ts;  (Rg J)[i][k] = (1/B)(k < B ? Rg[i][B+k] : Rg[i][k-B] - Rg[i][k]), on the
-    // MFMA pipe.  Wave w owns the 16-column block j = w and computes the blocks (i, j), i <= j (A' is
-    // symmetric; the mirror is written too).  Rg is upper triangular, so Rg[j][k] = 0 for k < 16 j: only the
-    // k-blocks j..3 contribute -- 80 MFMAs in all instead of a 64^3 VALU product.
-    {
-        const double invB = 1.0 / (double)B;
-        const int w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
-        v4d acc[4];
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib) acc[ib] = (v4d){0.0, 0.0, 0.0, 0.0};
-        const double* brow = Rs + (16 * w + cc) * TS;
-        for (int kb = w; kb < 4; ++kb) {
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int k = 16 * kb + 4 * s4 + ks;
-                const int k1 = (k < B) ? B + k : k - B;
-                const double bv = brow[k];
-#pragma unroll
-                for (int ib = 0; ib < 4; ++ib) {       // independent accumulator chains; ib <= w is wave-uniform
-                    if (ib <= w) {
-                        const double* arow = Rs + (16 * ib + cc) * TS;
-                        const double a1 = arow[k1 < 64 ? k1 : 63], a0 = arow[k];
-                        const double a = (k < n) ? ((k < B) ? a1 : a1 - a0) : 0.0;
-                        acc[ib] = GSMVI_MFMA_F64(a, bv, acc[ib]);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib) {
-            if (ib <= w) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * ib + ks + 4 * r, j = 16 * w + cc;
-                    const double v = (i == j ? 1.0 : 0.0) + ((i < n && j < n) ? acc[ib][r] * invB : 0.0);
-                    Ts[i * TS + j] = v;
-                    if (ib != w) Ts[j * TS + i] = v;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    SMALL_STAMP(3);
-    chol64_lds(Ts, rinv_t, n, &fail_t);                // Ts = T (upper): exists iff M is positive definite
-    SMALL_STAMP(4);
-    const int bad = (fail_g != 0) || (fail_t != 0);
-    if (tid == 0) *bad_out = bad;
-    if (bad) return;                                   // block-uniform
-
-    // ---- K = Rg^-1 (T - I) Rg^-T, column c of the n x n result per quad ----
-    const int c = tid >> 2, q = tid & 3;               // 64 columns x 4 lanes
-    double x[16];
-    // phase 1: x = Rg^-T e_c  (forward substitution with the lower factor L = Rg^T, L[t][p] = Rg[p][t])
-#pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = (q + 4 * r == c) ? 1.0 : 0.0;
-#pragma unroll
-    for (int p = 0; p < 64; ++p) {
-        const int pr = p >> 2, pq = p & 3;
-        const double mine = x[pr] * rinv_g[p];
-        if (q == pq) x[pr] = mine;
-        const double xp = quad_bcast_rt<0>(mine, pq);
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (4 * r + 3 > p) {
-                const int t = q + 4 * r;
-                const double rv = Rs[p * TS + t];
-                x[r] -= (t > p) ? rv * xp : 0.0;
-            }
-    }
-    // Column c of W = Rg^-T (lower triangular) is now in the quad's registers.  K = W^T (T - I) W is two
-    // 64 x 64 x 64 products on the MFMA pipe instead of a second and a third 64-step substitution:
-    //   P = (T - I) W   then   K = W^T P.
-    __syncthreads();                                   // every quad is done reading Rg
-    SMALL_STAMP(5);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Rs[(q + 4 * r) * TS + c] = x[r];       // Rs <- W
-    for (int e = tid; e < 64 * 64; e += 256) {         // Ts <- T - I, strictly-lower part cleared
-        const int i = e >> 6, j = e & 63;
-        if (j < i) Ts[i * TS + j] = 0.0;
-        else if (j == i) Ts[i * TS + j] -= 1.0;
-    }
-    __syncthreads();
-    {
-        const int w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
-        // Wave w owns the 16-column block j = w of both products; the four row blocks are independent chains.
-        // P[i][j] = sum_k (T - I)[i][k] W[k][j]: T - I is upper (k >= i), W lower (k >= j): k-blocks max(i, j)..3.
-        v4d acc[4];
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib) acc[ib] = (v4d){0.0, 0.0, 0.0, 0.0};
-        for (int kb = w; kb < 4; ++kb) {
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int k = 16 * kb + 4 * s4 + ks;
-                const double bv = Rs[k * TS + 16 * w + cc];
-#pragma unroll
-                for (int ib = 0; ib < 4; ++ib)
-                    if (ib <= kb) acc[ib] = GSMVI_MFMA_F64(Ts[(16 * ib + cc) * TS + k], bv, acc[ib]);
-            }
-        }
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Ps[(16 * ib + ks + 4 * r) * TS + 16 * w + cc] = acc[ib][r];
-        __syncthreads();
-        // K[i][j] = sum_k W[k][i] P[k][j]: W[k][i] = 0 for k < i: k-blocks i..3.
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib) acc[ib] = (v4d){0.0, 0.0, 0.0, 0.0};
-        for (int kb = 0; kb < 4; ++kb) {
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int k = 16 * kb + 4 * s4 + ks;
-                const double bv = Ps[k * TS + 16 * w + cc];
-#pragma unroll
-                for (int ib = 0; ib < 4; ++ib)
-                    if (ib <= kb) acc[ib] = GSMVI_MFMA_F64(Rs[k * TS + 16 * ib + cc], bv, acc[ib]);
-            }
-        }
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * ib + ks + 4 * r, j = 16 * w + cc;
-                if (i < n && j < n) Kmat[(size_t)i * n + j] = acc[ib][r];
-            }
-    }
-    SMALL_STAMP(6);
-#undef SMALL_STAMP
-}
-
-// ---- the same chain with EIGHT waves (n = 2B <= 64): waves 0-3 are the Cholesky team, waves 4-7 helpers ---------------
-// What changes against k_gsmf_small (kept as the reference, tuning knob small_v=1):
-//   * W = Rg^-T (64 substitution steps, 7.4 us, no barrier of its own) runs on the helper waves WHILE the Cholesky
-//     team factors A' (14.4 us, one barrier per pivot): the helpers execute one barrier per substitution step so that
-//     the workgroup barrier counts match (s_barrier counts waves, not program counters), and stay ahead of the
-//     factorisation (115 ns per step against 190 ns per pivot);
+// All matrices live in LDS ([64][TS], padded with the identity beyond n).  Waves 0-3 are the Cholesky team, waves 4-7 helpers:
+//   * W = Rg^-T (64 substitution steps, one column per QUAD of lanes, the pivot value broadcast inside the quad by DPP) runs
+//     on the helper waves WHILE the Cholesky team factors A': the helpers execute one barrier per substitution step so that
+//     the workgroup barrier counts match (s_barrier counts waves, not program counters);
 //   * the three MFMA phases (A', P = (T - I) W, K = W^T P) use all eight waves (two per SIMD: the fp64 MFMA pipe
 //     delivers 46 TF chip-wide there against 34 TF with one), row blocks split by parity between the two teams.
+// *bad = 1 if either Cholesky fails (NaN, or M not positive definite) and K is then irrelevant.
 // NP forward-substitution steps of W = Rg^-T for the calling quad's column, ONE workgroup barrier per step (matches the
 // per-pivot barrier of chol64_rows_s running on the other four waves)
 template <int NP>
@@ -764,7 +591,9 @@ __global__ __launch_bounds__(512) void k_gsmf_small8(int n, int B, const double*
     __syncthreads();
     const int w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
     const int wj = w & 3, g2 = w >> 2;                 // column block of this wave, team index (row-block parity)
-    {   // A' = I + (Rg J) Rg^T into Ts (see k_gsmf_small); wave (wj, g2) computes the blocks (ib, wj), ib <= wj, ib % 2 == g2
+    {   // A' = I + (Rg J) Rg^T into Ts;  (Rg J)[i][k] = (1/B)(k < B ? Rg[i][B+k] : Rg[i][k-B] - Rg[i][k]), on the MFMA pipe.
+        // A' is symmetric (the mirror is written too); Rg is upper triangular, so Rg[j][k] = 0 for k < 16 j: only the
+        // k-blocks j..3 contribute.  Wave (wj, g2) computes the blocks (ib, wj), ib <= wj, ib % 2 == g2
         const double invB = 1.0 / (double)B;
         v4d acc[2];
         acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -1076,7 +905,7 @@ __global__ __launch_bounds__(256) void k_gsmf_unpack(int D, int B, const double*
 // Front half: per-sample stage for B samples.  Fills Rt = [Z; U] (2B x D), Rtt (D x 2B) and Tm = [X - mu; U Fm]
 // in the workspace (layout for n = 2B rows).
 static int factor_front(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
-                        const double* G, int ldg, const double* mu0, const double* F0, int ldf0, bool with_uf = true) {
+                        const double* G, int ldg, const double* mu0, const double* F0, int ldf0) {
     const int n = 2 * B, nq = n;
     double* Rt = ctx->sg;                          // n x D   [Z; U]
     double* Tm = Rt + (size_t)n * D;               // n x D   [X - mu; U Fm]
@@ -1093,43 +922,20 @@ static int factor_front(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doub
 #undef GS
     }
     if ((rc = chk("k_gsmf_scalars"))) return rc;
-    if (!with_uf) return GSMVI_OK;
     // bottom half of Tm: U Fm
     return gsmvi_panel_product_out(ctx, st, D, D, B, Rt + (size_t)B * D, D, nullptr, 1.0, F0, ldf0, nullptr,
                                    Tm + (size_t)B * D, D);
 }
 
 static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
-                       double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, hipEvent_t join = nullptr);
+                       double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev);
 
 int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
                       const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double* mu, double* F,
                       int ldf, int* info_dev, int* n_reverts_dev) {
-    // U F (a pass over the factor, needed only by Fs = K Tm at the very end) is independent of the Gram product and
-    // the one-workgroup 2B x 2B chain: it runs on the context's second stream beside them, forked and joined with
-    // events (graph-capturable: a capture of the caller's stream pulls the second stream in through the event wait).
-    // The two concurrent panel products get disjoint slab regions of the workspace.
-    const int n = 2 * B;
-    const size_t gram_slabs = (size_t)GSMVI_MAX_KC * n * n;
-    const bool fork = ctx->tune_fork && ctx->side && ctx->tune_seam_finish < 2 &&
-                      gram_slabs + (size_t)GSMVI_MAX_KC * B * D <= (size_t)GSMVI_MAX_KC * ctx->rmax * ctx->max_D;
-    int rc = factor_front(ctx, st, D, B, Z, ldz, X, ldx, G, ldg, mu0, F0, ldf0, !fork);
+    int rc = factor_front(ctx, st, D, B, Z, ldz, X, ldx, G, ldg, mu0, F0, ldf0);
     if (rc) return rc;
-    if (!fork) return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev);
-    if (hipEventRecord(ctx->ev_fork, st) != hipSuccess || hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0) != hipSuccess)
-        return chk("fork of the factor update");
-    {
-        double* Rt = ctx->sg;
-        double* Tm = Rt + (size_t)n * D;
-        double* pp_main = ctx->pp;
-        ctx->pp = pp_main + gram_slabs;                 // slabs of the side product behind those of the Gram product
-        rc = gsmvi_panel_product_out(ctx, ctx->side, D, D, B, Rt + (size_t)B * D, D, nullptr, 1.0, F0, ldf0, nullptr,
-                                     Tm + (size_t)B * D, D);
-        ctx->pp = pp_main;
-        if (rc) return rc;
-    }
-    if (hipEventRecord(ctx->ev_join, ctx->side) != hipSuccess) return chk("join of the factor update");
-    return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, ctx->ev_join);
+    return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev);
 }
 
 // Batch-sharded form, stage 1: this rank's B_local samples -> records.
@@ -1161,7 +967,7 @@ int gsmvi_factor_apply_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const 
 
 // Back half: from Rt, Rtt, Tm (n = 2B rows) to (mu, F).
 static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
-                       double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, hipEvent_t join) {
+                       double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev) {
     const int n = 2 * B, nq = n;                   // n is even
     // workspace carve: ctx->sg holds 4*rmax*max_D doubles (rmax = 2B+8; ws_sizes in gsmvi_abi.hip)
     double* Rt = ctx->sg;                          // n x D   [Z; U]
@@ -1180,15 +986,9 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
     if (n <= 64) {
         // everything small in one workgroup, then Fs = K Tm as one skinny GEMM (K = n)
         double* Kmat = Rg;                         // reuse the n x n slot
-        if (ctx->tune_small_v == 1)
-            hipLaunchKernelGGL(k_gsmf_small, dim3(1), dim3(256), 0, st, n, B, Gam, Kmat, info_dev,
-                               (ctx->tune_cov_dbg & 128) ? reinterpret_cast<unsigned long long*>(ctx->pp) : nullptr);
-        else
-            hipLaunchKernelGGL(k_gsmf_small8, dim3(1), dim3(512), 0, st, n, B, Gam, Kmat, info_dev,
-                               (ctx->tune_cov_dbg & 128) ? reinterpret_cast<unsigned long long*>(ctx->pp) : nullptr);
+        hipLaunchKernelGGL(k_gsmf_small8, dim3(1), dim3(512), 0, st, n, B, Gam, Kmat, info_dev,
+                           (ctx->tune_cov_dbg & 128) ? reinterpret_cast<unsigned long long*>(ctx->pp) : nullptr);
         if ((rc = chk("k_gsmf_small"))) return rc;
-        // (the bottom half of Tm comes from the second stream when the update was forked)
-        if (join && hipStreamWaitEvent(st, join, 0) != hipSuccess) return chk("join of the factor update");
         // inner dimension n <= one chunk, so there is exactly one slab: it is written straight into Fs
         if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, Fs, &kc2)))
             return rc;
@@ -1215,8 +1015,6 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
             hipLaunchKernelGGL(k_gsmf_gemm128<1>, dim3(gw), dim3(256), 0, st, n, Wm, Pm, Kmat, info_dev); // K = W^T P
             if ((rc = chk("k_gsmf_gemm128"))) return rc;
         }
-        // (the bottom half of Tm comes from the second stream when the update was forked)
-        if (join && hipStreamWaitEvent(st, join, 0) != hipSuccess) return chk("join of the factor update");
         // inner dimension n <= one chunk, so there is exactly one slab: it is written straight into Fs
         if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, Fs, &kc2)))
             return rc;

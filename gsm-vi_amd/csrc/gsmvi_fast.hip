@@ -37,12 +37,13 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
                                                     const double* __restrict__ M, int ldm,
                                                     double* Pp, int chunks_per_wg, int ncols,
                                                     unsigned long long* __restrict__ stamps, double* __restrict__ Out,
-                                                    int ldo, const double* __restrict__ addvec, unsigned* cnt) {
+                                                    int ldo, const double* __restrict__ addvec) {
+    // timeline diagnostic: a kernel's slot holds GSMVI_STAMP_WG workgroups x 8 words; workgroups beyond it write nothing
 #define PSTAMP(k)                                                                                              \
     do {                                                                                                       \
-        if (stamps && threadIdx.x == 0)                                                                        \
-            stamps[(size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k)] =       \
-                __builtin_amdgcn_s_memrealtime();                                                              \
+        const unsigned wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                   \
+        if (stamps && threadIdx.x == 0 && wg_ < GSMVI_STAMP_WG)                                                \
+            stamps[(size_t)wg_ * 8 + (k)] = __builtin_amdgcn_s_memrealtime();                                  \
     } while (0)
     PSTAMP(0);
     constexpr int LDG = CHW + 2;                   // LDS row stride of the staged A chunk (doubles)
@@ -132,12 +133,7 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
         for (int r = 0; r < 4; ++r) red[(w * NR + 16 * mt + ks + 4 * r) * 17 + c] = acc[mt][r];
     __syncthreads();
     // Out == nullptr: the slab Pp[kc] is the result (a finish pass or a consumer sums the KC slabs).
-    // Out != nullptr: FINISHED output Out = addvec + sum_kc slab[kc] from this launch -- for KC == 1 directly; otherwise through
-    // the per-strip seam of gsmvi_fused.hip (pieces stored write-through, one agent-scope ticket per workgroup, the last of
-    // the strip's KC workgroups sums the pieces in the order of k_panel_finish: results are bit-identical to product +
-    // finish).  The ABI takes this form only while the grid has at most one workgroup per CU.
-    const int KC = gridDim.y;
-    const bool seam = Out != nullptr && KC > 1;
+    // Out != nullptr (only launched with KC == 1): FINISHED output Out = addvec + slab, no finish pass.
     for (int idx = tid; idx < NR * 16; idx += 512) {
         const int rr = idx >> 4, cc = idx & 15;
         const int row = r0 + rr;
@@ -145,36 +141,8 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
             double s = 0.0;
 #pragma unroll
             for (int ww = 0; ww < 8; ww += 2) s += red[(ww * NR + rr) * 17 + cc] + red[((ww + 1) * NR + rr) * 17 + cc];
-            double* dst = &Pp[((size_t)blockIdx.y * nrows + row) * ncols + blockIdx.x * 16 + cc];
-            if (Out == nullptr) *dst = s;
-            else if (!seam) Out[(size_t)row * ldo + blockIdx.x * 16 + cc] = s + (addvec ? addvec[blockIdx.x * 16 + cc] : 0.0);
-            else __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1: write-through
-        }
-    }
-    if (seam) {
-        __shared__ unsigned s_ticket;
-        unsigned* my_cnt = cnt + (size_t)blockIdx.z * gridDim.x + blockIdx.x;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) s_ticket = __hip_atomic_fetch_add(my_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (s_ticket == (unsigned)(KC - 1)) {
-            if (tid == 0) __hip_atomic_store(my_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int idx = tid; idx < NR * 16; idx += 512) {
-                const int rr = idx >> 4, cc = idx & 15;
-                const int row = r0 + rr;
-                if (row < nrows) {
-                    double pv[8];
-#pragma unroll
-                    for (int kc = 0; kc < 8; ++kc)
-                        pv[kc] = __hip_atomic_load(&Pp[((size_t)(kc < KC ? kc : KC - 1) * nrows + row) * ncols +
-                                                       blockIdx.x * 16 + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    double t = 0.0;
-#pragma unroll
-                    for (int kc = 0; kc < 8; ++kc) t += (kc < KC) ? pv[kc] : 0.0;
-                    Out[(size_t)row * ldo + blockIdx.x * 16 + cc] = t + (addvec ? addvec[blockIdx.x * 16 + cc] : 0.0);
-                }
-            }
+            if (Out == nullptr) Pp[((size_t)blockIdx.y * nrows + row) * ncols + blockIdx.x * 16 + cc] = s;
+            else Out[(size_t)row * ldo + blockIdx.x * 16 + cc] = s + (addvec ? addvec[blockIdx.x * 16 + cc] : 0.0);
         }
     }
     if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PSTAMP(3); }
@@ -193,6 +161,7 @@ __global__ __launch_bounds__(NT) void k_gsm_scalars_fast(int D, int B, int KC, c
                                                          const double* __restrict__ Pp,
                                                          double* __restrict__ rec, int ldrec,
                                                          unsigned long long* __restrict__ stamps) {
+    if (blockIdx.x >= GSMVI_STAMP_WG) stamps = nullptr;          // timeline diagnostic: slot capacity
     if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8] = __builtin_amdgcn_s_memrealtime();
     constexpr int NW = NT / 64;
     __shared__ double lds[2 * NW];
@@ -285,6 +254,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
     do {                                                                                  \
         if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
+    if (blockIdx.x >= GSMVI_STAMP_WG) stamps = nullptr;          // timeline diagnostic: slot capacity (D >= 2048 has more workgroups)
     STAMP(0);
     constexpr int RS = 48;                       // LDS row stride (doubles): 32 columns + 16 pad
     constexpr int NPASS = (SB > 32) ? SB / 32 : 1;   // samples are staged 32 at a time: <= 74 KB of LDS, so
@@ -444,10 +414,10 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
 void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int nrows, const double* A,
                              int lda, const double* shift, double alpha, const double* M, int ldm, double* Pp,
                              int chunks_per_wg, int ncols, unsigned long long* stamps, double* Out, int ldo,
-                             const double* addvec, unsigned* cnt) {
+                             const double* addvec) {
 #define PF(MTV, HS, CW)                                                                                          \
     GSMVI_LAUNCH((k_panel_fast<MTV, HS, CW>), grid, dim3(512), 0, st, ev, D, nrows, A, lda, shift, alpha, M, ldm, \
-                 Pp, chunks_per_wg, ncols, stamps, Out, ldo, addvec, cnt)
+                 Pp, chunks_per_wg, ncols, stamps, Out, ldo, addvec)
     if (shift) {
         if (MT == 1) PF(1, true, 256); else if (MT == 2) PF(2, true, 256); else PF(4, true, 128);
     } else {

@@ -5,14 +5,9 @@
 // np.random.multivariate_normal, gsm_numpy.py:116).  A failed pivot (<= 0 or NaN) sets *info to
 // 1 + pivot index, mirroring "LinAlgError or NaN => not good".
 //
-// Blocked right-looking algorithm, block size 64, in place on R (initialised to triu(S)):
-//   for k = 0 .. D/64-1:
-//     k_potrf_panel    : every workgroup factors the 64x64 diagonal block in LDS (redundantly,
-//                        it is 32 KB), workgroup 0 stores it; each workgroup then solves
-//                        R_kk^T X = S_k,cols for its 64 columns of the block row (one column per
-//                        quad of lanes, forward substitution in registers).
-//     k_potrf_trailing : S_ij -= R_ki^T R_kj for the upper-triangle 64x64 tiles of the trailing
-//                        matrix, fp64 MFMA, K = 64.
+// Blocked right-looking algorithm, block size 64, ONE launch per block step (k_potrf_step8 below): every 64 x 64 tile
+// workgroup turns the triangular solve of block row k-1 into an MFMA product with W = R_{k-1,k-1}^-T, applies the rank-64
+// update to its tile, and the diagonal tile goes on to factor itself in LDS and to publish W_k.
 // The strictly lower triangle of R is zero on exit (the sampler's panel product reads all of R).
 #include "gsmvi_common.h"
 #include "gsmvi_ctx.h"
@@ -20,162 +15,11 @@
 
 #define NB 64
 
-// R = triu(S), lower part zero, *info = 0
-__global__ __launch_bounds__(256) void k_potrf_init(int D, const double* __restrict__ S, int lds,
-                                                    double* __restrict__ R, int ldr, int* __restrict__ info) {
-    const size_t n = (size_t)D * D;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
-        const int r = (int)(idx / D), c = (int)(idx % D);
-        R[(size_t)r * ldr + c] = (c >= r) ? S[(size_t)r * lds + c] : 0.0;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *info = 0;
-}
-
 #include "gsmvi_chol64.h"
-
-// Block step k: diagonal factor + block-row solve.  grid.x = 1 + ceil(cols_right / 64).
-// The factored diagonal block goes to diag_out (workspace), NOT into R: sibling workgroups of this
-// launch read the un-factored block from R with no ordering against workgroup 0.
-__global__ __launch_bounds__(256) void k_potrf_panel(int D, int k, double* __restrict__ R, int ldr,
-                                                     double* __restrict__ diag_out, int* __restrict__ info) {
-    __shared__ __attribute__((aligned(16))) double T[64 * TS];
-    __shared__ double rinv[64];
-    __shared__ int sh_fail;
-    const int tid = threadIdx.x;
-    const int k0 = k * NB;
-    const int nb = (D - k0) < NB ? (D - k0) : NB;
-    for (int e = tid; e < 64 * 64; e += 256) {
-        const int i = e >> 6, q = e & 63;
-        T[i * TS + q] = (i < nb && q < nb && q >= i) ? R[(size_t)(k0 + i) * ldr + k0 + q] : (i == q ? 1.0 : 0.0);
-    }
-    if (tid < 64) rinv[tid] = 1.0;
-    // this workgroup's 64 columns of the block row: loaded BEFORE the factorisation so that their latency hides behind it
-    const int colq = tid >> 2, q = tid & 3;
-    const int col = k0 + NB + ((int)blockIdx.x - 1) * 64 + colq;
-    const int colc = col < D ? col : D - 1;
-    double x[16];
-    if (blockIdx.x > 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = R[(size_t)(k0 + q + 4 * r) * ldr + colc];
-    }
-    __syncthreads();
-    chol64_lds(T, rinv, nb, &sh_fail);
-    if (blockIdx.x == 0) {
-        for (int e = tid; e < 64 * 64; e += 256) diag_out[e] = T[(e >> 6) * TS + (e & 63)];
-        if (tid == 0 && sh_fail != 0 && *info == 0) *info = k0 + sh_fail;
-        return;
-    }
-    // Solve R_kk^T X = S_k,cols for 64 columns per workgroup.  A column is shared by a QUAD of lanes:
-    // lane q of the quad owns rows q, q+4, ..., q+60 (16 registers), so the 2016 multiply-adds of a
-    // column are spread over four lanes and stay balanced as the pivot advances.  At pivot p the
-    // owning lane scales x[p] and broadcasts it inside the quad; every lane then updates its rows
-    // t > p:  x[t] -= R_kk[p][t] x[p].  (A workgroup with blockIdx.x > 0 exists only when columns remain
-    // to the right, i.e. nb == 64.)
-#pragma unroll
-    for (int p = 0; p < NB; ++p) {
-        const int pr = p >> 2, pq = p & 3;                 // pivot row p lives in register pr of quad lane pq
-        const double mine = x[pr] * rinv[p];
-        if (q == pq) x[pr] = mine;
-        const double xp = quad_bcast_rt<0>(mine, pq);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // rows q + 4r > p  (compile-time bound on r, lane-dependent part folded into a select)
-            if (4 * r + 3 > p) {
-                const int t = q + 4 * r;
-                const double rv = T[p * TS + t];
-                x[r] -= (t > p) ? rv * xp : 0.0;
-            }
-        }
-    }
-    if (col < D) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) R[(size_t)(k0 + q + 4 * r) * ldr + col] = x[r];
-    }
-}
-
-// Trailing update with block row k: for 64x64 tiles (ti <= tj) of the trailing matrix,
-//   S[I][J] -= sum_p R[k0+p][I]^T R[k0+p][J],  MFMA K = 64.
-__global__ __launch_bounds__(256) void k_potrf_trailing(int D, int k, double* __restrict__ R, int ldr) {
-    constexpr int RS = 66;
-    __shared__ double FA[64 * RS];
-    __shared__ double FB[64 * RS];
-    const int k0 = k * NB, t0 = k0 + NB;
-    const int ntr = (D - t0 + 63) >> 6;
-    int ti, tj;
-    {
-        const int idx = blockIdx.x;
-        const double q = 2.0 * ntr + 1.0;
-        int t = (int)((q - sqrt(q * q - 8.0 * (double)idx)) * 0.5);
-        if (t < 0) t = 0;
-        while (t > 0 && t * ntr - (t * (t - 1)) / 2 > idx) --t;
-        while ((t + 1) * ntr - ((t + 1) * t) / 2 <= idx) ++t;
-        ti = t;
-        tj = t + (idx - (t * ntr - (t * (t - 1)) / 2));
-    }
-    const int I0 = t0 + ti * 64, J0 = t0 + tj * 64;
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
-    const int wr = w >> 1, wc = w & 1;
-
-    // stage R[k0 + p][I0 + i] -> FA[i][p], R[k0 + p][J0 + j] -> FB[j][p]
-    double va[16], vb[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int p = (tid >> 6) + 4 * q, i = tid & 63;
-        const int gi = I0 + i, gj = J0 + i;
-        va[q] = (gi < D) ? R[(size_t)(k0 + p) * ldr + gi] : 0.0;
-        vb[q] = (gj < D) ? R[(size_t)(k0 + p) * ldr + gj] : 0.0;
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int p = (tid >> 6) + 4 * q, i = tid & 63;
-        FA[i * RS + p] = va[q];
-        FB[i * RS + p] = vb[q];
-    }
-    __syncthreads();
-    v4d acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-    const double* a0p = FA + (32 * wr + c) * RS + ks;
-    const double* a1p = a0p + 16 * RS;
-    const double* b0p = FB + (32 * wc + c) * RS + ks;
-    const double* b1p = b0p + 16 * RS;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        const double a0 = a0p[4 * s], a1 = a1p[4 * s], b0 = b0p[4 * s], b1 = b1p[4 * s];
-        acc[0][0] = GSMVI_MFMA_F64(a0, b0, acc[0][0]);
-        acc[0][1] = GSMVI_MFMA_F64(a0, b1, acc[0][1]);
-        acc[1][0] = GSMVI_MFMA_F64(a1, b0, acc[1][0]);
-        acc[1][1] = GSMVI_MFMA_F64(a1, b1, acc[1][1]);
-    }
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = I0 + 32 * wr + 16 * rt + ks + 4 * r;
-                const int col = J0 + 32 * wc + 16 * ct + c;
-                if (row < D && col < D && col >= row) R[(size_t)row * ldr + col] -= acc[rt][ct][r];
-            }
-}
-
-// copy the factored diagonal blocks from the workspace into R
-__global__ __launch_bounds__(256) void k_potrf_finish(int D, const double* __restrict__ diag, double* __restrict__ R,
-                                                      int ldr) {
-    const int k = blockIdx.x, k0 = k * NB;
-    const int nb = (D - k0) < NB ? (D - k0) : NB;
-    const double* T = diag + (size_t)k * NB * NB;
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-        const int i = e >> 6, q = e & 63;
-        if (i < nb && q < nb && q >= i) R[(size_t)(k0 + i) * ldr + k0 + q] = T[e];
-    }
-}
 
 // =====================================================================================
 // C = F^T F (Gram matrix of the columns; the covariance a square factor represents).  One workgroup per 64x64 tile
-// of the upper triangle, K = D in chunks of 64 staged transposed in LDS exactly like k_potrf_trailing; the mirror
+// of the upper triangle, K = D in chunks of 64 staged transposed in LDS ([col][66]); the mirror
 // tile is written from the same accumulators, so C is exactly symmetric.  Used once per fit (return value of the
 // factor-form fit) and per monitor checkpoint: not on the per-iteration path.
 // =====================================================================================
@@ -303,237 +147,24 @@ int gsmvi_whiten_impl(hipStream_t st, int D, int nrows, const double* R, int ldr
 }
 
 // =====================================================================================
-// Version 2: ONE launch per block step (the version above: two -- and 15 us of 64-pivot substitutions per step on every
-// workgroup).  Step k, one 256-thread workgroup per 64x64 tile (I, J), k <= I <= J, of the trailing matrix:
+// Step k, one 512-thread workgroup per 64x64 tile (I, J), k <= I <= J, of the trailing matrix:
 //   X_I = W_{k-1} B_I,  X_J = W_{k-1} B_J     B = block row k-1 as it stood BEFORE its triangular solve (rowbuf),
 //                                             W_{k-1} = R_{k-1,k-1}^-T (wbuf): the solve is an MFMA product
 //   T   = A[I][J] - X_I^T X_J                 (A read from S until a tile has been written once, then from R)
 //   I == k          : X_J is block (k-1, J) of the factor -> R; the mirror block (J, k-1) is zeroed
-//   I == k,  J == k : T = R_kk^T R_kk in LDS (chol64), R_kk -> R, W_k = R_kk^-T by one forward substitution -> wbuf
+//   I == k,  J == k : T = R_kk^T R_kk in LDS (chol64), R_kk -> R, W_k = R_kk^-T -> wbuf
 //   I == k,  J >  k : T is block (k, J) of the NEXT unsolved block row -> rowbuf (double-buffered with wbuf by k & 1)
 //   I >  k          : T -> R
-// The diagonal tile is workgroup 0 of its launch; its chain (2 products, chol64, substitution) bounds the step.
-// Products: X[i][j] = sum_p W[i][p] B[p][j] and T[i][j] -= sum_p X_I[p][i] X_J[p][j], both as k_potrf_trailing
-// (operands transposed in LDS [row][66], 2x2 MFMA tiles per wave, K = 64).
-// =====================================================================================
-__device__ __forceinline__ void potrf_mma64(const double* FA, const double* FB, v4d (&acc)[2][2], int wr, int wc, int c,
-                                            int ks) {
-    constexpr int RS = 66;
-    const double* a0p = FA + (32 * wr + c) * RS + ks;
-    const double* a1p = a0p + 16 * RS;
-    const double* b0p = FB + (32 * wc + c) * RS + ks;
-    const double* b1p = b0p + 16 * RS;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        const double a0 = a0p[4 * s], a1 = a1p[4 * s], b0 = b0p[4 * s], b1 = b1p[4 * s];
-        acc[0][0] = GSMVI_MFMA_F64(a0, b0, acc[0][0]);
-        acc[0][1] = GSMVI_MFMA_F64(a0, b1, acc[0][1]);
-        acc[1][0] = GSMVI_MFMA_F64(a1, b0, acc[1][0]);
-        acc[1][1] = GSMVI_MFMA_F64(a1, b1, acc[1][1]);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_potrf_step(int D, int k, const double* S, int lds, double* R, int ldr,
-                                                    double* rowbuf, int ldrow, double* wbuf, int* __restrict__ info) {
-    constexpr int RS = 66;
-    static_assert(RS == TS, "chol64 runs in the staging buffer");
-    __shared__ __attribute__((aligned(16))) double L0[64 * RS];     // W (operand A of the solve), later the tile for chol64
-    __shared__ __attribute__((aligned(16))) double L1[64 * RS];     // B_I / B_J transposed, later X_J transposed
-    __shared__ __attribute__((aligned(16))) double L2[64 * RS];     // X_I transposed
-    __shared__ double rinv[64];
-    __shared__ int sh_fail;
-    const int nblk = (D + NB - 1) / NB, m = nblk - k;
-    int ti, tj;
-    {
-        const int idx = blockIdx.x;
-        int t = 0, base = 0;
-        while (base + (m - t) <= idx) { base += m - t; ++t; }
-        ti = t;
-        tj = t + (idx - base);
-    }
-    const int I0 = (k + ti) * NB, J0 = (k + tj) * NB;
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
-    const int wr = w >> 1, wc = w & 1;
-    const bool first_row = (ti == 0), diag = (ti == 0 && tj == 0), same = (ti == tj);
-    const double* Asrc = (k <= 1) ? S : R;
-    const int lda = (k <= 1) ? lds : ldr;
-    const double* Bsrc = (k == 1) ? S : rowbuf + (size_t)((k - 1) & 1) * NB * ldrow;    // unsolved block row k-1
-    const int ldb = (k == 1) ? lds : ldrow;
-
-    // ---- every global load of this workgroup up front: the tile (accumulator layout), W, B_I, B_J ----
-    double tv[2][2][4];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = I0 + 32 * wr + 16 * rt + ks + 4 * r, col = J0 + 32 * wc + 16 * ct + c;
-                tv[rt][ct][r] = (row < D && col < D) ? Asrc[(size_t)row * lda + col] : ((row == col) ? 1.0 : 0.0);
-            }
-    v4d acc[2][2];
-    if (k > 0) {
-        const double* Wk = wbuf + (size_t)((k - 1) & 1) * NB * NB;
-        double vw[16], vi[16], vj[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int e = tid + 256 * q;                          // W is stored [i][p] row-major: straight copy
-            vw[q] = Wk[e];
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int p = (tid >> 6) + 4 * q, i = tid & 63;
-            const int gi = I0 + i, gj = J0 + i;
-            vi[q] = (gi < D) ? Bsrc[(size_t)p * ldb + gi] : 0.0;
-            vj[q] = (!same && gj < D) ? Bsrc[(size_t)p * ldb + gj] : 0.0;
-        }
-        // (for k == 1 the block row sits in rows 0..63 of S; for k >= 2 in the row buffer: p indexes both alike)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int e = tid + 256 * q;
-            L0[(e >> 6) * RS + (e & 63)] = vw[q];
-            const int p = (tid >> 6) + 4 * q, i = tid & 63;
-            L1[i * RS + p] = vi[q];
-        }
-        __syncthreads();
-        // X_I = W B_I
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-        potrf_mma64(L0, L1, acc, wr, wc, c, ks);
-        __syncthreads();                                          // all reads of L1 (B_I) are done
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 32 * wr + 16 * rt + ks + 4 * r, col = 32 * wc + 16 * ct + c;
-                    L2[col * RS + row] = acc[rt][ct][r];          // X_I^T for the tile product
-                    if (first_row && same) {                      // (k, k): X_I is block (k-1, k) of the factor
-                        const int gc = J0 + col;
-                        if (gc < D) R[(size_t)((k - 1) * NB + row) * ldr + gc] = acc[rt][ct][r];
-                    }
-                }
-        if (!same) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int p = (tid >> 6) + 4 * q, i = tid & 63;
-                L1[i * RS + p] = vj[q];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-            potrf_mma64(L0, L1, acc, wr, wc, c, ks);              // X_J = W B_J
-            __syncthreads();
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 32 * wr + 16 * rt + ks + 4 * r, col = 32 * wc + 16 * ct + c;
-                        L1[col * RS + row] = acc[rt][ct][r];      // X_J^T
-                        if (first_row) {
-                            const int gc = J0 + col;
-                            if (gc < D) R[(size_t)((k - 1) * NB + row) * ldr + gc] = acc[rt][ct][r];
-                        }
-                    }
-        }
-        __syncthreads();
-        // T -= X_I^T X_J
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-        potrf_mma64(L2, same ? L2 : L1, acc, wr, wc, c, ks);
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) tv[rt][ct][r] -= acc[rt][ct][r];
-        if (first_row) {                                          // zero the mirror block (J, k-1) of the finished block row
-            for (int e = tid; e < NB * NB; e += 256) {
-                const int jr = e >> 6, p = e & 63;
-                if (J0 + jr < D) R[(size_t)(J0 + jr) * ldr + (k - 1) * NB + p] = 0.0;
-            }
-        }
-    }
-    if (!diag) {
-        double* dst = first_row ? rowbuf + (size_t)(k & 1) * NB * ldrow : R;
-        const int ldd = first_row ? ldrow : ldr;
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int lrow = 32 * wr + 16 * rt + ks + 4 * r, col = J0 + 32 * wc + 16 * ct + c;
-                    const int row = first_row ? lrow : I0 + lrow;
-                    if (I0 + lrow < D && col < D) dst[(size_t)row * ldd + col] = tv[rt][ct][r];
-                }
-        return;
-    }
-    // ---- the diagonal tile (k, k): factor it, publish R_kk and W_k = R_kk^-T ----
-    const int nb = (D - I0) < NB ? (D - I0) : NB;
-    __syncthreads();                                              // everyone is done with L0 (W of the previous step)
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 32 * wr + 16 * rt + ks + 4 * r, j = 32 * wc + 16 * ct + c;
-                L0[i * RS + j] = (i < nb && j < nb) ? tv[rt][ct][r] : (i == j ? 1.0 : 0.0);
-            }
-    if (tid < 64) rinv[tid] = 1.0;
-    __syncthreads();
-    chol64_lds(L0, rinv, nb, &sh_fail);
-    if (tid == 0 && sh_fail != 0 && *info == 0) *info = I0 + sh_fail;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int i = e >> 6, j = e & 63;
-        if (i < nb && j < nb) R[(size_t)(I0 + i) * ldr + I0 + j] = (j >= i) ? L0[i * RS + j] : 0.0;
-    }
-    if (m == 1) return;                                           // last step: nobody needs W
-    // W = R_kk^-T: column cq of the lower-triangular W per quad of lanes (forward substitution with L = R_kk^T,
-    // L[t][p] = R_kk[p][t]; lane q of the quad owns rows q, q+4, ..), as in k_gsmf_small
-    {
-        const int cq = tid >> 2, q = tid & 3;
-        double x[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = (q + 4 * r == cq) ? 1.0 : 0.0;
-#pragma unroll
-        for (int p = 0; p < 64; ++p) {
-            const int pr = p >> 2, pq = p & 3;
-            const double mine = x[pr] * rinv[p];
-            if (q == pq) x[pr] = mine;
-            const double xp = quad_bcast_rt<0>(mine, pq);
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (4 * r + 3 > p) {
-                    const int t = q + 4 * r;
-                    const double rv = L0[p * RS + t];
-                    x[r] -= (t > p) ? rv * xp : 0.0;
-                }
-        }
-        double* Wk = wbuf + (size_t)(k & 1) * NB * NB;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Wk[(q + 4 * r) * NB + cq] = x[r];     // W[t][cq]
-    }
-}
-
-// =====================================================================================
-// Version 3 = version 2 with EIGHT waves per tile workgroup:
+// The diagonal tile is workgroup 0 of its launch; its chain (2 products, chol64, W) bounds the step.
+// Eight waves per tile workgroup:
 //   * the three 64^3 products run two waves per SIMD (wave w: rows 32 wr + 16 rr .., columns 32 wc .., one 16 x 32 strip
 //     of accumulators; the fp64 MFMA pipe delivers 46 TF chip-wide there against 34 TF with one wave per SIMD);
 //   * in the diagonal tile, W_k = R_kk^-T is built by waves 4-7 WHILE waves 0-3 factor the tile: substitution step p needs
 //     row p of the factor and its pivot only, and chol64_rows_s has published both (unscaled, in LDS) by the barrier that
 //     opens pivot p.  The helpers execute one barrier per step (matching the factorisation's per-pivot barrier) and
-//     derive 1/sqrt(d_p) themselves.  Version 2 ran the 64 substitution steps (7.4 us) after the factorisation.
+//     derive 1/sqrt(d_p) themselves.
+// (Round 1's two-launch step and round 2's four-wave fused step were removed in round 3: 630 / 504 us against 439 us at
+// D = 1024; profiles/r02/.)
 // =====================================================================================
 // nsteps (wave-uniform, <= 16): k-steps of 4 to run -- the solve's left operand W is lower triangular, so the row block
 // 16 rb .. 16 rb + 15 of X = W B needs k < 16 (rb + 1) only
@@ -769,48 +400,19 @@ __global__ __launch_bounds__(512) void k_potrf_step8(int D, int k, const double*
 
 #undef PSTAMP
 
-static int potrf_v1(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
-                    int* info_dev) {
-    double* diag = ctx->pp;                       // nblk x 64 x 64 doubles; the panel-partial slab is idle here
-    int blocks = (int)(((size_t)D * D + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_potrf_init, dim3(blocks), dim3(256), 0, st, D, S, lds, R, ldr, info_dev);
-    const int nblk = (D + NB - 1) / NB;
-    for (int k = 0; k < nblk; ++k) {
-        const int right = D - (k + 1) * NB;
-        const int pg = 1 + (right > 0 ? (right + 63) / 64 : 0);
-        hipLaunchKernelGGL(k_potrf_panel, dim3(pg), dim3(256), 0, st, D, k, R, ldr,
-                           diag + (size_t)k * NB * NB, info_dev);
-        if (right > 0) {
-            const int ntr = (right + 63) / 64;
-            hipLaunchKernelGGL(k_potrf_trailing, dim3(ntr * (ntr + 1) / 2), dim3(256), 0, st, D, k, R, ldr);
-        }
-    }
-    hipLaunchKernelGGL(k_potrf_finish, dim3(nblk), dim3(256), 0, st, D, diag, R, ldr);
-    return 0;
-}
-
 __global__ void k_potrf_clear_info(int* info) { *info = 0; }
 
 int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                      int* info_dev) {
-    if (ctx->tune_potrf_v == 1) {
-        potrf_v1(ctx, st, D, S, lds, R, ldr, info_dev);
-    } else {
-        // one launch per block step; workspace (the idle panel-partial slab): two row buffers and two W blocks
-        const int nblk = (D + NB - 1) / NB, ldrow = nblk * NB;
-        double* rowbuf = ctx->pp;
-        double* wbuf = rowbuf + (size_t)2 * NB * ldrow;
-        hipLaunchKernelGGL(k_potrf_clear_info, dim3(1), dim3(1), 0, st, info_dev);
-        for (int k = 0; k < nblk; ++k) {
-            const int m = nblk - k;
-            if (ctx->tune_potrf_v == 2)
-                hipLaunchKernelGGL(k_potrf_step, dim3(m * (m + 1) / 2), dim3(256), 0, st, D, k, S, lds, R, ldr, rowbuf,
-                                   ldrow, wbuf, info_dev);
-            else
-                hipLaunchKernelGGL(k_potrf_step8, dim3(m * (m + 1) / 2), dim3(512), 0, st, D, k, S, lds, R, ldr, rowbuf,
-                                   ldrow, wbuf, info_dev, ctx->timeline_stamps(3));
-        }
+    // one launch per block step; workspace (the idle panel-partial slab): two row buffers and two W blocks
+    const int nblk = (D + NB - 1) / NB, ldrow = nblk * NB;
+    double* rowbuf = ctx->pp;
+    double* wbuf = rowbuf + (size_t)2 * NB * ldrow;
+    hipLaunchKernelGGL(k_potrf_clear_info, dim3(1), dim3(1), 0, st, info_dev);
+    for (int k = 0; k < nblk; ++k) {
+        const int m = nblk - k;
+        hipLaunchKernelGGL(k_potrf_step8, dim3(m * (m + 1) / 2), dim3(512), 0, st, D, k, S, lds, R, ldr, rowbuf, ldrow,
+                           wbuf, info_dev, ctx->timeline_stamps(3));
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -23,6 +23,7 @@ class HipEngine:
     """One context (workspace + launch heuristics) on one device; grows on demand."""
 
     name = "hip"
+    bam_max_batch = 128        # device chain of BaM's (B+1) x (B+1) matrix function (csrc/gsmvi_bam_small.hip)
 
     def __init__(self, device=None, max_D=0, max_B=0):
         self.lib = _lib.load_library()
@@ -135,8 +136,10 @@ class HipEngine:
         return C.c_void_p(t.data_ptr())
 
     # ---- the hot path -------------------------------------------------------------------
-    def gsm_update(self, X, G, mu0, S0, out=None):
-        """(mu, S) = gsm_update(samples, vs, mu0, S0)   [gsmvi/gsm_numpy.py:27-55]."""
+    def gsm_update(self, X, G, mu0, S0, out=None, general=False):
+        """(mu, S) = gsm_update(samples, vs, mu0, S0)   [gsmvi/gsm_numpy.py:27-55].  S0 must be symmetric (a covariance)
+        unless ``general=True``, which reads all of S0 (gsmvi_gsm_update_general_f64: the reference's literal
+        S0 + mean semantics for any square S0; not a performance path)."""
         assert X.dim() == 2 and G.dim() == 2            # gsm_numpy.py:43-44
         B, D = X.shape
         assert G.shape == (B, D) and mu0.shape == (D,) and S0.shape == (D, D)
@@ -146,7 +149,8 @@ class HipEngine:
         pg, ldg = self._mat(G, "vs")
         ps0, lds0 = self._mat(S0, "S0")
         ps, lds = self._mat(S, "S")
-        _lib.check("gsmvi_gsm_update_f64", self.lib.gsmvi_gsm_update_f64(
+        name = "gsmvi_gsm_update_general_f64" if general else "gsmvi_gsm_update_f64"
+        _lib.check(name, getattr(self.lib, name)(
             self._ctx, self._stream(), D, B, px, ldx, pg, ldg, self._vec(mu0, "mu0"), ps0, lds0,
             self._vec(mu, "mu"), ps, lds))
         return mu, S
@@ -362,6 +366,8 @@ class HipEngine:
         """(mu, S) of BaM [gsmvi/bam.py:72-114]; S symmetrised, jitter on the diagonal."""
         assert X.dim() == 2 and G.dim() == 2            # bam.py:47-48
         B, D = X.shape
+        if B > self.bam_max_batch:                      # a deterministic limit: never inside a retry loop
+            raise ValueError(f"BaM update: batch size {B} exceeds the device chain's limit of {self.bam_max_batch}")
         self._ensure(D, B)
         mu, S = (self.empty(D), self.empty(D, D)) if out is None else out
         flag = self.new_flag() if flag is None else flag

@@ -14,35 +14,31 @@ def _is_torch(x):
     return isinstance(x, torch.Tensor)
 
 
-def gsm_update(samples, vs, mu0, S0, engine=None):
+def gsm_update(samples, vs, mu0, S0, engine=None, assume_symmetric=None):
     """Drop-in for ``gsm_update(samples, vs, mu0, S0)`` (gsmvi/gsm_numpy.py:27-55, gsmvi/gsm.py:31-58).
 
     Inputs (B,D), (B,D), (D,), (D,D); returns new ``(mu, S)`` and never modifies its inputs.
     numpy in -> float64 numpy out (as gsm_numpy.py:47 does); CUDA torch tensors in -> torch out.
     Shape errors raise AssertionError like the reference (gsm_numpy.py:43-44).
+
+    ``assume_symmetric`` (not in the reference): the fast update kernel reads only the upper triangle of S0 (a
+    covariance is symmetric).  ``None`` (default): a HOST S0 is checked on the host before its upload (no device
+    work, no synchronisation) and a non-symmetric one takes the general kernels, which read all of S0 and keep the
+    reference's literal semantics S = S0 + mean (gsm_numpy.py:50-53); a DEVICE S0 is taken to be symmetric -- no
+    D x D compare and no host synchronisation sit in front of the update.  ``False`` forces the general kernels,
+    ``True`` skips the host check as well.
     """
     assert len(samples.shape) == 2
     assert len(vs.shape) == 2
     eng = engine if engine is not None else get_engine()
     want_torch = _is_torch(samples)
-    S0d = eng.asarray(S0)
-    # The fast update kernel reads only the upper triangle of S0 (a covariance is symmetric).  This user-facing
-    # one-off call keeps the reference's semantics (S = S0 + mean, gsm_numpy.py:50-53) for ANY S0: a non-symmetric
-    # S0 is routed to the generic kernels, which read all of it.  The fit loops call the engine directly.
-    symmetric = bool((S0d == S0d.T).all()) if _is_torch(S0d) else bool(np.array_equal(S0d, S0d.T))
-    Xd, Gd, m0 = eng.asarray(samples), eng.asarray(vs), eng.asarray(mu0)
-    if symmetric or not hasattr(eng, "set_tuning"):
+    if assume_symmetric is None:
+        assume_symmetric = True if _is_torch(S0) else bool(np.array_equal(np.asarray(S0), np.asarray(S0).T))
+    Xd, Gd, m0, S0d = eng.asarray(samples), eng.asarray(vs), eng.asarray(mu0), eng.asarray(S0)
+    if assume_symmetric:
         mu, S = eng.gsm_update(Xd, Gd, m0, S0d)
     else:
-        # row b of the panel stage is g_b^T S0; the reference forms S0 g_b (gsm_numpy.py:7): hand the panel stage
-        # S0^T, and let the generic update kernel read all of S0
-        eng.set_tuning("no_fast", 1)
-        try:
-            S0t = S0d.T.contiguous() if _is_torch(S0d) else np.ascontiguousarray(S0d.T)
-            rec = eng.gsm_local_stage(Xd, Gd, m0, S0t)
-            mu, S = eng.gsm_apply(rec, m0, S0d)
-        finally:
-            eng.set_tuning("no_fast", 0)
+        mu, S = eng.gsm_update(Xd, Gd, m0, S0d, general=True)
     return (mu, S) if want_torch else (eng.to_numpy(mu), eng.to_numpy(S))
 
 

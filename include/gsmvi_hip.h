@@ -18,8 +18,8 @@
  *
  * Conventions
  *   - All matrices are row-major float64 in DEVICE memory; `ld*` are leading dimensions in elements.
- *   - Calls are asynchronous on `stream` (a hipStream_t passed as void*); nothing synchronises (sole
- *     exception: the opt-in bam_host test knob of gsmvi_bam_update_f64), so call sequences can be captured into a hipGraph.
+ *   - Calls are asynchronous on `stream` (a hipStream_t passed as void*); nothing synchronises,
+ *     so call sequences can be captured into a hipGraph.
  *   - Inputs are never modified; outputs must not alias inputs (reference updates are pure,
  *     gsm_numpy.py:47-55) unless an entry point says otherwise.
  *   - S0 must be symmetric (it is a covariance); the kernels read it once, by rows.
@@ -65,7 +65,9 @@ size_t gsmvi_workspace_bytes(int max_D, int max_B);
  * current when they are called (what torch.cuda.set_device / hipSetDevice in the calling loop guarantees). */
 int gsmvi_create(gsmvi_ctx** out, int device, int max_D, int max_B);
 int gsmvi_destroy(gsmvi_ctx* ctx);
-/* Launch-heuristic knob for experiments: name in {"panel_kc","update_tile", ...}; value<=0 = auto */
+/* Launch-heuristic knobs for tests and A/B measurements: "panel_kc" (split-K count of the panel products; <= 0 = auto),
+ * "no_fast" (1 = force the guarded generic kernels), "direct_out" (0 = always product + finish pass), "update_sb",
+ * "scalars_nt", "bam_full", "bam_kenq"; diagnostics "timeline", "cov_dbg" (see gsmvi_hip_debug.h). */
 int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value);
 
 /*
@@ -78,13 +80,24 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value);
  * PRECONDITION: S0 is symmetric (a covariance).  For D % 32 == 0 and B in {16, 32, 64} the update kernel reads only
  * the UPPER triangle of S0 and mirrors the result, so S comes out exactly symmetric; for other shapes the generic
  * kernel reads all of S0.  A non-symmetric S0 therefore gives shape-dependent results that differ from
- * gsm_numpy.py:50-53 (S0 + mean); the Python drop-in gsm_update() symmetry-checks host inputs for that reason.
+ * gsm_numpy.py:50-53 (S0 + mean): use gsmvi_gsm_update_general_f64 for such an S0 (the Python drop-in gsm_update() does
+ * so for host inputs it finds non-symmetric, and on request for device inputs).
  * One context per stream: calls on one gsmvi_ctx share its workspace and must not run concurrently.
  */
 int gsmvi_gsm_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
                          const double* X, int ldx, const double* G, int ldg,
                          const double* mu0, const double* S0, int lds0,
                          double* mu, double* S, int lds);
+
+/*
+ * The same update for an S0 that is not symmetric: the reference's literal semantics S = S0 + mean_b (...) with S0 g_b in
+ * the per-sample stage (gsm_numpy.py:7,50-53) for ANY square S0.  Reads all of S0 (transposed panel product + the guarded
+ * update kernel); the Python drop-in gsm_update(..., assume_symmetric=False) calls it.  Not a performance path.
+ */
+int gsmvi_gsm_update_general_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
+                                 const double* X, int ldx, const double* G, int ldg,
+                                 const double* mu0, const double* S0, int lds0,
+                                 double* mu, double* S, int lds);
 
 /*
  * The same update in two stages, for the batch-sharded multi-GPU path (one process per GPU):
@@ -181,11 +194,6 @@ int gsmvi_gsm_factor_apply_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
  * scalars, ms[2] covariance update (-1 where a stage did not run).
  */
 int gsmvi_set_profiling(gsmvi_ctx* ctx, int on);
-/* Diagnostic builds only (tuning knob cov_dbg=16): read back in-kernel timeline stamps. */
-int gsmvi_debug_read_stamps(gsmvi_ctx* ctx, unsigned long long* out, int n);
-/* Diagnostic: read back a slice of the context workspace (region 0 panel slabs, 1 finished panels,
- * 2 small matrices). */
-int gsmvi_debug_read_workspace(gsmvi_ctx* ctx, int region, size_t offset, double* out, size_t n);
 int gsmvi_get_profile(gsmvi_ctx* ctx, float* ms, int n);
 
 /*
@@ -257,9 +265,7 @@ int gsmvi_commit_f64(gsmvi_ctx* ctx, void* stream, int D, const int* info_dev,
  * The (B+1) x (B+1) matrix function of bam.py:108-110 -- which the reference evaluates on the host through
  * jax.pure_callback (bam.py:15-22) -- runs on the device for B <= 128 (scaled coupled Newton-Schulz square root on
  * the MFMA pipe + a one-workgroup Cholesky, csrc/gsmvi_bam_small.hip): no synchronisation, graph-capturable.  For
- * B > 128 the call returns GSMVI_ERR_UNSUPPORTED: there is no silent host computation in this library.  (A host
- * eigen-solve of the small problem exists as the tests' reference behind gsmvi_set_tuning(ctx, "bam_host", 1); it
- * synchronises `stream` and cannot be captured.)
+ * B > 128 the call returns GSMVI_ERR_UNSUPPORTED before anything is enqueued: there is no host computation in this library.
  * *info_dev = 1 if that small problem was not finite / not positive definite (then mu, S are NaN-poisoned and the
  * caller's accept/revert must reject them).
  */

@@ -1,0 +1,24 @@
+/*
+ * gsmvi_hip_debug.h -- diagnostic entry points of libgsmvi_hip.so (NOT part of the drop-in boundary of gsmvi_hip.h).
+ * Used by scripts/ (in-kernel timelines) and by a few tests that inspect the workspace; both synchronise the device.
+ */
+#ifndef GSMVI_HIP_DEBUG_H
+#define GSMVI_HIP_DEBUG_H
+
+#include "gsmvi_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Read back in-kernel s_memrealtime stamps: with the tuning knob "timeline" = 1 the first n words of the stamp buffer
+ * ([kernel slot 0..3][512 workgroups][8 words]; workgroups beyond 512 write nothing), otherwise (knob "cov_dbg" bits
+ * 16 / 128) the first n words of the panel-partial slab. */
+int gsmvi_debug_read_stamps(gsmvi_ctx* ctx, unsigned long long* out, int n);
+/* Read back a slice of the context workspace (region 0 panel slabs, 1 finished panels, 2 small matrices). */
+int gsmvi_debug_read_workspace(gsmvi_ctx* ctx, int region, size_t offset, double* out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSMVI_HIP_DEBUG_H */

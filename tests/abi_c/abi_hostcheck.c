@@ -28,8 +28,9 @@ int main(void) {
     EXPECT(gsmvi_create(NULL, 0, 8, 2), GSMVI_ERR_BAD_ARG);
     EXPECT(gsmvi_create(&ctx, 0, 0, 2), GSMVI_ERR_BAD_ARG);
     EXPECT(gsmvi_destroy(NULL), GSMVI_OK);
-    EXPECT(gsmvi_set_tuning(NULL, "fused", 1), GSMVI_ERR_BAD_ARG);
+    EXPECT(gsmvi_set_tuning(NULL, "no_fast", 1), GSMVI_ERR_BAD_ARG);
     EXPECT(gsmvi_gsm_update_f64(NULL, NULL, 8, 2, buf, 8, buf, 8, buf, buf, 8, buf, buf, 8), GSMVI_ERR_BAD_ARG);
+    EXPECT(gsmvi_gsm_update_general_f64(NULL, NULL, 8, 2, buf, 8, buf, 8, buf, buf, 8, buf, buf, 8), GSMVI_ERR_BAD_ARG);
     EXPECT(gsmvi_gsm_local_stage_f64(NULL, NULL, 8, 2, buf, 8, buf, 8, buf, buf, 8, buf, 24), GSMVI_ERR_BAD_ARG);
     EXPECT(gsmvi_gsm_apply_f64(NULL, NULL, 8, 2, buf, 24, buf, buf, 8, buf, buf, 8), GSMVI_ERR_BAD_ARG);
     EXPECT(gsmvi_gsm_update_sharded_f64(NULL, NULL, NULL, 8, 2, buf, 8, buf, 8, buf, buf, 8, buf, buf, buf, 8), GSMVI_ERR_BAD_ARG);

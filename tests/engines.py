@@ -50,8 +50,8 @@ class OracleEngine:
             return out
         return z
 
-    def gsm_update(self, X, G, mu0, S0, out=None):
-        mu, S = orc.gsm_update_batched(X, G, mu0, S0)
+    def gsm_update(self, X, G, mu0, S0, out=None, general=False):
+        mu, S = orc.gsm_update_faithful(X, G, mu0, S0) if general else orc.gsm_update_batched(X, G, mu0, S0)
         if out is not None:
             out[0][...] = mu
             out[1][...] = S

@@ -9,9 +9,13 @@ from conftest import ROOT
 
 
 def _header_symbols():
-    txt = open(os.path.join(ROOT, "include", "gsmvi_hip.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(gsmvi_[a-z0-9_]+)\s*\(", txt)))
+    """Every function include/gsmvi_hip.h (the boundary) and include/gsmvi_hip_debug.h (diagnostics) declare."""
+    out = set()
+    for h in ("gsmvi_hip.h", "gsmvi_hip_debug.h"):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        out |= set(re.findall(r"\b(gsmvi_[a-z0-9_]+)\s*\(", txt))
+    return sorted(out)
 
 
 def test_library_is_built():
@@ -25,7 +29,7 @@ def test_exports_every_declared_symbol():
     declared = _header_symbols()
     assert len(declared) >= 12
     for name in declared:
-        assert hasattr(lib, name), f"{name} declared in gsmvi_hip.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     assert set(_lib.exported_symbols()) == set(declared), "ctypes table out of sync with the header"
 
 

@@ -327,39 +327,3 @@ def test_factor_update_with_linearly_dependent_rows(D, B):
                                            eng.asarray(F0), n_reverts=n_rev)
     F2n = F2.cpu().numpy()
     assert rel_err(F2n.T @ F2n, np.eye(D)) < 1e-9 and np.abs(mu2.cpu().numpy() - mu0).max() < 1e-9
-
-
-def test_small_chain_versions_agree():
-    """k_gsmf_small (four waves, round 1; knob small_v=1) against the default k_gsmf_small8: same update to round-off."""
-    import gsmvi_amd
-    eng = gsmvi_amd.get_engine()
-    for D, B in ((256, 32), (100, 17), (64, 8)):
-        orc, st, F0 = _setup(D, B, D + B)
-        args = tuple(eng.asarray(a) for a in (st["Z"], st["samples"], st["vs"], st["mu0"], F0))
-        mu8, F8, f8 = eng.gsm_factor_update(*args)
-        eng.set_tuning("small_v", 1)
-        try:
-            mu4, F4, f4 = eng.gsm_factor_update(*args)
-        finally:
-            eng.set_tuning("small_v", 2)
-        assert eng.read_flag(f8) == eng.read_flag(f4) == 0
-        assert rel_err(mu4.cpu().numpy(), mu8.cpu().numpy()) < 1e-12
-        a, b = F4.cpu().numpy(), F8.cpu().numpy()
-        assert rel_err(a.T @ a, b.T @ b) < 1e-12
-
-
-def test_forked_factor_update_equals_the_single_stream_form():
-    """Knob fork=1 (U F on the context's second stream; measured slower, kept as an experiment): same numbers."""
-    import torch
-    import gsmvi_amd
-    eng = gsmvi_amd.get_engine()
-    orc, st, F0 = _setup(256, 32, 9)
-    args = tuple(eng.asarray(a) for a in (st["Z"], st["samples"], st["vs"], st["mu0"], F0))
-    mu0_, F0_, _ = eng.gsm_factor_update(*args)
-    eng.set_tuning("fork", 1)
-    try:
-        for _ in range(5):
-            mu1, F1, fl = eng.gsm_factor_update(*args)
-            assert torch.equal(mu1, mu0_) and torch.equal(F1, F0_) and eng.read_flag(fl) == 0
-    finally:
-        eng.set_tuning("fork", 0)

@@ -308,21 +308,14 @@ def test_nonsymmetric_s0_keeps_the_reference_semantics(eng):
     assert abs(S[5, 40] - S[40, 5] - 0.25) < 1e-12
     mu2, S2 = gsmvi_amd.gsm_update(st["samples"], st["vs"], st["mu0"], st["S0"])      # symmetric: fast path again
     assert np.array_equal(S2, S2.T)
-
-
-@pytest.mark.parametrize("D", [100, 256, 1024])
-def test_potrf_versions_agree(eng, D):
-    """The reference forms kept behind the potrf_v knob (1 = round-1 two-launch step, 2 = fused step with four waves)
-    against the default eight-wave step: same factor to round-off, same flag."""
-    orc = _oracle()
-    st = orc.make_update_state(D, 2, D)
-    S = eng.asarray(st["S0"])
-    R3, f3 = eng.potrf(S)
-    try:
-        for v in (1, 2):
-            eng.set_tuning("potrf_v", v)
-            Rv, fv = eng.potrf(S)
-            assert eng.read_flag(fv) == eng.read_flag(f3) == 0
-            assert rel_err(Rv.cpu().numpy(), R3.cpu().numpy()) < 1e-11, v
-    finally:
-        eng.set_tuning("potrf_v", 3)
+    # device tensors: no D x D compare, no synchronisation in front of the update -- symmetric unless the caller says otherwise
+    dev = [eng.asarray(st[k]) for k in ("samples", "vs", "mu0")]
+    mu3, S3 = gsmvi_amd.gsm_update(*dev, eng.asarray(S0), assume_symmetric=False)
+    assert rel_err(S3.cpu().numpy(), S_o) < 1e-11 and rel_err(mu3.cpu().numpy(), mu_o) < 1e-11
+    # the general entry point on ragged and fast-path shapes alike
+    for (D, B) in ((37, 5), (256, 32)):
+        st2 = orc.make_update_state(D, B, 11)
+        S0n = st2["S0"] + 0.05 * np.random.RandomState(1).standard_normal((D, D))
+        mu_o2, S_o2 = orc.gsm_update_faithful(st2["samples"], st2["vs"], st2["mu0"], S0n)
+        mu4, S4 = gsmvi_amd.gsm_update(st2["samples"], st2["vs"], st2["mu0"], S0n)
+        assert rel_err(mu4, mu_o2) < 1e-11 and rel_err(S4, S_o2) < 1e-11, (D, B)
