@@ -11,12 +11,22 @@
 // A factor of M:  Gamma = Rt Rt^T = Rg^T Rg (Cholesky),  I + Rg J Rg^T = T^T T (Cholesky; it exists iff
 // M is positive definite -- this IS the reference's accept/revert test, gsm_numpy.py:121-125,132-146,
 // on an n x n matrix instead of D x D),  C = I + Rt^T Rg^-1 (T - I) Rg^-T Rt,  C^T C = M, hence
-//   Fm' = C Fm = Fm + Rt^T Fs,   Fs = Rg^-1 (T - I) Rg^-T Tm,   Tm = Rt Fm = [X - mu; U Fm].
-// Per iteration Fm is read three times (W, U Fm, update) and written once; no O(D^3) work.
+//   Fm' = C Fm = Fm + Rt^T K Rt Fm,   K = Rg^-1 (T - I) Rg^-T.
+// Round 3 -- everything of size D is done in the basis [Z; V], V = W + Z (the whitened residual, -> 0 at the fixed point):
+//   u_b = beta_b z_b + alpha_b v_b,  alpha = 1/(1+rho),  beta = (w.v / den)/(1+rho),  i.e.  Rt = S [Z; V],
+//   S = [[I, 0], [diag(beta), diag(alpha)]].  The per-sample dots are entries of the Gram matrix
+//   Gamma1 = [Z; V][Z; V]^T (zz, zv, vv on its diagonals: zw = zv - zz, ww = vv - 2 zv + zz, w.v = vv - zv), so there is no
+//   per-sample launch and no pass over D between W and the next product:  Gamma = S Gamma1 S^T (formed inside the
+//   small-matrix kernel),  K'' = S^T K S,  Tm = [Z; V] Fm = [X - mu; V Fm],
+//   Fm' = Fm + [Z; V]^T (K'' Tm),   mu' = mu + (1/B) sum_b (beta_b (x_b - mu) + alpha_b (v_b Fm)).
+//   (V, not W, is the second block: beta z and alpha v are both small near the fixed point, so no large terms cancel
+//   in Gamma's U-block -- the rank-revealing rule for dependent rows relies on its rounding floor.)
+// Per iteration Fm is read three times (W, V Fm, update) and written once; no O(D^3) work.
 // Requires n = 2B <= D (Gamma must be nonsingular) and n <= 128.
 #include "gsmvi_common.h"
 #include "gsmvi_ctx.h"
 #include "gsmvi_chol64.h"
+#include "gsmvi_chol64b.h"
 #include "../../include/gsmvi_hip.h"
 
 // ---- transposed panel product partials: Pp[kc][r][j] = sum_{i in chunk(kc)} A[r][i] M[j][i] ----------
@@ -172,70 +182,34 @@ __global__ __launch_bounds__(512) void k_panel_t_fast(int D, int nrows, const do
     }
 }
 
-// ---- whitened per-sample stage: one 1024-thread workgroup per sample (D <= 16384) -----------------
-//   w_b = sum_kc Pp[kc][b];  scalars;  u_b;  writes Rt = [Z; U] (n x D), its transpose Rtt (D x nq) and the
-//   top half of Tm = Rt Fm, i.e. X - mu.
-template <int EPT>
-__global__ __launch_bounds__(1024) void k_gsmf_scalars(int D, int B, int KC, const double* __restrict__ Z, int ldz,
-                                                       const double* __restrict__ X, int ldx,
-                                                       const double* __restrict__ mu0,
-                                                       const double* __restrict__ Pp, double* __restrict__ Rt,
-                                                       double* __restrict__ Rtt, int nq, double* __restrict__ Tm) {
-    __shared__ double lds[34];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    double wv[EPT], zv[EPT], xv[EPT], mv[EPT];
+// ---- elementwise stage behind W = G Fm^T: finishes the split-K slabs and builds the D-sized operands -------------
+//   w = sum_kc Pp[kc][b];  Rt1 = [Z; V] with V = W + Z (n x D);  top half of Tm1 = [Z; V] Fm, i.e. X - mu.
+__global__ __launch_bounds__(256) void k_gsmf_prep(int D, int B, int KC, const double* __restrict__ Z, int ldz,
+                                                   const double* __restrict__ X, int ldx,
+                                                   const double* __restrict__ mu0, const double* __restrict__ Pp,
+                                                   double* __restrict__ Rt1, double* __restrict__ Tm1) {
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= D) return;
+    double pw[GSMVI_MAX_KC];
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {                 // all loads of the row in one batch
-        const int i = tid + 1024 * e;
-        const int ic = i < D ? i : D - 1;
-        double t = 0.0;
-        for (int kc = 0; kc < KC; ++kc) t += Pp[((size_t)kc * B + b) * D + ic];
-        wv[e] = t;
-        zv[e] = Z[(size_t)b * ldz + ic];
-        xv[e] = X[(size_t)b * ldx + ic];
-        mv[e] = mu0[ic];
-    }
-    double p0 = 0.0, p1 = 0.0;
+    for (int kc = 0; kc < GSMVI_MAX_KC; ++kc) pw[kc] = Pp[((size_t)(kc < KC ? kc : KC - 1) * B + b) * D + i];
+    const double z = Z[(size_t)b * ldz + i], x = X[(size_t)b * ldx + i], m = mu0[i];
+    double w = 0.0;
 #pragma unroll
-    for (int e = 0; e < EPT; ++e)
-        if (tid + 1024 * e < D) {
-            p0 += wv[e] * wv[e];
-            p1 += zv[e] * wv[e];
-        }
-    p0 = wave_sum(p0);
-    p1 = wave_sum(p1);
-    if ((tid & 63) == 0) {
-        lds[2 * (tid >> 6)] = p0;
-        lds[2 * (tid >> 6) + 1] = p1;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double ww = 0.0, zw = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            ww += lds[2 * k];
-            zw += lds[2 * k + 1];
-        }
-        const double rho = 0.5 * sqrt(1.0 + 4.0 * (ww + zw * zw)) - 0.5;
-        const double den = 1.0 + rho - zw;
-        lds[32] = 1.0 / (1.0 + rho);
-        lds[33] = (ww + zw) / den;
-    }
-    __syncthreads();
-    const double beta = lds[32], cz = lds[33];
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int i = tid + 1024 * e;
-        if (i < D) {
-            const double z = zv[e];
-            const double u = ((wv[e] + z) + z * cz) * beta;
-            Rt[(size_t)b * D + i] = z;
-            Rt[(size_t)(B + b) * D + i] = u;
-            Rtt[(size_t)i * nq + b] = z;
-            Rtt[(size_t)i * nq + B + b] = u;
-            Tm[(size_t)b * D + i] = xv[e] - mv[e];
-        }
-    }
+    for (int kc = 0; kc < GSMVI_MAX_KC; ++kc) w += (kc < KC) ? pw[kc] : 0.0;
+    Rt1[(size_t)b * D + i] = z;
+    Rt1[(size_t)(B + b) * D + i] = w + z;
+    Tm1[(size_t)b * D + i] = x - m;
+}
+
+// The per-sample scalars from the Gram matrix Gamma1 = [Z; V][Z; V]^T (zz = Gamma1[b][b], zv = Gamma1[b][B+b],
+// vv = Gamma1[B+b][B+b]):  u_b = beta z_b + alpha v_b  (gsm_numpy.py:8-17 in whitened form, see the file header)
+__device__ __forceinline__ void gsmf_coefs(double zz, double zv, double vv, double* alpha, double* beta) {
+    const double zw = zv - zz, ww = vv - 2.0 * zv + zz, wv = vv - zv;
+    const double rho = 0.5 * sqrt(1.0 + 4.0 * (ww + zw * zw)) - 0.5;
+    const double den = 1.0 + rho - zw;
+    *alpha = 1.0 / (1.0 + rho);
+    *beta = (wv / den) / (1.0 + rho);
 }
 
 // LDS[128][130] <- upper triangle of the n x n matrix src (n <= 128), zero below, identity beyond n.
@@ -413,14 +387,15 @@ __global__ __launch_bounds__(256) void k_gsmf_update(int D, int KF, const double
 // 16-row block w >> 1 and the two 16-column blocks of half w & 1.  Every global load of the workgroup -- the F0
 // tile in accumulator layout and all n rows of both operand tiles -- is issued in one batch; the operand rows
 // then pass through LDS 32 at a time, [k][80] (64 columns + 16 pad: both MFMA operand reads conflict-free).
-// Tile row 0 also writes mu = mu0 + mean_b (U Fm)_b (rows B..2B-1 of Tm) for its 64 columns, and workgroup 0
-// counts the revert.  When *bad (the 2B x 2B positive-definite test failed) F = F0 and mu = mu0.
+// Tile row 0 also writes mu = mu0 + sum_b coef[b] Tm[b] (coef = [beta; alpha] / B from the small-matrix kernel: the mean of
+// the rows u_b Fm) for its 64 columns, and workgroup 0 counts the revert.  When *bad (the 2B x 2B positive-definite test failed) F = F0 and mu = mu0.
 template <int NP>
 __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const double* __restrict__ Rt,
                                                           const double* __restrict__ Fs,
                                                           const double* __restrict__ F0, int ldf0,
                                                           double* __restrict__ F, int ldf,
                                                           const double* __restrict__ Tm,
+                                                          const double* __restrict__ coef,
                                                           const double* __restrict__ mu0, double* __restrict__ mu,
                                                           const int* __restrict__ bad, int* __restrict__ n_reverts) {
     constexpr int RS = 80, KP = 32;
@@ -449,9 +424,9 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const do
         }
     const int skip = *bad;
     double msum = 0.0;
-    if (ti == 0) {                               // partial column sums of rows B + g, B + g + 8, ... of Tm
+    if (ti == 0) {                               // partial weighted column sums of rows g, g + 8, ... of Tm = [X - mu; V Fm]
         const int g = tid >> 6, col = J0 + (tid & 63);
-        for (int b = g; b < B; b += 8) msum += Tm[(size_t)(B + b) * D + col];
+        for (int b = g; b < 2 * B; b += 8) msum += coef[b] * Tm[(size_t)b * D + col];
     }
     if (blockIdx.x == 0 && tid == 0 && skip && n_reverts) *n_reverts += 1;
     v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
@@ -493,112 +468,124 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const do
             double s = 0.0;
 #pragma unroll
             for (int g = 0; g < 8; ++g) s += sm[g * 64 + tid];
-            mu[J0 + tid] = skip ? mu0[J0 + tid] : mu0[J0 + tid] + s / (double)B;
+            mu[J0 + tid] = skip ? mu0[J0 + tid] : mu0[J0 + tid] + s;
         }
     }
 }
 
-// Prepares the 64 x 64 LDS Gram matrix M (row stride STR) for the semi-definite rule of chol64_rows_s: lowers every diagonal
-// entry by its rounding floor, M_pp <- M_pp (1 - GSMVI_DEP_TOL), and returns (block-uniform) whether every entry is below
-// 2^32 and not NaN.
-template <int STR>
-__device__ __forceinline__ bool diag_prepare(double* M, int* sh_flag) {
-    if (threadIdx.x == 0) *sh_flag = 1;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const double d = M[threadIdx.x * STR + threadIdx.x];
-        M[threadIdx.x * STR + threadIdx.x] = d - GSMVI_DEP_TOL * d;
-        if (!(d < 4294967296.0)) *sh_flag = 0;
-    }
-    __syncthreads();
-    return *sh_flag != 0;
-}
-
 // ---- everything small in ONE workgroup (n = 2B <= 64), eight waves ---------------------------------------------------
-//   Gamma -> Rg (Cholesky) -> A' = I + Rg J Rg^T -> T (Cholesky, the PD test) -> K = Rg^-1 (T - I) Rg^-T.
-// All matrices live in LDS ([64][TS], padded with the identity beyond n).  Waves 0-3 are the Cholesky team, waves 4-7 helpers:
-//   * W = Rg^-T (64 substitution steps, one column per QUAD of lanes, the pivot value broadcast inside the quad by DPP) runs
-//     on the helper waves WHILE the Cholesky team factors A': the helpers execute one barrier per substitution step so that
-//     the workgroup barrier counts match (s_barrier counts waves, not program counters);
-//   * the three MFMA phases (A', P = (T - I) W, K = W^T P) use all eight waves (two per SIMD: the fp64 MFMA pipe
-//     delivers 46 TF chip-wide there against 34 TF with one), row blocks split by parity between the two teams.
-// *bad = 1 if either Cholesky fails (NaN, or M not positive definite) and K is then irrelevant.
-// NP forward-substitution steps of W = Rg^-T for the calling quad's column, ONE workgroup barrier per step (matches the
-// per-pivot barrier of chol64_rows_s running on the other four waves)
-template <int NP>
-__device__ __forceinline__ void wsubst_steps(double (&x)[16], int sq, const double* Rs, const double* rinv_g) {
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        __syncthreads();
-        const int pr = p >> 2, pq = p & 3;
-        const double mine = x[pr] * rinv_g[p];
-        if (sq == pq) x[pr] = mine;
-        const double xp = quad_bcast_rt<0>(mine, pq);       // DPP, not ds_bpermute: the chain stays off the LDS pipeline
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (4 * r + 3 > p) {
-                const int t = sq + 4 * r;
-                const double rv = Rs[p * TS + t];
-                x[r] -= (t > p) ? rv * xp : 0.0;
-            }
-    }
-}
-
-__global__ __launch_bounds__(512) void k_gsmf_small8(int n, int B, const double* __restrict__ Gam,
-                                                     double* __restrict__ Kmat, int* __restrict__ bad_out,
-                                                     unsigned long long* __restrict__ stamps) {
+//   Gamma -> Rg, W = Rg^-T (blocked Cholesky of [Gamma | I]) -> A' = I + Rg J Rg^T -> T (Cholesky, the PD test)
+//   -> K = Rg^-1 (T - I) Rg^-T = W^T (T - I) W.
+// Round 3: both factorisations are chol64_blk (gsmvi_chol64b.h: 16-pivot panels in one wave's registers, no workgroup
+// barrier on the pivot chain; W comes out of the augmented identity columns, so the 64-step substitution of round 2 is
+// gone); round 2's k_gsmf_small8 spent 13 + 15 us of its 39 us in two chol64_rows_s calls.
+// LDS: E1 [64][146] = [Gamma -> Rg | W], later P = (T - I) W in its left half; E2 [64][82] = A' -> T.  Padded with the
+// identity beyond n.  Gamma = Rt Rt^T is only positive SEMI-definite when rows of [Z; U] are linearly dependent (an
+// isotropic state on an isotropic target makes every u_b - a_b z_b parallel to mu - m; the exact fixed point makes U = -Z):
+// the dependent rows drop out of Rg (zero row, zero diagonal) and get a unit pivot in W, which leaves
+// C^T C = I + Rt^T J Rt intact (factor form); the rule is off (dependent => failure) when a diagonal
+// entry of Gamma reaches 2^32 (fixture G4).  *bad_out = 1 if either Cholesky fails (NaN, or M not positive definite);
+// K is then irrelevant.
+#define GSMF_ES1 146
+#define GSMF_ES2 82
+__global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double* __restrict__ Gp, int kcg,
+                                                      double* __restrict__ Kmat, double* __restrict__ coef,
+                                                      int* __restrict__ bad_out,
+                                                      unsigned long long* __restrict__ stamps) {
 #define SMALL_STAMP(k)                                                                      \
     do {                                                                                    \
         if (stamps && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memrealtime();        \
     } while (0)
     SMALL_STAMP(0);
-    __shared__ __attribute__((aligned(16))) double Rs[64 * TS];
-    __shared__ __attribute__((aligned(16))) double Ts[64 * TS];
-    __shared__ __attribute__((aligned(16))) double Ps[64 * TS];
-    __shared__ double rinv_g[64], rinv_t[64];
-    __shared__ int fail_g, fail_t;
+    constexpr int ES1 = GSMF_ES1, ES2 = GSMF_ES2;
+    __shared__ __attribute__((aligned(16))) double E1[64 * ES1];
+    __shared__ __attribute__((aligned(16))) double E2[64 * ES2];
+    __shared__ __attribute__((aligned(16))) double scr[CHOLB_SCRATCH_DOUBLES(true)];
+    __shared__ double s_alpha[32], s_beta[32];
+    __shared__ int fail_g, fail_t, sh_moderate;
     const int tid = threadIdx.x;
-    const bool team = tid < 256;                       // Cholesky team (waves 0-3) / helpers (waves 4-7)
-    {
-        double g[8];
+    if (tid == 0) sh_moderate = 1;
+    {   // Gamma1 = sum of the kcg split-K slabs of the Gram product (n x n each, full matrix) -> E2, raw
+        double g[8], t[GSMVI_MAX_KC][8];
+#pragma unroll
+        for (int kc = 0; kc < GSMVI_MAX_KC; ++kc)      // every load of every slab in one batch (clamped slab index)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = tid + 512 * k, i = e >> 6, q = e & 63;
+                t[kc][k] = Gp[(size_t)(kc < kcg ? kc : kcg - 1) * n * n + (size_t)(i < n ? i : n - 1) * n + (q < n ? q : n - 1)];
+            }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int e = tid + 512 * k, i = e >> 6, q = e & 63;
-            g[k] = Gam[(size_t)(i < n ? i : n - 1) * n + (q < n ? q : n - 1)];
+            double a = 0.0;
+#pragma unroll
+            for (int kc = 0; kc < GSMVI_MAX_KC; ++kc) a += (kc < kcg) ? t[kc][k] : 0.0;
+            g[k] = a;
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int e = tid + 512 * k, i = e >> 6, q = e & 63;
-            Rs[i * TS + q] = (i < n && q < n && q >= i) ? g[k] : (i == q ? 1.0 : 0.0);
+            E2[i * ES2 + q] = g[k];
         }
     }
-    if (tid < 64) rinv_g[tid] = rinv_t[tid] = 1.0;
+    __syncthreads();
+    if (tid < B) {                                     // per-sample scalars (gsm_numpy.py:8-17, whitened; file header)
+        double al, be;
+        gsmf_coefs(E2[tid * ES2 + tid], E2[tid * ES2 + B + tid], E2[(B + tid) * ES2 + B + tid], &al, &be);
+        s_alpha[tid] = al;
+        s_beta[tid] = be;
+        coef[tid] = be / (double)B;                    // mean: mu' = mu + sum_b coef[b] (x_b - mu) + coef[B + b] (v_b Fm)
+        coef[B + tid] = al / (double)B;
+    }
+    __syncthreads();
+    {   // Gamma = S Gamma1 S^T (upper triangle), S = [[I, 0], [diag(beta), diag(alpha)]]; identity beyond n
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = tid + 512 * k, i = e >> 6, q = e & 63;
+            double v = (i == q) ? 1.0 : 0.0;
+            if (i < n && q < n && q >= i) {
+                if (q < B) v = E2[i * ES2 + q];                                           // Z Z^T
+                else if (i < B) {
+                    const int b = q - B;
+                    v = s_beta[b] * E2[i * ES2 + b] + s_alpha[b] * E2[i * ES2 + q];        // Z U^T
+                } else {
+                    const int a = i - B, b = q - B;                                      // U U^T
+                    v = s_beta[a] * (s_beta[b] * E2[a * ES2 + b] + s_alpha[b] * E2[a * ES2 + q]) +
+                        s_alpha[a] * (s_beta[b] * E2[i * ES2 + b] + s_alpha[b] * E2[i * ES2 + q]);
+                }
+                if (i == q) {                          // rounding floor of the row (gsmvi_chol64.h) and the magnitude guard
+                    if (!(v < 4294967296.0)) sh_moderate = 0;
+                    v -= GSMVI_DEP_TOL * v;
+                }
+            } else if (i < n && q < n) v = 0.0;
+            E1[i * ES1 + q] = v;
+        }
+    }
     __syncthreads();
     SMALL_STAMP(1);
-    // Gamma = Rt Rt^T is only positive SEMI-definite when rows of [Z; U] are linearly dependent (an isotropic state on
-    // an isotropic target makes every u_b - a_b z_b parallel to mu - m; the exact fixed point makes U = -Z ...): the
-    // dependent rows drop out of Rg (zero row, zero diagonal) and get a unit diagonal in the substitution below, which
-    // leaves C^T C = I + Rt^T J Rt intact (factor form).
-    const bool moderate = diag_prepare<TS>(Rs, &fail_t);
-    if (team) chol64_rows_s<TS, true>(Rs, rinv_g, n, &fail_g, moderate);
-    else chol64_helper_idle<TS>(n);
+    const bool moderate = sh_moderate != 0;
+    chol64_blk<ES1, true, true>(E1, scr, n, &fail_g, moderate);     // E1 = [Rg | W]
     SMALL_STAMP(2);
-    for (int e = tid; e < 64 * 64; e += 512) {
-        const int i = e >> 6, q = e & 63;
-        if (q < i) Rs[i * TS + q] = 0.0;
-    }
-    if (tid < 64 && rinv_g[tid] == 0.0) rinv_g[tid] = 1.0;
-    __syncthreads();
     const int w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
-    const int wj = w & 3, g2 = w >> 2;                 // column block of this wave, team index (row-block parity)
-    {   // A' = I + (Rg J) Rg^T into Ts;  (Rg J)[i][k] = (1/B)(k < B ? Rg[i][B+k] : Rg[i][k-B] - Rg[i][k]), on the MFMA pipe.
+    const int wj = w & 3, g2 = w >> 2;                 // column block of this wave, row-block parity
+    const int nblk = (n + 15) >> 4;
+    // W <- W S (column operations on the right half of E1; the A' phase below reads only the left half, so both share this
+    // barrier interval): K'' = S^T K S = (W S)^T (T - I) (W S)
+    for (int e = tid; e < 64 * 32; e += 512) {
+        const int r = e >> 5, b = e & 31;
+        if (b < B) {
+            const double wz = E1[r * ES1 + 64 + b], wu = E1[r * ES1 + 64 + B + b];
+            E1[r * ES1 + 64 + b] = wz + s_beta[b] * wu;
+            E1[r * ES1 + 64 + B + b] = s_alpha[b] * wu;
+        }
+    }
+    {   // A' = I + (Rg J) Rg^T into E2;  (Rg J)[i][k] = (1/B)(k < B ? Rg[i][B+k] : Rg[i][k-B] - Rg[i][k]), on the MFMA pipe.
         // A' is symmetric (the mirror is written too); Rg is upper triangular, so Rg[j][k] = 0 for k < 16 j: only the
         // k-blocks j..3 contribute.  Wave (wj, g2) computes the blocks (ib, wj), ib <= wj, ib % 2 == g2
         const double invB = 1.0 / (double)B;
         v4d acc[2];
         acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
-        const double* brow = Rs + (16 * wj + cc) * TS;
-        for (int kb = wj; kb < 4; ++kb) {
+        const double* brow = E1 + (16 * wj + cc) * ES1;
+        for (int kb = wj; kb < nblk; ++kb) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const int k = 16 * kb + 4 * s4 + ks;
@@ -608,7 +595,7 @@ __global__ __launch_bounds__(512) void k_gsmf_small8(int n, int B, const double*
                 for (int h = 0; h < 2; ++h) {
                     const int ib = 2 * h + g2;
                     if (ib <= wj) {
-                        const double* arow = Rs + (16 * ib + cc) * TS;
+                        const double* arow = E1 + (16 * ib + cc) * ES1;
                         const double a1 = arow[k1 < 64 ? k1 : 63], a0 = arow[k];
                         const double a = (k < n) ? ((k < B) ? a1 : a1 - a0) : 0.0;
                         acc[h] = GSMVI_MFMA_F64(a, bv, acc[h]);
@@ -624,84 +611,59 @@ __global__ __launch_bounds__(512) void k_gsmf_small8(int n, int B, const double*
                 for (int r = 0; r < 4; ++r) {
                     const int i = 16 * ib + ks + 4 * r, j = 16 * wj + cc;
                     const double v = (i == j ? 1.0 : 0.0) + ((i < n && j < n) ? acc[h][r] * invB : 0.0);
-                    Ts[i * TS + j] = v;
-                    if (ib != wj) Ts[j * TS + i] = v;
+                    E2[i * ES2 + j] = v;
+                    if (ib != wj) E2[j * ES2 + i] = v;
                 }
             }
         }
     }
     __syncthreads();
     SMALL_STAMP(3);
-    // ---- Cholesky of A' (the positive-definite test) || W = Rg^-T by substitution ----
-    double x[16];
-    const int sc = (tid & 255) >> 2, sq = tid & 3;     // helper thread: column sc of W, quad lane sq (rows sq, sq+4, ..)
-    if (team) {
-        chol64_rows_s<TS>(Ts, rinv_t, n, &fail_t);
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = (sq + 4 * r == sc) ? 1.0 : 0.0;
-        // one instantiation per pivot count of the factorisation running beside us (16 ceil(n/16)): the loop must be
-        // fully unrolled (x[] is indexed with compile-time constants) and free of per-step branches (a predicated
-        // body measured 22 us for the pair at n = 64 against 16.6 us straight-line); rows beyond n are identity.
-        switch ((n + 15) >> 4) {
-            case 1: wsubst_steps<16>(x, sq, Rs, rinv_g); break;
-            case 2: wsubst_steps<32>(x, sq, Rs, rinv_g); break;
-            case 3: wsubst_steps<48>(x, sq, Rs, rinv_g); break;
-            default: wsubst_steps<64>(x, sq, Rs, rinv_g); break;
-        }
-        __syncthreads();
-        __syncthreads();
-        __syncthreads();
-    }
+    chol64_blk<ES2, false, false>(E2, scr, n, &fail_t);             // E2 = T (upper): exists iff M is positive definite
     SMALL_STAMP(4);
     const int bad = (fail_g != 0) || (fail_t != 0);
     if (tid == 0) *bad_out = bad;
     if (bad) return;                                   // block-uniform
-    // every helper has finished reading Rg (its 64 steps precede the last three barriers): Rs <- W, Ts <- T - I
-    if (!team) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Rs[(sq + 4 * r) * TS + sc] = x[r];
-    } else {
-        for (int e = tid; e < 64 * 64; e += 256) {
-            const int i = e >> 6, j = e & 63;
-            if (j < i) Ts[i * TS + j] = 0.0;
-            else if (j == i) Ts[i * TS + j] -= 1.0;
-        }
-    }
-    __syncthreads();
-    SMALL_STAMP(5);
     {
-        // P[i][j] = sum_k (T - I)[i][k] W[k][j]: k-blocks max(i, j)..3; wave (wj, g2): column block wj, row blocks ib % 2 == g2
+        // P[i][j] = sum_k (T - I)[i][k] W[k][j]: T - I upper (k >= i), W lower (k >= j): k-blocks max(i, j)..3; wave (wj, g2):
+        // column block wj, row blocks ib % 2 == g2.  P goes into the left half of E1 (Rg is dead).  The blocks of E2 below
+        // the diagonal still hold A' and are never read (ib <= kb).
         v4d acc[2];
         acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
-        for (int kb = wj; kb < 4; ++kb) {
+        const double* Wm = E1 + 64;
+        for (int kb = wj; kb < nblk; ++kb) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const int k = 16 * kb + 4 * s4 + ks;
-                const double bv = Rs[k * TS + 16 * wj + cc];
+                const double bv = Wm[k * ES1 + 16 * wj + cc];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int ib = 2 * h + g2;
-                    if (ib <= kb) acc[h] = GSMVI_MFMA_F64(Ts[(16 * ib + cc) * TS + k], bv, acc[h]);
+                    if (ib <= kb) {
+                        const int i = 16 * ib + cc;
+                        acc[h] = GSMVI_MFMA_F64(E2[i * ES2 + k] - (i == k ? 1.0 : 0.0), bv, acc[h]);
+                    }
                 }
             }
         }
+        // (E1's left half was last read in the A' phase, two barriers ago)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Ps[(16 * (2 * h + g2) + ks + 4 * r) * TS + 16 * wj + cc] = acc[h][r];
+            for (int r = 0; r < 4; ++r) E1[(16 * (2 * h + g2) + ks + 4 * r) * ES1 + 16 * wj + cc] = acc[h][r];
         __syncthreads();
-        // K[i][j] = sum_k W[k][i] P[k][j]: k-blocks i..3
+        SMALL_STAMP(5);
+        // K[i][j] = sum_k W[k][i] P[k][j]: W[k][i] = 0 for k < i: k-blocks i..3
         acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
-        for (int kb = 0; kb < 4; ++kb) {
+        for (int kb = 0; kb < nblk; ++kb) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const int k = 16 * kb + 4 * s4 + ks;
-                const double bv = Ps[k * TS + 16 * wj + cc];
+                const double bv = E1[k * ES1 + 16 * wj + cc];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int ib = 2 * h + g2;
-                    if (ib <= kb) acc[h] = GSMVI_MFMA_F64(Rs[k * TS + 16 * ib + cc], bv, acc[h]);
+                    if (ib <= kb) acc[h] = GSMVI_MFMA_F64(Wm[k * ES1 + 16 * ib + cc], bv, acc[h]);
                 }
             }
         }
@@ -815,24 +777,82 @@ __global__ __launch_bounds__(256) void k_gsmf_gemm128(int n, const double* __res
 
 // ---- new mean and the revert passthrough for the K-matrix path -----------------------------------------
 __global__ __launch_bounds__(256) void k_gsmf_mean(int D, int B, const double* __restrict__ Tm,
+                                                   const double* __restrict__ coef,
                                                    const double* __restrict__ mu0, double* __restrict__ mu,
                                                    const int* __restrict__ bad, int* __restrict__ n_reverts) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= D) return;
     if (j == 0 && n_reverts && *bad) *n_reverts += 1;      // one launch per update on the stream: no race
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const int n = 2 * B;
     int b = 0;
-    for (; b + 8 <= B; b += 8) {                   // eight independent loads in flight per trip
+    for (; b + 8 <= n; b += 8) {                   // eight independent loads in flight per trip
         double v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = Tm[(size_t)(B + b + k) * D + j];
+        for (int k = 0; k < 8; ++k) v[k] = coef[b + k] * Tm[(size_t)(b + k) * D + j];
         s0 += v[0] + v[4];
         s1 += v[1] + v[5];
         s2 += v[2] + v[6];
         s3 += v[3] + v[7];
     }
-    for (; b < B; ++b) s0 += Tm[(size_t)(B + b) * D + j];
-    mu[j] = (*bad) ? mu0[j] : mu0[j] + ((s0 + s1) + (s2 + s3)) / (double)B;
+    for (; b < n; ++b) s0 += coef[b] * Tm[(size_t)b * D + j];
+    mu[j] = (*bad) ? mu0[j] : mu0[j] + ((s0 + s1) + (s2 + s3));
+}
+
+// ---- 64 < n <= 128: Gamma = S Gamma1 S^T and the per-sample coefficients from the Gram slabs ---------------------------
+// 256 elements of Gamma per workgroup; every workgroup derives the B coefficient pairs itself (3 kcg loads per sample)
+__global__ __launch_bounds__(256) void k_gsmf_gamma_big(int n, int B, const double* __restrict__ Gp, int kcg,
+                                                        double* __restrict__ Gam, double* __restrict__ coef,
+                                                        double* __restrict__ ab) {
+    __shared__ double s_alpha[64], s_beta[64];
+    const int tid = threadIdx.x;
+    auto g1 = [&](int i, int q) {                      // one entry of Gamma1: the kcg slabs, all loads in one batch
+        double t[GSMVI_MAX_KC];
+#pragma unroll
+        for (int kc = 0; kc < GSMVI_MAX_KC; ++kc) t[kc] = Gp[(size_t)(kc < kcg ? kc : kcg - 1) * n * n + (size_t)i * n + q];
+        double a = 0.0;
+#pragma unroll
+        for (int kc = 0; kc < GSMVI_MAX_KC; ++kc) a += (kc < kcg) ? t[kc] : 0.0;
+        return a;
+    };
+    if (tid < B) {
+        double al, be;
+        gsmf_coefs(g1(tid, tid), g1(tid, B + tid), g1(B + tid, B + tid), &al, &be);
+        s_alpha[tid] = al;
+        s_beta[tid] = be;
+        if (blockIdx.x == 0) {
+            coef[tid] = be / (double)B;
+            coef[B + tid] = al / (double)B;
+            ab[tid] = be;                              // for k_gsmf_wscale
+            ab[B + tid] = al;
+        }
+    }
+    __syncthreads();
+    const int e = blockIdx.x * 256 + tid;
+    if (e >= n * n) return;
+    const int i = e / n, q = e % n;
+    double v;
+    if (i < B && q < B) v = g1(i, q);
+    else if (i < B) v = s_beta[q - B] * g1(i, q - B) + s_alpha[q - B] * g1(i, q);
+    else if (q < B) v = s_beta[i - B] * g1(i - B, q) + s_alpha[i - B] * g1(i, q);
+    else {
+        const int a = i - B, b = q - B;
+        v = s_beta[a] * (s_beta[b] * g1(a, b) + s_alpha[b] * g1(a, q)) +
+            s_alpha[a] * (s_beta[b] * g1(i, b) + s_alpha[b] * g1(i, q));
+    }
+    Gam[e] = v;
+}
+
+// W <- W S in place (n x n, column pairs (b, B + b)): K'' = S^T K S = (W S)^T (T - I) (W S)
+__global__ __launch_bounds__(256) void k_gsmf_wscale(int n, int B, double* __restrict__ Wm, const double* __restrict__ ab,
+                                                     const int* __restrict__ bad) {
+    if (*bad) return;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * B) return;
+    const int r = e / B, b = e % B;
+    const double wz = Wm[(size_t)r * n + b], wu = Wm[(size_t)r * n + B + b];
+    Wm[(size_t)r * n + b] = wz + ab[b] * wu;
+    Wm[(size_t)r * n + B + b] = ab[B + b] * wu;
 }
 
 int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
@@ -873,7 +893,7 @@ int gsmvi_panel_t_product(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     return chk("k_panel_t");
 }
 
-// ---- records of the batch-sharded factor path: rec[b] = [ x_b - mu (D) | u_b (D) | (u Fm)_b (D) ] ------------
+// ---- records of the batch-sharded factor path: rec[b] = [ x_b - mu (D) | v_b (D) | (v Fm)_b (D) ], v = w + z ---------
 __global__ __launch_bounds__(256) void k_gsmf_pack(int D, int Bl, const double* __restrict__ Rt,
                                                    const double* __restrict__ Tm, double* __restrict__ rec,
                                                    int ldrec) {
@@ -885,44 +905,34 @@ __global__ __launch_bounds__(256) void k_gsmf_pack(int D, int Bl, const double* 
     rb[2 * D + i] = Tm[(size_t)(Bl + b) * D + i];
 }
 
-// Rt = [Z; U], its transpose Rtt (D x n), Tm = [X - mu; U Fm] from the replicated draws and ALL records
+// Rt1 = [Z; V] and Tm1 = [X - mu; V Fm] from the replicated draws and ALL records
 __global__ __launch_bounds__(256) void k_gsmf_unpack(int D, int B, const double* __restrict__ Z, int ldz,
                                                      const double* __restrict__ rec, int ldrec,
-                                                     double* __restrict__ Rt, double* __restrict__ Rtt, int nq,
-                                                     double* __restrict__ Tm) {
+                                                     double* __restrict__ Rt, double* __restrict__ Tm) {
     const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
     if (i >= D) return;
     const double* rb = rec + (size_t)b * ldrec;
-    const double z = Z[(size_t)b * ldz + i], u = rb[D + i];
-    Rt[(size_t)b * D + i] = z;
-    Rt[(size_t)(B + b) * D + i] = u;
-    Rtt[(size_t)i * nq + b] = z;
-    Rtt[(size_t)i * nq + B + b] = u;
+    Rt[(size_t)b * D + i] = Z[(size_t)b * ldz + i];
+    Rt[(size_t)(B + b) * D + i] = rb[D + i];
     Tm[(size_t)b * D + i] = rb[i];
     Tm[(size_t)(B + b) * D + i] = rb[2 * D + i];
 }
 
-// Front half: per-sample stage for B samples.  Fills Rt = [Z; U] (2B x D), Rtt (D x 2B) and Tm = [X - mu; U Fm]
-// in the workspace (layout for n = 2B rows).
+// Front half: the D-sized operands of B samples.  Fills Rt1 = [Z; V] (2B x D) and Tm1 = [X - mu; V Fm] in the workspace
+// (layout for n = 2B rows).
 static int factor_front(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
                         const double* G, int ldg, const double* mu0, const double* F0, int ldf0) {
-    const int n = 2 * B, nq = n;
-    double* Rt = ctx->sg;                          // n x D   [Z; U]
-    double* Tm = Rt + (size_t)n * D;               // n x D   [X - mu; U Fm]
-    double* Fs = Tm + (size_t)n * D;               // n x D
-    double* Rtt = Fs + (size_t)n * D;              // D x n
-    // W = G Fm^T
+    const int n = 2 * B;
+    double* Rt = ctx->sg;                          // n x D   [Z; V]
+    double* Tm = Rt + (size_t)n * D;               // n x D   [X - mu; V Fm]
+    // W = G Fm^T (split-K slabs), finished inside the elementwise stage
     int kc = 1;
     int rc = gsmvi_panel_t_product(ctx, st, D, B, G, ldg, F0, ldf0, D, ctx->pp, &kc);
     if (rc) return rc;
-    {
-        const int ept = (D + 1023) / 1024;
-#define GS(E) hipLaunchKernelGGL(k_gsmf_scalars<E>, dim3(B), dim3(1024), 0, st, D, B, kc, Z, ldz, X, ldx, mu0, ctx->pp, Rt, Rtt, nq, Tm)
-        if (ept <= 1) GS(1); else if (ept <= 2) GS(2); else if (ept <= 4) GS(4); else if (ept <= 8) GS(8); else GS(16);
-#undef GS
-    }
-    if ((rc = chk("k_gsmf_scalars"))) return rc;
-    // bottom half of Tm: U Fm
+    hipLaunchKernelGGL(k_gsmf_prep, dim3((D + 255) / 256, B), dim3(256), 0, st, D, B, kc, Z, ldz, X, ldx, mu0, ctx->pp, Rt,
+                       Tm);
+    if ((rc = chk("k_gsmf_prep"))) return rc;
+    // bottom half of Tm1: V Fm
     return gsmvi_panel_product_out(ctx, st, D, D, B, Rt + (size_t)B * D, D, nullptr, 1.0, F0, ldf0, nullptr,
                                    Tm + (size_t)B * D, D);
 }
@@ -957,38 +967,37 @@ int gsmvi_factor_apply_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const 
     const int n = 2 * B;
     double* Rt = ctx->sg;
     double* Tm = Rt + (size_t)n * D;
-    double* Fs = Tm + (size_t)n * D;
-    double* Rtt = Fs + (size_t)n * D;
-    hipLaunchKernelGGL(k_gsmf_unpack, dim3((D + 255) / 256, B), dim3(256), 0, st, D, B, Z, ldz, rec, ldrec, Rt, Rtt, n, Tm);
+    hipLaunchKernelGGL(k_gsmf_unpack, dim3((D + 255) / 256, B), dim3(256), 0, st, D, B, Z, ldz, rec, ldrec, Rt, Tm);
     int rc = chk("k_gsmf_unpack");
     if (rc) return rc;
     return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev);
 }
 
-// Back half: from Rt, Rtt, Tm (n = 2B rows) to (mu, F).
+// Back half: from Rt1 = [Z; V], Tm1 = [X - mu; V Fm] (n = 2B rows) to (mu, F).
 static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
                        double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev) {
-    const int n = 2 * B, nq = n;                   // n is even
+    const int n = 2 * B;                           // n is even
     // workspace carve: ctx->sg holds 4*rmax*max_D doubles (rmax = 2B+8; ws_sizes in gsmvi_abi.hip)
-    double* Rt = ctx->sg;                          // n x D   [Z; U]
-    double* Tm = Rt + (size_t)n * D;               // n x D   [X - mu; U Fm]
+    double* Rt = ctx->sg;                          // n x D   [Z; V]
+    double* Tm = Rt + (size_t)n * D;               // n x D   [X - mu; V Fm]
     double* Fs = Tm + (size_t)n * D;               // n x D
-    double* Rtt = Fs + (size_t)n * D;              // D x n
-    double* Gam = ctx->small;                      // n x n
+    double* Gam = ctx->small;                      // n x n slots of the small-matrix workspace (six of them: 6 rmax^2)
     double* Rg = Gam + (size_t)n * n;
     double* Ap = Rg + (size_t)n * n;
     double* Tt = Ap + (size_t)n * n;
+    double* coef = Tt + (size_t)2 * n * n;         // sixth slot: [beta; alpha] / B (2B), then [beta; alpha] (2B)
     int* info_g = ctx->ints;
     int* info_t = ctx->ints + 1;
-    int rc, kc2 = 1;
-    // Gamma = Rt Rt^T
-    if ((rc = gsmvi_panel_product_out(ctx, st, D, n, n, Rt, D, nullptr, 1.0, Rtt, nq, nullptr, Gam, n))) return rc;
+    int rc, kc2 = 1, kcg = 1;
+    // Gamma1 = [Z; V][Z; V]^T: split-K slabs of the transposed panel product (A = M = Rt1), summed by their consumer
+    double* Gp = ctx->pp;
+    if ((rc = gsmvi_panel_t_product(ctx, st, D, n, Rt, D, Rt, D, n, Gp, &kcg))) return rc;
     if (n <= 64) {
-        // everything small in one workgroup, then Fs = K Tm as one skinny GEMM (K = n)
-        double* Kmat = Rg;                         // reuse the n x n slot
-        hipLaunchKernelGGL(k_gsmf_small8, dim3(1), dim3(512), 0, st, n, B, Gam, Kmat, info_dev,
-                           (ctx->tune_cov_dbg & 128) ? reinterpret_cast<unsigned long long*>(ctx->pp) : nullptr);
-        if ((rc = chk("k_gsmf_small"))) return rc;
+        // everything small in one workgroup, then Fs = K'' Tm1 as one skinny GEMM (inner dimension n)
+        double* Kmat = Rg;
+        hipLaunchKernelGGL(k_gsmf_small16, dim3(1), dim3(512), 0, st, n, B, Gp, kcg, Kmat, coef, info_dev,
+                           (ctx->tune_cov_dbg & 128) ? reinterpret_cast<unsigned long long*>(ctx->pp) + (size_t)GSMVI_MAX_KC * n * n : nullptr);
+        if ((rc = chk("k_gsmf_small16"))) return rc;
         // inner dimension n <= one chunk, so there is exactly one slab: it is written straight into Fs
         if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, Fs, &kc2)))
             return rc;
@@ -997,22 +1006,24 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
             return GSMVI_ERR_UNSUPPORTED;
         }
     } else {
-        // 64 < n <= 128: the two n x n Choleskys one workgroup each, K in its own kernel, then the same skinny
-        // GEMM Fs = K Tm
+        // 64 < n <= 128: Gamma, the two n x n Choleskys one workgroup each, W and K in their own kernels, then the same
+        // skinny GEMM Fs = K'' Tm1
         double* Kmat = Gam;                        // Gamma is dead once Rg exists
         double* Wm = Ap;                           // A' is dead once T exists
-        double* Pm = Tt + (size_t)n * n;           // fifth n x n slot of the small-matrix workspace
+        double* Pm = Tt + (size_t)n * n;           // fifth n x n slot
+        hipLaunchKernelGGL(k_gsmf_gamma_big, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, Gam, coef, coef + n);
         hipLaunchKernelGGL(k_chol128<true>, dim3(1), dim3(512), 0, st, n, Gam, Rg, info_g);   // Gram matrix: semi-definite rule
         hipLaunchKernelGGL(k_gsmf_small_a, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, st, n, B, Rg, info_g, Ap);
         hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n, Ap, Tt, info_t);
         if ((rc = chk("k_chol128"))) return rc;
         hipLaunchKernelGGL(k_gsmf_kmat_big, dim3((n + 15) / 16), dim3(256), 0, st, n, Rg, Wm, info_g, info_t,
                            info_dev);
+        hipLaunchKernelGGL(k_gsmf_wscale, dim3((n * B + 255) / 256), dim3(256), 0, st, n, B, Wm, coef + n, info_dev);
         if ((rc = chk("k_gsmf_kmat_big"))) return rc;
         {
             const int nb = (n + 15) / 16, gw = (nb * nb + 3) / 4;
-            hipLaunchKernelGGL(k_gsmf_gemm128<0>, dim3(gw), dim3(256), 0, st, n, Tt, Wm, Pm, info_dev);   // P = (T - I) W
-            hipLaunchKernelGGL(k_gsmf_gemm128<1>, dim3(gw), dim3(256), 0, st, n, Wm, Pm, Kmat, info_dev); // K = W^T P
+            hipLaunchKernelGGL(k_gsmf_gemm128<0>, dim3(gw), dim3(256), 0, st, n, Tt, Wm, Pm, info_dev);   // P = (T - I) W S
+            hipLaunchKernelGGL(k_gsmf_gemm128<1>, dim3(gw), dim3(256), 0, st, n, Wm, Pm, Kmat, info_dev); // K'' = (W S)^T P
             if ((rc = chk("k_gsmf_gemm128"))) return rc;
         }
         // inner dimension n <= one chunk, so there is exactly one slab: it is written straight into Fs
@@ -1026,12 +1037,12 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
     const int nt = (D + 63) / 64;
     if (!ctx->tune_no_fast && D % 64 == 0 && (n == 32 || n == 64 || n == 128)) {
         // the fast kernel also writes the mean and counts the revert
-#define UF(NPV) hipLaunchKernelGGL(k_gsmf_update_fast<NPV>, dim3(nt * nt), dim3(512), 0, st, D, B, Rt, Fs, F0, ldf0, F, ldf, Tm, mu0, mu, info_dev, n_reverts_dev)
+#define UF(NPV) hipLaunchKernelGGL(k_gsmf_update_fast<NPV>, dim3(nt * nt), dim3(512), 0, st, D, B, Rt, Fs, F0, ldf0, F, ldf, Tm, coef, mu0, mu, info_dev, n_reverts_dev)
         if (n == 32) UF(1); else if (n == 64) UF(2); else UF(4);
 #undef UF
         return chk("k_gsmf_update_fast");
     }
-    hipLaunchKernelGGL(k_gsmf_mean, dim3((D + 255) / 256), dim3(256), 0, st, D, B, Tm, mu0, mu, info_dev, n_reverts_dev);
+    hipLaunchKernelGGL(k_gsmf_mean, dim3((D + 255) / 256), dim3(256), 0, st, D, B, Tm, coef, mu0, mu, info_dev, n_reverts_dev);
     if ((rc = chk("k_gsmf_mean"))) return rc;
     hipLaunchKernelGGL(k_gsmf_update, dim3(nt * nt), dim3(256), 0, st, D, n, Rt, Fs, F0, ldf0, F, ldf, info_dev);
     return chk("k_gsmf_update");

@@ -12,11 +12,11 @@ A = torch.randn(D, D, **kw); S0 = A @ A.T / D + 0.1 * torch.eye(D, dtype=torch.f
 F0 = torch.linalg.cholesky(S0).T.contiguous(); mu0 = torch.randn(D, **kw); Z = torch.randn(B, D, **kw)
 X = (mu0 + Z @ F0).contiguous(); G = -(X - 0.5)
 eng.set_tuning("cov_dbg", 128)
-names = ["load", "chol(Gamma)", "A'", "chol(A')", "W=Rg^-T", "K=W^T(T-I)W"]
+names = ["load", "chol([Gamma|I])->Rg,W", "A'", "chol(A')", "P=(T-I)W", "K=W^T P"]
 for trial in range(3):
     for _ in range(20):
         eng.gsm_factor_update(Z, X, G, mu0, F0)
-    buf = (C.c_ulonglong * 8)()
-    eng.lib.gsmvi_debug_read_stamps(eng._ctx, buf, 8)
-    st = np.array(buf, dtype=np.int64)[:7]
+    buf = (C.c_double * 8)()                      # the stamps sit behind the Gram slabs in the panel-partial region
+    eng.lib.gsmvi_debug_read_workspace(eng._ctx, 0, 8 * (2 * B) ** 2, buf, 8)
+    st = np.frombuffer(buf, dtype=np.int64)[:7]
     print("  ".join(f"{n} {d / 100.0:.2f}us" for n, d in zip(names, np.diff(st))), f" total {(st[6] - st[0]) / 100.0:.2f}us")

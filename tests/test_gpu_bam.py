@@ -194,6 +194,16 @@ def test_no_silent_host_path_for_large_batches():
     eng = gsmvi_amd.get_engine()
     st = orc.make_update_state(300, 130, seed=2)
     X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
-    with pytest.raises(gsmvi_amd.GsmviError) as ei:
+    with pytest.raises(ValueError):                                  # the Python driver refuses up front (no retry loop)
         eng.bam_update(X, G, mu0, S0, 1.0)
-    assert ei.value.status == 5                                      # GSMVI_ERR_UNSUPPORTED
+    limit = type(eng).bam_max_batch
+    eng.bam_max_batch = 10 ** 9                                      # reach the C entry point itself
+    try:
+        with pytest.raises(gsmvi_amd.GsmviError) as ei:
+            eng.bam_update(X, G, mu0, S0, 1.0)
+        assert ei.value.status == 5                                  # GSMVI_ERR_UNSUPPORTED
+    finally:
+        eng.bam_max_batch = limit
+    with pytest.raises(ValueError):
+        gsmvi_amd.BaM(300, None, lambda x: -x).fit(0, gsmvi_amd.Regularizers().constant(1.0), batch_size=130, niter=2,
+                                                   verbose=False)
