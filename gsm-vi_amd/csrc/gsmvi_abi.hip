@@ -34,7 +34,7 @@ void gsmvi_launch_commit(hipStream_t st, int D, const int* info, const double* m
 void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int nrows, const double* A,
                              int lda, const double* shift, double alpha, const double* M, int ldm, double* Pp,
                              int chunks_per_wg, int ncols, unsigned long long* stamps, double* Out, int ldo,
-                             const double* addvec);
+                             const double* addvec, const struct gsmvi_panel_extras* px);
 bool gsmvi_launch_gsm_scalars_fast(hipStream_t st, hipEvent_t* ev, int D, int B, int KC, const double* X, int ldx,
                                    const double* G, int ldg, const double* mu0, const double* Pp, double* rec,
                                    int ldrec, int nt, unsigned long long* stamps);
@@ -143,7 +143,9 @@ static void ws_sizes(int D, int B, size_t* n_pp, size_t* n_sg, size_t* n_small, 
     if (*n_pp < potrf_scratch) *n_pp = potrf_scratch;
     *n_sg = (size_t)R * D * 4;                                 // SG + BaM factor panels
     // + the device chain of BaM's small matrix function: five padded 144 x 144 iterates, coefficients, BB (n <= 129)
-    *n_small = (size_t)8 * R + (size_t)6 * R * R + 4096 + (size_t)5 * 144 * 144 + 64 + (size_t)129 * 129 + 64;
+    // + the factor path: a seventh R x R slot (finished Gram matrix) and the split-K slabs of the Gram product (+ 16 stamp words)
+    *n_small = (size_t)8 * R + (size_t)7 * R * R + 4096 + (size_t)5 * 144 * 144 + 64 + (size_t)129 * 129 + 64 +
+               (size_t)GSMVI_MAX_KC * R * R + 16;
 }
 
 size_t gsmvi_workspace_bytes(int max_D, int max_B) {
@@ -189,6 +191,7 @@ int gsmvi_create(gsmvi_ctx** out, int device, int max_D, int max_B) {
     c->sg = c->pp + n_pp;
     c->small = c->sg + n_sg;
     c->ints = reinterpret_cast<int*>(c->small + n_small);
+    c->gram_slabs = c->small + n_small - ((size_t)GSMVI_MAX_KC * c->rmax * c->rmax + 16);
     e = hipMemset(c->ws, 0, c->ws_bytes);
     if (e == hipSuccess) e = gsmvi_cov_update_prepare();
     if (e == hipSuccess) e = gsmvi_bam_prepare();
@@ -326,8 +329,11 @@ int gsmvi_panel_product_out(gsmvi_ctx* ctx, hipStream_t st, int D, int ncols, in
             kc = (nchunks + cpw - 1) / cpw;
             // only the hand-off-free case (kc == 1): the product writes the finished output itself
             if (kc == 1 && strips * zblocks <= 1024) {
+                const gsmvi_panel_extras px = ctx->px;
+                ctx->px = gsmvi_panel_extras();
+                ctx->px_used = 1;
                 gsmvi_launch_panel_fast(st, nullptr, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm,
-                                        ctx->pp, cpw, ncols, ctx->timeline_stamps(0), Out, ldo, addvec);
+                                        ctx->pp, cpw, ncols, ctx->timeline_stamps(0), Out, ldo, addvec, &px);
                 return check_launch("k_panel_fast(out)");
             }
         }
@@ -357,9 +363,12 @@ int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D
     const int cpw = (nchunks + kc - 1) / kc;
     kc = (nchunks + cpw - 1) / cpw;
     *kc_out = kc;
+    const gsmvi_panel_extras px = ctx->px;
+    ctx->px = gsmvi_panel_extras();                // extras are for ONE launch; px_used reports whether the fast kernel took them
+    ctx->px_used = fast ? 1 : 0;
     if (fast) {
         gsmvi_launch_panel_fast(st, ev, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm, Pp,
-                                cpw, ncols, ctx->timeline_stamps(0), nullptr, 0, nullptr);
+                                cpw, ncols, ctx->timeline_stamps(0), nullptr, 0, nullptr, &px);
         return check_launch("k_panel_fast");
     }
     gsmvi_launch_panel_partial(st, ev, MT, dim3(strips, kc, zblocks), D, ncols, nrows, A, lda, shift, alpha, M,

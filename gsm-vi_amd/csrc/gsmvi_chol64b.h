@@ -2,19 +2,24 @@
 //
 // chol64_rows_s (gsmvi_chol64.h) pays one LDS round trip and one s_barrier per pivot: ~190 ns x 64 pivots = 12-15 us for
 // one 64 x 64 factorisation on one CU.  Here the matrix is processed in four block rows of 16:
-//   panel    : ONE wave holds the 16 x (columns to the right) block row, a column per lane (16 registers), and runs the 16
-//              pivots in registers: the pivot and the next row's multiplier are broadcast with v_readlane, the other
-//              multipliers come back from a wave-private LDS row as broadcast reads (no barrier: a wave's LDS operations
-//              execute in order); the elimination is the unscaled (LDL^T) form, so the reciprocal 1/d_p (v_rcp_f64 + two
-//              Newton steps) is the only long operation on the pivot chain, and the rows are scaled by 1/sqrt(d_p) at the end.
-//              Because the lanes to the right of the diagonal block are eliminated with it, the block row comes out SOLVED
-//              (R_kj = R_kk^-T A_kj): there is no separate triangular solve.
+//   panel    : the 16 x (columns to the right) block row is held a column per lane, and its 16 pivots run in registers: the
+//              pivot and the next row's multiplier are broadcast with v_readlane, the other multipliers come back from an
+//              LDS copy of the pivot row as broadcast reads (no barrier: a wave's LDS operations execute in order); the
+//              elimination is the unscaled (LDL^T) form, so the reciprocal 1/d_p (v_rcp_f64 + two Newton steps) is the only
+//              long operation on the pivot chain, and the rows are scaled by 1/sqrt(d_p) at the end.  Because the lanes to
+//              the right of the diagonal block are eliminated with it, the block row comes out SOLVED (R_kj = R_kk^-T A_kj):
+//              there is no separate triangular solve.
+//              One wave running all 16 pivots is ISSUE-bound (~45 instructions = ~290 cycles per pivot, 1.9 us per panel),
+//              so the 16 rows are split between TWO waves on two SIMDs: the wave that owns rows 0-7 runs pivots 0-7 and
+//              publishes each pivot row (unscaled, and scaled by 1/d_p) with a counter in LDS; the wave that owns rows 8-15
+//              applies them to its rows as they appear (it spins on the counter: both waves are resident, the first never
+//              waits for the second) and then runs pivots 8-15.  ~25 instructions per pivot on the chain wave.
 //   trailing : the rank-16 updates A_ij -= R_ki^T R_kj of the remaining block rows on the MFMA pipe, all eight waves.
 // Two workgroup barriers per block step (8 in all instead of 64 + 3).
 // AUG = true factors the augmented matrix [A | I]: the same row operations turn the identity into W = R^-T (lower
 // triangular, E[:, 64:128]), which the callers need as an explicit matrix (the triangular solves of the factor path and of
-// the blocked D x D Cholesky are MFMA products with W).  The augmented columns ride in the lanes of a second panel wave
-// that repeats the diagonal block's arithmetic (bit-identical multipliers), and in the same trailing products.
+// the blocked D x D Cholesky are MFMA products with W).  The augmented columns ride in the lanes of a second pair of panel
+// waves that repeats the diagonal block's arithmetic (bit-identical multipliers), and in the same trailing products.
 //
 // Layout: E[64][ES] in LDS, row-major; columns 0..63 = A (upper triangle + diagonal valid on entry; everything strictly
 // below the diagonal BLOCKS must be zero on entry if the caller wants a clean upper factor; padded with the identity
@@ -23,6 +28,7 @@
 // Semantics = chol64_rows_s: *sh_fail = 1-based index of the first bad pivot (<= 0, NaN, inf) or 0; SEMIDEF (the caller has
 // lowered the diagonal by its rounding floor, see gsmvi_chol64.h) turns a pivot <= 0 into a DROPPED row -- zero row and
 // zero diagonal in R, unit pivot in W -- unless allow_dep is false.
+// Needs 512 threads (eight waves); every thread of the workgroup must call it.
 #pragma once
 #include "gsmvi_common.h"
 #include "gsmvi_chol64.h"
@@ -40,13 +46,130 @@ __device__ __forceinline__ double rsq_nr2(double d) {             // 1/sqrt(d)
     return y;
 }
 
-// LDS scratch of chol64_blk: per panel wave the 16 x 64 unscaled pivot rows and 16 row scales (AUG: two panel waves)
-#define CHOLB_SCRATCH_PER_WAVE (16 * 64 + 16)
-#define CHOLB_SCRATCH_DOUBLES(AUGV) (((AUGV) ? 2 : 1) * CHOLB_SCRATCH_PER_WAVE)
+// LDS scratch of chol64_blk, per column set (AUG: two sets): [16][64] unscaled pivot rows, [8][64] pivot rows scaled by
+// 1/d_p (pivots 0-7, for the wave that owns rows 8-15), [2][8] row scales, the publish counter
+#define CHOLB_SCRATCH_PER_SET (16 * 64 + 8 * 64 + 16 + 2)
+#define CHOLB_SCRATCH_DOUBLES(AUGV) (((AUGV) ? 2 : 1) * CHOLB_SCRATCH_PER_SET)
 
 #ifndef CHOLB_STAMP
 #define CHOLB_STAMP(k) ((void)0)
 #endif
+#ifndef CHOLB_PSTAMP
+#define CHOLB_PSTAMP(h, i) ((void)0)       // scripts/chol64b_test.hip: per-pivot stamps inside a panel
+#endif
+
+// One wave's half (rows 8H .. 8H+7) of a 16-row panel.  col: this lane's column of E; lanes 0-15 of every panel wave hold the
+// diagonal block's columns.  write_back: false for inactive lanes and for the replica of the diagonal block in the second
+// column set.  pub: value the publish counter has when this panel starts (monotone over the block steps).
+template <int ES, bool SEMIDEF, int H>
+__device__ __forceinline__ void cholb_panel_half(double* E, int k0, int col, bool write_back, bool aug, bool diag_lane,
+                                                 double* ur, double* tr, double* rsb, volatile int* cnt, int pub,
+                                                 bool allow_dep, int* sh_failmin) {
+    const int l = threadIdx.x & 63, c = l & 15;
+    constexpr int R0 = 8 * H;
+    double v[8];
+    CHOLB_PSTAMP(H, 0);
+    {
+        const double* ep = E + (k0 + R0) * ES + col;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = ep[i * ES];
+    }
+    // Every LDS read below is issued ONE PIVOT before its values are used (explicit software pipelining): a wave issues in
+    // order, so an s_waitcnt in front of an elimination FMA also holds back the reciprocal chain of the next pivot behind
+    // it -- with the reads issued at their point of use the LDS round trip (~130 cycles) sat on the chain of every pivot.
+    if (H == 1) {
+        // pivots 0-7 belong to the other wave: apply each one as soon as it is published
+        double tq;
+        v2d uq[4];
+        auto fetch = [&](int p) {
+            while (__builtin_amdgcn_readfirstlane(*cnt) < pub + p + 1) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            tq = tr[p * 64 + l];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) uq[j] = *reinterpret_cast<const v2d*>(&ur[p * 64 + 8 + 2 * j]);
+        };
+        fetch(0);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const double t = tq;
+            v2d uu[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) uu[j] = uq[j];
+            if (p + 1 < 8) fetch(p + 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[2 * j] = __builtin_fma(-uu[j].x, t, v[2 * j]);
+                v[2 * j + 1] = __builtin_fma(-uu[j].y, t, v[2 * j + 1]);
+            }
+        }
+    }
+    CHOLB_PSTAMP(H, 1);
+    int fail = 0;
+    double t_prev = 0.0;
+    v2d u_prev[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u_prev[j] = (v2d){0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int p = R0 + q;
+        CHOLB_PSTAMP(H, 2 + q);
+        ur[p * 64 + l] = v[q];                                    // the unscaled pivot row, final
+        const double d = readlane_f64(v[q], p);                   // lane p of this wave = column p of the diagonal block
+        // the reciprocal starts from the broadcast pivot itself (no test in front of it on the chain).  A dropped pivot
+        // (SEMIDEF: d <= 0) must eliminate nothing; a FAILED pivot makes the whole result irrelevant, so outside SEMIDEF
+        // nothing is masked.  The pass/fail verdicts are taken from the saved diagonal after the loop, all at once: per pivot
+        // they cost six instructions of a wave that issues one every ~6 cycles.
+        const double dinv = rcp_nr2(d);
+        const double t = (!SEMIDEF || d > 0.0) ? v[q] * dinv : 0.0;
+        if (H == 0) {
+            tr[p * 64 + l] = t;
+            asm volatile("" ::: "memory");                        // program order = LDS order inside one wave
+            *cnt = pub + q + 1;
+        }
+        // rows >= q + 1: the PREVIOUS pivot's update (its multipliers were read from LDS one pivot ago)
+        if (q >= 1) {
+#pragma unroll
+            for (int i = q + 1; i < 8; ++i) {
+                const double uv = (i & 1) ? u_prev[i >> 1].y : u_prev[i >> 1].x;
+                v[i] = __builtin_fma(-uv, t_prev, v[i]);
+            }
+        }
+        if (q + 1 < 8) {                                          // the next pivot's row: this pivot's update, multiplier by v_readlane
+            const double u = readlane_f64(v[q], p + 1);
+            v[q + 1] = __builtin_fma(-u, t, v[q + 1]);
+        }
+        // this pivot's multipliers for the rows >= q + 2, used during the next pivot
+#pragma unroll
+        for (int j = (q + 2) >> 1; j < 4; ++j) u_prev[j] = *reinterpret_cast<const v2d*>(&ur[p * 64 + R0 + 2 * j]);
+        t_prev = t;
+    }
+    CHOLB_PSTAMP(H, 10);
+    {   // row scales 1/sqrt(d_p) of this wave's eight rows at once: lane c owns pivot R0 + (c & 7).  Dropped row: zero in R,
+        // unit pivot in W.
+        const int pp = R0 + (c & 7);
+        const double dg = ur[pp * 64 + pp];
+        const bool ok = dg > 0.0 && dg < 1.7976931348623157e308;    // false for NaN, <= 0, inf
+        const bool dep = SEMIDEF && allow_dep && dg <= 0.0 && dg > -1.7976931348623157e308;
+        const unsigned long long badm = __builtin_amdgcn_ballot_w64(!ok && !dep) & 0xffull;   // lanes 0-7: pivots R0 .. R0+7
+        if (badm != 0) fail = k0 + R0 + __builtin_ctzll(badm) + 1;
+        const double rs = ok ? rsq_nr2(ok ? dg : 1.0) : 0.0;
+        rsb[8 * H + (c & 7)] = rs;
+#pragma unroll
+        for (int p2 = 0; p2 < 8; p2 += 2) {
+            const v2d r2 = *reinterpret_cast<const v2d*>(&rsb[8 * H + p2]);
+            v[p2] *= (aug && r2.x == 0.0) ? 1.0 : r2.x;
+            v[p2 + 1] *= (aug && r2.y == 0.0) ? 1.0 : r2.y;
+        }
+    }
+    CHOLB_PSTAMP(H, 11);
+    if (write_back) {
+        double* ep = E + (k0 + R0) * ES + col;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ep[i * ES] = (diag_lane && R0 + i > c) ? 0.0 : v[i];   // strictly-lower part of the diagonal block zeroed
+    }
+    if (fail != 0 && l == 0) atomicMin(sh_failmin, fail);
+    CHOLB_PSTAMP(H, 12);
+}
 
 template <int ES, bool SEMIDEF, bool AUG>
 __device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, int* sh_fail, bool allow_dep = true) {
@@ -59,77 +182,33 @@ __device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, i
             E[i * ES + 64 + q] = (i == q) ? 1.0 : 0.0;
         }
     }
-    if (tid == 0) *sh_fail = 0;
+    if (tid == 0) *sh_fail = 0x7fffffff;
+    if (tid < (AUG ? 2 : 1)) *reinterpret_cast<volatile int*>(scratch + tid * CHOLB_SCRATCH_PER_SET + 16 * 64 + 8 * 64 + 16) = 0;
     __syncthreads();
 #pragma unroll 1
     for (int k = 0; k < nblk; ++k) {                              // block-uniform
         const int k0 = 16 * k;
         CHOLB_STAMP(1 + 2 * k);
         // ---- panel: block row k, columns to the right of (and including) the diagonal block, plus the W columns 0 .. 16k+15.
-        // Column groups of 16 in this order: A-groups k .. nblk-1, then W-groups 0 .. k.  Wave 0 takes the first four (its
-        // lanes 0-15 = the diagonal block), wave 1 (AUG) repeats the diagonal block in lanes 0-15 and takes groups 4 .. 6.
-        if (w < (AUG ? 2 : 1)) {
+        // Column groups of 16 in this order: A-groups k .. nblk-1, then W-groups 0 .. k.  Column set 0 (waves 0, 1) takes
+        // the first four (lanes 0-15 = the diagonal block), set 1 (waves 2, 3; AUG) repeats the diagonal block in lanes
+        // 0-15 and takes groups 4 .. 6.  Even wave of a set: rows 0-7, odd wave: rows 8-15.
+        if (w < (AUG ? 4 : 2)) {
+            const int set = w >> 1;
             const int nA = nblk - k, nslots = nA + (AUG ? k + 1 : 0);
-            const int slot = (w == 0) ? g : (g == 0 ? 0 : 3 + g);
+            const int slot = (set == 0) ? g : (g == 0 ? 0 : 3 + g);
             const bool active = slot < nslots;
             const bool aug = slot >= nA;
             const int col = (active ? (aug ? 64 + 16 * (slot - nA) : 16 * (k + slot)) : k0) + c;
-            double v[16];
-            {
-                const double* ep = E + k0 * ES + col;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = ep[i * ES];
-            }
-            // The UNSCALED pivot row goes to LDS the moment it is final (before its reciprocal is known): the multipliers of
-            // the elimination are read back from there as lane-uniform ds_read_b128 broadcasts, two per instruction.  (A
-            // v_readlane pair per multiplier made the loop issue-bound -- 30 SGPRs per pivot, spilled through v_writelane --
-            // 3.0 us per 16 pivots; this form 1 us.)  The rank-1 update is S[i][j] -= S[p][i] (S[p][j] / d_p): the 1/d_p rides
-            // on the lane's own entry, so only the next pivot's row waits for the reciprocal.
-            double* ur = scratch + w * CHOLB_SCRATCH_PER_WAVE;    // [16][64] unscaled rows, then [16] row scales
-            double* rsb = ur + 16 * 64;
-            int fail = 0;
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                ur[p * 64 + l] = v[p];
-                const double d = readlane_f64(v[p], p);           // lane p of this wave = column p of the diagonal block
-                const bool ok = d > 0.0 && d < 1.7976931348623157e308;   // false for NaN, <= 0, inf
-                const bool dep = SEMIDEF && allow_dep && d <= 0.0 && d > -1.7976931348623157e308;
-                if (!ok && !dep && fail == 0) fail = k0 + p + 1;
-                // the reciprocal starts from the broadcast pivot itself (no test in front of it on the chain).  A dropped
-                // pivot (SEMIDEF) must eliminate nothing; a FAILED pivot makes the whole result irrelevant, so outside
-                // SEMIDEF nothing is masked
-                const double dinv = rcp_nr2(d);
-                const double t = (!SEMIDEF || ok) ? v[p] * dinv : 0.0;
-                if (p + 1 < 16) {                                 // the next pivot's row first, its multiplier by v_readlane
-                    const double u = readlane_f64(v[p], p + 1);
-                    v[p + 1] = __builtin_fma(-u, t, v[p + 1]);
-                }
-#pragma unroll
-                for (int i2 = (p + 2) & ~1; i2 < 16; i2 += 2) {
-                    const v2d uu = *reinterpret_cast<const v2d*>(&ur[p * 64 + i2]);
-                    if (i2 >= p + 2) v[i2] = __builtin_fma(-uu.x, t, v[i2]);
-                    v[i2 + 1] = __builtin_fma(-uu.y, t, v[i2 + 1]);
-                }
-            }
-            {   // row scales 1/sqrt(d_p), all sixteen at once: lane c owns pivot c.  Dropped row: zero in R, unit pivot in W.
-                const double dg = ur[c * 64 + c];
-                const bool ok = dg > 0.0 && dg < 1.7976931348623157e308;
-                const double rs = ok ? rsq_nr2(ok ? dg : 1.0) : 0.0;
-                rsb[c] = rs;
-#pragma unroll
-                for (int p2 = 0; p2 < 16; p2 += 2) {
-                    const v2d r2 = *reinterpret_cast<const v2d*>(&rsb[p2]);
-                    v[p2] *= (aug && r2.x == 0.0) ? 1.0 : r2.x;
-                    v[p2 + 1] *= (aug && r2.y == 0.0) ? 1.0 : r2.y;
-                }
-            }
-            if (active && !(w == 1 && g == 0)) {
-                double* ep = E + k0 * ES + col;
-                const bool dg = (slot == 0);                      // the diagonal block: its strictly-lower part is zeroed
-#pragma unroll
-                for (int i = 0; i < 16; ++i) ep[i * ES] = (dg && i > c) ? 0.0 : v[i];
-            }
-            if (tid == 0 && fail != 0 && fail <= nb && *sh_fail == 0) *sh_fail = fail;
+            double* ur = scratch + set * CHOLB_SCRATCH_PER_SET;
+            double* tr = ur + 16 * 64;
+            double* rsb = tr + 8 * 64;
+            volatile int* cnt = reinterpret_cast<volatile int*>(rsb + 16);
+            const bool wb = active && !(set == 1 && g == 0);
+            if ((w & 1) == 0)
+                cholb_panel_half<ES, SEMIDEF, 0>(E, k0, col, wb, aug, slot == 0, ur, tr, rsb, cnt, 8 * k, allow_dep, sh_fail);
+            else
+                cholb_panel_half<ES, SEMIDEF, 1>(E, k0, col, wb, aug, slot == 0, ur, tr, rsb, cnt, 8 * k, allow_dep, sh_fail);
         }
         __syncthreads();
         CHOLB_STAMP(2 + 2 * k);
@@ -163,4 +242,9 @@ __device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, i
         }
         __syncthreads();
     }
+    if (tid == 0) {                                               // failures beyond nb are the identity padding: none
+        const int f = *sh_fail;
+        *sh_fail = (f == 0x7fffffff || f > nb) ? 0 : f;
+    }
+    __syncthreads();
 }

@@ -6,7 +6,29 @@
 #define GSMVI_MAX_KC 8
 #define GSMVI_STAMP_WORDS (4 * 4096)   // timeline diagnostic: 4 kernels x 512 workgroups x 8 words
 
+// Optional extras of ONE fast panel-product launch (k_panel_fast), consumed -- and cleared -- by the next product that takes
+// the fast kernel; `px_used` tells the caller whether that happened (the guarded kernels ignore them: the caller then runs
+// its separate finish passes).
+struct gsmvi_panel_extras {
+    // rows >= msplit of the right operand M come as split-K slabs: M[row][col] = sum_{q < kcm} msl[q * mstride + (row - msplit) * ldsl + col];
+    // the finished rows are also written to mfin (row stride ldfin) by the z == 0 workgroups when mfin != nullptr
+    const double* msl = nullptr;
+    int kcm = 0;
+    size_t mstride = 0;
+    int ldsl = 0, msplit = 0;
+    double* mfin = nullptr;
+    int ldfin = 0;
+    // side job shared by all workgroups of the launch: sj_dst[i] = sum_{q < sj_kc} sj_src[q * sj_stride + i], i < sj_len
+    const double* sj_src = nullptr;
+    int sj_kc = 0;
+    size_t sj_stride = 0;
+    int sj_len = 0;
+    double* sj_dst = nullptr;
+};
+
 struct gsmvi_ctx {
+    gsmvi_panel_extras px;     // see above
+    int px_used = 0;
     int device = 0;
     int max_D = 0, max_B = 0;
     int num_cu = 256;
@@ -17,6 +39,7 @@ struct gsmvi_ctx {
     double* sg = nullptr;      // [4][rmax][max_D] finished panels (SG, BaM factor panels)
     double* small = nullptr;   // coefficients and small dense matrices
     int* ints = nullptr;       // device ints (flags)
+    double* gram_slabs = nullptr;   // [GSMVI_MAX_KC][rmax][rmax] split-K slabs of the factor path's Gram product, + 16 stamp words
     int tune_panel_kc = 0;
     int tune_update_sb = 0;
     int tune_cov_dbg = 0;      // ablation bits for k_gsm_cov_sym (wrong results; timing only)

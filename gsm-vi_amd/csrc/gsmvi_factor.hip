@@ -506,20 +506,29 @@ __global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double
     const int tid = threadIdx.x;
     if (tid == 0) sh_moderate = 1;
     {   // Gamma1 = sum of the kcg split-K slabs of the Gram product (n x n each, full matrix) -> E2, raw
-        double g[8], t[GSMVI_MAX_KC][8];
-#pragma unroll
-        for (int kc = 0; kc < GSMVI_MAX_KC; ++kc)      // every load of every slab in one batch (clamped slab index)
+        double g[8];
+        if (kcg == 1) {                                // block-uniform: the finished matrix (the lean path's side job)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int e = tid + 512 * k, i = e >> 6, q = e & 63;
-                t[kc][k] = Gp[(size_t)(kc < kcg ? kc : kcg - 1) * n * n + (size_t)(i < n ? i : n - 1) * n + (q < n ? q : n - 1)];
+                g[k] = Gp[(size_t)(i < n ? i : n - 1) * n + (q < n ? q : n - 1)];
             }
+        } else {
+            double t[GSMVI_MAX_KC][8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            double a = 0.0;
+            for (int kc = 0; kc < GSMVI_MAX_KC; ++kc)  // every load of every slab in one batch (clamped slab index)
 #pragma unroll
-            for (int kc = 0; kc < GSMVI_MAX_KC; ++kc) a += (kc < kcg) ? t[kc][k] : 0.0;
-            g[k] = a;
+                for (int k = 0; k < 8; ++k) {
+                    const int e = tid + 512 * k, i = e >> 6, q = e & 63;
+                    t[kc][k] = Gp[(size_t)(kc < kcg ? kc : kcg - 1) * n * n + (size_t)(i < n ? i : n - 1) * n + (q < n ? q : n - 1)];
+                }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                double a = 0.0;
+#pragma unroll
+                for (int kc = 0; kc < GSMVI_MAX_KC; ++kc) a += (kc < kcg) ? t[kc][k] : 0.0;
+                g[k] = a;
+            }
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -918,45 +927,105 @@ __global__ __launch_bounds__(256) void k_gsmf_unpack(int D, int B, const double*
     Tm[(size_t)(B + b) * D + i] = rb[2 * D + i];
 }
 
-// Front half: the D-sized operands of B samples.  Fills Rt1 = [Z; V] (2B x D) and Tm1 = [X - mu; V Fm] in the workspace
-// (layout for n = 2B rows).
-static int factor_front(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
-                        const double* G, int ldg, const double* mu0, const double* F0, int ldf0) {
-    const int n = 2 * B;
-    double* Rt = ctx->sg;                          // n x D   [Z; V]
-    double* Tm = Rt + (size_t)n * D;               // n x D   [X - mu; V Fm]
-    // W = G Fm^T (split-K slabs), finished inside the elementwise stage
+// Workspace of the factor path: ctx->sg = Rt1 [Z; V] (n x D) | Tm1 [X - mu; V Fm] (n x D) | Fs (n x D); ctx->small = seven
+// n x n slots (Gamma, Rg / K'', A', T, P, coefficients, finished Gram matrix); ctx->gram_slabs; ctx->pp = split-K slabs of
+// the D-wide products (W, then V Fm).
+struct factor_ws {
+    double *Rt, *Tm, *Fs, *Gam, *Rg, *Ap, *Tt, *Pm, *coef, *Gam1, *Gp;
+    unsigned long long* stamps;
+};
+static factor_ws factor_carve(gsmvi_ctx* ctx, int D, int n) {
+    factor_ws w;
+    w.Rt = ctx->sg;
+    w.Tm = w.Rt + (size_t)n * D;
+    w.Fs = w.Tm + (size_t)n * D;
+    w.Gam = ctx->small;
+    w.Rg = w.Gam + (size_t)n * n;
+    w.Ap = w.Rg + (size_t)n * n;
+    w.Tt = w.Ap + (size_t)n * n;
+    w.Pm = w.Tt + (size_t)n * n;
+    w.coef = w.Pm + (size_t)n * n;                 // [beta; alpha] / B (2B), then [beta; alpha] (2B)
+    w.Gam1 = w.coef + (size_t)n * n;
+    w.Gp = ctx->gram_slabs;
+    w.stamps = (ctx->tune_cov_dbg & 128)
+                   ? reinterpret_cast<unsigned long long*>(ctx->gram_slabs + (size_t)GSMVI_MAX_KC * ctx->rmax * ctx->rmax)
+                   : nullptr;
+    return w;
+}
+
+// W = G Fm^T (split-K slabs), finished inside the elementwise stage: Rt1 = [Z; V], top half of Tm1 = X - mu
+static int factor_w_prep(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
+                         const double* G, int ldg, const double* mu0, const double* F0, int ldf0) {
+    const factor_ws w = factor_carve(ctx, D, 2 * B);
     int kc = 1;
     int rc = gsmvi_panel_t_product(ctx, st, D, B, G, ldg, F0, ldf0, D, ctx->pp, &kc);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gsmf_prep, dim3((D + 255) / 256, B), dim3(256), 0, st, D, B, kc, Z, ldz, X, ldx, mu0, ctx->pp, Rt,
-                       Tm);
-    if ((rc = chk("k_gsmf_prep"))) return rc;
-    // bottom half of Tm1: V Fm
-    return gsmvi_panel_product_out(ctx, st, D, D, B, Rt + (size_t)B * D, D, nullptr, 1.0, F0, ldf0, nullptr,
-                                   Tm + (size_t)B * D, D);
+    hipLaunchKernelGGL(k_gsmf_prep, dim3((D + 255) / 256, B), dim3(256), 0, st, D, B, kc, Z, ldz, X, ldx, mu0, ctx->pp, w.Rt,
+                       w.Tm);
+    return chk("k_gsmf_prep");
 }
 
+// Back half: from Rt1 = [Z; V], Tm1 = [X - mu; V Fm] (n = 2B rows) to (mu, F).  The Gram matrix comes as kcg slabs at Gp
+// (kcg = 1: finished); V Fm either finished in Tm1 (vf_slabs == nullptr) or as kcv split-K slabs summed by their consumer.
 static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
-                       double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev);
+                       double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, const double* Gp, int kcg,
+                       const double* vf_slabs, int kcv);
+
+// the Gram product Gamma1 = [Z; V][Z; V]^T as split-K slabs (transposed panel product with A = M = Rt1)
+static int factor_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int n, const factor_ws& w, int* kcg) {
+    return gsmvi_panel_t_product(ctx, st, D, n, w.Rt, D, w.Rt, D, n, w.Gp, kcg);
+}
 
 int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
                       const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double* mu, double* F,
                       int ldf, int* info_dev, int* n_reverts_dev) {
-    int rc = factor_front(ctx, st, D, B, Z, ldz, X, ldx, G, ldg, mu0, F0, ldf0);
+    const int n = 2 * B;
+    const factor_ws w = factor_carve(ctx, D, n);
+    int rc = factor_w_prep(ctx, st, D, B, Z, ldz, X, ldx, G, ldg, mu0, F0, ldf0);
     if (rc) return rc;
-    return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev);
+    int kcg = 1, kcv = 1;
+    if ((rc = factor_gram(ctx, st, D, n, w, &kcg))) return rc;
+    // Launch diet (round 3).  Where the skinny product Fs = K'' Tm1 will run on the fast kernel (inner dimension n a multiple
+    // of 64), the V Fm product keeps its split-K slabs -- that consumer sums them while it loads its right operand -- and
+    // carries the finish of the Gram slabs as a side job of its 256 workgroups (the one-workgroup chain kernel would pull
+    // them through a single CU: measured +5.6 us).  Otherwise: product + finish launches, as before.
+    const bool lean = !ctx->tune_no_fast && ctx->tune_direct_out && n % 64 == 0 && D % 64 == 0 && ldf0 % 2 == 0 &&
+                      (reinterpret_cast<uintptr_t>(F0) & 15u) == 0;
+    if (lean) {
+        if (kcg > 1) {
+            ctx->px.sj_src = w.Gp;
+            ctx->px.sj_kc = kcg;
+            ctx->px.sj_stride = (size_t)n * n;
+            ctx->px.sj_len = n * n;
+            ctx->px.sj_dst = w.Gam1;
+        }
+        if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, D, B, w.Rt + (size_t)B * D, D, nullptr, 1.0, F0, ldf0, ctx->pp,
+                                         &kcv)))
+            return rc;
+        if (!ctx->px_used) {                       // (cannot happen under `lean`; kept as a guard)
+            gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "fast panel kernel expected (internal error)");
+            return GSMVI_ERR_UNSUPPORTED;
+        }
+        return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, kcg > 1 ? w.Gam1 : w.Gp, 1,
+                           ctx->pp, kcv);
+    }
+    if ((rc = gsmvi_panel_product_out(ctx, st, D, D, B, w.Rt + (size_t)B * D, D, nullptr, 1.0, F0, ldf0, nullptr,
+                                      w.Tm + (size_t)B * D, D)))
+        return rc;
+    return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, w.Gp, kcg, nullptr, 0);
 }
 
 // Batch-sharded form, stage 1: this rank's B_local samples -> records.
 int gsmvi_factor_local_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int Bl, const double* Z, int ldz, const double* X,
                             int ldx, const double* G, int ldg, const double* mu0, const double* F0, int ldf0,
                             double* rec, int ldrec) {
-    int rc = factor_front(ctx, st, D, Bl, Z, ldz, X, ldx, G, ldg, mu0, F0, ldf0);
+    const factor_ws w = factor_carve(ctx, D, 2 * Bl);
+    int rc = factor_w_prep(ctx, st, D, Bl, Z, ldz, X, ldx, G, ldg, mu0, F0, ldf0);
     if (rc) return rc;
-    const double* Rt = ctx->sg;
-    const double* Tm = Rt + (size_t)2 * Bl * D;
-    hipLaunchKernelGGL(k_gsmf_pack, dim3((D + 255) / 256, Bl), dim3(256), 0, st, D, Bl, Rt, Tm, rec, ldrec);
+    if ((rc = gsmvi_panel_product_out(ctx, st, D, D, Bl, w.Rt + (size_t)Bl * D, D, nullptr, 1.0, F0, ldf0, nullptr,
+                                      w.Tm + (size_t)Bl * D, D)))
+        return rc;
+    hipLaunchKernelGGL(k_gsmf_pack, dim3((D + 255) / 256, Bl), dim3(256), 0, st, D, Bl, w.Rt, w.Tm, rec, ldrec);
     return chk("k_gsmf_pack");
 }
 
@@ -965,74 +1034,61 @@ int gsmvi_factor_apply_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const 
                             int ldrec, const double* mu0, const double* F0, int ldf0, double* mu, double* F, int ldf,
                             int* info_dev, int* n_reverts_dev) {
     const int n = 2 * B;
-    double* Rt = ctx->sg;
-    double* Tm = Rt + (size_t)n * D;
-    hipLaunchKernelGGL(k_gsmf_unpack, dim3((D + 255) / 256, B), dim3(256), 0, st, D, B, Z, ldz, rec, ldrec, Rt, Tm);
+    const factor_ws w = factor_carve(ctx, D, n);
+    hipLaunchKernelGGL(k_gsmf_unpack, dim3((D + 255) / 256, B), dim3(256), 0, st, D, B, Z, ldz, rec, ldrec, w.Rt, w.Tm);
     int rc = chk("k_gsmf_unpack");
     if (rc) return rc;
-    return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev);
+    int kcg = 1;
+    if ((rc = factor_gram(ctx, st, D, n, w, &kcg))) return rc;
+    return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, w.Gp, kcg, nullptr, 0);
 }
 
-// Back half: from Rt1 = [Z; V], Tm1 = [X - mu; V Fm] (n = 2B rows) to (mu, F).
 static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
-                       double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev) {
+                       double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, const double* Gp, int kcg,
+                       const double* vf_slabs, int kcv) {
     const int n = 2 * B;                           // n is even
-    // workspace carve: ctx->sg holds 4*rmax*max_D doubles (rmax = 2B+8; ws_sizes in gsmvi_abi.hip)
-    double* Rt = ctx->sg;                          // n x D   [Z; V]
-    double* Tm = Rt + (size_t)n * D;               // n x D   [X - mu; V Fm]
-    double* Fs = Tm + (size_t)n * D;               // n x D
-    double* Gam = ctx->small;                      // n x n slots of the small-matrix workspace (six of them: 6 rmax^2)
-    double* Rg = Gam + (size_t)n * n;
-    double* Ap = Rg + (size_t)n * n;
-    double* Tt = Ap + (size_t)n * n;
-    double* coef = Tt + (size_t)2 * n * n;         // sixth slot: [beta; alpha] / B (2B), then [beta; alpha] (2B)
+    const factor_ws w = factor_carve(ctx, D, n);
+    double *Rt = w.Rt, *Tm = w.Tm, *Fs = w.Fs, *coef = w.coef;
     int* info_g = ctx->ints;
     int* info_t = ctx->ints + 1;
-    int rc, kc2 = 1, kcg = 1;
-    // Gamma1 = [Z; V][Z; V]^T: split-K slabs of the transposed panel product (A = M = Rt1), summed by their consumer
-    double* Gp = ctx->pp;
-    if ((rc = gsmvi_panel_t_product(ctx, st, D, n, Rt, D, Rt, D, n, Gp, &kcg))) return rc;
+    int rc, kc2 = 1;
+    double* Kmat;
     if (n <= 64) {
-        // everything small in one workgroup, then Fs = K'' Tm1 as one skinny GEMM (inner dimension n)
-        double* Kmat = Rg;
-        hipLaunchKernelGGL(k_gsmf_small16, dim3(1), dim3(512), 0, st, n, B, Gp, kcg, Kmat, coef, info_dev,
-                           (ctx->tune_cov_dbg & 128) ? reinterpret_cast<unsigned long long*>(ctx->pp) + (size_t)GSMVI_MAX_KC * n * n : nullptr);
+        // everything small in one workgroup
+        Kmat = w.Rg;
+        hipLaunchKernelGGL(k_gsmf_small16, dim3(1), dim3(512), 0, st, n, B, Gp, kcg, Kmat, coef, info_dev, w.stamps);
         if ((rc = chk("k_gsmf_small16"))) return rc;
-        // inner dimension n <= one chunk, so there is exactly one slab: it is written straight into Fs
-        if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, Fs, &kc2)))
-            return rc;
-        if (kc2 != 1) {
-            gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "K Tm product was split (internal error)");
-            return GSMVI_ERR_UNSUPPORTED;
-        }
     } else {
-        // 64 < n <= 128: Gamma, the two n x n Choleskys one workgroup each, W and K in their own kernels, then the same
-        // skinny GEMM Fs = K'' Tm1
-        double* Kmat = Gam;                        // Gamma is dead once Rg exists
-        double* Wm = Ap;                           // A' is dead once T exists
-        double* Pm = Tt + (size_t)n * n;           // fifth n x n slot
-        hipLaunchKernelGGL(k_gsmf_gamma_big, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, Gam, coef, coef + n);
-        hipLaunchKernelGGL(k_chol128<true>, dim3(1), dim3(512), 0, st, n, Gam, Rg, info_g);   // Gram matrix: semi-definite rule
-        hipLaunchKernelGGL(k_gsmf_small_a, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, st, n, B, Rg, info_g, Ap);
-        hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n, Ap, Tt, info_t);
+        // 64 < n <= 128: Gamma, the two n x n Choleskys one workgroup each, W and K in their own kernels
+        Kmat = w.Gam;                              // Gamma is dead once Rg exists
+        double* Wm = w.Ap;                         // A' is dead once T exists
+        hipLaunchKernelGGL(k_gsmf_gamma_big, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, w.Gam, coef, coef + n);
+        hipLaunchKernelGGL(k_chol128<true>, dim3(1), dim3(512), 0, st, n, w.Gam, w.Rg, info_g);   // Gram matrix: semi-definite rule
+        hipLaunchKernelGGL(k_gsmf_small_a, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, st, n, B, w.Rg, info_g, w.Ap);
+        hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n, w.Ap, w.Tt, info_t);
         if ((rc = chk("k_chol128"))) return rc;
-        hipLaunchKernelGGL(k_gsmf_kmat_big, dim3((n + 15) / 16), dim3(256), 0, st, n, Rg, Wm, info_g, info_t,
-                           info_dev);
+        hipLaunchKernelGGL(k_gsmf_kmat_big, dim3((n + 15) / 16), dim3(256), 0, st, n, w.Rg, Wm, info_g, info_t, info_dev);
         hipLaunchKernelGGL(k_gsmf_wscale, dim3((n * B + 255) / 256), dim3(256), 0, st, n, B, Wm, coef + n, info_dev);
         if ((rc = chk("k_gsmf_kmat_big"))) return rc;
-        {
-            const int nb = (n + 15) / 16, gw = (nb * nb + 3) / 4;
-            hipLaunchKernelGGL(k_gsmf_gemm128<0>, dim3(gw), dim3(256), 0, st, n, Tt, Wm, Pm, info_dev);   // P = (T - I) W S
-            hipLaunchKernelGGL(k_gsmf_gemm128<1>, dim3(gw), dim3(256), 0, st, n, Wm, Pm, Kmat, info_dev); // K'' = (W S)^T P
-            if ((rc = chk("k_gsmf_gemm128"))) return rc;
-        }
-        // inner dimension n <= one chunk, so there is exactly one slab: it is written straight into Fs
-        if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, Fs, &kc2)))
-            return rc;
-        if (kc2 != 1) {
-            gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "K Tm product was split (internal error)");
-            return GSMVI_ERR_UNSUPPORTED;
-        }
+        const int nb = (n + 15) / 16, gw = (nb * nb + 3) / 4;
+        hipLaunchKernelGGL(k_gsmf_gemm128<0>, dim3(gw), dim3(256), 0, st, n, w.Tt, Wm, w.Pm, info_dev);   // P = (T - I) W S
+        hipLaunchKernelGGL(k_gsmf_gemm128<1>, dim3(gw), dim3(256), 0, st, n, Wm, w.Pm, Kmat, info_dev);   // K'' = (W S)^T P
+        if ((rc = chk("k_gsmf_gemm128"))) return rc;
+    }
+    // Fs = K'' Tm1 as one skinny GEMM: inner dimension n <= one chunk, so there is exactly one slab, written straight into Fs
+    if (vf_slabs) {                                // rows B .. 2B-1 of Tm1 = sum of the V Fm slabs; finished into Tm1 on the way
+        ctx->px.msl = vf_slabs;
+        ctx->px.kcm = kcv;
+        ctx->px.mstride = (size_t)B * D;
+        ctx->px.ldsl = D;
+        ctx->px.msplit = B;
+        ctx->px.mfin = Tm + (size_t)B * D;
+        ctx->px.ldfin = D;
+    }
+    if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, Fs, &kc2))) return rc;
+    if (kc2 != 1 || (vf_slabs && !ctx->px_used)) {
+        gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "K Tm product was split or left the fast kernel (internal error)");
+        return GSMVI_ERR_UNSUPPORTED;
     }
     const int nt = (D + 63) / 64;
     if (!ctx->tune_no_fast && D % 64 == 0 && (n == 32 || n == 64 || n == 128)) {

@@ -9,6 +9,7 @@
 // the design rule is: issue every global load of a workgroup in ONE batch, wait once, then MFMA,
 // then store.  No data-dependent branch sits between a load and its use.
 #include "gsmvi_common.h"
+#include "gsmvi_ctx.h"
 #include <hip/hip_ext.h>
 
 #define GSMVI_LAUNCH(kern, grid, block, shmem, st, ev, ...)                                         \
@@ -31,13 +32,16 @@
 // D % 64 == 0: a wave's 32 rows are all inside or all outside the matrix.  M has ncols columns (a multiple of
 // 16; ncols = D for the square matrices, 2B for the factor path's Gram product); slabs are nrows x ncols.
 // =====================================================================================
-template <int MT, bool HAS_SHIFT, int CHW>
+// EXTRA = true adds the two optional pieces of gsmvi_panel_extras (gsmvi_ctx.h): right-operand rows taken from split-K slabs
+// of a previous product (summed while they are loaded, so that product needs no finish launch), and a slab-summing side
+// job shared by all workgroups (finishes the small Gram matrix of the factor path beside this launch's own work).
+template <int MT, bool HAS_SHIFT, int CHW, bool EXTRA>
 __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const double* __restrict__ A, int lda,
                                                     const double* __restrict__ shift, double alpha,
                                                     const double* __restrict__ M, int ldm,
                                                     double* Pp, int chunks_per_wg, int ncols,
                                                     unsigned long long* __restrict__ stamps, double* __restrict__ Out,
-                                                    int ldo, const double* __restrict__ addvec) {
+                                                    int ldo, const double* __restrict__ addvec, gsmvi_panel_extras px) {
     // timeline diagnostic: a kernel's slot holds GSMVI_STAMP_WG workgroups x 8 words; workgroups beyond it write nothing
 #define PSTAMP(k)                                                                                              \
     do {                                                                                                       \
@@ -89,7 +93,29 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
         }                                      // loaded value may sit in front of the M stream's issue
         __builtin_amdgcn_sched_barrier(0);
         double m[NST];
-        {
+        if (EXTRA && px.msl != nullptr && (wave_in ? wbase : 0) + ks >= px.msplit) {
+            // wave-uniform when msplit is a multiple of the wave's row count (it is for B % 16 == 0); rows come in steps of 4,
+            // so ks >= ... holds for all s of this lane once it holds for s = 0
+            const double* sp = px.msl + (size_t)((wave_in ? wbase : 0) + ks - px.msplit) * px.ldsl + j;
+            double t[NST][GSMVI_MAX_KC];
+#pragma unroll
+            for (int s = 0; s < NST; ++s)
+#pragma unroll
+                for (int q = 0; q < GSMVI_MAX_KC; ++q)
+                    t[s][q] = sp[(size_t)(q < px.kcm ? q : px.kcm - 1) * px.mstride + (size_t)(4 * s) * px.ldsl];
+#pragma unroll
+            for (int s = 0; s < NST; ++s) {
+                double a = 0.0;
+#pragma unroll
+                for (int q = 0; q < GSMVI_MAX_KC; ++q) a += (q < px.kcm) ? t[s][q] : 0.0;
+                m[s] = a;
+            }
+            if (px.mfin != nullptr && blockIdx.z == 0 && wave_in) {
+                double* fp = px.mfin + (size_t)(wbase + ks - px.msplit) * px.ldfin + j;
+#pragma unroll
+                for (int s = 0; s < NST; ++s) fp[(size_t)(4 * s) * px.ldfin] = m[s];
+            }
+        } else {
             const double* mp = M + (size_t)((wave_in ? wbase : 0) + ks) * ldm + j;
 #pragma unroll
             for (int s = 0; s < NST; ++s) m[s] = mp[(size_t)(4 * s) * ldm];
@@ -143,6 +169,21 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
             for (int ww = 0; ww < 8; ww += 2) s += red[(ww * NR + rr) * 17 + cc] + red[((ww + 1) * NR + rr) * 17 + cc];
             if (Out == nullptr) Pp[((size_t)blockIdx.y * nrows + row) * ncols + blockIdx.x * 16 + cc] = s;
             else Out[(size_t)row * ldo + blockIdx.x * 16 + cc] = s + (addvec ? addvec[blockIdx.x * 16 + cc] : 0.0);
+        }
+    }
+    if (EXTRA && px.sj_src != nullptr) {            // side job: this workgroup's slice of a slab sum
+        const int nwg = gridDim.x * gridDim.y * gridDim.z;
+        const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const int per = (px.sj_len + nwg - 1) / nwg;
+        const int i = wg * per + tid;
+        if (tid < per && i < px.sj_len) {
+            double t[GSMVI_MAX_KC];
+#pragma unroll
+            for (int q = 0; q < GSMVI_MAX_KC; ++q) t[q] = px.sj_src[(size_t)(q < px.sj_kc ? q : px.sj_kc - 1) * px.sj_stride + i];
+            double a = 0.0;
+#pragma unroll
+            for (int q = 0; q < GSMVI_MAX_KC; ++q) a += (q < px.sj_kc) ? t[q] : 0.0;
+            px.sj_dst[i] = a;
         }
     }
     if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PSTAMP(3); }
@@ -414,15 +455,20 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
 void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int nrows, const double* A,
                              int lda, const double* shift, double alpha, const double* M, int ldm, double* Pp,
                              int chunks_per_wg, int ncols, unsigned long long* stamps, double* Out, int ldo,
-                             const double* addvec) {
-#define PF(MTV, HS, CW)                                                                                          \
-    GSMVI_LAUNCH((k_panel_fast<MTV, HS, CW>), grid, dim3(512), 0, st, ev, D, nrows, A, lda, shift, alpha, M, ldm, \
-                 Pp, chunks_per_wg, ncols, stamps, Out, ldo, addvec)
+                             const double* addvec, const gsmvi_panel_extras* px) {
+    const gsmvi_panel_extras none;
+    const bool extra = px && (px->msl || px->sj_src);
+    const gsmvi_panel_extras pxv = extra ? *px : none;
+#define PF(MTV, HS, CW, EX)                                                                                          \
+    GSMVI_LAUNCH((k_panel_fast<MTV, HS, CW, EX>), grid, dim3(512), 0, st, ev, D, nrows, A, lda, shift, alpha, M, ldm, \
+                 Pp, chunks_per_wg, ncols, stamps, Out, ldo, addvec, pxv)
+#define PFE(MTV, HS, CW) do { if (extra) PF(MTV, HS, CW, true); else PF(MTV, HS, CW, false); } while (0)
     if (shift) {
-        if (MT == 1) PF(1, true, 256); else if (MT == 2) PF(2, true, 256); else PF(4, true, 128);
+        if (MT == 1) PFE(1, true, 256); else if (MT == 2) PFE(2, true, 256); else PFE(4, true, 128);
     } else {
-        if (MT == 1) PF(1, false, 256); else if (MT == 2) PF(2, false, 256); else PF(4, false, 128);
+        if (MT == 1) PFE(1, false, 256); else if (MT == 2) PFE(2, false, 256); else PFE(4, false, 128);
     }
+#undef PFE
 #undef PF
 }
 

@@ -5,7 +5,10 @@
 #include <cstdio>
 #include <vector>
 __device__ unsigned long long g_stamp[16];
+__device__ unsigned long long g_cyc[2];
 #define CHOLB_STAMP(k) do { if (threadIdx.x == 0) g_stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long g_ps[2][16];
+#define CHOLB_PSTAMP(h, i) ((void)0)
 #include "../gsm-vi_amd/csrc/gsmvi_chol64b.h"
 
 template <bool SEMIDEF, bool AUG>
@@ -22,8 +25,10 @@ __global__ __launch_bounds__(512) void k(int n, const double* A, double* R, doub
     }
     __syncthreads();
     CHOLB_STAMP(0);
+    if (threadIdx.x == 0) g_cyc[0] = __builtin_amdgcn_s_memtime();
     chol64_blk<ES, SEMIDEF, AUG>(E, scr, n, &sf, true);
     CHOLB_STAMP(15);
+    if (threadIdx.x == 0) g_cyc[1] = __builtin_amdgcn_s_memtime();
     for (int e = threadIdx.x; e < 64 * 64; e += 512) {
         const int i = e >> 6, q = e & 63;
         R[e] = E[i * ES + q];
@@ -52,6 +57,7 @@ static int run(const char* name, int n, const std::vector<double>& A, int expect
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { printf("%s: HIP error %s\n", name, hipGetErrorString(e)); return 1; }
     unsigned long long st[16]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamp), sizeof st);
+    unsigned long long cy[2]; hipMemcpyFromSymbol(cy, HIP_SYMBOL(g_cyc), sizeof cy);
     std::vector<double> R(64 * 64), W(64 * 64); int fail = -1;
     hipMemcpy(R.data(), dR, 64 * 64 * 8, hipMemcpyDeviceToHost);
     hipMemcpy(W.data(), dW, 64 * 64 * 8, hipMemcpyDeviceToHost);
@@ -90,11 +96,18 @@ static int run(const char* name, int n, const std::vector<double>& A, int expect
     printf("%-28s n=%2d fail=%d (expect %d)  recon %.1e  vs host %.1e  |W R^T - I| %.1e  lower %.1e  total %.2f us %s\n", name, n,
            fail, expect_fail, erec, eref, einv, elow, (st[15] - st[0]) / 100.0, bad ? "  <-- BAD" : "");
     if (n == 64 && check) {
-        printf("    panel/trailing per block step (us):");
+        printf("    shader clock %.0f MHz;", (double)(cy[1] - cy[0]) / ((st[15] - st[0]) / 100.0));
+        printf(" panel/trailing per block step (us):");
         for (int kk = 0; kk < 4; ++kk)
             printf("  [%.2f %.2f]", (st[2 + 2 * kk] - st[1 + 2 * kk]) / 100.0,
                    kk < 3 ? (st[3 + 2 * kk] - st[2 + 2 * kk]) / 100.0 : 0.0);
         printf("\n");
+        unsigned long long ps[2][16]; hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_ps), sizeof ps);
+        for (int h = 0; h < 2; ++h) {
+            printf("    half %d (cycles since half 0 start): load %lld, apply-end %lld, pivots:", h, (long long)(ps[h][0] - ps[0][0]), (long long)(ps[h][1] - ps[0][0]));
+            for (int q = 0; q < 8; ++q) printf(" %lld", (long long)(ps[h][2 + q] - ps[0][0]));
+            printf(" | scales %lld wb %lld end %lld\n", (long long)(ps[h][10] - ps[0][0]), (long long)(ps[h][11] - ps[0][0]), (long long)(ps[h][12] - ps[0][0]));
+        }
     }
     hipFree(dA); hipFree(dR); hipFree(dW); hipFree(df);
     return bad;
