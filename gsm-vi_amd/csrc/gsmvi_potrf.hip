@@ -16,6 +16,7 @@
 #define NB 64
 
 #include "gsmvi_chol64.h"
+#include "gsmvi_chol64b.h"
 
 // =====================================================================================
 // C = F^T F (Gram matrix of the columns; the covariance a square factor represents).  One workgroup per 64x64 tile
@@ -159,10 +160,9 @@ int gsmvi_whiten_impl(hipStream_t st, int D, int nrows, const double* R, int ldr
 // Eight waves per tile workgroup:
 //   * the three 64^3 products run two waves per SIMD (wave w: rows 32 wr + 16 rr .., columns 32 wc .., one 16 x 32 strip
 //     of accumulators; the fp64 MFMA pipe delivers 46 TF chip-wide there against 34 TF with one wave per SIMD);
-//   * in the diagonal tile, W_k = R_kk^-T is built by waves 4-7 WHILE waves 0-3 factor the tile: substitution step p needs
-//     row p of the factor and its pivot only, and chol64_rows_s has published both (unscaled, in LDS) by the barrier that
-//     opens pivot p.  The helpers execute one barrier per step (matching the factorisation's per-pivot barrier) and
-//     derive 1/sqrt(d_p) themselves.
+//   * the diagonal tile is factored by chol64_blk (gsmvi_chol64b.h, round 3): 16-pivot panels in registers without a
+//     workgroup barrier per pivot, and W_k = R_kk^-T falls out of the augmented identity columns (round 2 ran a 64-step
+//     substitution on four helper waves beside a one-barrier-per-pivot factorisation: 16.6 us per step against ~10.5).
 // (Round 1's two-launch step and round 2's four-wave fused step were removed in round 3: 630 / 504 us against 439 us at
 // D = 1024; profiles/r02/.)
 // =====================================================================================
@@ -191,11 +191,15 @@ __global__ __launch_bounds__(512) void k_potrf_step8(int D, int k, const double*
     } while (0)
     PSTAMP(0);
     constexpr int RS = 66;
-    static_assert(RS == TS, "chol64 runs in the staging buffer");
-    __shared__ __attribute__((aligned(16))) double L0[64 * RS];
-    __shared__ __attribute__((aligned(16))) double L1[64 * RS];
-    __shared__ __attribute__((aligned(16))) double L2[64 * RS];
-    __shared__ double rinv[64];
+    // one LDS block: the three 64 x 66 staging tiles of the products; the diagonal tile reuses it afterwards as the
+    // [tile | W] matrix (64 x 146) and the panel scratch of chol64_blk
+    constexpr int ESD = 146;
+    constexpr int LDS_DOUBLES = (3 * 64 * RS > 64 * ESD + CHOLB_SCRATCH_DOUBLES(true)) ? 3 * 64 * RS
+                                                                                        : 64 * ESD + CHOLB_SCRATCH_DOUBLES(true);
+    __shared__ __attribute__((aligned(16))) double Lall[LDS_DOUBLES];
+    double* const L0 = Lall;
+    double* const L1 = Lall + 64 * RS;
+    double* const L2 = Lall + 2 * 64 * RS;
     __shared__ int sh_fail;
     const int nblk = (D + NB - 1) / NB, m = nblk - k;
     int ti, tj;
@@ -311,91 +315,32 @@ __global__ __launch_bounds__(512) void k_potrf_step8(int D, int k, const double*
             }
         return;
     }
-    // ---- the diagonal tile (k, k): waves 0-3 factor it, waves 4-7 build W_k = R_kk^-T one pivot behind ----
+    // ---- the diagonal tile (k, k): blocked Cholesky of [tile | I] (chol64_blk): R_kk and W_k = R_kk^-T in one pass ----
     const int nb = (D - I0) < NB ? (D - I0) : NB;
-    __syncthreads();
+    double* const E = Lall;                                       // [64][ESD]: columns 0..63 the tile, 64..127 W
+    double* const scr = Lall + 64 * ESD;
+    __syncthreads();                                              // everyone is done with the staging tiles
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = lrow0 + 4 * r, j = 32 * wc + 16 * ct + c;
-            L0[i * RS + j] = (i < nb && j < nb) ? tv[ct][r] : (i == j ? 1.0 : 0.0);
+            E[i * ESD + j] = (i < nb && j < nb) ? (j >= i ? tv[ct][r] : 0.0) : (i == j ? 1.0 : 0.0);
         }
-    if (tid < 64) rinv[tid] = 1.0;
     __syncthreads();
     PSTAMP(3);
-    if (tid < 256) {
-        chol64_rows_s<TS>(L0, rinv, nb, &sh_fail);     // (raising this team's wave priority with s_setprio changed nothing)
-        PSTAMP(4);
-        if (tid == 0 && sh_fail != 0 && *info == 0) *info = I0 + sh_fail;
-        for (int e = tid; e < NB * NB; e += 256) {
-            const int i = e >> 6, j = e & 63;
-            if (i < nb && j < nb) R[(size_t)(I0 + i) * ldr + I0 + j] = (j >= i) ? L0[i * RS + j] : 0.0;
-        }
-        if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PSTAMP(5); }
-        return;
+    chol64_blk<ESD, false, true>(E, scr, nb, &sh_fail);
+    PSTAMP(4);
+    if (tid == 0 && sh_fail != 0 && *info == 0) *info = I0 + sh_fail;
+    for (int e = tid; e < NB * NB; e += 512) {
+        const int i = e >> 6, j = e & 63;
+        if (i < nb && j < nb) R[(size_t)(I0 + i) * ldr + I0 + j] = (j >= i) ? E[i * ESD + j] : 0.0;
     }
-    if (m == 1) {                                                 // last step: nobody needs W; only match the barriers
-        chol64_helper_idle<TS>(nb);
-        return;
-    }
-    {
-        // nb == 64 here (only the last block can be ragged).  Column cq of the lower-triangular W per quad of lanes; step p:
-        // x_p *= 1/sqrt(d_p), x_t -= R[p][t] x_p (t > p) with R[p][t] = T[p][t] / sqrt(d_p), T = the published unscaled row.
-        // Row ownership inside the quad: lane q owns the row PAIRS {8r + 2q, 8r + 2q + 1}, r = 0..7 (x[2r], x[2r+1]), so a
-        // step reads the published row with 8 ds_read_b128 per lane instead of 16 ds_read_b64: the helpers' LDS traffic
-        // is what slows the factorisation beside them (scripts/potrf_timeline.py: 12.5 us alone, 18.4 us with b64 reads).
-        const int st = tid - 256, cq = st >> 2, q = st & 3;
-        double x[16];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            x[2 * r] = (8 * r + 2 * q == cq) ? 1.0 : 0.0;
-            x[2 * r + 1] = (8 * r + 2 * q + 1 == cq) ? 1.0 : 0.0;
-        }
-        // software-pipelined by one more pivot: behind barrier p the helper starts 1/sqrt(d_p) (a dependent chain of ~10
-        // instructions) and meanwhile runs the arithmetic of step p - 1, whose scale it already holds
-        double ri_prev = 0.0;
-#pragma unroll
-        for (int p = 0; p <= 64; ++p) {
-            double ri = 0.0;
-            if (p < 64) {
-                __syncthreads();                                  // = the barrier that opens pivot p: row p and d_p are final
-                const double d = L0[p * RS + p];
-                const bool ok = d > 0.0 && d < 1.7976931348623157e308;
-                const double dd = ok ? d : 1.0;
-                double y = __builtin_amdgcn_rsq(dd);
-                y = y * (1.5 - 0.5 * dd * y * y);
-                y = y * (1.5 - 0.5 * dd * y * y);
-                ri = ok ? y : 0.0;                                // the rinv[p] the factorisation will publish at its end
-            }
-            if (p > 0) {
-                const int ps = p - 1;
-                const int pr = 2 * (ps >> 3) + (ps & 1), pq = (ps >> 1) & 3;     // register and quad lane that hold x_ps
-                const double mine = x[pr] * ri_prev;
-                if (q == pq) x[pr] = mine;
-                const double xp = quad_bcast_rt<0>(mine, pq) * ri_prev;   // x_p / sqrt(d_p): scales the unscaled row (pq is a
-                                                                            // compile-time constant after unrolling)
-#pragma unroll
-                for (int r = 0; r < 8; ++r)
-                    if (8 * r + 7 > ps) {
-                        const int t = 8 * r + 2 * q;
-                        const v2d rv = *reinterpret_cast<const v2d*>(&L0[ps * RS + t]);   // RS and t even: 16-byte aligned
-                        x[2 * r] -= (t > ps) ? rv.x * xp : 0.0;
-                        x[2 * r + 1] -= (t + 1 > ps) ? rv.y * xp : 0.0;
-                    }
-            }
-            ri_prev = ri;
-        }
-        __syncthreads();
-        __syncthreads();
-        __syncthreads();
+    if (m > 1) {                                                  // the next step's triangular solve: W_k[i][p], row-major
         double* Wk = wbuf + (size_t)(k & 1) * NB * NB;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            Wk[(8 * r + 2 * q) * NB + cq] = x[2 * r];
-            Wk[(8 * r + 2 * q + 1) * NB + cq] = x[2 * r + 1];
-        }
+        for (int e = tid; e < NB * NB; e += 512) Wk[e] = E[(e >> 6) * ESD + 64 + (e & 63)];
     }
+    if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PSTAMP(5); }
 }
 
 #undef PSTAMP
