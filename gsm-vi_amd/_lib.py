@@ -40,6 +40,13 @@ _SIGS = {
                                       C.c_int, _c_dp, _c_dp, C.c_int]),
     "gsmvi_gsm_update_sharded_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int,
                                                _c_dp, C.c_int, _c_dp, _c_dp, C.c_int, _c_dp, _c_dp, _c_dp, C.c_int]),
+    "gsmvi_set_rccl_library": (C.c_int, [C.c_void_p]),
+    "gsmvi_gsm_factor_update_sharded_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int,
+                                                      _c_dp, C.c_int, _c_dp, C.c_int, _c_dp, _c_dp, C.c_int, _c_dp, _c_dp,
+                                                      _c_dp, C.c_int, _c_dp, _c_dp]),
+    "gsmvi_bam_update_sharded_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp,
+                                               C.c_int, _c_dp, _c_dp, C.c_int, C.c_double, C.c_double, _c_dp, _c_dp, _c_dp,
+                                               C.c_int, _c_dp]),
     "gsmvi_gsm_rows_stage_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp,
                                            C.c_int, _c_dp, C.c_int]),
     "gsmvi_gsm_records_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int,

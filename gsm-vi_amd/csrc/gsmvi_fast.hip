@@ -325,12 +325,12 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
             rem -= inrow;
             ++ti;
         }
-        tj0 = ti + 2 * rem;
+        tj0 = ti + ((nt - ti) & 1) + 2 * rem;                    // odd tile count: the pairs start right of the diagonal tile
         two = true;
     } else {
-        const int k = blockIdx.x - n_two;                        // k-th row with an odd tile count
-        ti = ((nt & 1) ? 0 : 1) + 2 * k;
-        tj0 = nt - 1;
+        const int k = blockIdx.x - n_two;                        // k-th row with an odd tile count: its DIAGONAL tile (no
+        ti = ((nt & 1) ? 0 : 1) + 2 * k;                         // mirror store, so the late single-tile workgroups are light)
+        tj0 = ti;
         two = false;
     }
     const bool diag = (tj0 == ti);
@@ -342,11 +342,16 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
     const bool mine = (t == 0) || two;           // does this wave's tile exist
 
     // ---- every global load of this workgroup, in one batch --------------------------------
-    double s0[4];
-    const size_t srow = (size_t)(I0 + 16 * wr + ks);
-    const int scol = J0 + 32 * ((t == 1 && two) ? 1 : 0) + 16 * wc + c;
+    // S0 tile of this wave's tile t in STORE layout: 16-B units, unit = (row i, column pair j2), two per thread -- a row of
+    // the tile is one 256-B segment.  (Round 2 loaded and stored 8 B per lane in accumulator layout.)
+    const int Jt = J0 + 32 * ((t == 1 && two) ? 1 : 0);
+    const int tl = tid & 255;
+    v2d s0v[2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s0[r] = (dbg & 2) ? 1.0 : S0[(srow + 4 * r) * lds0 + scol];
+    for (int q = 0; q < 2; ++q) {
+        const int unit = q * 256 + tl, i = unit >> 4, j2 = unit & 15;
+        s0v[q] = (dbg & 2) ? (v2d){1.0, 1.0} : *reinterpret_cast<const v2d*>(S0 + (size_t)(I0 + i) * lds0 + Jt + 2 * j2);
+    }
     __builtin_amdgcn_sched_barrier(0);           // keep the HBM loads of S0 ahead of the L2-resident staging loads
     v2d stg[UPT];
 #pragma unroll
@@ -409,30 +414,40 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
             }
         }
     }
-    double wv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) wv[r] = s0[r] + (accd[r] - acce[r]) * invB;
-    if (mine) {                                  // direct store S[I, J_t]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) S[(srow + 4 * r) * lds + scol] = wv[r];
-    }
-    if (stamps) { asm volatile("" :: "v"(wv[0]), "v"(wv[1]), "v"(wv[2]), "v"(wv[3])); STAMP(3); }
-
-    // ---- mirror stores S[J_t, I] = W_t^T through LDS, and the new mean ---------------------------
+    // ---- stores through LDS, 16 B per lane: the update tile U_t = (D_I^T D_J - E_I^T E_J)/B goes to LDS in accumulator
+    // layout; W_t = S0[I, J_t] + U_t is formed in store layout (row segments of 256 B), stored, written back to LDS, and
+    // the mirror S[J_t, I] = W_t^T is read from there by columns (row stride 33: conflict-free both ways)
     __syncthreads();                             // everyone is done reading the factor tiles
     double* LW = smem + t * 32 * 33;             // [2][32 x 33]
-    const bool need = mine && !(t == 0 && diag) && !(dbg & 1);
-    if (need) {
+    if (mine) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) LW[(16 * wr + ks + 4 * r) * 33 + 16 * wc + c] = wv[r];
+        for (int r = 0; r < 4; ++r) LW[(16 * wr + ks + 4 * r) * 33 + 16 * wc + c] = (accd[r] - acce[r]) * invB;
     }
+    if (stamps) STAMP(3);
+    __syncthreads();
+    if (mine) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int unit = q * 256 + tl, i = unit >> 4, j2 = unit & 15;
+            v2d wv2;
+            wv2.x = s0v[q].x + LW[i * 33 + 2 * j2];
+            wv2.y = s0v[q].y + LW[i * 33 + 2 * j2 + 1];
+            *reinterpret_cast<v2d*>(S + (size_t)(I0 + i) * lds + Jt + 2 * j2) = wv2;
+            LW[i * 33 + 2 * j2] = wv2.x;
+            LW[i * 33 + 2 * j2 + 1] = wv2.y;
+        }
+    }
+    const bool need = mine && !(t == 0 && diag) && !(dbg & 1);
     __syncthreads();
     if (need) {
-        // element (row j = 16 wr + ks + 4r of J_t, col i = 16 wc + c of I) = W_t[i][j]
+        // unit = (row j of J_t, column pair i2 of I): S[J_t + j][I0 + 2 i2 .. + 1] = W_t[2 i2 .. + 1][j]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double v = LW[(16 * wc + c) * 33 + 16 * wr + ks + 4 * r];
-            S[(size_t)(J0 + 32 * t + 16 * wr + ks + 4 * r) * lds + I0 + 16 * wc + c] = v;
+        for (int q = 0; q < 2; ++q) {
+            const int unit = q * 256 + tl, j = unit >> 4, i2 = unit & 15;
+            v2d m2;
+            m2.x = LW[(2 * i2) * 33 + j];
+            m2.y = LW[(2 * i2 + 1) * 33 + j];
+            *reinterpret_cast<v2d*>(S + (size_t)(Jt + j) * lds + I0 + 2 * i2) = m2;
         }
     }
     if (diag) {

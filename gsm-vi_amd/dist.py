@@ -30,6 +30,35 @@ def _all_gather(t_all, t_loc, group=None):
     dist.all_gather_into_tensor(t_all, t_loc.contiguous(), group=group)
 
 
+def _broadcast(t, src, group=None):
+    """broadcast on the group's backend (device tensors staged through the host for a gloo group, as in _all_gather)."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+        return
+    dist.broadcast(t, src=src, group=group)
+
+
+def root_potrf(eng, S, R, flag, group=None, root=0):
+    """The Cholesky accept test of a batch-sharded DENSE fit (gsm_numpy.py:121-125,132-146): the replicas hold identical
+    covariances, so ONE rank factors (O(D^3)) and broadcasts the factor and its flag instead of every rank repeating the
+    factorisation (D^2 doubles over xGMI: 8 MiB at D = 1024 against a ~0.3 ms Cholesky).  Replicas stay bit-identical."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world == 1:
+        return eng.potrf(S, out=R, flag=flag)
+    if rank == root:
+        eng.potrf(S, out=R, flag=flag)
+    src = dist.get_global_rank(group, root) if group is not None else root
+    tR, tf = _as_torch(R), _as_torch(flag if not hasattr(flag, "v") else np.array([flag.v], dtype=np.int32))
+    _broadcast(tR, src, group)
+    _broadcast(tf, src, group)
+    if hasattr(flag, "v"):                       # the oracle-backed engine of the CPU tests keeps its flag in .v
+        flag.v = int(tf[0])
+    return R, flag
+
+
 def shard_bounds(B, world, rank):
     """Contiguous equal shards; B must be divisible by the world size (one fixed-size all-gather)."""
     assert B % world == 0, f"batch size {B} must be divisible by the number of ranks {world}"
@@ -62,7 +91,7 @@ def sharded_gsm_factor_update(eng, Z, X_local, G_local, mu0, F0, lo, group=None,
 
     Z (B, D): the whitened draws of ALL samples, replicated (same key on every rank); X_local, G_local: samples
     and scores of this rank's rows [lo, lo + B/P).  Each rank runs the per-sample stage for its rows (two of
-    the three passes over F0 divided by P), records [x - mu0 | u | u F0] are all-gathered (3D doubles per
+    the three passes over F0 divided by P), records [x - mu0 | v | v F0] (v = w + z, the whitened residual) are all-gathered (3D doubles per
     sample, like the dense path) and every replica applies the identical rank-2B factor update."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     Bl = X_local.shape[0]

@@ -198,7 +198,11 @@ class GSM:
                 vs = self.lp_g(X) if native else eng.asarray(self.lp_g(eng.to_numpy(X)))
                 eng.gsm_update(X, vs, mean_t, cov_t, out=(mean_new, cov_new))
             nevals += B
-            eng.potrf(cov_new, out=R_new, flag=flag)              # _check_goodness, :121,:132-146
+            if shard:                                             # one rank factors, the others receive (dist.root_potrf)
+                from .dist import root_potrf
+                root_potrf(eng, cov_new, R_new, flag, group=group)
+            else:
+                eng.potrf(cov_new, out=R_new, flag=flag)          # _check_goodness, :121,:132-146
             eng.commit(flag, mean_new, cov_new, mean_t, cov_t, n_rev)
             if use_factor:
                 eng.commit(flag, mean_new, R_new, mean_t, R, None)

@@ -134,6 +134,14 @@ int gsmvi_gsm_update_sharded_f64(gsmvi_ctx* ctx, void* stream, void* nccl_comm, 
                                  double* mu, double* S, int lds);
 
 /*
+ * The RCCL library the sharded entry points call into.  By default they resolve ncclAllGather / ncclCommCount /
+ * ncclCommUserRank at first use from the RCCL instance already loaded in the process (falling back to librccl.so.1).  A
+ * process that holds several RCCL copies (e.g. torch's bundled one beside the system one) passes the dlopen handle of the
+ * copy that CREATED its communicators here, before the first sharded call; afterwards the choice is fixed.
+ */
+int gsmvi_set_rccl_library(void* dl_handle);
+
+/*
  * The same update with the covariance sharded by ROW BLOCKS (the decomposition that divides
  * the HBM-bound passes by the number of GPUs).  A rank owns rows [row0, row0 + nrows) of S0 as an
  * nrows x D row-major block; X, G, mu0 are replicated.
@@ -170,13 +178,13 @@ int gsmvi_gsm_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
 /*
  * The factor-form update in two stages, for the batch-sharded multi-GPU path (BASELINE config 5 on several GPUs;
  * same decomposition as gsmvi_gsm_local_stage_f64 / gsmvi_gsm_apply_f64):
- *   local stage : for this rank's B_local samples (rows of Z, X, G): W = G F0^T, the whitened scalars, u_b and
- *                 u_b F0; one record per sample  rec[b] = [ x_b - mu0 (D) | u_b (D) | u_b F0 (D) ], row stride
+ *   local stage : for this rank's B_local samples (rows of Z, X, G): W = G F0^T, the whitened residual v_b = w_b + z_b
+ *                 and v_b F0; one record per sample  rec[b] = [ x_b - mu0 (D) | v_b (D) | v_b F0 (D) ], row stride
  *                 ldrec >= gsmvi_gsm_record_len(D).  Two of the three passes over F0 are divided by the number of
  *                 ranks.  Records of all ranks are all-gathered (RCCL) by the caller;
  *   apply       : every replica holds the same Z (B x D: the draw stream is replicated, gsmvi_randn_f64 is
- *                 counter-based) and all B records, and runs the 2B x 2B positive-definite test and the rank-2B
- *                 factor update.  Same outputs and revert semantics as gsmvi_gsm_factor_update_f64.
+ *                 counter-based) and all B records, and runs the Gram product of [Z; V], the per-sample scalars (they are
+ *                 entries of that Gram matrix), the 2B x 2B positive-definite test and the rank-2B factor update.  Same outputs and revert semantics as gsmvi_gsm_factor_update_f64.
  * gsmvi_gsm_factor_update_f64 == local stage with B_local = B followed by apply.
  */
 int gsmvi_gsm_factor_local_stage_f64(gsmvi_ctx* ctx, void* stream, int D, int B_local,
@@ -186,6 +194,19 @@ int gsmvi_gsm_factor_apply_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
                                const double* Z, int ldz, const double* rec, int ldrec,
                                const double* mu0, const double* F0, int ldf0,
                                double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev);
+
+/*
+ * The factor-form update batch-sharded over RCCL in ONE call: local stage on this rank's rows -> ncclAllGather of the
+ * records (in place in rec_all: (B_local * nranks) x gsmvi_gsm_record_len(D) doubles) -> combined update on every replica.
+ * Z_all holds the replicated draws of ALL B = B_local * nranks samples (the draw stream is counter-based; rank r's samples
+ * are rows [r B_local, (r + 1) B_local)); X_local, G_local are this rank's rows.  Same outputs and revert semantics as
+ * gsmvi_gsm_factor_update_f64; everything is validated before the first launch.
+ */
+int gsmvi_gsm_factor_update_sharded_f64(gsmvi_ctx* ctx, void* stream, void* nccl_comm, int D, int B_local,
+                                        const double* Z_all, int ldz, const double* X_local, int ldx,
+                                        const double* G_local, int ldg, const double* mu0, const double* F0, int ldf0,
+                                        double* rec_all, double* mu, double* F, int ldf, int* info_dev,
+                                        int* n_reverts_dev);
 
 /*
  * Profiling mode (used by bench.py for the roofline line): when on, the three kernels of the GSM
@@ -273,6 +294,17 @@ int gsmvi_bam_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
                          const double* X, int ldx, const double* G, int ldg,
                          const double* mu0, const double* S0, int lds0, double reg, double jitter,
                          double* mu, double* S, int lds, int* info_dev);
+
+/*
+ * BaM update batch-sharded over RCCL (BASELINE config 4: B = 128 as 16 per GPU): BaM's statistics couple all samples, so the
+ * ranks all-gather their (x_b, g_b) rows (two ncclAllGather of B_local x D doubles per rank) into xg_all (caller-owned,
+ * 2 x B x D doubles: [X_all | G_all]) and every replica runs gsmvi_bam_update_f64 on the full batch; what is divided is the
+ * score evaluation in front of it.  Validated before the first launch.
+ */
+int gsmvi_bam_update_sharded_f64(gsmvi_ctx* ctx, void* stream, void* nccl_comm, int D, int B_local,
+                                 const double* X_local, int ldx, const double* G_local, int ldg,
+                                 const double* mu0, const double* S0, int lds0, double reg, double jitter,
+                                 double* xg_all, double* mu, double* S, int lds, int* info_dev);
 
 #ifdef __cplusplus
 }

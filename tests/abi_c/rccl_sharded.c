@@ -1,9 +1,10 @@
-/* Plain-C consumer of the RCCL-taking entry point (include/gsmvi_hip.h: gsmvi_gsm_update_sharded_f64): one process
- * per GPU, the caller owns the ncclComm_t.
+/* Plain-C consumer of the RCCL-taking entry points (include/gsmvi_hip.h: gsmvi_gsm_update_sharded_f64,
+ * gsmvi_gsm_factor_update_sharded_f64, gsmvi_bam_update_sharded_f64): one process per GPU, the caller owns the ncclComm_t.
  *   rccl_sharded <in.bin> <out.bin> <nranks> <rank> <idfile>
  * Rank 0 writes the ncclUniqueId to <idfile>, the other ranks wait for it.  Every rank reads the full problem of
- * in.bin (format of abi_smoke.c), takes rows [rank*B/nranks, (rank+1)*B/nranks) of X and G as its shard and writes
- * mu[D], S[D*D] of the combined update to <out.bin>.<rank>. */
+ * in.bin (int D, int B, then X[B*D], G[B*D], mu0[D], S0[D*D], Z[B*D], F0[D*D] with X = mu0 + Z F0, S0 = F0^T F0), takes
+ * rows [rank*B/nranks, (rank+1)*B/nranks) of X and G as its shard and writes to <out.bin>.<rank>:
+ *   mu[D], S[D*D] (dense update) | mu[D], F[D*D], flag (factor-form update) | mu[D], S[D*D] (BaM update, reg 2, jitter 0). */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -24,8 +25,9 @@ int main(int argc, char** argv) {
     int D, B;
     if (fread(&D, 4, 1, f) != 1 || fread(&B, 4, 1, f) != 1) return 1;
     const size_t nbd = (size_t)B * D, ndd = (size_t)D * D;
-    double* h = (double*)malloc(sizeof(double) * (2 * nbd + D + ndd));
-    if (fread(h, sizeof(double), 2 * nbd + D + ndd, f) != 2 * nbd + D + ndd) return 1;
+    const size_t nin = 3 * nbd + D + 2 * ndd;
+    double* h = (double*)malloc(sizeof(double) * nin);
+    if (fread(h, sizeof(double), nin, f) != nin) return 1;
     fclose(f);
     if (B % nranks) return 1;
     const int Bl = B / nranks;
@@ -76,14 +78,42 @@ int main(int argc, char** argv) {
         return 5;
     CHECK_HIP(hipStreamSynchronize(st));
 
-    double* out = (double*)malloc(sizeof(double) * (D + ndd));
+    const size_t nout = 3 * (D + ndd) + 1;
+    double* out = (double*)malloc(sizeof(double) * nout);
     CHECK_HIP(hipMemcpy(out, mu, sizeof(double) * D, hipMemcpyDeviceToHost));
     CHECK_HIP(hipMemcpy(out + D, S, sizeof(double) * ndd, hipMemcpyDeviceToHost));
+
+    /* factor-form update through the communicator: Z is replicated, X and G are this rank's rows */
+    double *Z, *F0, *xg;
+    int* flag;
+    CHECK_HIP(hipMalloc((void**)&Z, sizeof(double) * nbd));
+    CHECK_HIP(hipMalloc((void**)&F0, sizeof(double) * ndd));
+    CHECK_HIP(hipMalloc((void**)&xg, sizeof(double) * 2 * nbd));
+    CHECK_HIP(hipMalloc((void**)&flag, 2 * sizeof(int)));
+    CHECK_HIP(hipMemset(flag, 0, 2 * sizeof(int)));
+    CHECK_HIP(hipMemcpy(Z, h + 2 * nbd + D + ndd, sizeof(double) * nbd, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(F0, h + 3 * nbd + D + ndd, sizeof(double) * ndd, hipMemcpyHostToDevice));
+    for (int rep = 0; rep < 2; ++rep)
+        CHECK_ABI(gsmvi_gsm_factor_update_sharded_f64(ctx, st, comm, D, Bl, Z, D, X, D, G, D, mu0, F0, D, rec, mu, S, D, flag,
+                                                      flag + 1));
+    CHECK_HIP(hipStreamSynchronize(st));
+    int hflag[2];
+    CHECK_HIP(hipMemcpy(hflag, flag, sizeof hflag, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(out + D + ndd, mu, sizeof(double) * D, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(out + 2 * D + ndd, S, sizeof(double) * ndd, hipMemcpyDeviceToHost));
+    out[2 * (D + ndd)] = (double)(hflag[0] + 1000 * hflag[1]);
+
+    /* BaM update through the communicator: the (x_b, g_b) rows are all-gathered into xg */
+    CHECK_ABI(gsmvi_bam_update_sharded_f64(ctx, st, comm, D, Bl, X, D, G, D, mu0, S0, D, 2.0, 0.0, xg, mu, S, D, flag));
+    CHECK_HIP(hipStreamSynchronize(st));
+    CHECK_HIP(hipMemcpy(out + 2 * (D + ndd) + 1, mu, sizeof(double) * D, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(out + 2 * (D + ndd) + 1 + D, S, sizeof(double) * ndd, hipMemcpyDeviceToHost));
+
     char name[4096];
     snprintf(name, sizeof name, "%s.%d", argv[2], rank);
     f = fopen(name, "wb");
     if (!f) return 1;
-    fwrite(out, sizeof(double), D + ndd, f);
+    fwrite(out, sizeof(double), nout, f);
     fclose(f);
     CHECK_NCCL(ncclCommDestroy(comm));
     CHECK_ABI(gsmvi_destroy(ctx));

@@ -114,9 +114,10 @@ def test_plain_c_program_drives_the_abi(tmp_path, D, B):
 @pytest.mark.gpu
 @pytest.mark.parametrize("D,B", [(1024, 32), (100, 6)])
 def test_rccl_taking_entry_point_from_plain_c(tmp_path, D, B):
-    """tests/abi_c/rccl_sharded.c: a C program owning the ncclComm_t drives gsmvi_gsm_update_sharded_f64 (local
-    stage -> ncclAllGather on the caller's stream -> combined update).  One rank per visible GPU, at most 2 (the GPU
-    box has one; RCCL does not allow two ranks on one device)."""
+    """tests/abi_c/rccl_sharded.c: a C program owning the ncclComm_t drives gsmvi_gsm_update_sharded_f64,
+    gsmvi_gsm_factor_update_sharded_f64 and gsmvi_bam_update_sharded_f64 (local stage -> ncclAllGather on the caller's
+    stream -> combined update).  One rank per visible GPU, at most 2 (the GPU box has one; RCCL does not allow two
+    ranks on one device)."""
     import subprocess
     import numpy as np
     import torch
@@ -133,8 +134,9 @@ def test_rccl_taking_entry_point_from_plain_c(tmp_path, D, B):
     st = orc.make_update_state(D, B, 7)
     with open(tmp_path / "in.bin", "wb") as f:
         f.write(np.array([D, B], dtype=np.int32).tobytes())
-        for k in ("samples", "vs", "mu0", "S0"):
+        for k in ("samples", "vs", "mu0", "S0", "Z"):
             f.write(np.ascontiguousarray(st[k], dtype=np.float64).tobytes())
+        f.write(np.ascontiguousarray(st["L"].T, dtype=np.float64).tobytes())     # F0: S0 = F0^T F0, samples = mu0 + Z F0
     nranks = min(2, torch.cuda.device_count())
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
     procs = [subprocess.Popen([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(nranks), str(r),
@@ -144,11 +146,19 @@ def test_rccl_taking_entry_point_from_plain_c(tmp_path, D, B):
     for q, (so, se) in zip(procs, outs):
         assert q.returncode == 0, (q.returncode, se[-2000:])
     mu_o, S_o = orc.gsm_update_faithful(st["samples"], st["vs"], st["mu0"], st["S0"])
+    from oracle import bam_oracle as borc
+    mu_b, S_b = borc.bam_lowrank_update_exact(st["samples"], st["vs"], st["mu0"], st["S0"], 2.0)
+    S_b = 0.5 * (S_b + S_b.T)
     res = []
+    n1 = D + D * D
     for r in range(nranks):
         out = np.frombuffer(open(str(tmp_path / "out.bin") + f".{r}", "rb").read(), dtype=np.float64)
-        mu, S = out[:D], out[D:].reshape(D, D)
+        mu, S = out[:D], out[D:n1].reshape(D, D)
         assert rel_err(mu, mu_o) < 1e-11 and rel_err(S, S_o) < 1e-11
+        muf, F, fl = out[n1:n1 + D], out[n1 + D:2 * n1].reshape(D, D), out[2 * n1]
+        assert fl == 0.0 and rel_err(muf, mu_o) < 1e-10 and rel_err(F.T @ F, S_o) < 1e-10      # factor form = dense update
+        mub, Sb = out[2 * n1 + 1:2 * n1 + 1 + D], out[2 * n1 + 1 + D:].reshape(D, D)
+        assert rel_err(mub, mu_b) < 1e-7 and rel_err(Sb, S_b) < 1e-7                              # BaM vs the restatement
         res.append(out)
     assert all(np.array_equal(res[0], x) for x in res)          # replicas bit-identical
 
