@@ -61,6 +61,8 @@ _SIGS = {
     "gsmvi_gsm_factor_apply_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int,
                                              _c_dp, _c_dp, C.c_int, _c_dp, _c_dp, C.c_int, _c_dp, _c_dp]),
     "gsmvi_randn_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, _c_dp, _c_dp]),
+    "gsmvi_randn_batch_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int64, _c_dp, _c_dp,
+                                        _c_dp]),
     "gsmvi_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "gsmvi_debug_read_workspace": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_double), C.c_size_t]),
     "gsmvi_debug_read_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]),

@@ -104,7 +104,8 @@ class BaM:
         rs = np.random.RandomState(seed)
         assert rng in ("auto", "numpy", "device"), "rng must be 'auto', 'numpy' or 'device'"
         dev_rng = rng == "device" or (rng == "auto" and sampler == "cholesky")   # as GSM.fit: see its docstring
-        Zbuf = eng.empty(B, D) if dev_rng else None
+        KB = 16                         # the device draws come a block of KB per launch (the stream does not depend on the state)
+        Zblk = eng.empty(KB, B, D) if dev_rng else None
         ndraw = 0                       # counter-based stream: one `call` per draw, retries included
         native = bool(getattr(self.lp_g, "device_native", False))
         mon_native = bool(getattr(monitor, "device_native", False)) if monitor is not None else False
@@ -154,7 +155,9 @@ class BaM:
                         X = eng.asarray(_legacy_mvn(rs, eng.to_numpy(mean_t), eng.to_numpy(cov_t), B))
                     else:
                         if dev_rng:
-                            Z = eng.normal(B, D, seed, ndraw, out=Zbuf)
+                            if ndraw % KB == 0:
+                                eng.normal_batch(KB, B, D, seed, ndraw, out=Zblk)
+                            Z = Zblk[ndraw % KB]
                             ndraw += 1
                         else:
                             Z = eng.normal_from_host(rs.standard_normal((B, D)))

@@ -575,8 +575,43 @@ __global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double
     chol64_blk<ES1, true, true>(E1, scr, n, &fail_g, moderate);     // E1 = [Rg | W]
     SMALL_STAMP(2);
     const int w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
-    const int wj = w & 3, g2 = w >> 2;                 // column block of this wave, row-block parity
     const int nblk = (n + 15) >> 4;
+    // The three 64^3 products below run one 16 x 16 output block at a time on a wave, the operands of a k-block (four MFMA
+    // steps) fetched from LDS into registers one k-block AHEAD of their use; the blocks are dealt to the eight waves by the
+    // tables so that every wave has (nearly) the same number of k-blocks -- the triangular structure makes the block costs
+    // differ (round 2 gave each wave a fixed column block: up to 2x imbalance, operands read at their point of use).
+    // task = 4 * ib + jb + 1 (0 = none)
+#define GSMF_T(i, j) (4 * (i) + (j) + 1)
+    static constexpr unsigned char TASK_A[8][2] = {   // A'(ib, jb), ib <= jb: cost 4 - jb k-blocks
+        {GSMF_T(0, 0), 0}, {GSMF_T(0, 1), 0}, {GSMF_T(1, 1), 0}, {GSMF_T(0, 2), GSMF_T(0, 3)},
+        {GSMF_T(1, 2), GSMF_T(1, 3)}, {GSMF_T(2, 2), GSMF_T(2, 3)}, {GSMF_T(3, 3), 0}, {0, 0}};
+    static constexpr unsigned char TASK_P[8][3] = {   // P(ib, jb): cost 4 - max(ib, jb)
+        {GSMF_T(0, 0), 0, 0}, {GSMF_T(0, 1), GSMF_T(3, 0), 0}, {GSMF_T(1, 0), GSMF_T(3, 1), 0}, {GSMF_T(1, 1), GSMF_T(3, 2), 0},
+        {GSMF_T(0, 2), GSMF_T(1, 2), 0}, {GSMF_T(2, 0), GSMF_T(2, 1), 0}, {GSMF_T(2, 2), GSMF_T(0, 3), GSMF_T(1, 3)},
+        {GSMF_T(2, 3), GSMF_T(3, 3), 0}};
+    static constexpr unsigned char TASK_K[8][2] = {   // K(ib, jb): cost 4 - ib
+        {GSMF_T(0, 0), GSMF_T(3, 0)}, {GSMF_T(0, 1), GSMF_T(3, 1)}, {GSMF_T(0, 2), GSMF_T(3, 2)}, {GSMF_T(0, 3), GSMF_T(3, 3)},
+        {GSMF_T(1, 0), GSMF_T(2, 0)}, {GSMF_T(1, 1), GSMF_T(2, 1)}, {GSMF_T(1, 2), GSMF_T(2, 2)}, {GSMF_T(1, 3), GSMF_T(2, 3)}};
+#undef GSMF_T
+    // one output block: acc = sum over the k-blocks kb0 .. nblk-1 of A(ib-rows, k) B(k, jb-cols); fa(k) / fb(k) fetch the
+    // operand values of this lane for contraction index k
+    auto block_chain = [&](int kb0, auto fa, auto fb) {
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        double a[4], b[4], an[4], bn[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { a[s4] = fa(16 * kb0 + 4 * s4 + ks); b[s4] = fb(16 * kb0 + 4 * s4 + ks); }
+        for (int kb = kb0; kb < nblk; ++kb) {
+            if (kb + 1 < nblk) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) { an[s4] = fa(16 * (kb + 1) + 4 * s4 + ks); bn[s4] = fb(16 * (kb + 1) + 4 * s4 + ks); }
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = GSMVI_MFMA_F64(a[s4], b[s4], acc);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) { a[s4] = an[s4]; b[s4] = bn[s4]; }
+        }
+        return acc;
+    };
     // W <- W S (column operations on the right half of E1; the A' phase below reads only the left half, so both share this
     // barrier interval): K'' = S^T K S = (W S)^T (T - I) (W S)
     for (int e = tid; e < 64 * 32; e += 512) {
@@ -589,41 +624,38 @@ __global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double
     }
     {   // A' = I + (Rg J) Rg^T into E2;  (Rg J)[i][k] = (1/B)(k < B ? Rg[i][B+k] : Rg[i][k-B] - Rg[i][k]), on the MFMA pipe.
         // A' is symmetric (the mirror is written too); Rg is upper triangular, so Rg[j][k] = 0 for k < 16 j: only the
-        // k-blocks j..3 contribute.  Wave (wj, g2) computes the blocks (ib, wj), ib <= wj, ib % 2 == g2
+        // k-blocks jb..3 contribute to the block (ib, jb), ib <= jb
         const double invB = 1.0 / (double)B;
-        v4d acc[2];
-        acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
-        const double* brow = E1 + (16 * wj + cc) * ES1;
-        for (int kb = wj; kb < nblk; ++kb) {
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int k = 16 * kb + 4 * s4 + ks;
-                const int k1 = (k < B) ? B + k : k - B;
-                const double bv = brow[k];
+        for (int tq = 0; tq < 2; ++tq) {
+            const int task = TASK_A[w][tq];
+            if (task == 0) continue;                   // wave-uniform
+            const int ib = (task - 1) >> 2, jb = (task - 1) & 3;
+            if (jb >= nblk) {                          // beyond n: the identity padding
+                continue;
+            }
+            const double* arow = E1 + (16 * ib + cc) * ES1;
+            const double* brow = E1 + (16 * jb + cc) * ES1;
+            const v4d acc = block_chain(
+                jb,
+                [&](int k) {
+                    const int k1 = (k < B) ? B + k : k - B;
+                    const double a1 = arow[k1 < 64 ? k1 : 63], a0 = arow[k];
+                    return (k < n) ? ((k < B) ? a1 : a1 - a0) : 0.0;
+                },
+                [&](int k) { return brow[k]; });
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int ib = 2 * h + g2;
-                    if (ib <= wj) {
-                        const double* arow = E1 + (16 * ib + cc) * ES1;
-                        const double a1 = arow[k1 < 64 ? k1 : 63], a0 = arow[k];
-                        const double a = (k < n) ? ((k < B) ? a1 : a1 - a0) : 0.0;
-                        acc[h] = GSMVI_MFMA_F64(a, bv, acc[h]);
-                    }
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ib + ks + 4 * r, j = 16 * jb + cc;
+                const double v = (i == j ? 1.0 : 0.0) + ((i < n && j < n) ? acc[r] * invB : 0.0);
+                E2[i * ES2 + j] = v;
+                if (ib != jb) E2[j * ES2 + i] = v;
             }
         }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int ib = 2 * h + g2;
-            if (ib <= wj) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * ib + ks + 4 * r, j = 16 * wj + cc;
-                    const double v = (i == j ? 1.0 : 0.0) + ((i < n && j < n) ? acc[h][r] * invB : 0.0);
-                    E2[i * ES2 + j] = v;
-                    if (ib != wj) E2[j * ES2 + i] = v;
-                }
-            }
+        // blocks beyond n: identity padding (written by everybody's share)
+        for (int e = tid; e < 64 * 64; e += 512) {
+            const int i = e >> 6, j = e & 63;
+            if ((i >> 4) >= nblk || (j >> 4) >= nblk) E2[i * ES2 + j] = (i == j) ? 1.0 : 0.0;
         }
     }
     __syncthreads();
@@ -634,55 +666,47 @@ __global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double
     if (tid == 0) *bad_out = bad;
     if (bad) return;                                   // block-uniform
     {
-        // P[i][j] = sum_k (T - I)[i][k] W[k][j]: T - I upper (k >= i), W lower (k >= j): k-blocks max(i, j)..3; wave (wj, g2):
-        // column block wj, row blocks ib % 2 == g2.  P goes into the left half of E1 (Rg is dead).  The blocks of E2 below
-        // the diagonal still hold A' and are never read (ib <= kb).
-        v4d acc[2];
-        acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+        // P[i][j] = sum_k (T - I)[i][k] W[k][j]: T - I upper (k >= i), W lower (k >= j): k-blocks max(i, j)..3.  P goes into the
+        // left half of E1 (Rg is dead; it was last read in the A' phase, two barriers ago).  The blocks of E2 below the
+        // diagonal still hold A' and are never read (k-block >= ib).
         const double* Wm = E1 + 64;
-        for (int kb = wj; kb < nblk; ++kb) {
+        v4d pacc[3];
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int k = 16 * kb + 4 * s4 + ks;
-                const double bv = Wm[k * ES1 + 16 * wj + cc];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int ib = 2 * h + g2;
-                    if (ib <= kb) {
-                        const int i = 16 * ib + cc;
-                        acc[h] = GSMVI_MFMA_F64(E2[i * ES2 + k] - (i == k ? 1.0 : 0.0), bv, acc[h]);
-                    }
-                }
-            }
+        for (int tq = 0; tq < 3; ++tq) {
+            pacc[tq] = (v4d){0.0, 0.0, 0.0, 0.0};
+            const int task = TASK_P[w][tq];
+            if (task == 0) continue;
+            const int ib = (task - 1) >> 2, jb = (task - 1) & 3;
+            if (ib >= nblk || jb >= nblk) continue;
+            const int i = 16 * ib + cc;
+            pacc[tq] = block_chain(
+                ib > jb ? ib : jb, [&](int k) { return E2[i * ES2 + k] - (i == k ? 1.0 : 0.0); },
+                [&](int k) { return Wm[k * ES1 + 16 * jb + cc]; });
         }
-        // (E1's left half was last read in the A' phase, two barriers ago)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int tq = 0; tq < 3; ++tq) {
+            const int task = TASK_P[w][tq];
+            if (task == 0) continue;
+            const int ib = (task - 1) >> 2, jb = (task - 1) & 3;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) E1[(16 * (2 * h + g2) + ks + 4 * r) * ES1 + 16 * wj + cc] = acc[h][r];
+            for (int r = 0; r < 4; ++r) E1[(16 * ib + ks + 4 * r) * ES1 + 16 * jb + cc] = pacc[tq][r];
+        }
         __syncthreads();
         SMALL_STAMP(5);
-        // K[i][j] = sum_k W[k][i] P[k][j]: W[k][i] = 0 for k < i: k-blocks i..3
-        acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
-        for (int kb = 0; kb < nblk; ++kb) {
+        // K''[i][j] = sum_k W[k][i] P[k][j]: W[k][i] = 0 for k < i: k-blocks i..3
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const int k = 16 * kb + 4 * s4 + ks;
-                const double bv = E1[k * ES1 + 16 * wj + cc];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int ib = 2 * h + g2;
-                    if (ib <= kb) acc[h] = GSMVI_MFMA_F64(Wm[k * ES1 + 16 * ib + cc], bv, acc[h]);
-                }
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int tq = 0; tq < 2; ++tq) {
+            const int task = TASK_K[w][tq];
+            const int ib = (task - 1) >> 2, jb = (task - 1) & 3;
+            if (ib >= nblk || jb >= nblk) continue;
+            const v4d acc = block_chain(
+                ib, [&](int k) { return Wm[k * ES1 + 16 * ib + cc]; }, [&](int k) { return E1[k * ES1 + 16 * jb + cc]; });
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = 16 * (2 * h + g2) + ks + 4 * r, j = 16 * wj + cc;
-                if (i < n && j < n) Kmat[(size_t)i * n + j] = acc[h][r];
+                const int i = 16 * ib + ks + 4 * r, j = 16 * jb + cc;
+                if (i < n && j < n) Kmat[(size_t)i * n + j] = acc[r];
             }
+        }
     }
     SMALL_STAMP(6);
 #undef SMALL_STAMP

@@ -37,9 +37,18 @@ __device__ __forceinline__ double u53(unsigned a, unsigned b) {
 }
 
 // One thread per element pair; `raw` (may be NULL) receives the four Philox words of every pair (tests).
+// blockIdx.y = c: draw number call + c goes to out + c n (several iterations' draws from one launch).  call_in (may be
+// NULL): a device word added to `call` -- with call_out = the OTHER word of a ping-pong pair receiving *call_in + gridDim.y,
+// a captured launch advances through the stream on every replay of its graph (nobody in this launch reads call_out).
 __global__ __launch_bounds__(256) void k_randn(unsigned long long seed, unsigned long long call, long long n,
-                                               double* __restrict__ out, unsigned* __restrict__ raw) {
+                                               double* __restrict__ out, unsigned* __restrict__ raw,
+                                               const unsigned long long* __restrict__ call_in,
+                                               unsigned long long* __restrict__ call_out) {
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long base = call_in ? *call_in : 0ull;
+    if (call_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *call_out = base + gridDim.y;
+    call += base + blockIdx.y;
+    out += (size_t)blockIdx.y * n;
     if (2 * p >= n) return;
     unsigned w[4];
     philox4x32_10((unsigned)p, (unsigned)((unsigned long long)p >> 32), (unsigned)call, (unsigned)(call >> 32),
@@ -56,21 +65,34 @@ __global__ __launch_bounds__(256) void k_randn(unsigned long long seed, unsigned
     if (2 * p + 1 < n) out[2 * p + 1] = r * s;
 }
 
-extern "C" int gsmvi_randn_f64(gsmvi_ctx* ctx, void* stream, uint64_t seed, uint64_t call, int64_t n, double* out,
-                               uint32_t* raw) {
-    if (!ctx) { gsmvi_set_error("%s: %s", "gsmvi_randn_f64", "ctx is NULL"); return GSMVI_ERR_BAD_ARG; }
-    if (n < 0 || (n > 0 && !out)) {
-        gsmvi_set_error("%s: %s", "gsmvi_randn_f64", "n < 0 or out is NULL");
+static int randn_launch(const char* fn, gsmvi_ctx* ctx, void* stream, uint64_t seed, uint64_t call, int ncalls, int64_t n,
+                        double* out, uint32_t* raw, const uint64_t* call_in, uint64_t* call_out) {
+    if (!ctx) { gsmvi_set_error("%s: %s", fn, "ctx is NULL"); return GSMVI_ERR_BAD_ARG; }
+    if (n < 0 || ncalls < 1 || ncalls > 65535 || (n > 0 && !out) || (call_out && call_out == call_in)) {
+        gsmvi_set_error("%s: %s", fn, "bad size, out is NULL, or call_out aliases call_in");
         return GSMVI_ERR_BAD_ARG;
     }
     if (n == 0) return GSMVI_OK;
     const long long pairs = (n + 1) / 2;
-    hipLaunchKernelGGL(k_randn, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       (unsigned long long)seed, (unsigned long long)call, (long long)n, out, raw);
+    hipLaunchKernelGGL(k_randn, dim3((unsigned)((pairs + 255) / 256), (unsigned)ncalls), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), (unsigned long long)seed, (unsigned long long)call, (long long)n, out,
+                       raw, reinterpret_cast<const unsigned long long*>(call_in),
+                       reinterpret_cast<unsigned long long*>(call_out));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         gsmvi_set_error("launch of %s failed: %s", "k_randn", hipGetErrorString(e));
         return GSMVI_ERR_HIP;
     }
     return GSMVI_OK;
+}
+
+extern "C" int gsmvi_randn_f64(gsmvi_ctx* ctx, void* stream, uint64_t seed, uint64_t call, int64_t n, double* out,
+                               uint32_t* raw) {
+    return randn_launch("gsmvi_randn_f64", ctx, stream, seed, call, 1, n, out, raw, nullptr, nullptr);
+}
+
+extern "C" int gsmvi_randn_batch_f64(gsmvi_ctx* ctx, void* stream, uint64_t seed, uint64_t call0, int ncalls, int64_t n,
+                                     double* out, const uint64_t* call_in_dev, uint64_t* call_out_dev) {
+    return randn_launch("gsmvi_randn_batch_f64", ctx, stream, seed, call0, ncalls, n, out, nullptr, call_in_dev,
+                        call_out_dev);
 }

@@ -119,6 +119,20 @@ class HipEngine:
             C.c_void_p(raw.data_ptr()) if raw is not None else None))
         return Z
 
+    def normal_batch(self, ncalls, B, D, seed, call0=0, out=None, call_in=None, call_out=None):
+        """(ncalls, B, D) standard normals: slice c is bit-identical to ``normal(B, D, seed, call0 + c)`` -- one launch for a
+        block of fit iterations (the draw stream does not depend on the state).  ``call_in`` / ``call_out``: device int64
+        words (1-element tensors); *call_in is added to call0 on the device and *call_out receives *call_in + ncalls, so a
+        graph-captured launch advances through the stream on every replay."""
+        self._ensure(max(self._max_D, 1), max(self._max_B, 1))
+        Z = self.empty(ncalls, B, D) if out is None else out
+        assert Z.is_contiguous() and Z.numel() == ncalls * B * D
+        _lib.check("gsmvi_randn_batch_f64", self.lib.gsmvi_randn_batch_f64(
+            self._ctx, self._stream(), int(seed) & (2 ** 64 - 1), int(call0), int(ncalls), B * D, C.c_void_p(Z.data_ptr()),
+            C.c_void_p(call_in.data_ptr()) if call_in is not None else None,
+            C.c_void_p(call_out.data_ptr()) if call_out is not None else None))
+        return Z
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 

@@ -73,7 +73,7 @@ class GSM:
     # ------------------------------------------------------------------------------
     def fit(self, key, mean=None, cov=None, batch_size=2, niter=5000, nprint=10, verbose=True,
             check_goodness=True, monitor=None, *, sampler="cholesky", rng="auto", as_torch=False,
-            forced_samples=None, method="auto", shard=False, group=None):
+            forced_samples=None, method="auto", shard=False, group=None, graph=None):
         """Fit N(mean, cov) to the target (gsmvi/gsm_numpy.py:77-129, gsmvi/gsm.py:79-133).
 
         Same arguments and return value as the reference.  Behaviour kept: ``niter + 1`` updates
@@ -102,6 +102,9 @@ class GSM:
                     replicated; each rank evaluates ``lp_g`` only on its batch_size/world rows, the
                     per-sample records are all-gathered (RCCL) and every replica applies the identical
                     combined update (gsm-vi_amd/dist.py).  All ranks return the same (mean, cov).
+          graph   : None (default) / True: the factor-form fit replays blocks of 16 iterations as one hipGraph when every
+                    launch in them is capturable (a score marked ``graph_safe`` such as ``GaussianTarget.lp_g``, the
+                    device draw stream, no sharding); False: always issue the launches from Python.  Same numbers.
           method  : "auto" (default) = "factor" whenever it applies (2*batch_size <= min(D, 128), the device
                     Cholesky sampler, no teacher-forced samples) and "dense" otherwise.  Why that is a drop-in
                     default: for the same draws the two forms give the same (mean, cov) to round-off
@@ -136,7 +139,7 @@ class GSM:
         self.method_used = method
         if method == "factor":
             return self._fit_factor(key, mean, cov, batch_size, niter, nprint, verbose, monitor, rng, as_torch,
-                                    shard, group)
+                                    shard, group, graph)
         assert method == "dense", "method must be 'auto', 'dense' or 'factor'"
         eng = self._engine if self._engine is not None else get_engine()
         D, B = self.D, int(batch_size)
@@ -147,7 +150,8 @@ class GSM:
         rs = np.random.RandomState(seed)
         assert rng in ("auto", "numpy", "device"), "rng must be 'auto', 'numpy' or 'device'"
         dev_rng = rng == "device" or (rng == "auto" and sampler == "cholesky")
-        Zbuf = eng.empty(B, D) if dev_rng else None
+        KB = 16
+        Zblk = eng.empty(KB, B, D) if dev_rng else None
         native = bool(getattr(self.lp_g, "device_native", False))
         mon_native = bool(getattr(monitor, "device_native", False)) if monitor is not None else False
 
@@ -183,7 +187,12 @@ class GSM:
             elif sampler == "svd":
                 X = eng.asarray(_legacy_mvn(rs, eng.to_numpy(mean_t), eng.to_numpy(cov_t), B))
             else:
-                Z = eng.normal(B, D, seed, i, out=Zbuf) if dev_rng else eng.normal_from_host(rs.standard_normal((B, D)))
+                if dev_rng:                                     # a block of KB iterations' draws per launch (same stream)
+                    if i % KB == 0:
+                        eng.normal_batch(min(KB, niter + 1 - i), B, D, seed, i, out=Zblk[:min(KB, niter + 1 - i)])
+                    Z = Zblk[i % KB]
+                else:
+                    Z = eng.normal_from_host(rs.standard_normal((B, D)))
                 X = eng.sample(Z, mean_t, R, out=Xbuf)
             if shard:
                 from .dist import sharded_gsm_update, shard_bounds
@@ -221,7 +230,7 @@ class GSM:
 
     # ------------------------------------------------------------------------------
     def _fit_factor(self, key, mean, cov, batch_size, niter, nprint, verbose, monitor, rng, as_torch, shard=False,
-                    group=None):
+                    group=None, graph=None):
         """Factor-form fit loop (see ``fit(method="factor")``): same driver logic as gsm_numpy.py:77-129,
         state (mean, F) with cov = F^T F materialised only for the monitor and the return value.
         ``shard=True``: every rank draws the same Z, samples and scores only its batch_size/world rows, and the
@@ -259,28 +268,101 @@ class GSM:
         nprint = max(1, min(int(nprint), int(niter))) if niter > 0 else 1
         every = max(1, niter // nprint) if niter > 0 else 1
         reverts_seen = 0
-        i = 0
-        for i in range(niter + 1):
-            if verbose and i % every == 0:
-                print(f"Iteration {i} of {niter}")
-                r = eng.read_flag(n_rev)
-                if r > reverts_seen:
-                    print(f"Bad update for covariance matrix. Revert ({r - reverts_seen} since last print)")
-                    reverts_seen = r
-            if monitor is not None and i % monitor.checkpoint == 0:
-                monitor(i, state(), self.lp, key, nevals=nevals)
-                nevals = 0
-            Z = eng.normal(B, D, seed, i, out=Zbuf) if dev_rng else eng.normal_from_host(rs.standard_normal((B, D)))
-            X = eng.sample(Z[lo:hi], mean_t, F, out=Xbuf)         # only this rank's rows when sharded
-            vs = self.lp_g(X) if native else eng.asarray(self.lp_g(eng.to_numpy(X)))
+        # The draw stream does not depend on the state: the device draws come a BLOCK of KB iterations per launch.
+        KB = 16
+        Zblk = eng.empty(KB, B, D) if dev_rng else None
+        Gbuf = eng.empty(hi - lo, D)
+        # A block of KB iterations whose launches are all capturable (a `graph_safe` device score, the counter-based draw
+        # stream, no sharding collective) is captured ONCE into a hipGraph and replayed: at small D the Python / launch
+        # overhead of ~10 calls per iteration is the bound (D = 256, B = 8: 58 us eager against 50 us replayed).  Blocks
+        # that contain a print or a monitor call run eagerly, so the reference's cadence is untouched.
+        use_graph = (graph is not False and dev_rng and native and not shard and niter + 1 >= 3 * KB
+                     and bool(getattr(self.lp_g, "graph_safe", False)))
+        takes_out = False
+        if use_graph:
+            import inspect
+            try:
+                takes_out = "out" in inspect.signature(self.lp_g).parameters
+            except (TypeError, ValueError):
+                takes_out = False
+        gstate = {"graph": None}
+        if use_graph:
+            ctr = [torch.zeros(1, dtype=torch.int64, device=Zblk.device) for _ in range(2)]
+        state_bufs = [(mean_t, F), (mean_new, F_new)]
+
+        def iteration(Zi, a):
+            mu_a, F_a = state_bufs[a]
+            mu_b, F_b = state_bufs[1 - a]
+            X = eng.sample(Zi[lo:hi], mu_a, F_a, out=Xbuf)       # only this rank's rows when sharded
+            if native:
+                vs = self.lp_g(X, out=Gbuf) if takes_out else self.lp_g(X)
+            else:
+                vs = eng.asarray(self.lp_g(eng.to_numpy(X)))
             if shard:
-                sharded_gsm_factor_update(eng, Z, X, vs, mean_t, F, lo, group=group, out=(mean_new, F_new),
+                sharded_gsm_factor_update(eng, Zi, X, vs, mu_a, F_a, lo, group=group, out=(mu_b, F_b),
                                           flag=flag, n_reverts=n_rev)
             else:
-                eng.gsm_factor_update(Z, X, vs, mean_t, F, out=(mean_new, F_new), flag=flag, n_reverts=n_rev)
-            nevals += B
-            mean_t, mean_new = mean_new, mean_t             # the kernel already returned the reverted state
-            F, F_new = F_new, F                             # when its PD test failed: accept = pointer swap
+                eng.gsm_factor_update(Zi, X, vs, mu_a, F_a, out=(mu_b, F_b), flag=flag, n_reverts=n_rev)
+
+        def graph_block():
+            """KB iterations (KB even: the ping-pong state ends where it started) as one replayed graph; the draw counter
+            lives on the device and advances by KB per replay (two half-block draws on a ping-pong word pair)."""
+            if gstate["graph"] is None:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(side):
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(g, stream=side):
+                        for half in range(2):
+                            eng.normal_batch(KB // 2, B, D, seed, 0, out=Zblk[half * (KB // 2):(half + 1) * (KB // 2)],
+                                             call_in=ctr[half], call_out=ctr[1 - half])
+                            for k in range(KB // 2):
+                                iteration(Zblk[half * (KB // 2) + k], k & 1)
+                torch.cuda.current_stream().wait_stream(side)
+                gstate["graph"] = g
+            gstate["graph"].replay()
+
+        a = 0                                                   # which buffer pair holds the current state
+        i = 0
+        while i <= niter:
+            blk_end = min(i + KB, niter + 1)
+            eventful = any((verbose and j % every == 0) or (monitor is not None and j % monitor.checkpoint == 0)
+                           for j in range(i, blk_end))
+            # (the first block always runs eagerly: every kernel has been launched, and the context sized, before a capture)
+            if use_graph and i > 0 and a == 0 and not eventful and blk_end - i == KB:
+                ctr[0].fill_(i)                                 # (stream-ordered; the graph reads it on the device)
+                try:
+                    graph_block()
+                except Exception:                               # capture unsupported here: stay eager for the rest of the fit
+                    if gstate["graph"] is not None:
+                        raise
+                    use_graph = False
+                    torch.cuda.synchronize()
+                    continue
+                nevals += B * KB
+                i = blk_end
+                continue
+            if dev_rng:
+                eng.normal_batch(blk_end - i, B, D, seed, i, out=Zblk[:blk_end - i])
+            for j in range(i, blk_end):
+                mean_t, F = state_bufs[a]
+                if verbose and j % every == 0:
+                    print(f"Iteration {j} of {niter}")
+                    r = eng.read_flag(n_rev)
+                    if r > reverts_seen:
+                        print(f"Bad update for covariance matrix. Revert ({r - reverts_seen} since last print)")
+                        reverts_seen = r
+                if monitor is not None and j % monitor.checkpoint == 0:
+                    monitor(j, state(), self.lp, key, nevals=nevals)
+                    nevals = 0
+                Zi = Zblk[j - i] if dev_rng else eng.normal_from_host(rs.standard_normal((B, D)))
+                iteration(Zi, a)
+                nevals += B
+                a = 1 - a                                       # the kernel already returned the reverted state when its PD
+            i = blk_end                                         # test failed: accept = swapping the buffer pair
+        mean_t, F = state_bufs[a]
+        i = niter
         if verbose:
             r = eng.read_flag(n_rev)
             if r > reverts_seen:

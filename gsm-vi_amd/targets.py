@@ -12,10 +12,16 @@ import torch
 from .engine import get_engine
 
 
-def device_score(fn):
-    """Decorator: ``fn`` maps a float64 CUDA tensor (B,D) to a float64 CUDA tensor (B,D)."""
-    fn.device_native = True
-    return fn
+def device_score(fn=None, *, graph_safe=False):
+    """Decorator: ``fn`` maps a float64 CUDA tensor (B,D) to a float64 CUDA tensor (B,D).
+    ``@device_score(graph_safe=True)`` additionally promises that a call is capturable into a hipGraph (only stream-ordered
+    device work on the current stream, no host synchronisation, deterministic launch sequence): the factor-form fit then
+    replays blocks of iterations as one graph instead of issuing every launch from Python."""
+    def mark(f):
+        f.device_native = True
+        f.graph_safe = bool(graph_safe)
+        return f
+    return mark(fn) if fn is not None else mark
 
 
 def score_from_logp(logp):
@@ -44,9 +50,10 @@ class GaussianTarget:
         self.P = eng.asarray(0.5 * (P + P.T))
         self.D = int(self.mean.shape[0])
 
-        def lp_g(x):
-            return eng.gaussian_score(x, self.mean, self.P)
+        def lp_g(x, out=None):
+            return eng.gaussian_score(x, self.mean, self.P, out=out)
         lp_g.device_native = True
+        lp_g.graph_safe = True          # one capturable kernel launch, no allocation when `out` is given, no host work
         self.lp_g = lp_g
 
     def lp(self, x):

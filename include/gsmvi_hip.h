@@ -273,6 +273,16 @@ int gsmvi_randn_f64(gsmvi_ctx* ctx, void* stream, uint64_t seed, uint64_t call, 
                     uint32_t* raw);
 
 /*
+ * The draws of SEVERAL consecutive calls from one launch: out[c * n + i] = element i of draw number call0 + c, c < ncalls --
+ * bit-identical to ncalls calls of gsmvi_randn_f64 (a fit loop draws a block of iterations ahead: the stream does not depend
+ * on the state).  call_in_dev (device uint64, may be NULL) is added to call0 on the device; call_out_dev (may be NULL, must
+ * not alias call_in_dev) receives *call_in_dev + ncalls.  With the two words of a ping-pong pair a launch captured into a
+ * hipGraph advances through the stream on every replay.
+ */
+int gsmvi_randn_batch_f64(gsmvi_ctx* ctx, void* stream, uint64_t seed, uint64_t call0, int ncalls, int64_t n, double* out,
+                          const uint64_t* call_in_dev, uint64_t* call_out_dev);
+
+/*
  * Commit-or-revert (gsm_numpy.py:121-125): if *info_dev == 0 copy (mu_new, S_new) over (mu, S),
  * else leave them; *n_reverts_dev is incremented on a revert.  Device-side, no host sync.
  */

@@ -50,6 +50,13 @@ class OracleEngine:
             return out
         return z
 
+    def normal_batch(self, ncalls, B, D, seed, call0=0, out=None, call_in=None, call_out=None):
+        z = np.stack([orc.philox_randn(seed, call0 + c, B * D).reshape(B, D) for c in range(ncalls)])
+        if out is not None:
+            out[...] = z
+            return out
+        return z
+
     def gsm_update(self, X, G, mu0, S0, out=None, general=False):
         mu, S = orc.gsm_update_faithful(X, G, mu0, S0) if general else orc.gsm_update_batched(X, G, mu0, S0)
         if out is not None:
