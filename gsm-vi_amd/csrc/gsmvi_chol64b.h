@@ -16,10 +16,12 @@
 //              waits for the second) and then runs pivots 8-15.  ~25 instructions per pivot on the chain wave.
 //   trailing : the rank-16 updates A_ij -= R_ki^T R_kj of the remaining block rows on the MFMA pipe, all eight waves.
 // Two workgroup barriers per block step (8 in all instead of 64 + 3).
-// AUG = true factors the augmented matrix [A | I]: the same row operations turn the identity into W = R^-T (lower
+// AUG = 1 factors the augmented matrix [A | I]: the same row operations turn the identity into W = R^-T (lower
 // triangular, E[:, 64:128]), which the callers need as an explicit matrix (the triangular solves of the factor path and of
 // the blocked D x D Cholesky are MFMA products with W).  The augmented columns ride in the lanes of a second pair of panel
 // waves that repeats the diagonal block's arithmetic (bit-identical multipliers), and in the same trailing products.
+// AUG = 2: the right half E[:, 64:128] holds CALLER DATA C (dense, 64 columns) and comes out as R^-T C -- the block-row
+// solve of a larger blocked factorisation (k_chol128: [A11 | A12] -> [R11 | R12]); three pairs of panel waves.
 //
 // Layout: E[64][ES] in LDS, row-major; columns 0..63 = A (upper triangle + diagonal valid on entry; everything strictly
 // below the diagonal BLOCKS must be zero on entry if the caller wants a clean upper factor; padded with the identity
@@ -46,10 +48,10 @@ __device__ __forceinline__ double rsq_nr2(double d) {             // 1/sqrt(d)
     return y;
 }
 
-// LDS scratch of chol64_blk, per column set (AUG: two sets): [16][64] unscaled pivot rows, [8][64] pivot rows scaled by
-// 1/d_p (pivots 0-7, for the wave that owns rows 8-15), [2][8] row scales, the publish counter
+// LDS scratch of chol64_blk, per column set (AUG = 0 / 1 / 2: one / two / three sets): [16][64] unscaled pivot rows, [8][64]
+// pivot rows scaled by 1/d_p (pivots 0-7, for the wave that owns rows 8-15), [2][8] row scales, the publish counter
 #define CHOLB_SCRATCH_PER_SET (16 * 64 + 8 * 64 + 16 + 2)
-#define CHOLB_SCRATCH_DOUBLES(AUGV) (((AUGV) ? 2 : 1) * CHOLB_SCRATCH_PER_SET)
+#define CHOLB_SCRATCH_DOUBLES(AUGV) (((int)(AUGV) + 1) * CHOLB_SCRATCH_PER_SET)
 
 #ifndef CHOLB_STAMP
 #define CHOLB_STAMP(k) ((void)0)
@@ -171,32 +173,34 @@ __device__ __forceinline__ void cholb_panel_half(double* E, int k0, int col, boo
     CHOLB_PSTAMP(H, 12);
 }
 
-template <int ES, bool SEMIDEF, bool AUG>
+template <int ES, bool SEMIDEF, int AUG>
 __device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, int* sh_fail, bool allow_dep = true) {
     static_assert(ES % 2 == 0, "rows must stay 16-byte aligned");
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, g = l >> 4;
     const int nblk = (nb + 15) >> 4;
-    if (AUG) {
+    if (AUG == 1) {
         for (int e = tid; e < 64 * 64; e += 512) {
             const int i = e >> 6, q = e & 63;
             E[i * ES + 64 + q] = (i == q) ? 1.0 : 0.0;
         }
     }
     if (tid == 0) *sh_fail = 0x7fffffff;
-    if (tid < (AUG ? 2 : 1)) *reinterpret_cast<volatile int*>(scratch + tid * CHOLB_SCRATCH_PER_SET + 16 * 64 + 8 * 64 + 16) = 0;
+    if (tid < AUG + 1) *reinterpret_cast<volatile int*>(scratch + tid * CHOLB_SCRATCH_PER_SET + 16 * 64 + 8 * 64 + 16) = 0;
     __syncthreads();
 #pragma unroll 1
     for (int k = 0; k < nblk; ++k) {                              // block-uniform
         const int k0 = 16 * k;
         CHOLB_STAMP(1 + 2 * k);
-        // ---- panel: block row k, columns to the right of (and including) the diagonal block, plus the W columns 0 .. 16k+15.
-        // Column groups of 16 in this order: A-groups k .. nblk-1, then W-groups 0 .. k.  Column set 0 (waves 0, 1) takes
-        // the first four (lanes 0-15 = the diagonal block), set 1 (waves 2, 3; AUG) repeats the diagonal block in lanes
-        // 0-15 and takes groups 4 .. 6.  Even wave of a set: rows 0-7, odd wave: rows 8-15.
-        if (w < (AUG ? 4 : 2)) {
+        // ---- panel: block row k, columns to the right of (and including) the diagonal block, plus the right-half columns
+        // (W-groups 0 .. k for AUG = 1: the identity's fill-in; all four groups for AUG = 2).  Column groups of 16 in this
+        // order: A-groups k .. nblk-1, then the right-half groups.  Column set s (waves 2s, 2s+1) holds the diagonal block in
+        // lanes 0-15 (set 0 the original, the others bit-identical replicas) and the groups 3s+1 .. 3s+3 in lanes 16-63.
+        // Even wave of a set: rows 0-7, odd wave: rows 8-15.
+        const int nW = (AUG == 1) ? k + 1 : (AUG == 2 ? 4 : 0);
+        if (w < 2 * (AUG + 1)) {
             const int set = w >> 1;
-            const int nA = nblk - k, nslots = nA + (AUG ? k + 1 : 0);
-            const int slot = (set == 0) ? g : (g == 0 ? 0 : 3 + g);
+            const int nA = nblk - k, nslots = nA + nW;
+            const int slot = (g == 0) ? 0 : 3 * set + g;
             const bool active = slot < nslots;
             const bool aug = slot >= nA;
             const int col = (active ? (aug ? 64 + 16 * (slot - nA) : 16 * (k + slot)) : k0) + c;
@@ -204,11 +208,11 @@ __device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, i
             double* tr = ur + 16 * 64;
             double* rsb = tr + 8 * 64;
             volatile int* cnt = reinterpret_cast<volatile int*>(rsb + 16);
-            const bool wb = active && !(set == 1 && g == 0);
+            const bool wb = active && !(set > 0 && g == 0);
             if ((w & 1) == 0)
-                cholb_panel_half<ES, SEMIDEF, 0>(E, k0, col, wb, aug, slot == 0, ur, tr, rsb, cnt, 8 * k, allow_dep, sh_fail);
+                cholb_panel_half<ES, SEMIDEF, 0>(E, k0, col, wb, aug && AUG == 1, slot == 0, ur, tr, rsb, cnt, 8 * k, allow_dep, sh_fail);
             else
-                cholb_panel_half<ES, SEMIDEF, 1>(E, k0, col, wb, aug, slot == 0, ur, tr, rsb, cnt, 8 * k, allow_dep, sh_fail);
+                cholb_panel_half<ES, SEMIDEF, 1>(E, k0, col, wb, aug && AUG == 1, slot == 0, ur, tr, rsb, cnt, 8 * k, allow_dep, sh_fail);
         }
         __syncthreads();
         CHOLB_STAMP(2 + 2 * k);
@@ -216,7 +220,6 @@ __device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, i
         // ---- trailing: for every remaining block row i and every column group j (A-groups i .. nblk-1, W-groups 0 .. k):
         //   E[rows of i][group j] -= R_ki^T E[rows of k][group j],   K = 16 = four fp64 MFMA 16x16x4
         {
-            const int nW = AUG ? k + 1 : 0;
             int idx = w;
             for (int i = k + 1; i < nblk; ++i) {                  // wave-uniform walk over the flat product list
                 const int cnt = (nblk - i) + nW;

@@ -270,50 +270,97 @@ __global__ __launch_bounds__(256) void k_gsmf_small_a(int n, int B, const double
 }
 
 // ---- Cholesky A = R^T R of one n x n matrix, 64 < n <= 128, in ONE workgroup ----------------------------
-// The matrix lives in LDS ([128][130], identity beyond n).  2 x 2 blocks of 64: chol64 of A11, the block row
-// R12 = R11^-T A12 one column per quad of lanes (as k_potrf_panel), A22 -= R12^T R12 with a 4 x 4 register
-// tile per thread, chol64 of A22.  *info = 1-based index of the first bad pivot (0 = ok); R gets the upper
-// factor with a zero strictly-lower triangle.
+// 2 x 2 blocks of 64 on chol64_blk (gsmvi_chol64b.h): the first block row [A11 | A12] is factored AND solved in one call
+// (AUG = 2: the columns of A12 ride in the panel waves, [R11 | R12] comes out), A22 -= R12^T R12 runs on the MFMA pipe,
+// then A22 is factored.  Round 2 ran chol64_rows_s (one barrier per pivot) with a helper-wave row solve: 46 us per call.
+// *info = 1-based index of the first bad pivot (0 = ok); R gets the upper factor with a zero strictly-lower triangle.
+// SEMIDEF: the rank-revealing rule for Gram matrices (gsmvi_chol64.h), off when a diagonal entry reaches 2^32.
 template <bool SEMIDEF>
 __global__ __launch_bounds__(512) void k_chol128(int n, const double* __restrict__ A, double* __restrict__ R,
                                                  int* __restrict__ info) {
-    // Eight waves (round 2).  Waves 0-3 factor A11 (chol64_rows_s needs exactly 256 threads) while waves 4-7 solve the block
-    // row R12 = R11^-T A12 ONE PIVOT BEHIND: substitution step p needs row p of the factor and its pivot only, both published
-    // (unscaled, in LDS) by the barrier that opens pivot p; the helpers execute one barrier per step, as in k_potrf_step8.
-    // A22 -= R12^T R12 then runs on the MFMA pipe with all eight waves (it was a VALU loop of 64 x 16 FMAs per thread), and
-    // the second block is factored by waves 0-3 with the helpers matching its barriers.  55 -> ~37 us per call.
-    constexpr int MS = 130;
-    __shared__ __attribute__((aligned(16))) double M[128 * MS];
-    __shared__ double rinv[128];
-    __shared__ int sh_fail[2];
-    const int tid = threadIdx.x;
-    const bool team = tid < 256;
-    if (team) load_upper128(M, A, n);
-    if (tid < 128) rinv[tid] = 1.0;
+    constexpr int ES1 = 146, ES2 = 82;
+    __shared__ __attribute__((aligned(16))) double E1[64 * ES1];
+    __shared__ __attribute__((aligned(16))) double E2[64 * ES2];
+    __shared__ __attribute__((aligned(16))) double scr[CHOLB_SCRATCH_DOUBLES(2)];
+    __shared__ int sh_fail[2], sh_moderate;
+    const int tid = threadIdx.x, n2 = n - 64;
+    if (tid == 0) sh_moderate = 1;
     __syncthreads();
-    bool moderate = true;
-    if (SEMIDEF) {                                  // rounding-floor shift of the diagonal and the magnitude guard
-        if (tid == 0) sh_fail[1] = 1;
-        __syncthreads();
-        if (tid < 128) {
-            const double d = M[tid * MS + tid];
-            M[tid * MS + tid] = d - GSMVI_DEP_TOL * d;           // rounding floor of the row, see chol64_rows_s
-            if (!(d < 4294967296.0)) sh_fail[1] = 0;
+    for (int e0 = tid; e0 < 64 * 128; e0 += 512 * 8) {           // first block row: eight clamped loads per thread in flight
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 512 * u, i = e >> 7, q = e & 127;
+            v[u] = A[(size_t)i * n + (q < n ? q : n - 1)];
         }
-        __syncthreads();
-        moderate = sh_fail[1] != 0;
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 512 * u, i = e >> 7, q = e & 127;
+            double x = (q < n) ? v[u] : 0.0;
+            if (q < 64 && q < i) x = 0.0;                        // strictly-lower part of the diagonal block
+            if (SEMIDEF && q == i) {
+                if (!(x < 4294967296.0)) sh_moderate = 0;
+                x -= GSMVI_DEP_TOL * x;
+            }
+            E1[i * ES1 + q + (q >= 64 ? 0 : 0)] = x;             // columns 64..127 = A12 (zero beyond n)
+        }
     }
-    if (team) chol64_rows_s<MS, SEMIDEF>(M, rinv, 64, &sh_fail[0], moderate);
-    else chol128_helper_rowsolve<MS>(M);               // R12 = R11^-T A12, one pivot behind (gsmvi_chol64.h)
+    for (int e0 = tid; e0 < 64 * 64; e0 += 512 * 8) {            // A22, padded with the identity beyond n2
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 512 * u, i = e >> 6, q = e & 63;
+            v[u] = A[(size_t)(64 + (i < n2 ? i : n2 - 1)) * n + 64 + (q < n2 ? q : n2 - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 512 * u, i = e >> 6, q = e & 63;
+            double x = (i < n2 && q < n2) ? (q >= i ? v[u] : 0.0) : (i == q ? 1.0 : 0.0);
+            if (SEMIDEF && q == i && i < n2) {
+                if (!(x < 4294967296.0)) sh_moderate = 0;
+                x -= GSMVI_DEP_TOL * x;
+            }
+            E2[i * ES2 + q] = x;
+        }
+    }
     __syncthreads();
-    chol128_rank64_update<MS>(M);                       // A22 -= R12^T R12 on the MFMA pipe
+    const bool moderate = sh_moderate != 0;
+    chol64_blk<ES1, SEMIDEF, 2>(E1, scr, 64, &sh_fail[0], moderate);   // [A11 | A12] -> [R11 | R12]
+    {   // A22 -= R12^T R12 (upper 16 x 16 blocks, K = 64) on the MFMA pipe
+        const int w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+        for (int blk = w; blk < 10; blk += 8) {
+            int bi = 0, rem = blk;
+            while (rem >= 4 - bi) { rem -= 4 - bi; ++bi; }
+            const int bj = bi + rem;
+            const double* ap = E1 + ks * ES1 + 64 + 16 * bi + c;
+            const double* bp = E1 + ks * ES1 + 64 + 16 * bj + c;
+            double a[16], b[16], tv[4];
+#pragma unroll
+            for (int st = 0; st < 16; ++st) { a[st] = ap[4 * st * ES1]; b[st] = bp[4 * st * ES1]; }
+            double* tp = E2 + (16 * bi + ks) * ES2 + 16 * bj + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tv[r] = tp[4 * r * ES2];
+            v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int st = 0; st < 16; st += 2) {
+                acc0 = GSMVI_MFMA_F64(a[st], b[st], acc0);
+                acc1 = GSMVI_MFMA_F64(a[st + 1], b[st + 1], acc1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * bi + ks + 4 * r, j = 16 * bj + c;
+                if (j >= i) tp[4 * r * ES2] = tv[r] - (acc0[r] + acc1[r]);
+            }
+        }
+    }
     __syncthreads();
-    if (team) chol64_rows_s<MS, SEMIDEF>(M + 64 * MS + 64, rinv + 64, n - 64, &sh_fail[1], moderate);
-    else chol64_helper_idle<MS>(n - 64);
+    chol64_blk<ES2, SEMIDEF, 0>(E2, scr, n2, &sh_fail[1], moderate);
     for (int e = tid; e < n * n; e += 512) {
         const int i = e / n, j = e % n;
-        R[e] = (j >= i) ? M[i * MS + j] : 0.0;
+        double x = 0.0;
+        if (i < 64) x = (j >= i) ? E1[i * ES1 + j] : 0.0;        // [R11 | R12]: columns 64.. sit at E1[:, 64 + (j - 64)]
+        else if (j >= i) x = E2[(i - 64) * ES2 + (j - 64)];
+        R[e] = x;
     }
     if (tid == 0) *info = sh_fail[0] != 0 ? sh_fail[0] : (sh_fail[1] != 0 ? 64 + sh_fail[1] : 0);
 }
