@@ -144,7 +144,9 @@ static void ws_sizes(int D, int B, size_t* n_pp, size_t* n_sg, size_t* n_small, 
     *n_sg = (size_t)R * D * 4;                                 // SG + BaM factor panels
     // + the device chain of BaM's small matrix function: five padded 144 x 144 iterates, coefficients, BB (n <= 129)
     // + the factor path: a seventh R x R slot (finished Gram matrix) and the split-K slabs of the Gram product (+ 16 stamp words)
-    *n_small = (size_t)8 * R + (size_t)7 * R * R + 4096 + (size_t)5 * 144 * 144 + 64 + (size_t)129 * 129 + 64 +
+    // BaM's Newton-Schulz iterates: five ld x ld matrices, ld = 144 for B + 1 <= 129, else B + 1 rounded up to 16 (R/2 + 16 covers it)
+    const size_t ldb = (R / 2 + 16 > 144) ? (size_t)(R / 2 + 16) : 144;
+    *n_small = (size_t)8 * R + (size_t)7 * R * R + 4096 + (size_t)5 * ldb * ldb + 64 + ldb * ldb + 64 +
                (size_t)GSMVI_MAX_KC * R * R + 16;
 }
 

@@ -97,10 +97,11 @@ __global__ __launch_bounds__(256) void k_bam_stats(int D, int B, const double* _
 }
 
 // ---- Z = L^-1 (P + M1^T Vf), the new mean, and the signed factor panel -------------------------
-// One column of D per thread, 64 threads per block; the thread's Vf column and running Z column live
-// in LDS ([k][64], conflict-free).  M1, L are read with wave-uniform indices (scalar loads, L2 hits).
+// One column of D per thread, COLS threads per block (64 for n <= 160, 32 for n <= 320, 16 for n <= 640: the LDS of a CU
+// bounds n COLS); the thread's Vf column and running Z column live in LDS ([k][COLS], conflict-free).  M1, L are read with wave-uniform indices (scalar loads, L2 hits).
 // Ft = [Vf; Z], Fs = [Vf; -Z]  (rows n..2n-1 written here; rows 0..n-1 by k_bam_stats).
-__global__ __launch_bounds__(64) void k_bam_forward(int D, int n, const double* __restrict__ P,
+template <int COLS>
+__global__ __launch_bounds__(COLS) void k_bam_forward(int D, int n, const double* __restrict__ P,
                                                     const double* __restrict__ M1, const double* __restrict__ L,
                                                     const double* __restrict__ Ldinv,
                                                     const double* __restrict__ zg, const double* __restrict__ vg,
@@ -108,22 +109,22 @@ __global__ __launch_bounds__(64) void k_bam_forward(int D, int n, const double* 
                                                     const double* __restrict__ xbar, double reg,
                                                     double* __restrict__ Ft, double* __restrict__ Fs,
                                                     double* __restrict__ mu) {
-    extern __shared__ double sm[];                 // vf[n][64], z[n][64]
+    extern __shared__ double sm[];                 // vf[n][COLS], z[n][COLS]
     double* vf = sm;
-    double* z = sm + (size_t)n * 64;
+    double* z = sm + (size_t)n * COLS;
     const int t = threadIdx.x;
-    const int i = blockIdx.x * 64 + t;
+    const int i = blockIdx.x * COLS + t;
     const int ic = i < D ? i : D - 1;
-    for (int k = 0; k < n; ++k) vf[k * 64 + t] = Ft[(size_t)k * D + ic];
+    for (int k = 0; k < n; ++k) vf[k * COLS + t] = Ft[(size_t)k * D + ic];
     double dot_v = 0.0, dot_z = 0.0;
     for (int r = 0; r < n; ++r) {
         double a = P[(size_t)r * D + ic];
-        for (int k = 0; k < n; ++k) a += M1[(size_t)k * n + r] * vf[k * 64 + t];       // (M1^T vf)_r
-        for (int k = 0; k < r; ++k) a -= L[(size_t)r * n + k] * z[k * 64 + t];
+        for (int k = 0; k < n; ++k) a += M1[(size_t)k * n + r] * vf[k * COLS + t];       // (M1^T vf)_r
+        for (int k = 0; k < r; ++k) a -= L[(size_t)r * n + k] * z[k * COLS + t];
         const double zr = a * Ldinv[r];
-        z[r * 64 + t] = zr;
+        z[r * COLS + t] = zr;
         dot_z += zr * zg[r];
-        dot_v += vf[r * 64 + t] * vg[r];
+        dot_v += vf[r * COLS + t] * vg[r];
         if (i < D) {
             Ft[(size_t)(n + r) * D + i] = zr;
             Fs[(size_t)(n + r) * D + i] = -zr;
@@ -440,8 +441,9 @@ __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, cons
         }                                                                     \
     } while (0)
 
-int gsmvi_bam_small_device(hipStream_t st, int n, double reg, const double* Nd, const double* M1, const double* N0,
-                           double* scratch, double* Ld, double* Upk, int* info_dev, int* hint_host, int force_kenq);
+int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* Nd, const double* M1,
+                           const double* N0, double* scratch, double* Ld, double* Upk, int* info_dev, int* hint_host,
+                           int force_kenq);
 int gsmvi_bam_small_nmax();
 size_t gsmvi_bam_small_scratch_doubles(int n);
 
@@ -462,7 +464,7 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     double* Ld = M1 + (size_t)n * n;               // n x n, then Ldinv (n), zg (n), vg (n)
 
     if (n > gsmvi_bam_small_nmax()) {              // checked before anything is enqueued
-        gsmvi_set_error("%s: %s", "gsmvi_bam_update_f64", "B + 1 exceeds the device matrix-function chain");
+        gsmvi_set_error("%s: %s", "gsmvi_bam_update_f64", "B + 1 > 640 exceeds the device chain (LDS of the forward substitution)");
         return GSMVI_ERR_UNSUPPORTED;
     }
     hipLaunchKernelGGL(k_bam_stats, dim3((D + 63) / 64), dim3(256), 0, st, D, B, X, ldx, G, ldg, mu0, reg, xbar,
@@ -490,11 +492,11 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
             else
                 ctx->bam_hint_host = nullptr;
         }
-        if ((rc = gsmvi_bam_small_device(st, n, reg, Nd, M1, N0, scratch, Ld, Upk, info_dev ? info_dev : ctx->ints + 8,
+        if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, Upk, info_dev ? info_dev : ctx->ints + 8,
                                          ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq)))
             return rc;
     }
-    const bool lanes16 = n <= BAMF_NMAX;
+    const bool lanes16 = n <= 129;              // the sizes whose Cholesky kernel (k_bam_chol_out) also emits the packed rows
     if (lanes16) {
         // T1 = M1^T Vf into rows n..2n-1 of Fs, then the 16-lanes-per-column substitution
         if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, M1T, n, nullptr, 1.0, Ft, D, ctx->pp, &kc))) return rc;
@@ -502,8 +504,9 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
         hipLaunchKernelGGL(k_bam_forward16, dim3((D + 15) / 16), dim3(256), 0, st, D, n, P, Upk, Ldinv, Ldinv + n,
                            Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu);
     } else {
-        hipLaunchKernelGGL(k_bam_forward, dim3((D + 63) / 64), dim3(64), sizeof(double) * 2 * n * 64, st, D, n, P, M1,
-                           Ld, Ldinv, Ldinv + n, Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu);
+#define BFW(CV) hipLaunchKernelGGL(k_bam_forward<CV>, dim3((D + CV - 1) / CV), dim3(CV), sizeof(double) * 2 * n * CV, st, D, n, P, M1, Ld, Ldinv, Ldinv + n, Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu)
+        if (n <= 160) BFW(64); else if (n <= 320) BFW(32); else BFW(16);
+#undef BFW
     }
     const int nt = (D + 63) / 64;
     if (!ctx->tune_no_fast && D % 64 == 0 && n2 <= 288) {
@@ -524,6 +527,13 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
 }
 
 hipError_t gsmvi_bam_prepare() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_bam_forward),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bam_forward<64>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bam_forward<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bam_forward<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+    return e;
 }

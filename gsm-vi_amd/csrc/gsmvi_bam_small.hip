@@ -24,8 +24,10 @@
 #include "gsmvi_chol64.h"
 #include "../../include/gsmvi_hip.h"
 
-#define BAMS_NMAX 129
-#define BAMS_LD 144                  // padded leading dimension of the iteration matrices (9 blocks of 16)
+#define BAMS_NMAX 129                // largest n of the one-workgroup Cholesky k_bam_chol_out; above it: blocked potrf + k_bam_post_big
+#define BAMS_NBIG 640                // largest n altogether (LDS of the forward substitution kernel, 16 columns per workgroup)
+#define BAMS_LD 144                  // padded leading dimension of the iteration matrices for n <= 129 (9 blocks of 16);
+                                     // larger n: n rounded up to 16 (passed to the kernels as `ld`)
 #define BAMS_KMAX 32                 // launches enqueued; k* <= BAMS_KMAX is checked on the device (else flagged)
 // coef layout (doubles): [0..KMAX) c_k^2, [40] k*, [41] s, [42] 1 if s is not finite or the bound did not close in KMAX steps
 // (KMAX = 32 scaled steps cover cond(A) up to ~1e20, beyond what fp64 can represent in N + I/4)
@@ -34,7 +36,7 @@
 // Every workgroup sums the diagonal itself (n loads) and fills its share of Y0 / Z0; workgroup 0 also runs the scalar
 // recurrence.  A NaN / inf anywhere in N needs no flag of its own: it propagates through the products into BB, where
 // k_bam_chol_out rejects it.
-__global__ __launch_bounds__(256) void k_bam_ns_prep(int n, const double* __restrict__ Nm, double* __restrict__ Y,
+__global__ __launch_bounds__(256) void k_bam_ns_prep(int n, int ld, const double* __restrict__ Nm, double* __restrict__ Y,
                                                      double* __restrict__ Z, double* __restrict__ coef,
                                                      int* __restrict__ hint_host) {
     __shared__ double red[4];
@@ -46,8 +48,8 @@ __global__ __launch_bounds__(256) void k_bam_ns_prep(int n, const double* __rest
     __syncthreads();
     const double s = (red[0] + red[1]) + (red[2] + red[3]);
     const double sinv = 1.0 / s;
-    for (int e = blockIdx.x * 256 + tid; e < BAMS_LD * BAMS_LD; e += gridDim.x * 256) {
-        const int i = e / BAMS_LD, j = e % BAMS_LD;
+    for (int e = blockIdx.x * 256 + tid; e < ld * ld; e += gridDim.x * 256) {
+        const int i = e / ld, j = e % ld;
         const bool in = i < n && j < n;
         const double v = in ? Nm[(size_t)i * n + j] + (i == j ? 0.25 : 0.0) : 0.0;
         Y[e] = v * sinv;
@@ -82,41 +84,44 @@ __global__ __launch_bounds__(256) void k_bam_ns_prep(int n, const double* __rest
 // 32-B segments, the matrices are L2-resident), B by rows of 16 consecutive columns (128-B segments).
 template <int MODE>
 __device__ __forceinline__ void bams_block(const double* __restrict__ A, const double* __restrict__ Bm,
-                                           double* __restrict__ Out, int blk, int nb, int nk, double c2, double scale) {
-    // one WORKGROUP per 16 x 16 block; wave w takes the k-steps w, w + 4, ... (at most 9), every load of the wave in one
-    // batch; the four partial blocks are summed through LDS in a fixed order
+                                           double* __restrict__ Out, int blk, int nb, int nk, double c2, double scale,
+                                           int ld) {
+    // one WORKGROUP per 16 x 16 block; wave w takes the k-steps w, w + 4, ... in batches of nine (one batch for ld = 144),
+    // every load of a batch issued together; the four partial blocks are summed through LDS in a fixed order
     __shared__ double red[4 * 256];
     const int i0 = (blk / nb) * 16, j0 = (blk % nb) * 16;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, cc = l & 15, ks = l >> 4;
-    double a[9], b[9];
-#pragma unroll
-    for (int u = 0; u < 9; ++u) {
-        const int st = w + 4 * u;
-        const int k = 4 * st + ks;
-        const int kc = k < BAMS_LD ? k : BAMS_LD - 1;
-        const double av = A[(size_t)(i0 + cc) * BAMS_LD + kc];
-        const double bv = Bm[(size_t)kc * BAMS_LD + j0 + cc];
-        a[u] = MODE == 2 ? ((kc == i0 + cc ? 1.5 : 0.0) - 0.5 * c2 * av) : av;
-        b[u] = MODE == 1 ? ((kc == j0 + cc ? 1.5 : 0.0) - 0.5 * c2 * bv) : bv;
-        if (st >= nk) { a[u] = 0.0; b[u] = 0.0; }
-    }
     v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int u0 = 0; w + 4 * u0 < nk; u0 += 9) {
+        double a[9], b[9];
 #pragma unroll
-    for (int u = 0; u + 1 < 9; u += 2) {
-        acc0 = GSMVI_MFMA_F64(a[u], b[u], acc0);
-        acc1 = GSMVI_MFMA_F64(a[u + 1], b[u + 1], acc1);
+        for (int u = 0; u < 9; ++u) {
+            const int st = w + 4 * (u0 + u);
+            const int k = 4 * st + ks;
+            const int kc = k < ld ? k : ld - 1;
+            const double av = A[(size_t)(i0 + cc) * ld + kc];
+            const double bv = Bm[(size_t)kc * ld + j0 + cc];
+            a[u] = MODE == 2 ? ((kc == i0 + cc ? 1.5 : 0.0) - 0.5 * c2 * av) : av;
+            b[u] = MODE == 1 ? ((kc == j0 + cc ? 1.5 : 0.0) - 0.5 * c2 * bv) : bv;
+            if (st >= nk) { a[u] = 0.0; b[u] = 0.0; }
+        }
+#pragma unroll
+        for (int u = 0; u + 1 < 9; u += 2) {
+            acc0 = GSMVI_MFMA_F64(a[u], b[u], acc0);
+            acc1 = GSMVI_MFMA_F64(a[u + 1], b[u + 1], acc1);
+        }
+        acc0 = GSMVI_MFMA_F64(a[8], b[8], acc0);
     }
-    acc0 = GSMVI_MFMA_F64(a[8], b[8], acc0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[w * 256 + (ks + 4 * r) * 16 + cc] = acc0[r] + acc1[r];
     __syncthreads();
     const int t = threadIdx.x;                               // element (t >> 4, t & 15) of the block
     const double v = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
-    Out[(size_t)(i0 + (t >> 4)) * BAMS_LD + j0 + (t & 15)] = scale * v;
+    Out[(size_t)(i0 + (t >> 4)) * ld + j0 + (t & 15)] = scale * v;
 }
 
 // M = Z Y (the scaling enters through T in the step kernel)
-__global__ __launch_bounds__(256) void k_bam_ns_zy(int n, int k, const double* __restrict__ Ya,
+__global__ __launch_bounds__(256) void k_bam_ns_zy(int n, int ld, int k, const double* __restrict__ Ya,
                                                    const double* __restrict__ Za, const double* __restrict__ Yb,
                                                    const double* __restrict__ Zb, double* __restrict__ Mm,
                                                    const double* __restrict__ coef) {
@@ -124,11 +129,11 @@ __global__ __launch_bounds__(256) void k_bam_ns_zy(int n, int k, const double* _
     const double* Y = (k & 1) ? Yb : Ya;
     const double* Z = (k & 1) ? Zb : Za;
     const int nb = (n + 15) >> 4, nk = (n + 3) >> 2;
-    bams_block<0>(Z, Y, Mm, blockIdx.x, nb, nk, 0.0, 1.0);
+    bams_block<0>(Z, Y, Mm, blockIdx.x, nb, nk, 0.0, 1.0, ld);
 }
 
 // Y' = c Y T and Z' = c T Z (in THIS order), T = 1.5 I - 0.5 c^2 M.  Blocks [0, nb^2) -> Y', the rest -> Z'.
-__global__ __launch_bounds__(256) void k_bam_ns_step(int n, int k, double* __restrict__ Ya, double* __restrict__ Za,
+__global__ __launch_bounds__(256) void k_bam_ns_step(int n, int ld, int k, double* __restrict__ Ya, double* __restrict__ Za,
                                                      double* __restrict__ Yb, double* __restrict__ Zb,
                                                      const double* __restrict__ Mm, const double* __restrict__ coef) {
     if ((double)k >= coef[40] || coef[42] != 0.0) return;
@@ -138,8 +143,8 @@ __global__ __launch_bounds__(256) void k_bam_ns_step(int n, int k, double* __res
     double* Yo = (k & 1) ? Ya : Yb;
     double* Zo = (k & 1) ? Za : Zb;
     const int nb = (n + 15) >> 4, nk = (n + 3) >> 2;
-    if ((int)blockIdx.x < nb * nb) bams_block<1>(Yi, Mm, Yo, blockIdx.x, nb, nk, c2, c);             // Y' = c Y T
-    else bams_block<2>(Mm, Zi, Zo, blockIdx.x - nb * nb, nb, nk, c2, c);                            // Z' = c T Z
+    if ((int)blockIdx.x < nb * nb) bams_block<1>(Yi, Mm, Yo, blockIdx.x, nb, nk, c2, c, ld);         // Y' = c Y T
+    else bams_block<2>(Mm, Zi, Zo, blockIdx.x - nb * nb, nb, nk, c2, c, ld);                        // Z' = c T Z
 }
 
 // ---- n <= 48: the whole iteration in ONE workgroup, matrices in LDS, exactly k* steps --------------------------------
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(576) void k_bam_ns_small(int n, const double* __res
 // correctness; normally the kernel returns at once.  Same products, same order, same ping-pong parity.
 template <int MODE>
 __device__ __forceinline__ void bams_block_wave(const double* A, const double* Bm, double* Out, int blk, int nb, int nk,
-                                                double c2, double scale) {
+                                                double c2, double scale, int ld) {
     const int i0 = (blk / nb) * 16, j0 = (blk % nb) * 16;
     const int l = threadIdx.x & 63, cc = l & 15, ks = l >> 4;
     v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
@@ -269,9 +274,9 @@ __device__ __forceinline__ void bams_block_wave(const double* A, const double* B
 #pragma unroll
         for (int u = 0; u < 12; ++u) {
             const int k = 4 * (s0 + u) + ks;
-            const int kc = k < BAMS_LD ? k : BAMS_LD - 1;
-            const double av = A[(size_t)(i0 + cc) * BAMS_LD + kc];
-            const double bv = Bm[(size_t)kc * BAMS_LD + j0 + cc];
+            const int kc = k < ld ? k : ld - 1;
+            const double av = A[(size_t)(i0 + cc) * ld + kc];
+            const double bv = Bm[(size_t)kc * ld + j0 + cc];
             a[u] = MODE == 2 ? ((kc == i0 + cc ? 1.5 : 0.0) - 0.5 * c2 * av) : av;
             b[u] = MODE == 1 ? ((kc == j0 + cc ? 1.5 : 0.0) - 0.5 * c2 * bv) : bv;
             if (s0 + u >= nk) { a[u] = 0.0; b[u] = 0.0; }
@@ -283,10 +288,10 @@ __device__ __forceinline__ void bams_block_wave(const double* A, const double* B
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Out[(size_t)(i0 + ks + 4 * r) * BAMS_LD + j0 + cc] = scale * (acc0[r] + acc1[r]);
+    for (int r = 0; r < 4; ++r) Out[(size_t)(i0 + ks + 4 * r) * ld + j0 + cc] = scale * (acc0[r] + acc1[r]);
 }
 
-__global__ __launch_bounds__(1024) void k_bam_ns_tail(int n, int kenq, double* Ya, double* Za, double* Yb, double* Zb,
+__global__ __launch_bounds__(1024) void k_bam_ns_tail(int n, int ld, int kenq, double* Ya, double* Za, double* Yb, double* Zb,
                                                       double* Mm, const double* coef) {
     const int kstar = (int)coef[40];
     if (kenq >= kstar || coef[42] != 0.0) return;            // the usual case: nothing left to do
@@ -297,12 +302,12 @@ __global__ __launch_bounds__(1024) void k_bam_ns_tail(int n, int kenq, double* Y
         double* Zi = (k & 1) ? Zb : Za;
         double* Yo = (k & 1) ? Ya : Yb;
         double* Zo = (k & 1) ? Za : Zb;
-        for (int blk = w; blk < nb * nb; blk += 16) bams_block_wave<0>(Zi, Yi, Mm, blk, nb, nk, 0.0, 1.0);
+        for (int blk = w; blk < nb * nb; blk += 16) bams_block_wave<0>(Zi, Yi, Mm, blk, nb, nk, 0.0, 1.0, ld);
         __threadfence_block();
         __syncthreads();
         for (int blk = w; blk < 2 * nb * nb; blk += 16) {
-            if (blk < nb * nb) bams_block_wave<1>(Yi, Mm, Yo, blk, nb, nk, c2, c);
-            else bams_block_wave<2>(Mm, Zi, Zo, blk - nb * nb, nb, nk, c2, c);
+            if (blk < nb * nb) bams_block_wave<1>(Yi, Mm, Yo, blk, nb, nk, c2, c, ld);
+            else bams_block_wave<2>(Mm, Zi, Zo, blk - nb * nb, nb, nk, c2, c, ld);
         }
         __threadfence_block();
         __syncthreads();
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(1024) void k_bam_ns_tail(int n, int kenq, double* Y
 }
 
 // BB = N + I/2 + sqrt(s) sym(Y_final)   (n x n, row-major, ld n)
-__global__ __launch_bounds__(256) void k_bam_ns_bb(int n, const double* __restrict__ Nm, const double* __restrict__ Ya,
+__global__ __launch_bounds__(256) void k_bam_ns_bb(int n, int ld, const double* __restrict__ Nm, const double* __restrict__ Ya,
                                                    const double* __restrict__ Yb, const double* __restrict__ coef,
                                                    double* __restrict__ BBg) {
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(256) void k_bam_ns_bb(int n, const double* __restri
     const int kstar = (int)coef[40];
     const double* Y = (kstar & 1) ? Yb : Ya;                 // iterate k* lives in buffer k* & 1
     const double rs = sqrt(coef[41]);
-    const double y = 0.5 * (Y[(size_t)i * BAMS_LD + j] + Y[(size_t)j * BAMS_LD + i]);
+    const double y = 0.5 * (Y[(size_t)i * ld + j] + Y[(size_t)j * ld + i]);
     BBg[e] = (coef[42] != 0.0) ? __longlong_as_double(0x7ff8000000000000LL) : Nm[e] + (i == j ? 0.5 : 0.0) + rs * y;
 }
 
@@ -470,9 +475,82 @@ __global__ __launch_bounds__(512) void k_bam_chol_out(int n, double reg, const d
     }
 }
 
-int gsmvi_bam_small_device(hipStream_t st, int n, double reg, const double* Nd, const double* M1, const double* N0,
-                           double* scratch, double* Ld, double* Upk, int* info_dev, int* hint_host, int force_kenq) {
-    const size_t LL = (size_t)BAMS_LD * BAMS_LD;
+// ---- n > 129: the small outputs from the blocked Cholesky factor of BB (gsmvi_potrf_impl: BB = R^T R) ------------------
+// One workgroup: Ld = R^T (lower), Ldinv, vg = Vf gbar = M1[:, n-1] / r1s, zg = L^-1 (P gbar + M1^T vg) by a column-oriented
+// forward substitution (row pp of R is contiguous; eight rows' loads in flight).  A failed factorisation (or a NaN in it)
+// poisons every output, as k_bam_chol_out does.
+__global__ __launch_bounds__(1024) void k_bam_post_big(int n, double reg, const double* __restrict__ Rb,
+                                                       const int* __restrict__ info_p, const double* __restrict__ M1,
+                                                       const double* __restrict__ N0, double* __restrict__ Ld,
+                                                       int* __restrict__ info) {
+    __shared__ double sc[BAMS_NBIG + 8], av[BAMS_NBIG + 8];
+    __shared__ int sh_bad;
+    const int tid = threadIdx.x;
+    double* Ldinv = Ld + (size_t)n * n;
+    double* zg = Ldinv + n;
+    double* vg = zg + n;
+    if (tid == 0) sh_bad = (*info_p != 0) ? 1 : 0;
+    const double r1s = sqrt(reg / (1.0 + reg));
+    for (int p = tid; p < n; p += 1024) sc[p] = M1[(size_t)p * n + (n - 1)] / r1s;
+    __syncthreads();
+    for (int p = tid; p < n; p += 1024) {
+        double a0 = N0[(size_t)p * n + (n - 1)] / r1s, a1 = 0.0;
+        int kk = 0;
+        for (; kk + 8 <= n; kk += 8) {
+            double m[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m[u] = M1[(size_t)(kk + u) * n + p];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { a0 += m[u] * sc[kk + u]; a1 += m[u + 1] * sc[kk + u + 1]; }
+        }
+        for (; kk < n; ++kk) a0 += M1[(size_t)kk * n + p] * sc[kk];
+        av[p] = a0 + a1;
+        const double dg = Rb[(size_t)p * n + p];
+        if (!(dg > 0.0) || !(dg < 1.7976931348623157e308)) sh_bad = 1;
+    }
+    __syncthreads();
+    const int bad = sh_bad;
+    if (tid == 0) *info = bad;
+    if (bad) {
+        const double qn = __longlong_as_double(0x7ff8000000000000LL);
+        for (size_t e = tid; e < (size_t)n * n + 3 * n; e += 1024) Ld[e] = qn;
+        return;
+    }
+    for (int e = tid; e < n * n; e += 1024) {
+        const int i = e / n, j = e % n;                      // L[i][j] = R[j][i], j <= i
+        Ld[e] = (j <= i) ? Rb[(size_t)j * n + i] : 0.0;
+    }
+    for (int p = tid; p < n; p += 1024) { Ldinv[p] = 1.0 / Rb[(size_t)p * n + p]; vg[p] = sc[p]; }
+    // zg = L^-1 a: thread p owns a[p] (n <= 1024 threads... n <= BAMS_NBIG); step pp needs R[pp][p], p > pp
+    double mine = (tid < n) ? av[tid] : 0.0;
+    const int pc = tid < n ? tid : n - 1;
+    for (int p0 = 0; p0 < n; p0 += 8) {
+        double r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = Rb[(size_t)(p0 + u < n ? p0 + u : n - 1) * n + pc];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int pp = p0 + u;
+            if (pp < n) {                                    // block-uniform
+                if (tid == pp) av[pp] = mine / r[u];         // r[u] = R[pp][pp] in thread pp
+                __syncthreads();
+                const double zk = av[pp];
+                if (tid > pp && tid < n) mine -= r[u] * zk;
+                __syncthreads();
+            }
+        }
+    }
+    if (tid < n) zg[tid] = av[tid];
+}
+
+int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
+                     int* info_dev);
+
+int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* Nd, const double* M1,
+                           const double* N0, double* scratch, double* Ld, double* Upk, int* info_dev, int* hint_host,
+                           int force_kenq) {
+    const int ld = n <= BAMS_NMAX ? BAMS_LD : ((n + 15) / 16) * 16;
+    const size_t LL = (size_t)ld * ld;
     double* Ya = scratch;
     double* Za = Ya + LL;
     double* Yb = Za + LL;
@@ -492,17 +570,28 @@ int gsmvi_bam_small_device(hipStream_t st, int n, double reg, const double* Nd, 
             if (h > 0 && h + 2 < BAMS_KMAX) kenq = h + 2;
         }
         if (force_kenq > 0 && force_kenq < BAMS_KMAX) kenq = force_kenq;       // tests: exercise the safety net
-        hipLaunchKernelGGL(k_bam_ns_prep, dim3(27), dim3(256), 0, st, n, Nd, Ya, Za, coef, hint_host);
+        hipLaunchKernelGGL(k_bam_ns_prep, dim3(27), dim3(256), 0, st, n, ld, Nd, Ya, Za, coef, hint_host);
         const int nb = (n + 15) / 16;
         for (int k = 0; k < kenq; ++k) {
-            hipLaunchKernelGGL(k_bam_ns_zy, dim3(nb * nb), dim3(256), 0, st, n, k, Ya, Za, Yb, Zb, Mm, coef);
-            hipLaunchKernelGGL(k_bam_ns_step, dim3(2 * nb * nb), dim3(256), 0, st, n, k, Ya, Za, Yb, Zb, Mm, coef);
+            hipLaunchKernelGGL(k_bam_ns_zy, dim3(nb * nb), dim3(256), 0, st, n, ld, k, Ya, Za, Yb, Zb, Mm, coef);
+            hipLaunchKernelGGL(k_bam_ns_step, dim3(2 * nb * nb), dim3(256), 0, st, n, ld, k, Ya, Za, Yb, Zb, Mm, coef);
         }
         if (kenq < BAMS_KMAX)
-            hipLaunchKernelGGL(k_bam_ns_tail, dim3(1), dim3(1024), 0, st, n, kenq, Ya, Za, Yb, Zb, Mm, coef);
-        hipLaunchKernelGGL(k_bam_ns_bb, dim3((n * n + 255) / 256), dim3(256), 0, st, n, Nd, Ya, Yb, coef, BBg);
+            hipLaunchKernelGGL(k_bam_ns_tail, dim3(1), dim3(1024), 0, st, n, ld, kenq, Ya, Za, Yb, Zb, Mm, coef);
+        hipLaunchKernelGGL(k_bam_ns_bb, dim3((n * n + 255) / 256), dim3(256), 0, st, n, ld, Nd, Ya, Yb, coef, BBg);
     }
-    hipLaunchKernelGGL(k_bam_chol_out, dim3(1), dim3(512), 0, st, n, reg, BBg, M1, N0, Ld, Upk, info_dev);
+    if (n <= BAMS_NMAX) {
+        hipLaunchKernelGGL(k_bam_chol_out, dim3(1), dim3(512), 0, st, n, reg, BBg, M1, N0, Ld, Upk, info_dev);
+    } else {
+        // beyond the one-workgroup Cholesky: the blocked multi-workgroup factorisation of the D x D path (its workspace is
+        // the idle panel-partial slab), then the small outputs in one workgroup.  Upk is not produced: these sizes take
+        // the generic forward-substitution kernel, which reads Ld.
+        double* Rb = Mm;                                     // the iterates are dead once BB exists
+        int* info_p = ctx->ints + 9;
+        int rc = gsmvi_potrf_impl(ctx, st, n, BBg, n, Rb, n, info_p);
+        if (rc != GSMVI_OK) return rc;
+        hipLaunchKernelGGL(k_bam_post_big, dim3(1), dim3(1024), 0, st, n, reg, Rb, info_p, M1, N0, Ld, info_dev);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         gsmvi_set_error("BaM small-matrix launch failed: %s%s", hipGetErrorString(e), "");
@@ -511,5 +600,8 @@ int gsmvi_bam_small_device(hipStream_t st, int n, double reg, const double* Nd, 
     return GSMVI_OK;
 }
 
-int gsmvi_bam_small_nmax() { return BAMS_NMAX; }
-size_t gsmvi_bam_small_scratch_doubles(int n) { return (size_t)5 * BAMS_LD * BAMS_LD + 64 + (size_t)n * n; }
+int gsmvi_bam_small_nmax() { return BAMS_NBIG; }
+size_t gsmvi_bam_small_scratch_doubles(int n) {
+    const size_t ld = n <= BAMS_NMAX ? BAMS_LD : ((n + 15) / 16) * 16;
+    return (size_t)5 * ld * ld + 64 + (size_t)n * n;
+}

@@ -233,11 +233,13 @@ __device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, i
                     double* tp = E + (16 * i + g) * ES + gcol + c;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) tv[r] = tp[4 * r * ES];
-                    v4d acc = {0.0, 0.0, 0.0, 0.0};
+                    v4d acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};   // two chains of two
+                    acc = GSMVI_MFMA_F64(a[0], b[0], acc);
+                    acc1 = GSMVI_MFMA_F64(a[1], b[1], acc1);
+                    acc = GSMVI_MFMA_F64(a[2], b[2], acc);
+                    acc1 = GSMVI_MFMA_F64(a[3], b[3], acc1);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) acc = GSMVI_MFMA_F64(a[s], b[s], acc);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) tp[4 * r * ES] = tv[r] - acc[r];
+                    for (int r = 0; r < 4; ++r) tp[4 * r * ES] = tv[r] - (acc[r] + acc1[r]);
                     idx += 8;
                 }
                 idx -= cnt;

@@ -643,7 +643,7 @@ __global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double
     // one output block: acc = sum over the k-blocks kb0 .. nblk-1 of A(ib-rows, k) B(k, jb-cols); fa(k) / fb(k) fetch the
     // operand values of this lane for contraction index k
     auto block_chain = [&](int kb0, auto fa, auto fb) {
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        v4d acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};   // two chains: a dependent fp64 MFMA waits ~2x its issue time
         double a[4], b[4], an[4], bn[4];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) { a[s4] = fa(16 * kb0 + 4 * s4 + ks); b[s4] = fb(16 * kb0 + 4 * s4 + ks); }
@@ -653,10 +653,15 @@ __global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double
                 for (int s4 = 0; s4 < 4; ++s4) { an[s4] = fa(16 * (kb + 1) + 4 * s4 + ks); bn[s4] = fb(16 * (kb + 1) + 4 * s4 + ks); }
             }
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) acc = GSMVI_MFMA_F64(a[s4], b[s4], acc);
+            for (int s4 = 0; s4 < 4; s4 += 2) {
+                acc = GSMVI_MFMA_F64(a[s4], b[s4], acc);
+                acc1 = GSMVI_MFMA_F64(a[s4 + 1], b[s4 + 1], acc1);
+            }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) { a[s4] = an[s4]; b[s4] = bn[s4]; }
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += acc1[r];
         return acc;
     };
     // W <- W S (column operations on the right half of E1; the A' phase below reads only the left half, so both share this
@@ -879,6 +884,148 @@ __global__ __launch_bounds__(256) void k_gsmf_mean(int D, int B, const double* _
     mu[j] = (*bad) ? mu0[j] : mu0[j] + ((s0 + s1) + (s2 + s3));
 }
 
+// ---- rank-n update with the skinny product folded in (n = 32 NP <= 64, D % 64 == 0): F = F0 + Rt1^T (K'' Tm1) ----------------
+// k_gsmf_update_fast needs Fs = K'' Tm1 from a launch of its own (a 64-strip product, ~6 us + a launch boundary at D = 1024).
+// Here every 64 x 64 tile workgroup forms ITS 64 columns of Fs itself: K'' (n x n) and the tile's columns of Tm1 = [X - mu; V Fm]
+// go to LDS (the V Fm rows summed from the split-K slabs of that product while they are loaded), Fs_tile = K'' Tm1_tile is 32
+// MFMAs per wave, and the rank-n update reads it from LDS.  The product is repeated by the D / 64 workgroups of a tile
+// column -- 16 x 0.5 MFLOP at D = 1024, cheap beside a dependent launch.  Tile row 0 also writes the mean, workgroup 0 counts
+// the revert; *bad => F = F0, mu = mu0.
+template <int NP>
+__global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const double* __restrict__ Rt,
+                                                        const double* __restrict__ Kmat, const double* __restrict__ Tm,
+                                                        const double* __restrict__ vf_slabs, int kcv,
+                                                        const double* __restrict__ F0, int ldf0, double* __restrict__ F,
+                                                        int ldf, const double* __restrict__ coef,
+                                                        const double* __restrict__ mu0, double* __restrict__ mu,
+                                                        const int* __restrict__ bad, int* __restrict__ n_reverts) {
+    constexpr int N = 32 * NP, RS = 80, KS = N + 2;
+    __shared__ __attribute__((aligned(16))) double bufA[N * RS];      // Tm1 tile [k][64 cols], later the Rt1 tile
+    __shared__ __attribute__((aligned(16))) double bufB[N * RS];      // Fs tile
+    __shared__ __attribute__((aligned(16))) double bufK[N * KS];      // K''
+    __shared__ double msm[8 * 64];
+    const int nt = D >> 6;
+    const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
+    const int I0 = ti * 64, J0 = tj * 64;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+    const int wr = w >> 1, wc = w & 1;
+    const int skip = *bad;
+    if (blockIdx.x == 0 && tid == 0 && skip && n_reverts) *n_reverts += 1;
+    // ---- all global loads of the first phase: F0 tile (accumulator layout), K'', the Tm1 tile, the Rt1 tile ----
+    double f0[2][4];
+    const size_t frow = (size_t)(I0 + 16 * wr + ks);
+    const int fcol = J0 + 32 * wc + c;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f0[blk][r] = F0[(frow + 4 * r) * ldf0 + fcol + 16 * blk];
+    constexpr int KU = N * N / 2 / 512;            // 16-B units of K'' per thread (N = 64: 4, N = 32: 1)
+    v2d gk[KU];
+#pragma unroll
+    for (int q = 0; q < KU; ++q) gk[q] = *reinterpret_cast<const v2d*>(Kmat + (size_t)(q * 512 + tid) * 2);
+    constexpr int TU = N * 32 / 512;               // 16-B units of an N x 64 tile per thread (N = 64: 4)
+    v2d gt[TU], gr[TU];
+#pragma unroll
+    for (int q = 0; q < TU; ++q) {
+        const int u = q * 512 + tid, row = u >> 5, c2 = 2 * (u & 31);
+        if (row >= B && vf_slabs != nullptr) {     // V Fm rows: sum of the kcv slabs (row is wave-uniform for B % 16 == 0)
+            v2d t[GSMVI_MAX_KC];
+#pragma unroll
+            for (int kq = 0; kq < GSMVI_MAX_KC; ++kq)
+                t[kq] = *reinterpret_cast<const v2d*>(vf_slabs + ((size_t)(kq < kcv ? kq : kcv - 1) * B + (row - B)) * D + J0 + c2);
+            v2d a = {0.0, 0.0};
+#pragma unroll
+            for (int kq = 0; kq < GSMVI_MAX_KC; ++kq)
+                if (kq < kcv) { a.x += t[kq].x; a.y += t[kq].y; }
+            gt[q] = a;
+        } else {
+            gt[q] = *reinterpret_cast<const v2d*>(Tm + (size_t)row * D + J0 + c2);
+        }
+        gr[q] = *reinterpret_cast<const v2d*>(Rt + (size_t)row * D + I0 + c2);
+    }
+#pragma unroll
+    for (int q = 0; q < KU; ++q) {
+        const int e = (q * 512 + tid) * 2, i = e / N, j = e % N;
+        bufK[i * KS + j] = gk[q].x;
+        bufK[i * KS + j + 1] = gk[q].y;
+    }
+#pragma unroll
+    for (int q = 0; q < TU; ++q) {
+        const int u = q * 512 + tid, row = u >> 5, c2 = 2 * (u & 31);
+        *reinterpret_cast<v2d*>(bufA + row * RS + c2) = gt[q];
+    }
+    __syncthreads();
+    double msum = 0.0;
+    if (ti == 0) {                                 // weighted column sums of Tm1: the mean of the rows u_b Fm
+        const int g = tid >> 6, col = tid & 63;
+        for (int b = g; b < N; b += 8) msum += coef[b] * bufA[b * RS + col];
+    }
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    if (!skip) {
+        // Fs_tile = K'' Tm1_tile: wave (wr, wc) -> rows 16 wr.., columns 32 wc.. (N = 32: only wr < 2 has rows)
+        if (16 * wr < N) {
+            double a[N / 4], b0[N / 4], b1[N / 4];
+            const double* ap = bufK + (16 * wr + c) * KS + ks;
+            const double* bp = bufA + ks * RS + 32 * wc + c;
+#pragma unroll
+            for (int st = 0; st < N / 4; ++st) {
+                a[st] = ap[4 * st];
+                b0[st] = bp[4 * st * RS];
+                b1[st] = bp[4 * st * RS + 16];
+            }
+            v4d p0 = {0.0, 0.0, 0.0, 0.0}, p1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int st = 0; st < N / 4; ++st) {
+                p0 = GSMVI_MFMA_F64(a[st], b0[st], p0);
+                p1 = GSMVI_MFMA_F64(a[st], b1[st], p1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bufB[(16 * wr + ks + 4 * r) * RS + 32 * wc + c] = p0[r];
+                bufB[(16 * wr + ks + 4 * r) * RS + 32 * wc + c + 16] = p1[r];
+            }
+        }
+    }
+    __syncthreads();                               // Fs tile complete; every read of the Tm1 tile is done
+#pragma unroll
+    for (int q = 0; q < TU; ++q) {
+        const int u = q * 512 + tid, row = u >> 5, c2 = 2 * (u & 31);
+        *reinterpret_cast<v2d*>(bufA + row * RS + c2) = gr[q];
+    }
+    __syncthreads();
+    if (!skip) {
+        double a[N / 4], b0[N / 4], b1[N / 4];
+        const double* ap = bufA + ks * RS + 16 * wr + c;
+        const double* bp = bufB + ks * RS + 32 * wc + c;
+#pragma unroll
+        for (int st = 0; st < N / 4; ++st) {
+            a[st] = ap[4 * st * RS];
+            b0[st] = bp[4 * st * RS];
+            b1[st] = bp[4 * st * RS + 16];
+        }
+#pragma unroll
+        for (int st = 0; st < N / 4; ++st) {
+            acc0 = GSMVI_MFMA_F64(a[st], b0[st], acc0);
+            acc1 = GSMVI_MFMA_F64(a[st], b1[st], acc1);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        F[(frow + 4 * r) * ldf + fcol] = skip ? f0[0][r] : f0[0][r] + acc0[r];
+        F[(frow + 4 * r) * ldf + fcol + 16] = skip ? f0[1][r] : f0[1][r] + acc1[r];
+    }
+    if (ti == 0) {
+        msm[tid] = msum;                           // [8][64]
+        __syncthreads();
+        if (tid < 64) {
+            double s = 0.0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += msm[g * 64 + tid];
+            mu[J0 + tid] = skip ? mu0[J0 + tid] : mu0[J0 + tid] + s;
+        }
+    }
+}
+
 // ---- 64 < n <= 128: Gamma = S Gamma1 S^T and the per-sample coefficients from the Gram slabs ---------------------------
 // 256 elements of Gamma per workgroup; every workgroup derives the B coefficient pairs itself (3 kcg loads per sample)
 __global__ __launch_bounds__(256) void k_gsmf_gamma_big(int n, int B, const double* __restrict__ Gp, int kcg,
@@ -1056,12 +1203,12 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
     if (rc) return rc;
     int kcg = 1, kcv = 1;
     if ((rc = factor_gram(ctx, st, D, n, w, &kcg))) return rc;
-    // Launch diet (round 3).  Where the skinny product Fs = K'' Tm1 will run on the fast kernel (inner dimension n a multiple
-    // of 64), the V Fm product keeps its split-K slabs -- that consumer sums them while it loads its right operand -- and
-    // carries the finish of the Gram slabs as a side job of its 256 workgroups (the one-workgroup chain kernel would pull
-    // them through a single CU: measured +5.6 us).  Otherwise: product + finish launches, as before.
-    const bool lean = !ctx->tune_no_fast && ctx->tune_direct_out && n % 64 == 0 && D % 64 == 0 && ldf0 % 2 == 0 &&
-                      (reinterpret_cast<uintptr_t>(F0) & 15u) == 0;
+    // Launch diet (round 3).  Where the consumer of V Fm can sum split-K slabs while it loads them (n = 32, 64: the update
+    // kernel with the skinny product folded in; n = 128: the fast panel kernel of Fs = K'' Tm1), the V Fm product keeps its
+    // slabs and carries the finish of the Gram slabs as a side job of its workgroups (the one-workgroup chain kernel would
+    // pull them through a single CU: measured +5.6 us).  Otherwise: product + finish launches, as before.
+    const bool lean = !ctx->tune_no_fast && ctx->tune_direct_out && (n % 64 == 0 || n == 32) && D % 64 == 0 && ldf0 % 2 == 0 &&
+                      ldf % 2 == 0 && (reinterpret_cast<uintptr_t>(F0) & 15u) == 0;
     if (lean) {
         if (kcg > 1) {
             ctx->px.sj_src = w.Gp;
@@ -1145,6 +1292,14 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         hipLaunchKernelGGL(k_gsmf_gemm128<0>, dim3(gw), dim3(256), 0, st, n, w.Tt, Wm, w.Pm, info_dev);   // P = (T - I) W S
         hipLaunchKernelGGL(k_gsmf_gemm128<1>, dim3(gw), dim3(256), 0, st, n, Wm, w.Pm, Kmat, info_dev);   // K'' = (W S)^T P
         if ((rc = chk("k_gsmf_gemm128"))) return rc;
+    }
+    if (!ctx->tune_no_fast && ctx->tune_direct_out && D % 64 == 0 && (n == 32 || n == 64) && ldf0 % 2 == 0 && ldf % 2 == 0) {
+        // n <= 64: the skinny product Fs = K'' Tm1 is folded into the update kernel (k_gsmf_update_fs): one launch less
+        const int ntl = D / 64;
+#define UFS(NPV) hipLaunchKernelGGL(k_gsmf_update_fs<NPV>, dim3(ntl * ntl), dim3(512), 0, st, D, B, Rt, Kmat, Tm, vf_slabs, kcv, F0, ldf0, F, ldf, coef, mu0, mu, info_dev, n_reverts_dev)
+        if (n == 32) UFS(1); else UFS(2);
+#undef UFS
+        return chk("k_gsmf_update_fs");
     }
     // Fs = K'' Tm1 as one skinny GEMM: inner dimension n <= one chunk, so there is exactly one slab, written straight into Fs
     if (vf_slabs) {                                // rows B .. 2B-1 of Tm1 = sum of the V Fm slabs; finished into Tm1 on the way

@@ -23,7 +23,8 @@ class HipEngine:
     """One context (workspace + launch heuristics) on one device; grows on demand."""
 
     name = "hip"
-    bam_max_batch = 128        # device chain of BaM's (B+1) x (B+1) matrix function (csrc/gsmvi_bam_small.hip)
+    bam_max_batch = 639        # B + 1 <= 640: LDS of BaM's forward-substitution kernel (csrc/gsmvi_bam.hip); the one-workgroup
+                               # chain covers B <= 128, larger batches take the blocked multi-workgroup Cholesky
 
     def __init__(self, device=None, max_D=0, max_B=0):
         self.lib = _lib.load_library()

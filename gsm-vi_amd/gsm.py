@@ -102,9 +102,10 @@ class GSM:
                     replicated; each rank evaluates ``lp_g`` only on its batch_size/world rows, the
                     per-sample records are all-gathered (RCCL) and every replica applies the identical
                     combined update (gsm-vi_amd/dist.py).  All ranks return the same (mean, cov).
-          graph   : None (default) / True: the factor-form fit replays blocks of 16 iterations as one hipGraph when every
-                    launch in them is capturable (a score marked ``graph_safe`` such as ``GaussianTarget.lp_g``, the
-                    device draw stream, no sharding); False: always issue the launches from Python.  Same numbers.
+          graph   : the factor-form fit can replay blocks of 16 iterations as one hipGraph when every launch in them is
+                    capturable (a score marked ``graph_safe`` such as ``GaussianTarget.lp_g``, the device draw stream, no
+                    sharding).  None (default): do so for D <= 512, where the Python / launch overhead is the bound; True:
+                    always; False: never.  Same numbers either way.
           method  : "auto" (default) = "factor" whenever it applies (2*batch_size <= min(D, 128), the device
                     Cholesky sampler, no teacher-forced samples) and "dense" otherwise.  Why that is a drop-in
                     default: for the same draws the two forms give the same (mean, cov) to round-off
@@ -276,8 +277,10 @@ class GSM:
         # stream, no sharding collective) is captured ONCE into a hipGraph and replayed: at small D the Python / launch
         # overhead of ~10 calls per iteration is the bound (D = 256, B = 8: 58 us eager against 50 us replayed).  Blocks
         # that contain a print or a monitor call run eagerly, so the reference's cadence is untouched.
-        use_graph = (graph is not False and dev_rng and native and not shard and niter + 1 >= 3 * KB
-                     and bool(getattr(self.lp_g, "graph_safe", False)))
+        # By default only where it pays: at D >= 1024 the iteration is GPU-bound (D = 1024, B = 32: 85 us eager = 85 us replayed)
+        # and capturing ~200 kernel nodes costs a few ms, so graph=None takes the graph for D <= 512; graph=True forces it.
+        use_graph = ((graph is True or (graph is None and D <= 512)) and dev_rng and native and not shard
+                     and niter + 1 >= 3 * KB and bool(getattr(self.lp_g, "graph_safe", False)))
         takes_out = False
         if use_graph:
             import inspect

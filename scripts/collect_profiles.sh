@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats and, in separate passes, the HBM
 # traffic counters for the bench workload.  Output: gpurun_out/prof_$1/ (copy summaries to profiles/).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT
@@ -17,7 +17,7 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- 
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $ARGS --no-graph > $OUT/pmc_mfma.log 2>&1
 # the >= 0.50 HBM-roofline point of the covariance kernel (D=4096, B=32) and the fit-iteration kernel tables
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_d4096 -- python3 $ROOT/bench.py --D 4096 --B 32 --steps 60 --warmup 12 --no-cpu-baseline > $OUT/trace_d4096.log 2>&1
-for cfg in "1024 32 factor" "1024 32 dense" "4096 64 factor" "256 8 factor"; do
+for cfg in "1024 32 factor" "1024 32 dense" "4096 64 factor" "256 8 factor" "1024 32 bam"; do
   tag=$(echo $cfg | tr ' ' '_')
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fit_$tag -- python3 $ROOT/scripts/factor_prof.py $cfg > $OUT/fit_$tag.log 2>&1
   echo "== fit iteration kernels, D B method = $cfg (41 iterations; name, calls, avg ns, % of GPU time)" >> $OUT/fit_iteration_kernels.txt
@@ -81,7 +81,7 @@ if cov:
                                                        "kernel_avg_us": v["kernel_avg_us"], "util": v["mfma_util"],
                                                        "f64_flop": v["mfma_f64_flop"]}
                              for k, v in res.get("mfma_util", {}).items()
-                             if any(t in k for t in ("k_gsm_cov_sym", "k_panel_fast<2, false", "k_gsmf_update_fast"))}},
+                             if any(t in k for t in ("k_gsm_cov_sym", "k_panel_fast<2, false", "k_gsmf_update_f"))}},
               open(out + "/traffic.json", "w"), indent=1)
 json.dump(res, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])

@@ -5,6 +5,10 @@ from oracle import gsm_oracle as orc
 D, B = int(sys.argv[1]), int(sys.argv[2])
 m, cov_t, P = orc.make_gaussian_target(D, 0)
 tgt = gsmvi_amd.GaussianTarget(m, precision=P)
-gsm = gsmvi_amd.GSM(D, tgt.lp, tgt.lp_g)
-gsm.fit(1, niter=40, batch_size=B, verbose=False, rng="device", method=sys.argv[3] if len(sys.argv) > 3 else "factor")
+method = sys.argv[3] if len(sys.argv) > 3 else "factor"
+if method == "bam":
+    gsmvi_amd.BaM(D, tgt.lp, tgt.lp_g).fit(1, gsmvi_amd.Regularizers().constant(1.0), niter=40, batch_size=B, verbose=False)
+else:
+    # graph=False: every launch of every iteration goes through the profiler's kernel trace
+    gsmvi_amd.GSM(D, tgt.lp, tgt.lp_g).fit(1, niter=40, batch_size=B, verbose=False, rng="device", method=method, graph=False)
 torch.cuda.synchronize()

@@ -18,7 +18,8 @@ for trial in range(3):
         eng.gsm_factor_update(Z, X, G, mu0, F0)
     buf = (C.c_double * 8)()                      # the stamps are the last 16 words of the small-matrix workspace (ws_sizes)
     R = 2 * eng._max_B + 8
-    n_small = 8 * R + 7 * R * R + 4096 + 5 * 144 * 144 + 64 + 129 * 129 + 64 + 8 * R * R + 16
+    ldb = max(R // 2 + 16, 144)
+    n_small = 8 * R + 7 * R * R + 4096 + 5 * ldb * ldb + 64 + ldb * ldb + 64 + 8 * R * R + 16
     eng.lib.gsmvi_debug_read_workspace(eng._ctx, 2, n_small - 16, buf, 8)
     st = np.frombuffer(buf, dtype=np.int64)[:7]
     print("  ".join(f"{n} {d / 100.0:.2f}us" for n, d in zip(names, np.diff(st))), f" total {(st[6] - st[0]) / 100.0:.2f}us")

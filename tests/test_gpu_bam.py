@@ -185,14 +185,32 @@ def test_full_form_gap_stays_small_at_moderate_reg(golden):
         assert rel_err(S, Sf) < 1e-6 and rel_err(mu, g[f"{c}/mu_full"]) < 1e-6, c
 
 
-def test_no_silent_host_path_for_large_batches():
-    """B > 128 is beyond the device chain of the (B+1) x (B+1) matrix function: the call must say so
-    (GSMVI_ERR_UNSUPPORTED, before anything is enqueued) instead of computing on the host -- there is no host
-    arithmetic in the library."""
+@pytest.mark.parametrize("D,B,reg", [(300, 130, 1.0), (1024, 256, 1.0), (200, 300, 0.5), (512, 400, 2.0)])
+def test_batches_beyond_the_one_workgroup_chain(D, B, reg):
+    """bam.py:31-69 has no batch bound.  B > 128 takes the multi-workgroup Newton-Schulz steps on an n-sized grid, the
+    blocked Cholesky of BB (the D x D path's gsmvi_potrf kernels) and the generic forward substitution; checked against the
+    restatement and the update's defining equation (round 2 returned UNSUPPORTED here)."""
     import gsmvi_amd
     orc, borc = _o()
     eng = gsmvi_amd.get_engine()
-    st = orc.make_update_state(300, 130, seed=2)
+    st = orc.make_update_state(D, B, seed=D + B)
+    X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
+    mu, S, flag = eng.bam_update(X, G, mu0, S0, reg, 0.0)
+    assert eng.read_flag(flag) == 0
+    mu_o, S_o = borc.bam_lowrank_update_exact(st["samples"], st["vs"], st["mu0"], st["S0"], reg)
+    Sn = S.cpu().numpy()
+    assert rel_err(Sn, 0.5 * (S_o + S_o.T)) < 1e-8 and rel_err(mu.cpu().numpy(), mu_o) < 1e-8
+    U, V, xbar, gbar = _bam_uv(st["samples"], st["vs"], st["mu0"], st["S0"], reg)
+    assert _backward_error(Sn, U, V) < 1e-14 and np.array_equal(Sn, Sn.T)
+
+
+def test_batch_bound_is_reported_up_front():
+    """B + 1 > 640 is beyond the device chain: the Python driver says so before anything runs (no retry loop), and the
+    C entry point returns GSMVI_ERR_UNSUPPORTED before anything is enqueued -- there is no host arithmetic in the library."""
+    import gsmvi_amd
+    orc, borc = _o()
+    eng = gsmvi_amd.get_engine()
+    st = orc.make_update_state(64, 700, seed=2)
     X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
     with pytest.raises(ValueError):                                  # the Python driver refuses up front (no retry loop)
         eng.bam_update(X, G, mu0, S0, 1.0)
@@ -205,5 +223,5 @@ def test_no_silent_host_path_for_large_batches():
     finally:
         eng.bam_max_batch = limit
     with pytest.raises(ValueError):
-        gsmvi_amd.BaM(300, None, lambda x: -x).fit(0, gsmvi_amd.Regularizers().constant(1.0), batch_size=130, niter=2,
-                                                   verbose=False)
+        gsmvi_amd.BaM(64, None, lambda x: -x).fit(0, gsmvi_amd.Regularizers().constant(1.0), batch_size=700, niter=2,
+                                                  verbose=False)
