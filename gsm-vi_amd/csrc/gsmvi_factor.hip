@@ -891,6 +891,7 @@ __global__ __launch_bounds__(256) void k_gsmf_mean(int D, int B, const double* _
 // MFMAs per wave, and the rank-n update reads it from LDS.  The product is repeated by the D / 64 workgroups of a tile
 // column -- 16 x 0.5 MFLOP at D = 1024, cheap beside a dependent launch.  Tile row 0 also writes the mean, workgroup 0 counts
 // the revert; *bad => F = F0, mu = mu0.
+// n = 2B may be smaller than N = 32 NP (n = 16, BASELINE config 2): rows and columns beyond n are loaded as zeros.
 template <int NP>
 __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const double* __restrict__ Rt,
                                                         const double* __restrict__ Kmat, const double* __restrict__ Tm,
@@ -920,14 +921,22 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const doub
 #pragma unroll
         for (int r = 0; r < 4; ++r) f0[blk][r] = F0[(frow + 4 * r) * ldf0 + fcol + 16 * blk];
     constexpr int KU = N * N / 2 / 512;            // 16-B units of K'' per thread (N = 64: 4, N = 32: 1)
+    const int n = 2 * B;
     v2d gk[KU];
 #pragma unroll
-    for (int q = 0; q < KU; ++q) gk[q] = *reinterpret_cast<const v2d*>(Kmat + (size_t)(q * 512 + tid) * 2);
+    for (int q = 0; q < KU; ++q) {
+        const int e = (q * 512 + tid) * 2, i = e / N, j = e % N;
+        gk[q] = (i < n && j < n) ? *reinterpret_cast<const v2d*>(Kmat + (size_t)i * n + j) : (v2d){0.0, 0.0};
+    }
     constexpr int TU = N * 32 / 512;               // 16-B units of an N x 64 tile per thread (N = 64: 4)
     v2d gt[TU], gr[TU];
 #pragma unroll
     for (int q = 0; q < TU; ++q) {
         const int u = q * 512 + tid, row = u >> 5, c2 = 2 * (u & 31);
+        if (row >= n) {
+            gt[q] = gr[q] = (v2d){0.0, 0.0};
+            continue;
+        }
         if (row >= B && vf_slabs != nullptr) {     // V Fm rows: sum of the kcv slabs (row is wave-uniform for B % 16 == 0)
             v2d t[GSMVI_MAX_KC];
 #pragma unroll
@@ -958,7 +967,7 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const doub
     double msum = 0.0;
     if (ti == 0) {                                 // weighted column sums of Tm1: the mean of the rows u_b Fm
         const int g = tid >> 6, col = tid & 63;
-        for (int b = g; b < N; b += 8) msum += coef[b] * bufA[b * RS + col];
+        for (int b = g; b < n; b += 8) msum += coef[b] * bufA[b * RS + col];
     }
     v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     if (!skip) {
@@ -1207,7 +1216,7 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
     // kernel with the skinny product folded in; n = 128: the fast panel kernel of Fs = K'' Tm1), the V Fm product keeps its
     // slabs and carries the finish of the Gram slabs as a side job of its workgroups (the one-workgroup chain kernel would
     // pull them through a single CU: measured +5.6 us).  Otherwise: product + finish launches, as before.
-    const bool lean = !ctx->tune_no_fast && ctx->tune_direct_out && (n % 64 == 0 || n == 32) && D % 64 == 0 && ldf0 % 2 == 0 &&
+    const bool lean = !ctx->tune_no_fast && ctx->tune_direct_out && (n % 64 == 0 || n == 32 || n == 16) && D % 64 == 0 && ldf0 % 2 == 0 &&
                       ldf % 2 == 0 && (reinterpret_cast<uintptr_t>(F0) & 15u) == 0;
     if (lean) {
         if (kcg > 1) {
@@ -1293,11 +1302,12 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         hipLaunchKernelGGL(k_gsmf_gemm128<1>, dim3(gw), dim3(256), 0, st, n, Wm, w.Pm, Kmat, info_dev);   // K'' = (W S)^T P
         if ((rc = chk("k_gsmf_gemm128"))) return rc;
     }
-    if (!ctx->tune_no_fast && ctx->tune_direct_out && D % 64 == 0 && (n == 32 || n == 64) && ldf0 % 2 == 0 && ldf % 2 == 0) {
+    if (!ctx->tune_no_fast && ctx->tune_direct_out && D % 64 == 0 && (n == 16 || n == 32 || n == 64) && ldf0 % 2 == 0 &&
+        ldf % 2 == 0) {
         // n <= 64: the skinny product Fs = K'' Tm1 is folded into the update kernel (k_gsmf_update_fs): one launch less
         const int ntl = D / 64;
 #define UFS(NPV) hipLaunchKernelGGL(k_gsmf_update_fs<NPV>, dim3(ntl * ntl), dim3(512), 0, st, D, B, Rt, Kmat, Tm, vf_slabs, kcv, F0, ldf0, F, ldf, coef, mu0, mu, info_dev, n_reverts_dev)
-        if (n == 32) UFS(1); else UFS(2);
+        if (n <= 32) UFS(1); else UFS(2);
 #undef UFS
         return chk("k_gsmf_update_fs");
     }
