@@ -73,7 +73,7 @@ class BaM:
 
     def fit(self, key, regf, mean=None, cov=None, batch_size=2, niter=5000, nprint=10, verbose=True,
             check_goodness=True, monitor=None, retries=10, jitter=1e-6, *, sampler="cholesky", rng="auto",
-            as_torch=False, forced_samples=None, shard=False, group=None, check_update_flag=False):
+            as_torch=False, forced_samples=None, shard=False, group=None, check_update_flag=False, method="dense"):
         """gsmvi/bam.py:140-216.  Kept: niter+1 iterations (:178); nprint clamp (:177); reg = regf(i)
         per attempt (:196); jitter on the diagonal and symmetrisation (:198-199, done in-kernel);
         retry on any exception up to ``retries`` then re-raise (:189-206); Cholesky accept/revert of
@@ -92,9 +92,23 @@ class BaM:
         device update never raises: a numerical failure poisons the outputs with NaN, the Cholesky accept test
         rejects them and the iteration is a revert (counted in ``n_reverts``), not a retry.
         ``check_update_flag=True`` restores the retry: the update's device flag is read every iteration (one host
-        synchronisation) and a non-zero flag raises FloatingPointError into the retry loop."""
+        synchronisation) and a non-zero flag raises FloatingPointError into the retry loop.
+        ``method="factor"`` (needs 2*batch_size <= min(D, 128), sampler="cholesky", no forced samples, no sharding):
+        the state is (mean, F) with cov = F^T F; every iteration samples with F itself and applies the factor-form BaM
+        update (engine.bam_factor_update) -- four passes over F, no D x D covariance, no D^3 Cholesky for the accept
+        test (the update's own 2B x 2B positive-definiteness test decides accept/revert, counted in ``n_reverts``).
+        The covariance is formed once, for the return value (and for each monitor call).  ``jitter`` is NOT applied in
+        this form (a diagonal shift is not a low-rank change of the factor); everything else -- niter+1 iterations, reg =
+        regf(i) per attempt, retries, monitor cadence -- is the loop above."""
         eng = self._engine if self._engine is not None else get_engine()
         D, B = self.D, int(batch_size)
+        assert method in ("dense", "factor"), "method must be 'dense' or 'factor'"
+        self.method_used = method
+        if method == "factor":
+            assert sampler == "cholesky" and forced_samples is None and not shard, \
+                "method='factor' samples with its own factor (sampler='cholesky', no forced samples, no sharding)"
+            return self._fit_factor(eng, key, regf, mean, cov, B, niter, nprint, verbose, monitor, retries, rng, as_torch,
+                                    check_update_flag)
         bmax = getattr(eng, "bam_max_batch", None)
         if bmax is not None and B > bmax:               # deterministic: raised here, not inside the retry loop
             raise ValueError(f"BaM.fit: batch_size {B} exceeds the device update's limit of {bmax}")
@@ -202,6 +216,89 @@ class BaM:
             mc = [mean_t, cov_t] if mon_native else [eng.to_numpy(mean_t).copy(), eng.to_numpy(cov_t).copy()]
             monitor(i, mc, self.lp, key, nevals=nevals)
         self.n_reverts = eng.read_flag(n_rev)
+        if as_torch:
+            return mean_t, cov_t
+        return eng.to_numpy(mean_t), eng.to_numpy(cov_t)
+
+    # ------------------------------------------------------------------------------
+    def _fit_factor(self, eng, key, regf, mean, cov, B, niter, nprint, verbose, monitor, retries, rng, as_torch,
+                    check_update_flag):
+        """Factor-form BaM fit (see ``fit(method="factor")``): the loop of gsmvi/bam.py:140-216 on the state (mean, F)."""
+        D = self.D
+        assert 2 * B <= min(D, 128), "method='factor' needs 2*batch_size <= min(D, 128)"
+        mean_t = eng.zeros(D) if mean is None else eng.clone(mean).reshape(D)
+        cov0 = eng.eye(D) if cov is None else eng.clone(cov).reshape(D, D)
+        flag, n_rev = eng.new_flag(), eng.new_flag()
+        F, _ = eng.potrf(cov0, flag=flag)                   # one factorisation for the whole fit
+        if eng.read_flag(flag) != 0:
+            raise ValueError("initial covariance is not positive definite")
+        seed = int(np.asarray(key.cpu() if _is_torch(key) else key).flatten()[-1])
+        rs = np.random.RandomState(seed)
+        assert rng in ("auto", "numpy", "device"), "rng must be 'auto', 'numpy' or 'device'"
+        dev_rng = rng != "numpy"
+        KB = 16
+        Zblk = eng.empty(KB, B, D) if dev_rng else None
+        ndraw = 0
+        native = bool(getattr(self.lp_g, "device_native", False))
+        mon_native = bool(getattr(monitor, "device_native", False)) if monitor is not None else False
+        mean_new, F_new, Xbuf = eng.empty(D), eng.empty(D, D), eng.empty(B, D)
+        state_bufs = [(mean_t, F), (mean_new, F_new)]
+        a = 0
+
+        def state():
+            c = eng.gram(state_bufs[a][1])
+            m = state_bufs[a][0]
+            return [m, c] if mon_native else [eng.to_numpy(m).copy(), eng.to_numpy(c).copy()]
+
+        nevals = 1
+        if nprint > niter:
+            nprint = niter
+        every = max(1, niter // nprint) if nprint > 0 else 1
+        reverts_seen = 0
+        i = 0
+        for i in range(niter + 1):
+            if verbose and i % every == 0:
+                print(f"Iteration {i} of {niter}")
+                r = eng.read_flag(n_rev)
+                if r > reverts_seen:
+                    print(f"Bad update for covariance matrix. Revert ({r - reverts_seen} since last print)")
+                    reverts_seen = r
+            if monitor is not None and i % monitor.checkpoint == 0:
+                monitor(i, state(), self.lp, key, nevals=nevals)
+                nevals = 0
+            mu_a, F_a = state_bufs[a]
+            mu_b, F_b = state_bufs[1 - a]
+            j = 0
+            while True:
+                try:
+                    if dev_rng:
+                        if ndraw % KB == 0:
+                            eng.normal_batch(KB, B, D, seed, ndraw, out=Zblk)
+                        Z = Zblk[ndraw % KB]
+                        ndraw += 1
+                    else:
+                        Z = eng.normal_from_host(rs.standard_normal((B, D)))
+                    X = eng.sample(Z, mu_a, F_a, out=Xbuf)
+                    vs = self.lp_g(X) if native else eng.asarray(self.lp_g(eng.to_numpy(X)))
+                    nevals += B
+                    reg = regf(i)
+                    eng.bam_factor_update(Z, X, vs, mu_a, F_a, reg, out=(mu_b, F_b), flag=flag, n_reverts=n_rev)
+                    if check_update_flag and eng.read_flag(flag) != 0:
+                        raise FloatingPointError("BaM update flagged a numerical failure (device flag != 0)")
+                    break
+                except Exception as e:                      # noqa: BLE001 -- reference behaviour
+                    if j < retries:
+                        j += 1
+                        print(f"Failed with exception {e}")
+                        print(f"Trying again {j} of {retries}")
+                    else:
+                        raise e
+            a = 1 - a               # the kernel already returned the reverted state when its test failed: accept = swap
+        if monitor is not None:
+            monitor(i, state(), self.lp, key, nevals=nevals)
+        self.n_reverts = eng.read_flag(n_rev)
+        mean_t, F = state_bufs[a]
+        cov_t = eng.gram(F)
         if as_torch:
             return mean_t, cov_t
         return eng.to_numpy(mean_t), eng.to_numpy(cov_t)

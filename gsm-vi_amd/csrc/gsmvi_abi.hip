@@ -59,6 +59,9 @@ int gsmvi_factor_apply_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B,
 int gsmvi_bam_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X, int ldx,
                    const double* G, int ldg, const double* mu0, const double* S0, int lds0, double reg,
                    double jitter, double* mu, double* S, int lds, int* info_dev);
+int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
+                          const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double reg, double* mu,
+                          double* F, int ldf, int* info_dev, int* n_reverts_dev);
 
 #include "gsmvi_ctx.h"
 
@@ -141,7 +144,7 @@ static void ws_sizes(int D, int B, size_t* n_pp, size_t* n_sg, size_t* n_small, 
     size_t potrf_scratch = dpad * 64;                          // v1: one factored 64 x 64 block per step
     if (potrf_scratch < 2 * 64 * dpad + 2 * 64 * 64) potrf_scratch = 2 * 64 * dpad + 2 * 64 * 64;   // v2: row buffers + W
     if (*n_pp < potrf_scratch) *n_pp = potrf_scratch;
-    *n_sg = (size_t)R * D * 4;                                 // SG + BaM factor panels
+    *n_sg = (size_t)R * D * 8;                                 // SG + BaM factor panels (the factor-form BaM update holds 10 B + 8 rows)
     // + the device chain of BaM's small matrix function: five padded 144 x 144 iterates, coefficients, BB (n <= 129)
     // + the factor path: a seventh R x R slot (finished Gram matrix) and the split-K slabs of the Gram product (+ 16 stamp words)
     // BaM's Newton-Schulz iterates: five ld x ld matrices, ld = 144 for B + 1 <= 129, else B + 1 rounded up to 16 (R/2 + 16 covers it)
@@ -677,6 +680,23 @@ int gsmvi_bam_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const doubl
     BAD_ARG(!(reg > 0.0), "reg must be positive");
     return gsmvi_bam_impl(ctx, reinterpret_cast<hipStream_t>(stream), D, B, X, ldx, G, ldg, mu0, S0, lds0, reg,
                           jitter, mu, S, lds, info_dev);
+}
+
+int gsmvi_bam_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* Z, int ldz, const double* X,
+                                int ldx, const double* G, int ldg, const double* mu0, const double* F0, int ldf0,
+                                double reg, double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev) {
+    int st = check_common(ctx, D, B, __func__);
+    if (st != GSMVI_OK) return st;
+    BAD_ARG(!Z || !X || !G || !mu0 || !F0 || !mu || !F || !info_dev, "NULL argument");
+    BAD_ARG(ldz < D || ldx < D || ldg < D || ldf0 < D || ldf < D, "leading dimension smaller than D");
+    BAD_ARG(F == F0 || mu == mu0, "outputs must not alias inputs");
+    BAD_ARG(!(reg > 0.0), "reg must be positive");
+    if (2 * B > D || 2 * B > 128 || D > 16384) {
+        gsmvi_set_error("%s: %s", __func__, "the factor form needs 2B <= D and 2B <= 128; use gsmvi_bam_update_f64");
+        return GSMVI_ERR_UNSUPPORTED;
+    }
+    return gsmvi_bam_factor_impl(ctx, reinterpret_cast<hipStream_t>(stream), D, B, Z, ldz, X, ldx, G, ldg, mu0, F0, ldf0, reg,
+                                 mu, F, ldf, info_dev, n_reverts_dev);
 }
 
 }  // extern "C"

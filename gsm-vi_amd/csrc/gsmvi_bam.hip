@@ -526,6 +526,139 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     return GSMVI_OK;
 }
 
+// ===== factor-form BaM update: Sigma = F^T F, no D x D covariance and no D^3 factorisation =================================
+// (north_star's factor-form extension applied to bam.py:72-114)  With S0 = F0^T F0, x_b = mu0 + z_b F0:
+//   U = Q Q^T depends on the scores only through  sum_b (g_b - gbar)(g_b - gbar)^T  and gbar gbar^T, and the centred rows span
+//   B - 1 dimensions: an orthonormal (Helmert) recombination of the B centred rows gives B - 1 rows with the same Gram sum,
+//   so Q gets n = B columns instead of B + 1 (rows k < B-1: sqrt(reg/B) helmert_k(g), row B-1: sqrt(reg/(1+reg)) gbar), and the
+//   same for the sample factor Vf.  BaM's update depends on Q and Vf only through Q Q^T and Vf^T Vf (bam.py:31-69), so S is unchanged.
+//   Everything of bam.py:107-111 is then done in WHITENED coordinates (Vf = Vw F0, P = Wq F0, Z = Zw F0):
+//     Wq = Qt F0^T,  [N0; M1] = [Wq; Vw] Wq^T,  Zw = L^-1 (Wq + M1^T Vw),   S = F0^T (I + Vw^T Vw - Zw^T Zw) F0,
+//   and the factor of M = I + Rt^T J Rt, Rt = [Vw; Zw], J = diag(I, -I) is taken by the SAME 2B x 2B chain as the GSM factor
+//   update (gsmvi_factor.hip, jmode): F = F0 + Rt^T K (Rt F0).  The mean (bam.py:112) needs S gbar = (h F0) with
+//   h = wg + Vw^T (Vw wg) - Zw^T (Zw wg), wg = F0 gbar: the forward-substitution kernel emits r1 h as an extra row of Rt (its
+//   "mean" output with mu0 = xbar = 0), which rides through the Rt F0 product.  Four passes over F0 (Wq, Rt F0, and the
+//   read + write of the update), no pass over a covariance.
+__global__ __launch_bounds__(64) void k_bamf_stats(int D, int B, const double* __restrict__ Z, int ldz,
+                                                   const double* __restrict__ X, int ldx,
+                                                   const double* __restrict__ G, int ldg, double reg,
+                                                   double* __restrict__ xbar, double* __restrict__ gbar,
+                                                   double* __restrict__ zerov, double* __restrict__ Qt,
+                                                   double* __restrict__ Vw) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= D) return;
+    double sx = 0.0, sg = 0.0, sz = 0.0;
+    int b = 0;
+    for (; b + 7 < B; b += 8) {
+        double vx[8], vg[8], vz[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            vx[u] = X[(size_t)(b + u) * ldx + i];
+            vg[u] = G[(size_t)(b + u) * ldg + i];
+            vz[u] = Z[(size_t)(b + u) * ldz + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { sx += vx[u]; sg += vg[u]; sz += vz[u]; }
+    }
+    for (; b < B; ++b) { sx += X[(size_t)b * ldx + i]; sg += G[(size_t)b * ldg + i]; sz += Z[(size_t)b * ldz + i]; }
+    const double xb = sx / B, gb = sg / B, zb = sz / B;
+    const double a = sqrt(reg / B), r1s = sqrt(reg / (1.0 + reg));
+    xbar[i] = xb;
+    gbar[i] = gb;
+    zerov[i] = 0.0;
+    Qt[(size_t)(B - 1) * D + i] = r1s * gb;
+    Vw[(size_t)(B - 1) * D + i] = -r1s * zb;               // sqrt(r1) (mu0 - xbar) = -sqrt(r1) zbar F0
+    // Helmert rows of the centred values: row k-1 = (sum_{j<k} c_j - k c_k) / sqrt(k (k+1)), k = 1 .. B-1
+    double pg = G[i] - gb, pz = Z[i] - zb;
+    for (int k = 1; k < B; ++k) {
+        const double cg = G[(size_t)k * ldg + i] - gb, cz = Z[(size_t)k * ldz + i] - zb;
+        const double sc = a / sqrt((double)k * (double)(k + 1));
+        Qt[(size_t)(k - 1) * D + i] = sc * (pg - k * cg);
+        Vw[(size_t)(k - 1) * D + i] = sc * (pz - k * cz);
+        pg += cg;
+        pz += cz;
+    }
+}
+
+// mu = mu0/(1+reg) + r1 (S gbar) + r1 xbar, or mu0 on a reverted update (bam.py:112)
+__global__ __launch_bounds__(256) void k_bamf_commit(int D, const double* __restrict__ sg_r1, const double* __restrict__ mu0,
+                                                     const double* __restrict__ xbar, double reg,
+                                                     const int* __restrict__ bad, double* __restrict__ mu) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= D) return;
+    const double r1 = reg / (1.0 + reg);
+    mu[i] = *bad ? mu0[i] : mu0[i] / (1.0 + reg) + sg_r1[i] + r1 * xbar[i];
+}
+
+int gsmvi_panel_t_product(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* A, int lda, const double* M,
+                          int ldm, int mrows, double* Pp, int* kc_out);
+int gsmvi_factor_back_signed(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, const double* mu0, const double* F0, int ldf0,
+                             double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev);
+
+int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
+                          const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double reg, double* mu,
+                          double* F, int ldf, int* info_dev, int* n_reverts_dev) {
+    const int n = B, n2 = 2 * n;
+    // workspace (ctx->sg holds 8 rmax max_D doubles, rmax = 2B + 8): 10 n + 5 rows of D
+    double* Qt = ctx->sg;                          // n x D
+    double* Wq = Qt + (size_t)n * D;               // n x D      } [Wq; Vw]: left operand of the Gram product
+    double* Ft = Wq + (size_t)n * D;               // [Vw; Zw; r1 h]  (2n + 1) x D: Rt of the factor chain + the mean's row
+    double* T1 = Ft + (size_t)(n2 + 1) * D;        // rows n .. 2n-1 hold M1^T Vw, then -Zw (the substitution kernel's Fs)
+    double* Tm = T1 + (size_t)n2 * D;              // (2n + 1) x D = Ft F0
+    double* Fsf = Tm + (size_t)(n2 + 1) * D;       // 2n x D: K'' Tm of the generic update path
+    double* xbar = Fsf + (size_t)n2 * D;
+    double* gbar = xbar + D;
+    double* zerov = gbar + D;
+    double* N0 = ctx->small;                       // n x n   } stacked [N0; M1] = [Wq; Vw] Wq^T: ONE transposed panel product
+    double* M1 = N0 + (size_t)n * n;
+    double* Ld = M1 + (size_t)n * n;               // n x n, then Ldinv (n), zg (n), vg (n)
+    double* Nd = Ld + (size_t)n * n + 3 * n;
+    double* M1T = Nd + (size_t)n * n;
+    double* Upk = M1T + (size_t)n * n;
+    double* scratch = Upk + (size_t)n * (n + 1) / 2 + 2;
+    const double* Ldinv = Ld + (size_t)n * n;
+    int* info_bam = ctx->ints + 8;
+    int kc = 1, rc;
+
+    hipLaunchKernelGGL(k_bamf_stats, dim3((D + 63) / 64), dim3(64), 0, st, D, B, Z, ldz, X, ldx, G, ldg, reg, xbar, gbar, zerov,
+                       Qt, Ft);
+    if ((rc = gsmvi_panel_t_product(ctx, st, D, n, Qt, D, F0, ldf0, D, ctx->pp, &kc))) return rc;
+    if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, Wq, D))) return rc;
+    if ((rc = gsmvi_panel_t_product(ctx, st, D, n2, Wq, D, Wq, D, n, ctx->pp, &kc))) return rc;
+    if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
+    hipLaunchKernelGGL(k_bam_nmat, dim3((n * n + 255) / 256), dim3(256), 0, st, n, M1, N0, Nd, M1T);
+    if (!ctx->bam_hint_host) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&ctx->bam_hint_host), 64, hipHostMallocMapped) == hipSuccess)
+            *ctx->bam_hint_host = 0;
+        else
+            ctx->bam_hint_host = nullptr;
+    }
+    if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, Upk, info_bam,
+                                     ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq)))
+        return rc;
+    // T1 = M1^T Vw, then Zw = L^-1 (Wq + T1) by the 16-lanes-per-column substitution; its mean output (mu0 = xbar = 0) is
+    // r1 (wg + Vw^T vg - Zw^T zg) = r1 h, written as row 2n of Ft
+    if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, M1T, n, nullptr, 1.0, Ft, D, ctx->pp, &kc))) return rc;
+    if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, T1 + (size_t)n * D, D))) return rc;
+    hipLaunchKernelGGL(k_bam_forward16, dim3((D + 15) / 16), dim3(256), 0, st, D, n, Wq, Upk, Ldinv, Ldinv + n, Ldinv + 2 * n,
+                       zerov, zerov, reg, Ft, T1, Ft + (size_t)n2 * D);
+    if ((rc = gsmvi_panel_product_out(ctx, st, D, D, n2 + 1, Ft, D, nullptr, 1.0, F0, ldf0, nullptr, Tm, D))) return rc;
+    ctx->fo_Rt = Ft;
+    ctx->fo_Tm = Tm;
+    ctx->fo_Fs = Fsf;
+    rc = gsmvi_factor_back_signed(ctx, st, D, n, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev);
+    ctx->fo_Rt = ctx->fo_Tm = ctx->fo_Fs = nullptr;
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_bamf_commit, dim3((D + 255) / 256), dim3(256), 0, st, D, Tm + (size_t)n2 * D, mu0, xbar, reg, info_dev,
+                       mu);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        gsmvi_set_error("BaM (factor form) launch failed: %s%s", hipGetErrorString(e), "");
+        return GSMVI_ERR_HIP;
+    }
+    return GSMVI_OK;
+}
+
 hipError_t gsmvi_bam_prepare() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bam_forward<64>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -36,7 +36,8 @@ struct gsmvi_ctx {
     void* ws = nullptr;        // one hipMalloc
     size_t ws_bytes = 0;
     double* pp = nullptr;      // panel partials [GSMVI_MAX_KC][rmax][max_D]
-    double* sg = nullptr;      // [4][rmax][max_D] finished panels (SG, BaM factor panels)
+    double* sg = nullptr;      // [8][rmax][max_D] finished panels (SG, BaM factor panels)
+    double *fo_Rt = nullptr, *fo_Tm = nullptr, *fo_Fs = nullptr;   // set only inside the factor-form BaM update: where ITS [Vw; Zw], Tm, Fs panels live
     double* small = nullptr;   // coefficients and small dense matrices
     int* ints = nullptr;       // device ints (flags)
     double* gram_slabs = nullptr;   // [GSMVI_MAX_KC][rmax][rmax] split-K slabs of the factor path's Gram product, + 16 stamp words

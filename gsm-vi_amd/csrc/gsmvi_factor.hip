@@ -238,7 +238,7 @@ __device__ __forceinline__ void load_upper128(double* Mt, const double* __restri
 // 16 x 16 outputs per workgroup; the 16 rows of (Rg J) and the 16 rows of Rg it needs are staged in LDS
 // ([row][130]: reading one row per lane is conflict-free).
 __global__ __launch_bounds__(256) void k_gsmf_small_a(int n, int B, const double* __restrict__ Rg,
-                                                      const int* __restrict__ info_g, double* __restrict__ Ap) {
+                                                      const int* __restrict__ info_g, double* __restrict__ Ap, int jmode) {
     __shared__ double RJ[16 * 130];
     __shared__ double RR[16 * 130];
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
@@ -248,7 +248,10 @@ __global__ __launch_bounds__(256) void k_gsmf_small_a(int n, int B, const double
         const int gi = i0 + r, gj = j0 + r;
         double vj = 0.0, vr = 0.0;
         if (k < n) {
-            if (gi < n) vj = (k < B) ? Rg[(size_t)gi * n + B + k] : (Rg[(size_t)gi * n + k - B] - Rg[(size_t)gi * n + k]);
+            if (gi < n) {
+                if (jmode) vj = (k < B) ? Rg[(size_t)gi * n + k] : -Rg[(size_t)gi * n + k];       // J = diag(I, -I), unscaled
+                else vj = (k < B) ? Rg[(size_t)gi * n + B + k] : (Rg[(size_t)gi * n + k - B] - Rg[(size_t)gi * n + k]);
+            }
             if (gj < n) vr = Rg[(size_t)gj * n + k];
         }
         RJ[r * 130 + k] = vj;
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(256) void k_gsmf_small_a(int n, int B, const double
     }
     const int i = i0 + ty, j = j0 + tx;
     if (i < n && j < n) {
-        double v = (i == j ? 1.0 : 0.0) + (s0 + s1) / (double)B;
+        double v = (i == j ? 1.0 : 0.0) + (jmode ? (s0 + s1) : (s0 + s1) / (double)B);
         if (*info_g != 0) v = (i == j) ? -1.0 : 0.0;     // Gamma was singular: force the PD test to fail
         Ap[(size_t)i * n + j] = v;
     }
@@ -535,10 +538,13 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const do
 // K is then irrelevant.
 #define GSMF_ES1 146
 #define GSMF_ES2 82
+// jmode = 1 (factor-form BaM, gsmvi_bam.hip): Gp is the Gram matrix of Rt = [Vw; Zw] itself (S = I), J = diag(I_B, -I_B)
+// (M = I + Vw^T Vw - Zw^T Zw), the coefficients come out as zeros (the mean is BaM's own).
 __global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double* __restrict__ Gp, int kcg,
                                                       double* __restrict__ Kmat, double* __restrict__ coef,
                                                       int* __restrict__ bad_out,
-                                                      unsigned long long* __restrict__ stamps) {
+                                                      unsigned long long* __restrict__ stamps, int jmode,
+                                                      const int* __restrict__ prior_bad) {
 #define SMALL_STAMP(k)                                                                      \
     do {                                                                                    \
         if (stamps && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memrealtime();        \
@@ -585,12 +591,12 @@ __global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double
     }
     __syncthreads();
     if (tid < B) {                                     // per-sample scalars (gsm_numpy.py:8-17, whitened; file header)
-        double al, be;
-        gsmf_coefs(E2[tid * ES2 + tid], E2[tid * ES2 + B + tid], E2[(B + tid) * ES2 + B + tid], &al, &be);
+        double al = 1.0, be = 0.0;
+        if (!jmode) gsmf_coefs(E2[tid * ES2 + tid], E2[tid * ES2 + B + tid], E2[(B + tid) * ES2 + B + tid], &al, &be);
         s_alpha[tid] = al;
         s_beta[tid] = be;
-        coef[tid] = be / (double)B;                    // mean: mu' = mu + sum_b coef[b] (x_b - mu) + coef[B + b] (v_b Fm)
-        coef[B + tid] = al / (double)B;
+        coef[tid] = jmode ? 0.0 : be / (double)B;      // mean: mu' = mu + sum_b coef[b] (x_b - mu) + coef[B + b] (v_b Fm)
+        coef[B + tid] = jmode ? 0.0 : al / (double)B;
     }
     __syncthreads();
     {   // Gamma = S Gamma1 S^T (upper triangle), S = [[I, 0], [diag(beta), diag(alpha)]]; identity beyond n
@@ -677,7 +683,7 @@ __global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double
     {   // A' = I + (Rg J) Rg^T into E2;  (Rg J)[i][k] = (1/B)(k < B ? Rg[i][B+k] : Rg[i][k-B] - Rg[i][k]), on the MFMA pipe.
         // A' is symmetric (the mirror is written too); Rg is upper triangular, so Rg[j][k] = 0 for k < 16 j: only the
         // k-blocks jb..3 contribute to the block (ib, jb), ib <= jb
-        const double invB = 1.0 / (double)B;
+        const double invB = jmode ? 1.0 : 1.0 / (double)B;
 #pragma unroll
         for (int tq = 0; tq < 2; ++tq) {
             const int task = TASK_A[w][tq];
@@ -693,6 +699,7 @@ __global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double
                 [&](int k) {
                     const int k1 = (k < B) ? B + k : k - B;
                     const double a1 = arow[k1 < 64 ? k1 : 63], a0 = arow[k];
+                    if (jmode) return (k < n) ? ((k < B) ? a0 : -a0) : 0.0;      // J = diag(I, -I)
                     return (k < n) ? ((k < B) ? a1 : a1 - a0) : 0.0;
                 },
                 [&](int k) { return brow[k]; });
@@ -714,7 +721,7 @@ __global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double
     SMALL_STAMP(3);
     chol64_blk<ES2, false, false>(E2, scr, n, &fail_t);             // E2 = T (upper): exists iff M is positive definite
     SMALL_STAMP(4);
-    const int bad = (fail_g != 0) || (fail_t != 0);
+    const int bad = (fail_g != 0) || (fail_t != 0) || (prior_bad && *prior_bad != 0);   // prior: BaM's own chain failed
     if (tid == 0) *bad_out = bad;
     if (bad) return;                                   // block-uniform
     {
@@ -783,10 +790,11 @@ __device__ __forceinline__ void kmat_load_lds(double* Mt, double* rinv, const do
 __global__ __launch_bounds__(256) void k_gsmf_kmat_big(int n, const double* __restrict__ Rg,
                                                        double* __restrict__ Wout,
                                                        const int* __restrict__ info_g,
-                                                       const int* __restrict__ info_t, int* __restrict__ bad_out) {
+                                                       const int* __restrict__ info_t, int* __restrict__ bad_out,
+                                                       const int* __restrict__ prior_bad) {
     __shared__ __attribute__((aligned(16))) double Mt[128 * 130];
     __shared__ double rinv[128];
-    const int bad = (*info_g != 0) || (*info_t != 0);
+    const int bad = (*info_g != 0) || (*info_t != 0) || (prior_bad && *prior_bad != 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) *bad_out = bad;
     if (bad) return;                                         // block-uniform
     const int tid = threadIdx.x, c = tid >> 4, q = tid & 15, grp = tid & 48;   // grp: first lane of the group in the wave
@@ -1039,7 +1047,7 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const doub
 // 256 elements of Gamma per workgroup; every workgroup derives the B coefficient pairs itself (3 kcg loads per sample)
 __global__ __launch_bounds__(256) void k_gsmf_gamma_big(int n, int B, const double* __restrict__ Gp, int kcg,
                                                         double* __restrict__ Gam, double* __restrict__ coef,
-                                                        double* __restrict__ ab) {
+                                                        double* __restrict__ ab, int jmode) {
     __shared__ double s_alpha[64], s_beta[64];
     const int tid = threadIdx.x;
     auto g1 = [&](int i, int q) {                      // one entry of Gamma1: the kcg slabs, all loads in one batch
@@ -1052,13 +1060,13 @@ __global__ __launch_bounds__(256) void k_gsmf_gamma_big(int n, int B, const doub
         return a;
     };
     if (tid < B) {
-        double al, be;
-        gsmf_coefs(g1(tid, tid), g1(tid, B + tid), g1(B + tid, B + tid), &al, &be);
+        double al = 1.0, be = 0.0;
+        if (!jmode) gsmf_coefs(g1(tid, tid), g1(tid, B + tid), g1(B + tid, B + tid), &al, &be);
         s_alpha[tid] = al;
         s_beta[tid] = be;
         if (blockIdx.x == 0) {
-            coef[tid] = be / (double)B;
-            coef[B + tid] = al / (double)B;
+            coef[tid] = jmode ? 0.0 : be / (double)B;
+            coef[B + tid] = jmode ? 0.0 : al / (double)B;
             ab[tid] = be;                              // for k_gsmf_wscale
             ab[B + tid] = al;
         }
@@ -1163,9 +1171,9 @@ struct factor_ws {
 };
 static factor_ws factor_carve(gsmvi_ctx* ctx, int D, int n) {
     factor_ws w;
-    w.Rt = ctx->sg;
-    w.Tm = w.Rt + (size_t)n * D;
-    w.Fs = w.Tm + (size_t)n * D;
+    w.Rt = ctx->fo_Rt ? ctx->fo_Rt : ctx->sg;
+    w.Tm = ctx->fo_Tm ? ctx->fo_Tm : w.Rt + (size_t)n * D;
+    w.Fs = ctx->fo_Fs ? ctx->fo_Fs : w.Tm + (size_t)n * D;
     w.Gam = ctx->small;
     w.Rg = w.Gam + (size_t)n * n;
     w.Ap = w.Rg + (size_t)n * n;
@@ -1196,7 +1204,7 @@ static int factor_w_prep(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const dou
 // (kcg = 1: finished); V Fm either finished in Tm1 (vf_slabs == nullptr) or as kcv split-K slabs summed by their consumer.
 static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
                        double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, const double* Gp, int kcg,
-                       const double* vf_slabs, int kcv);
+                       const double* vf_slabs, int kcv, int jmode = 0);
 
 // the Gram product Gamma1 = [Z; V][Z; V]^T as split-K slabs (transposed panel product with A = M = Rt1)
 static int factor_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int n, const factor_ws& w, int* kcg) {
@@ -1242,6 +1250,18 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
     return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, w.Gp, kcg, nullptr, 0);
 }
 
+// Factor-form BaM (gsmvi_bam.hip): Rt = [Vw; Zw] and Tm = Rt Fm (2 Bh rows each) are in the panels named by ctx->fo_Rt / fo_Tm;
+// F = F0 + Rt^T K Tm with M = I + Vw^T Vw - Zw^T Zw = C^T C (J = diag(I, -I)).  mu receives mu0: the caller owns BaM's mean.
+int gsmvi_factor_back_signed(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, const double* mu0, const double* F0, int ldf0,
+                             double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev) {
+    const int n = 2 * Bh;
+    const factor_ws w = factor_carve(ctx, D, n);
+    int kcg = 1;
+    int rc = factor_gram(ctx, st, D, n, w, &kcg);
+    if (rc) return rc;
+    return factor_back(ctx, st, D, Bh, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, w.Gp, kcg, nullptr, 0, 1);
+}
+
 // Batch-sharded form, stage 1: this rank's B_local samples -> records.
 int gsmvi_factor_local_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int Bl, const double* Z, int ldz, const double* X,
                             int ldx, const double* G, int ldg, const double* mu0, const double* F0, int ldf0,
@@ -1272,7 +1292,7 @@ int gsmvi_factor_apply_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const 
 
 static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
                        double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, const double* Gp, int kcg,
-                       const double* vf_slabs, int kcv) {
+                       const double* vf_slabs, int kcv, int jmode) {
     const int n = 2 * B;                           // n is even
     const factor_ws w = factor_carve(ctx, D, n);
     double *Rt = w.Rt, *Tm = w.Tm, *Fs = w.Fs, *coef = w.coef;
@@ -1280,21 +1300,23 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
     int* info_t = ctx->ints + 1;
     int rc, kc2 = 1;
     double* Kmat;
+    const int* prior = jmode ? ctx->ints + 8 : nullptr;      // the flag of BaM's (B x B) chain
+
     if (n <= 64) {
         // everything small in one workgroup
         Kmat = w.Rg;
-        hipLaunchKernelGGL(k_gsmf_small16, dim3(1), dim3(512), 0, st, n, B, Gp, kcg, Kmat, coef, info_dev, w.stamps);
+        hipLaunchKernelGGL(k_gsmf_small16, dim3(1), dim3(512), 0, st, n, B, Gp, kcg, Kmat, coef, info_dev, w.stamps, jmode, prior);
         if ((rc = chk("k_gsmf_small16"))) return rc;
     } else {
         // 64 < n <= 128: Gamma, the two n x n Choleskys one workgroup each, W and K in their own kernels
         Kmat = w.Gam;                              // Gamma is dead once Rg exists
         double* Wm = w.Ap;                         // A' is dead once T exists
-        hipLaunchKernelGGL(k_gsmf_gamma_big, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, w.Gam, coef, coef + n);
+        hipLaunchKernelGGL(k_gsmf_gamma_big, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, w.Gam, coef, coef + n, jmode);
         hipLaunchKernelGGL(k_chol128<true>, dim3(1), dim3(512), 0, st, n, w.Gam, w.Rg, info_g);   // Gram matrix: semi-definite rule
-        hipLaunchKernelGGL(k_gsmf_small_a, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, st, n, B, w.Rg, info_g, w.Ap);
+        hipLaunchKernelGGL(k_gsmf_small_a, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, st, n, B, w.Rg, info_g, w.Ap, jmode);
         hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n, w.Ap, w.Tt, info_t);
         if ((rc = chk("k_chol128"))) return rc;
-        hipLaunchKernelGGL(k_gsmf_kmat_big, dim3((n + 15) / 16), dim3(256), 0, st, n, w.Rg, Wm, info_g, info_t, info_dev);
+        hipLaunchKernelGGL(k_gsmf_kmat_big, dim3((n + 15) / 16), dim3(256), 0, st, n, w.Rg, Wm, info_g, info_t, info_dev, prior);
         hipLaunchKernelGGL(k_gsmf_wscale, dim3((n * B + 255) / 256), dim3(256), 0, st, n, B, Wm, coef + n, info_dev);
         if ((rc = chk("k_gsmf_kmat_big"))) return rc;
         const int nb = (n + 15) / 16, gw = (nb * nb + 3) / 4;

@@ -263,6 +263,24 @@ class HipEngine:
             C.c_void_p(n_reverts.data_ptr()) if n_reverts is not None else None))
         return mu, F, flag
 
+    def bam_factor_update(self, Z, X, G, mu0, F0, reg, out=None, flag=None, n_reverts=None):
+        """Factor-form BaM update: Sigma = F^T F, X = mu0 + Z F0.  Returns (mu, F, flag); F^T F equals the S of
+        ``bam_update`` (jitter 0) to round-off; flag != 0: (mu, F) = (mu0, F0) (revert; counted in n_reverts)."""
+        B, D = Z.shape
+        self._ensure(D, B)
+        mu, F = (self.empty(D), self.empty(D, D)) if out is None else out
+        flag = self.new_flag() if flag is None else flag
+        pz, ldz = self._mat(Z, "Z")
+        px, ldx = self._mat(X, "X")
+        pg, ldg = self._mat(G, "G")
+        pf0, ldf0 = self._mat(F0, "F0")
+        pf, ldf = self._mat(F, "F")
+        _lib.check("gsmvi_bam_factor_update_f64", self.lib.gsmvi_bam_factor_update_f64(
+            self._ctx, self._stream(), D, B, pz, ldz, px, ldx, pg, ldg, self._vec(mu0, "mu0"), pf0, ldf0, float(reg),
+            self._vec(mu, "mu"), pf, ldf, C.c_void_p(flag.data_ptr()),
+            C.c_void_p(n_reverts.data_ptr()) if n_reverts is not None else None))
+        return mu, F, flag
+
     def gsm_factor_local_stage(self, Z_l, X_l, G_l, mu0, F0, out=None):
         """Records [x - mu0 | u | u F0] of this rank's samples (batch-sharded factor path)."""
         Bl, D = Z_l.shape

@@ -294,9 +294,10 @@ int gsmvi_commit_f64(gsmvi_ctx* ctx, void* stream, int D, const int* info_dev,
  * BaM update (gsmvi/bam.py:72-114 with the exact rank-(B+1) factor of U; equals bam.py:31-69).
  * Symmetrised output (bam.py:199 does this in fit); jitter is added to the diagonal (bam.py:198).
  * The (B+1) x (B+1) matrix function of bam.py:108-110 -- which the reference evaluates on the host through
- * jax.pure_callback (bam.py:15-22) -- runs on the device for B <= 128 (scaled coupled Newton-Schulz square root on
- * the MFMA pipe + a one-workgroup Cholesky, csrc/gsmvi_bam_small.hip): no synchronisation, graph-capturable.  For
- * B > 128 the call returns GSMVI_ERR_UNSUPPORTED before anything is enqueued: there is no host computation in this library.
+ * jax.pure_callback (bam.py:15-22) -- runs on the device (scaled coupled Newton-Schulz square root on the MFMA pipe +
+ * a one-workgroup Cholesky for B <= 128, the blocked Cholesky of gsmvi_potrf_f64 up to B = 639; csrc/gsmvi_bam_small.hip):
+ * no synchronisation, graph-capturable.  For B > 639 the call returns GSMVI_ERR_UNSUPPORTED before anything is enqueued:
+ * there is no host computation in this library.
  * *info_dev = 1 if that small problem was not finite / not positive definite (then mu, S are NaN-poisoned and the
  * caller's accept/revert must reject them).
  */
@@ -315,6 +316,20 @@ int gsmvi_bam_update_sharded_f64(gsmvi_ctx* ctx, void* stream, void* nccl_comm, 
                                  const double* X_local, int ldx, const double* G_local, int ldg,
                                  const double* mu0, const double* S0, int lds0, double reg, double jitter,
                                  double* xg_all, double* mu, double* S, int lds, int* info_dev);
+
+/*
+ * BaM update in FACTOR form (north_star's factor-form extension applied to gsmvi/bam.py:72-114): Sigma0 = F0^T F0 in,
+ * Sigma = F^T F out, with F^T F equal to the S of gsmvi_bam_update_f64 (jitter = 0) to round-off and the same mean.  No D x D
+ * covariance is formed and no D x D factorisation is taken: four passes over F0 and a 2B x 2B chain (the one of
+ * gsmvi_gsm_factor_update_f64).  Z (B x D) are the whitened draws of the samples: X = mu0 + Z F0 (the caller's contract, as
+ * for the GSM factor update).  Needs 2B <= min(D, 128) (GSMVI_ERR_UNSUPPORTED otherwise, before anything is enqueued).
+ * *info_dev = 1 and (mu, F) = (mu0, F0) if BaM's B x B matrix function or the 2B x 2B chain failed (non-finite input, or a
+ * Sigma that is not positive definite to working precision); *n_reverts_dev (may be NULL) is then incremented.
+ */
+int gsmvi_bam_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
+                                const double* Z, int ldz, const double* X, int ldx, const double* G, int ldg,
+                                const double* mu0, const double* F0, int ldf0, double reg,
+                                double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev);
 
 #ifdef __cplusplus
 }

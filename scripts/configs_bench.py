@@ -155,6 +155,21 @@ for name, D, B in (("c4", 1024, 128), ("c4_B32", 1024, 32)):
     bam.fit(1, sched, niter=n - 1, batch_size=B, verbose=False, rng="device")
     torch.cuda.synchronize()
     r["F_fit_bam"] = {"it_per_s": n / (time.perf_counter() - t0), "n": n}
+    if 2 * B <= 128:                                              # factor form: Sigma = F^T F, no D^3 step per iteration
+        F0, _ = eng.potrf(st["S0"])
+        Z = eng.normal(B, D, 5, 0)
+        Xf = eng.sample(Z, st["mu0"], F0)
+        Gf = tgt.lp_g(Xf)
+        Fo = eng.empty(D, D)
+        f_bamf = lambda: eng.bam_factor_update(Z, Xf, Gf, st["mu0"], F0, 1.0, out=(mu, Fo), flag=flag)
+        r["U_bam_factor_update"] = ev_times(f_bamf, 5, 100)
+        r["U_bam_factor_update"]["graph_us"] = graph_time(f_bamf, 4, 4)
+        bam.fit(1, sched, niter=3, batch_size=B, verbose=False, rng="device", method="factor")
+        torch.cuda.synchronize()
+        n, t0 = 400, time.perf_counter()
+        bam.fit(1, sched, niter=n - 1, batch_size=B, verbose=False, rng="device", method="factor")
+        torch.cuda.synchronize()
+        r["F_fit_bam_factor"] = {"it_per_s": n / (time.perf_counter() - t0), "n": n, "n_reverts": bam.n_reverts}
     h = {k: st[k].cpu().numpy() for k in ("X", "G", "mu0", "S0")}
     r["cpu_lowrank_update"] = cpu_time(lambda: borc.bam_lowrank_update_exact(h["X"], h["G"], h["mu0"], h["S0"], 1.0), 4.0)
     res["configs"][name] = r

@@ -212,6 +212,26 @@ class OracleEngine:
         elif n_reverts is not None:
             n_reverts.v += 1
 
+    def bam_factor_update(self, Z, X, G, mu0, F0, reg, out=None, flag=None, n_reverts=None):
+        """Factor-form BaM on the host: the dense restatement on S0 = F0^T F0 and ANY factor of its result (here the
+        upper Cholesky factor; the device kernel returns a different, equally valid F with the same F^T F)."""
+        flag = Flag() if flag is None else flag
+        mu, S = borc.bam_lowrank_update_exact(X, G, mu0, F0.T @ F0, reg)
+        S = 0.5 * (S + S.T)
+        try:
+            Fn, flag.v = np.linalg.cholesky(S).T, 0
+            if not (np.isfinite(Fn).all() and np.isfinite(mu).all()):
+                raise np.linalg.LinAlgError
+        except np.linalg.LinAlgError:
+            mu, Fn, flag.v = mu0.copy(), F0.copy(), 1
+            if n_reverts is not None:
+                n_reverts.v += 1
+        if out is not None:
+            out[0][...] = mu
+            out[1][...] = Fn
+            return out[0], out[1], flag
+        return mu, Fn, flag
+
     def bam_update(self, X, G, mu0, S0, reg, jitter=0.0, out=None, flag=None):
         mu, S = borc.bam_lowrank_update_exact(X, G, mu0, S0, reg)
         S = 0.5 * (S + S.T) + jitter * np.eye(S.shape[0])

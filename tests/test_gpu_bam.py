@@ -225,3 +225,108 @@ def test_batch_bound_is_reported_up_front():
     with pytest.raises(ValueError):
         gsmvi_amd.BaM(64, None, lambda x: -x).fit(0, gsmvi_amd.Regularizers().constant(1.0), batch_size=700, niter=2,
                                                   verbose=False)
+
+
+# ---- factor-form BaM (Sigma = F^T F; gsmvi_bam_factor_update_f64) ----------------------------------------------------------
+def _factor_state(eng, D, B, seed):
+    """mu0, F0 (a dense, non-triangular factor), whitened draws Z, samples X = mu0 + Z F0 and scores of a Gaussian target."""
+    orc, _ = _o()
+    rs = np.random.RandomState(seed)
+    F0 = rs.standard_normal((D, D)) / np.sqrt(D) + 0.7 * np.eye(D)
+    mu0 = rs.standard_normal(D)
+    Z = rs.standard_normal((B, D))
+    X = mu0 + Z @ F0
+    m, _, P = orc.make_gaussian_target(D, seed + 1)
+    G = orc.gaussian_score(X, m, P)
+    return mu0, F0, Z, X, G
+
+
+@pytest.mark.parametrize("reg", [0.5, 20.0])
+@pytest.mark.parametrize("D,B", [(64, 8), (256, 16), (1024, 32), (1024, 64), (512, 7), (300, 20), (130, 33), (128, 1),
+                                 (96, 48)])
+def test_factor_form_update_equals_the_dense_update(D, B, reg):
+    """F^T F of the factor-form update = S of the dense update (jitter 0) on S0 = F0^T F0, same mean -- against the HIP dense
+    path (<= 1e-9 at moderate reg), against the scipy restatement, and through the update's defining equation
+    S U S + S = V (oracle-independent).  Sizes cover the one-workgroup 2B x 2B chain (2B = 16, 32, 64 with the folded
+    update kernel; ragged 2B = 14, 40, 66, 2), the 128-row chain (B = 64, 48) and D not a multiple of 64."""
+    import gsmvi_amd
+    _, borc = _o()
+    eng = gsmvi_amd.get_engine()
+    mu0, F0, Z, X, G = _factor_state(eng, D, B, seed=D + B)
+    dv = [eng.asarray(a) for a in (Z, X, G, mu0, F0)]
+    n_rev = eng.new_flag()
+    mu_f, F, flag = eng.bam_factor_update(*dv, reg, n_reverts=n_rev)
+    assert eng.read_flag(flag) == 0 and eng.read_flag(n_rev) == 0
+    S0 = F0.T @ F0
+    mu_d, S_d, _ = eng.bam_update(dv[1], dv[2], dv[3], eng.asarray(S0), reg, 0.0)
+    Fn = F.cpu().numpy()
+    S_f = Fn.T @ Fn
+    tol = 1e-9 if reg <= 1.0 else 2e-8
+    assert rel_err(S_f, S_d.cpu().numpy()) < tol and rel_err(mu_f.cpu().numpy(), mu_d.cpu().numpy()) < tol
+    assert rel_err(eng.gram(F).cpu().numpy(), S_f) < 1e-13
+    mu_o, S_o = borc.bam_lowrank_update_exact(X, G, mu0, S0, reg)
+    assert rel_err(S_f, 0.5 * (S_o + S_o.T)) < 1e-7 and rel_err(mu_f.cpu().numpy(), mu_o) < 1e-7
+    U, V, xbar, gbar = _bam_uv(X, G, mu0, S0, reg)
+    assert _backward_error(S_f, U, V) < 1e-13
+    mu_def = mu0 / (1 + reg) + reg / (1 + reg) * (S_f @ gbar + xbar)
+    assert rel_err(mu_f.cpu().numpy(), mu_def) < (1e-8 if reg <= 1.0 else 1e-7)   # S gbar from the factors: ||S|| ||gbar|| >> result
+
+
+def test_factor_form_update_reverts_and_bounds():
+    """A non-finite score poisons the small chain: flag = 1, (mu, F) = (mu0, F0), the revert is counted; batches beyond
+    2B <= min(D, 128) are refused before anything is enqueued."""
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    mu0, F0, Z, X, G = _factor_state(eng, 256, 16, seed=5)
+    G[3, 7] = np.nan
+    dv = [eng.asarray(a) for a in (Z, X, G, mu0, F0)]
+    n_rev = eng.new_flag()
+    mu, F, flag = eng.bam_factor_update(*dv, 1.0, n_reverts=n_rev)
+    assert eng.read_flag(flag) == 1 and eng.read_flag(n_rev) == 1
+    assert np.array_equal(mu.cpu().numpy(), mu0) and np.array_equal(F.cpu().numpy(), F0)
+    for D, B in ((256, 65), (40, 21)):
+        mu0, F0, Z, X, G = _factor_state(eng, D, B, seed=6)
+        with pytest.raises(gsmvi_amd.GsmviError) as ei:
+            eng.bam_factor_update(*[eng.asarray(a) for a in (Z, X, G, mu0, F0)], 1.0)
+        assert ei.value.status == 5
+
+
+def test_factor_form_fit_follows_the_dense_fit_on_the_same_samples():
+    """The factor-form fit's own samples, recorded and forced into the dense fit (jitter 0): BaM's update depends on
+    (X, G, mu0, S0) only, so both fits walk the same (mean, cov) trajectory to round-off."""
+    import gsmvi_amd
+    from gsmvi_amd.targets import GaussianTarget, device_score
+    orc, _ = _o()
+    D, B, niter = 128, 16, 25
+    m, cov_t, P = orc.make_gaussian_target(D, 3)
+    tgt = GaussianTarget(m, precision=P)
+    seen = []
+
+    @device_score
+    def lp_g(x):
+        seen.append(x.clone())
+        return tgt.lp_g(x)
+
+    reg_f, reg_d = gsmvi_amd.Regularizers(), gsmvi_amd.Regularizers()
+    bam = gsmvi_amd.BaM(D, None, lp_g)
+    mean_f, cov_f = bam.fit(7, reg_f.custom(lambda i: 100.0 / i), batch_size=B, niter=niter, verbose=False,
+                            method="factor")
+    assert bam.n_reverts == 0 and len(seen) == niter + 1
+    forced = [x.cpu().numpy() for x in seen]
+    mean_d, cov_d = gsmvi_amd.BaM(D, None, tgt.lp_g).fit(7, reg_d.custom(lambda i: 100.0 / i), batch_size=B, niter=niter,
+                                                        verbose=False, jitter=0.0, forced_samples=forced)
+    assert rel_err(mean_f, mean_d) < 1e-8 and rel_err(cov_f, cov_d) < 1e-8
+
+
+def test_factor_form_fit_converges_on_a_gaussian_target():
+    import gsmvi_amd
+    from gsmvi_amd.targets import GaussianTarget
+    orc, _ = _o()
+    D, B = 64, 16
+    m, cov_t, P = orc.make_gaussian_target(D, 11)
+    tgt = GaussianTarget(m, precision=P)
+    reg = gsmvi_amd.Regularizers()
+    bam = gsmvi_amd.BaM(D, tgt.lp, tgt.lp_g)
+    mean, cov = bam.fit(3, reg.custom(lambda i: 200.0 / i), batch_size=B, niter=400, verbose=False, method="factor")
+    assert bam.n_reverts == 0
+    assert rel_err(mean, m) < 1e-3 and rel_err(cov, cov_t) < 1e-2

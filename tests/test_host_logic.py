@@ -133,6 +133,32 @@ def test_bam_fit_converges_and_schedule_counts_calls():
     assert np.allclose(mean, m, atol=1e-3) and np.allclose(cov, cov_t, atol=1e-3, rtol=1e-3)
 
 
+def test_bam_factor_fit_runs_the_same_loop():
+    """method="factor": state (mean, F), accept/revert decided by the update, same schedule / monitor / retry semantics."""
+    D = 6
+    m, cov_t, P = orc.make_gaussian_target(D, 23)
+    reg = Regularizers()
+    seen = []
+
+    class Mon:
+        checkpoint = 25
+
+        def __call__(self, i, params, lp, key, nevals=1):
+            seen.append((i, nevals, np.allclose(params[1], params[1].T)))
+
+    bam = BaM(D, None, lambda x: orc.gaussian_score(x, m, P), engine=OracleEngine())
+    mean, cov = bam.fit(5, regf=reg.custom(lambda i: 100 / (1 + i)), niter=100, batch_size=3, verbose=False,
+                        method="factor", monitor=Mon())
+    assert bam.method_used == "factor" and reg.counter == 101 and bam.n_reverts == 0
+    assert [s[0] for s in seen] == [0, 25, 50, 75, 100, 100] and all(s[2] for s in seen)
+    assert seen[1][1] == 25 * 3                        # nevals between checkpoints = iterations x batch
+    assert np.allclose(mean, m, atol=1e-3) and np.allclose(cov, cov_t, atol=1e-3, rtol=1e-3)
+    with pytest.raises(AssertionError):                # 2B <= D
+        bam.fit(5, regf=reg.constant(1.0), niter=1, batch_size=4, verbose=False, method="factor")
+    with pytest.raises(AssertionError):
+        bam.fit(5, regf=reg.constant(1.0), niter=1, batch_size=2, verbose=False, method="factor", sampler="svd")
+
+
 def test_bam_retries_then_reraises(capsys):
     D = 3
     calls = [0]
