@@ -160,8 +160,12 @@ __global__ __launch_bounds__(256) void k_bam_nmat(int n, const double* __restric
 // (9 registers).  U = L^T is staged in LDS in packed upper form (row p holds L[p..n-1][p], contiguous, so the
 // lanes of a group read consecutive words); pivot p is broadcast inside the group with one shuffle.
 // T1 arrives in rows n..2n-1 of Fs and is overwritten there with -Z by the lane that read it.
+// INLINE_T1 (n <= 64): T1 is not read but formed here, M1 (n x n, [k][r]) staged in LDS and the column's Vf values passed round
+// the 16-lane group by shuffles -- n^2 / 16 multiply-adds per lane instead of a skinny panel product + finish launch pair.
 #define BAMF_NMAX 144
+template <bool INLINE_T1>
 __global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const double* __restrict__ P,
+                                                       const double* __restrict__ M1,
                                                        const double* __restrict__ Upk,
                                                        const double* __restrict__ Ldinv,
                                                        const double* __restrict__ zg, const double* __restrict__ vg,
@@ -171,6 +175,7 @@ __global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const doubl
                                                        double* __restrict__ mu) {
     __shared__ __attribute__((aligned(16))) double U[BAMF_NMAX * (BAMF_NMAX + 1) / 2];
     __shared__ double sdi[BAMF_NMAX], szg[BAMF_NMAX], svg[BAMF_NMAX];
+    __shared__ double sM1[INLINE_T1 ? 64 * 64 : 1];
     const int tid = threadIdx.x, c = tid >> 4, q = tid & 15, grp = tid & 48;
     const int j = blockIdx.x * 16 + c, jc = j < D ? j : D - 1;
     const int npk = n * (n + 1) / 2;
@@ -201,11 +206,42 @@ __global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const doubl
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const int r = q + 16 * i, rc = r < n ? r : n - 1;
-        const double a = P[(size_t)rc * D + jc] + Fs[(size_t)(n + rc) * D + jc];
+        double a = P[(size_t)rc * D + jc];
+        if (!INLINE_T1) a += Fs[(size_t)(n + rc) * D + jc];
         x[i] = r < n ? a : 0.0;
         vf[i] = r < n ? Ft[(size_t)rc * D + jc] : 0.0;
     }
+    if (INLINE_T1) {
+        double mv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + 256 * u;
+            mv[u] = M1[e < n * n ? e : n * n - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = tid + 256 * u;
+            if (e < n * n) sM1[e] = mv[u];             // [k][r], ld n
+        }
+    }
     __syncthreads();
+    if (INLINE_T1) {                                   // x += M1^T vf: vf_k lives in lane k & 15 of the group, register k >> 4
+#pragma unroll
+        for (int ik = 0; ik < 4; ++ik) {
+            if (16 * ik >= n) break;                   // uniform
+            for (int qk = 0; qk < 16; ++qk) {
+                const int k = 16 * ik + qk;
+                if (k >= n) break;                     // uniform
+                const double vk = __shfl(vf[ik], (tid & 48) | qk, 64);
+                const double* mrow = sM1 + k * n + q;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = q + 16 * i;
+                    x[i] += (r < n) ? mrow[r < n ? 16 * i : 0] * vk : 0.0;
+                }
+            }
+        }
+    }
     // forward substitution; the 16 pivots of a block stay a rolled loop (static register index = block)
 #pragma unroll
     for (int pb = 0; pb < 9; ++pb) {
@@ -446,6 +482,9 @@ int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, co
                            int force_kenq);
 int gsmvi_bam_small_nmax();
 size_t gsmvi_bam_small_scratch_doubles(int n);
+int gsmvi_bam_small_fused_nmax();
+int gsmvi_bam_small_fused(hipStream_t st, int n, double reg, const double* slabs, int kc, int ldslab, size_t slab_stride,
+                          double* M1, double* Ld, double* Upk, int* info_dev);
 
 int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X, int ldx, const double* G,
                    int ldg, const double* mu0, const double* S0, int lds0, double reg, double jitter, double* mu,
@@ -475,15 +514,19 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     // M1 = Vf Q and N0 = P Q share the right operand; P and Vf (the first n rows of Ft) are adjacent in the workspace,
     // so both Gram matrices come from one 2n-row panel product, finished into the adjacent [N0; M1]
     if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, nq, n2, P, D, nullptr, 1.0, Qm, nq, ctx->pp, &kc))) return rc;
-    if ((rc = gsmvi_panel_finish_cols(st, nq, n, n2, kc, ctx->pp, N0, n))) return rc;
-
-    // N = M1^T M1 + sym(N0) and M1^T on the device
     double* Nd = Ld + (size_t)n * n + 3 * n;       // n x n
     double* M1T = Nd + (size_t)n * n;              // n x n
     double* Upk = M1T + (size_t)n * n;             // n(n+1)/2: packed rows of L^T
-    hipLaunchKernelGGL(k_bam_nmat, dim3((n * n + 255) / 256), dim3(256), 0, st, n, M1, N0, Nd, M1T);
     const double* Ldinv = Ld + (size_t)n * n;
-    {
+    if (n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full) {
+        // n <= 48: slab sum, N, the matrix function, its Cholesky factor and the small outputs in ONE one-workgroup launch
+        if ((rc = gsmvi_bam_small_fused(st, n, reg, ctx->pp, kc, nq, (size_t)n2 * nq, M1, Ld, Upk,
+                                        info_dev ? info_dev : ctx->ints + 8)))
+            return rc;
+    } else {
+        if ((rc = gsmvi_panel_finish_cols(st, nq, n, n2, kc, ctx->pp, N0, n))) return rc;
+        // N = M1^T M1 + sym(N0) and M1^T on the device
+        hipLaunchKernelGGL(k_bam_nmat, dim3((n * n + 255) / 256), dim3(256), 0, st, n, M1, N0, Nd, M1T);
         // the whole (B+1) x (B+1) matrix function on the device (gsmvi_bam_small.hip): no copy, no synchronisation
         double* scratch = Upk + (size_t)n * (n + 1) / 2 + 2;
         if (!ctx->bam_hint_host) {                 // pinned, device-visible word for the step-count hint
@@ -497,11 +540,15 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
             return rc;
     }
     const bool lanes16 = n <= 129;              // the sizes whose Cholesky kernel (k_bam_chol_out) also emits the packed rows
-    if (lanes16) {
+    if (lanes16 && n <= 64) {
+        // the 16-lanes-per-column substitution with T1 = M1^T Vf formed inside
+        hipLaunchKernelGGL(k_bam_forward16<true>, dim3((D + 15) / 16), dim3(256), 0, st, D, n, P, M1, Upk, Ldinv, Ldinv + n,
+                           Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu);
+    } else if (lanes16) {
         // T1 = M1^T Vf into rows n..2n-1 of Fs, then the 16-lanes-per-column substitution
         if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, M1T, n, nullptr, 1.0, Ft, D, ctx->pp, &kc))) return rc;
         if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, Fs + (size_t)n * D, D))) return rc;
-        hipLaunchKernelGGL(k_bam_forward16, dim3((D + 15) / 16), dim3(256), 0, st, D, n, P, Upk, Ldinv, Ldinv + n,
+        hipLaunchKernelGGL(k_bam_forward16<false>, dim3((D + 15) / 16), dim3(256), 0, st, D, n, P, M1, Upk, Ldinv, Ldinv + n,
                            Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu);
     } else {
 #define BFW(CV) hipLaunchKernelGGL(k_bam_forward<CV>, dim3((D + CV - 1) / CV), dim3(CV), sizeof(double) * 2 * n * CV, st, D, n, P, M1, Ld, Ldinv, Ldinv + n, Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu)
@@ -539,39 +586,61 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
 //   h = wg + Vw^T (Vw wg) - Zw^T (Zw wg), wg = F0 gbar: the forward-substitution kernel emits r1 h as an extra row of Rt (its
 //   "mean" output with mu0 = xbar = 0), which rides through the Rt F0 product.  Four passes over F0 (Wq, Rt F0, and the
 //   read + write of the update), no pass over a covariance.
-__global__ __launch_bounds__(64) void k_bamf_stats(int D, int B, const double* __restrict__ Z, int ldz,
-                                                   const double* __restrict__ X, int ldx,
-                                                   const double* __restrict__ G, int ldg, double reg,
-                                                   double* __restrict__ xbar, double* __restrict__ gbar,
-                                                   double* __restrict__ zerov, double* __restrict__ Qt,
-                                                   double* __restrict__ Vw) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= D) return;
+// Workgroup = 64 columns x 4 sample groups: the B x 64 tiles of G and Z are staged in LDS by all four groups (coalesced rows,
+// every load of a thread in flight together), group g then writes the Helmert rows k = g B/4 + 1 .. (g+1) B/4 of its column
+// from the LDS tile (its starting prefix sum recomputed from the tile).  B <= 64 (the factor form's bound).
+__global__ __launch_bounds__(256) void k_bamf_stats(int D, int B, const double* __restrict__ Z, int ldz,
+                                                    const double* __restrict__ X, int ldx,
+                                                    const double* __restrict__ G, int ldg, double reg,
+                                                    double* __restrict__ xbar, double* __restrict__ gbar,
+                                                    double* __restrict__ zerov, double* __restrict__ Qt,
+                                                    double* __restrict__ Vw) {
+    __shared__ double tg[64][65], tz[64][65];      // [sample][column]
+    __shared__ double red[3][4][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + c, ic = i < D ? i : D - 1;
     double sx = 0.0, sg = 0.0, sz = 0.0;
-    int b = 0;
-    for (; b + 7 < B; b += 8) {
-        double vx[8], vg[8], vz[8];
+    {
+        double vx[16], vg[16], vz[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            vx[u] = X[(size_t)(b + u) * ldx + i];
-            vg[u] = G[(size_t)(b + u) * ldg + i];
-            vz[u] = Z[(size_t)(b + u) * ldz + i];
+        for (int u = 0; u < 16; ++u) {
+            const int b = g + 4 * u, bc = b < B ? b : B - 1;
+            vx[u] = X[(size_t)bc * ldx + ic];
+            vg[u] = G[(size_t)bc * ldg + ic];
+            vz[u] = Z[(size_t)bc * ldz + ic];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { sx += vx[u]; sg += vg[u]; sz += vz[u]; }
+        for (int u = 0; u < 16; ++u) {
+            const int b = g + 4 * u;
+            if (b < B) {
+                sx += vx[u]; sg += vg[u]; sz += vz[u];
+                tg[b][c] = vg[u];
+                tz[b][c] = vz[u];
+            }
+        }
     }
-    for (; b < B; ++b) { sx += X[(size_t)b * ldx + i]; sg += G[(size_t)b * ldg + i]; sz += Z[(size_t)b * ldz + i]; }
-    const double xb = sx / B, gb = sg / B, zb = sz / B;
+    red[0][g][c] = sx;
+    red[1][g][c] = sg;
+    red[2][g][c] = sz;
+    __syncthreads();
+    const double xb = ((red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c])) / B;
+    const double gb = ((red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c])) / B;
+    const double zb = ((red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c])) / B;
     const double a = sqrt(reg / B), r1s = sqrt(reg / (1.0 + reg));
-    xbar[i] = xb;
-    gbar[i] = gb;
-    zerov[i] = 0.0;
-    Qt[(size_t)(B - 1) * D + i] = r1s * gb;
-    Vw[(size_t)(B - 1) * D + i] = -r1s * zb;               // sqrt(r1) (mu0 - xbar) = -sqrt(r1) zbar F0
+    if (i >= D) return;
+    if (g == 0) {
+        xbar[i] = xb;
+        gbar[i] = gb;
+        zerov[i] = 0.0;
+        Qt[(size_t)(B - 1) * D + i] = r1s * gb;
+        Vw[(size_t)(B - 1) * D + i] = -r1s * zb;           // sqrt(r1) (mu0 - xbar) = -sqrt(r1) zbar F0
+    }
     // Helmert rows of the centred values: row k-1 = (sum_{j<k} c_j - k c_k) / sqrt(k (k+1)), k = 1 .. B-1
-    double pg = G[i] - gb, pz = Z[i] - zb;
-    for (int k = 1; k < B; ++k) {
-        const double cg = G[(size_t)k * ldg + i] - gb, cz = Z[(size_t)k * ldz + i] - zb;
+    const int k0 = 1 + (g * (B - 1)) / 4, k1 = 1 + ((g + 1) * (B - 1)) / 4;     // this group's k range [k0, k1)
+    double pg = 0.0, pz = 0.0;
+    for (int j = 0; j < k0; ++j) { pg += tg[j][c] - gb; pz += tz[j][c] - zb; }
+    for (int k = k0; k < k1; ++k) {
+        const double cg = tg[k][c] - gb, cz = tz[k][c] - zb;
         const double sc = a / sqrt((double)k * (double)(k + 1));
         Qt[(size_t)(k - 1) * D + i] = sc * (pg - k * cg);
         Vw[(size_t)(k - 1) * D + i] = sc * (pz - k * cz);
@@ -592,8 +661,9 @@ __global__ __launch_bounds__(256) void k_bamf_commit(int D, const double* __rest
 
 int gsmvi_panel_t_product(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* A, int lda, const double* M,
                           int ldm, int mrows, double* Pp, int* kc_out);
-int gsmvi_factor_back_signed(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, const double* mu0, const double* F0, int ldf0,
-                             double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev);
+int gsmvi_factor_signed_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, int* kcg);
+int gsmvi_factor_signed_back(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, const double* mu0, const double* F0, int ldf0,
+                             double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, int kcg, int finished);
 
 int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
                           const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double reg, double* mu,
@@ -620,33 +690,40 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     int* info_bam = ctx->ints + 8;
     int kc = 1, rc;
 
-    hipLaunchKernelGGL(k_bamf_stats, dim3((D + 63) / 64), dim3(64), 0, st, D, B, Z, ldz, X, ldx, G, ldg, reg, xbar, gbar, zerov,
+    hipLaunchKernelGGL(k_bamf_stats, dim3((D + 63) / 64), dim3(256), 0, st, D, B, Z, ldz, X, ldx, G, ldg, reg, xbar, gbar, zerov,
                        Qt, Ft);
     if ((rc = gsmvi_panel_t_product(ctx, st, D, n, Qt, D, F0, ldf0, D, ctx->pp, &kc))) return rc;
     if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, Wq, D))) return rc;
     if ((rc = gsmvi_panel_t_product(ctx, st, D, n2, Wq, D, Wq, D, n, ctx->pp, &kc))) return rc;
-    if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
-    hipLaunchKernelGGL(k_bam_nmat, dim3((n * n + 255) / 256), dim3(256), 0, st, n, M1, N0, Nd, M1T);
-    if (!ctx->bam_hint_host) {
-        if (hipHostMalloc(reinterpret_cast<void**>(&ctx->bam_hint_host), 64, hipHostMallocMapped) == hipSuccess)
-            *ctx->bam_hint_host = 0;
-        else
-            ctx->bam_hint_host = nullptr;
+    if (n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full) {
+        if ((rc = gsmvi_bam_small_fused(st, n, reg, ctx->pp, kc, n, (size_t)n2 * n, M1, Ld, Upk, info_bam))) return rc;
+    } else {
+        if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
+        hipLaunchKernelGGL(k_bam_nmat, dim3((n * n + 255) / 256), dim3(256), 0, st, n, M1, N0, Nd, M1T);
+        if (!ctx->bam_hint_host) {
+            if (hipHostMalloc(reinterpret_cast<void**>(&ctx->bam_hint_host), 64, hipHostMallocMapped) == hipSuccess)
+                *ctx->bam_hint_host = 0;
+            else
+                ctx->bam_hint_host = nullptr;
+        }
+        if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, Upk, info_bam,
+                                         ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq)))
+            return rc;
     }
-    if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, Upk, info_bam,
-                                     ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq)))
-        return rc;
-    // T1 = M1^T Vw, then Zw = L^-1 (Wq + T1) by the 16-lanes-per-column substitution; its mean output (mu0 = xbar = 0) is
-    // r1 (wg + Vw^T vg - Zw^T zg) = r1 h, written as row 2n of Ft
-    if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, M1T, n, nullptr, 1.0, Ft, D, ctx->pp, &kc))) return rc;
-    if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, T1 + (size_t)n * D, D))) return rc;
-    hipLaunchKernelGGL(k_bam_forward16, dim3((D + 15) / 16), dim3(256), 0, st, D, n, Wq, Upk, Ldinv, Ldinv + n, Ldinv + 2 * n,
-                       zerov, zerov, reg, Ft, T1, Ft + (size_t)n2 * D);
-    if ((rc = gsmvi_panel_product_out(ctx, st, D, D, n2 + 1, Ft, D, nullptr, 1.0, F0, ldf0, nullptr, Tm, D))) return rc;
+    // Zw = L^-1 (Wq + M1^T Vw) by the 16-lanes-per-column substitution (M1^T Vw formed inside); its mean output
+    // (mu0 = xbar = 0) is r1 (wg + Vw^T vg - Zw^T zg) = r1 h, written as row 2n of Ft
+    hipLaunchKernelGGL(k_bam_forward16<true>, dim3((D + 15) / 16), dim3(256), 0, st, D, n, Wq, M1, Upk, Ldinv, Ldinv + n,
+                       Ldinv + 2 * n, zerov, zerov, reg, Ft, T1, Ft + (size_t)n2 * D);
     ctx->fo_Rt = Ft;
     ctx->fo_Tm = Tm;
     ctx->fo_Fs = Fsf;
-    rc = gsmvi_factor_back_signed(ctx, st, D, n, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev);
+    int kcg = 1;
+    rc = gsmvi_factor_signed_gram(ctx, st, D, n, &kcg);                 // Gram slabs of [Vw; Zw]; their finish rides on ...
+    if (!rc) rc = gsmvi_panel_product_out(ctx, st, D, D, n2 + 1, Ft, D, nullptr, 1.0, F0, ldf0, nullptr, Tm, D);   // ... this
+    const int finished = ctx->px_used;
+    ctx->px = gsmvi_panel_extras();
+    if (!rc)
+        rc = gsmvi_factor_signed_back(ctx, st, D, n, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, kcg, finished);
     ctx->fo_Rt = ctx->fo_Tm = ctx->fo_Fs = nullptr;
     if (rc) return rc;
     hipLaunchKernelGGL(k_bamf_commit, dim3((D + 255) / 256), dim3(256), 0, st, D, Tm + (size_t)n2 * D, mu0, xbar, reg, info_dev,

@@ -22,6 +22,7 @@
 #include "gsmvi_common.h"
 #include "gsmvi_ctx.h"
 #include "gsmvi_chol64.h"
+#include "gsmvi_chol64b.h"
 #include "../../include/gsmvi_hip.h"
 
 #define BAMS_NMAX 129                // largest n of the one-workgroup Cholesky k_bam_chol_out; above it: blocked potrf + k_bam_post_big
@@ -541,6 +542,266 @@ __global__ __launch_bounds__(1024) void k_bam_post_big(int n, double reg, const 
         }
     }
     if (tid < n) zg[tid] = av[tid];
+}
+
+// ---- n <= 48: the WHOLE small chain in one workgroup (round 3) ---------------------------------------------------------
+// From the split-K slabs of the stacked Gram product [N0; M1] to everything the substitution kernel consumes: slab sum,
+// N = M1^T M1 + sym(N0), the scaled Newton-Schulz iteration (same recurrence, same product order as k_bam_ns_small), BB, its
+// Cholesky factor (chol64_blk, gsmvi_chol64b.h) and the small outputs -- one launch instead of finish + nmat + iteration +
+// Cholesky (4 launches, 77 + 10 us at n = 32).  fp64 MFMA throughput of ONE CU is the bound of the iteration (a 16x16x4 fp64
+// MFMA occupies a SIMD for ~107 cycles): only the nb x nb blocks that exist are computed (the round-2 kernel always ran nine
+// waves over a 3 x 3 block grid), dealt to the eight waves so that they spread over the four SIMDs.
+// Slab element (r, c) of slab k: slabs[k * slab_stride + r * ldslab + c], rows 0..n-1 = N0, rows n..2n-1 = M1.
+// Outputs: M1g (n x n finished M1), Ld (n x n lower), Ldinv, zg, vg behind it, Upk (packed rows of R), *info.
+#define BAMQ_SN 48
+#define BAMQ_LD 50
+#define BAMQ_ES 82
+__global__ __launch_bounds__(512) void k_bam_small48(int n, double reg, const double* __restrict__ slabs, int kc, int ldslab,
+                                                     long long slab_stride, double* __restrict__ M1g,
+                                                     double* __restrict__ Ld, double* __restrict__ Upk,
+                                                     int* __restrict__ info) {
+    constexpr int MSZ = BAMQ_SN * BAMQ_LD;                   // 2400 doubles per matrix
+    __shared__ __attribute__((aligned(16))) double sm[7 * MSZ];
+    __shared__ __attribute__((aligned(16))) double scr[CHOLB_SCRATCH_DOUBLES(0)];
+    __shared__ double coefs[BAMS_KMAX + 4], n0c[BAMQ_SN], sc[BAMQ_SN], av[BAMQ_SN], red[8];
+    __shared__ int sh_fail, sh_bad;
+    double* Ms = sm + 4 * MSZ;
+    double* M1s = sm + 5 * MSZ;
+    double* Nm = sm + 6 * MSZ;
+    double* E = sm + 2 * MSZ;                                // 64 x 82 over Z0, Z1, Ms once the iteration is done (5248 <= 7200)
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
+    const int nb = (n + 15) >> 4, nk = (n + 3) >> 2, nblocks = nb * nb;
+    for (int e = tid; e < 7 * MSZ; e += 512) sm[e] = 0.0;
+    if (tid == 0) sh_bad = 0;
+    __syncthreads();
+    // slab sums: N0 -> Ms (temporarily), M1 -> M1s and out
+    for (int e0 = 0; e0 < 2 * n * n; e0 += 512 * 4) {
+        double t[4][GSMVI_MAX_KC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int e = e0 + 512 * u + tid;
+            if (e >= 2 * n * n) e = 2 * n * n - 1;
+            const int r = e / n, c = e - r * n;
+#pragma unroll
+            for (int k = 0; k < GSMVI_MAX_KC; ++k)
+                t[u][k] = slabs[(size_t)(k < kc ? k : kc - 1) * slab_stride + (size_t)r * ldslab + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 512 * u + tid;
+            if (e < 2 * n * n) {
+                const int r = e / n, c = e - r * n;
+                double a = 0.0;
+#pragma unroll
+                for (int k = 0; k < GSMVI_MAX_KC; ++k) a += (k < kc) ? t[u][k] : 0.0;
+                if (r < n) Ms[r * BAMQ_LD + c] = a;
+                else {
+                    M1s[(r - n) * BAMQ_LD + c] = a;
+                    M1g[(size_t)(r - n) * n + c] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < n) n0c[tid] = Ms[tid * BAMQ_LD + n - 1];
+    // N = M1^T M1 + sym(N0)
+    for (int blk = w; blk < nblocks; blk += 8) {
+        const int i0 = 16 * (blk / nb), j0 = 16 * (blk % nb);
+        v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        for (int st = 0; st < nk; st += 2) {
+            const int k0 = 4 * st + ks, k1 = k0 + 4;         // (k1 may run into the zero padding: rows < 48 + 4 stay inside sm)
+            acc0 = GSMVI_MFMA_F64(M1s[k0 * BAMQ_LD + i0 + cc], M1s[k0 * BAMQ_LD + j0 + cc], acc0);
+            if (st + 1 < nk) acc1 = GSMVI_MFMA_F64(M1s[k1 * BAMQ_LD + i0 + cc], M1s[k1 * BAMQ_LD + j0 + cc], acc1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + ks + 4 * r, j = j0 + cc;
+            if (i < n && j < n) Nm[i * BAMQ_LD + j] = (acc0[r] + acc1[r]) + 0.5 * (Ms[i * BAMQ_LD + j] + Ms[j * BAMQ_LD + i]);
+        }
+    }
+    __syncthreads();
+    {   // s = trace(N + I/4)
+        double tr = (tid < n) ? Nm[tid * BAMQ_LD + tid] + 0.25 : 0.0;
+        tr = wave_sum(tr);
+        if (l == 0) red[w] = tr;
+    }
+    __syncthreads();
+    const double s = red[0];                                 // n <= 48: the first wave holds every diagonal entry
+    const double sinv = 1.0 / s;
+    for (int e = tid; e < BAMQ_SN * BAMQ_SN; e += 512) {
+        const int i = e / BAMQ_SN, j = e - i * BAMQ_SN;
+        const bool in = i < n && j < n;
+        sm[i * BAMQ_LD + j] = in ? (Nm[i * BAMQ_LD + j] + (i == j ? 0.25 : 0.0)) * sinv : 0.0;
+        sm[2 * MSZ + i * BAMQ_LD + j] = (in && i == j) ? 1.0 : 0.0;
+        Ms[i * BAMQ_LD + j] = 0.0;
+    }
+    if (tid == 0) {                                          // the scaling recurrence (k_bam_ns_prep)
+        double lb = 0.25 * sinv;
+        const bool s_ok = (s == s) && s > 0.0 && s < 1e300;
+        if (!(lb > 0.0) || lb > 1.0) lb = 1.0;
+        int kstar = BAMS_KMAX + 1;
+        for (int k = 0; k < BAMS_KMAX; ++k) {
+            const double c2 = (lb < 0.25) ? 3.0 / (1.0 + sqrt(lb) + lb) : 1.0;
+            coefs[k] = c2;
+            const double x = c2 * lb;
+            lb = x * (3.0 - x) * (3.0 - x) * 0.25;
+            if (lb > 1.0) lb = 1.0;
+            if (1.0 - lb < 5e-9 && kstar > BAMS_KMAX) kstar = k + 2;
+        }
+        coefs[BAMS_KMAX + 1] = (!s_ok || kstar > BAMS_KMAX) ? 1.0 : 0.0;
+        if (kstar > BAMS_KMAX) kstar = BAMS_KMAX;
+        coefs[BAMS_KMAX] = (double)kstar;
+    }
+    __syncthreads();
+    const int kstar = (int)coefs[BAMS_KMAX];
+    const bool failed = coefs[BAMS_KMAX + 1] != 0.0;
+    constexpr int NST = BAMQ_SN / 4;
+    for (int k = 0; k < kstar && !failed; ++k) {
+        const double* Y = sm + (k & 1) * MSZ;
+        const double* Z = sm + (2 + (k & 1)) * MSZ;
+        double* Yo = sm + ((k & 1) ^ 1) * MSZ;
+        double* Zo = sm + (2 + ((k & 1) ^ 1)) * MSZ;
+        const double c2 = coefs[k], c = sqrt(c2);
+        for (int blk = w; blk < nblocks; blk += 8) {         // M = Z Y
+            const int i0 = 16 * (blk / nb), j0 = 16 * (blk % nb);
+            double a[NST], b[NST];
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                const int kk = 4 * st + ks;
+                a[st] = Z[(i0 + cc) * BAMQ_LD + kk];
+                b[st] = Y[kk * BAMQ_LD + j0 + cc];
+            }
+            v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int st = 0; st < NST; st += 2) {
+                if (st < nk) {
+                    acc0 = GSMVI_MFMA_F64(a[st], b[st], acc0);
+                    acc1 = GSMVI_MFMA_F64(a[st + 1], b[st + 1], acc1);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ms[(i0 + ks + 4 * r) * BAMQ_LD + j0 + cc] = acc0[r] + acc1[r];
+        }
+        __syncthreads();
+        for (int blk = w; blk < nblocks; blk += 8) {         // Y' = c Y T,  Z' = c T Z,  T = 1.5 I - 0.5 c2 M
+            const int i0 = 16 * (blk / nb), j0 = 16 * (blk % nb);
+            double ya[NST], tb[NST], ta[NST], zb[NST];
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                const int kk = 4 * st + ks;
+                tb[st] = (kk == j0 + cc ? 1.5 : 0.0) - 0.5 * c2 * Ms[kk * BAMQ_LD + j0 + cc];
+                ta[st] = (kk == i0 + cc ? 1.5 : 0.0) - 0.5 * c2 * Ms[(i0 + cc) * BAMQ_LD + kk];
+                ya[st] = Y[(i0 + cc) * BAMQ_LD + kk];
+                zb[st] = Z[kk * BAMQ_LD + j0 + cc];
+            }
+            v4d ay0 = {0.0, 0.0, 0.0, 0.0}, ay1 = ay0, az0 = ay0, az1 = ay0;
+#pragma unroll
+            for (int st = 0; st < NST; st += 2) {
+                if (st < nk) {
+                    ay0 = GSMVI_MFMA_F64(ya[st], tb[st], ay0);
+                    az0 = GSMVI_MFMA_F64(ta[st], zb[st], az0);
+                    ay1 = GSMVI_MFMA_F64(ya[st + 1], tb[st + 1], ay1);
+                    az1 = GSMVI_MFMA_F64(ta[st + 1], zb[st + 1], az1);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Yo[(i0 + ks + 4 * r) * BAMQ_LD + j0 + cc] = c * (ay0[r] + ay1[r]);
+                Zo[(i0 + ks + 4 * r) * BAMQ_LD + j0 + cc] = c * (az0[r] + az1[r]);
+            }
+        }
+        __syncthreads();
+    }
+    // BB = N + I/2 + sqrt(s) sym(Y) -> E (upper triangle, identity beyond n), then its Cholesky factor
+    {
+        const double* Yf = sm + (kstar & 1) * MSZ;
+        const double rs = sqrt(s);
+        int nan_in = failed ? 1 : 0;
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                        // (E overlays Z and Ms, both dead; Y, Nm are not overlaid)
+            const int e = tid + 512 * u, i = e >> 6, j = e & 63;
+            const bool in = i < n && j < n;
+            double x = (i == j) ? 1.0 : 0.0;
+            if (in) {
+                x = Nm[i * BAMQ_LD + j] + (i == j ? 0.5 : 0.0) + rs * 0.5 * (Yf[i * BAMQ_LD + j] + Yf[j * BAMQ_LD + i]);
+                if (!(x == x)) nan_in = 1;
+                if (j < i) x = 0.0;
+            }
+            v[u] = x;
+        }
+        __syncthreads();                                     // every read of the iterates' last products is done
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 512 * u, i = e >> 6, j = e & 63;
+            E[i * BAMQ_ES + j] = v[u];
+        }
+        if (nan_in) sh_bad = 1;
+    }
+    __syncthreads();
+    chol64_blk<BAMQ_ES, false, 0>(E, scr, n, &sh_fail);
+    // vg = Vf gbar = M1[:, n-1] / r1s,  a = P gbar + M1^T vg (bam.py:107 applied to gbar)
+    const double r1s = sqrt(reg / (1.0 + reg));
+    if (tid < n) sc[tid] = M1s[tid * BAMQ_LD + n - 1] / r1s;
+    __syncthreads();
+    if (tid < n) {
+        double a0 = n0c[tid] / r1s, a1 = 0.0;
+        int kk = 0;
+        for (; kk + 1 < n; kk += 2) {
+            a0 += M1s[kk * BAMQ_LD + tid] * sc[kk];
+            a1 += M1s[(kk + 1) * BAMQ_LD + tid] * sc[kk + 1];
+        }
+        if (kk < n) a0 += M1s[kk * BAMQ_LD + tid] * sc[kk];
+        av[tid] = a0 + a1;
+    }
+    __syncthreads();
+    double* Ldinv = Ld + (size_t)n * n;
+    double* zg = Ldinv + n;
+    double* vg = zg + n;
+    const int bad = sh_bad || sh_fail != 0;
+    if (tid == 0) *info = bad;
+    const size_t npk = (size_t)n * (n + 1) / 2;
+    if (bad) {                                               // poison: nothing stale may be applied
+        const double qn = __longlong_as_double(0x7ff8000000000000LL);
+        for (size_t e = tid; e < (size_t)n * n + 3 * n; e += 512) Ld[e] = qn;
+        for (size_t e = tid; e < npk; e += 512) Upk[e] = qn;
+        return;
+    }
+    for (int e = tid; e < n * n; e += 512) {
+        const int i = e / n, j = e - i * n;                  // L[i][j] = R[j][i], j <= i
+        Ld[e] = (j <= i) ? E[j * BAMQ_ES + i] : 0.0;
+        if (j >= i) Upk[(size_t)i * n - ((size_t)i * (i - 1)) / 2 - i + j] = E[i * BAMQ_ES + j];
+    }
+    if (tid < n) {
+        Ldinv[tid] = 1.0 / E[tid * BAMQ_ES + tid];
+        vg[tid] = sc[tid];
+    }
+    if (tid < 64) {                                          // zg = L^-1 a, L = R^T: one wave, one row per lane
+        double a0 = (tid < n) ? av[tid] : 0.0;
+        const double rinv = 1.0 / E[(tid < n ? tid : 0) * BAMQ_ES + (tid < n ? tid : 0)];
+        for (int pp = 0; pp < n; ++pp) {
+            const double zk = __shfl(a0 * rinv, pp, 64);
+            if (tid == pp) a0 = zk;
+            const double r0 = E[pp * BAMQ_ES + tid];
+            if (tid > pp) a0 -= r0 * zk;
+        }
+        if (tid < n) zg[tid] = a0;
+    }
+}
+
+int gsmvi_bam_small_fused_nmax() { return BAMQ_SN; }
+
+// n <= 48: slabs of [N0; M1] in, everything out (see k_bam_small48)
+int gsmvi_bam_small_fused(hipStream_t st, int n, double reg, const double* slabs, int kc, int ldslab, size_t slab_stride,
+                          double* M1, double* Ld, double* Upk, int* info_dev) {
+    hipLaunchKernelGGL(k_bam_small48, dim3(1), dim3(512), 0, st, n, reg, slabs, kc, ldslab, (long long)slab_stride, M1, Ld, Upk,
+                       info_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        gsmvi_set_error("BaM small-matrix launch failed: %s%s", hipGetErrorString(e), "");
+        return GSMVI_ERR_HIP;
+    }
+    return GSMVI_OK;
 }
 
 int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,

@@ -1252,14 +1252,28 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
 
 // Factor-form BaM (gsmvi_bam.hip): Rt = [Vw; Zw] and Tm = Rt Fm (2 Bh rows each) are in the panels named by ctx->fo_Rt / fo_Tm;
 // F = F0 + Rt^T K Tm with M = I + Vw^T Vw - Zw^T Zw = C^T C (J = diag(I, -I)).  mu receives mu0: the caller owns BaM's mean.
-int gsmvi_factor_back_signed(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, const double* mu0, const double* F0, int ldf0,
-                             double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev) {
+// Two calls with the caller's Rt Fm product between them: _gram launches the Gram product and arms the finish of its slabs
+// as a side job of the NEXT fast panel launch (the one-workgroup chain would pull the slabs through a single CU otherwise);
+// _back takes the finished matrix if that launch took the job (ctx->px_used), else the slabs.
+int gsmvi_factor_signed_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, int* kcg) {
     const int n = 2 * Bh;
     const factor_ws w = factor_carve(ctx, D, n);
-    int kcg = 1;
-    int rc = factor_gram(ctx, st, D, n, w, &kcg);
+    int rc = factor_gram(ctx, st, D, n, w, kcg);
     if (rc) return rc;
-    return factor_back(ctx, st, D, Bh, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, w.Gp, kcg, nullptr, 0, 1);
+    if (*kcg > 1) {
+        ctx->px.sj_src = w.Gp;
+        ctx->px.sj_kc = *kcg;
+        ctx->px.sj_stride = (size_t)n * n;
+        ctx->px.sj_len = n * n;
+        ctx->px.sj_dst = w.Gam1;
+    }
+    return GSMVI_OK;
+}
+int gsmvi_factor_signed_back(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, const double* mu0, const double* F0, int ldf0,
+                             double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, int kcg, int finished) {
+    const factor_ws w = factor_carve(ctx, D, 2 * Bh);
+    return factor_back(ctx, st, D, Bh, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, (kcg > 1 && finished) ? w.Gam1 : w.Gp,
+                       finished ? 1 : kcg, nullptr, 0, 1);
 }
 
 // Batch-sharded form, stage 1: this rank's B_local samples -> records.
