@@ -483,8 +483,8 @@ int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, co
 int gsmvi_bam_small_nmax();
 size_t gsmvi_bam_small_scratch_doubles(int n);
 int gsmvi_bam_small_fused_nmax();
-int gsmvi_bam_small_fused(hipStream_t st, int n, double reg, const double* slabs, int kc, int ldslab, size_t slab_stride,
-                          double* M1, double* Ld, double* Upk, int* info_dev);
+int gsmvi_bam_small_fused(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* slabs, int kc, int ldslab,
+                          size_t slab_stride, double* M1, double* Ld, double* Upk, int* info_dev);
 
 int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X, int ldx, const double* G,
                    int ldg, const double* mu0, const double* S0, int lds0, double reg, double jitter, double* mu,
@@ -520,7 +520,7 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     const double* Ldinv = Ld + (size_t)n * n;
     if (n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full) {
         // n <= 48: slab sum, N, the matrix function, its Cholesky factor and the small outputs in ONE one-workgroup launch
-        if ((rc = gsmvi_bam_small_fused(st, n, reg, ctx->pp, kc, nq, (size_t)n2 * nq, M1, Ld, Upk,
+        if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, nq, (size_t)n2 * nq, M1, Ld, Upk,
                                         info_dev ? info_dev : ctx->ints + 8)))
             return rc;
     } else {
@@ -696,7 +696,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, Wq, D))) return rc;
     if ((rc = gsmvi_panel_t_product(ctx, st, D, n2, Wq, D, Wq, D, n, ctx->pp, &kc))) return rc;
     if (n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full) {
-        if ((rc = gsmvi_bam_small_fused(st, n, reg, ctx->pp, kc, n, (size_t)n2 * n, M1, Ld, Upk, info_bam))) return rc;
+        if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, n, (size_t)n2 * n, M1, Ld, Upk, info_bam))) return rc;
     } else {
         if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
         hipLaunchKernelGGL(k_bam_nmat, dim3((n * n + 255) / 256), dim3(256), 0, st, n, M1, N0, Nd, M1T);

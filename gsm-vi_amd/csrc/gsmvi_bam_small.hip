@@ -556,10 +556,17 @@ __global__ __launch_bounds__(1024) void k_bam_post_big(int n, double reg, const 
 #define BAMQ_SN 48
 #define BAMQ_LD 50
 #define BAMQ_ES 82
+template <int NB>
 __global__ __launch_bounds__(512) void k_bam_small48(int n, double reg, const double* __restrict__ slabs, int kc, int ldslab,
                                                      long long slab_stride, double* __restrict__ M1g,
                                                      double* __restrict__ Ld, double* __restrict__ Upk,
-                                                     int* __restrict__ info) {
+                                                     int* __restrict__ info, unsigned long long* __restrict__ stamps) {
+#define Q_STAMP(k)                                                                          \
+    do {                                                                                    \
+        if (stamps && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memrealtime();        \
+    } while (0)
+    Q_STAMP(0);
+    if (stamps && (threadIdx.x & 63) == 0) stamps[8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg(2308);   // HW_ID.SIMD_ID
     constexpr int MSZ = BAMQ_SN * BAMQ_LD;                   // 2400 doubles per matrix
     __shared__ __attribute__((aligned(16))) double sm[7 * MSZ];
     __shared__ __attribute__((aligned(16))) double scr[CHOLB_SCRATCH_DOUBLES(0)];
@@ -570,7 +577,8 @@ __global__ __launch_bounds__(512) void k_bam_small48(int n, double reg, const do
     double* Nm = sm + 6 * MSZ;
     double* E = sm + 2 * MSZ;                                // 64 x 82 over Z0, Z1, Ms once the iteration is done (5248 <= 7200)
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
-    const int nb = (n + 15) >> 4, nk = (n + 3) >> 2, nblocks = nb * nb;
+    constexpr int nb = NB, nblocks = NB * NB;              // NB = ceil(n / 16): the block grid is a compile-time shape
+    const int nk = (n + 3) >> 2;
     for (int e = tid; e < 7 * MSZ; e += 512) sm[e] = 0.0;
     if (tid == 0) sh_bad = 0;
     __syncthreads();
@@ -603,7 +611,12 @@ __global__ __launch_bounds__(512) void k_bam_small48(int n, double reg, const do
         }
     }
     __syncthreads();
-    if (tid < n) n0c[tid] = Ms[tid * BAMQ_LD + n - 1];
+    Q_STAMP(1);
+    const double r1s = sqrt(reg / (1.0 + reg));
+    if (tid < n) {
+        n0c[tid] = Ms[tid * BAMQ_LD + n - 1];
+        sc[tid] = M1s[tid * BAMQ_LD + n - 1] / r1s;          // vg = Vf gbar = M1[:, n-1] / r1s
+    }
     // N = M1^T M1 + sym(N0)
     for (int blk = w; blk < nblocks; blk += 8) {
         const int i0 = 16 * (blk / nb), j0 = 16 * (blk % nb);
@@ -619,14 +632,44 @@ __global__ __launch_bounds__(512) void k_bam_small48(int n, double reg, const do
             if (i < n && j < n) Nm[i * BAMQ_LD + j] = (acc0[r] + acc1[r]) + 0.5 * (Ms[i * BAMQ_LD + j] + Ms[j * BAMQ_LD + i]);
         }
     }
-    __syncthreads();
-    {   // s = trace(N + I/4)
-        double tr = (tid < n) ? Nm[tid * BAMQ_LD + tid] + 0.25 : 0.0;
+    if (w == 7) {
+        // meanwhile, on the last wave: s = trace(N + I/4) = ||M1||_F^2 + trace(N0) + n/4 straight from the operands, and the
+        // scalar scaling recurrence (k_bam_ns_prep) -- ~120 ns per step of one lane, stopped at k*
+        double tr = 0.0;
+        if (l < n) {
+            double t0 = Ms[l * BAMQ_LD + l] + 0.25, t1 = 0.0;
+            for (int k = 0; k + 1 < n; k += 2) {
+                const double m0 = M1s[k * BAMQ_LD + l], m1 = M1s[(k + 1) * BAMQ_LD + l];
+                t0 = __builtin_fma(m0, m0, t0);
+                t1 = __builtin_fma(m1, m1, t1);
+            }
+            if (n & 1) { const double m0 = M1s[(n - 1) * BAMQ_LD + l]; t0 = __builtin_fma(m0, m0, t0); }
+            tr = t0 + t1;
+        }
         tr = wave_sum(tr);
-        if (l == 0) red[w] = tr;
+        if (l == 0) {
+            const double s0 = tr;
+            red[0] = s0;
+            double lb = 0.25 / s0;
+            const bool s_ok = (s0 == s0) && s0 > 0.0 && s0 < 1e300;
+            if (!(lb > 0.0) || lb > 1.0) lb = 1.0;
+            int kst = BAMS_KMAX + 1;
+            for (int k = 0; k < BAMS_KMAX; ++k) {
+                const double c2 = (lb < 0.25) ? 3.0 / (1.0 + sqrt(lb) + lb) : 1.0;
+                coefs[k] = c2;
+                const double x = c2 * lb;
+                lb = x * (3.0 - x) * (3.0 - x) * 0.25;
+                if (lb > 1.0) lb = 1.0;
+                if (1.0 - lb < 5e-9 && kst > BAMS_KMAX) kst = k + 2;
+                if (k + 1 >= kst) break;                     // coefs[0 .. k*-1] are all the iteration reads
+            }
+            coefs[BAMS_KMAX + 1] = (!s_ok || kst > BAMS_KMAX) ? 1.0 : 0.0;
+            if (kst > BAMS_KMAX) kst = BAMS_KMAX;
+            coefs[BAMS_KMAX] = (double)kst;
+        }
     }
     __syncthreads();
-    const double s = red[0];                                 // n <= 48: the first wave holds every diagonal entry
+    const double s = red[0];
     const double sinv = 1.0 / s;
     for (int e = tid; e < BAMQ_SN * BAMQ_SN; e += 512) {
         const int i = e / BAMQ_SN, j = e - i * BAMQ_SN;
@@ -635,83 +678,90 @@ __global__ __launch_bounds__(512) void k_bam_small48(int n, double reg, const do
         sm[2 * MSZ + i * BAMQ_LD + j] = (in && i == j) ? 1.0 : 0.0;
         Ms[i * BAMQ_LD + j] = 0.0;
     }
-    if (tid == 0) {                                          // the scaling recurrence (k_bam_ns_prep)
-        double lb = 0.25 * sinv;
-        const bool s_ok = (s == s) && s > 0.0 && s < 1e300;
-        if (!(lb > 0.0) || lb > 1.0) lb = 1.0;
-        int kstar = BAMS_KMAX + 1;
-        for (int k = 0; k < BAMS_KMAX; ++k) {
-            const double c2 = (lb < 0.25) ? 3.0 / (1.0 + sqrt(lb) + lb) : 1.0;
-            coefs[k] = c2;
-            const double x = c2 * lb;
-            lb = x * (3.0 - x) * (3.0 - x) * 0.25;
-            if (lb > 1.0) lb = 1.0;
-            if (1.0 - lb < 5e-9 && kstar > BAMS_KMAX) kstar = k + 2;
+    if (tid < n) {                                           // a = P gbar + M1^T vg (bam.py:107 applied to gbar)
+        double a0 = n0c[tid] / r1s, a1 = 0.0;
+        int kk = 0;
+        for (; kk + 1 < n; kk += 2) {
+            a0 += M1s[kk * BAMQ_LD + tid] * sc[kk];
+            a1 += M1s[(kk + 1) * BAMQ_LD + tid] * sc[kk + 1];
         }
-        coefs[BAMS_KMAX + 1] = (!s_ok || kstar > BAMS_KMAX) ? 1.0 : 0.0;
-        if (kstar > BAMS_KMAX) kstar = BAMS_KMAX;
-        coefs[BAMS_KMAX] = (double)kstar;
+        if (kk < n) a0 += M1s[kk * BAMQ_LD + tid] * sc[kk];
+        av[tid] = a0 + a1;
     }
     __syncthreads();
+    Q_STAMP(2);
     const int kstar = (int)coefs[BAMS_KMAX];
     const bool failed = coefs[BAMS_KMAX + 1] != 0.0;
-    constexpr int NST = BAMQ_SN / 4;
+    constexpr int NST = 4 * NB;                              // k-steps of a product (the last up to three may be zero padding)
+    // One step = two barrier intervals.  A wave owns block w (and wave 0 block 8 when nb = 3).  The Y- and Z-operands of the
+    // second interval do not depend on M, so they are fetched during the first one, behind its MFMAs.
     for (int k = 0; k < kstar && !failed; ++k) {
         const double* Y = sm + (k & 1) * MSZ;
         const double* Z = sm + (2 + (k & 1)) * MSZ;
         double* Yo = sm + ((k & 1) ^ 1) * MSZ;
         double* Zo = sm + (2 + ((k & 1) ^ 1)) * MSZ;
         const double c2 = coefs[k], c = sqrt(c2);
-        for (int blk = w; blk < nblocks; blk += 8) {         // M = Z Y
-            const int i0 = 16 * (blk / nb), j0 = 16 * (blk % nb);
-            double a[NST], b[NST];
+        constexpr int NSLOT = (NB * NB > 8) ? 2 : 1;
+        double ya[NSLOT][NST], zb[NSLOT][NST];
 #pragma unroll
-            for (int st = 0; st < NST; ++st) {
-                const int kk = 4 * st + ks;
-                a[st] = Z[(i0 + cc) * BAMQ_LD + kk];
-                b[st] = Y[kk * BAMQ_LD + j0 + cc];
-            }
-            v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        for (int slot = 0; slot < NSLOT; ++slot) {           // M = Z Y
+            const int blk = w + 8 * slot;
+            if (blk < nblocks) {                             // wave-uniform
+                const int i0 = 16 * (blk / nb), j0 = 16 * (blk % nb);
+                double a[NST], b[NST];
 #pragma unroll
-            for (int st = 0; st < NST; st += 2) {
-                if (st < nk) {
+                for (int st = 0; st < NST; ++st) {
+                    const int kk = 4 * st + ks;
+                    a[st] = Z[(i0 + cc) * BAMQ_LD + kk];
+                    b[st] = Y[kk * BAMQ_LD + j0 + cc];
+                }
+#pragma unroll
+                for (int st = 0; st < NST; ++st) {
+                    const int kk = 4 * st + ks;
+                    ya[slot][st] = Y[(i0 + cc) * BAMQ_LD + kk];
+                    zb[slot][st] = Z[kk * BAMQ_LD + j0 + cc];
+                }
+                v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int st = 0; st < NST; st += 2) {
                     acc0 = GSMVI_MFMA_F64(a[st], b[st], acc0);
                     acc1 = GSMVI_MFMA_F64(a[st + 1], b[st + 1], acc1);
                 }
-            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Ms[(i0 + ks + 4 * r) * BAMQ_LD + j0 + cc] = acc0[r] + acc1[r];
+                for (int r = 0; r < 4; ++r) Ms[(i0 + ks + 4 * r) * BAMQ_LD + j0 + cc] = acc0[r] + acc1[r];
+            }
         }
         __syncthreads();
-        for (int blk = w; blk < nblocks; blk += 8) {         // Y' = c Y T,  Z' = c T Z,  T = 1.5 I - 0.5 c2 M
-            const int i0 = 16 * (blk / nb), j0 = 16 * (blk % nb);
-            double ya[NST], tb[NST], ta[NST], zb[NST];
 #pragma unroll
-            for (int st = 0; st < NST; ++st) {
-                const int kk = 4 * st + ks;
-                tb[st] = (kk == j0 + cc ? 1.5 : 0.0) - 0.5 * c2 * Ms[kk * BAMQ_LD + j0 + cc];
-                ta[st] = (kk == i0 + cc ? 1.5 : 0.0) - 0.5 * c2 * Ms[(i0 + cc) * BAMQ_LD + kk];
-                ya[st] = Y[(i0 + cc) * BAMQ_LD + kk];
-                zb[st] = Z[kk * BAMQ_LD + j0 + cc];
-            }
-            v4d ay0 = {0.0, 0.0, 0.0, 0.0}, ay1 = ay0, az0 = ay0, az1 = ay0;
+        for (int slot = 0; slot < NSLOT; ++slot) {           // Y' = c Y T,  Z' = c T Z,  T = 1.5 I - 0.5 c2 M
+            const int blk = w + 8 * slot;
+            if (blk < nblocks) {
+                const int i0 = 16 * (blk / nb), j0 = 16 * (blk % nb);
+                double tb[NST], ta[NST];
 #pragma unroll
-            for (int st = 0; st < NST; st += 2) {
-                if (st < nk) {
-                    ay0 = GSMVI_MFMA_F64(ya[st], tb[st], ay0);
-                    az0 = GSMVI_MFMA_F64(ta[st], zb[st], az0);
-                    ay1 = GSMVI_MFMA_F64(ya[st + 1], tb[st + 1], ay1);
-                    az1 = GSMVI_MFMA_F64(ta[st + 1], zb[st + 1], az1);
+                for (int st = 0; st < NST; ++st) {
+                    const int kk = 4 * st + ks;
+                    tb[st] = (kk == j0 + cc ? 1.5 : 0.0) - 0.5 * c2 * Ms[kk * BAMQ_LD + j0 + cc];
+                    ta[st] = (kk == i0 + cc ? 1.5 : 0.0) - 0.5 * c2 * Ms[(i0 + cc) * BAMQ_LD + kk];
                 }
-            }
+                v4d ay0 = {0.0, 0.0, 0.0, 0.0}, ay1 = ay0, az0 = ay0, az1 = ay0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                Yo[(i0 + ks + 4 * r) * BAMQ_LD + j0 + cc] = c * (ay0[r] + ay1[r]);
-                Zo[(i0 + ks + 4 * r) * BAMQ_LD + j0 + cc] = c * (az0[r] + az1[r]);
+                for (int st = 0; st < NST; st += 2) {
+                    ay0 = GSMVI_MFMA_F64(ya[slot][st], tb[st], ay0);
+                    az0 = GSMVI_MFMA_F64(ta[st], zb[slot][st], az0);
+                    ay1 = GSMVI_MFMA_F64(ya[slot][st + 1], tb[st + 1], ay1);
+                    az1 = GSMVI_MFMA_F64(ta[st + 1], zb[slot][st + 1], az1);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    Yo[(i0 + ks + 4 * r) * BAMQ_LD + j0 + cc] = c * (ay0[r] + ay1[r]);
+                    Zo[(i0 + ks + 4 * r) * BAMQ_LD + j0 + cc] = c * (az0[r] + az1[r]);
+                }
             }
         }
         __syncthreads();
     }
+    Q_STAMP(3);
     // BB = N + I/2 + sqrt(s) sym(Y) -> E (upper triangle, identity beyond n), then its Cholesky factor
     {
         const double* Yf = sm + (kstar & 1) * MSZ;
@@ -730,7 +780,6 @@ __global__ __launch_bounds__(512) void k_bam_small48(int n, double reg, const do
             }
             v[u] = x;
         }
-        __syncthreads();                                     // every read of the iterates' last products is done
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = tid + 512 * u, i = e >> 6, j = e & 63;
@@ -739,22 +788,9 @@ __global__ __launch_bounds__(512) void k_bam_small48(int n, double reg, const do
         if (nan_in) sh_bad = 1;
     }
     __syncthreads();
+    Q_STAMP(4);
     chol64_blk<BAMQ_ES, false, 0>(E, scr, n, &sh_fail);
-    // vg = Vf gbar = M1[:, n-1] / r1s,  a = P gbar + M1^T vg (bam.py:107 applied to gbar)
-    const double r1s = sqrt(reg / (1.0 + reg));
-    if (tid < n) sc[tid] = M1s[tid * BAMQ_LD + n - 1] / r1s;
-    __syncthreads();
-    if (tid < n) {
-        double a0 = n0c[tid] / r1s, a1 = 0.0;
-        int kk = 0;
-        for (; kk + 1 < n; kk += 2) {
-            a0 += M1s[kk * BAMQ_LD + tid] * sc[kk];
-            a1 += M1s[(kk + 1) * BAMQ_LD + tid] * sc[kk + 1];
-        }
-        if (kk < n) a0 += M1s[kk * BAMQ_LD + tid] * sc[kk];
-        av[tid] = a0 + a1;
-    }
-    __syncthreads();
+    Q_STAMP(5);
     double* Ldinv = Ld + (size_t)n * n;
     double* zg = Ldinv + n;
     double* vg = zg + n;
@@ -767,35 +803,47 @@ __global__ __launch_bounds__(512) void k_bam_small48(int n, double reg, const do
         for (size_t e = tid; e < npk; e += 512) Upk[e] = qn;
         return;
     }
-    for (int e = tid; e < n * n; e += 512) {
-        const int i = e / n, j = e - i * n;                  // L[i][j] = R[j][i], j <= i
-        Ld[e] = (j <= i) ? E[j * BAMQ_ES + i] : 0.0;
-        if (j >= i) Upk[(size_t)i * n - ((size_t)i * (i - 1)) / 2 - i + j] = E[i * BAMQ_ES + j];
-    }
-    if (tid < n) {
-        Ldinv[tid] = 1.0 / E[tid * BAMQ_ES + tid];
-        vg[tid] = sc[tid];
-    }
-    if (tid < 64) {                                          // zg = L^-1 a, L = R^T: one wave, one row per lane
-        double a0 = (tid < n) ? av[tid] : 0.0;
-        const double rinv = 1.0 / E[(tid < n ? tid : 0) * BAMQ_ES + (tid < n ? tid : 0)];
-        for (int pp = 0; pp < n; ++pp) {
-            const double zk = __shfl(a0 * rinv, pp, 64);
-            if (tid == pp) a0 = zk;
-            const double r0 = E[pp * BAMQ_ES + tid];
-            if (tid > pp) a0 -= r0 * zk;
+    if (w == 0) {                                            // zg = L^-1 a (bam.py:110 applied to gbar), L = R^T: one row per lane,
+        double rcol[16 * NB];                                // the lane's column of R in registers: only shuffle + fma on the chain
+#pragma unroll
+        for (int pp = 0; pp < 16 * NB; ++pp) rcol[pp] = E[pp * BAMQ_ES + l];
+        const int lc = l < n ? l : 0;
+        const double dg = E[lc * BAMQ_ES + lc], rinv = 1.0 / dg;
+        double a0 = (l < n) ? av[l] : 0.0;
+#pragma unroll
+        for (int pp = 0; pp < 16 * NB; ++pp) {
+            if (pp < n) {                                    // uniform
+                const double zk = __shfl(a0 * rinv, pp, 64);
+                a0 = (l == pp) ? zk : ((l > pp) ? __builtin_fma(-rcol[pp], zk, a0) : a0);
+            }
         }
-        if (tid < n) zg[tid] = a0;
+        if (l < n) {
+            zg[l] = a0;
+            Ldinv[l] = rinv;
+            vg[l] = sc[l];
+        }
+    } else {
+        for (int e = tid - 64; e < n * n; e += 448) {
+            const int i = e / n, j = e - i * n;              // L[i][j] = R[j][i], j <= i
+            Ld[e] = (j <= i) ? E[j * BAMQ_ES + i] : 0.0;
+            if (j >= i) Upk[(size_t)i * n - ((size_t)i * (i - 1)) / 2 - i + j] = E[i * BAMQ_ES + j];
+        }
     }
+    if (stamps && tid == 0) { stamps[6] = __builtin_amdgcn_s_memrealtime(); stamps[7] = (unsigned long long)kstar; }
+#undef Q_STAMP
 }
 
 int gsmvi_bam_small_fused_nmax() { return BAMQ_SN; }
 
 // n <= 48: slabs of [N0; M1] in, everything out (see k_bam_small48)
-int gsmvi_bam_small_fused(hipStream_t st, int n, double reg, const double* slabs, int kc, int ldslab, size_t slab_stride,
-                          double* M1, double* Ld, double* Upk, int* info_dev) {
-    hipLaunchKernelGGL(k_bam_small48, dim3(1), dim3(512), 0, st, n, reg, slabs, kc, ldslab, (long long)slab_stride, M1, Ld, Upk,
-                       info_dev);
+int gsmvi_bam_small_fused(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* slabs, int kc, int ldslab,
+                          size_t slab_stride, double* M1, double* Ld, double* Upk, int* info_dev) {
+    unsigned long long* stamps = (ctx->tune_cov_dbg & 256)           // diagnostic (scripts/bam48_timeline.py): phase stamps
+                                     ? reinterpret_cast<unsigned long long*>(ctx->gram_slabs + (size_t)GSMVI_MAX_KC * ctx->rmax * ctx->rmax)
+                                     : nullptr;
+#define SMALL48(NBV) hipLaunchKernelGGL(k_bam_small48<NBV>, dim3(1), dim3(512), 0, st, n, reg, slabs, kc, ldslab, (long long)slab_stride, M1, Ld, Upk, info_dev, stamps)
+    if (n <= 16) SMALL48(1); else if (n <= 32) SMALL48(2); else SMALL48(3);
+#undef SMALL48
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         gsmvi_set_error("BaM small-matrix launch failed: %s%s", hipGetErrorString(e), "");
