@@ -661,9 +661,9 @@ __global__ __launch_bounds__(256) void k_bamf_commit(int D, const double* __rest
 
 int gsmvi_panel_t_product(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* A, int lda, const double* M,
                           int ldm, int mrows, double* Pp, int* kc_out);
-int gsmvi_factor_signed_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, int* kcg);
+int gsmvi_factor_signed_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, int* kcg, int* info_dev, int* rides);
 int gsmvi_factor_signed_back(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, const double* mu0, const double* F0, int ldf0,
-                             double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, int kcg, int finished);
+                             double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, int kcg, int rides, int taken);
 
 int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
                           const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double reg, double* mu,
@@ -717,13 +717,13 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     ctx->fo_Rt = Ft;
     ctx->fo_Tm = Tm;
     ctx->fo_Fs = Fsf;
-    int kcg = 1;
-    rc = gsmvi_factor_signed_gram(ctx, st, D, n, &kcg);                 // Gram slabs of [Vw; Zw]; their finish rides on ...
+    int kcg = 1, rides = 0;
+    rc = gsmvi_factor_signed_gram(ctx, st, D, n, &kcg, info_dev, &rides);   // Gram slabs of [Vw; Zw]; the 2B x 2B chain rides in ...
     if (!rc) rc = gsmvi_panel_product_out(ctx, st, D, D, n2 + 1, Ft, D, nullptr, 1.0, F0, ldf0, nullptr, Tm, D);   // ... this
-    const int finished = ctx->px_used;
+    const int taken = ctx->px_used;
     ctx->px = gsmvi_panel_extras();
     if (!rc)
-        rc = gsmvi_factor_signed_back(ctx, st, D, n, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, kcg, finished);
+        rc = gsmvi_factor_signed_back(ctx, st, D, n, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, kcg, rides, taken);
     ctx->fo_Rt = ctx->fo_Tm = ctx->fo_Fs = nullptr;
     if (rc) return rc;
     hipLaunchKernelGGL(k_bamf_commit, dim3((D + 255) / 256), dim3(256), 0, st, D, Tm + (size_t)n2 * D, mu0, xbar, reg, info_dev,

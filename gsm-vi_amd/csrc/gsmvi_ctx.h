@@ -24,11 +24,21 @@ struct gsmvi_panel_extras {
     size_t sj_stride = 0;
     int sj_len = 0;
     double* sj_dst = nullptr;
+    // rider (factor path, n = 2B <= 64): ONE extra workgroup of the launch -- the grid gets one more x index; its (y, z) = (0, 0)
+    // workgroup runs the 2B x 2B chain gsmf_small16_body (gsmvi_small16.h) beside the product, the others of that column exit
+    int rd_on = 0, rd_n = 0, rd_B = 0, rd_kcg = 0, rd_jmode = 0;
+    const double* rd_Gp = nullptr;
+    double *rd_Kmat = nullptr, *rd_coef = nullptr;
+    int* rd_bad = nullptr;
+    unsigned long long* rd_stamps = nullptr;
+    const int* rd_prior = nullptr;
 };
 
 struct gsmvi_ctx {
     gsmvi_panel_extras px;     // see above
     int px_used = 0;
+    int tune_gram_mt = 1;      // row-block cap of the Gram product when the chain rides (fewer split-K slabs for its one CU)
+    int tune_rider = 1;        // the 2B x 2B chain rides in the V Fm product's launch (0: its own launch, for A/B runs)
     int device = 0;
     int max_D = 0, max_B = 0;
     int num_cu = 256;

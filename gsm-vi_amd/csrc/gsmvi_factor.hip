@@ -27,6 +27,7 @@
 #include "gsmvi_ctx.h"
 #include "gsmvi_chol64.h"
 #include "gsmvi_chol64b.h"
+#include "gsmvi_small16.h"
 #include "../../include/gsmvi_hip.h"
 
 // ---- transposed panel product partials: Pp[kc][r][j] = sum_{i in chunk(kc)} A[r][i] M[j][i] ----------
@@ -200,16 +201,6 @@ __global__ __launch_bounds__(256) void k_gsmf_prep(int D, int B, int KC, const d
     Rt1[(size_t)b * D + i] = z;
     Rt1[(size_t)(B + b) * D + i] = w + z;
     Tm1[(size_t)b * D + i] = x - m;
-}
-
-// The per-sample scalars from the Gram matrix Gamma1 = [Z; V][Z; V]^T (zz = Gamma1[b][b], zv = Gamma1[b][B+b],
-// vv = Gamma1[B+b][B+b]):  u_b = beta z_b + alpha v_b  (gsm_numpy.py:8-17 in whitened form, see the file header)
-__device__ __forceinline__ void gsmf_coefs(double zz, double zv, double vv, double* alpha, double* beta) {
-    const double zw = zv - zz, ww = vv - 2.0 * zv + zz, wv = vv - zv;
-    const double rho = 0.5 * sqrt(1.0 + 4.0 * (ww + zw * zw)) - 0.5;
-    const double den = 1.0 + rho - zw;
-    *alpha = 1.0 / (1.0 + rho);
-    *beta = (wv / den) / (1.0 + rho);
 }
 
 // LDS[128][130] <- upper triangle of the n x n matrix src (n <= 128), zero below, identity beyond n.
@@ -523,252 +514,16 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const do
     }
 }
 
-// ---- everything small in ONE workgroup (n = 2B <= 64), eight waves ---------------------------------------------------
-//   Gamma -> Rg, W = Rg^-T (blocked Cholesky of [Gamma | I]) -> A' = I + Rg J Rg^T -> T (Cholesky, the PD test)
-//   -> K = Rg^-1 (T - I) Rg^-T = W^T (T - I) W.
-// Round 3: both factorisations are chol64_blk (gsmvi_chol64b.h: 16-pivot panels in one wave's registers, no workgroup
-// barrier on the pivot chain; W comes out of the augmented identity columns, so the 64-step substitution of round 2 is
-// gone); round 2's k_gsmf_small8 spent 13 + 15 us of its 39 us in two chol64_rows_s calls.
-// LDS: E1 [64][146] = [Gamma -> Rg | W], later P = (T - I) W in its left half; E2 [64][82] = A' -> T.  Padded with the
-// identity beyond n.  Gamma = Rt Rt^T is only positive SEMI-definite when rows of [Z; U] are linearly dependent (an
-// isotropic state on an isotropic target makes every u_b - a_b z_b parallel to mu - m; the exact fixed point makes U = -Z):
-// the dependent rows drop out of Rg (zero row, zero diagonal) and get a unit pivot in W, which leaves
-// C^T C = I + Rt^T J Rt intact (factor form); the rule is off (dependent => failure) when a diagonal
-// entry of Gamma reaches 2^32 (fixture G4).  *bad_out = 1 if either Cholesky fails (NaN, or M not positive definite);
-// K is then irrelevant.
-#define GSMF_ES1 146
-#define GSMF_ES2 82
-// jmode = 1 (factor-form BaM, gsmvi_bam.hip): Gp is the Gram matrix of Rt = [Vw; Zw] itself (S = I), J = diag(I_B, -I_B)
-// (M = I + Vw^T Vw - Zw^T Zw), the coefficients come out as zeros (the mean is BaM's own).
+// ---- everything small in ONE workgroup (n = 2B <= 64): gsmf_small16_body (gsmvi_small16.h) --------------------------------
+// Stand-alone launch of the chain; the lean path runs the same body as a RIDER workgroup of the V Fm panel product instead
+// (gsmvi_fast.hip, k_panel_fast<.., RIDER>), so that the product and its launch boundary hide behind the chain.
 __global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double* __restrict__ Gp, int kcg,
                                                       double* __restrict__ Kmat, double* __restrict__ coef,
                                                       int* __restrict__ bad_out,
                                                       unsigned long long* __restrict__ stamps, int jmode,
                                                       const int* __restrict__ prior_bad) {
-#define SMALL_STAMP(k)                                                                      \
-    do {                                                                                    \
-        if (stamps && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memrealtime();        \
-    } while (0)
-    SMALL_STAMP(0);
-    constexpr int ES1 = GSMF_ES1, ES2 = GSMF_ES2;
-    __shared__ __attribute__((aligned(16))) double E1[64 * ES1];
-    __shared__ __attribute__((aligned(16))) double E2[64 * ES2];
-    __shared__ __attribute__((aligned(16))) double scr[CHOLB_SCRATCH_DOUBLES(true)];
-    __shared__ double s_alpha[32], s_beta[32];
-    __shared__ int fail_g, fail_t, sh_moderate;
-    const int tid = threadIdx.x;
-    if (tid == 0) sh_moderate = 1;
-    {   // Gamma1 = sum of the kcg split-K slabs of the Gram product (n x n each, full matrix) -> E2, raw
-        double g[8];
-        if (kcg == 1) {                                // block-uniform: the finished matrix (the lean path's side job)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int e = tid + 512 * k, i = e >> 6, q = e & 63;
-                g[k] = Gp[(size_t)(i < n ? i : n - 1) * n + (q < n ? q : n - 1)];
-            }
-        } else {
-            double t[GSMVI_MAX_KC][8];
-#pragma unroll
-            for (int kc = 0; kc < GSMVI_MAX_KC; ++kc)  // every load of every slab in one batch (clamped slab index)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int e = tid + 512 * k, i = e >> 6, q = e & 63;
-                    t[kc][k] = Gp[(size_t)(kc < kcg ? kc : kcg - 1) * n * n + (size_t)(i < n ? i : n - 1) * n + (q < n ? q : n - 1)];
-                }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                double a = 0.0;
-#pragma unroll
-                for (int kc = 0; kc < GSMVI_MAX_KC; ++kc) a += (kc < kcg) ? t[kc][k] : 0.0;
-                g[k] = a;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int e = tid + 512 * k, i = e >> 6, q = e & 63;
-            E2[i * ES2 + q] = g[k];
-        }
-    }
-    __syncthreads();
-    if (tid < B) {                                     // per-sample scalars (gsm_numpy.py:8-17, whitened; file header)
-        double al = 1.0, be = 0.0;
-        if (!jmode) gsmf_coefs(E2[tid * ES2 + tid], E2[tid * ES2 + B + tid], E2[(B + tid) * ES2 + B + tid], &al, &be);
-        s_alpha[tid] = al;
-        s_beta[tid] = be;
-        coef[tid] = jmode ? 0.0 : be / (double)B;      // mean: mu' = mu + sum_b coef[b] (x_b - mu) + coef[B + b] (v_b Fm)
-        coef[B + tid] = jmode ? 0.0 : al / (double)B;
-    }
-    __syncthreads();
-    {   // Gamma = S Gamma1 S^T (upper triangle), S = [[I, 0], [diag(beta), diag(alpha)]]; identity beyond n
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int e = tid + 512 * k, i = e >> 6, q = e & 63;
-            double v = (i == q) ? 1.0 : 0.0;
-            if (i < n && q < n && q >= i) {
-                if (q < B) v = E2[i * ES2 + q];                                           // Z Z^T
-                else if (i < B) {
-                    const int b = q - B;
-                    v = s_beta[b] * E2[i * ES2 + b] + s_alpha[b] * E2[i * ES2 + q];        // Z U^T
-                } else {
-                    const int a = i - B, b = q - B;                                      // U U^T
-                    v = s_beta[a] * (s_beta[b] * E2[a * ES2 + b] + s_alpha[b] * E2[a * ES2 + q]) +
-                        s_alpha[a] * (s_beta[b] * E2[i * ES2 + b] + s_alpha[b] * E2[i * ES2 + q]);
-                }
-                if (i == q) {                          // rounding floor of the row (gsmvi_chol64.h) and the magnitude guard
-                    if (!(v < 4294967296.0)) sh_moderate = 0;
-                    v -= GSMVI_DEP_TOL * v;
-                }
-            } else if (i < n && q < n) v = 0.0;
-            E1[i * ES1 + q] = v;
-        }
-    }
-    __syncthreads();
-    SMALL_STAMP(1);
-    const bool moderate = sh_moderate != 0;
-    chol64_blk<ES1, true, true>(E1, scr, n, &fail_g, moderate);     // E1 = [Rg | W]
-    SMALL_STAMP(2);
-    const int w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
-    const int nblk = (n + 15) >> 4;
-    // The three 64^3 products below run one 16 x 16 output block at a time on a wave, the operands of a k-block (four MFMA
-    // steps) fetched from LDS into registers one k-block AHEAD of their use; the blocks are dealt to the eight waves by the
-    // tables so that every wave has (nearly) the same number of k-blocks -- the triangular structure makes the block costs
-    // differ (round 2 gave each wave a fixed column block: up to 2x imbalance, operands read at their point of use).
-    // task = 4 * ib + jb + 1 (0 = none)
-#define GSMF_T(i, j) (4 * (i) + (j) + 1)
-    static constexpr unsigned char TASK_A[8][2] = {   // A'(ib, jb), ib <= jb: cost 4 - jb k-blocks
-        {GSMF_T(0, 0), 0}, {GSMF_T(0, 1), 0}, {GSMF_T(1, 1), 0}, {GSMF_T(0, 2), GSMF_T(0, 3)},
-        {GSMF_T(1, 2), GSMF_T(1, 3)}, {GSMF_T(2, 2), GSMF_T(2, 3)}, {GSMF_T(3, 3), 0}, {0, 0}};
-    static constexpr unsigned char TASK_P[8][3] = {   // P(ib, jb): cost 4 - max(ib, jb)
-        {GSMF_T(0, 0), 0, 0}, {GSMF_T(0, 1), GSMF_T(3, 0), 0}, {GSMF_T(1, 0), GSMF_T(3, 1), 0}, {GSMF_T(1, 1), GSMF_T(3, 2), 0},
-        {GSMF_T(0, 2), GSMF_T(1, 2), 0}, {GSMF_T(2, 0), GSMF_T(2, 1), 0}, {GSMF_T(2, 2), GSMF_T(0, 3), GSMF_T(1, 3)},
-        {GSMF_T(2, 3), GSMF_T(3, 3), 0}};
-    static constexpr unsigned char TASK_K[8][2] = {   // K(ib, jb): cost 4 - ib
-        {GSMF_T(0, 0), GSMF_T(3, 0)}, {GSMF_T(0, 1), GSMF_T(3, 1)}, {GSMF_T(0, 2), GSMF_T(3, 2)}, {GSMF_T(0, 3), GSMF_T(3, 3)},
-        {GSMF_T(1, 0), GSMF_T(2, 0)}, {GSMF_T(1, 1), GSMF_T(2, 1)}, {GSMF_T(1, 2), GSMF_T(2, 2)}, {GSMF_T(1, 3), GSMF_T(2, 3)}};
-#undef GSMF_T
-    // one output block: acc = sum over the k-blocks kb0 .. nblk-1 of A(ib-rows, k) B(k, jb-cols); fa(k) / fb(k) fetch the
-    // operand values of this lane for contraction index k
-    auto block_chain = [&](int kb0, auto fa, auto fb) {
-        v4d acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};   // two chains: a dependent fp64 MFMA waits ~2x its issue time
-        double a[4], b[4], an[4], bn[4];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) { a[s4] = fa(16 * kb0 + 4 * s4 + ks); b[s4] = fb(16 * kb0 + 4 * s4 + ks); }
-        for (int kb = kb0; kb < nblk; ++kb) {
-            if (kb + 1 < nblk) {
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) { an[s4] = fa(16 * (kb + 1) + 4 * s4 + ks); bn[s4] = fb(16 * (kb + 1) + 4 * s4 + ks); }
-            }
-#pragma unroll
-            for (int s4 = 0; s4 < 4; s4 += 2) {
-                acc = GSMVI_MFMA_F64(a[s4], b[s4], acc);
-                acc1 = GSMVI_MFMA_F64(a[s4 + 1], b[s4 + 1], acc1);
-            }
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) { a[s4] = an[s4]; b[s4] = bn[s4]; }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] += acc1[r];
-        return acc;
-    };
-    // W <- W S (column operations on the right half of E1; the A' phase below reads only the left half, so both share this
-    // barrier interval): K'' = S^T K S = (W S)^T (T - I) (W S)
-    for (int e = tid; e < 64 * 32; e += 512) {
-        const int r = e >> 5, b = e & 31;
-        if (b < B) {
-            const double wz = E1[r * ES1 + 64 + b], wu = E1[r * ES1 + 64 + B + b];
-            E1[r * ES1 + 64 + b] = wz + s_beta[b] * wu;
-            E1[r * ES1 + 64 + B + b] = s_alpha[b] * wu;
-        }
-    }
-    {   // A' = I + (Rg J) Rg^T into E2;  (Rg J)[i][k] = (1/B)(k < B ? Rg[i][B+k] : Rg[i][k-B] - Rg[i][k]), on the MFMA pipe.
-        // A' is symmetric (the mirror is written too); Rg is upper triangular, so Rg[j][k] = 0 for k < 16 j: only the
-        // k-blocks jb..3 contribute to the block (ib, jb), ib <= jb
-        const double invB = jmode ? 1.0 : 1.0 / (double)B;
-#pragma unroll
-        for (int tq = 0; tq < 2; ++tq) {
-            const int task = TASK_A[w][tq];
-            if (task == 0) continue;                   // wave-uniform
-            const int ib = (task - 1) >> 2, jb = (task - 1) & 3;
-            if (jb >= nblk) {                          // beyond n: the identity padding
-                continue;
-            }
-            const double* arow = E1 + (16 * ib + cc) * ES1;
-            const double* brow = E1 + (16 * jb + cc) * ES1;
-            const v4d acc = block_chain(
-                jb,
-                [&](int k) {
-                    const int k1 = (k < B) ? B + k : k - B;
-                    const double a1 = arow[k1 < 64 ? k1 : 63], a0 = arow[k];
-                    if (jmode) return (k < n) ? ((k < B) ? a0 : -a0) : 0.0;      // J = diag(I, -I)
-                    return (k < n) ? ((k < B) ? a1 : a1 - a0) : 0.0;
-                },
-                [&](int k) { return brow[k]; });
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * ib + ks + 4 * r, j = 16 * jb + cc;
-                const double v = (i == j ? 1.0 : 0.0) + ((i < n && j < n) ? acc[r] * invB : 0.0);
-                E2[i * ES2 + j] = v;
-                if (ib != jb) E2[j * ES2 + i] = v;
-            }
-        }
-        // blocks beyond n: identity padding (written by everybody's share)
-        for (int e = tid; e < 64 * 64; e += 512) {
-            const int i = e >> 6, j = e & 63;
-            if ((i >> 4) >= nblk || (j >> 4) >= nblk) E2[i * ES2 + j] = (i == j) ? 1.0 : 0.0;
-        }
-    }
-    __syncthreads();
-    SMALL_STAMP(3);
-    chol64_blk<ES2, false, false>(E2, scr, n, &fail_t);             // E2 = T (upper): exists iff M is positive definite
-    SMALL_STAMP(4);
-    const int bad = (fail_g != 0) || (fail_t != 0) || (prior_bad && *prior_bad != 0);   // prior: BaM's own chain failed
-    if (tid == 0) *bad_out = bad;
-    if (bad) return;                                   // block-uniform
-    {
-        // P[i][j] = sum_k (T - I)[i][k] W[k][j]: T - I upper (k >= i), W lower (k >= j): k-blocks max(i, j)..3.  P goes into the
-        // left half of E1 (Rg is dead; it was last read in the A' phase, two barriers ago).  The blocks of E2 below the
-        // diagonal still hold A' and are never read (k-block >= ib).
-        const double* Wm = E1 + 64;
-        v4d pacc[3];
-#pragma unroll
-        for (int tq = 0; tq < 3; ++tq) {
-            pacc[tq] = (v4d){0.0, 0.0, 0.0, 0.0};
-            const int task = TASK_P[w][tq];
-            if (task == 0) continue;
-            const int ib = (task - 1) >> 2, jb = (task - 1) & 3;
-            if (ib >= nblk || jb >= nblk) continue;
-            const int i = 16 * ib + cc;
-            pacc[tq] = block_chain(
-                ib > jb ? ib : jb, [&](int k) { return E2[i * ES2 + k] - (i == k ? 1.0 : 0.0); },
-                [&](int k) { return Wm[k * ES1 + 16 * jb + cc]; });
-        }
-#pragma unroll
-        for (int tq = 0; tq < 3; ++tq) {
-            const int task = TASK_P[w][tq];
-            if (task == 0) continue;
-            const int ib = (task - 1) >> 2, jb = (task - 1) & 3;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) E1[(16 * ib + ks + 4 * r) * ES1 + 16 * jb + cc] = pacc[tq][r];
-        }
-        __syncthreads();
-        SMALL_STAMP(5);
-        // K''[i][j] = sum_k W[k][i] P[k][j]: W[k][i] = 0 for k < i: k-blocks i..3
-#pragma unroll
-        for (int tq = 0; tq < 2; ++tq) {
-            const int task = TASK_K[w][tq];
-            const int ib = (task - 1) >> 2, jb = (task - 1) & 3;
-            if (ib >= nblk || jb >= nblk) continue;
-            const v4d acc = block_chain(
-                ib, [&](int k) { return Wm[k * ES1 + 16 * ib + cc]; }, [&](int k) { return E1[k * ES1 + 16 * jb + cc]; });
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * ib + ks + 4 * r, j = 16 * jb + cc;
-                if (i < n && j < n) Kmat[(size_t)i * n + j] = acc[r];
-            }
-        }
-    }
-    SMALL_STAMP(6);
-#undef SMALL_STAMP
+    __shared__ __attribute__((aligned(16))) double lds[GSMF_SMALL16_LDS];
+    gsmf_small16_body(lds, n, B, Gp, kcg, Kmat, coef, bad_out, stamps, jmode, prior_bad);
 }
 
 // ---- K = Rg^-1 (T - I) Rg^-T = W^T (T - I) W, W = Rg^-T, for 64 < n <= 128 -----------------------------------
@@ -1112,9 +867,19 @@ static int chk(const char* what) {
 }
 
 // Pp[kc][B][mrows] partial slabs of A M^T (A: B x D, M: mrows x D); *kc_out slabs.
+static int gsmvi_panel_t_product_mt(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* A, int lda, const double* M,
+                                    int ldm, int mrows, double* Pp, int* kc_out, int mt_cap);
 int gsmvi_panel_t_product(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* A, int lda, const double* M,
                           int ldm, int mrows, double* Pp, int* kc_out) {
-    const int MT = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+    return gsmvi_panel_t_product_mt(ctx, st, D, B, A, lda, M, ldm, mrows, Pp, kc_out, 4);
+}
+// mt_cap: largest row-block multiple (16 mt_cap rows per workgroup).  The chunk width is 256 columns for mt <= 2 and 128 for
+// mt = 4, so capping at 2 halves the number of split-K slabs a small product leaves behind (4 instead of 8 at D = 1024) at
+// the same number of workgroups -- what the one-workgroup consumer of the Gram slabs wants.
+static int gsmvi_panel_t_product_mt(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* A, int lda, const double* M,
+                                    int ldm, int mrows, double* Pp, int* kc_out, int mt_cap) {
+    int MT = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+    if (MT > mt_cap) MT = mt_cap;
     const int CH = (MT == 4) ? 128 : 256;
     const bool fast_t = !ctx->tune_no_fast && D % 64 == 0 && mrows % 16 == 0 && lda % 2 == 0 && ldm % 2 == 0 &&
                         (reinterpret_cast<uintptr_t>(A) & 15u) == 0 && (reinterpret_cast<uintptr_t>(M) & 15u) == 0;
@@ -1204,11 +969,11 @@ static int factor_w_prep(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const dou
 // (kcg = 1: finished); V Fm either finished in Tm1 (vf_slabs == nullptr) or as kcv split-K slabs summed by their consumer.
 static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
                        double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, const double* Gp, int kcg,
-                       const double* vf_slabs, int kcv, int jmode = 0);
+                       const double* vf_slabs, int kcv, int jmode = 0, int chain_done = 0);
 
 // the Gram product Gamma1 = [Z; V][Z; V]^T as split-K slabs (transposed panel product with A = M = Rt1)
-static int factor_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int n, const factor_ws& w, int* kcg) {
-    return gsmvi_panel_t_product(ctx, st, D, n, w.Rt, D, w.Rt, D, n, w.Gp, kcg);
+static int factor_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int n, const factor_ws& w, int* kcg, int mt_cap = 4) {
+    return gsmvi_panel_t_product_mt(ctx, st, D, n, w.Rt, D, w.Rt, D, n, w.Gp, kcg, mt_cap);
 }
 
 int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
@@ -1219,7 +984,7 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
     int rc = factor_w_prep(ctx, st, D, B, Z, ldz, X, ldx, G, ldg, mu0, F0, ldf0);
     if (rc) return rc;
     int kcg = 1, kcv = 1;
-    if ((rc = factor_gram(ctx, st, D, n, w, &kcg))) return rc;
+    if ((rc = factor_gram(ctx, st, D, n, w, &kcg, (ctx->tune_rider && n <= 64) ? ctx->tune_gram_mt : 4))) return rc;
     // Launch diet (round 3).  Where the consumer of V Fm can sum split-K slabs while it loads them (n = 32, 64: the update
     // kernel with the skinny product folded in; n = 128: the fast panel kernel of Fs = K'' Tm1), the V Fm product keeps its
     // slabs and carries the finish of the Gram slabs as a side job of its workgroups (the one-workgroup chain kernel would
@@ -1227,7 +992,21 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
     const bool lean = !ctx->tune_no_fast && ctx->tune_direct_out && (n % 64 == 0 || n == 32 || n == 16) && D % 64 == 0 && ldf0 % 2 == 0 &&
                       ldf % 2 == 0 && (reinterpret_cast<uintptr_t>(F0) & 15u) == 0;
     if (lean) {
-        if (kcg > 1) {
+        const bool rider = ctx->tune_rider && n <= 64;
+        if (rider) {                               // the 2B x 2B chain rides in the V Fm launch and sums the Gram slabs itself
+            gsmvi_panel_extras& px = ctx->px;
+            px.rd_on = 1;
+            px.rd_n = n;
+            px.rd_B = B;
+            px.rd_Gp = w.Gp;
+            px.rd_kcg = kcg;
+            px.rd_Kmat = w.Rg;
+            px.rd_coef = w.coef;
+            px.rd_bad = info_dev;
+            px.rd_stamps = w.stamps;
+            px.rd_jmode = 0;
+            px.rd_prior = nullptr;
+        } else if (kcg > 1) {
             ctx->px.sj_src = w.Gp;
             ctx->px.sj_kc = kcg;
             ctx->px.sj_stride = (size_t)n * n;
@@ -1241,6 +1020,8 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
             gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "fast panel kernel expected (internal error)");
             return GSMVI_ERR_UNSUPPORTED;
         }
+        if (rider)
+            return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, w.Gp, kcg, ctx->pp, kcv, 0, 1);
         return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, kcg > 1 ? w.Gam1 : w.Gp, 1,
                            ctx->pp, kcv);
     }
@@ -1252,15 +1033,29 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
 
 // Factor-form BaM (gsmvi_bam.hip): Rt = [Vw; Zw] and Tm = Rt Fm (2 Bh rows each) are in the panels named by ctx->fo_Rt / fo_Tm;
 // F = F0 + Rt^T K Tm with M = I + Vw^T Vw - Zw^T Zw = C^T C (J = diag(I, -I)).  mu receives mu0: the caller owns BaM's mean.
-// Two calls with the caller's Rt Fm product between them: _gram launches the Gram product and arms the finish of its slabs
-// as a side job of the NEXT fast panel launch (the one-workgroup chain would pull the slabs through a single CU otherwise);
-// _back takes the finished matrix if that launch took the job (ctx->px_used), else the slabs.
-int gsmvi_factor_signed_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, int* kcg) {
+// Two calls with the caller's Rt Fm product between them: _gram launches the Gram product and arms the NEXT fast panel launch
+// with the 2B x 2B chain as its rider workgroup (2B <= 64) or with the finish of the Gram slabs as a side job;
+// _back runs whatever that launch did not take.
+int gsmvi_factor_signed_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, int* kcg, int* info_dev, int* rides) {
     const int n = 2 * Bh;
     const factor_ws w = factor_carve(ctx, D, n);
-    int rc = factor_gram(ctx, st, D, n, w, kcg);
+    *rides = (ctx->tune_rider && n <= 64 && !ctx->tune_no_fast) ? 1 : 0;
+    int rc = factor_gram(ctx, st, D, n, w, kcg, *rides ? ctx->tune_gram_mt : 4);
     if (rc) return rc;
-    if (*kcg > 1) {
+    if (*rides) {                                  // the chain rides in the caller's next fast panel launch (k_panel_fast<.., RIDER>)
+        gsmvi_panel_extras& px = ctx->px;
+        px.rd_on = 1;
+        px.rd_n = n;
+        px.rd_B = Bh;
+        px.rd_Gp = w.Gp;
+        px.rd_kcg = *kcg;
+        px.rd_Kmat = w.Rg;
+        px.rd_coef = w.coef;
+        px.rd_bad = info_dev;
+        px.rd_stamps = w.stamps;
+        px.rd_jmode = 1;
+        px.rd_prior = ctx->ints + 8;               // the flag of BaM's (B x B) chain
+    } else if (*kcg > 1) {
         ctx->px.sj_src = w.Gp;
         ctx->px.sj_kc = *kcg;
         ctx->px.sj_stride = (size_t)n * n;
@@ -1269,11 +1064,13 @@ int gsmvi_factor_signed_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, int*
     }
     return GSMVI_OK;
 }
+// taken = ctx->px_used of the panel launch behind _gram: the chain has run (rides) / the Gram matrix is finished (side job)
 int gsmvi_factor_signed_back(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, const double* mu0, const double* F0, int ldf0,
-                             double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, int kcg, int finished) {
+                             double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, int kcg, int rides, int taken) {
     const factor_ws w = factor_carve(ctx, D, 2 * Bh);
+    const int finished = !rides && taken;
     return factor_back(ctx, st, D, Bh, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, (kcg > 1 && finished) ? w.Gam1 : w.Gp,
-                       finished ? 1 : kcg, nullptr, 0, 1);
+                       finished ? 1 : kcg, nullptr, 0, 1, (rides && taken) ? 1 : 0);
 }
 
 // Batch-sharded form, stage 1: this rank's B_local samples -> records.
@@ -1306,7 +1103,7 @@ int gsmvi_factor_apply_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const 
 
 static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
                        double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, const double* Gp, int kcg,
-                       const double* vf_slabs, int kcv, int jmode) {
+                       const double* vf_slabs, int kcv, int jmode, int chain_done) {
     const int n = 2 * B;                           // n is even
     const factor_ws w = factor_carve(ctx, D, n);
     double *Rt = w.Rt, *Tm = w.Tm, *Fs = w.Fs, *coef = w.coef;
@@ -1319,8 +1116,10 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
     if (n <= 64) {
         // everything small in one workgroup
         Kmat = w.Rg;
-        hipLaunchKernelGGL(k_gsmf_small16, dim3(1), dim3(512), 0, st, n, B, Gp, kcg, Kmat, coef, info_dev, w.stamps, jmode, prior);
-        if ((rc = chk("k_gsmf_small16"))) return rc;
+        if (!chain_done) {                         // (chain_done: it ran as the rider workgroup of the caller's panel product)
+            hipLaunchKernelGGL(k_gsmf_small16, dim3(1), dim3(512), 0, st, n, B, Gp, kcg, Kmat, coef, info_dev, w.stamps, jmode, prior);
+            if ((rc = chk("k_gsmf_small16"))) return rc;
+        }
     } else {
         // 64 < n <= 128: Gamma, the two n x n Choleskys one workgroup each, W and K in their own kernels
         Kmat = w.Gam;                              // Gamma is dead once Rg exists

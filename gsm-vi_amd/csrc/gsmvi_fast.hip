@@ -10,6 +10,7 @@
 // then store.  No data-dependent branch sits between a load and its use.
 #include "gsmvi_common.h"
 #include "gsmvi_ctx.h"
+#include "gsmvi_small16.h"
 #include <hip/hip_ext.h>
 
 #define GSMVI_LAUNCH(kern, grid, block, shmem, st, ev, ...)                                         \
@@ -35,7 +36,12 @@
 // EXTRA = true adds the two optional pieces of gsmvi_panel_extras (gsmvi_ctx.h): right-operand rows taken from split-K slabs
 // of a previous product (summed while they are loaded, so that product needs no finish launch), and a slab-summing side
 // job shared by all workgroups (finishes the small Gram matrix of the factor path beside this launch's own work).
-template <int MT, bool HAS_SHIFT, int CHW, bool EXTRA>
+// RIDER = true (factor path, round 3): the launch carries ONE more workgroup -- x index gridDim.x - 1, (y, z) = (0, 0) -- that
+// runs the 2B x 2B chain of the factor update (gsmf_small16_body) while the other workgroups form V Fm: the chain (31 us on one
+// CU) does not depend on this product, only the update kernel behind both does, so the product and one launch boundary
+// disappear from the iteration's critical path.  The chain's 142 KB of LDS become the launch's LDS size (one workgroup per
+// CU for the product: it finishes long before the chain either way).
+template <int MT, bool HAS_SHIFT, int CHW, bool EXTRA, bool RIDER = false>
 __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const double* __restrict__ A, int lda,
                                                     const double* __restrict__ shift, double alpha,
                                                     const double* __restrict__ M, int ldm,
@@ -56,8 +62,15 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
     constexpr int NST = RW / 4;                    // MFMA steps per wave and chunk
     constexpr int U16 = CHW / 2;                   // 16-B units per staged row
     constexpr int UPT = NR * U16 / 512;            // staging units per thread
-    constexpr int SMEM = (NR * LDG > 8 * NR * 17) ? NR * LDG : 8 * NR * 17;
+    constexpr int SMEM_P = (NR * LDG > 8 * NR * 17) ? NR * LDG : 8 * NR * 17;
+    constexpr int SMEM = (RIDER && GSMF_SMALL16_LDS > SMEM_P) ? GSMF_SMALL16_LDS : SMEM_P;
     __shared__ __attribute__((aligned(16))) double As[SMEM];       // staging buffer, reused for the reduction
+    if (RIDER && blockIdx.x == gridDim.x - 1) {                     // block-uniform
+        if (blockIdx.y == 0 && blockIdx.z == 0)
+            gsmf_small16_body(As, px.rd_n, px.rd_B, px.rd_Gp, px.rd_kcg, px.rd_Kmat, px.rd_coef, px.rd_bad, px.rd_stamps,
+                              px.rd_jmode, px.rd_prior);
+        return;
+    }
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
     const int j = blockIdx.x * 16 + c;
     const int r0 = blockIdx.z * NR;
@@ -472,8 +485,18 @@ void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, 
                              int chunks_per_wg, int ncols, unsigned long long* stamps, double* Out, int ldo,
                              const double* addvec, const gsmvi_panel_extras* px) {
     const gsmvi_panel_extras none;
-    const bool extra = px && (px->msl || px->sj_src);
+    const bool rider = px && px->rd_on && !shift;
+    const bool extra = px && (px->msl || px->sj_src || rider);
     const gsmvi_panel_extras pxv = extra ? *px : none;
+    if (rider) {
+        grid.x += 1;
+#define PFR(MTV, CW)                                                                                                 \
+    GSMVI_LAUNCH((k_panel_fast<MTV, false, CW, true, true>), grid, dim3(512), 0, st, ev, D, nrows, A, lda, shift, alpha, M, \
+                 ldm, Pp, chunks_per_wg, ncols, stamps, Out, ldo, addvec, pxv)
+        if (MT == 1) PFR(1, 256); else if (MT == 2) PFR(2, 256); else PFR(4, 128);
+#undef PFR
+        return;
+    }
 #define PF(MTV, HS, CW, EX)                                                                                          \
     GSMVI_LAUNCH((k_panel_fast<MTV, HS, CW, EX>), grid, dim3(512), 0, st, ev, D, nrows, A, lda, shift, alpha, M, ldm, \
                  Pp, chunks_per_wg, ncols, stamps, Out, ldo, addvec, pxv)

@@ -327,3 +327,51 @@ def test_factor_update_with_linearly_dependent_rows(D, B):
                                            eng.asarray(F0), n_reverts=n_rev)
     F2n = F2.cpu().numpy()
     assert rel_err(F2n.T @ F2n, np.eye(D)) < 1e-9 and np.abs(mu2.cpu().numpy() - mu0).max() < 1e-9
+
+
+@pytest.mark.parametrize("D,B", [(64, 8), (256, 8), (512, 16), (1024, 32)])
+def test_chain_as_rider_workgroup_equals_its_own_launch(D, B):
+    """Round 3: on the lean path (D % 64 == 0, 2B in {16, 32, 64}) the 2B x 2B chain runs as ONE extra workgroup of the V Fm
+    panel-product launch (k_panel_fast<.., RIDER>) instead of a launch of its own.  Same device function, same Gram slabs:
+    the results are bit-identical to the stand-alone launch (knob rider=0) at equal slab split, agree with it to rounding at
+    the default split, survive a graph replay, and a NaN score still reverts."""
+    import torch
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    orc, st, F0 = _setup(D, B, D + 3 * B)
+    dv = [eng.asarray(st[k]) for k in ("Z", "samples", "vs", "mu0")] + [eng.asarray(F0)]
+    res = {}
+    try:
+        for rider, gmt in ((0, 4), (1, 4), (1, 1)):
+            eng.set_tuning("rider", rider)
+            eng.set_tuning("gram_mt", gmt)
+            mu, F, flag = eng.gsm_factor_update(*dv)
+            assert eng.read_flag(flag) == 0
+            res[(rider, gmt)] = (mu.cpu().numpy(), F.cpu().numpy())
+        assert np.array_equal(res[(0, 4)][0], res[(1, 4)][0]) and np.array_equal(res[(0, 4)][1], res[(1, 4)][1])
+        assert rel_err(res[(1, 1)][1], res[(0, 4)][1]) < 1e-11 and rel_err(res[(1, 1)][0], res[(0, 4)][0]) < 1e-11
+        mu_o, S_o = orc.gsm_update_batched(st["samples"], st["vs"], st["mu0"], st["S0"])
+        Fn = res[(1, 1)][1]
+        assert rel_err(Fn.T @ Fn, S_o) < 1e-10 and rel_err(res[(1, 1)][0], mu_o) < 1e-10
+        # graph replay of the riding form
+        out = (eng.empty(D), eng.empty(D, D))
+        flag = eng.new_flag()
+        eng.gsm_factor_update(*dv, out=out, flag=flag)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            eng.gsm_factor_update(*dv, out=out, flag=flag)
+        out[0].zero_(); out[1].zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out[1].cpu().numpy(), res[(1, 1)][1]) and eng.read_flag(flag) == 0
+        # a poisoned score: flag, revert
+        Gbad = dv[2].clone()
+        Gbad[0, 0] = float("nan")
+        n_rev = eng.new_flag()
+        mu, F, flag = eng.gsm_factor_update(dv[0], dv[1], Gbad, dv[3], dv[4], n_reverts=n_rev)
+        assert eng.read_flag(flag) == 1 and eng.read_flag(n_rev) == 1
+        assert np.array_equal(F.cpu().numpy(), F0) and np.array_equal(mu.cpu().numpy(), st["mu0"])
+    finally:
+        eng.set_tuning("rider", 1)
+        eng.set_tuning("gram_mt", 1)
