@@ -201,6 +201,9 @@ int gsmvi_create(gsmvi_ctx** out, int device, int max_D, int max_B) {
     if (e == hipSuccess) e = gsmvi_cov_update_prepare();
     if (e == hipSuccess) e = gsmvi_bam_prepare();
     for (int k = 0; k < 8 && e == hipSuccess; ++k) e = hipEventCreate(&c->ev[k]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) {
         gsmvi_set_error("context initialisation failed: %s%s", hipGetErrorString(e), "");
         (void)hipFree(c->ws);
@@ -222,6 +225,9 @@ int gsmvi_destroy(gsmvi_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     for (int k = 0; k < 8; ++k)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->bam_hint_host) (void)hipHostFree(ctx->bam_hint_host);
     if (ctx->stamps) (void)hipFree(ctx->stamps);
     hipError_t e = hipFree(ctx->ws);
@@ -240,6 +246,7 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     else if (!strcmp(name, "no_fast")) ctx->tune_no_fast = value;
     else if (!strcmp(name, "direct_out")) ctx->tune_direct_out = value;
     else if (!strcmp(name, "rider")) ctx->tune_rider = value;
+    else if (!strcmp(name, "fork_min_D")) ctx->tune_fork_min_D = value;
     else if (!strcmp(name, "gram_mt")) ctx->tune_gram_mt = value > 0 ? value : 4;
     else if (!strcmp(name, "bam_full")) ctx->tune_bam_full = value;
     else if (!strcmp(name, "bam_kenq")) ctx->tune_bam_kenq = value;

@@ -64,6 +64,9 @@ struct gsmvi_ctx {
     int tune_bam_kenq = 0;     // > 0: enqueue exactly this many multi-workgroup steps (tests of the tail kernel)
     int tune_bam_full = 0;     // 1 = always enqueue every Newton-Schulz step (ignore the hint; tests)
     int profiling = 0;         // when set, the update kernels are launched with dispatch-timestamp events
+    hipStream_t side = nullptr;         // second stream of the factor path at large D (V Fm beside the 2B x 2B chain), with its
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // fork / join events (no timing)
+    int tune_fork_min_D = 3072;         // smallest D that forks (the two event edges cost ~10 us; 0 = never)
     hipEvent_t ev[8] = {};     // [2*stage], [2*stage+1]: panel, scalars, cov-update, spare
     int ev_valid[4] = {};
 

@@ -969,7 +969,7 @@ static int factor_w_prep(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const dou
 // (kcg = 1: finished); V Fm either finished in Tm1 (vf_slabs == nullptr) or as kcv split-K slabs summed by their consumer.
 static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
                        double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, const double* Gp, int kcg,
-                       const double* vf_slabs, int kcv, int jmode = 0, int chain_done = 0);
+                       const double* vf_slabs, int kcv, int jmode = 0, int chain_done = 0, hipEvent_t join = nullptr);
 
 // the Gram product Gamma1 = [Z; V][Z; V]^T as split-K slabs (transposed panel product with A = M = Rt1)
 static int factor_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int n, const factor_ws& w, int* kcg, int mt_cap = 4) {
@@ -984,13 +984,35 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
     int rc = factor_w_prep(ctx, st, D, B, Z, ldz, X, ldx, G, ldg, mu0, F0, ldf0);
     if (rc) return rc;
     int kcg = 1, kcv = 1;
-    if ((rc = factor_gram(ctx, st, D, n, w, &kcg, (ctx->tune_rider && n <= 64) ? ctx->tune_gram_mt : 4))) return rc;
     // Launch diet (round 3).  Where the consumer of V Fm can sum split-K slabs while it loads them (n = 32, 64: the update
     // kernel with the skinny product folded in; n = 128: the fast panel kernel of Fs = K'' Tm1), the V Fm product keeps its
     // slabs and carries the finish of the Gram slabs as a side job of its workgroups (the one-workgroup chain kernel would
     // pull them through a single CU: measured +5.6 us).  Otherwise: product + finish launches, as before.
     const bool lean = !ctx->tune_no_fast && ctx->tune_direct_out && (n % 64 == 0 || n == 32 || n == 16) && D % 64 == 0 && ldf0 % 2 == 0 &&
                       ldf % 2 == 0 && (reinterpret_cast<uintptr_t>(F0) & 15u) == 0;
+    // Large D, n = 128: the V Fm product (MFMA-bound, 65 us at D = 4096) does not depend on the Gram product and the eight small
+    // launches of the 2B x 2B chain (~100 us on a few CUs), so it runs on the context's second stream beside them; the two
+    // event edges cost ~10 us, which is why D = 1024 does not fork (measured in round 2: slower there).
+    if (lean && n > 64 && ctx->side && ctx->tune_fork_min_D > 0 && D >= ctx->tune_fork_min_D) {
+        hipError_t e = hipEventRecord(ctx->ev_fork, st);                   // [Z; V] and X - mu exist: fork here
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);
+        if (e != hipSuccess) { gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "fork failed"); return GSMVI_ERR_HIP; }
+        if ((rc = factor_gram(ctx, st, D, n, w, &kcg))) return rc;
+        if ((rc = gsmvi_panel_product_nc(ctx, ctx->side, nullptr, D, D, B, w.Rt + (size_t)B * D, D, nullptr, 1.0, F0, ldf0, ctx->pp,
+                                         &kcv)))
+            return rc;
+        if (!ctx->px_used) {
+            gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "fast panel kernel expected (internal error)");
+            return GSMVI_ERR_UNSUPPORTED;
+        }
+        if (hipEventRecord(ctx->ev_join, ctx->side) != hipSuccess) {
+            gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "join failed");
+            return GSMVI_ERR_HIP;
+        }
+        return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, w.Gp, kcg, ctx->pp, kcv, 0, 0,
+                           ctx->ev_join);
+    }
+    if ((rc = factor_gram(ctx, st, D, n, w, &kcg, (ctx->tune_rider && n <= 64) ? ctx->tune_gram_mt : 4))) return rc;
     if (lean) {
         const bool rider = ctx->tune_rider && n <= 64;
         if (rider) {                               // the 2B x 2B chain rides in the V Fm launch and sums the Gram slabs itself
@@ -1103,7 +1125,7 @@ int gsmvi_factor_apply_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const 
 
 static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
                        double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, const double* Gp, int kcg,
-                       const double* vf_slabs, int kcv, int jmode, int chain_done) {
+                       const double* vf_slabs, int kcv, int jmode, int chain_done, hipEvent_t join) {
     const int n = 2 * B;                           // n is even
     const factor_ws w = factor_carve(ctx, D, n);
     double *Rt = w.Rt, *Tm = w.Tm, *Fs = w.Fs, *coef = w.coef;
@@ -1147,6 +1169,10 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         return chk("k_gsmf_update_fs");
     }
     // Fs = K'' Tm1 as one skinny GEMM: inner dimension n <= one chunk, so there is exactly one slab, written straight into Fs
+    if (join && hipStreamWaitEvent(st, join, 0) != hipSuccess) {       // the V Fm slabs come from the side stream (large D)
+        gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "hipStreamWaitEvent failed");
+        return GSMVI_ERR_HIP;
+    }
     if (vf_slabs) {                                // rows B .. 2B-1 of Tm1 = sum of the V Fm slabs; finished into Tm1 on the way
         ctx->px.msl = vf_slabs;
         ctx->px.kcm = kcv;

@@ -375,3 +375,39 @@ def test_chain_as_rider_workgroup_equals_its_own_launch(D, B):
     finally:
         eng.set_tuning("rider", 1)
         eng.set_tuning("gram_mt", 1)
+
+
+@pytest.mark.parametrize("D,B", [(256, 64), (1024, 64)])
+def test_side_stream_fork_of_the_large_d_path_changes_nothing(D, B):
+    """n = 2B = 128 at D >= 3072 (BASELINE config 5): the V Fm product runs on the context's second stream beside the Gram
+    product and the 2B x 2B chain (fork / join by two events inside the call).  Forced on here at small D (knob
+    fork_min_D): bit-identical to the one-stream order, also from a replayed graph."""
+    import torch
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    orc, st, F0 = _setup(D, B, D + B)
+    dv = [eng.asarray(st[k]) for k in ("Z", "samples", "vs", "mu0")] + [eng.asarray(F0)]
+    try:
+        eng.set_tuning("fork_min_D", 0)
+        mu0_, F0_, fl = eng.gsm_factor_update(*dv)
+        assert eng.read_flag(fl) == 0
+        eng.set_tuning("fork_min_D", 64)
+        out = (eng.empty(D), eng.empty(D, D))
+        flag = eng.new_flag()
+        for _ in range(3):
+            eng.gsm_factor_update(*dv, out=out, flag=flag)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], mu0_) and torch.equal(out[1], F0_) and eng.read_flag(flag) == 0
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            eng.gsm_factor_update(*dv, out=out, flag=flag)
+            eng.gsm_factor_update(*dv, out=out, flag=flag)
+        out[0].zero_(); out[1].zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], mu0_) and torch.equal(out[1], F0_)
+        mu_o, S_o = orc.gsm_update_batched(st["samples"], st["vs"], st["mu0"], st["S0"])
+        Fn = out[1].cpu().numpy()
+        assert rel_err(Fn.T @ Fn, S_o) < 1e-10
+    finally:
+        eng.set_tuning("fork_min_D", 3072)
