@@ -246,6 +246,8 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     else if (!strcmp(name, "no_fast")) ctx->tune_no_fast = value;
     else if (!strcmp(name, "direct_out")) ctx->tune_direct_out = value;
     else if (!strcmp(name, "rider")) ctx->tune_rider = value;
+    else if (!strcmp(name, "wide")) ctx->tune_wide = value;
+    else if (!strcmp(name, "wide_kc")) ctx->tune_wide_kc = value;
     else if (!strcmp(name, "fork_min_D")) ctx->tune_fork_min_D = value;
     else if (!strcmp(name, "gram_mt")) ctx->tune_gram_mt = value > 0 ? value : 4;
     else if (!strcmp(name, "bam_full")) ctx->tune_bam_full = value;
@@ -367,6 +369,18 @@ int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D
     const int zblocks = (nrows + 16 * MT - 1) / (16 * MT);
     const int a_vec_ok = (lda % 2 == 0) && aligned16(A);
     const bool fast = !ctx->tune_no_fast && ncols % 16 == 0 && D % 64 == 0 && a_vec_ok && (!shift || aligned16(shift));
+    // 64-row panels of a D-sized product are MFMA-bound: the 64 x 64-tile kernel (gsmvi_wide.hip).  Not with extras: those
+    // launches (K'' Tm with slab-summed rows, side jobs, the rider) stay on the narrow kernel.
+    if (fast && MT == 4 && ctx->tune_wide && ncols % 64 == 0 && ncols >= 1024 && D >= 1024 && ldm % 2 == 0 && aligned16(M) &&
+        !ctx->px.msl && !ctx->px.sj_src && !ctx->px.rd_on) {
+        int kcw = 1, kper = D;
+        gsmvi_panel_wide_split(D, (ncols / 64) * zblocks, ctx->num_cu, ctx->tune_wide_kc, &kcw, &kper);
+        *kc_out = kcw;
+        ctx->px = gsmvi_panel_extras();
+        ctx->px_used = 1;
+        gsmvi_launch_panel_wide(st, ev, false, D, nrows, A, lda, shift, alpha, M, ldm, Pp, kper, kcw, ncols);
+        return check_launch("k_panel_wide");
+    }
     const int chw = fast ? gsmvi_panel_fast_chunk(MT) : 256;       // rows of M per chunk
     const int nchunks = (D + chw - 1) / chw;
     int kc = ctx->tune_panel_kc > 0 ? ctx->tune_panel_kc

@@ -37,6 +37,8 @@ struct gsmvi_panel_extras {
 struct gsmvi_ctx {
     gsmvi_panel_extras px;     // see above
     int px_used = 0;
+    int tune_wide = 1;         // 64-row panels (B = 64) of D-sized products on the 64 x 64-tile kernels of gsmvi_wide.hip
+    int tune_wide_kc = 0;      // > 0: force their split-K count (A/B runs)
     int tune_gram_mt = 1;      // row-block cap of the Gram product when the chain rides (fewer split-K slabs for its one CU)
     int tune_rider = 1;        // the 2B x 2B chain rides in the V Fm product's launch (0: its own launch, for A/B runs)
     int device = 0;
@@ -81,6 +83,10 @@ struct gsmvi_ctx {
     }
 };
 
+void gsmvi_panel_wide_split(int D, int tiles, int num_cu, int kc_force, int* kc_out, int* kper_out);
+void gsmvi_launch_panel_wide(hipStream_t st, hipEvent_t* ev, bool transposed, int D, int nrows, const double* A, int lda,
+                             const double* shift, double alpha, const double* M, int ldm, double* Pp, int kper, int kc,
+                             int ncols);
 int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D, int ncols, int nrows,
                            const double* A, int lda, const double* shift, double alpha, const double* M, int ldm,
                            double* Pp, int* kc_out);

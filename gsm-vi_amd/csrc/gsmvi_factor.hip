@@ -883,6 +883,14 @@ static int gsmvi_panel_t_product_mt(gsmvi_ctx* ctx, hipStream_t st, int D, int B
     const int CH = (MT == 4) ? 128 : 256;
     const bool fast_t = !ctx->tune_no_fast && D % 64 == 0 && mrows % 16 == 0 && lda % 2 == 0 && ldm % 2 == 0 &&
                         (reinterpret_cast<uintptr_t>(A) & 15u) == 0 && (reinterpret_cast<uintptr_t>(M) & 15u) == 0;
+    if (fast_t && MT == 4 && ctx->tune_wide && mrows % 64 == 0 && mrows >= 1024 && D >= 1024) {
+        // 64-row panels of a D-sized product are MFMA-bound: the 64 x 64-tile kernel (gsmvi_wide.hip)
+        int kcw = 1, kper = D;
+        gsmvi_panel_wide_split(D, (mrows / 64) * ((B + 63) / 64), ctx->num_cu, ctx->tune_wide_kc, &kcw, &kper);
+        *kc_out = kcw;
+        gsmvi_launch_panel_wide(st, nullptr, true, D, B, A, lda, nullptr, 1.0, M, ldm, Pp, kper, kcw, mrows);
+        return chk("k_panel_wide");
+    }
     const int strips = (mrows + 15) / 16, nchunks = (D + CH - 1) / CH, zb = (B + 16 * MT - 1) / (16 * MT);
     int kc = (2 * ctx->num_cu + strips * zb - 1) / (strips * zb);
     if (kc > nchunks) kc = nchunks;

@@ -17,7 +17,7 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- 
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $ARGS --no-graph > $OUT/pmc_mfma.log 2>&1
 # the >= 0.50 HBM-roofline point of the covariance kernel (D=4096, B=32) and the fit-iteration kernel tables
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_d4096 -- python3 $ROOT/bench.py --D 4096 --B 32 --steps 60 --warmup 12 --no-cpu-baseline > $OUT/trace_d4096.log 2>&1
-for cfg in "1024 32 factor" "1024 32 dense" "4096 64 factor" "256 8 factor" "1024 32 bam"; do
+for cfg in "1024 32 factor" "1024 32 dense" "4096 64 factor" "256 8 factor" "1024 32 bam" "1024 32 bamf"; do
   tag=$(echo $cfg | tr ' ' '_')
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fit_$tag -- python3 $ROOT/scripts/factor_prof.py $cfg > $OUT/fit_$tag.log 2>&1
   echo "== fit iteration kernels, D B method = $cfg (41 iterations; name, calls, avg ns, % of GPU time)" >> $OUT/fit_iteration_kernels.txt

@@ -388,7 +388,8 @@ def test_side_stream_fork_of_the_large_d_path_changes_nothing(D, B):
     orc, st, F0 = _setup(D, B, D + B)
     dv = [eng.asarray(st[k]) for k in ("Z", "samples", "vs", "mu0")] + [eng.asarray(F0)]
     try:
-        eng.set_tuning("fork_min_D", 0)
+        eng.set_tuning("wide", 0)                   # same kernels on both sides (the forked product carries no side job, so with
+        eng.set_tuning("fork_min_D", 0)             # wide=1 it would take the 64 x 64-tile kernel: equal to rounding, not bitwise)
         mu0_, F0_, fl = eng.gsm_factor_update(*dv)
         assert eng.read_flag(fl) == 0
         eng.set_tuning("fork_min_D", 64)
@@ -409,5 +410,47 @@ def test_side_stream_fork_of_the_large_d_path_changes_nothing(D, B):
         mu_o, S_o = orc.gsm_update_batched(st["samples"], st["vs"], st["mu0"], st["S0"])
         Fn = out[1].cpu().numpy()
         assert rel_err(Fn.T @ Fn, S_o) < 1e-10
+        eng.set_tuning("wide", 1)                   # the default kernels under the fork
+        mu_w, F_w, fl = eng.gsm_factor_update(*dv)
+        assert eng.read_flag(fl) == 0 and rel_err(F_w.cpu().numpy(), Fn) < 1e-12
     finally:
+        eng.set_tuning("wide", 1)
         eng.set_tuning("fork_min_D", 3072)
+
+
+@pytest.mark.parametrize("D", [1024, 2048])
+def test_wide_panel_kernels_agree_with_the_strip_kernels(D):
+    """B = 64 (BASELINE config 5's batch): D-sized 64-row panel products run on the 64 x 64-tile kernels of gsmvi_wide.hip
+    (MFMA-bound regime) instead of the 16-column strips.  Sampler, Gaussian score, dense update and factor update with the
+    wide kernels against the strip kernels (knob wide=0) and against the oracle; odd split-K counts included."""
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    B = 64
+    orc, st, F0 = _setup(D, B, D + B)
+    m, _, P = orc.make_gaussian_target(D, 5)
+    Z, X, G, mu0, F0d, S0 = (eng.asarray(a) for a in (st["Z"], st["samples"], st["vs"], st["mu0"], F0, st["S0"]))
+    md, Pd = eng.asarray(m), eng.asarray(0.5 * (P + P.T))
+    out = {}
+    try:
+        for wide, kc in ((0, 0), (1, 0), (1, 3), (1, 1)):
+            eng.set_tuning("wide", wide)
+            eng.set_tuning("wide_kc", kc)
+            xs = eng.sample(Z, mu0, F0d)
+            gs = eng.gaussian_score(X, md, Pd)
+            mu_f, F_f, flag = eng.gsm_factor_update(Z, X, G, mu0, F0d)
+            mu_d, S_d = eng.gsm_update(X, G, mu0, S0)
+            assert eng.read_flag(flag) == 0
+            out[(wide, kc)] = [t.cpu().numpy() for t in (xs, gs, mu_f, F_f, mu_d, S_d)]
+        ref = out[(0, 0)]
+        for key, vals in out.items():
+            for a, b in zip(vals, ref):
+                assert rel_err(a, b) < 1e-12, key
+        xs, gs, mu_f, F_f, mu_d, S_d = out[(1, 0)]
+        assert rel_err(xs, st["samples"]) < 1e-12
+        assert rel_err(gs, orc.gaussian_score(st["samples"], m, 0.5 * (P + P.T))) < 1e-11
+        mu_o, S_o = orc.gsm_update_batched(st["samples"], st["vs"], st["mu0"], st["S0"])
+        assert rel_err(S_d, S_o) < 1e-11 and rel_err(mu_d, mu_o) < 1e-11
+        assert rel_err(F_f.T @ F_f, S_o) < 1e-10 and rel_err(mu_f, mu_o) < 1e-10
+    finally:
+        eng.set_tuning("wide", 1)
+        eng.set_tuning("wide_kc", 0)
