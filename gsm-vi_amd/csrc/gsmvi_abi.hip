@@ -142,7 +142,7 @@ static void ws_sizes(int D, int B, size_t* n_pp, size_t* n_sg, size_t* n_small, 
     // potrf parks its factored 64x64 diagonal blocks here: one per block step of max(D, 2B+8)
     const size_t dpad = (size_t)(((D > R ? D : R) + 63) / 64) * 64;
     size_t potrf_scratch = dpad * 64;                          // v1: one factored 64 x 64 block per step
-    if (potrf_scratch < 2 * 64 * dpad + 2 * 64 * 64) potrf_scratch = 2 * 64 * dpad + 2 * 64 * 64;   // v2: row buffers + W
+    if (potrf_scratch < 3 * 64 * dpad + 2 * 64 * 64) potrf_scratch = 3 * 64 * dpad + 2 * 64 * 64;   // row buffers + W + X^T blocks
     if (*n_pp < potrf_scratch) *n_pp = potrf_scratch;
     *n_sg = (size_t)R * D * 8;                                 // SG + BaM factor panels (the factor-form BaM update holds 10 B + 8 rows)
     // + the device chain of BaM's small matrix function: five padded 144 x 144 iterates, coefficients, BB (n <= 129)
@@ -246,6 +246,7 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     else if (!strcmp(name, "no_fast")) ctx->tune_no_fast = value;
     else if (!strcmp(name, "direct_out")) ctx->tune_direct_out = value;
     else if (!strcmp(name, "rider")) ctx->tune_rider = value;
+    else if (!strcmp(name, "potrf_split_m")) ctx->tune_potrf_split_m = value;
     else if (!strcmp(name, "wide")) ctx->tune_wide = value;
     else if (!strcmp(name, "wide_kc")) ctx->tune_wide_kc = value;
     else if (!strcmp(name, "fork_min_D")) ctx->tune_fork_min_D = value;

@@ -37,6 +37,7 @@ struct gsmvi_panel_extras {
 struct gsmvi_ctx {
     gsmvi_panel_extras px;     // see above
     int px_used = 0;
+    int tune_potrf_split_m = 0;   // > 0: tile rows from which a Cholesky block step runs its row solve as a separate launch (A/B)
     int tune_wide = 1;         // 64-row panels (B = 64) of D-sized products on the 64 x 64-tile kernels of gsmvi_wide.hip
     int tune_wide_kc = 0;      // > 0: force their split-K count (A/B runs)
     int tune_gram_mt = 1;      // row-block cap of the Gram product when the chain rides (fewer split-K slabs for its one CU)

@@ -182,9 +182,65 @@ __device__ __forceinline__ void potrf_mma64x8(const double* FA, const double* FB
     }
 }
 
+// ---- split form of the early steps of a LARGE matrix (round 3) ----------------------------------------------------------
+// In the fused step every tile (I, J) recomputes X_I and X_J: three 64^3 products per tile where one is needed.  That is
+// free while a step has fewer tiles than the chip has CUs (the diagonal tile's chain bounds the step), and it is 2/3 of the
+// work when it has many: D = 4096 spends 69 GFLOP where the factorisation has 23 (1.46 ms of the 2.67 ms at the measured
+// fp64 MFMA rate).  For steps with m = nblk - k >= POTRF_SPLIT_M tile rows the solve runs once per block in its own launch:
+//   k_potrf_solve : workgroup j: X_J = W_{k-1} B_J, J = k + j  ->  block (k-1, J) of R, its mirror block zeroed, and X_J^T
+//                   (64 x 64, [column][p]) into xbuf for the tiles
+//   k_potrf_step8<true> : the tile loads X_I^T, X_J^T from xbuf (L2 hits) and does the one product it owns.
+#define POTRF_SPLIT_M 24
+__global__ __launch_bounds__(512) void k_potrf_solve(int D, int k, const double* S, int lds, double* R, int ldr,
+                                                     const double* rowbuf, int ldrow, const double* wbuf,
+                                                     double* __restrict__ xbuf) {
+    constexpr int RS = 66;
+    __shared__ __attribute__((aligned(16))) double L0[64 * RS], L1[64 * RS];
+    const int J0 = (k + blockIdx.x) * NB;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+    const int wr = (w >> 1) & 1, wc = w & 1, rr = w >> 2;
+    const double* Bsrc = (k == 1) ? S : rowbuf + (size_t)((k - 1) & 1) * NB * ldrow;
+    const int ldb = (k == 1) ? lds : ldrow;
+    const double* Wk = wbuf + (size_t)((k - 1) & 1) * NB * NB;
+    double vw[8], vj[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) vw[q] = Wk[tid + 512 * q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int p = (tid >> 6) + 8 * q, gj = J0 + (tid & 63);
+        vj[q] = (gj < D) ? Bsrc[(size_t)p * ldb + gj] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int e = tid + 512 * q;
+        L0[(e >> 6) * RS + (e & 63)] = vw[q];
+        L1[(tid & 63) * RS + (tid >> 6) + 8 * q] = vj[q];
+    }
+    __syncthreads();
+    v4d acc[2];
+    acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+    potrf_mma64x8(L0, L1, acc, wr, rr, wc, c, ks, 4 * (2 * wr + rr + 1));       // X_J = W B_J (W lower triangular)
+    const int lrow0 = 32 * wr + 16 * rr + ks;
+    double* xo = xbuf + (size_t)(k + blockIdx.x) * NB * NB;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = lrow0 + 4 * r, col = 32 * wc + 16 * ct + c, gc = J0 + col;
+            if (gc < D) R[(size_t)((k - 1) * NB + row) * ldr + gc] = acc[ct][r];
+            xo[col * NB + row] = acc[ct][r];
+        }
+    for (int e = tid; e < NB * NB; e += 512) {
+        const int jr = e >> 6, p = e & 63;
+        if (J0 + jr < D) R[(size_t)(J0 + jr) * ldr + (k - 1) * NB + p] = 0.0;
+    }
+}
+
+template <bool PRESOLVED>
 __global__ __launch_bounds__(512) void k_potrf_step8(int D, int k, const double* S, int lds, double* R, int ldr,
                                                      double* rowbuf, int ldrow, double* wbuf, int* __restrict__ info,
-                                                     unsigned long long* __restrict__ stamps) {
+                                                     unsigned long long* __restrict__ stamps,
+                                                     const double* __restrict__ xbuf) {
 #define PSTAMP(i)                                                                                                  \
     do {                                                                                                           \
         if (stamps && blockIdx.x == 0 && threadIdx.x == 0 && k < 64) stamps[k * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
@@ -229,7 +285,31 @@ __global__ __launch_bounds__(512) void k_potrf_step8(int D, int k, const double*
             tv[ct][r] = (row < D && col < D) ? Asrc[(size_t)row * lda + col] : ((row == col) ? 1.0 : 0.0);
         }
     v4d acc[2];
-    if (k > 0) {
+    if (PRESOLVED) {
+        // X_I^T and X_J^T ([column][p], 64 x 64 each) from the solve launch: straight into the operand tiles
+        const double* xi = xbuf + (size_t)(k + ti) * NB * NB;
+        const double* xj = xbuf + (size_t)(k + tj) * NB * NB;
+        double vi[8], vj[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            vi[q] = xi[tid + 512 * q];
+            vj[q] = xj[tid + 512 * q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 512 * q;
+            L2[(e >> 6) * RS + (e & 63)] = vi[q];
+            L1[(e >> 6) * RS + (e & 63)] = vj[q];
+        }
+        __syncthreads();
+        PSTAMP(2);
+        acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+        potrf_mma64x8(L2, L1, acc, wr, rr, wc, c, ks);                // T -= X_I^T X_J
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tv[ct][r] -= acc[ct][r];
+    } else if (k > 0) {
         const double* Wk = wbuf + (size_t)((k - 1) & 1) * NB * NB;
         double vw[8], vi[8], vj[8];
 #pragma unroll
@@ -349,15 +429,23 @@ __global__ void k_potrf_clear_info(int* info) { *info = 0; }
 
 int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                      int* info_dev) {
-    // one launch per block step; workspace (the idle panel-partial slab): two row buffers and two W blocks
+    // one launch per block step (two for the early steps of a large matrix); workspace (the idle panel-partial slab): two row
+    // buffers, two W blocks and the X^T blocks of the split steps
     const int nblk = (D + NB - 1) / NB, ldrow = nblk * NB;
     double* rowbuf = ctx->pp;
     double* wbuf = rowbuf + (size_t)2 * NB * ldrow;
     hipLaunchKernelGGL(k_potrf_clear_info, dim3(1), dim3(1), 0, st, info_dev);
+    double* xbuf = wbuf + (size_t)2 * NB * NB;                    // nblk blocks of 64 x 64: X_J^T of the split steps
     for (int k = 0; k < nblk; ++k) {
         const int m = nblk - k;
-        hipLaunchKernelGGL(k_potrf_step8, dim3(m * (m + 1) / 2), dim3(512), 0, st, D, k, S, lds, R, ldr, rowbuf, ldrow,
-                           wbuf, info_dev, ctx->timeline_stamps(3));
+        if (k > 0 && m >= (ctx->tune_potrf_split_m > 0 ? ctx->tune_potrf_split_m : POTRF_SPLIT_M) && !ctx->tune_no_fast) {
+            hipLaunchKernelGGL(k_potrf_solve, dim3(m), dim3(512), 0, st, D, k, S, lds, R, ldr, rowbuf, ldrow, wbuf, xbuf);
+            hipLaunchKernelGGL(k_potrf_step8<true>, dim3(m * (m + 1) / 2), dim3(512), 0, st, D, k, S, lds, R, ldr, rowbuf,
+                               ldrow, wbuf, info_dev, ctx->timeline_stamps(3), xbuf);
+        } else {
+            hipLaunchKernelGGL(k_potrf_step8<false>, dim3(m * (m + 1) / 2), dim3(512), 0, st, D, k, S, lds, R, ldr, rowbuf,
+                               ldrow, wbuf, info_dev, ctx->timeline_stamps(3), xbuf);
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -201,6 +201,27 @@ def test_potrf_matches_numpy(eng, D):
     assert rel_err(Rn.T @ Rn, st["S0"]) < 1e-12
 
 
+@pytest.mark.parametrize("D", [1600, 2048, 2500, 4096])
+def test_potrf_split_row_solve_of_large_matrices(eng, D):
+    """D >= 1537: the early block steps (>= 24 tile rows) run the triangular solve of a block row once, in its own launch
+    (k_potrf_solve), instead of inside every tile; the late steps stay fused.  Against LAPACK, with a ragged last block
+    (1600 = 25 blocks, 2500 = 39 blocks + 4), a non-PD pivot in a split step and one in a fused step."""
+    rs = np.random.RandomState(D)
+    A = rs.standard_normal((D, D + 8)) / np.sqrt(D)
+    S = A @ A.T + 0.05 * np.eye(D)
+    R, flag = eng.potrf(eng.asarray(S))
+    assert eng.read_flag(flag) == 0
+    Rn = R.cpu().numpy()
+    assert rel_err(Rn, np.linalg.cholesky(S).T) < 1e-10
+    assert np.array_equal(np.tril(Rn, -1), np.zeros_like(Rn))
+    assert rel_err(Rn.T @ Rn, S) < 1e-12
+    for bad_at in (130, D - 70):
+        Sb = S.copy()
+        Sb[bad_at, bad_at] = -1.0
+        _, flag = eng.potrf(eng.asarray(Sb))
+        assert eng.read_flag(flag) == bad_at + 1
+
+
 def test_potrf_flags_non_pd_and_nan(eng, golden):
     g = golden("g4_revert.npz")
     _, flag = eng.potrf(eng.asarray(g["S"]))            # the reference's failing covariance
