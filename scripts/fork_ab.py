@@ -36,5 +36,6 @@ for fork in (0, 1, 0, 1):
         gr.replay()
     torch.cuda.synchronize()
     print(f"D={D} B={B} fork={fork}: factor update {t_e:.1f} us eager, {(time.perf_counter() - t0) / 40 * 1e6:.1f} us graph")
-print("bit-identical:", torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]))
+print("fork vs one stream, max rel diff of F:", float((res[0][1] - res[1][1]).abs().max() / res[0][1].abs().max()),
+      "(0 with wide=0: same kernels on both sides; the forked product carries no side job and takes the wide kernel)")
 eng.set_tuning("fork_min_D", 3072)
