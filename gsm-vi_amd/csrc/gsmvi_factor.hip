@@ -203,26 +203,6 @@ __global__ __launch_bounds__(256) void k_gsmf_prep(int D, int B, int KC, const d
     Tm1[(size_t)b * D + i] = x - m;
 }
 
-// LDS[128][130] <- upper triangle of the n x n matrix src (n <= 128), zero below, identity beyond n.
-// Clamped unconditional loads, 16 in flight per thread: a guarded load per iteration serialises 64 L2 round trips.
-__device__ __forceinline__ void load_upper128(double* Mt, const double* __restrict__ src, int n) {
-    const int j = threadIdx.x & 127, jc = j < n ? j : n - 1, ih = threadIdx.x >> 7;
-#pragma unroll
-    for (int it0 = 0; it0 < 64; it0 += 16) {
-        double v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int i = ih + 2 * (it0 + u), ic = i < n ? i : n - 1;
-            v[u] = src[(size_t)ic * n + jc];
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int i = ih + 2 * (it0 + u);
-            Mt[i * 130 + j] = (i < n && j < n) ? (j >= i ? v[u] : 0.0) : (i == j ? 1.0 : 0.0);
-        }
-    }
-}
-
 // ---- A' = I + Rg J Rg^T  (n x n, 64 < n <= 128),  J = (1/B) [[0, I], [I, -I]],  Rg upper triangular ----
 //   (Rg J)[i][k] = (1/B) * ( k <  B : Rg[i][B+k]
 //                            k >= B : Rg[i][k-B] - Rg[i][k] )
@@ -355,6 +335,220 @@ __global__ __launch_bounds__(512) void k_chol128(int n, const double* __restrict
         if (i < 64) x = (j >= i) ? E1[i * ES1 + j] : 0.0;        // [R11 | R12]: columns 64.. sit at E1[:, 64 + (j - 64)]
         else if (j >= i) x = E2[(i - 64) * ES2 + (j - 64)];
         R[e] = x;
+    }
+    if (tid == 0) *info = sh_fail[0] != 0 ? sh_fail[0] : (sh_fail[1] != 0 ? 64 + sh_fail[1] : 0);
+}
+
+// ---- the same factorisation WITH the inverse factor: A = R^T R and W = R^-T (lower triangular), 64 < n <= 128 -------------
+// The Gram matrix of the factor path needs W = Rg^-T as an explicit matrix (K'' = (W S)^T (T - I)(W S)).  Round 2 got it from a
+// 128-step substitution in a launch of its own (k_gsmf_kmat_big: 25 us).  Here both diagonal blocks are factored as
+// [A_kk | I] -> [R_kk | W_kk] (chol64_blk, AUG = 1: +1.8 us each over the plain factorisation) and the off-diagonal blocks are
+// MFMA products of things already in LDS:
+//   R12 = D' W11 A12           (the row operations that turned I into W11, applied to A12; D' zeroes the rows the
+//                               rank-revealing rule dropped, which is what the riding columns of AUG = 2 would hold)
+//   A22' = A22 - R12^T R12,    [A22' | I] -> [R22 | W22]
+//   W21 = -(W22 R12^T) W11     (block inverse of a triangular matrix)
+// One workgroup, E1 [64][146] is used for both factorisations (R11, W11 go to global memory in between; W11 is read back
+// for the last product), B12 [64][66] holds R12, then W11.  Same dropped-row convention as k_gsmf_kmat_big's unit pivots.
+template <bool SEMIDEF>
+__global__ __launch_bounds__(512) void k_chol128w(int n, const double* __restrict__ A, double* __restrict__ R,
+                                                  double* __restrict__ Wo, int* __restrict__ info) {
+    constexpr int ES1 = 146, BS = 66;
+    __shared__ __attribute__((aligned(16))) double E1[64 * ES1];
+    __shared__ __attribute__((aligned(16))) double B12[64 * BS];
+    __shared__ __attribute__((aligned(16))) double scr[CHOLB_SCRATCH_DOUBLES(1)];
+    __shared__ int sh_fail[2], sh_moderate;
+    const int tid = threadIdx.x, n2 = n - 64;
+    const int w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+    if (tid == 0) sh_moderate = 1;
+    __syncthreads();
+    {   // A11 (upper triangle) -> E1 left half; the magnitude guard looks at BOTH diagonal blocks, as k_chol128 does
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 512 * u, i = e >> 6, q = e & 63;
+            v[u] = A[(size_t)i * n + q];
+        }
+        const double d2 = (tid < n2) ? A[(size_t)(64 + tid) * n + 64 + tid] : 0.0;
+        if (SEMIDEF && !(d2 < 4294967296.0)) sh_moderate = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 512 * u, i = e >> 6, q = e & 63;
+            double x = (q < i) ? 0.0 : v[u];
+            if (SEMIDEF && q == i) {
+                if (!(x < 4294967296.0)) sh_moderate = 0;
+                x -= GSMVI_DEP_TOL * x;
+            }
+            E1[i * ES1 + q] = x;
+        }
+    }
+    __syncthreads();
+    const bool moderate = sh_moderate != 0;
+    chol64_blk<ES1, SEMIDEF, 1>(E1, scr, 64, &sh_fail[0], moderate);   // [A11 | I] -> [R11 | W11]
+    // R12 = D' W11 A12: block (ib, jb), k-blocks 0 .. ib (W11 is lower triangular); A12 straight from global memory
+    for (int blk = w; blk < 16; blk += 8) {
+        const int ib = blk >> 2, jb = blk & 3;
+        const int gj = 64 + 16 * jb + c;
+        double a[16], b[16];
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const int k = 4 * st + ks;
+            a[st] = E1[(16 * ib + c) * ES1 + 64 + k];
+            b[st] = A[(size_t)k * n + (gj < n ? gj : n - 1)];
+        }
+        v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int st = 0; st < 16; st += 2) {
+            if (st < 4 * (ib + 1)) {                                   // wave-uniform
+                acc0 = GSMVI_MFMA_F64(a[st], gj < n ? b[st] : 0.0, acc0);
+                acc1 = GSMVI_MFMA_F64(a[st + 1], gj < n ? b[st + 1] : 0.0, acc1);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * ib + ks + 4 * r, j = 16 * jb + c;
+            double x = acc0[r] + acc1[r];
+            if (E1[i * ES1 + i] == 0.0) x = 0.0;                        // a dropped row of R
+            B12[i * BS + j] = x;
+            if (64 + j < n) R[(size_t)i * n + 64 + j] = x;
+        }
+    }
+    __syncthreads();
+    // R11, W11 out (and the two zero blocks); meanwhile the updated A22 in registers: upper 16 x 16 blocks, K = 64
+    for (int e = tid; e < 64 * 64; e += 512) {
+        const int i = e >> 6, j = e & 63;
+        R[(size_t)i * n + j] = (j >= i) ? E1[i * ES1 + j] : 0.0;
+        Wo[(size_t)i * n + j] = (j <= i) ? E1[i * ES1 + 64 + j] : 0.0;
+        if (64 + j < n) Wo[(size_t)i * n + 64 + j] = 0.0;               // W12 = 0
+        if (i < n2) R[(size_t)(64 + i) * n + j] = 0.0;                  // R21 = 0
+    }
+    double t22[2][4];
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+        const int blk = w + 8 * slot;
+        if (blk < 10) {
+            int bi = 0, rem = blk;
+            while (rem >= 4 - bi) { rem -= 4 - bi; ++bi; }
+            const int bj = bi + rem;
+            double a[16], b[16];
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                a[st] = B12[(4 * st + ks) * BS + 16 * bi + c];
+                b[st] = B12[(4 * st + ks) * BS + 16 * bj + c];
+            }
+            v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int st = 0; st < 16; st += 2) {
+                acc0 = GSMVI_MFMA_F64(a[st], b[st], acc0);
+                acc1 = GSMVI_MFMA_F64(a[st + 1], b[st + 1], acc1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * bi + ks + 4 * r, j = 16 * bj + c;
+                double x = (i == j) ? 1.0 : 0.0;                        // identity beyond n2
+                if (i < n2 && j < n2) {
+                    x = A[(size_t)(64 + i) * n + 64 + j];
+                    if (SEMIDEF && i == j) x -= GSMVI_DEP_TOL * x;
+                    x -= acc0[r] + acc1[r];
+                }
+                t22[slot][r] = (j >= i) ? x : 0.0;
+            }
+        }
+    }
+    __syncthreads();                                                    // every read of R11 / W11 in E1 is done
+    for (int e = tid; e < 64 * 64; e += 512) {                          // blocks below the block diagonal: zero
+        const int i = e >> 6, j = e & 63;
+        if ((j >> 4) < (i >> 4)) E1[i * ES1 + j] = 0.0;
+    }
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+        const int blk = w + 8 * slot;
+        if (blk < 10) {
+            int bi = 0, rem = blk;
+            while (rem >= 4 - bi) { rem -= 4 - bi; ++bi; }
+            const int bj = bi + rem;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) E1[(16 * bi + ks + 4 * r) * ES1 + 16 * bj + c] = t22[slot][r];
+        }
+    }
+    __syncthreads();
+    chol64_blk<ES1, SEMIDEF, 1>(E1, scr, n2, &sh_fail[1], moderate);   // [A22' | I] -> [R22 | W22]
+    for (int e = tid; e < 64 * 64; e += 512) {
+        const int i = e >> 6, j = e & 63;
+        if (i < n2 && j < n2) {
+            R[(size_t)(64 + i) * n + 64 + j] = (j >= i) ? E1[i * ES1 + j] : 0.0;
+            Wo[(size_t)(64 + i) * n + 64 + j] = (j <= i) ? E1[i * ES1 + 64 + j] : 0.0;
+        }
+    }
+    __syncthreads();                                                    // R22 (E1 left half) is out: the half becomes T1
+    // T1 = W22 R12^T: (i in block 2, j in block 1), k over block 2; W22[i][k] = 0 for k > i
+    {
+        double t1[2][4];
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot) {
+            const int blk = w + 8 * slot, ib = blk >> 2, jb = blk & 3;
+            double a[16], b[16];
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                const int k = 4 * st + ks;
+                a[st] = E1[(16 * ib + c) * ES1 + 64 + k];
+                b[st] = B12[(16 * jb + c) * BS + k];
+            }
+            v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int st = 0; st < 16; st += 2) {
+                if (st < 4 * (ib + 1)) {
+                    acc0 = GSMVI_MFMA_F64(a[st], b[st], acc0);
+                    acc1 = GSMVI_MFMA_F64(a[st + 1], b[st + 1], acc1);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t1[slot][r] = acc0[r] + acc1[r];
+        }
+        __syncthreads();                                                // all reads of B12 (R12) and of E1's left half are done
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot) {
+            const int blk = w + 8 * slot, ib = blk >> 2, jb = blk & 3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) E1[(16 * ib + ks + 4 * r) * ES1 + 16 * jb + c] = t1[slot][r];
+        }
+        // W11 back from global memory (written by this workgroup before two barriers) into B12
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 512 * u, i = e >> 6, j = e & 63;
+            v[u] = __builtin_nontemporal_load(Wo + (size_t)i * n + j);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 512 * u, i = e >> 6, j = e & 63;
+            B12[i * BS + j] = v[u];
+        }
+    }
+    __syncthreads();
+    // W21 = -T1 W11: (i in block 2, j in block 1), k over block 1; W11[k][j] = 0 for k < j
+    for (int blk = w; blk < 16; blk += 8) {
+        const int ib = blk >> 2, jb = blk & 3;
+        double a[16], b[16];
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const int k = 4 * st + ks;
+            a[st] = E1[(16 * ib + c) * ES1 + k];
+            b[st] = B12[k * BS + 16 * jb + c];
+        }
+        v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int st = 0; st < 16; st += 2) {
+            if (st >= 4 * jb) {                                         // wave-uniform
+                acc0 = GSMVI_MFMA_F64(a[st], b[st], acc0);
+                acc1 = GSMVI_MFMA_F64(a[st + 1], b[st + 1], acc1);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * ib + ks + 4 * r, j = 16 * jb + c;
+            if (i < n2) Wo[(size_t)(64 + i) * n + j] = -(acc0[r] + acc1[r]);
+        }
     }
     if (tid == 0) *info = sh_fail[0] != 0 ? sh_fail[0] : (sh_fail[1] != 0 ? 64 + sh_fail[1] : 0);
 }
@@ -527,64 +721,8 @@ __global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double
 }
 
 // ---- K = Rg^-1 (T - I) Rg^-T = W^T (T - I) W, W = Rg^-T, for 64 < n <= 128 -----------------------------------
-// k_gsmf_kmat_big: W by forward substitution.  One workgroup handles 16 columns, SIXTEEN lanes per column (lane
-// q of the group owns rows q, q+16, ..); Rg is resident in LDS ([128][130], padded with the identity beyond
-// n); each substitution step broadcasts the pivot value inside the 16-lane group.  The two products then run
-// on the MFMA pipe (k_gsmf_gemm128), instead of a second and a third 128-step substitution.
-__device__ __forceinline__ void kmat_load_lds(double* Mt, double* rinv, const double* __restrict__ src, int n,
-                                              bool want_rinv) {
-    load_upper128(Mt, src, n);
-    __syncthreads();
-    if (want_rinv && threadIdx.x < 128) {              // a zero diagonal marks a dependent row of [Z; U]: unit pivot
-        const double dg = Mt[threadIdx.x * 130 + threadIdx.x];
-        rinv[threadIdx.x] = dg == 0.0 ? 1.0 : 1.0 / dg;
-    }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void k_gsmf_kmat_big(int n, const double* __restrict__ Rg,
-                                                       double* __restrict__ Wout,
-                                                       const int* __restrict__ info_g,
-                                                       const int* __restrict__ info_t, int* __restrict__ bad_out,
-                                                       const int* __restrict__ prior_bad) {
-    __shared__ __attribute__((aligned(16))) double Mt[128 * 130];
-    __shared__ double rinv[128];
-    const int bad = (*info_g != 0) || (*info_t != 0) || (prior_bad && *prior_bad != 0);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *bad_out = bad;
-    if (bad) return;                                         // block-uniform
-    const int tid = threadIdx.x, c = tid >> 4, q = tid & 15, grp = tid & 48;   // grp: first lane of the group in the wave
-    const int cg = blockIdx.x * 16 + c;
-    double x[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) x[r] = (q + 16 * r == cg) ? 1.0 : 0.0;
-    // The pivot loops are blocked 8 x 16: the outer block index is unrolled (static register indices), the 16
-    // pivots inside a block stay a rolled loop -- fully unrolled, the scheduler hoists every LDS read and spills.
-    // phase 1: x = Rg^-T e_c   (L = Rg^T, L[t][p] = Rg[p][t]: row p of Rg)
-    kmat_load_lds(Mt, rinv, Rg, n, true);
-#pragma unroll
-    for (int pb = 0; pb < 8; ++pb) {
-#pragma unroll 2
-        for (int pq = 0; pq < 16; ++pq) {
-            const int p = 16 * pb + pq;
-            const double mine = x[pb] * rinv[p];
-            if (q == pq) x[pb] = mine;
-            const double xp = __shfl(mine, grp | pq, 64);
-            const double* row = Mt + p * 130 + q;
-            x[pb] -= (q > pq) ? row[16 * pb] * xp : 0.0;
-#pragma unroll
-            for (int r = pb + 1; r < 8; ++r) x[r] -= row[16 * r] * xp;
-        }
-    }
-    // W = Rg^-T (lower triangular), column cg in this group's registers
-    if (cg < n) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int t = q + 16 * r;
-            if (t < n) Wout[(size_t)t * n + cg] = x[r];
-        }
-    }
-}
-
+// W comes out of the Gram matrix's factorisation itself (k_chol128w); the two products run on the MFMA pipe
+// (k_gsmf_gemm128).  (Round 2's 128-step substitution launch k_gsmf_kmat_big was removed in round 3: 25 us.)
 // ---- C = op(A) B for n x n matrices (n <= 128), one 16 x 16 block per wave -------------------------------
 //   MODE 0:  C = (A - I) B     (A = T upper triangular: P = (T - I) W)
 //   MODE 1:  C = A^T B         (A = W lower triangular: K = W^T P)
@@ -806,6 +944,7 @@ __global__ __launch_bounds__(256) void k_gsmf_gamma_big(int n, int B, const doub
     __shared__ double s_alpha[64], s_beta[64];
     const int tid = threadIdx.x;
     auto g1 = [&](int i, int q) {                      // one entry of Gamma1: the kcg slabs, all loads in one batch
+        if (kcg == 1) return Gp[(size_t)i * n + q];    // block-uniform: the finished matrix
         double t[GSMVI_MAX_KC];
 #pragma unroll
         for (int kc = 0; kc < GSMVI_MAX_KC; ++kc) t[kc] = Gp[(size_t)(kc < kcg ? kc : kcg - 1) * n * n + (size_t)i * n + q];
@@ -843,9 +982,16 @@ __global__ __launch_bounds__(256) void k_gsmf_gamma_big(int n, int B, const doub
 }
 
 // W <- W S in place (n x n, column pairs (b, B + b)): K'' = S^T K S = (W S)^T (T - I) (W S)
+// This launch also takes the accept / revert decision of the chain: every workgroup derives it from the two factorisations'
+// flags (and BaM's, prior_bad), workgroup 0 publishes it
 __global__ __launch_bounds__(256) void k_gsmf_wscale(int n, int B, double* __restrict__ Wm, const double* __restrict__ ab,
-                                                     const int* __restrict__ bad) {
-    if (*bad) return;
+                                                     int* __restrict__ bad, const int* __restrict__ info_g,
+                                                     const int* __restrict__ info_t, const int* __restrict__ prior_bad) {
+    if (info_g != nullptr) {
+        const int b = (*info_g != 0) || (*info_t != 0) || (prior_bad && *prior_bad != 0);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *bad = b;
+        if (b) return;
+    } else if (*bad) return;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= n * B) return;
     const int r = e / B, b = e % B;
@@ -1153,18 +1299,20 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
     } else {
         // 64 < n <= 128: Gamma, the two n x n Choleskys one workgroup each, W and K in their own kernels
         Kmat = w.Gam;                              // Gamma is dead once Rg exists
-        double* Wm = w.Ap;                         // A' is dead once T exists
+        double* Wm = w.Pm;
         hipLaunchKernelGGL(k_gsmf_gamma_big, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, w.Gam, coef, coef + n, jmode);
-        hipLaunchKernelGGL(k_chol128<true>, dim3(1), dim3(512), 0, st, n, w.Gam, w.Rg, info_g);   // Gram matrix: semi-definite rule
+        // Gram matrix: semi-definite rule; W = Rg^-T comes out of the same factorisation (no substitution launch)
+        hipLaunchKernelGGL(k_chol128w<true>, dim3(1), dim3(512), 0, st, n, w.Gam, w.Rg, w.Pm, info_g);
         hipLaunchKernelGGL(k_gsmf_small_a, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, st, n, B, w.Rg, info_g, w.Ap, jmode);
         hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n, w.Ap, w.Tt, info_t);
         if ((rc = chk("k_chol128"))) return rc;
-        hipLaunchKernelGGL(k_gsmf_kmat_big, dim3((n + 15) / 16), dim3(256), 0, st, n, w.Rg, Wm, info_g, info_t, info_dev, prior);
-        hipLaunchKernelGGL(k_gsmf_wscale, dim3((n * B + 255) / 256), dim3(256), 0, st, n, B, Wm, coef + n, info_dev);
-        if ((rc = chk("k_gsmf_kmat_big"))) return rc;
+        // W S in place (where k_chol128w left W); this launch also takes the chain's accept / revert decision
+        hipLaunchKernelGGL(k_gsmf_wscale, dim3((n * B + 255) / 256), dim3(256), 0, st, n, B, Wm, coef + n, info_dev, info_g, info_t, prior);
+        double* Pmat = w.Ap;                       // A' is dead once T exists
+        if ((rc = chk("k_gsmf_wscale"))) return rc;
         const int nb = (n + 15) / 16, gw = (nb * nb + 3) / 4;
-        hipLaunchKernelGGL(k_gsmf_gemm128<0>, dim3(gw), dim3(256), 0, st, n, w.Tt, Wm, w.Pm, info_dev);   // P = (T - I) W S
-        hipLaunchKernelGGL(k_gsmf_gemm128<1>, dim3(gw), dim3(256), 0, st, n, Wm, w.Pm, Kmat, info_dev);   // K'' = (W S)^T P
+        hipLaunchKernelGGL(k_gsmf_gemm128<0>, dim3(gw), dim3(256), 0, st, n, w.Tt, Wm, Pmat, info_dev);   // P = (T - I) W S
+        hipLaunchKernelGGL(k_gsmf_gemm128<1>, dim3(gw), dim3(256), 0, st, n, Wm, Pmat, Kmat, info_dev);   // K'' = (W S)^T P
         if ((rc = chk("k_gsmf_gemm128"))) return rc;
     }
     if (!ctx->tune_no_fast && ctx->tune_direct_out && D % 64 == 0 && (n == 16 || n == 32 || n == 64) && ldf0 % 2 == 0 &&

@@ -454,3 +454,29 @@ def test_wide_panel_kernels_agree_with_the_strip_kernels(D):
     finally:
         eng.set_tuning("wide", 1)
         eng.set_tuning("wide_kc", 0)
+
+
+@pytest.mark.parametrize("D,B", [(256, 64), (200, 33), (320, 40), (1024, 48), (512, 63)])
+def test_inverse_factor_from_the_factorisation(D, B):
+    """64 < 2B <= 128: W = Rg^-T comes out of the blocked factorisation of the Gram matrix (k_chol128w: both diagonal blocks
+    as [A | I] -> [R | W], off-diagonal blocks as MFMA products; round 2 ran a 128-step substitution launch, which agreed
+    with this path to 1e-12 before it was removed).  Against the oracle, incl. ragged 2B (66, 80, 96, 126) and linearly
+    dependent rows, whose dropped pivots must come out the same way in R and in W."""
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    orc, st, F0 = _setup(D, B, D + 7 * B)
+    dv = [eng.asarray(st[k]) for k in ("Z", "samples", "vs", "mu0")] + [eng.asarray(F0)]
+    mu, F, flag = eng.gsm_factor_update(*dv)
+    assert eng.read_flag(flag) == 0
+    mu_o, S_o = orc.gsm_update_batched(st["samples"], st["vs"], st["mu0"], st["S0"])
+    Fn = F.cpu().numpy()
+    assert rel_err(Fn.T @ Fn, S_o) < 1e-10 and rel_err(mu.cpu().numpy(), mu_o) < 1e-10
+    # dependent rows of [Z; V] (two pairs of identical samples): the rank-revealing rule drops them
+    Z2, X2, G2 = st["Z"].copy(), st["samples"].copy(), st["vs"].copy()
+    Z2[1], X2[1], G2[1] = Z2[0], X2[0], G2[0]
+    Z2[B - 1], X2[B - 1], G2[B - 1] = Z2[B - 2], X2[B - 2], G2[B - 2]
+    mu, F, flag = eng.gsm_factor_update(*[eng.asarray(a) for a in (Z2, X2, G2, st["mu0"], F0)])
+    assert eng.read_flag(flag) == 0
+    mu_o, S_o = orc.gsm_update_batched(X2, G2, st["mu0"], st["S0"])
+    Fn = F.cpu().numpy()
+    assert rel_err(Fn.T @ Fn, S_o) < 1e-9 and rel_err(mu.cpu().numpy(), mu_o) < 1e-9
