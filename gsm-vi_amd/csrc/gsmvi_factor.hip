@@ -1123,11 +1123,36 @@ static int factor_w_prep(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const dou
 // (kcg = 1: finished); V Fm either finished in Tm1 (vf_slabs == nullptr) or as kcv split-K slabs summed by their consumer.
 static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
                        double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, const double* Gp, int kcg,
-                       const double* vf_slabs, int kcv, int jmode = 0, int chain_done = 0, hipEvent_t join = nullptr);
+                       const double* vf_slabs, int kcv, int jmode = 0, int chain_done = 0, int fork_vf = 0);
 
 // the Gram product Gamma1 = [Z; V][Z; V]^T as split-K slabs (transposed panel product with A = M = Rt1)
 static int factor_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int n, const factor_ws& w, int* kcg, int mt_cap = 4) {
     return gsmvi_panel_t_product_mt(ctx, st, D, n, w.Rt, D, w.Rt, D, n, w.Gp, kcg, mt_cap);
+}
+
+// V Fm (rows B .. 2B-1 of Rt times Fm) as split-K slabs in ctx->pp, on the context's second stream: forked from `st` here,
+// joined by the consumer's hipStreamWaitEvent(st, ctx->ev_join)
+static int factor_fork_point(gsmvi_ctx* ctx, hipStream_t st) {
+    hipError_t e = hipEventRecord(ctx->ev_fork, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);
+    if (e != hipSuccess) { gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "fork failed"); return GSMVI_ERR_HIP; }
+    return GSMVI_OK;
+}
+static int factor_fork_vf(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Rt, const double* F0, int ldf0, int* kcv,
+                          bool fork_here = true) {
+    int rc = fork_here ? factor_fork_point(ctx, st) : GSMVI_OK;
+    if (rc) return rc;
+    rc = gsmvi_panel_product_nc(ctx, ctx->side, nullptr, D, D, B, Rt + (size_t)B * D, D, nullptr, 1.0, F0, ldf0, ctx->pp, kcv);
+    if (rc) return rc;
+    if (!ctx->px_used) {
+        gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "fast panel kernel expected (internal error)");
+        return GSMVI_ERR_UNSUPPORTED;
+    }
+    if (hipEventRecord(ctx->ev_join, ctx->side) != hipSuccess) {
+        gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "join failed");
+        return GSMVI_ERR_HIP;
+    }
+    return GSMVI_OK;
 }
 
 int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
@@ -1148,23 +1173,21 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
     // launches of the 2B x 2B chain (~100 us on a few CUs), so it runs on the context's second stream beside them; the two
     // event edges cost ~10 us, which is why D = 1024 does not fork (measured in round 2: slower there).
     if (lean && n > 64 && ctx->side && ctx->tune_fork_min_D > 0 && D >= ctx->tune_fork_min_D) {
-        hipError_t e = hipEventRecord(ctx->ev_fork, st);                   // [Z; V] and X - mu exist: fork here
-        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);
-        if (e != hipSuccess) { gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "fork failed"); return GSMVI_ERR_HIP; }
+        // Where to fork.  Launched eagerly, the best place is behind the last multi-workgroup kernel in front of the one-workgroup
+        // factorisations (inside factor_back, fork_vf = 1): V Fm then overlaps those, and the memory-bound Gram / Gamma kernels run
+        // without its competition (313 -> 299 us at D = 4096).  Replayed from a hipGraph that placement is SLOWER (335 us: the
+        // graph executor orders the branch in front of the factorisation it should run beside), so under stream capture the
+        // fork stays in front of the Gram product (fork_vf = 2: 314 us).
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        const int fork_vf = (cap == hipStreamCaptureStatusActive) ? 2 : 1;
+        if (fork_vf == 2 && (rc = factor_fork_point(ctx, st))) return rc;
         if ((rc = factor_gram(ctx, st, D, n, w, &kcg))) return rc;
-        if ((rc = gsmvi_panel_product_nc(ctx, ctx->side, nullptr, D, D, B, w.Rt + (size_t)B * D, D, nullptr, 1.0, F0, ldf0, ctx->pp,
-                                         &kcv)))
-            return rc;
-        if (!ctx->px_used) {
-            gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "fast panel kernel expected (internal error)");
-            return GSMVI_ERR_UNSUPPORTED;
-        }
-        if (hipEventRecord(ctx->ev_join, ctx->side) != hipSuccess) {
-            gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "join failed");
-            return GSMVI_ERR_HIP;
-        }
-        return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, w.Gp, kcg, ctx->pp, kcv, 0, 0,
-                           ctx->ev_join);
+        // (captured AFTER the Gram node: the graph executor issues nodes in creation order, and a 512-workgroup product issued
+        // first delays the Gram product it does not depend on)
+        if (fork_vf == 2 && (rc = factor_fork_vf(ctx, st, D, B, w.Rt, F0, ldf0, &kcv, false))) return rc;
+        return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, w.Gp, kcg,
+                           fork_vf == 2 ? ctx->pp : nullptr, kcv, 0, 0, fork_vf);
     }
     if ((rc = factor_gram(ctx, st, D, n, w, &kcg, (ctx->tune_rider && n <= 64) ? ctx->tune_gram_mt : 4))) return rc;
     if (lean) {
@@ -1279,7 +1302,7 @@ int gsmvi_factor_apply_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const 
 
 static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
                        double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, const double* Gp, int kcg,
-                       const double* vf_slabs, int kcv, int jmode, int chain_done, hipEvent_t join) {
+                       const double* vf_slabs, int kcv, int jmode, int chain_done, int fork_vf) {
     const int n = 2 * B;                           // n is even
     const factor_ws w = factor_carve(ctx, D, n);
     double *Rt = w.Rt, *Tm = w.Tm, *Fs = w.Fs, *coef = w.coef;
@@ -1301,6 +1324,10 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         Kmat = w.Gam;                              // Gamma is dead once Rg exists
         double* Wm = w.Pm;
         hipLaunchKernelGGL(k_gsmf_gamma_big, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, w.Gam, coef, coef + n, jmode);
+        if (fork_vf == 1) {                        // V Fm on the second stream from here on: beside the one-workgroup kernels below
+            if ((rc = factor_fork_vf(ctx, st, D, B, Rt, F0, ldf0, &kcv))) return rc;
+            vf_slabs = ctx->pp;
+        }
         // Gram matrix: semi-definite rule; W = Rg^-T comes out of the same factorisation (no substitution launch)
         hipLaunchKernelGGL(k_chol128w<true>, dim3(1), dim3(512), 0, st, n, w.Gam, w.Rg, w.Pm, info_g);
         hipLaunchKernelGGL(k_gsmf_small_a, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, st, n, B, w.Rg, info_g, w.Ap, jmode);
@@ -1325,7 +1352,7 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         return chk("k_gsmf_update_fs");
     }
     // Fs = K'' Tm1 as one skinny GEMM: inner dimension n <= one chunk, so there is exactly one slab, written straight into Fs
-    if (join && hipStreamWaitEvent(st, join, 0) != hipSuccess) {       // the V Fm slabs come from the side stream (large D)
+    if (fork_vf && hipStreamWaitEvent(st, ctx->ev_join, 0) != hipSuccess) {       // the V Fm slabs come from the side stream (large D)
         gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "hipStreamWaitEvent failed");
         return GSMVI_ERR_HIP;
     }
