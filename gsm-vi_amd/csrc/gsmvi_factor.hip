@@ -723,27 +723,42 @@ __global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double
 // ---- K = Rg^-1 (T - I) Rg^-T = W^T (T - I) W, W = Rg^-T, for 64 < n <= 128 -----------------------------------
 // W comes out of the Gram matrix's factorisation itself (k_chol128w); the two products run on the MFMA pipe
 // (k_gsmf_gemm128).  (Round 2's 128-step substitution launch k_gsmf_kmat_big was removed in round 3: 25 us.)
-// ---- C = op(A) B for n x n matrices (n <= 128), one 16 x 16 block per wave -------------------------------
-//   MODE 0:  C = (A - I) B     (A = T upper triangular: P = (T - I) W)
-//   MODE 1:  C = A^T B         (A = W lower triangular: K = W^T P)
+// ---- P = (T - I) (W S) and K'' = (W S)^T P for n x n matrices (n <= 128), one 16 x 16 block per wave ------------------
+//   MODE 0:  C = (A - I) (W S)     A = T upper triangular, W = Rg^-T as k_chol128w left it
+//   MODE 1:  C = (W S)^T B         B = P
+// The column operation W S (S = [[I, 0], [diag beta, diag alpha]]: column b <- W[:, b] + beta_b W[:, B+b], column B+b <-
+// alpha_b W[:, B+b]; ab = [beta; alpha] from k_gsmf_gamma_big) is applied while W is loaded -- it was a launch of its own.
+// MODE 0 also takes the chain's accept / revert decision from the two factorisations' flags (and BaM's, prior_bad): every
+// workgroup derives it, workgroup 0 publishes it for MODE 1 and the update kernel.
 // All operand fragments of a block are loaded from L2 in one batch, then one MFMA chain of n/4 steps.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_gsmf_gemm128(int n, const double* __restrict__ A,
+__global__ __launch_bounds__(256) void k_gsmf_gemm128(int n, int B, const double* __restrict__ A,
                                                       const double* __restrict__ Bm, double* __restrict__ Cm,
-                                                      const int* __restrict__ bad) {
-    if (*bad) return;
+                                                      const double* __restrict__ ab, int* __restrict__ bad,
+                                                      const int* __restrict__ info_g, const int* __restrict__ info_t,
+                                                      const int* __restrict__ prior_bad) {
+    if (MODE == 0) {
+        const int b = (*info_g != 0) || (*info_t != 0) || (prior_bad && *prior_bad != 0);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *bad = b;
+        if (b) return;
+    } else if (*bad) return;
     const int nb = (n + 15) >> 4;
     const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blk >= nb * nb) return;                                  // wave-uniform
     const int i0 = (blk / nb) * 16, j0 = (blk % nb) * 16;
     const int l = threadIdx.x & 63, cc = l & 15, ks = l >> 4;
+    const double* Wsrc = MODE == 0 ? Bm : A;                     // the operand that is W
+    const int wc = MODE == 0 ? ((j0 + cc) < n ? j0 + cc : n - 1) : ((i0 + cc) < n ? i0 + cc : n - 1);   // this lane's column of W
+    const int wc2 = wc < B ? wc + B : wc;                        // its partner column (itself for the alpha columns)
+    const double s1 = wc < B ? 1.0 : 0.0, s2 = ab[wc];           // (W S)[:, c] = s1 W[:, c] + s2 W[:, c2]: beta_c for c < B, alpha_{c-B} above
     double a[32], b[32];
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
         const int k = 4 * s + ks;
         const int kc = k < n ? k : n - 1, ic = (i0 + cc) < n ? i0 + cc : n - 1, jc = (j0 + cc) < n ? j0 + cc : n - 1;
-        const double av = MODE == 0 ? A[(size_t)ic * n + kc] - (ic == kc ? 1.0 : 0.0) : A[(size_t)kc * n + ic];
-        const double bv = Bm[(size_t)kc * n + jc];
+        const double ws = s1 * Wsrc[(size_t)kc * n + wc] + s2 * Wsrc[(size_t)kc * n + wc2];
+        const double av = MODE == 0 ? A[(size_t)ic * n + kc] - (ic == kc ? 1.0 : 0.0) : ws;
+        const double bv = MODE == 0 ? ws : Bm[(size_t)kc * n + jc];
         const bool in = k < n && (i0 + cc) < n;
         a[s] = in ? av : 0.0;
         b[s] = (k < n && (j0 + cc) < n) ? bv : 0.0;
@@ -961,7 +976,7 @@ __global__ __launch_bounds__(256) void k_gsmf_gamma_big(int n, int B, const doub
         if (blockIdx.x == 0) {
             coef[tid] = jmode ? 0.0 : be / (double)B;
             coef[B + tid] = jmode ? 0.0 : al / (double)B;
-            ab[tid] = be;                              // for k_gsmf_wscale
+            ab[tid] = be;                              // for k_gsmf_gemm128 (W S)
             ab[B + tid] = al;
         }
     }
@@ -979,25 +994,6 @@ __global__ __launch_bounds__(256) void k_gsmf_gamma_big(int n, int B, const doub
             s_alpha[a] * (s_beta[b] * g1(i, b) + s_alpha[b] * g1(i, q));
     }
     Gam[e] = v;
-}
-
-// W <- W S in place (n x n, column pairs (b, B + b)): K'' = S^T K S = (W S)^T (T - I) (W S)
-// This launch also takes the accept / revert decision of the chain: every workgroup derives it from the two factorisations'
-// flags (and BaM's, prior_bad), workgroup 0 publishes it
-__global__ __launch_bounds__(256) void k_gsmf_wscale(int n, int B, double* __restrict__ Wm, const double* __restrict__ ab,
-                                                     int* __restrict__ bad, const int* __restrict__ info_g,
-                                                     const int* __restrict__ info_t, const int* __restrict__ prior_bad) {
-    if (info_g != nullptr) {
-        const int b = (*info_g != 0) || (*info_t != 0) || (prior_bad && *prior_bad != 0);
-        if (blockIdx.x == 0 && threadIdx.x == 0) *bad = b;
-        if (b) return;
-    } else if (*bad) return;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n * B) return;
-    const int r = e / B, b = e % B;
-    const double wz = Wm[(size_t)r * n + b], wu = Wm[(size_t)r * n + B + b];
-    Wm[(size_t)r * n + b] = wz + ab[b] * wu;
-    Wm[(size_t)r * n + B + b] = ab[B + b] * wu;
 }
 
 int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
@@ -1333,13 +1329,11 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         hipLaunchKernelGGL(k_gsmf_small_a, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, st, n, B, w.Rg, info_g, w.Ap, jmode);
         hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n, w.Ap, w.Tt, info_t);
         if ((rc = chk("k_chol128"))) return rc;
-        // W S in place (where k_chol128w left W); this launch also takes the chain's accept / revert decision
-        hipLaunchKernelGGL(k_gsmf_wscale, dim3((n * B + 255) / 256), dim3(256), 0, st, n, B, Wm, coef + n, info_dev, info_g, info_t, prior);
         double* Pmat = w.Ap;                       // A' is dead once T exists
-        if ((rc = chk("k_gsmf_wscale"))) return rc;
         const int nb = (n + 15) / 16, gw = (nb * nb + 3) / 4;
-        hipLaunchKernelGGL(k_gsmf_gemm128<0>, dim3(gw), dim3(256), 0, st, n, w.Tt, Wm, Pmat, info_dev);   // P = (T - I) W S
-        hipLaunchKernelGGL(k_gsmf_gemm128<1>, dim3(gw), dim3(256), 0, st, n, Wm, Pmat, Kmat, info_dev);   // K'' = (W S)^T P
+        // P = (T - I) (W S), with the chain's accept / revert decision; then K'' = (W S)^T P
+        hipLaunchKernelGGL(k_gsmf_gemm128<0>, dim3(gw), dim3(256), 0, st, n, B, w.Tt, Wm, Pmat, coef + n, info_dev, info_g, info_t, prior);
+        hipLaunchKernelGGL(k_gsmf_gemm128<1>, dim3(gw), dim3(256), 0, st, n, B, Wm, Pmat, Kmat, coef + n, info_dev, info_g, info_t, prior);
         if ((rc = chk("k_gsmf_gemm128"))) return rc;
     }
     if (!ctx->tune_no_fast && ctx->tune_direct_out && D % 64 == 0 && (n == 16 || n == 32 || n == 64) && ldf0 % 2 == 0 &&
