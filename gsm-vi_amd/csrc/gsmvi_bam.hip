@@ -1,9 +1,11 @@
 // BaM (batch-and-match) update for gfx950, fp64.   Reference: gsmvi/bam.py:72-114 (low-rank form),
 // which equals gsmvi/bam.py:31-69 (full form) to round-off.
 //
-// With n = B+1 and the exact factor U = Q Q^T (replacing ARPACK svds, bam.py:10-13):
-//   Qt (n x D) rows  sqrt(reg/B)(g_b - gbar), sqrt(reg/(1+reg)) gbar                      (bam.py:55-59)
-//   Vf (n x D) rows  sqrt(reg/B)(x_b - xbar), sqrt(reg/(1+reg)) (mu0 - xbar)   V = S0 + Vf^T Vf (bam.py:50-53,60)
+// With an exact factor U = Q Q^T of n = B columns (replacing ARPACK svds, bam.py:10-13; the B centred
+// rows sqrt(reg/B)(g_b - gbar) span B - 1 dimensions, so an orthonormal -- Helmert -- recombination gives B - 1 rows with the
+// same Gram sum; until round 3 the B + 1 rows themselves were used):
+//   Qt (n x D) rows  sqrt(reg/B) helmert_k(g), k < B;  sqrt(reg/(1+reg)) gbar            (bam.py:55-59)
+//   Vf (n x D) rows  sqrt(reg/B) helmert_k(x), k < B;  sqrt(reg/(1+reg)) (mu0 - xbar)   V = S0 + Vf^T Vf (bam.py:50-53,60)
 //   P  = Qt S0                      one pass over S0, fp64-MFMA panel product
 //   M1 = Vf Q,  N0 = P Q            (n x n) Gram matrices over D;  A^T = P + M1^T Vf        (bam.py:107)
 //   N  = A^T Q = N0 + M1^T M1;  BB = ((N + I/4)^(1/2) + I/2)^2 = N + I/2 + (N + I/4)^(1/2)  (bam.py:108-109)
@@ -22,77 +24,117 @@
 #include "gsmvi_ctx.h"
 #include "../../include/gsmvi_hip.h"
 
-// ---- column means and the factor panels -----------------------------------------------------
-// Workgroup = 64 columns x 4 sample groups (thread (g, c): samples g, g + 4, ...; eight independent loads in
-// flight); the four partial column sums are combined through LDS in a fixed order.  Qt, Vf row-major n x D (ld D);
-// Qm = Qt^T as D x n (ld nq), written through an LDS transpose so that both layouts are stored coalesced.
-__global__ __launch_bounds__(256) void k_bam_stats(int D, int B, const double* __restrict__ X, int ldx,
-                                                   const double* __restrict__ G, int ldg,
-                                                   const double* __restrict__ mu0, double reg,
-                                                   double* __restrict__ xbar, double* __restrict__ gbar,
-                                                   double* __restrict__ Qt, double* __restrict__ Vf,
-                                                   double* __restrict__ Vf2, double* __restrict__ Qm, int nq) {
-    __shared__ double red[2][4][64];
-    __shared__ double tq[64][33];                  // transpose buffer: 64 columns x 32 samples (+1 pad)
+// ---- column means and the Helmert factor panels (both BaM forms) ------------------------------------------------------
+// Qt (B x D): rows k-1 = sqrt(reg/B) helmert_k(g), k = 1 .. B-1, row B-1 = sqrt(reg/(1+reg)) gbar; Vout the same for the
+// source V (the samples X with shift = mu0 in the dense form: last row sqrt(r1)(mu0 - xbar); the whitened draws Z with
+// shift = NULL in the factor form: last row -sqrt(r1) zbar), where helmert_k(v) = (sum_{j<k} c_j - k c_k)/sqrt(k(k+1)), c = v - mean.
+// Workgroup = 64 columns x 4 sample groups; group g owns the rows k in [k0, k1) (and the samples of that range: two passes
+// over them, the second served by L2), its starting prefix sum comes from the other groups' partial sums.  Any B >= 1.
+__global__ __launch_bounds__(256) void k_bam_stats_h(int D, int B, const double* __restrict__ V, int ldv,
+                                                     const double* __restrict__ shift, const double* __restrict__ X,
+                                                     int ldx, const double* __restrict__ G, int ldg, double reg,
+                                                     double* __restrict__ xbar, double* __restrict__ gbar,
+                                                     double* __restrict__ zerov, double* __restrict__ Qt,
+                                                     double* __restrict__ Vout, double* __restrict__ Vout2) {
+    __shared__ double red[3][4][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + c, ic = i < D ? i : D - 1;
-    double sx = 0.0, sg = 0.0;
-    int b = g;
-    for (; b + 28 < B; b += 32) {
-        double vx[8], vg[8];
+    const int k0 = 1 + (g * (B - 1)) / 4, k1 = 1 + ((g + 1) * (B - 1)) / 4;   // rows k in [k0, k1)
+    const int s0 = g == 0 ? 0 : k0;                                          // samples [s0, k1) are summed by this group
+    double sv = 0.0, sg = 0.0, sx = 0.0;
+    {
+        int b = s0;
+        for (; b + 7 < k1; b += 8) {
+            double tv[8], tg[8], tx[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            vx[u] = X[(size_t)(b + 4 * u) * ldx + ic];
-            vg[u] = G[(size_t)(b + 4 * u) * ldg + ic];
+            for (int u = 0; u < 8; ++u) {
+                tv[u] = V[(size_t)(b + u) * ldv + ic];
+                tg[u] = G[(size_t)(b + u) * ldg + ic];
+                tx[u] = X ? X[(size_t)(b + u) * ldx + ic] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { sv += tv[u]; sg += tg[u]; sx += tx[u]; }
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { sx += vx[u]; sg += vg[u]; }
+        for (; b < k1; ++b) {
+            sv += V[(size_t)b * ldv + ic];
+            sg += G[(size_t)b * ldg + ic];
+            if (X) sx += X[(size_t)b * ldx + ic];
+        }
     }
-    for (; b < B; b += 4) { sx += X[(size_t)b * ldx + ic]; sg += G[(size_t)b * ldg + ic]; }
-    red[0][g][c] = sx;
+    red[0][g][c] = sv;
     red[1][g][c] = sg;
+    red[2][g][c] = sx;
     __syncthreads();
-    const double xb = ((red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c])) / B;
+    const double vb = ((red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c])) / B;
     const double gb = ((red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c])) / B;
     const double a = sqrt(reg / B), r1s = sqrt(reg / (1.0 + reg));
+    __syncthreads();                                         // the raw sums have been read by everybody: red is reused below
     if (g == 0 && i < D) {
+        const double xb = X ? ((red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c])) / B : vb;
         xbar[i] = xb;
         gbar[i] = gb;
-        Qt[(size_t)B * D + i] = r1s * gb;
-        Qm[(size_t)i * nq + B] = r1s * gb;
-        for (int cz = B + 1; cz < nq; ++cz) Qm[(size_t)i * nq + cz] = 0.0;      // padding columns of the 16-wide strips
-        Vf[(size_t)B * D + i] = r1s * (mu0[i] - xb);
-        Vf2[(size_t)B * D + i] = r1s * (mu0[i] - xb);
+        if (zerov) zerov[i] = 0.0;
+        const double vl = -r1s * (vb - (shift ? shift[i] : 0.0));
+        Qt[(size_t)(B - 1) * D + i] = r1s * gb;
+        Vout[(size_t)(B - 1) * D + i] = vl;
+        if (Vout2) Vout2[(size_t)(B - 1) * D + i] = vl;
     }
-    // rows of Qt / Vf, 32 samples per pass; Qm through the transpose buffer
-    for (int b0 = 0; b0 < B; b0 += 32) {
+    // prefix of the CENTRED values in front of this group's samples: a second pass over the own samples (centred partial sums:
+    // sum(raw) - k mean would cancel badly when the mean is large beside the spread), then the groups in front are added up
+    {
+        double cv = 0.0, cg = 0.0;
+        int b = s0;
+        for (; b + 7 < k1; b += 8) {
+            double tv[8], tg[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                tv[u] = V[(size_t)(b + u) * ldv + ic];
+                tg[u] = G[(size_t)(b + u) * ldg + ic];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { cv += tv[u] - vb; cg += tg[u] - gb; }
+        }
+        for (; b < k1; ++b) { cv += V[(size_t)b * ldv + ic] - vb; cg += G[(size_t)b * ldg + ic] - gb; }
+        red[0][g][c] = cv;
+        red[1][g][c] = cg;
+    }
+    __syncthreads();
+    double pv = 0.0, pg = 0.0;
+    for (int q = 0; q < g; ++q) { pv += red[0][q][c]; pg += red[1][q][c]; }
+    int k = s0;
+    for (; k + 7 < k1; k += 8) {
+        double tv[8], tg[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int bb = b0 + g + 4 * u;
-            double q = 0.0;
-            if (bb < B) {
-                q = a * (G[(size_t)bb * ldg + ic] - gb);
-                const double v = a * (X[(size_t)bb * ldx + ic] - xb);
-                if (i < D) {
-                    Qt[(size_t)bb * D + i] = q;
-                    Vf[(size_t)bb * D + i] = v;
-                    Vf2[(size_t)bb * D + i] = v;
-                }
-            }
-            tq[c][g + 4 * u] = q;
+            tv[u] = V[(size_t)(k + u) * ldv + ic];
+            tg[u] = G[(size_t)(k + u) * ldg + ic];
         }
-        __syncthreads();
-        // 64 columns x 32 samples -> Qm[i][b0 .. b0+31]: thread (row = tid >> 2, 8 samples each)
-        {
-            const int cr = threadIdx.x >> 2, s0 = (threadIdx.x & 3) * 8;
-            const int gi = blockIdx.x * 64 + cr;
-            if (gi < D) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (b0 + s0 + u < B) Qm[(size_t)gi * nq + b0 + s0 + u] = tq[cr][s0 + u];
+        for (int u = 0; u < 8; ++u) {
+            const int kk = k + u;
+            const double cv = tv[u] - vb, cg = tg[u] - gb;
+            if (kk >= 1 && i < D) {
+                const double sc = a / sqrt((double)kk * (double)(kk + 1));
+                const double ov = sc * (pv - kk * cv);
+                Qt[(size_t)(kk - 1) * D + i] = sc * (pg - kk * cg);
+                Vout[(size_t)(kk - 1) * D + i] = ov;
+                if (Vout2) Vout2[(size_t)(kk - 1) * D + i] = ov;
             }
+            pv += cv;
+            pg += cg;
         }
-        __syncthreads();
+    }
+    for (; k < k1; ++k) {
+        const double cv = V[(size_t)k * ldv + ic] - vb, cg = G[(size_t)k * ldg + ic] - gb;
+        if (k >= 1 && i < D) {
+            const double sc = a / sqrt((double)k * (double)(k + 1));
+            const double ov = sc * (pv - k * cv);
+            Qt[(size_t)(k - 1) * D + i] = sc * (pg - k * cg);
+            Vout[(size_t)(k - 1) * D + i] = ov;
+            if (Vout2) Vout2[(size_t)(k - 1) * D + i] = ov;
+        }
+        pv += cv;
+        pg += cg;
     }
 }
 
@@ -482,6 +524,8 @@ int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, co
                            int force_kenq);
 int gsmvi_bam_small_nmax();
 size_t gsmvi_bam_small_scratch_doubles(int n);
+int gsmvi_panel_t_product(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* A, int lda, const double* M,
+                          int ldm, int mrows, double* Pp, int* kc_out);
 int gsmvi_bam_small_fused_nmax();
 int gsmvi_bam_small_fused(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* slabs, int kc, int ldslab,
                           size_t slab_stride, double* M1, double* Ld, double* Upk, int* info_dev);
@@ -489,42 +533,43 @@ int gsmvi_bam_small_fused(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, con
 int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X, int ldx, const double* G,
                    int ldg, const double* mu0, const double* S0, int lds0, double reg, double jitter, double* mu,
                    double* S, int lds, int* info_dev) {
-    const int n = B + 1, n2 = 2 * n, nq = (n + 15) & ~15;      // Q^T padded to whole 16-column strips (zeros)
-    // workspace carve (ctx->sg holds 4*rmax*max_D doubles, rmax = 2B+8 >= 2n+6)
+    // n = B columns of Q and rows of Vf (round 3: the Helmert recombination of the B centred rows, k_bam_stats_h; the
+    // reference's own factorisation has B + 1.  U = Q Q^T and Vf^T Vf -- all the update depends on -- are unchanged)
+    const int n = B, n2 = 2 * n;
+    // workspace carve (ctx->sg holds 8*rmax*max_D doubles, rmax = 2B+8)
     double* Qt = ctx->sg;                          // n x D
     double* P = Qt + (size_t)n * D;                // n x D
     double* Ft = P + (size_t)n * D;                // [Vf; Z]   2n x D
     double* Fs = Ft + (size_t)n2 * D;              // [Vf; -Z]  2n x D
-    double* Qm = Fs + (size_t)n2 * D;              // D x nq
-    double* xbar = Qm + (size_t)D * nq;
+    double* xbar = Fs + (size_t)n2 * D;
     double* gbar = xbar + D;
-    double* N0 = ctx->small;                       // n x n   } stacked [N0; M1] = [P; Vf] Q: ONE panel product
+    double* N0 = ctx->small;                       // n x n   } stacked [N0; M1] = [P; Vf] Qt^T: ONE transposed panel product
     double* M1 = N0 + (size_t)n * n;               // n x n   }
     double* Ld = M1 + (size_t)n * n;               // n x n, then Ldinv (n), zg (n), vg (n)
 
     if (n > gsmvi_bam_small_nmax()) {              // checked before anything is enqueued
-        gsmvi_set_error("%s: %s", "gsmvi_bam_update_f64", "B + 1 > 640 exceeds the device chain (LDS of the forward substitution)");
+        gsmvi_set_error("%s: %s", "gsmvi_bam_update_f64", "B > 640 exceeds the device chain (LDS of the forward substitution)");
         return GSMVI_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(k_bam_stats, dim3((D + 63) / 64), dim3(256), 0, st, D, B, X, ldx, G, ldg, mu0, reg, xbar,
-                       gbar, Qt, Ft, Fs, Qm, nq);
+    hipLaunchKernelGGL(k_bam_stats_h, dim3((D + 63) / 64), dim3(256), 0, st, D, B, X, ldx, mu0, (const double*)nullptr, 0, G, ldg,
+                       reg, xbar, gbar, (double*)nullptr, Qt, Ft, Fs);
     int kc = 1, rc;
     if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, D, n, Qt, D, nullptr, 1.0, S0, lds0, ctx->pp, &kc))) return rc;
     if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, P, D))) return rc;
-    // M1 = Vf Q and N0 = P Q share the right operand; P and Vf (the first n rows of Ft) are adjacent in the workspace,
-    // so both Gram matrices come from one 2n-row panel product, finished into the adjacent [N0; M1]
-    if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, nq, n2, P, D, nullptr, 1.0, Qm, nq, ctx->pp, &kc))) return rc;
+    // M1 = Vf Qt^T and N0 = P Qt^T share the right operand; P and Vf (the first n rows of Ft) are adjacent in the workspace,
+    // so both Gram matrices come from one 2n-row transposed panel product, finished into the adjacent [N0; M1]
+    if ((rc = gsmvi_panel_t_product(ctx, st, D, n2, P, D, Qt, D, n, ctx->pp, &kc))) return rc;
     double* Nd = Ld + (size_t)n * n + 3 * n;       // n x n
     double* M1T = Nd + (size_t)n * n;              // n x n
     double* Upk = M1T + (size_t)n * n;             // n(n+1)/2: packed rows of L^T
     const double* Ldinv = Ld + (size_t)n * n;
     if (n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full) {
         // n <= 48: slab sum, N, the matrix function, its Cholesky factor and the small outputs in ONE one-workgroup launch
-        if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, nq, (size_t)n2 * nq, M1, Ld, Upk,
+        if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, n, (size_t)n2 * n, M1, Ld, Upk,
                                         info_dev ? info_dev : ctx->ints + 8)))
             return rc;
     } else {
-        if ((rc = gsmvi_panel_finish_cols(st, nq, n, n2, kc, ctx->pp, N0, n))) return rc;
+        if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
         // N = M1^T M1 + sym(N0) and M1^T on the device
         hipLaunchKernelGGL(k_bam_nmat, dim3((n * n + 255) / 256), dim3(256), 0, st, n, M1, N0, Nd, M1T);
         // the whole (B+1) x (B+1) matrix function on the device (gsmvi_bam_small.hip): no copy, no synchronisation
@@ -586,69 +631,6 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
 //   h = wg + Vw^T (Vw wg) - Zw^T (Zw wg), wg = F0 gbar: the forward-substitution kernel emits r1 h as an extra row of Rt (its
 //   "mean" output with mu0 = xbar = 0), which rides through the Rt F0 product.  Four passes over F0 (Wq, Rt F0, and the
 //   read + write of the update), no pass over a covariance.
-// Workgroup = 64 columns x 4 sample groups: the B x 64 tiles of G and Z are staged in LDS by all four groups (coalesced rows,
-// every load of a thread in flight together), group g then writes the Helmert rows k = g B/4 + 1 .. (g+1) B/4 of its column
-// from the LDS tile (its starting prefix sum recomputed from the tile).  B <= 64 (the factor form's bound).
-__global__ __launch_bounds__(256) void k_bamf_stats(int D, int B, const double* __restrict__ Z, int ldz,
-                                                    const double* __restrict__ X, int ldx,
-                                                    const double* __restrict__ G, int ldg, double reg,
-                                                    double* __restrict__ xbar, double* __restrict__ gbar,
-                                                    double* __restrict__ zerov, double* __restrict__ Qt,
-                                                    double* __restrict__ Vw) {
-    __shared__ double tg[64][65], tz[64][65];      // [sample][column]
-    __shared__ double red[3][4][64];
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + c, ic = i < D ? i : D - 1;
-    double sx = 0.0, sg = 0.0, sz = 0.0;
-    {
-        double vx[16], vg[16], vz[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int b = g + 4 * u, bc = b < B ? b : B - 1;
-            vx[u] = X[(size_t)bc * ldx + ic];
-            vg[u] = G[(size_t)bc * ldg + ic];
-            vz[u] = Z[(size_t)bc * ldz + ic];
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int b = g + 4 * u;
-            if (b < B) {
-                sx += vx[u]; sg += vg[u]; sz += vz[u];
-                tg[b][c] = vg[u];
-                tz[b][c] = vz[u];
-            }
-        }
-    }
-    red[0][g][c] = sx;
-    red[1][g][c] = sg;
-    red[2][g][c] = sz;
-    __syncthreads();
-    const double xb = ((red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c])) / B;
-    const double gb = ((red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c])) / B;
-    const double zb = ((red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c])) / B;
-    const double a = sqrt(reg / B), r1s = sqrt(reg / (1.0 + reg));
-    if (i >= D) return;
-    if (g == 0) {
-        xbar[i] = xb;
-        gbar[i] = gb;
-        zerov[i] = 0.0;
-        Qt[(size_t)(B - 1) * D + i] = r1s * gb;
-        Vw[(size_t)(B - 1) * D + i] = -r1s * zb;           // sqrt(r1) (mu0 - xbar) = -sqrt(r1) zbar F0
-    }
-    // Helmert rows of the centred values: row k-1 = (sum_{j<k} c_j - k c_k) / sqrt(k (k+1)), k = 1 .. B-1
-    const int k0 = 1 + (g * (B - 1)) / 4, k1 = 1 + ((g + 1) * (B - 1)) / 4;     // this group's k range [k0, k1)
-    double pg = 0.0, pz = 0.0;
-    for (int j = 0; j < k0; ++j) { pg += tg[j][c] - gb; pz += tz[j][c] - zb; }
-    for (int k = k0; k < k1; ++k) {
-        const double cg = tg[k][c] - gb, cz = tz[k][c] - zb;
-        const double sc = a / sqrt((double)k * (double)(k + 1));
-        Qt[(size_t)(k - 1) * D + i] = sc * (pg - k * cg);
-        Vw[(size_t)(k - 1) * D + i] = sc * (pz - k * cz);
-        pg += cg;
-        pz += cz;
-    }
-}
-
 // mu = mu0/(1+reg) + r1 (S gbar) + r1 xbar, or mu0 on a reverted update (bam.py:112)
 __global__ __launch_bounds__(256) void k_bamf_commit(int D, const double* __restrict__ sg_r1, const double* __restrict__ mu0,
                                                      const double* __restrict__ xbar, double reg,
@@ -690,8 +672,8 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     int* info_bam = ctx->ints + 8;
     int kc = 1, rc;
 
-    hipLaunchKernelGGL(k_bamf_stats, dim3((D + 63) / 64), dim3(256), 0, st, D, B, Z, ldz, X, ldx, G, ldg, reg, xbar, gbar, zerov,
-                       Qt, Ft);
+    hipLaunchKernelGGL(k_bam_stats_h, dim3((D + 63) / 64), dim3(256), 0, st, D, B, Z, ldz, (const double*)nullptr, X, ldx, G, ldg,
+                       reg, xbar, gbar, zerov, Qt, Ft, (double*)nullptr);
     if ((rc = gsmvi_panel_t_product(ctx, st, D, n, Qt, D, F0, ldf0, D, ctx->pp, &kc))) return rc;
     if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, Wq, D))) return rc;
     if ((rc = gsmvi_panel_t_product(ctx, st, D, n2, Wq, D, Wq, D, n, ctx->pp, &kc))) return rc;

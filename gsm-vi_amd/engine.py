@@ -23,7 +23,7 @@ class HipEngine:
     """One context (workspace + launch heuristics) on one device; grows on demand."""
 
     name = "hip"
-    bam_max_batch = 639        # B + 1 <= 640: LDS of BaM's forward-substitution kernel (csrc/gsmvi_bam.hip); the one-workgroup
+    bam_max_batch = 640        # B <= 640: LDS of BaM's forward-substitution kernel (csrc/gsmvi_bam.hip); the one-workgroup
                                # chain covers B <= 128, larger batches take the blocked multi-workgroup Cholesky
 
     def __init__(self, device=None, max_D=0, max_B=0):

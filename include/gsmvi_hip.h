@@ -291,12 +291,13 @@ int gsmvi_commit_f64(gsmvi_ctx* ctx, void* stream, int D, const int* info_dev,
                      double* mu, double* S, int lds, int* n_reverts_dev);
 
 /*
- * BaM update (gsmvi/bam.py:72-114 with the exact rank-(B+1) factor of U; equals bam.py:31-69).
+ * BaM update (gsmvi/bam.py:72-114 with an exact rank-B factor of U; equals bam.py:31-69).
  * Symmetrised output (bam.py:199 does this in fit); jitter is added to the diagonal (bam.py:198).
- * The (B+1) x (B+1) matrix function of bam.py:108-110 -- which the reference evaluates on the host through
+ * The B x B matrix function of bam.py:108-110 (B + 1 columns in the reference's factorisation of U; an orthonormal
+ * recombination of the centred score rows saves one without changing U) -- which the reference evaluates on the host through
  * jax.pure_callback (bam.py:15-22) -- runs on the device (scaled coupled Newton-Schulz square root on the MFMA pipe +
- * a one-workgroup Cholesky for B <= 128, the blocked Cholesky of gsmvi_potrf_f64 up to B = 639; csrc/gsmvi_bam_small.hip):
- * no synchronisation, graph-capturable.  For B > 639 the call returns GSMVI_ERR_UNSUPPORTED before anything is enqueued:
+ * a one-workgroup Cholesky for B <= 129, the blocked Cholesky of gsmvi_potrf_f64 up to B = 640; csrc/gsmvi_bam_small.hip):
+ * no synchronisation, graph-capturable.  For B > 640 the call returns GSMVI_ERR_UNSUPPORTED before anything is enqueued:
  * there is no host computation in this library.
  * *info_dev = 1 if that small problem was not finite / not positive definite (then mu, S are NaN-poisoned and the
  * caller's accept/revert must reject them).
