@@ -10,7 +10,7 @@ from .gsm import _legacy_mvn, _is_torch
 def bam_lowrank_update(samples, vs, mu0, S0, reg, engine=None, jitter=0.0):
     """Drop-in for ``bam_lowrank_update(samples, vs, mu0, S0, reg)`` (gsmvi/bam.py:72-114).
 
-    The D x B ARPACK factor of U (bam.py:10-13,104) is replaced by U's exact rank-(B+1) factor, so
+    The D x B ARPACK factor of U (bam.py:10-13,104) is replaced by an exact rank-B factor of U (Helmert recombination of the centred score rows), so
     there is no B < D restriction; the returned S is symmetrised (the reference symmetrises in
     ``fit``, bam.py:199)."""
     assert len(samples.shape) == 2

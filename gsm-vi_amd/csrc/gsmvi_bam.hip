@@ -572,7 +572,7 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
         if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
         // N = M1^T M1 + sym(N0) and M1^T on the device
         hipLaunchKernelGGL(k_bam_nmat, dim3((n * n + 255) / 256), dim3(256), 0, st, n, M1, N0, Nd, M1T);
-        // the whole (B+1) x (B+1) matrix function on the device (gsmvi_bam_small.hip): no copy, no synchronisation
+        // the whole n x n matrix function on the device (gsmvi_bam_small.hip): no copy, no synchronisation
         double* scratch = Upk + (size_t)n * (n + 1) / 2 + 2;
         if (!ctx->bam_hint_host) {                 // pinned, device-visible word for the step-count hint
             if (hipHostMalloc(reinterpret_cast<void**>(&ctx->bam_hint_host), 64, hipHostMallocMapped) == hipSuccess)

@@ -1,5 +1,5 @@
-// BaM's (B+1) x (B+1) matrix function on the DEVICE (gsmvi/bam.py:108-110; the reference evaluates it on the host
-// through jax.pure_callback + scipy sqrtm, bam.py:15-22).  n = B + 1 <= 129.
+// BaM's n x n matrix function (n = B since round 3, B + 1 before) on the DEVICE (gsmvi/bam.py:108-110; the reference evaluates it on the host
+// through jax.pure_callback + scipy sqrtm, bam.py:15-22).
 //
 //   BB = ((N + I/4)^(1/2) + I/2)^2 = N + I/2 + (N + I/4)^(1/2),   BB = L L^T,   zg = L^-1 (P gbar + M1^T Vf gbar)
 //
