@@ -140,7 +140,7 @@ def test_example_scripts_run():
     import sys
     from conftest import ROOT
     for script, args in (("gsm_gaussian.py", ["5", "2", "500", "dense"]), ("gsm_gaussian.py", ["16", "4", "600", "factor"]),
-                         ("bam_gaussian.py", ["5", "2", "100"])):
+                         ("bam_gaussian.py", ["5", "2", "100"]), ("bam_gaussian.py", ["16", "4", "150", "factor"])):
         p = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script)] + args, capture_output=True,
                            text=True, timeout=300)
         assert p.returncode == 0, p.stderr[-2000:]
