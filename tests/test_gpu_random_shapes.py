@@ -54,3 +54,39 @@ def test_random_shapes_layouts_dtypes(D, B, seed, f32, pad, off, as_torch):
     assert mu.shape == (D,) and S.shape == (D, D)
     tol = 1e-10
     assert rel_err(mu, mu_o) < tol and rel_err(S, S_o) < tol, (D, B, seed, f32, pad, off, as_torch)
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(B=st.integers(1, 64), extra=st.integers(0, 200), seed=st.integers(0, 10_000), reg=st.sampled_from([0.3, 1.0, 7.0]),
+       pad=st.integers(0, 2))
+def test_random_shapes_of_the_factor_forms(B, extra, seed, reg, pad):
+    """Both factor-form updates (GSM: gsm_numpy.py:27-55, BaM: bam.py:72-114, on Sigma = F^T F) at random (D, B) with
+    2B <= D -- every route of the 2B x 2B chain (rider / stand-alone launch, one workgroup / the 128-row kernels, folded
+    and generic update kernels, D not a multiple of 64, strided factor) -- against the DENSE device updates on F0^T F0."""
+    import torch
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    D = 2 * B + extra
+    rs = np.random.RandomState(seed)
+    F0 = rs.standard_normal((D, D)) / np.sqrt(D) + 0.6 * np.eye(D)
+    mu0 = rs.standard_normal(D)
+    Z = rs.standard_normal((B, D))
+    X = mu0 + Z @ F0
+    A = rs.standard_normal((D, D)) / np.sqrt(D)
+    P = A @ A.T + 0.4 * np.eye(D)
+    G = -(X - rs.standard_normal(D)) @ P
+    Fbuf = torch.zeros(D, D + pad, dtype=torch.float64, device="cuda")
+    Fbuf[:, :D] = eng.asarray(F0)
+    F0d = Fbuf[:, :D]                                           # row stride D + pad
+    Zd, Xd, Gd, mud = (eng.asarray(a) for a in (Z, X, G, mu0))
+    S0 = eng.asarray(F0.T @ F0)
+    mu_d, S_d = eng.gsm_update(Xd, Gd, mud, S0)
+    mu_f, F, flag = eng.gsm_factor_update(Zd, Xd, Gd, mud, F0d)
+    assert eng.read_flag(flag) == 0
+    Fn = F.cpu().numpy()
+    assert rel_err(Fn.T @ Fn, S_d.cpu().numpy()) < 1e-10 and rel_err(mu_f.cpu().numpy(), mu_d.cpu().numpy()) < 1e-10, (D, B)
+    mu_bd, S_bd, _ = eng.bam_update(Xd, Gd, mud, S0, reg, 0.0)
+    mu_bf, Fb, flag = eng.bam_factor_update(Zd, Xd, Gd, mud, F0d, reg)
+    assert eng.read_flag(flag) == 0
+    Fbn = Fb.cpu().numpy()
+    assert rel_err(Fbn.T @ Fbn, S_bd.cpu().numpy()) < 1e-8 and rel_err(mu_bf.cpu().numpy(), mu_bd.cpu().numpy()) < 1e-8, (D, B, reg)
