@@ -180,21 +180,42 @@ __global__ __launch_bounds__(COLS) void k_bam_forward(int D, int n, const double
 }
 
 // ---- N = M1^T M1 + sym(N0) and M1^T (n x n), on the device ---------------------------------------
+// One 16 x 16 block of N per wave on the MFMA pipe (round 3; it was an n-long scalar loop per element: 20 us at n = 128):
+// k runs over the rows of M1 in batches of 64, operands straight from L2 (a wave's 16 lanes read 128 contiguous bytes of a
+// row), two accumulator chains.  The transposed block of M1 is written by the same wave.
 __global__ __launch_bounds__(256) void k_bam_nmat(int n, const double* __restrict__ M1,
                                                   const double* __restrict__ N0, double* __restrict__ Nm,
                                                   double* __restrict__ M1T) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n * n) return;
-    const int i = idx / n, j = idx % n;
-    double s0 = 0.0, s1 = 0.0;
-    int k = 0;
-    for (; k + 1 < n; k += 2) {
-        s0 += M1[(size_t)k * n + i] * M1[(size_t)k * n + j];
-        s1 += M1[(size_t)(k + 1) * n + i] * M1[(size_t)(k + 1) * n + j];
+    const int nb = (n + 15) >> 4;
+    const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blk >= nb * nb) return;                                  // wave-uniform
+    const int i0 = (blk / nb) * 16, j0 = (blk % nb) * 16;
+    const int l = threadIdx.x & 63, cc = l & 15, ks = l >> 4;
+    const int ic = (i0 + cc) < n ? i0 + cc : n - 1, jc = (j0 + cc) < n ? j0 + cc : n - 1;
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int kb = 0; kb < n; kb += 64) {
+        double a[16], b[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k = kb + 4 * s + ks, kc = k < n ? k : n - 1;
+            const double av = M1[(size_t)kc * n + ic], bv = M1[(size_t)kc * n + jc];
+            a[s] = (k < n && (i0 + cc) < n) ? av : 0.0;
+            b[s] = (k < n && (j0 + cc) < n) ? bv : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < 16; s += 2) {
+            acc0 = GSMVI_MFMA_F64(a[s], b[s], acc0);
+            acc1 = GSMVI_MFMA_F64(a[s + 1], b[s + 1], acc1);
+        }
     }
-    if (k < n) s0 += M1[(size_t)k * n + i] * M1[(size_t)k * n + j];
-    Nm[idx] = (s0 + s1) + 0.5 * (N0[(size_t)i * n + j] + N0[(size_t)j * n + i]);
-    M1T[idx] = M1[(size_t)j * n + i];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ks + 4 * r, j = j0 + cc;
+        if (i < n && j < n) {
+            Nm[(size_t)i * n + j] = (acc0[r] + acc1[r]) + 0.5 * (N0[(size_t)i * n + j] + N0[(size_t)j * n + i]);
+            M1T[(size_t)i * n + j] = M1[(size_t)j * n + i];
+        }
+    }
 }
 
 // ---- Z = L^-1 (P + T1), T1 = M1^T Vf precomputed by the panel product, n <= 144 -----------------------
@@ -571,7 +592,7 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     } else {
         if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
         // N = M1^T M1 + sym(N0) and M1^T on the device
-        hipLaunchKernelGGL(k_bam_nmat, dim3((n * n + 255) / 256), dim3(256), 0, st, n, M1, N0, Nd, M1T);
+        hipLaunchKernelGGL(k_bam_nmat, dim3((((n + 15) / 16) * ((n + 15) / 16) + 3) / 4), dim3(256), 0, st, n, M1, N0, Nd, M1T);
         // the whole n x n matrix function on the device (gsmvi_bam_small.hip): no copy, no synchronisation
         double* scratch = Upk + (size_t)n * (n + 1) / 2 + 2;
         if (!ctx->bam_hint_host) {                 // pinned, device-visible word for the step-count hint
@@ -681,7 +702,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
         if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, n, (size_t)n2 * n, M1, Ld, Upk, info_bam))) return rc;
     } else {
         if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
-        hipLaunchKernelGGL(k_bam_nmat, dim3((n * n + 255) / 256), dim3(256), 0, st, n, M1, N0, Nd, M1T);
+        hipLaunchKernelGGL(k_bam_nmat, dim3((((n + 15) / 16) * ((n + 15) / 16) + 3) / 4), dim3(256), 0, st, n, M1, N0, Nd, M1T);
         if (!ctx->bam_hint_host) {
             if (hipHostMalloc(reinterpret_cast<void**>(&ctx->bam_hint_host), 64, hipHostMallocMapped) == hipSuccess)
                 *ctx->bam_hint_host = 0;
