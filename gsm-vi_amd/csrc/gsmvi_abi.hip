@@ -293,6 +293,13 @@ int gsmvi_debug_read_workspace(gsmvi_ctx* ctx, int region, size_t offset, double
     return GSMVI_OK;
 }
 
+// device address of a workspace region (diagnostic scripts view intermediates in place: scripts/soak_c5_debug.py)
+int gsmvi_debug_workspace_ptr(gsmvi_ctx* ctx, int region, double** out) {
+    BAD_ARG(!ctx || !out || region < 0 || region > 2, "bad argument");
+    *out = region == 0 ? ctx->pp : (region == 1 ? ctx->sg : ctx->small);
+    return GSMVI_OK;
+}
+
 int gsmvi_set_profiling(gsmvi_ctx* ctx, int on) {
     BAD_ARG(!ctx, "ctx is NULL");
     ctx->profiling = on ? 1 : 0;

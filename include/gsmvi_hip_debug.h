@@ -17,6 +17,8 @@ extern "C" {
 int gsmvi_debug_read_stamps(gsmvi_ctx* ctx, unsigned long long* out, int n);
 /* Read back a slice of the context workspace (region 0 panel slabs, 1 finished panels, 2 small matrices). */
 int gsmvi_debug_read_workspace(gsmvi_ctx* ctx, int region, size_t offset, double* out, size_t n);
+/* Device address of the region's base (0: panel partials, 1: finished panels, 2: small matrices), for in-place views. */
+int gsmvi_debug_workspace_ptr(gsmvi_ctx* ctx, int region, double** out);
 
 #ifdef __cplusplus
 }
