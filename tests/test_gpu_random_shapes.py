@@ -90,3 +90,45 @@ def test_random_shapes_of_the_factor_forms(B, extra, seed, reg, pad):
     assert eng.read_flag(flag) == 0
     Fbn = Fb.cpu().numpy()
     assert rel_err(Fbn.T @ Fbn, S_bd.cpu().numpy()) < 1e-8 and rel_err(mu_bf.cpu().numpy(), mu_bd.cpu().numpy()) < 1e-8, (D, B, reg)
+
+
+@pytest.mark.parametrize("D,B", [(256, 8), (1024, 32), (1024, 64), (4096, 64), (200, 20), (320, 48)])
+def test_no_kernel_reads_outside_its_inputs(D, B):
+    """Every input of the four update families sits inside a NaN-filled buffer (NaN rows in front, behind, and in the row
+    padding): a kernel that reads one element outside an input -- instead of clamping to a valid one -- poisons its output.
+    Covers the fast families (rider, wide panels, side-stream fork at D = 4096, the one-launch BaM chain) and ragged shapes."""
+    import torch
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    rs = np.random.RandomState(D * 7 + B)
+
+    def guarded(a, pad=2):                       # a 2-D (or 1-D) array as a view into a NaN-filled device buffer
+        a = np.atleast_2d(a)
+        buf = torch.full((a.shape[0] + 2, a.shape[1] + pad), float("nan"), dtype=torch.float64, device="cuda")
+        buf[1:-1, :a.shape[1]] = eng.asarray(a)
+        return buf[1:-1, :a.shape[1]]
+
+    F0 = rs.standard_normal((D, D)) / np.sqrt(D) + 0.6 * np.eye(D)
+    mu0 = rs.standard_normal(D)
+    Z = rs.standard_normal((B, D))
+    X = mu0 + Z @ F0
+    A = rs.standard_normal((D, D)) / np.sqrt(D)
+    P = A @ A.T + 0.4 * np.eye(D)
+    m = rs.standard_normal(D)
+    G = -(X - m) @ P
+    S0 = F0.T @ F0
+    S0 = 0.5 * (S0 + S0.T)
+    Zg, Xg, Gg, Fg, Sg, Pg = (guarded(a) for a in (Z, X, G, F0, S0, P))
+    mug, mg = guarded(mu0)[0], guarded(m)[0]
+    outs = []
+    outs += list(eng.gsm_update(Xg, Gg, mug, Sg))
+    outs += list(eng.bam_update(Xg, Gg, mug, Sg, 1.0, 0.0)[:2])
+    outs.append(eng.sample(Zg, mug, Fg))
+    outs.append(eng.gaussian_score(Xg, mg, Pg))
+    outs.append(eng.potrf(Sg)[0])
+    if 2 * B <= min(D, 128):
+        outs += list(eng.gsm_factor_update(Zg, Xg, Gg, mug, Fg)[:2])
+        outs += list(eng.bam_factor_update(Zg, Xg, Gg, mug, Fg, 1.0)[:2])
+    torch.cuda.synchronize()
+    for k, o in enumerate(outs):
+        assert bool(torch.isfinite(o).all()), (D, B, k)
