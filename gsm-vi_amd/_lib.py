@@ -66,6 +66,7 @@ _SIGS = {
     "gsmvi_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "gsmvi_debug_read_workspace": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_double), C.c_size_t]),
     "gsmvi_debug_workspace_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "gsmvi_debug_chol128": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp]),
     "gsmvi_debug_read_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]),
     "gsmvi_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "gsmvi_gaussian_score_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp,

@@ -999,6 +999,18 @@ __global__ __launch_bounds__(256) void k_gsmf_gamma_big(int n, int B, const doub
 int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                      int* info_dev);
 
+// diagnostic (include/gsmvi_hip_debug.h): the one-workgroup n x n Cholesky kernels of the 2B x 2B chain on caller data
+extern "C" int gsmvi_debug_chol128(void* stream, int n, int with_inverse, const double* A, double* R, double* W, int* info_dev) {
+    if (n <= 64 || n > 128 || !A || !R || !info_dev || (with_inverse && !W)) {
+        gsmvi_set_error("%s: %s", "gsmvi_debug_chol128", "bad argument (64 < n <= 128)");
+        return GSMVI_ERR_BAD_ARG;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (with_inverse) hipLaunchKernelGGL(k_chol128w<true>, dim3(1), dim3(512), 0, st, n, A, R, W, info_dev);
+    else hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n, A, R, info_dev);
+    return hipGetLastError() == hipSuccess ? GSMVI_OK : GSMVI_ERR_HIP;
+}
+
 static int chk(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -19,6 +19,10 @@ int gsmvi_debug_read_stamps(gsmvi_ctx* ctx, unsigned long long* out, int n);
 int gsmvi_debug_read_workspace(gsmvi_ctx* ctx, int region, size_t offset, double* out, size_t n);
 /* Device address of the region's base (0: panel partials, 1: finished panels, 2: small matrices), for in-place views. */
 int gsmvi_debug_workspace_ptr(gsmvi_ctx* ctx, int region, double** out);
+/* The one-workgroup n x n Cholesky kernels of the factor path's 2B x 2B chain (64 < n <= 128) on caller data: A (n x n, upper
+ * triangle read) -> R (upper), and with_inverse != 0 also W = R^-T (lower) with the rank-revealing rule of the Gram matrix.
+ * For soak / determinism scripts. */
+int gsmvi_debug_chol128(void* stream, int n, int with_inverse, const double* A, double* R, double* W, int* info_dev);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Soak of the one-workgroup 128 x 128 Cholesky kernel of the factor chain (k_chol128<false>, via gsmvi_debug_chol128) on the
+A' = T^T T of a real D=4096, B=64 update: the same input factored over and over, every result compared on the device with the
+first one.  usage: chol128_soak.py [seconds] [with_inverse]"""
+import ctypes as C, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, gsmvi_amd
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+winv = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+eng = gsmvi_amd.get_engine()
+D, B = 4096, 64
+n = 2 * B
+rs = np.random.RandomState(D + B)
+F0 = eng.asarray(rs.standard_normal((D, D)) / np.sqrt(D) + 0.6 * np.eye(D))
+mu0 = eng.asarray(rs.standard_normal(D))
+Z = eng.asarray(rs.standard_normal((B, D)))
+X = eng.sample(Z, mu0, F0)
+G = -(X - 0.3)
+eng.gsm_factor_update(Z, X, G, mu0, F0)
+torch.cuda.synchronize()
+buf = (C.c_double * (n * n))()
+eng.lib.gsmvi_debug_read_workspace(eng._ctx, 2, (1 if winv else 3) * n * n, buf, n * n)     # Rg (slot 1) or T (slot 3)
+T = torch.from_numpy(np.frombuffer(buf, dtype=np.float64).reshape(n, n).copy()).cuda()
+A = (T.T @ T).contiguous()
+A = 0.5 * (A + A.T)
+R, W, Rref = torch.empty_like(A), torch.empty_like(A), torch.empty_like(A)
+info = torch.zeros(1, dtype=torch.int32, device="cuda")
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+ptr = lambda t: C.cast(t.data_ptr(), C.POINTER(C.c_double))
+call = lambda out: eng.lib.gsmvi_debug_chol128(st, n, winv, ptr(A), ptr(out), ptr(W), C.cast(info.data_ptr(), C.POINTER(C.c_double)))
+assert call(Rref) == 0
+torch.cuda.synchronize()
+print("info", int(info.item()), "| R^T R - A | / |A| =", float(((Rref.T @ Rref) - A).abs().max() / A.abs().max()))
+nbad = torch.zeros(1, dtype=torch.int64, device="cuda")
+first_bad = None
+t0, calls = time.perf_counter(), 0
+while time.perf_counter() - t0 < budget:
+    for _ in range(200):
+        call(R)
+        neq = (R != Rref).sum()
+        nbad += (neq > 0)
+        if first_bad is None:
+            pass
+        calls += 1
+    if int(nbad.item()) > 0 and first_bad is None:
+        first_bad = calls
+        break
+print(f"{calls} calls in {time.perf_counter() - t0:.0f} s, deviating results: {int(nbad.item())}")
+if first_bad is not None:
+    # hunt one deviating result and describe it
+    for _ in range(2000000):
+        call(R)
+        dm = (R != Rref)
+        if bool(dm.any()):
+            rows = dm.sum(1).tolist()
+            print("differing entries per row:", [(i, int(c)) for i, c in enumerate(rows) if c])
+            print("first differing (row, col):", dm.nonzero()[:32].tolist())
+            rel = (R - Rref).abs() / (Rref.abs() + 1e-300)
+            print("max rel diff per row (first 10 differing rows):", [(i, float(rel[i].max())) for i, c in enumerate(rows) if c][:10])
+            break

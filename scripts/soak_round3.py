@@ -26,7 +26,30 @@ for D, B in ((1024, 32), (256, 8), (4096, 64), (1024, 64)):
     X = eng.sample(Z, mu0, F0)
     G = -(X - 0.3)
     cases.append((D, B, Z, X, G, mu0, F0))
-ref, graphs, outs = {}, {}, {}
+import ctypes as C
+
+class View:
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+def stage_views(D, B):
+    # in-place views of the intermediates the last factor update left in the context workspace (GSM factor form, n = 2B)
+    n = 2 * B
+    R = 2 * eng._max_B + 8
+    ldb = max(R // 2 + 16, 144)
+    n_small = 8 * R + 7 * R * R + 4096 + 5 * ldb * ldb + 64 + ldb * ldb + 64 + 8 * R * R + 16
+    base = []
+    for r in range(3):
+        p = C.c_void_p()
+        assert eng.lib.gsmvi_debug_workspace_ptr(eng._ctx, r, C.byref(p)) == 0
+        base.append(p.value)
+    st = [("Rt", 1, 0, n * D), ("Tm top", 1, n * D, B * D), ("gram_slabs", 2, n_small - (8 * R * R + 16), 8 * n * n),
+          ("coef", 2, 5 * n * n, 2 * n), ("Rg", 2, n * n, n * n), ("W(Pm)", 2, 4 * n * n, n * n), ("T", 2, 3 * n * n, n * n),
+          ("P(Ap)", 2, 2 * n * n, n * n), ("K''(Gam)", 2, 0, n * n), ("pp (V Fm slabs)", 0, 0, 8 * B * D),
+          ("Tm bottom", 1, n * D + B * D, B * D), ("Fs", 1, 2 * n * D, n * D)]
+    return [(nm, torch.as_tensor(View(base[r] + 8 * off, cnt), device="cuda")) for nm, r, off, cnt in st]
+
+ref, graphs, outs, snaps = {}, {}, {}, {}
 n_calls, t0 = 0, time.perf_counter()
 rnd = 0
 while time.perf_counter() - t0 < budget:
@@ -57,11 +80,28 @@ while time.perf_counter() - t0 < budget:
             h = (mu.clone(), F.clone(), int(flag.item()))
             if key not in ref:
                 ref[key] = h
+                if kind == "gsm" and len(cases) == 1 and B == 64:      # (one case only: the context is not regrown later)
+                    snaps[key] = [(nm, v, v.clone()) for nm, v in stage_views(D, B)]
             else:
                 if not (h[2] == 0 and torch.equal(h[0], ref[key][0]) and torch.equal(h[1], ref[key][1])):
                     dF = (h[1] - ref[key][1]).abs()
                     bad.append((D, B, kind, rnd, "graph" if used_graph else "eager", h[2],
                                 float(dF.max()), int((dF > 0).sum()), float((h[0] - ref[key][0]).abs().max())))
+                    if key in snaps and len(bad) <= 3:
+                        for nm, v, r0 in snaps[key]:
+                            if nm == "T" and not torch.equal(v, r0):
+                                n_ = 2 * B
+                                dm = (v.view(n_, n_) != r0.view(n_, n_))
+                                rows = dm.sum(1).tolist()
+                                first = dm.nonzero()[:24].tolist()
+                                print("  T: differing entries per row:", [(i, int(c_)) for i, c_ in enumerate(rows) if c_], flush=True)
+                                print("  T: first differing (row, col):", first, flush=True)
+                                rel = ((v - r0).abs().view(n_, n_) / (r0.abs().view(n_, n_) + 1e-300))
+                                print("  T: max rel diff per differing row (first 12):", [(i, float(rel[i].max())) for i, c_ in enumerate(rows) if c_][:12], flush=True)
+                    if key in snaps:
+                        print("  stages that differ from the first call's:",
+                              [(nm, int((v != r0).sum()), float((v - r0).abs().max())) for nm, v, r0 in snaps[key] if not torch.equal(v, r0)],
+                              flush=True)
                     if len(bad) <= 5:
                         nz = (dF > 0).nonzero()
                         print("MISMATCH", bad[-1], "rows", int(nz[:, 0].min()), int(nz[:, 0].max()), "cols", int(nz[:, 1].min()),
