@@ -66,7 +66,7 @@ __device__ __forceinline__ double rsq_nr2(double d) {             // 1/sqrt(d)
 template <int ES, bool SEMIDEF, int H>
 __device__ __forceinline__ void cholb_panel_half(double* E, int k0, int col, bool write_back, bool aug, bool diag_lane,
                                                  double* ur, double* tr, double* rsb, volatile int* cnt, int pub,
-                                                 bool allow_dep, int* sh_failmin) {
+                                                 bool allow_dep, int* sh_failmin, double (&vkeep)[8]) {
     const int l = threadIdx.x & 63, c = l & 15;
     constexpr int R0 = 8 * H;
     double v[8];
@@ -164,11 +164,17 @@ __device__ __forceinline__ void cholb_panel_half(double* E, int k0, int col, boo
         }
     }
     CHOLB_PSTAMP(H, 11);
-    if (write_back) {
+    // The DIAGONAL block is not written back here: the other column sets hold replicas of it, loaded from E when their waves
+    // start this panel, and nothing orders those loads against this wave's end -- a replica wave that is scheduled ~1 us late
+    // (seen about once in 3e5 factorisations inside a busy pipeline, never with the kernel alone on the chip) would load rows
+    // that are already factored.  chol64_blk writes vkeep back behind the workgroup barrier that follows the panel phase.
+    if (write_back && !diag_lane) {
         double* ep = E + (k0 + R0) * ES + col;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ep[i * ES] = (diag_lane && R0 + i > c) ? 0.0 : v[i];   // strictly-lower part of the diagonal block zeroed
+        for (int i = 0; i < 8; ++i) ep[i * ES] = v[i];
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vkeep[i] = v[i];
     if (fail != 0 && l == 0) atomicMin(sh_failmin, fail);
     CHOLB_PSTAMP(H, 12);
 }
@@ -197,6 +203,7 @@ __device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, i
         // lanes 0-15 (set 0 the original, the others bit-identical replicas) and the groups 3s+1 .. 3s+3 in lanes 16-63.
         // Even wave of a set: rows 0-7, odd wave: rows 8-15.
         const int nW = (AUG == 1) ? k + 1 : (AUG == 2 ? 4 : 0);
+        double vk[8];
         if (w < 2 * (AUG + 1)) {
             const int set = w >> 1;
             const int nA = nblk - k, nslots = nA + nW;
@@ -210,11 +217,16 @@ __device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, i
             volatile int* cnt = reinterpret_cast<volatile int*>(rsb + 16);
             const bool wb = active && !(set > 0 && g == 0);
             if ((w & 1) == 0)
-                cholb_panel_half<ES, SEMIDEF, 0>(E, k0, col, wb, aug && AUG == 1, slot == 0, ur, tr, rsb, cnt, 8 * k, allow_dep, sh_fail);
+                cholb_panel_half<ES, SEMIDEF, 0>(E, k0, col, wb, aug && AUG == 1, slot == 0, ur, tr, rsb, cnt, 8 * k, allow_dep, sh_fail, vk);
             else
-                cholb_panel_half<ES, SEMIDEF, 1>(E, k0, col, wb, aug && AUG == 1, slot == 0, ur, tr, rsb, cnt, 8 * k, allow_dep, sh_fail);
+                cholb_panel_half<ES, SEMIDEF, 1>(E, k0, col, wb, aug && AUG == 1, slot == 0, ur, tr, rsb, cnt, 8 * k, allow_dep, sh_fail, vk);
         }
         __syncthreads();
+        if (w < 2 && g == 0) {                                    // set 0's diagonal-block lanes: the factored block, strictly-lower part zeroed
+            double* ep = E + (k0 + 8 * w) * ES + k0 + c;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ep[i * ES] = (8 * w + i > c) ? 0.0 : vk[i];
+        }
         CHOLB_STAMP(2 + 2 * k);
         if (k + 1 >= nblk) break;                                 // block-uniform: no trailing matrix
         // ---- trailing: for every remaining block row i and every column group j (A-groups i .. nblk-1, W-groups 0 .. k):

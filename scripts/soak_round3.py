@@ -80,7 +80,7 @@ while time.perf_counter() - t0 < budget:
             h = (mu.clone(), F.clone(), int(flag.item()))
             if key not in ref:
                 ref[key] = h
-                if kind == "gsm" and len(cases) == 1 and B == 64:      # (one case only: the context is not regrown later)
+                if kind == "gsm" and len(cases) == 1 and B == 64 and os.environ.get("SOAK_STAGES"):      # (one case only: the context is not regrown later)
                     snaps[key] = [(nm, v, v.clone()) for nm, v in stage_views(D, B)]
             else:
                 if not (h[2] == 0 and torch.equal(h[0], ref[key][0]) and torch.equal(h[1], ref[key][1])):
