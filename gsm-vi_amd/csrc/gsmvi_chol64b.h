@@ -216,6 +216,13 @@ __device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, i
             double* rsb = tr + 8 * 64;
             volatile int* cnt = reinterpret_cast<volatile int*>(rsb + 16);
             const bool wb = active && !(set > 0 && g == 0);
+#ifdef CHOLB_TEST_REPLICA_DELAY
+            // test hook (scripts/chol64b_test.hip, tests/test_gpu_aux.py): hold the replica sets' waves back for several
+            // microseconds, the schedule under which an in-place write-back of the diagonal block by set 0 would be loaded
+            if (set > 0)
+                for (int d_ = 0; d_ < CHOLB_TEST_REPLICA_DELAY; ++d_) __builtin_amdgcn_s_sleep(127);
+            asm volatile("s_nop 0" ::: "memory");     // the panel's LDS loads must not be scheduled in front of the delay
+#endif
             if ((w & 1) == 0)
                 cholb_panel_half<ES, SEMIDEF, 0>(E, k0, col, wb, aug && AUG == 1, slot == 0, ur, tr, rsb, cnt, 8 * k, allow_dep, sh_fail, vk);
             else

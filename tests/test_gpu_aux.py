@@ -139,3 +139,27 @@ def test_advi_with_the_device_target_and_device_monitor():
     assert len(losses) == 1501 and np.mean(losses[-100:]) < np.mean(losses[:100])
     assert np.allclose(mean, m, atol=0.15) and np.linalg.norm(c - cov_t) / np.linalg.norm(cov_t) < 0.3
     assert len(mon.rkl) == 5 and np.isfinite(mon.rkl).all() and mon.rkl[-1] < mon.rkl[0]
+
+
+def test_blocked_cholesky_with_late_replica_waves(tmp_path):
+    """chol64_blk keeps replicas of the 16 x 16 diagonal block in the other column sets' panel waves (AUG >= 1), loaded at an
+    unordered time; since round 3 the block is written back only behind the panel barrier (a once-in-3e5
+    deviation found by soaking).  The standalone harness is built plain and with the replica waves held back by ~7 us
+    (CHOLB_TEST_REPLICA_DELAY): [R | R^-T], the dropped-row rule and the failure indices must come out right under both
+    schedules.  (The delayed build also passed before the change: this guards the schedule, it is not a reproducer.)"""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    src = os.path.join(ROOT, "scripts", "chol64b_test.hip")
+    for delay in (0, 2):
+        exe = str(tmp_path / f"chol64b_test_{delay}")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "gsm-vi_amd", "csrc"),
+               src, "-o", exe] + ([f"-DCHOLB_TEST_REPLICA_DELAY={delay}"] if delay else [])
+        b = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert b.returncode == 0, b.stderr[-2000:]
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:]
