@@ -165,9 +165,9 @@ __device__ __forceinline__ void cholb_panel_half(double* E, int k0, int col, boo
     }
     CHOLB_PSTAMP(H, 11);
     // The DIAGONAL block is not written back here: the other column sets hold replicas of it, loaded from E when their waves
-    // start this panel, and nothing orders those loads against this wave's end -- a replica wave that is scheduled ~1 us late
-    // (seen about once in 3e5 factorisations inside a busy pipeline, never with the kernel alone on the chip) would load rows
-    // that are already factored.  chol64_blk writes vkeep back behind the workgroup barrier that follows the panel phase.
+    // start this panel, and nothing orders those loads against this wave's end.  chol64_blk writes vkeep back behind the
+    // workgroup barrier that follows the panel phase.  (Round 3: a deviation seen about once in 3e5 factor updates inside a
+    // busy pipeline, never with the kernel alone on the chip, has not been seen since this change -- DESIGN section 8.)
     if (write_back && !diag_lane) {
         double* ep = E + (k0 + R0) * ES + col;
 #pragma unroll
