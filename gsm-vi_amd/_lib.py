@@ -14,8 +14,15 @@ class GsmviError(RuntimeError):
         self.status = status
 
 
-def library_path():
-    return os.path.join(_HERE, "libgsmvi_hip.so")
+def library_path(debug=None):
+    """The product library; with GSMVI_HIP_DEBUG_LIB=1 (diagnostic scripts) the debug build of the same objects, which also
+    exports include/gsmvi_hip_debug.h."""
+    variant = os.environ.get("GSMVI_HIP_LIB_VARIANT", "")
+    if debug is None and variant:          # diagnostic builds of csrc/Makefile (e.g. `make oldwb`), debug export list
+        return os.path.join(_HERE, f"libgsmvi_hip_{variant}.so")
+    if debug is None:
+        debug = os.environ.get("GSMVI_HIP_DEBUG_LIB", "0") not in ("", "0")
+    return os.path.join(_HERE, "libgsmvi_hip_debug.so" if debug else "libgsmvi_hip.so")
 
 
 _c_dp = C.c_void_p   # device pointers travel as integers
@@ -64,10 +71,6 @@ _SIGS = {
     "gsmvi_randn_batch_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int64, _c_dp, _c_dp,
                                         _c_dp]),
     "gsmvi_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
-    "gsmvi_debug_read_workspace": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_double), C.c_size_t]),
-    "gsmvi_debug_workspace_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
-    "gsmvi_debug_chol128": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp]),
-    "gsmvi_debug_read_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]),
     "gsmvi_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "gsmvi_gaussian_score_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp,
                                            _c_dp, C.c_int, _c_dp, C.c_int]),
@@ -88,9 +91,23 @@ _SIGS = {
 }
 
 
-def exported_symbols():
-    """Names every build of the library must export (kept in sync with include/gsmvi_hip.h and gsmvi_hip_debug.h)."""
-    return sorted(_SIGS)
+# include/gsmvi_hip_debug.h: exported by libgsmvi_hip_debug.so only (diagnostic scripts; GSMVI_HIP_DEBUG_LIB=1)
+_DEBUG_SIGS = {
+    "gsmvi_debug_read_workspace": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_double), C.c_size_t]),
+    "gsmvi_debug_workspace_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "gsmvi_debug_chol128": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp]),
+    "gsmvi_debug_read_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]),
+}
+
+
+def exported_symbols(debug=False):
+    """Names the library exports: exactly include/gsmvi_hip.h for the product library; the debug build adds
+    include/gsmvi_hip_debug.h (csrc/exports.map / exports_debug.map are the linker's copies of these lists)."""
+    return sorted(list(_SIGS) + (list(_DEBUG_SIGS) if debug else []))
+
+
+def debug_build_selected():
+    return os.environ.get("GSMVI_HIP_DEBUG_LIB", "0") not in ("", "0") or bool(os.environ.get("GSMVI_HIP_LIB_VARIANT", ""))
 
 
 def load_library():
@@ -106,7 +123,10 @@ def load_library():
             "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C gsm-vi_amd/csrc`. "
             "gsmvi_amd has no CPU fallback.")
     lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
-    for name, (res, args) in _SIGS.items():
+    sigs = dict(_SIGS)
+    if debug_build_selected():
+        sigs.update(_DEBUG_SIGS)
+    for name, (res, args) in sigs.items():
         fn = getattr(lib, name)     # AttributeError here = ABI mismatch, surface it
         fn.restype = res
         fn.argtypes = args

@@ -321,11 +321,3 @@ __device__ __forceinline__ void chol128_rank64_update(double* M) {
         }
     }
 }
-
-__device__ __forceinline__ void chol64_lds(double* T, double* rinv, int nb, int* sh_fail) {
-#ifdef GSMVI_CHOL64_BLOCKED
-    chol64_lds_s<TS>(T, rinv, nb, sh_fail);
-#else
-    chol64_rows_s<TS>(T, rinv, nb, sh_fail);
-#endif
-}

@@ -168,11 +168,21 @@ __device__ __forceinline__ void cholb_panel_half(double* E, int k0, int col, boo
     // start this panel, and nothing orders those loads against this wave's end.  chol64_blk writes vkeep back behind the
     // workgroup barrier that follows the panel phase.  (Round 3: a deviation seen about once in 3e5 factor updates inside a
     // busy pipeline, never with the kernel alone on the chip, has not been seen since this change -- DESIGN section 8.)
+#ifdef CHOLB_TEST_OLD_WRITEBACK
+    // test builds only (scripts/chol64b_test.hip, `make oldwb`): the pre-fix behaviour, set 0 writes its factored diagonal rows
+    // back IN PLACE at the end of its half-panel -- the write the replicas' loads were not ordered against
+    if (write_back) {
+        double* ep = E + (k0 + R0) * ES + col;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ep[i * ES] = (diag_lane && R0 + i > c) ? 0.0 : v[i];
+    }
+#else
     if (write_back && !diag_lane) {
         double* ep = E + (k0 + R0) * ES + col;
 #pragma unroll
         for (int i = 0; i < 8; ++i) ep[i * ES] = v[i];
     }
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) vkeep[i] = v[i];
     if (fail != 0 && l == 0) atomicMin(sh_failmin, fail);
@@ -192,6 +202,9 @@ __device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, i
     }
     if (tid == 0) *sh_fail = 0x7fffffff;
     if (tid < AUG + 1) *reinterpret_cast<volatile int*>(scratch + tid * CHOLB_SCRATCH_PER_SET + 16 * 64 + 8 * 64 + 16) = 0;
+#ifdef CHOLB_TEST_FORCE_ORDER
+    if (tid == 0) *reinterpret_cast<volatile int*>(scratch + 16 * 64 + 8 * 64 + 17) = 0;
+#endif
     __syncthreads();
 #pragma unroll 1
     for (int k = 0; k < nblk; ++k) {                              // block-uniform
@@ -223,17 +236,33 @@ __device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, i
                 for (int d_ = 0; d_ < CHOLB_TEST_REPLICA_DELAY; ++d_) __builtin_amdgcn_s_sleep(127);
             asm volatile("s_nop 0" ::: "memory");     // the panel's LDS loads must not be scheduled in front of the delay
 #endif
+#ifdef CHOLB_TEST_FORCE_ORDER
+            // test hook: the replica sets' waves load their copy of the diagonal block only AFTER both waves of set 0 have
+            // finished this panel (a counter in the spare word of set 0's scratch) -- the latest legal schedule, forced.  With
+            // CHOLB_TEST_OLD_WRITEBACK this is exactly the interleaving the round-3 fix removes: the replicas load factored rows.
+            volatile int* order_flag = reinterpret_cast<volatile int*>(scratch + 16 * 64 + 8 * 64 + 17);
+            if (set > 0) {
+                while (__builtin_amdgcn_readfirstlane(*order_flag) < 2 * (k + 1)) __builtin_amdgcn_s_sleep(1);
+                asm volatile("s_nop 0" ::: "memory");
+            }
+#endif
             if ((w & 1) == 0)
                 cholb_panel_half<ES, SEMIDEF, 0>(E, k0, col, wb, aug && AUG == 1, slot == 0, ur, tr, rsb, cnt, 8 * k, allow_dep, sh_fail, vk);
             else
                 cholb_panel_half<ES, SEMIDEF, 1>(E, k0, col, wb, aug && AUG == 1, slot == 0, ur, tr, rsb, cnt, 8 * k, allow_dep, sh_fail, vk);
+#ifdef CHOLB_TEST_FORCE_ORDER
+            asm volatile("" ::: "memory");                        // a wave's LDS operations execute in program order
+            if (set == 0 && l == 0) atomicAdd(const_cast<int*>(order_flag), 1);
+#endif
         }
         __syncthreads();
+#ifndef CHOLB_TEST_OLD_WRITEBACK
         if (w < 2 && g == 0) {                                    // set 0's diagonal-block lanes: the factored block, strictly-lower part zeroed
             double* ep = E + (k0 + 8 * w) * ES + k0 + c;
 #pragma unroll
             for (int i = 0; i < 8; ++i) ep[i * ES] = (8 * w + i > c) ? 0.0 : vk[i];
         }
+#endif
         CHOLB_STAMP(2 + 2 * k);
         if (k + 1 >= nblk) break;                                 // block-uniform: no trailing matrix
         // ---- trailing: for every remaining block row i and every column group j (A-groups i .. nblk-1, W-groups 0 .. k):

@@ -29,6 +29,7 @@
 #include "gsmvi_chol64b.h"
 #include "gsmvi_small16.h"
 #include "../../include/gsmvi_hip.h"
+#include "../../include/gsmvi_hip_debug.h"
 
 // ---- transposed panel product partials: Pp[kc][r][j] = sum_{i in chunk(kc)} A[r][i] M[j][i] ----------
 // M has mrows rows of length D (mrows = D for the square factor; a row block of a sharded matrix otherwise);

@@ -14,6 +14,8 @@
 #include "../../include/gsmvi_hip.h"
 #include "gsmvi_ctx.h"
 
+int gsmvi_bam_small_nmax();
+
 namespace {
 typedef ncclResult_t (*all_gather_fn)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
 typedef ncclResult_t (*comm_int_fn)(const ncclComm_t, int*);
@@ -24,8 +26,9 @@ struct rccl_api {
     err_str_fn err_str = nullptr;
 };
 rccl_api g_rccl;
-std::once_flag g_rccl_once;
-void* g_rccl_user_handle = nullptr;              // set before first use by gsmvi_set_rccl_library
+std::mutex g_rccl_mu;
+int g_rccl_state = 0;                            // 0 = not tried yet, 1 = resolved, -1 = the last attempt found no RCCL
+void* g_rccl_user_handle = nullptr;              // set by gsmvi_set_rccl_library; a new handle re-arms a failed resolve
 
 void resolve_rccl() {
     void* h = g_rccl_user_handle;
@@ -43,8 +46,12 @@ void resolve_rccl() {
 }
 
 bool load_rccl() {
-    std::call_once(g_rccl_once, resolve_rccl);
-    return g_rccl.all_gather != nullptr;
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl_state == 0) {
+        resolve_rccl();
+        g_rccl_state = g_rccl.all_gather != nullptr ? 1 : -1;
+    }
+    return g_rccl_state == 1;
 }
 
 // communicator geometry, validated BEFORE anything is enqueued
@@ -77,11 +84,15 @@ int gather(const char* fn, void* nccl_comm, void* stream, const double* mine, do
 }  // namespace
 
 extern "C" int gsmvi_set_rccl_library(void* dl_handle) {
-    if (g_rccl.all_gather != nullptr) {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl_state == 1) {
         gsmvi_set_error("%s: %s", __func__, "RCCL was already resolved; call this before the first sharded entry point");
         return GSMVI_ERR_BAD_ARG;
     }
+    // not tried yet, or an earlier attempt found no RCCL (round-3 advice: that attempt used to consume the one-shot resolver,
+    // so a handle supplied afterwards was silently never used): the next sharded call resolves again, from this handle
     g_rccl_user_handle = dl_handle;
+    g_rccl_state = 0;
     return GSMVI_OK;
 }
 
@@ -153,9 +164,17 @@ extern "C" int gsmvi_bam_update_sharded_f64(gsmvi_ctx* ctx, void* stream, void* 
     int st = comm_geometry(__func__, nccl_comm, &nranks, &rank);
     if (st != GSMVI_OK) return st;
     const long long B = (long long)B_local * nranks;
-    if (D <= 0 || B_local <= 0 || ldx < D || ldg < D || D > ctx->max_D || B > ctx->max_B) {
-        gsmvi_set_error("%s: %s", __func__, "bad size, or (D, B_local x ranks) exceeds the context's workspace");
+    if (D <= 0 || B_local <= 0 || ldx < D || ldg < D || lds0 < D || lds < D) {
+        gsmvi_set_error("%s: %s", __func__, "non-positive size or a leading dimension smaller than D");
+        return GSMVI_ERR_BAD_ARG;
+    }
+    if (D > ctx->max_D || B > ctx->max_B) {
+        gsmvi_set_error("%s: %s", __func__, "(D, B_local x ranks) exceeds the context's workspace; create a larger context");
         return GSMVI_ERR_WORKSPACE;
+    }
+    if (B > gsmvi_bam_small_nmax()) {            // the combined batch, checked BEFORE the staging copies and the all-gathers
+        gsmvi_set_error("%s: %s", __func__, "B_local x ranks exceeds the device chain of the BaM update (B <= 640)");
+        return GSMVI_ERR_UNSUPPORTED;
     }
     // BaM's statistics couple all samples: the ranks exchange their (x_b, g_b) rows -- two all-gathers of B_local x D doubles
     // per rank (256 KiB at D = 1024, B = 128, 8 ranks) -- and every replica runs the identical update

@@ -35,6 +35,7 @@ class HipEngine:
         self._max_D = 0
         self._max_B = 0
         self._tuning = {}
+        self._retired = []         # outgrown contexts: kept alive, a captured hipGraph may still launch into their workspace
         if max_D and max_B:
             self._ensure(max_D, max_B)
 
@@ -44,8 +45,10 @@ class HipEngine:
             return
         newD, newB = max(D, self._max_D), max(B, self._max_B)
         if self._ctx:
-            torch.cuda.synchronize(self.device)
-            _lib.check("gsmvi_destroy", self.lib.gsmvi_destroy(self._ctx))
+            # The outgrown context is RETIRED, not destroyed: kernels enqueued on it may still be running and, worse, a hipGraph
+            # captured earlier (GSM.fit's replayed blocks, a user's torch.cuda.graph around engine calls) holds raw pointers
+            # into its workspace.  It costs its workspace (~100 MiB at D=4096) until release_retired() / close().
+            self._retired.append(self._ctx)
             self._ctx = C.c_void_p()
         ctx = C.c_void_p()
         _lib.check("gsmvi_create", self.lib.gsmvi_create(C.byref(ctx), self.device.index, newD, newB))
@@ -53,7 +56,16 @@ class HipEngine:
         for k, v in self._tuning.items():          # knobs survive a context regrow
             _lib.check("gsmvi_set_tuning", self.lib.gsmvi_set_tuning(self._ctx, k.encode(), int(v)))
 
+    def release_retired(self):
+        """Destroy the contexts a regrow left behind.  Only when no captured graph that used them will be replayed again."""
+        if self._retired:
+            torch.cuda.synchronize(self.device)
+            for c in self._retired:
+                self.lib.gsmvi_destroy(c)
+            self._retired = []
+
     def close(self):
+        self.release_retired()
         if self._ctx:
             torch.cuda.synchronize(self.device)
             self.lib.gsmvi_destroy(self._ctx)

@@ -22,18 +22,25 @@ def gsm_update(samples, vs, mu0, S0, engine=None, assume_symmetric=None):
     Shape errors raise AssertionError like the reference (gsm_numpy.py:43-44).
 
     ``assume_symmetric`` (not in the reference): the fast update kernel reads only the upper triangle of S0 (a
-    covariance is symmetric).  ``None`` (default): a HOST S0 is checked on the host before its upload (no device
-    work, no synchronisation) and a non-symmetric one takes the general kernels, which read all of S0 and keep the
-    reference's literal semantics S = S0 + mean (gsm_numpy.py:50-53); a DEVICE S0 is taken to be symmetric -- no
-    D x D compare and no host synchronisation sit in front of the update.  ``False`` forces the general kernels,
-    ``True`` skips the host check as well.
+    covariance is symmetric).  ``None`` (default): a HOST S0 -- a numpy array or a CPU torch tensor -- is checked on the
+    host before its upload (no device work, no synchronisation) and a non-symmetric one takes the general kernels, which
+    read all of S0 and keep the reference's literal semantics S = S0 + mean (gsm_numpy.py:50-53); a DEVICE (CUDA) S0 is
+    taken to be symmetric -- no D x D compare and no host synchronisation sit in front of the update: a non-symmetric
+    device S0 gives the update of its upper triangle mirrored, NOT the reference's result.  ``"check"`` compares a device
+    S0 with its transpose on the device (one D x D pass and one host synchronisation) and routes like the host check;
+    ``False`` forces the general kernels, ``True`` skips every check.
     """
     assert len(samples.shape) == 2
     assert len(vs.shape) == 2
     eng = engine if engine is not None else get_engine()
     want_torch = _is_torch(samples)
-    if assume_symmetric is None:
-        assume_symmetric = True if _is_torch(S0) else bool(np.array_equal(np.asarray(S0), np.asarray(S0).T))
+    if assume_symmetric is None or assume_symmetric == "check":
+        if _is_torch(S0) and S0.is_cuda:
+            assume_symmetric = bool(torch.equal(S0, S0.T)) if assume_symmetric == "check" else True
+        elif _is_torch(S0):
+            assume_symmetric = bool(torch.equal(S0, S0.T))
+        else:
+            assume_symmetric = bool(np.array_equal(np.asarray(S0), np.asarray(S0).T))
     Xd, Gd, m0, S0d = eng.asarray(samples), eng.asarray(vs), eng.asarray(mu0), eng.asarray(S0)
     if assume_symmetric:
         mu, S = eng.gsm_update(Xd, Gd, m0, S0d)
@@ -73,7 +80,7 @@ class GSM:
     # ------------------------------------------------------------------------------
     def fit(self, key, mean=None, cov=None, batch_size=2, niter=5000, nprint=10, verbose=True,
             check_goodness=True, monitor=None, *, sampler="cholesky", rng="auto", as_torch=False,
-            forced_samples=None, method="auto", shard=False, group=None, graph=None):
+            forced_samples=None, method="auto", shard=False, group=None, graph=None, root_potrf=False):
         """Fit N(mean, cov) to the target (gsmvi/gsm_numpy.py:77-129, gsmvi/gsm.py:79-133).
 
         Same arguments and return value as the reference.  Behaviour kept: ``niter + 1`` updates
@@ -102,6 +109,11 @@ class GSM:
                     replicated; each rank evaluates ``lp_g`` only on its batch_size/world rows, the
                     per-sample records are all-gathered (RCCL) and every replica applies the identical
                     combined update (gsm-vi_amd/dist.py).  All ranks return the same (mean, cov).
+          root_potrf : sharded DENSE fit only.  False (default): every rank factors its (bit-identical) covariance replica --
+                    the factorisations run in parallel and cost no wall-clock time over a single GPU's.  True: rank 0 factors
+                    and broadcasts the D x D factor and its flag (dist.root_potrf): saves the redundant D^3 work (energy, or
+                    a GPU shared with other work) at the price of a serial factorisation + 8 D^2-byte broadcast per
+                    iteration; not measured on more than one GPU, hence opt-in (round-3 advice).
           graph   : the factor-form fit can replay blocks of 16 iterations as one hipGraph when every launch in them is
                     capturable (a score marked ``graph_safe`` such as ``GaussianTarget.lp_g``, the device draw stream, no
                     sharding).  None (default): do so for D <= 512, where the Python / launch overhead is the bound; True:
@@ -208,9 +220,9 @@ class GSM:
                 vs = self.lp_g(X) if native else eng.asarray(self.lp_g(eng.to_numpy(X)))
                 eng.gsm_update(X, vs, mean_t, cov_t, out=(mean_new, cov_new))
             nevals += B
-            if shard:                                             # one rank factors, the others receive (dist.root_potrf)
-                from .dist import root_potrf
-                root_potrf(eng, cov_new, R_new, flag, group=group)
+            if shard and root_potrf:                              # opt-in: one rank factors, the others receive
+                from .dist import root_potrf as _root_potrf
+                _root_potrf(eng, cov_new, R_new, flag, group=group)
             else:
                 eng.potrf(cov_new, out=R_new, flag=flag)          # _check_goodness, :121,:132-146
             eng.commit(flag, mean_new, cov_new, mean_t, cov_t, n_rev)

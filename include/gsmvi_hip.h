@@ -36,6 +36,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is compiled with -fvisibility=hidden and linked with an export list (csrc/exports.map): exactly the
+ * functions declared between this push and its pop are visible (tests/test_abi.py compares `nm -D` with this file). */
+#pragma GCC visibility push(default)
 
 #define GSMVI_ABI_VERSION 1
 
@@ -332,6 +335,7 @@ int gsmvi_bam_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
                                 const double* mu0, const double* F0, int ldf0, double reg,
                                 double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,8 @@
 /*
- * gsmvi_hip_debug.h -- diagnostic entry points of libgsmvi_hip.so (NOT part of the drop-in boundary of gsmvi_hip.h).
- * Used by scripts/ (in-kernel timelines) and by a few tests that inspect the workspace; both synchronise the device.
+ * gsmvi_hip_debug.h -- diagnostic entry points (NOT part of the drop-in boundary of gsmvi_hip.h).  They are exported by
+ * libgsmvi_hip_debug.so only -- the same objects linked with csrc/exports_debug.map -- never by the product library
+ * libgsmvi_hip.so (its export list hides them and --gc-sections drops their host code).  Used by scripts/ (in-kernel
+ * timelines, soaks); select the debug build with GSMVI_HIP_DEBUG_LIB=1 before importing gsmvi_amd.
  */
 #ifndef GSMVI_HIP_DEBUG_H
 #define GSMVI_HIP_DEBUG_H
@@ -10,6 +12,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)
 
 /* Read back in-kernel s_memrealtime stamps: with the tuning knob "timeline" = 1 the first n words of the stamp buffer
  * ([kernel slot 0..3][512 workgroups][8 words]; workgroups beyond 512 write nothing), otherwise (knob "cov_dbg" bits
@@ -24,6 +27,7 @@ int gsmvi_debug_workspace_ptr(gsmvi_ctx* ctx, int region, double** out);
  * For soak / determinism scripts. */
 int gsmvi_debug_chol128(void* stream, int n, int with_inverse, const double* A, double* R, double* W, int* info_dev);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

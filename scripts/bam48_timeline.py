@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: phase times of k_bam_small48 (BaM's small chain, n <= 48, one workgroup) from s_memrealtime stamps."""
+import os as _os; _os.environ.setdefault("GSMVI_HIP_DEBUG_LIB", "1")   # gsmvi_debug_* are exported by libgsmvi_hip_debug.so only
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gsmvi_amd

@@ -2,6 +2,7 @@
 """Soak of the one-workgroup 128 x 128 Cholesky kernel of the factor chain (k_chol128<false>, via gsmvi_debug_chol128) on the
 A' = T^T T of a real D=4096, B=64 update: the same input factored over and over, every result compared on the device with the
 first one.  usage: chol128_soak.py [seconds] [with_inverse]"""
+import os as _os; _os.environ.setdefault("GSMVI_HIP_DEBUG_LIB", "1")   # gsmvi_debug_* are exported by libgsmvi_hip_debug.so only
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gsmvi_amd

@@ -1,4 +1,5 @@
 """Diagnostic: intermediates of the n = 128 factor chain on linearly dependent rows."""
+import os as _os; _os.environ.setdefault("GSMVI_HIP_DEBUG_LIB", "1")   # gsmvi_debug_* are exported by libgsmvi_hip_debug.so only
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, gsmvi_amd

@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("GSMVI_HIP_DEBUG_LIB", "1")   # gsmvi_debug_* are exported by libgsmvi_hip_debug.so only
 import ctypes as C, sys, numpy as np
 sys.path.insert(0, '.')
 import gsmvi_amd

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: phase times of k_gsmf_small (the 2B x 2B chain of the factor update) from s_memrealtime stamps."""
+import os as _os; _os.environ.setdefault("GSMVI_HIP_DEBUG_LIB", "1")   # gsmvi_debug_* are exported by libgsmvi_hip_debug.so only
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gsmvi_amd

@@ -3,6 +3,7 @@
 Fs, Gram slabs, Rg, T, W, P, K'', coefficients) are compared ON THE DEVICE with the first call's (in-place views of the context
 workspace through gsmvi_debug_workspace_ptr); on a mismatch every differing stage is reported in pipeline order.
 usage: soak_c5_debug.py [seconds] [D B] [knob=value ...]"""
+import os as _os; _os.environ.setdefault("GSMVI_HIP_DEBUG_LIB", "1")   # gsmvi_debug_* are exported by libgsmvi_hip_debug.so only
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gsmvi_amd

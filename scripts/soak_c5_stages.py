@@ -3,6 +3,7 @@
 scripts/soak_round3.py does), with the intermediates of the context workspace compared against the first call's snapshot
 ONLY when the result deviates (they survive until the next call): says which stage took the other outcome.
 usage: soak_c5_stages.py [seconds] [knob=value ...]"""
+import os as _os; _os.environ.setdefault("GSMVI_HIP_DEBUG_LIB", "1")   # gsmvi_debug_* are exported by libgsmvi_hip_debug.so only
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gsmvi_amd

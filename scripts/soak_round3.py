@@ -3,6 +3,8 @@
 back to back for a while, eagerly and from replayed graphs, every result compared bit for bit with the first one.
 usage: soak_round3.py [seconds]"""
 import os, sys, time
+if os.environ.get("SOAK_STAGES"):
+    os.environ.setdefault("GSMVI_HIP_DEBUG_LIB", "1")   # the stage views need gsmvi_debug_workspace_ptr (libgsmvi_hip_debug.so)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gsmvi_amd
 from oracle import gsm_oracle as orc

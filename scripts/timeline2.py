@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: timeline of ONE dense GSM update (all kernels) inside a replayed hipGraph, from in-kernel s_memrealtime stamps
 (100 MHz, one clock for the whole chip).  usage: timeline2.py [cold|warm] [name=value tuning ...]"""
+import os as _os; _os.environ.setdefault("GSMVI_HIP_DEBUG_LIB", "1")   # gsmvi_debug_* are exported by libgsmvi_hip_debug.so only
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gsmvi_amd

@@ -8,14 +8,26 @@ import pytest
 from conftest import ROOT
 
 
-def _header_symbols():
-    """Every function include/gsmvi_hip.h (the boundary) and include/gsmvi_hip_debug.h (diagnostics) declare."""
+def _header_symbols(headers=("gsmvi_hip.h",)):
+    """Every function the given headers declare (gsmvi_hip.h: the boundary; gsmvi_hip_debug.h: diagnostics)."""
     out = set()
-    for h in ("gsmvi_hip.h", "gsmvi_hip_debug.h"):
+    for h in headers:
         txt = open(os.path.join(ROOT, "include", h)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         out |= set(re.findall(r"\b(gsmvi_[a-z0-9_]+)\s*\(", txt))
     return sorted(out)
+
+
+def _nm_dynamic(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    return sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+
+
+def _map_symbols(name):
+    txt = open(os.path.join(ROOT, "gsm-vi_amd", "csrc", name)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(re.findall(r"^\s+(gsmvi_[a-z0-9_]+);", txt, flags=re.M))
 
 
 def test_library_is_built():
@@ -31,6 +43,26 @@ def test_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     assert set(_lib.exported_symbols()) == set(declared), "ctypes table out of sync with the header"
+
+
+def test_product_library_exports_exactly_the_header():
+    """-fvisibility=hidden + export list: `nm -D` of the product library is include/gsmvi_hip.h, symbol for symbol -- no
+    internal C++ functions, no kernel stubs, no diagnostic entry points."""
+    from gsmvi_amd import _lib
+    declared = _header_symbols()
+    assert _nm_dynamic(_lib.library_path(debug=False)) == declared
+    assert _map_symbols("exports.map") == declared
+
+
+def test_debug_library_adds_only_the_debug_header():
+    from gsmvi_amd import _lib
+    path = _lib.library_path(debug=True)
+    assert os.path.exists(path), "make -C gsm-vi_amd/csrc builds libgsmvi_hip_debug.so beside the product library"
+    both = _header_symbols(("gsmvi_hip.h", "gsmvi_hip_debug.h"))
+    assert _nm_dynamic(path) == both
+    assert _map_symbols("exports_debug.map") == both
+    assert set(_lib.exported_symbols(debug=True)) == set(both)
+    assert all(n.startswith("gsmvi_debug_") for n in set(both) - set(_header_symbols()))
 
 
 def test_abi_version_and_status_strings():

@@ -144,9 +144,14 @@ def test_advi_with_the_device_target_and_device_monitor():
 def test_blocked_cholesky_with_late_replica_waves(tmp_path):
     """chol64_blk keeps replicas of the 16 x 16 diagonal block in the other column sets' panel waves (AUG >= 1), loaded at an
     unordered time; since round 3 the block is written back only behind the panel barrier (a once-in-3e5
-    deviation found by soaking).  The standalone harness is built plain and with the replica waves held back by ~7 us
-    (CHOLB_TEST_REPLICA_DELAY): [R | R^-T], the dropped-row rule and the failure indices must come out right under both
-    schedules.  (The delayed build also passed before the change: this guards the schedule, it is not a reproducer.)"""
+    deviation found by soaking).  The standalone harness is built four ways:
+      plain, and with the replica waves held back by ~7 us (CHOLB_TEST_REPLICA_DELAY)   -> must pass;
+      CHOLB_TEST_FORCE_ORDER: the replicas load their copy only after BOTH waves of set 0 have finished the panel (an LDS
+        counter), i.e. the latest schedule the hardware may produce, forced                -> must pass;
+      the same forced order with CHOLB_TEST_OLD_WRITEBACK (the pre-fix in-place write-back of the factored diagonal rows)
+                                                                                          -> must FAIL ([R | R^-T]: W wrong),
+    which is the regression protection the delay-only build did not give: the mechanism the fix removes is shown to break the
+    result whenever the interleaving occurs, and the shipped header is shown immune to it."""
     import os
     import shutil
     import subprocess
@@ -155,11 +160,17 @@ def test_blocked_cholesky_with_late_replica_waves(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available on this box")
     src = os.path.join(ROOT, "scripts", "chol64b_test.hip")
-    for delay in (0, 2):
-        exe = str(tmp_path / f"chol64b_test_{delay}")
+    variants = [("plain", [], True), ("delay", ["-DCHOLB_TEST_REPLICA_DELAY=2"], True),
+                ("forced", ["-DCHOLB_TEST_FORCE_ORDER"], True),
+                ("forced_oldwb", ["-DCHOLB_TEST_FORCE_ORDER", "-DCHOLB_TEST_OLD_WRITEBACK"], False)]
+    for tag, defs, must_pass in variants:
+        exe = str(tmp_path / f"chol64b_test_{tag}")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "gsm-vi_amd", "csrc"),
-               src, "-o", exe] + ([f"-DCHOLB_TEST_REPLICA_DELAY={delay}"] if delay else [])
+               src, "-o", exe] + defs
         b = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         assert b.returncode == 0, b.stderr[-2000:]
         r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
-        assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:]
+        if must_pass:
+            assert r.returncode == 0 and "ALL OK" in r.stdout, (tag, r.stdout[-3000:])
+        else:
+            assert r.returncode != 0 and "FAILED" in r.stdout, (tag, "the pre-fix write-back survived the forced interleaving", r.stdout[-3000:])

@@ -333,6 +333,13 @@ def test_nonsymmetric_s0_keeps_the_reference_semantics(eng):
     dev = [eng.asarray(st[k]) for k in ("samples", "vs", "mu0")]
     mu3, S3 = gsmvi_amd.gsm_update(*dev, eng.asarray(S0), assume_symmetric=False)
     assert rel_err(S3.cpu().numpy(), S_o) < 1e-11 and rel_err(mu3.cpu().numpy(), mu_o) < 1e-11
+    # a HOST torch tensor is checked like a numpy array (round-3 advice); a device tensor on request ("check")
+    import torch
+    cpu_t = [torch.as_tensor(st[k]) for k in ("samples", "vs", "mu0")]
+    mu5, S5 = gsmvi_amd.gsm_update(*cpu_t, torch.as_tensor(S0))
+    assert rel_err(S5.cpu().numpy(), S_o) < 1e-11 and rel_err(mu5.cpu().numpy(), mu_o) < 1e-11
+    mu6, S6 = gsmvi_amd.gsm_update(*dev, eng.asarray(S0), assume_symmetric="check")
+    assert rel_err(S6.cpu().numpy(), S_o) < 1e-11 and rel_err(mu6.cpu().numpy(), mu_o) < 1e-11
     # the general entry point on ragged and fast-path shapes alike
     for (D, B) in ((37, 5), (256, 32)):
         st2 = orc.make_update_state(D, B, 11)
