@@ -356,6 +356,126 @@ __global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const doubl
     }
 }
 
+// ---- Z = W (P + M1^T Vf) with the explicit inverse factor W = L^-1 (k_bam_cholw), the new mean, the signed panel; n <= 128 ----
+// (round 4: bam.py:107,110 as two chained MFMA products instead of a panel product + finish + per-column substitution.)
+// One workgroup per 16 columns of D, eight waves, wave w owns the 16-row block w of both products:
+//   phase 1  T = M1^T Vf_tile (K = n), A = P_tile + T -> LDS           A-operand M1[k][r] straight from L2 (16 consecutive
+//            doubles per k), B-operand the Vf tile staged once in LDS ([k][16]: the four k-slots of a step read 512
+//            contiguous bytes, conflict-free)
+//   phase 2  Z = W A: row block w needs the k-blocks 0 .. w only (W is lower triangular); its W loads are issued before phase 1
+// Z goes to rows n .. 2n-1 of Ft and, negated, of Fs (rows 0 .. n-1 hold Vf: k_bam_stats_h).  Mean (bam.py:112):
+// mu = mu0/(1+reg) + r1 (S0 gbar + Vf^T vg - Z^T zg + xbar), the two dots from the tiles in LDS / registers, fixed order.
+__global__ __launch_bounds__(512) void k_bam_zw(int D, int n, const double* __restrict__ P, const double* __restrict__ M1,
+                                                const double* __restrict__ W, const double* __restrict__ zg,
+                                                const double* __restrict__ vg, const double* __restrict__ mu0,
+                                                const double* __restrict__ xbar, double reg, double* __restrict__ Ft,
+                                                double* __restrict__ Fs, double* __restrict__ mu) {
+    __shared__ __attribute__((aligned(16))) double Vs[128 * 16], As[128 * 16];
+    __shared__ double szg[128], svg[128], redz[8 * 4 * 16];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
+    const int j0 = blockIdx.x * 16;
+    const int nb = (n + 15) >> 4;
+    const int jc = (j0 + cc) < D ? j0 + cc : D - 1;
+    const bool colin = (j0 + cc) < D;
+    const int rA = 16 * w + cc, rAc = rA < n ? rA : n - 1;   // this lane's row as an MFMA A-operand row
+    // all global loads of the workgroup first: Vf tile (4 per thread), this wave's M1 columns and W rows, its P block
+    double vt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + 512 * u, k = e >> 4, c = e & 15;
+        const int kc = k < n ? k : n - 1, jj = (j0 + c) < D ? j0 + c : D - 1;
+        const double v = Ft[(size_t)kc * D + jj];
+        vt[u] = (k < n && (j0 + c) < D) ? v : 0.0;
+    }
+    double am[32], aw[32], pv[4];
+    if (w < nb) {                                            // wave-uniform
+#pragma unroll
+        for (int st = 0; st < 32; ++st) {
+            const int k = 4 * st + ks, kc = k < n ? k : n - 1;
+            const double m = M1[(size_t)kc * n + rAc];
+            am[st] = (k < n && rA < n) ? m : 0.0;
+        }
+#pragma unroll
+        for (int st = 0; st < 32; ++st) {
+            const int k = 4 * st + ks, kc = k < n ? k : n - 1;
+            double x = 0.0;
+            if (st < 4 * (w + 1)) x = W[(size_t)rAc * n + kc];
+            aw[st] = (k < n && rA < n) ? x : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * w + ks + 4 * r;
+            const double x = P[(size_t)(row < n ? row : n - 1) * D + jc];
+            pv[r] = (row < n && colin) ? x : 0.0;
+        }
+    }
+    if (tid < 128) {
+        szg[tid] = tid < n ? zg[tid] : 0.0;
+        svg[tid] = tid < n ? vg[tid] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Vs[tid + 512 * u] = vt[u];
+    __syncthreads();
+    if (w < nb) {
+        v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int st = 0; st < 32; st += 2) {
+            if (4 * st < n) {                                // block-uniform: k-steps beyond n are skipped
+                acc0 = GSMVI_MFMA_F64(am[st], Vs[(4 * st + ks) * 16 + cc], acc0);
+                acc1 = GSMVI_MFMA_F64(am[st + 1], Vs[(4 * st + 4 + ks) * 16 + cc], acc1);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) As[(16 * w + ks + 4 * r) * 16 + cc] = pv[r] + (acc0[r] + acc1[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) As[(16 * w + ks + 4 * r) * 16 + cc] = 0.0;
+    }
+    __syncthreads();
+    if (w < nb) {
+        v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int st = 0; st < 32; st += 2) {
+            if (st < 4 * (w + 1)) {                          // wave-uniform: k-blocks 0 .. w
+                acc0 = GSMVI_MFMA_F64(aw[st], As[(4 * st + ks) * 16 + cc], acc0);
+                acc1 = GSMVI_MFMA_F64(aw[st + 1], As[(4 * st + 4 + ks) * 16 + cc], acc1);
+            }
+        }
+        double pz = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * w + ks + 4 * r;
+            const double z = acc0[r] + acc1[r];
+            if (row < n) {
+                pz += z * szg[row];
+                if (colin) {
+                    Ft[(size_t)(n + row) * D + j0 + cc] = z;
+                    Fs[(size_t)(n + row) * D + j0 + cc] = -z;
+                }
+            }
+        }
+        redz[(w * 4 + ks) * 16 + cc] = pz;
+    } else {
+        redz[(w * 4 + ks) * 16 + cc] = 0.0;
+    }
+    __syncthreads();
+    if (tid < 16 && (j0 + tid) < D) {
+        double dz = 0.0;
+        for (int q = 0; q < 32; ++q) dz += redz[q * 16 + tid];
+        double d0 = 0.0, d1 = 0.0;
+        int k = 0;
+        for (; k + 1 < n; k += 2) {
+            d0 += Vs[k * 16 + tid] * svg[k];
+            d1 += Vs[(k + 1) * 16 + tid] * svg[k + 1];
+        }
+        if (k < n) d0 += Vs[k * 16 + tid] * svg[k];
+        const int j = j0 + tid;
+        const double r1 = reg / (1.0 + reg);
+        const double s0g = P[(size_t)(n - 1) * D + j] / sqrt(r1);          // (S0 gbar)_j = P[n-1][j]/sqrt(r1)
+        mu[j] = mu0[j] / (1.0 + reg) + r1 * (s0g + (d0 + d1) - dz + xbar[j]);
+    }
+}
+
 // ---- symmetric low-rank update  S = S0 + Ft^T Fs + jitter I   (Ft, Fs: KF x D row-major) --------
 // Ft^T Fs must be symmetric (Fs = K Ft with K symmetric).  One workgroup per 64x64 tile PAIR (I <= J)
 // of the upper triangle: W = S0[I,J] + Ft[:,I]^T Fs[:,J] (4 waves of 32x32, fp64 MFMA, factor rows
@@ -542,7 +662,7 @@ __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, cons
 
 int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* Nd, const double* M1,
                            const double* N0, double* scratch, double* Ld, double* Upk, int* info_dev, int* hint_host,
-                           int force_kenq);
+                           int force_kenq, double* Wscr);
 int gsmvi_bam_small_nmax();
 size_t gsmvi_bam_small_scratch_doubles(int n);
 int gsmvi_panel_t_product(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* A, int lda, const double* M,
@@ -584,6 +704,9 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     double* M1T = Nd + (size_t)n * n;              // n x n
     double* Upk = M1T + (size_t)n * n;             // n(n+1)/2: packed rows of L^T
     const double* Ldinv = Ld + (size_t)n * n;
+    // 48 < n <= 128 (round 4): Cholesky with the inverse factor + product-form Z (k_bam_cholw, k_bam_zw); "bam_subst" = 1 keeps
+    // the round-3 route (k_bam_chol_out + forward substitution) for A/B runs
+    const bool use_w = n > gsmvi_bam_small_fused_nmax() && n <= 128 && !ctx->tune_bam_subst;
     if (n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full) {
         // n <= 48: slab sum, N, the matrix function, its Cholesky factor and the small outputs in ONE one-workgroup launch
         if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, n, (size_t)n2 * n, M1, Ld, Upk,
@@ -602,11 +725,16 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
                 ctx->bam_hint_host = nullptr;
         }
         if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, Upk, info_dev ? info_dev : ctx->ints + 8,
-                                         ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq)))
+                                         ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq,
+                                         use_w ? M1T : nullptr)))
             return rc;
     }
     const bool lanes16 = n <= 129;              // the sizes whose Cholesky kernel (k_bam_chol_out) also emits the packed rows
-    if (lanes16 && n <= 64) {
+    if (use_w) {
+        // Z = W (P + M1^T Vf) by two chained MFMA products per 16 columns of D, the mean with it (W = L^-1 sits in Ld's slot)
+        hipLaunchKernelGGL(k_bam_zw, dim3((D + 15) / 16), dim3(512), 0, st, D, n, P, M1, Ld, Ldinv + n, Ldinv + 2 * n, mu0, xbar,
+                           reg, Ft, Fs, mu);
+    } else if (lanes16 && n <= 64) {
         // the 16-lanes-per-column substitution with T1 = M1^T Vf formed inside
         hipLaunchKernelGGL(k_bam_forward16<true>, dim3((D + 15) / 16), dim3(256), 0, st, D, n, P, M1, Upk, Ldinv, Ldinv + n,
                            Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu);
@@ -710,7 +838,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
                 ctx->bam_hint_host = nullptr;
         }
         if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, Upk, info_bam,
-                                         ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq)))
+                                         ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq, nullptr)))
             return rc;
     }
     // Zw = L^-1 (Wq + M1^T Vw) by the 16-lanes-per-column substitution (M1^T Vw formed inside); its mean output

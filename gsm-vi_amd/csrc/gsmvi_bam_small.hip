@@ -23,6 +23,7 @@
 #include "gsmvi_ctx.h"
 #include "gsmvi_chol64.h"
 #include "gsmvi_chol64b.h"
+#include "gsmvi_chol128.h"
 #include "../../include/gsmvi_hip.h"
 
 #define BAMS_NMAX 129                // largest n of the one-workgroup Cholesky k_bam_chol_out; above it: blocked potrf + k_bam_post_big
@@ -146,6 +147,95 @@ __global__ __launch_bounds__(256) void k_bam_ns_step(int n, int ld, int k, doubl
     const int nb = (n + 15) >> 4, nk = (n + 3) >> 2;
     if ((int)blockIdx.x < nb * nb) bams_block<1>(Yi, Mm, Yo, blockIdx.x, nb, nk, c2, c, ld);         // Y' = c Y T
     else bams_block<2>(Mm, Zi, Zo, blockIdx.x - nb * nb, nb, nk, c2, c, ld);                        // Z' = c T Z
+}
+
+// ---- ONE launch per step (round 4): M = Z Y is not handed over through memory, every workgroup forms the 16-wide panel of it
+// that its own output block needs --------------------------------------------------------------------------------------------
+// Two launches per step were launch-bound (2 x 4.7 us for 12.6 MFLOP at n = 128: 26 launches, 123 us of a 329 us update).
+// Here workgroup blk < nb^2 owns block (i, j) of Y' = c Y T and needs the COLUMN panel T(:, j) = 1.5 I - 0.5 c^2 (Z Y)(:, j);
+// workgroup nb^2 + blk owns block (i, j) of Z' = c T Z and needs the ROW panel T(i, :).  Eight waves: wave w forms the 16 x 16
+// block w of the panel (K = n: all 64 operand values of the lane loaded up front, two accumulator chains) -- an n / 16-fold
+// recomputation of M over the grid (0.52 MFLOP per workgroup, ~3 us on one CU's matrix pipes), cheaper than a second launch.
+// The panel goes to LDS as T; the own block's K = n product is split over the eight waves and summed through LDS in a fixed
+// order.  Every block of every product is computed exactly as it stands (same operands, same order in every workgroup that
+// needs it), so the iterates are deterministic and the two copies of a panel block in different workgroups are bit-identical.
+// Loads are issued before the step-count test (coef[40]): the launches beyond k* cost their launch, not a second round trip.
+__global__ __launch_bounds__(512) void k_bam_ns_fused(int n, int ld, int k, double* __restrict__ Ya, double* __restrict__ Za,
+                                                      double* __restrict__ Yb, double* __restrict__ Zb,
+                                                      const double* __restrict__ coef) {
+    __shared__ __attribute__((aligned(16))) double Ts[128 * 17];          // column panel: [k][16] (stride 16); row panel: [16][k]
+    __shared__ double red[8 * 256];
+    const int nb = (n + 15) >> 4;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
+    const bool isZ = (int)blockIdx.x >= nb * nb;
+    const int blk = isZ ? blockIdx.x - nb * nb : blockIdx.x;
+    const int bi = blk / nb, bj = blk - bi * nb, i0 = 16 * bi, j0 = 16 * bj;
+    const double* Y = (k & 1) ? Yb : Ya;
+    const double* Z = (k & 1) ? Zb : Za;
+    double* Yo = (k & 1) ? Ya : Yb;
+    double* Zo = (k & 1) ? Za : Zb;
+    const double kst = coef[40], fl = coef[42], c2 = coef[k];
+    // panel block w: Y' needs M(16w.., j0..) = Z(16w.., :) Y(:, j0..); Z' needs M(i0.., 16w..) = Z(i0.., :) Y(:, 16w..)
+    const int pr0 = isZ ? i0 : 16 * w, pc0 = isZ ? 16 * w : j0;
+    double a[32], b[32];
+    if (w < nb) {
+#pragma unroll
+        for (int st = 0; st < 32; ++st) {
+            const int kk = 4 * st + ks, kc = kk < ld ? kk : ld - 1;
+            a[st] = Z[(size_t)(pr0 + cc) * ld + kc];
+            b[st] = Y[(size_t)kc * ld + pc0 + cc];
+        }
+    }
+    // the own block's operand that does not depend on T: Y(i0.., k) for Y' (A-operand), Z(k, j0..) for Z' (B-operand); wave w takes
+    // the k-steps st = w, w + 8, ... (K = n <= 128: at most four)
+    double o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int kk = 4 * (w + 8 * u) + ks, kc = kk < ld ? kk : ld - 1;
+        o[u] = isZ ? Z[(size_t)kc * ld + j0 + cc] : Y[(size_t)(i0 + cc) * ld + kc];
+    }
+    asm volatile("" ::: "memory");                           // the operand loads above may not sink below the test that follows
+    if ((double)k >= kst || fl != 0.0) return;
+    const double c = sqrt(c2);
+    const int nk = (n + 3) >> 2;
+    if (w < nb) {
+        v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int st = 0; st < 32; st += 2) {
+            if (st < nk) {                                   // block-uniform
+                acc0 = GSMVI_MFMA_F64(a[st], b[st], acc0);
+                acc1 = GSMVI_MFMA_F64(a[st + 1], b[st + 1], acc1);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pr = pr0 + ks + 4 * r, pc = pc0 + cc;   // element (pr, pc) of M
+            const double t = (pr == pc ? 1.5 : 0.0) - 0.5 * c2 * (acc0[r] + acc1[r]);
+            if (isZ) Ts[(ks + 4 * r) * 129 + pc] = t;          // row panel  T(i0 + row, col):  [16][129]
+            else Ts[pr * 16 + cc] = t;                        // column panel T(row, j0 + col): [n][16]
+        }
+    }
+    __syncthreads();
+    {   // own block: Y'(i0.., j0..) = c sum_k Y(i0.., k) T(k, j0..)   |   Z'(i0.., j0..) = c sum_k T(i0.., k) Z(k, j0..)
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int st = w + 8 * u, kk = 4 * st + ks;
+            if (st < nk) {                                   // wave-uniform
+                const double tv = isZ ? Ts[cc * 129 + kk] : Ts[kk * 16 + cc];
+                acc = isZ ? GSMVI_MFMA_F64(tv, o[u], acc) : GSMVI_MFMA_F64(o[u], tv, acc);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w * 256 + (ks + 4 * r) * 16 + cc] = acc[r];
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const int t = tid;                                   // element (t >> 4, t & 15) of the block
+        const double v = ((red[t] + red[256 + t]) + (red[512 + t] + red[768 + t])) +
+                         ((red[1024 + t] + red[1280 + t]) + (red[1536 + t] + red[1792 + t]));
+        (isZ ? Zo : Yo)[(size_t)(i0 + (t >> 4)) * ld + j0 + (t & 15)] = c * v;
+    }
 }
 
 // ---- n <= 48: the whole iteration in ONE workgroup, matrices in LDS, exactly k* steps --------------------------------
@@ -473,6 +563,129 @@ __global__ __launch_bounds__(512) void k_bam_chol_out(int n, double reg, const d
         if (tid < n) zg[tid] = a0;
         if (tid + 64 < nlead) zg[tid + 64] = a1;
         if (tid == 0 && n > 128) zg[128] = a2 / rho_s;
+    }
+}
+
+// ---- BB, its Cholesky factor WITH the inverse factor W = L^-1, and the small outputs: ONE workgroup, n <= 128 (round 4) --------
+// Replaces k_bam_ns_bb + k_bam_chol_out + the forward substitution's dependence on the packed factor: BB = N + I/2 +
+// sqrt(s) sym(Y_final) is formed here (one launch less), factored as [BB | I] -> [R | W] on chol64_blk (n <= 64: one call;
+// 64 < n <= 128: chol128w_body, the 2 x 2 block scheme of the factor path's Gram matrix, 47 us against 73 us for the
+// barrier-per-pivot k_bam_chol_out it replaces), and what bam.py:110 calls solve(BB, .) becomes Z = W (P + M1^T Vf), an MFMA
+// product in k_bam_zw (gsmvi_bam.hip) instead of a 128-step substitution per column of D (33 us at D = 1024).  W = L^-1 with
+// cond(L) = sqrt(cond(BB)) <= ~1e4 on BASELINE config 4: the explicit triangular inverse changes Z by 1e-12 relative and the
+// update's backward error from 1.3e-17 to 3e-17 (numpy check beside the substitution; K8 asserts 1e-14).
+// Outputs: Wg (n x n, lower, zeros above the diagonal), then behind it [n unused], zg = W a (n), vg (n); Rg (n x n scratch, the
+// upper factor, not consumed); *info != 0 poisons Wg, zg, vg with NaN (nothing stale may be applied).
+template <bool BIG>   // BIG: 64 < n <= 128 (two block rows), else n <= 64 (the discarded branch's LDS arrays are not instantiated)
+__global__ __launch_bounds__(512) void k_bam_cholw(int n, int ld, double reg, const double* __restrict__ Nm,
+                                                   const double* __restrict__ Ya, const double* __restrict__ Yb,
+                                                   const double* __restrict__ coef, const double* __restrict__ M1,
+                                                   const double* __restrict__ N0, double* BBg, double* Rg, double* Wg,
+                                                   int* __restrict__ info) {
+    __shared__ double sc[128], av[128], part[4 * 128];
+    __shared__ int sh_bad, sh_info;
+    const int tid = threadIdx.x;
+    const int kstar = (int)coef[40];
+    const double* Y = (kstar & 1) ? Yb : Ya;                 // iterate k* lives in buffer k* & 1
+    const double rs = sqrt(coef[41]);
+    const bool ns_failed = coef[42] != 0.0;
+    if (tid == 0) { sh_bad = 0; sh_info = 0; }
+    __syncthreads();
+    int nan_in = ns_failed ? 1 : 0;
+    for (int e0 = 0; e0 < n * n; e0 += 512 * 8) {            // BB: eight elements (24 loads) in flight per thread
+        double a[8], y1[8], y2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 512 * u + tid, ec = e < n * n ? e : n * n - 1, i = ec / n, j = ec - i * n;
+            a[u] = Nm[ec];
+            y1[u] = Y[(size_t)i * ld + j];
+            y2[u] = Y[(size_t)j * ld + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 512 * u + tid;
+            if (e < n * n) {
+                const int i = e / n, j = e - i * n;
+                const double x = a[u] + (i == j ? 0.5 : 0.0) + rs * (0.5 * (y1[u] + y2[u]));
+                if (!(x == x)) nan_in = 1;
+                BBg[e] = x;
+            }
+        }
+    }
+    if (nan_in) sh_bad = 1;
+    const double r1s = sqrt(reg / (1.0 + reg));
+    if (tid < 128) sc[tid] = (tid < n) ? M1[(size_t)tid * n + (n - 1)] / r1s : 0.0;    // vg = Vf gbar = M1[:, n-1] / r1s
+    __syncthreads();                                         // (also: the BB stores are complete before chol128w_body loads them)
+    {   // a = P gbar + M1^T vg (bam.py:107 applied to gbar): four threads per entry, 32 loads each in flight
+        const int p = tid & 127, q = tid >> 7, pc = p < n ? p : n - 1;
+        double m[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int k = q + 4 * u;
+            m[u] = M1[(size_t)(k < n ? k : n - 1) * n + pc];
+        }
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < 32; u += 2) {
+            a0 += (q + 4 * u < n) ? m[u] * sc[q + 4 * u] : 0.0;
+            a1 += (q + 4 * u + 4 < n) ? m[u + 1] * sc[q + 4 * u + 4] : 0.0;
+        }
+        part[q * 128 + p] = a0 + a1;
+    }
+    __syncthreads();
+    if (tid < 128)
+        av[tid] = (tid < n) ? N0[(size_t)tid * n + (n - 1)] / r1s + ((part[tid] + part[128 + tid]) + (part[256 + tid] + part[384 + tid])) : 0.0;
+    if constexpr (BIG) {
+        chol128w_body<false>(n, BBg, Rg, Wg, info, &sh_info);
+    } else {
+        constexpr int ES = 146;
+        __shared__ __attribute__((aligned(16))) double E[64 * ES];
+        __shared__ __attribute__((aligned(16))) double scr1[CHOLB_SCRATCH_DOUBLES(1)];
+        __shared__ int sf;
+        for (int e = tid; e < 64 * 64; e += 512) {
+            const int i = e >> 6, j = e & 63;
+            const bool in = i < n && j < n;
+            E[i * ES + j] = in ? (j >= i ? BBg[(size_t)i * n + j] : 0.0) : (i == j ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        chol64_blk<ES, false, 1>(E, scr1, n, &sf);
+        for (int e = tid; e < n * n; e += 512) {
+            const int i = e / n, j = e - i * n;
+            Wg[e] = (j <= i) ? E[i * ES + 64 + j] : 0.0;
+            Rg[e] = (j >= i) ? E[i * ES + j] : 0.0;
+        }
+        if (tid == 0) { *info = sf; sh_info = sf; }
+    }
+    __syncthreads();                                         // W is in global memory, written by this workgroup
+    double* zg = Wg + (size_t)n * n + n;
+    double* vg = zg + n;
+    const int bad = sh_bad || sh_info != 0;
+    if (tid == 0) *info = bad;
+    if (bad) {
+        const double qn = __longlong_as_double(0x7ff8000000000000LL);
+        for (size_t e = tid; e < (size_t)n * n + 3 * n; e += 512) Wg[e] = qn;
+        return;
+    }
+    {   // zg = W a (bam.py:110 applied to gbar): four threads per row, the row's quarter in flight at once
+        const int i = tid & 127, q = tid >> 7, ic = i < n ? i : n - 1;
+        double wv[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int k = 32 * q + u;
+            wv[u] = Wg[(size_t)ic * n + (k < n ? k : n - 1)];
+        }
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < 32; u += 2) {
+            a0 += (32 * q + u < n) ? wv[u] * av[32 * q + u] : 0.0;
+            a1 += (32 * q + u + 1 < n) ? wv[u + 1] * av[32 * q + u + 1] : 0.0;
+        }
+        part[q * 128 + i] = a0 + a1;
+    }
+    __syncthreads();
+    if (tid < n) {
+        zg[tid] = (part[tid] + part[128 + tid]) + (part[256 + tid] + part[384 + tid]);
+        vg[tid] = sc[tid];
     }
 }
 
@@ -855,9 +1068,11 @@ int gsmvi_bam_small_fused(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, con
 int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                      int* info_dev);
 
+// Wscr != nullptr (48 < n <= 128 only): the round-4 route -- k_bam_cholw forms BB itself and leaves W = L^-1 (n x n) in Ld's
+// slot, zg / vg behind it as before, the upper factor in Wscr (scratch); Upk is not produced (k_bam_zw consumes W).
 int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* Nd, const double* M1,
                            const double* N0, double* scratch, double* Ld, double* Upk, int* info_dev, int* hint_host,
-                           int force_kenq) {
+                           int force_kenq, double* Wscr) {
     const int ld = n <= BAMS_NMAX ? BAMS_LD : ((n + 15) / 16) * 16;
     const size_t LL = (size_t)ld * ld;
     double* Ya = scratch;
@@ -881,15 +1096,27 @@ int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, co
         if (force_kenq > 0 && force_kenq < BAMS_KMAX) kenq = force_kenq;       // tests: exercise the safety net
         hipLaunchKernelGGL(k_bam_ns_prep, dim3(27), dim3(256), 0, st, n, ld, Nd, Ya, Za, coef, hint_host);
         const int nb = (n + 15) / 16;
+        const bool fused = n <= 128 && !ctx->tune_bam_ns2;    // one launch per step (k_bam_ns_fused); "bam_ns2" = 1: the two-launch steps
+        if (fused && hint_host && force_kenq <= 0 && kenq < BAMS_KMAX && kenq > 3) --kenq;   // k* + 1: a launch beyond k* costs ~3 us
         for (int k = 0; k < kenq; ++k) {
-            hipLaunchKernelGGL(k_bam_ns_zy, dim3(nb * nb), dim3(256), 0, st, n, ld, k, Ya, Za, Yb, Zb, Mm, coef);
-            hipLaunchKernelGGL(k_bam_ns_step, dim3(2 * nb * nb), dim3(256), 0, st, n, ld, k, Ya, Za, Yb, Zb, Mm, coef);
+            if (fused) {
+                hipLaunchKernelGGL(k_bam_ns_fused, dim3(2 * nb * nb), dim3(512), 0, st, n, ld, k, Ya, Za, Yb, Zb, coef);
+            } else {
+                hipLaunchKernelGGL(k_bam_ns_zy, dim3(nb * nb), dim3(256), 0, st, n, ld, k, Ya, Za, Yb, Zb, Mm, coef);
+                hipLaunchKernelGGL(k_bam_ns_step, dim3(2 * nb * nb), dim3(256), 0, st, n, ld, k, Ya, Za, Yb, Zb, Mm, coef);
+            }
         }
         if (kenq < BAMS_KMAX)
             hipLaunchKernelGGL(k_bam_ns_tail, dim3(1), dim3(1024), 0, st, n, ld, kenq, Ya, Za, Yb, Zb, Mm, coef);
-        hipLaunchKernelGGL(k_bam_ns_bb, dim3((n * n + 255) / 256), dim3(256), 0, st, n, ld, Nd, Ya, Yb, coef, BBg);
+        if (!(Wscr && n <= 128))
+            hipLaunchKernelGGL(k_bam_ns_bb, dim3((n * n + 255) / 256), dim3(256), 0, st, n, ld, Nd, Ya, Yb, coef, BBg);
     }
-    if (n <= BAMS_NMAX) {
+    if (Wscr && n > BAMS_SN && n <= 128) {
+        if (n > 64)
+            hipLaunchKernelGGL(k_bam_cholw<true>, dim3(1), dim3(512), 0, st, n, ld, reg, Nd, Ya, Yb, coef, M1, N0, BBg, Wscr, Ld, info_dev);
+        else
+            hipLaunchKernelGGL(k_bam_cholw<false>, dim3(1), dim3(512), 0, st, n, ld, reg, Nd, Ya, Yb, coef, M1, N0, BBg, Wscr, Ld, info_dev);
+    } else if (n <= BAMS_NMAX) {
         hipLaunchKernelGGL(k_bam_chol_out, dim3(1), dim3(512), 0, st, n, reg, BBg, M1, N0, Ld, Upk, info_dev);
     } else {
         // beyond the one-workgroup Cholesky: the blocked multi-workgroup factorisation of the D x D path (its workspace is

@@ -1,0 +1,227 @@
+// The one-workgroup 128 x 128 Cholesky WITH the inverse factor (64 < n <= 128), shared by the factor path's 2B x 2B chain
+// (k_chol128w, gsmvi_factor.hip) and the dense BaM chain (k_bam_cholw, gsmvi_bam_small.hip).  512 threads.
+#pragma once
+#include "gsmvi_common.h"
+#include "gsmvi_chol64.h"
+#include "gsmvi_chol64b.h"
+
+// ---- the same factorisation WITH the inverse factor: A = R^T R and W = R^-T (lower triangular), 64 < n <= 128 -------------
+// The Gram matrix of the factor path needs W = Rg^-T as an explicit matrix (K'' = (W S)^T (T - I)(W S)).  Round 2 got it from a
+// 128-step substitution in a launch of its own (k_gsmf_kmat_big: 25 us).  Here both diagonal blocks are factored as
+// [A_kk | I] -> [R_kk | W_kk] (chol64_blk, AUG = 1: +1.8 us each over the plain factorisation) and the off-diagonal blocks are
+// MFMA products of things already in LDS:
+//   R12 = D' W11 A12           (the row operations that turned I into W11, applied to A12; D' zeroes the rows the
+//                               rank-revealing rule dropped, which is what the riding columns of AUG = 2 would hold)
+//   A22' = A22 - R12^T R12,    [A22' | I] -> [R22 | W22]
+//   W21 = -(W22 R12^T) W11     (block inverse of a triangular matrix)
+// One workgroup, E1 [64][146] is used for both factorisations (R11, W11 go to global memory in between; W11 is read back
+// for the last product), B12 [64][66] holds R12, then W11.  Same dropped-row convention as k_gsmf_kmat_big's unit pivots.
+// (A device function since round 4: k_chol128w of the factor path and k_bam_cholw of the dense BaM chain share it.  A, R, Wo
+// must not alias; A is read until the second factorisation starts.  sh_info: optional LDS word that receives the same value as
+// *info -- valid for the whole workgroup after the caller's next barrier.)
+template <bool SEMIDEF>
+__device__ __forceinline__ void chol128w_body(int n, const double* __restrict__ A, double* __restrict__ R,
+                                              double* __restrict__ Wo, int* __restrict__ info, int* sh_info = nullptr) {
+    constexpr int ES1 = 146, BS = 66;
+    __shared__ __attribute__((aligned(16))) double E1[64 * ES1];
+    __shared__ __attribute__((aligned(16))) double B12[64 * BS];
+    __shared__ __attribute__((aligned(16))) double scr[CHOLB_SCRATCH_DOUBLES(1)];
+    __shared__ int sh_fail[2], sh_moderate;
+    const int tid = threadIdx.x, n2 = n - 64;
+    const int w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+    if (tid == 0) sh_moderate = 1;
+    __syncthreads();
+    {   // A11 (upper triangle) -> E1 left half; the magnitude guard looks at BOTH diagonal blocks, as k_chol128 does
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 512 * u, i = e >> 6, q = e & 63;
+            v[u] = A[(size_t)i * n + q];
+        }
+        const double d2 = (tid < n2) ? A[(size_t)(64 + tid) * n + 64 + tid] : 0.0;
+        if (SEMIDEF && !(d2 < 4294967296.0)) sh_moderate = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 512 * u, i = e >> 6, q = e & 63;
+            double x = (q < i) ? 0.0 : v[u];
+            if (SEMIDEF && q == i) {
+                if (!(x < 4294967296.0)) sh_moderate = 0;
+                x -= GSMVI_DEP_TOL * x;
+            }
+            E1[i * ES1 + q] = x;
+        }
+    }
+    __syncthreads();
+    const bool moderate = sh_moderate != 0;
+    chol64_blk<ES1, SEMIDEF, 1>(E1, scr, 64, &sh_fail[0], moderate);   // [A11 | I] -> [R11 | W11]
+    // R12 = D' W11 A12: block (ib, jb), k-blocks 0 .. ib (W11 is lower triangular); A12 straight from global memory
+    for (int blk = w; blk < 16; blk += 8) {
+        const int ib = blk >> 2, jb = blk & 3;
+        const int gj = 64 + 16 * jb + c;
+        double a[16], b[16];
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const int k = 4 * st + ks;
+            a[st] = E1[(16 * ib + c) * ES1 + 64 + k];
+            b[st] = A[(size_t)k * n + (gj < n ? gj : n - 1)];
+        }
+        v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int st = 0; st < 16; st += 2) {
+            if (st < 4 * (ib + 1)) {                                   // wave-uniform
+                acc0 = GSMVI_MFMA_F64(a[st], gj < n ? b[st] : 0.0, acc0);
+                acc1 = GSMVI_MFMA_F64(a[st + 1], gj < n ? b[st + 1] : 0.0, acc1);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * ib + ks + 4 * r, j = 16 * jb + c;
+            double x = acc0[r] + acc1[r];
+            if (E1[i * ES1 + i] == 0.0) x = 0.0;                        // a dropped row of R
+            B12[i * BS + j] = x;
+            if (64 + j < n) R[(size_t)i * n + 64 + j] = x;
+        }
+    }
+    __syncthreads();
+    // R11, W11 out (and the two zero blocks); meanwhile the updated A22 in registers: upper 16 x 16 blocks, K = 64
+    for (int e = tid; e < 64 * 64; e += 512) {
+        const int i = e >> 6, j = e & 63;
+        R[(size_t)i * n + j] = (j >= i) ? E1[i * ES1 + j] : 0.0;
+        Wo[(size_t)i * n + j] = (j <= i) ? E1[i * ES1 + 64 + j] : 0.0;
+        if (64 + j < n) Wo[(size_t)i * n + 64 + j] = 0.0;               // W12 = 0
+        if (i < n2) R[(size_t)(64 + i) * n + j] = 0.0;                  // R21 = 0
+    }
+    double t22[2][4];
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+        const int blk = w + 8 * slot;
+        if (blk < 10) {
+            int bi = 0, rem = blk;
+            while (rem >= 4 - bi) { rem -= 4 - bi; ++bi; }
+            const int bj = bi + rem;
+            double a[16], b[16];
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                a[st] = B12[(4 * st + ks) * BS + 16 * bi + c];
+                b[st] = B12[(4 * st + ks) * BS + 16 * bj + c];
+            }
+            v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int st = 0; st < 16; st += 2) {
+                acc0 = GSMVI_MFMA_F64(a[st], b[st], acc0);
+                acc1 = GSMVI_MFMA_F64(a[st + 1], b[st + 1], acc1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * bi + ks + 4 * r, j = 16 * bj + c;
+                double x = (i == j) ? 1.0 : 0.0;                        // identity beyond n2
+                if (i < n2 && j < n2) {
+                    x = A[(size_t)(64 + i) * n + 64 + j];
+                    if (SEMIDEF && i == j) x -= GSMVI_DEP_TOL * x;
+                    x -= acc0[r] + acc1[r];
+                }
+                t22[slot][r] = (j >= i) ? x : 0.0;
+            }
+        }
+    }
+    __syncthreads();                                                    // every read of R11 / W11 in E1 is done
+    for (int e = tid; e < 64 * 64; e += 512) {                          // blocks below the block diagonal: zero
+        const int i = e >> 6, j = e & 63;
+        if ((j >> 4) < (i >> 4)) E1[i * ES1 + j] = 0.0;
+    }
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+        const int blk = w + 8 * slot;
+        if (blk < 10) {
+            int bi = 0, rem = blk;
+            while (rem >= 4 - bi) { rem -= 4 - bi; ++bi; }
+            const int bj = bi + rem;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) E1[(16 * bi + ks + 4 * r) * ES1 + 16 * bj + c] = t22[slot][r];
+        }
+    }
+    __syncthreads();
+    chol64_blk<ES1, SEMIDEF, 1>(E1, scr, n2, &sh_fail[1], moderate);   // [A22' | I] -> [R22 | W22]
+    for (int e = tid; e < 64 * 64; e += 512) {
+        const int i = e >> 6, j = e & 63;
+        if (i < n2 && j < n2) {
+            R[(size_t)(64 + i) * n + 64 + j] = (j >= i) ? E1[i * ES1 + j] : 0.0;
+            Wo[(size_t)(64 + i) * n + 64 + j] = (j <= i) ? E1[i * ES1 + 64 + j] : 0.0;
+        }
+    }
+    __syncthreads();                                                    // R22 (E1 left half) is out: the half becomes T1
+    // T1 = W22 R12^T: (i in block 2, j in block 1), k over block 2; W22[i][k] = 0 for k > i
+    {
+        double t1[2][4];
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot) {
+            const int blk = w + 8 * slot, ib = blk >> 2, jb = blk & 3;
+            double a[16], b[16];
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                const int k = 4 * st + ks;
+                a[st] = E1[(16 * ib + c) * ES1 + 64 + k];
+                b[st] = B12[(16 * jb + c) * BS + k];
+            }
+            v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int st = 0; st < 16; st += 2) {
+                if (st < 4 * (ib + 1)) {
+                    acc0 = GSMVI_MFMA_F64(a[st], b[st], acc0);
+                    acc1 = GSMVI_MFMA_F64(a[st + 1], b[st + 1], acc1);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t1[slot][r] = acc0[r] + acc1[r];
+        }
+        __syncthreads();                                                // all reads of B12 (R12) and of E1's left half are done
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot) {
+            const int blk = w + 8 * slot, ib = blk >> 2, jb = blk & 3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) E1[(16 * ib + ks + 4 * r) * ES1 + 16 * jb + c] = t1[slot][r];
+        }
+        // W11 back from global memory (written by this workgroup before two barriers) into B12
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 512 * u, i = e >> 6, j = e & 63;
+            v[u] = __builtin_nontemporal_load(Wo + (size_t)i * n + j);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = tid + 512 * u, i = e >> 6, j = e & 63;
+            B12[i * BS + j] = v[u];
+        }
+    }
+    __syncthreads();
+    // W21 = -T1 W11: (i in block 2, j in block 1), k over block 1; W11[k][j] = 0 for k < j
+    for (int blk = w; blk < 16; blk += 8) {
+        const int ib = blk >> 2, jb = blk & 3;
+        double a[16], b[16];
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const int k = 4 * st + ks;
+            a[st] = E1[(16 * ib + c) * ES1 + k];
+            b[st] = B12[k * BS + 16 * jb + c];
+        }
+        v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int st = 0; st < 16; st += 2) {
+            if (st >= 4 * jb) {                                         // wave-uniform
+                acc0 = GSMVI_MFMA_F64(a[st], b[st], acc0);
+                acc1 = GSMVI_MFMA_F64(a[st + 1], b[st + 1], acc1);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * ib + ks + 4 * r, j = 16 * jb + c;
+            if (i < n2) Wo[(size_t)(64 + i) * n + j] = -(acc0[r] + acc1[r]);
+        }
+    }
+    if (tid == 0) {
+        const int f = sh_fail[0] != 0 ? sh_fail[0] : (sh_fail[1] != 0 ? 64 + sh_fail[1] : 0);
+        *info = f;
+        if (sh_info) *sh_info = f;
+    }
+}

@@ -301,6 +301,8 @@ class GSM:
             except (TypeError, ValueError):
                 takes_out = False
         gstate = {"graph": None}
+        self.graph_replays = 0                                  # blocks replayed from the captured graph (tests / diagnostics)
+        self.graph_fallback = None                              # the exception that sent a graph fit back to eager launches
         if use_graph:
             ctr = [torch.zeros(1, dtype=torch.int64, device=Zblk.device) for _ in range(2)]
         state_bufs = [(mean_t, F), (mean_new, F_new)]
@@ -349,12 +351,17 @@ class GSM:
                 ctr[0].fill_(i)                                 # (stream-ordered; the graph reads it on the device)
                 try:
                     graph_block()
-                except Exception:                               # capture unsupported here: stay eager for the rest of the fit
+                except Exception as exc:                        # capture unsupported here: stay eager for the rest of the fit
                     if gstate["graph"] is not None:
                         raise
+                    import warnings
+                    warnings.warn(f"GSM.fit: hipGraph capture of an iteration block failed ({type(exc).__name__}: {exc}); "
+                                  "the fit continues with eager launches (same numbers, more launch overhead)", RuntimeWarning)
+                    self.graph_fallback = exc
                     use_graph = False
                     torch.cuda.synchronize()
                     continue
+                self.graph_replays += 1
                 nevals += B * KB
                 i = blk_end
                 continue

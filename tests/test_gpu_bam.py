@@ -340,3 +340,55 @@ def test_factor_form_fit_converges_on_a_gaussian_target():
     mean, cov = bam.fit(3, reg.custom(lambda i: 200.0 / i), batch_size=B, niter=400, verbose=False, method="factor")
     assert bam.n_reverts == 0
     assert rel_err(mean, m) < 1e-3 and rel_err(cov, cov_t) < 1e-2
+
+
+@pytest.mark.parametrize("D,B,reg", [(1024, 128, 1.0), (1024, 96, 10.0), (512, 100, 0.5), (200, 64, 2.0), (256, 63, 10.0),
+                                     (130, 49, 1.0), (1024, 127, 100.0 / 3)])
+def test_round4_chain_equals_the_round3_chain(D, B, reg):
+    """Round 4 changed the dense BaM chain for 48 < n <= 128: one launch per Newton-Schulz step (k_bam_ns_fused: every
+    workgroup forms the panel of M = Z Y it needs), BB formed inside the Cholesky kernel, Cholesky WITH the inverse factor
+    (k_bam_cholw, chol64_blk / chol128w_body) and Z = W (P + M1^T Vf) as chained MFMA products (k_bam_zw) instead of a
+    forward substitution.  The round-3 kernels stay selectable (knobs bam_ns2 / bam_subst): same (mu, S) to rounding --
+    the explicit triangular inverse costs ~1e-12 relative on Z (cond(L) <= ~1e4 here) -- and the defining equation
+    S U S + S = V holds to the same backward error either way."""
+    import gsmvi_amd
+    orc, borc = _o()
+    eng = gsmvi_amd.get_engine()
+    st = orc.make_update_state(D, B, seed=D + B)
+    X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
+    res = {}
+    try:
+        for tag, ns2, subst in (("r4", 0, 0), ("ns2", 1, 0), ("subst", 0, 1), ("r3", 1, 1)):
+            eng.set_tuning("bam_ns2", ns2)
+            eng.set_tuning("bam_subst", subst)
+            mu, S, f = eng.bam_update(X, G, mu0, S0, reg, 0.0)
+            assert eng.read_flag(f) == 0, tag
+            res[tag] = (mu.cpu().numpy(), S.cpu().numpy())
+    finally:
+        eng.set_tuning("bam_ns2", 0)
+        eng.set_tuning("bam_subst", 0)
+    U, V, xbar, gbar = _bam_uv(st["samples"], st["vs"], st["mu0"], st["S0"], reg)
+    for tag, (mu, S) in res.items():
+        assert np.array_equal(S, S.T), tag
+        assert _backward_error(S, U, V) < 1e-14, (tag, _backward_error(S, U, V))
+        assert rel_err(S, res["r3"][1]) < 1e-9 and rel_err(mu, res["r3"][0]) < 1e-9, (tag, rel_err(S, res["r3"][1]))
+    mu_o, S_o = borc.bam_lowrank_update_exact(st["samples"], st["vs"], st["mu0"], st["S0"], reg)
+    assert rel_err(res["r4"][1], 0.5 * (S_o + S_o.T)) < 1e-7 and rel_err(res["r4"][0], mu_o) < 1e-7
+    # run-to-run identity of the new launch structure (fixed summation orders, no atomics)
+    mu2, S2, _ = eng.bam_update(X, G, mu0, S0, reg, 0.0)
+    assert np.array_equal(S2.cpu().numpy(), res["r4"][1]) and np.array_equal(mu2.cpu().numpy(), res["r4"][0])
+
+
+def test_round4_chain_rejects_nan_and_indefinite_inputs():
+    """k_bam_cholw poisons its outputs when BB has a NaN or a failing pivot: the flag is set and nothing stale is applied."""
+    import gsmvi_amd
+    orc, _ = _o()
+    eng = gsmvi_amd.get_engine()
+    st = orc.make_update_state(256, 64, seed=5)
+    X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
+    Gn = G.clone()
+    Gn[3, 17] = float("nan")
+    mu, S, f = eng.bam_update(X, Gn, mu0, S0, 1.0, 0.0)
+    assert eng.read_flag(f) != 0
+    mu, S, f = eng.bam_update(X, G, mu0, S0, 1.0, 0.0)           # and the context is usable afterwards
+    assert eng.read_flag(f) == 0 and bool(S.isfinite().all())

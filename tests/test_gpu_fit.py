@@ -145,3 +145,64 @@ def test_example_scripts_run():
                            text=True, timeout=300)
         assert p.returncode == 0, p.stderr[-2000:]
         assert "differs" not in p.stdout and "mean ok" in p.stdout, p.stdout
+
+
+@pytest.mark.parametrize("D,B,niter", [(256, 8, 95), (1024, 32, 79)])
+def test_graph_replayed_fit_is_bit_identical_to_the_eager_fit(D, B, niter):
+    """GSM.fit(graph=True) replays blocks of 16 iterations as ONE hipGraph (device draw counter advancing per replay,
+    ping-pong state buffers, the fast kernels -- rider workgroup, forked panel product -- captured from inside fit).  It
+    claims 'same numbers either way': the same fit with graph=False must give bit-identical (mean, cov) and revert count.
+    A draw counter that did not advance between replays, or a ping-pong state off by one, would change every bit."""
+    import warnings
+    import torch
+    import gsmvi_amd
+    orc = _orc()
+    m, cov_t, P = orc.make_gaussian_target(D, 3)
+    tgt = gsmvi_amd.GaussianTarget(m, precision=P)
+    assert getattr(tgt.lp_g, "graph_safe", False)
+    res = {}
+    for graph in (False, True):
+        gsm = gsmvi_amd.GSM(D, tgt.lp, tgt.lp_g)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                       # a silent eager fallback would make this test vacuous
+            mean, cov = gsm.fit(7, niter=niter, batch_size=B, verbose=False, graph=graph, as_torch=True)
+        torch.cuda.synchronize()
+        res[graph] = (mean.clone(), cov.clone(), gsm.n_reverts, gsm.graph_replays, gsm.method_used)
+    assert res[True][4] == "factor" and res[False][4] == "factor"
+    assert res[False][3] == 0
+    # niter + 1 iterations: the first block runs eagerly, the full blocks after it are replayed
+    assert res[True][3] == (niter + 1) // 16 - 1 and res[True][3] >= 3, res[True][3]
+    assert torch.equal(res[True][0], res[False][0]), float((res[True][0] - res[False][0]).abs().max())
+    assert torch.equal(res[True][1], res[False][1]), float((res[True][1] - res[False][1]).abs().max())
+    assert res[True][2] == res[False][2]
+
+
+def test_replayed_draw_launch_advances_through_the_stream():
+    """gsmvi_randn_batch_f64 with its call index on the device (call_in / call_out): two replays of ONE captured launch
+    pair give the draws of calls i .. i+15 and i+16 .. i+31, bit-identical to single-call draws (gsm_numpy.py:105,116:
+    one stream per key, consumed in order)."""
+    import torch
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    B, D, KB, seed, i0 = 4, 96, 16, 1234, 48
+    Z = eng.empty(KB, B, D)
+    ctr = [torch.zeros(1, dtype=torch.int64, device=Z.device) for _ in range(2)]
+    eng.normal_batch(KB // 2, B, D, seed, 0, out=Z[:KB // 2], call_in=ctr[0], call_out=ctr[1])     # warm-up (eager)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for half in range(2):
+                eng.normal_batch(KB // 2, B, D, seed, 0, out=Z[half * (KB // 2):(half + 1) * (KB // 2)],
+                                 call_in=ctr[half], call_out=ctr[1 - half])
+    torch.cuda.current_stream().wait_stream(side)
+    ctr[0].fill_(i0)
+    for rep in range(2):
+        g.replay()
+        torch.cuda.synchronize()
+        for c in range(KB):
+            ref = eng.normal(B, D, seed, i0 + KB * rep + c)
+            assert torch.equal(Z[c], ref), (rep, c)
+        assert int(ctr[0].item()) == i0 + KB * (rep + 1)
