@@ -88,6 +88,9 @@ _SIGS = {
     "gsmvi_bam_factor_update_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int,
                                               _c_dp, C.c_int, _c_dp, _c_dp, C.c_int, C.c_double, _c_dp, _c_dp, C.c_int,
                                               _c_dp, _c_dp]),
+    "gsmvi_bam_factor_update_sharded_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int,
+                                                      _c_dp, C.c_int, _c_dp, C.c_int, _c_dp, _c_dp, C.c_int, C.c_double,
+                                                      _c_dp, _c_dp, _c_dp, C.c_int, _c_dp, _c_dp]),
 }
 
 

@@ -73,7 +73,8 @@ class BaM:
 
     def fit(self, key, regf, mean=None, cov=None, batch_size=2, niter=5000, nprint=10, verbose=True,
             check_goodness=True, monitor=None, retries=10, jitter=1e-6, *, sampler="cholesky", rng="auto",
-            as_torch=False, forced_samples=None, shard=False, group=None, check_update_flag=False, method="dense"):
+            as_torch=False, forced_samples=None, shard=False, group=None, check_update_flag=False, method="dense",
+            root_potrf=False):
         """gsmvi/bam.py:140-216.  Kept: niter+1 iterations (:178); nprint clamp (:177); reg = regf(i)
         per attempt (:196); jitter on the diagonal and symmetrisation (:198-199, done in-kernel);
         retry on any exception up to ``retries`` then re-raise (:189-206); Cholesky accept/revert of
@@ -93,7 +94,13 @@ class BaM:
         rejects them and the iteration is a revert (counted in ``n_reverts``), not a retry.
         ``check_update_flag=True`` restores the retry: the update's device flag is read every iteration (one host
         synchronisation) and a non-zero flag raises FloatingPointError into the retry loop.
-        ``method="factor"`` (needs 2*batch_size <= min(D, 128), sampler="cholesky", no forced samples, no sharding):
+        ``root_potrf`` (sharded dense fit only; default False): True lets rank 0 run the accept test's Cholesky and broadcast
+        the factor and its flag (dist.root_potrf) instead of every rank factoring its identical replica -- saves the
+        redundant D^3 work, costs a serial factorisation + an 8 D^2-byte broadcast per iteration; opt-in until measured on
+        more than one GPU (see GSM.fit).
+        ``method="factor"`` with ``shard=True``: the (x_b, g_b) rows are all-gathered as in the dense form and every replica
+        runs the identical factor-form update (dist.sharded_bam_factor_update); retries are collective in the same way.
+        ``method="factor"`` (needs 2*batch_size <= min(D, 128), sampler="cholesky", no forced samples):
         the state is (mean, F) with cov = F^T F; every iteration samples with F itself and applies the factor-form BaM
         update (engine.bam_factor_update) -- four passes over F, no D x D covariance, no D^3 Cholesky for the accept
         test (the update's own 2B x 2B positive-definiteness test decides accept/revert, counted in ``n_reverts``).
@@ -105,10 +112,10 @@ class BaM:
         assert method in ("dense", "factor"), "method must be 'dense' or 'factor'"
         self.method_used = method
         if method == "factor":
-            assert sampler == "cholesky" and forced_samples is None and not shard, \
-                "method='factor' samples with its own factor (sampler='cholesky', no forced samples, no sharding)"
+            assert sampler == "cholesky" and forced_samples is None, \
+                "method='factor' samples with its own factor (sampler='cholesky', no forced samples)"
             return self._fit_factor(eng, key, regf, mean, cov, B, niter, nprint, verbose, monitor, retries, rng, as_torch,
-                                    check_update_flag)
+                                    check_update_flag, shard, group)
         bmax = getattr(eng, "bam_max_batch", None)
         if bmax is not None and B > bmax:               # deterministic: raised here, not inside the retry loop
             raise ValueError(f"BaM.fit: batch_size {B} exceeds the device update's limit of {bmax}")
@@ -207,7 +214,11 @@ class BaM:
                         print(f"Trying again {j} of {retries}")
                     else:
                         raise e
-            eng.potrf(cov_new, out=R_new, flag=flag)
+            if shard and root_potrf and world > 1:          # opt-in: one rank factors, the others receive
+                from .dist import root_potrf as _root_potrf
+                _root_potrf(eng, cov_new, R_new, flag, group=group)
+            else:
+                eng.potrf(cov_new, out=R_new, flag=flag)
             eng.commit(flag, mean_new, cov_new, mean_t, cov_t, n_rev)
             if use_factor:
                 eng.commit(flag, mean_new, R_new, mean_t, R, None)
@@ -222,8 +233,10 @@ class BaM:
 
     # ------------------------------------------------------------------------------
     def _fit_factor(self, eng, key, regf, mean, cov, B, niter, nprint, verbose, monitor, retries, rng, as_torch,
-                    check_update_flag):
-        """Factor-form BaM fit (see ``fit(method="factor")``): the loop of gsmvi/bam.py:140-216 on the state (mean, F)."""
+                    check_update_flag, shard=False, group=None):
+        """Factor-form BaM fit (see ``fit(method="factor")``): the loop of gsmvi/bam.py:140-216 on the state (mean, F).
+        ``shard=True``: every rank draws the same Z, samples and scores only its batch_size/world rows; the (x_b, g_b) rows
+        are all-gathered and every replica applies the identical factor update (dist.sharded_bam_factor_update)."""
         D = self.D
         assert 2 * B <= min(D, 128), "method='factor' needs 2*batch_size <= min(D, 128)"
         mean_t = eng.zeros(D) if mean is None else eng.clone(mean).reshape(D)
@@ -241,7 +254,14 @@ class BaM:
         ndraw = 0
         native = bool(getattr(self.lp_g, "device_native", False))
         mon_native = bool(getattr(monitor, "device_native", False)) if monitor is not None else False
-        mean_new, F_new, Xbuf = eng.empty(D), eng.empty(D, D), eng.empty(B, D)
+        lo, hi, world = 0, B, 1
+        if shard:
+            from .dist import sharded_bam_factor_update, shard_bounds
+            import torch.distributed as _dist
+            world = _dist.get_world_size(group) if _dist.is_initialized() else 1
+            rank = _dist.get_rank(group) if _dist.is_initialized() else 0
+            lo, hi = shard_bounds(B, world, rank)
+        mean_new, F_new, Xbuf = eng.empty(D), eng.empty(D, D), eng.empty(hi - lo, D)
         state_bufs = [(mean_t, F), (mean_new, F_new)]
         a = 0
 
@@ -278,11 +298,28 @@ class BaM:
                         ndraw += 1
                     else:
                         Z = eng.normal_from_host(rs.standard_normal((B, D)))
-                    X = eng.sample(Z, mu_a, F_a, out=Xbuf)
-                    vs = self.lp_g(X) if native else eng.asarray(self.lp_g(eng.to_numpy(X)))
+                    X = eng.sample(Z[lo:hi], mu_a, F_a, out=Xbuf)          # only this rank's rows when sharded
+                    err = None
+                    try:
+                        vs = self.lp_g(X) if native else eng.asarray(self.lp_g(eng.to_numpy(X)))
+                    except Exception as e_score:            # noqa: BLE001
+                        if not (shard and world > 1):
+                            raise
+                        err, vs = e_score, None
+                    if shard and world > 1:                 # agree on failure BEFORE anybody enters the gather (as the dense fit)
+                        import torch
+                        fb = torch.tensor([0 if err is None else 1], dtype=torch.int32,
+                                          device=X.device if _is_torch(X) else "cpu")
+                        _dist.all_reduce(fb, op=_dist.ReduceOp.MAX, group=group)
+                        if int(fb.item()) != 0:
+                            raise err if err is not None else RuntimeError("score evaluation failed on another rank")
                     nevals += B
                     reg = regf(i)
-                    eng.bam_factor_update(Z, X, vs, mu_a, F_a, reg, out=(mu_b, F_b), flag=flag, n_reverts=n_rev)
+                    if shard:
+                        sharded_bam_factor_update(eng, Z, X, vs, mu_a, F_a, reg, group=group, out=(mu_b, F_b), flag=flag,
+                                                  n_reverts=n_rev)
+                    else:
+                        eng.bam_factor_update(Z, X, vs, mu_a, F_a, reg, out=(mu_b, F_b), flag=flag, n_reverts=n_rev)
                     if check_update_flag and eng.read_flag(flag) != 0:
                         raise FloatingPointError("BaM update flagged a numerical failure (device flag != 0)")
                     break

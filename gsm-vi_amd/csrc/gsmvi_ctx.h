@@ -4,6 +4,7 @@
 #include <cstddef>
 
 #define GSMVI_MAX_KC 8
+#define GSMVI_FACTOR_NMAX 128        // largest 2B of the factor-form updates (the 2B x 2B chain of gsmvi_factor.hip)
 #define GSMVI_STAMP_WORDS (4 * 4096)   // timeline diagnostic: 4 kernels x 512 workgroups x 8 words
 
 // Optional extras of ONE fast panel-product launch (k_panel_fast), consumed -- and cleared -- by the next product that takes

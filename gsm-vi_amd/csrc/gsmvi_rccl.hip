@@ -137,8 +137,8 @@ extern "C" int gsmvi_gsm_factor_update_sharded_f64(gsmvi_ctx* ctx, void* stream,
         gsmvi_set_error("%s: %s", __func__, "(D, B_local x ranks) exceeds the context's workspace; create a larger context");
         return GSMVI_ERR_WORKSPACE;
     }
-    if (2 * B > D || 2 * B > 128) {
-        gsmvi_set_error("%s: %s", __func__, "the factor form needs 2B <= D and 2B <= 128 for the combined batch");
+    if (2 * B > D || 2 * B > GSMVI_FACTOR_NMAX) {
+        gsmvi_set_error("%s: %s", __func__, "the factor form needs 2B <= D and 2B <= its chain's bound for the combined batch");
         return GSMVI_ERR_UNSUPPORTED;
     }
     const int ldrec = gsmvi_gsm_record_len(D);
@@ -194,4 +194,48 @@ extern "C" int gsmvi_bam_update_sharded_f64(gsmvi_ctx* ctx, void* stream, void* 
     if ((st = gather(__func__, nccl_comm, stream, Xall + rank * count, Xall, count, nranks)) != GSMVI_OK) return st;
     if ((st = gather(__func__, nccl_comm, stream, Gall + rank * count, Gall, count, nranks)) != GSMVI_OK) return st;
     return gsmvi_bam_update_f64(ctx, stream, D, (int)B, Xall, D, Gall, D, mu0, S0, lds0, reg, jitter, mu, S, lds, info_dev);
+}
+
+extern "C" int gsmvi_bam_factor_update_sharded_f64(gsmvi_ctx* ctx, void* stream, void* nccl_comm, int D, int B_local,
+                                                   const double* Z_all, int ldz, const double* X_local, int ldx,
+                                                   const double* G_local, int ldg, const double* mu0, const double* F0,
+                                                   int ldf0, double reg, double* xg_all, double* mu, double* F, int ldf,
+                                                   int* info_dev, int* n_reverts_dev) {
+    if (!ctx || !nccl_comm || !Z_all || !X_local || !G_local || !mu0 || !F0 || !xg_all || !mu || !F || !info_dev) {
+        gsmvi_set_error("%s: %s", __func__, "NULL argument");
+        return GSMVI_ERR_BAD_ARG;
+    }
+    int nranks = 0, rank = 0;
+    int st = comm_geometry(__func__, nccl_comm, &nranks, &rank);
+    if (st != GSMVI_OK) return st;
+    const long long B = (long long)B_local * nranks;
+    if (D <= 0 || B_local <= 0 || ldz < D || ldx < D || ldg < D || ldf0 < D || ldf < D) {
+        gsmvi_set_error("%s: %s", __func__, "non-positive size or a leading dimension smaller than D");
+        return GSMVI_ERR_BAD_ARG;
+    }
+    if (D > ctx->max_D || B > ctx->max_B) {
+        gsmvi_set_error("%s: %s", __func__, "(D, B_local x ranks) exceeds the context's workspace; create a larger context");
+        return GSMVI_ERR_WORKSPACE;
+    }
+    if (2 * B > D || 2 * B > GSMVI_FACTOR_NMAX) {
+        gsmvi_set_error("%s: %s", __func__, "the factor form needs 2B <= D and 2B <= its chain's bound for the combined batch");
+        return GSMVI_ERR_UNSUPPORTED;
+    }
+    hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    double* Xall = xg_all;
+    double* Gall = xg_all + (size_t)B * D;
+    const size_t count = (size_t)B_local * D;
+    hipError_t e = hipMemcpy2DAsync(Xall + rank * count, (size_t)D * sizeof(double), X_local, (size_t)ldx * sizeof(double),
+                                    (size_t)D * sizeof(double), (size_t)B_local, hipMemcpyDeviceToDevice, hs);
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(Gall + rank * count, (size_t)D * sizeof(double), G_local, (size_t)ldg * sizeof(double),
+                             (size_t)D * sizeof(double), (size_t)B_local, hipMemcpyDeviceToDevice, hs);
+    if (e != hipSuccess) {
+        gsmvi_set_error("%s: staging copy failed: %s", __func__, hipGetErrorString(e));
+        return GSMVI_ERR_HIP;
+    }
+    if ((st = gather(__func__, nccl_comm, stream, Xall + rank * count, Xall, count, nranks)) != GSMVI_OK) return st;
+    if ((st = gather(__func__, nccl_comm, stream, Gall + rank * count, Gall, count, nranks)) != GSMVI_OK) return st;
+    return gsmvi_bam_factor_update_f64(ctx, stream, D, (int)B, Z_all, ldz, Xall, D, Gall, D, mu0, F0, ldf0, reg, mu, F, ldf,
+                                       info_dev, n_reverts_dev);
 }

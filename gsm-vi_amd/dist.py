@@ -161,3 +161,24 @@ def sharded_bam_update(eng, X_local, G_local, mu0, S0, reg, jitter=0.0, group=No
     if not isinstance(allp, torch.Tensor):
         allp = _as_torch(allp).numpy()
     return eng.bam_update(allp[:, :D], allp[:, D:], mu0, S0, reg, jitter, out=out, flag=flag)
+
+
+def sharded_bam_factor_update(eng, Z, X_local, G_local, mu0, F0, reg, group=None, out=None, flag=None, n_reverts=None):
+    """(mu, F, flag) of the factor-form BaM update (Sigma = F^T F; engine.bam_factor_update) for the union of all ranks'
+    samples -- BASELINE config 4 ("B=128 sharded 16/GPU") without a D x D covariance or a D^3 step on any rank.
+    Z (B, D): the whitened draws of ALL samples, replicated (every rank draws the same counter-based stream);
+    X_local, G_local: samples and scores of this rank's B/P rows.  As in ``sharded_bam_update`` the statistics couple all
+    samples, so the (x_b, g_b) rows are all-gathered (2 (B/P) D doubles per rank) and every replica runs the identical
+    update: fixed summation orders => replicas stay bit-identical."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return eng.bam_factor_update(Z, X_local, G_local, mu0, F0, reg, out=out, flag=flag, n_reverts=n_reverts)
+    Bl, D = X_local.shape
+    packed = eng.empty(Bl, 2 * D)
+    packed[:, :D] = X_local
+    packed[:, D:] = G_local
+    allp = eng.empty(Bl * world, 2 * D)
+    _all_gather(_as_torch(allp), _as_torch(packed), group)
+    if not isinstance(allp, torch.Tensor):
+        allp = _as_torch(allp).numpy()
+    return eng.bam_factor_update(Z, allp[:, :D], allp[:, D:], mu0, F0, reg, out=out, flag=flag, n_reverts=n_reverts)

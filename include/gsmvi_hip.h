@@ -335,6 +335,20 @@ int gsmvi_bam_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
                                 const double* mu0, const double* F0, int ldf0, double reg,
                                 double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev);
 
+/*
+ * Factor-form BaM update batch-sharded over RCCL (BASELINE config 4, "B = 128 sharded 16/GPU", without a D x D covariance or a
+ * D^3 step on any rank; round 4).  Z_all (B x D, B = B_local x ranks) are the whitened draws of ALL samples, replicated (every
+ * rank draws the same counter-based stream, gsmvi_randn_f64); X_local / G_local are the samples and scores of this rank's
+ * rows [rank B_local, (rank + 1) B_local).  As in gsmvi_bam_update_sharded_f64 the (x_b, g_b) rows are all-gathered into
+ * xg_all (caller-owned, 2 x B x D doubles) and every replica runs gsmvi_bam_factor_update_f64 on the full batch: replicas stay
+ * bit-identical.  Geometry and the 2B <= min(D, 256) bound are validated before the first launch.
+ */
+int gsmvi_bam_factor_update_sharded_f64(gsmvi_ctx* ctx, void* stream, void* nccl_comm, int D, int B_local,
+                                        const double* Z_all, int ldz, const double* X_local, int ldx,
+                                        const double* G_local, int ldg, const double* mu0, const double* F0, int ldf0,
+                                        double reg, double* xg_all, double* mu, double* F, int ldf, int* info_dev,
+                                        int* n_reverts_dev);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -1,10 +1,11 @@
 /* Plain-C consumer of the RCCL-taking entry points (include/gsmvi_hip.h: gsmvi_gsm_update_sharded_f64,
- * gsmvi_gsm_factor_update_sharded_f64, gsmvi_bam_update_sharded_f64): one process per GPU, the caller owns the ncclComm_t.
+ * gsmvi_gsm_factor_update_sharded_f64, gsmvi_bam_update_sharded_f64, gsmvi_bam_factor_update_sharded_f64): one process per GPU, the caller owns the ncclComm_t.
  *   rccl_sharded <in.bin> <out.bin> <nranks> <rank> <idfile>
  * Rank 0 writes the ncclUniqueId to <idfile>, the other ranks wait for it.  Every rank reads the full problem of
  * in.bin (int D, int B, then X[B*D], G[B*D], mu0[D], S0[D*D], Z[B*D], F0[D*D] with X = mu0 + Z F0, S0 = F0^T F0), takes
  * rows [rank*B/nranks, (rank+1)*B/nranks) of X and G as its shard and writes to <out.bin>.<rank>:
- *   mu[D], S[D*D] (dense update) | mu[D], F[D*D], flag (factor-form update) | mu[D], S[D*D] (BaM update, reg 2, jitter 0). */
+ *   mu[D], S[D*D] (dense update) | mu[D], F[D*D], flag (factor-form update) | mu[D], S[D*D] (BaM update, reg 2, jitter 0)
+ *   | mu[D], F[D*D], flag (factor-form BaM update, reg 2; only when 2B <= D, zeros otherwise). */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -78,7 +79,7 @@ int main(int argc, char** argv) {
         return 5;
     CHECK_HIP(hipStreamSynchronize(st));
 
-    const size_t nout = 3 * (D + ndd) + 1;
+    const size_t nout = 4 * (D + ndd) + 2;
     double* out = (double*)malloc(sizeof(double) * nout);
     CHECK_HIP(hipMemcpy(out, mu, sizeof(double) * D, hipMemcpyDeviceToHost));
     CHECK_HIP(hipMemcpy(out + D, S, sizeof(double) * ndd, hipMemcpyDeviceToHost));
@@ -108,6 +109,25 @@ int main(int argc, char** argv) {
     CHECK_HIP(hipStreamSynchronize(st));
     CHECK_HIP(hipMemcpy(out + 2 * (D + ndd) + 1, mu, sizeof(double) * D, hipMemcpyDeviceToHost));
     CHECK_HIP(hipMemcpy(out + 2 * (D + ndd) + 1 + D, S, sizeof(double) * ndd, hipMemcpyDeviceToHost));
+
+    /* factor-form BaM update through the communicator (round 4): Z replicated, the (x_b, g_b) rows all-gathered into xg */
+    {
+        double* o4 = out + 3 * (D + ndd) + 1;
+        memset(o4, 0, sizeof(double) * (D + ndd + 1));
+        if (2 * B <= D) {
+            CHECK_HIP(hipMemset(flag, 0, 2 * sizeof(int)));
+            CHECK_ABI(gsmvi_bam_factor_update_sharded_f64(ctx, st, comm, D, Bl, Z, D, X, D, G, D, mu0, F0, D, 2.0, xg, mu, S, D,
+                                                          flag, flag + 1));
+            CHECK_HIP(hipStreamSynchronize(st));
+            CHECK_HIP(hipMemcpy(hflag, flag, sizeof hflag, hipMemcpyDeviceToHost));
+            CHECK_HIP(hipMemcpy(o4, mu, sizeof(double) * D, hipMemcpyDeviceToHost));
+            CHECK_HIP(hipMemcpy(o4 + D, S, sizeof(double) * ndd, hipMemcpyDeviceToHost));
+            o4[D + ndd] = (double)(hflag[0] + 1000 * hflag[1]);
+        } else if (gsmvi_bam_factor_update_sharded_f64(ctx, st, comm, D, Bl, Z, D, X, D, G, D, mu0, F0, D, 2.0, xg, mu, S, D,
+                                                       flag, flag + 1) != GSMVI_ERR_UNSUPPORTED) {
+            return 6;                       /* 2B > D must be refused before anything is enqueued */
+        }
+    }
 
     char name[4096];
     snprintf(name, sizeof name, "%s.%d", argv[2], rank);

@@ -189,8 +189,12 @@ def test_rccl_taking_entry_point_from_plain_c(tmp_path, D, B):
         assert rel_err(mu, mu_o) < 1e-11 and rel_err(S, S_o) < 1e-11
         muf, F, fl = out[n1:n1 + D], out[n1 + D:2 * n1].reshape(D, D), out[2 * n1]
         assert fl == 0.0 and rel_err(muf, mu_o) < 1e-10 and rel_err(F.T @ F, S_o) < 1e-10      # factor form = dense update
-        mub, Sb = out[2 * n1 + 1:2 * n1 + 1 + D], out[2 * n1 + 1 + D:].reshape(D, D)
+        mub, Sb = out[2 * n1 + 1:2 * n1 + 1 + D], out[2 * n1 + 1 + D:3 * n1 + 1].reshape(D, D)
         assert rel_err(mub, mu_b) < 1e-7 and rel_err(Sb, S_b) < 1e-7                              # BaM vs the restatement
+        o4 = out[3 * n1 + 1:]
+        if 2 * B <= D:                                                                             # factor-form BaM = dense BaM
+            mubf, Fb, flb = o4[:D], o4[D:n1].reshape(D, D), o4[n1]
+            assert flb == 0.0 and rel_err(mubf, mu_b) < 1e-7 and rel_err(Fb.T @ Fb, S_b) < 1e-7
         res.append(out)
     assert all(np.array_equal(res[0], x) for x in res)          # replicas bit-identical
 

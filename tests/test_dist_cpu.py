@@ -92,6 +92,39 @@ def _worker(rank, world, port, q):
             7, Regularizers().constant(5.0), niter=20, batch_size=4, verbose=False)
         assert set(seen3) == {4 // world}
         err = max(err, np.abs(mean_bs - mean_b1).max(), np.abs(cov_bs - cov_b1).max())
+        # sharded FACTOR-FORM BaM (round 4; BASELINE config 4 is "B sharded per GPU"): update and fit, replicas identical
+        from gsmvi_amd.dist import sharded_bam_factor_update
+        mu_bf, F_bf, flb = sharded_bam_factor_update(eng, stf["Z"], stf["samples"][flo:fhi], stf["vs"][flo:fhi],
+                                                      stf["mu0"], F0, 2.0)
+        mu_bfo, S_bfo = borc.bam_lowrank_update_exact(stf["samples"], stf["vs"], stf["mu0"], stf["S0"], 2.0)
+        assert flb.v == 0
+        err = max(err, np.abs(mu_bf - mu_bfo).max(), np.abs(F_bf.T @ F_bf - 0.5 * (S_bfo + S_bfo.T)).max())
+        seen4 = []
+
+        def lp_g4(x):
+            seen4.append(x.shape[0])
+            return orc.gaussian_score(x, m2, P2)
+
+        mean_bfs, cov_bfs = BaM(10, None, lp_g4, engine=OracleEngine()).fit(7, Regularizers().constant(5.0), niter=20,
+                                                                            batch_size=4, verbose=False, shard=True,
+                                                                            method="factor")
+        mean_bf1, cov_bf1 = BaM(10, None, lambda x: orc.gaussian_score(x, m2, P2), engine=OracleEngine()).fit(
+            7, Regularizers().constant(5.0), niter=20, batch_size=4, verbose=False, method="factor")
+        assert set(seen4) == {4 // world}
+        err = max(err, np.abs(mean_bfs - mean_bf1).max(), np.abs(cov_bfs - cov_bf1).max())
+        t2 = torch.from_numpy(np.concatenate([mean_bfs, cov_bfs.ravel()]))
+        g2 = [torch.empty_like(t2) for _ in range(world)]
+        dist.all_gather(g2, t2)
+        same = same and all(torch.equal(g2[0], x) for x in g2)
+        # opt-in root Cholesky + broadcast (dist.root_potrf) in both dense fits: same numbers as the replicated factorisation
+        mean_rp, cov_rp = GSM(6, None, lambda x: orc.gaussian_score(x, m, P), engine=OracleEngine()).fit(
+            7, niter=30, batch_size=4, verbose=False, shard=True, method="dense", root_potrf=True)
+        mean_rd, cov_rd = GSM(6, None, lambda x: orc.gaussian_score(x, m, P), engine=OracleEngine()).fit(
+            7, niter=30, batch_size=4, verbose=False, shard=True, method="dense")
+        err = max(err, np.abs(mean_rp - mean_rd).max(), np.abs(cov_rp - cov_rd).max())
+        mean_brp, cov_brp = BaM(6, None, lambda x: orc.gaussian_score(x, m, P), engine=OracleEngine()).fit(
+            7, Regularizers().constant(5.0), niter=20, batch_size=4, verbose=False, shard=True, root_potrf=True)
+        err = max(err, np.abs(mean_brp - mean_bs).max(), np.abs(cov_brp - cov_bs).max())
         # row-block sharded covariance (ragged: D = 25 rows over 2 ranks = 13 + 12)
         from gsmvi_amd.dist import row_sharded_gsm_update, row_bounds
         st = orc.make_update_state(25, 6, 5)
@@ -159,7 +192,7 @@ def test_world1_no_process_group():
     assert np.abs(mu - mu_o).max() < 1e-12 and np.abs(S - S_o).max() < 1e-12
 
 
-def _retry_worker(rank, world, port, q):
+def _retry_worker(rank, world, port, q, method="dense"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -169,7 +202,7 @@ def _retry_worker(rank, world, port, q):
         from oracle import gsm_oracle as orc
         from engines import OracleEngine
         from gsmvi_amd.bam import BaM, Regularizers
-        D, B = 6, 4
+        D, B = (6, 4) if method == "dense" else (10, 4)      # factor form: 2B <= D
         m, cov_t, P = orc.make_gaussian_target(D, 4)
         calls = [0]
 
@@ -181,7 +214,7 @@ def _retry_worker(rank, world, port, q):
 
         reg = Regularizers()
         mean, cov = BaM(D, None, lp_g, engine=OracleEngine()).fit(5, reg.linear(10.0), niter=12, batch_size=B,
-                                                                   verbose=False, shard=True, retries=3)
+                                                                   verbose=False, shard=True, retries=3, method=method)
         t = torch.from_numpy(np.concatenate([mean, cov.ravel(), [float(reg.counter), float(calls[0])]]))
         gathered = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
@@ -191,14 +224,16 @@ def _retry_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_bam_retries_are_collective():
+@pytest.mark.parametrize("method", ["dense", "factor"])
+def test_sharded_bam_retries_are_collective(method):
     """A score failure on ONE rank must make EVERY rank retry (fail bit all-reduced before the gather): replicas
-    stay identical, the regulariser advances equally, nobody re-enters a collective alone (round-1 advice)."""
+    stay identical, the regulariser advances equally, nobody re-enters a collective alone (round-1 advice).  Both the
+    dense and (round 4) the factor-form sharded fit."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_retry_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 31500 + (os.getpid() % 2000) + (2000 if method == "factor" else 0)
+    procs = [ctx.Process(target=_retry_worker, args=(r, world, port, q, method)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]

@@ -90,6 +90,35 @@ def _worker(rank, world, port, q):
         bm1, bc1 = gsmvi_amd.BaM(D, None, tgt.lp_g, engine=eng).fit(7, reg1.constant(1.0), niter=15, batch_size=B,
                                                                     verbose=False)
         out["bam_err"] = max(np.abs(bm - bm1).max(), np.abs(bc - bc1).max())
+        # sharded FACTOR-FORM BaM (round 4): update on real kernels, then the fit; replicas bit-identical
+        from gsmvi_amd.dist import sharded_bam_factor_update
+        D2, B2 = 256, 16
+        st = orc.make_update_state(D2, B2, 5)
+        X, G, mu0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0"))
+        F0, Z = eng.asarray(st["L"].T.copy()), eng.asarray(st["Z"])
+        lo, hi = shard_bounds(B2, world, rank)
+        mu_bf, F_bf, flb = sharded_bam_factor_update(eng, Z, X[lo:hi], G[lo:hi], mu0, F0, 2.0)
+        mu_bo, S_bo = borc.bam_lowrank_update_exact(st["samples"], st["vs"], st["mu0"], st["S0"], 2.0)
+        Fn = F_bf.cpu().numpy()
+        assert eng.read_flag(flb) == 0
+        out["bamf_err"] = max(np.abs(Fn.T @ Fn - 0.5 * (S_bo + S_bo.T)).max() / np.abs(S_bo).max(),
+                              np.abs(mu_bf.cpu().numpy() - mu_bo).max() / np.abs(mu_bo).max())
+        t = torch.cat([mu_bf, F_bf.reshape(-1)]).cpu()
+        gathered = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        out["same_bamf"] = all(torch.equal(gathered[0], x) for x in gathered)
+        regf = gsmvi_amd.Regularizers()
+        fm, fc = gsmvi_amd.BaM(D, None, lp_g, engine=eng).fit(7, regf.constant(1.0), niter=15, batch_size=B,
+                                                              verbose=False, shard=True, method="factor")
+        regf1 = gsmvi_amd.Regularizers()
+        fm1, fc1 = gsmvi_amd.BaM(D, None, tgt.lp_g, engine=eng).fit(7, regf1.constant(1.0), niter=15, batch_size=B,
+                                                                    verbose=False, method="factor")
+        out["bamf_fit_err"] = max(np.abs(fm - fm1).max(), np.abs(fc - fc1).max())
+        # opt-in root Cholesky + broadcast in the sharded dense BaM fit
+        regr = gsmvi_amd.Regularizers()
+        rm, rc_ = gsmvi_amd.BaM(D, None, lp_g, engine=eng).fit(7, regr.constant(1.0), niter=15, batch_size=B,
+                                                               verbose=False, shard=True, root_potrf=True)
+        out["bam_root_err"] = max(np.abs(rm - bm).max(), np.abs(rc_ - bc).max())
         out["ok"] = True
     except Exception as e:                                   # noqa: BLE001
         import traceback
@@ -121,3 +150,4 @@ def test_two_hip_backed_ranks_share_one_gpu():
         assert o["same_1024"] and o["same_96"]
         assert o["method"] == "factor" and o["rows"] == [4]
         assert o["fit_err"] < 1e-9 and o["fit_err_dense"] < 1e-9 and o["bam_err"] < 1e-8, o
+        assert o["bamf_err"] < 1e-9 and o["same_bamf"] and o["bamf_fit_err"] < 1e-8 and o["bam_root_err"] == 0.0, o
