@@ -100,7 +100,7 @@ class BaM:
         more than one GPU (see GSM.fit).
         ``method="factor"`` with ``shard=True``: the (x_b, g_b) rows are all-gathered as in the dense form and every replica
         runs the identical factor-form update (dist.sharded_bam_factor_update); retries are collective in the same way.
-        ``method="factor"`` (needs 2*batch_size <= min(D, 128), sampler="cholesky", no forced samples):
+        ``method="factor"`` (needs 2*batch_size <= min(D, 256), sampler="cholesky", no forced samples):
         the state is (mean, F) with cov = F^T F; every iteration samples with F itself and applies the factor-form BaM
         update (engine.bam_factor_update) -- four passes over F, no D x D covariance, no D^3 Cholesky for the accept
         test (the update's own 2B x 2B positive-definiteness test decides accept/revert, counted in ``n_reverts``).
@@ -238,7 +238,7 @@ class BaM:
         ``shard=True``: every rank draws the same Z, samples and scores only its batch_size/world rows; the (x_b, g_b) rows
         are all-gathered and every replica applies the identical factor update (dist.sharded_bam_factor_update)."""
         D = self.D
-        assert 2 * B <= min(D, 128), "method='factor' needs 2*batch_size <= min(D, 128)"
+        assert 2 * B <= min(D, 256), "method='factor' needs 2*batch_size <= min(D, 256)"
         mean_t = eng.zeros(D) if mean is None else eng.clone(mean).reshape(D)
         cov0 = eng.eye(D) if cov is None else eng.clone(cov).reshape(D, D)
         flag, n_rev = eng.new_flag(), eng.new_flag()

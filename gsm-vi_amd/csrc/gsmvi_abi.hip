@@ -254,7 +254,7 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     else if (!strcmp(name, "bam_full")) ctx->tune_bam_full = value;
     else if (!strcmp(name, "bam_kenq")) ctx->tune_bam_kenq = value;
     else if (!strcmp(name, "bam_subst")) ctx->tune_bam_subst = value;
-    else if (!strcmp(name, "bam_ns2")) ctx->tune_bam_ns2 = value;
+    else if (!strcmp(name, "bam_nsfuse")) ctx->tune_bam_nsfuse = value;
     else if (!strcmp(name, "scalars_nt")) ctx->tune_scalars_nt = value;
     else if (!strcmp(name, "cov_dbg")) ctx->tune_cov_dbg = value;   // ablation bits, timing experiments only
     else if (!strcmp(name, "timeline")) {                           // whole-update timeline stamps (diagnostic)
@@ -661,8 +661,8 @@ int gsmvi_gsm_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, cons
     BAD_ARG(!Z || !X || !G || !mu0 || !F0 || !mu || !F || !info_dev, "NULL argument");
     BAD_ARG(ldz < D || ldx < D || ldg < D || ldf0 < D || ldf < D, "leading dimension smaller than D");
     BAD_ARG(F == F0 || mu == mu0, "outputs must not alias inputs");
-    if (2 * B > D || 2 * B > 128 || D > 16384) {
-        gsmvi_set_error("%s: %s", __func__, "the factor form needs 2B <= D and 2B <= 128; use gsmvi_gsm_update_f64");
+    if (2 * B > D || 2 * B > GSMVI_FACTOR_NMAX || D > 16384) {
+        gsmvi_set_error("%s: %s", __func__, "the factor form needs 2B <= D and 2B <= 256; use gsmvi_gsm_update_f64");
         return GSMVI_ERR_UNSUPPORTED;
     }
     return gsmvi_factor_impl(ctx, reinterpret_cast<hipStream_t>(stream), D, B, Z, ldz, X, ldx, G, ldg, mu0, F0, ldf0,
@@ -694,8 +694,8 @@ int gsmvi_gsm_factor_apply_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const
     BAD_ARG(ldz < D || ldf0 < D || ldf < D, "leading dimension smaller than D");
     BAD_ARG(ldrec < gsmvi_gsm_record_len(D), "ldrec smaller than gsmvi_gsm_record_len(D)");
     BAD_ARG(F == F0 || mu == mu0, "outputs must not alias inputs");
-    if (2 * B > D || 2 * B > 128 || D > 16384) {
-        gsmvi_set_error("%s: %s", __func__, "the factor form needs 2B <= D and 2B <= 128; use gsmvi_gsm_update_f64");
+    if (2 * B > D || 2 * B > GSMVI_FACTOR_NMAX || D > 16384) {
+        gsmvi_set_error("%s: %s", __func__, "the factor form needs 2B <= D and 2B <= 256; use gsmvi_gsm_update_f64");
         return GSMVI_ERR_UNSUPPORTED;
     }
     return gsmvi_factor_apply_impl(ctx, reinterpret_cast<hipStream_t>(stream), D, B, Z, ldz, rec, ldrec, mu0, F0, ldf0,
@@ -724,8 +724,8 @@ int gsmvi_bam_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B, cons
     BAD_ARG(ldz < D || ldx < D || ldg < D || ldf0 < D || ldf < D, "leading dimension smaller than D");
     BAD_ARG(F == F0 || mu == mu0, "outputs must not alias inputs");
     BAD_ARG(!(reg > 0.0), "reg must be positive");
-    if (2 * B > D || 2 * B > 128 || D > 16384) {
-        gsmvi_set_error("%s: %s", __func__, "the factor form needs 2B <= D and 2B <= 128; use gsmvi_bam_update_f64");
+    if (2 * B > D || 2 * B > GSMVI_FACTOR_NMAX || D > 16384) {
+        gsmvi_set_error("%s: %s", __func__, "the factor form needs 2B <= D and 2B <= 256; use gsmvi_bam_update_f64");
         return GSMVI_ERR_UNSUPPORTED;
     }
     return gsmvi_bam_factor_impl(ctx, reinterpret_cast<hipStream_t>(stream), D, B, Z, ldz, X, ldx, G, ldg, mu0, F0, ldf0, reg,

@@ -218,6 +218,59 @@ __global__ __launch_bounds__(256) void k_bam_nmat(int n, const double* __restric
     }
 }
 
+// ---- the same from the split-K SLABS of the stacked Gram product [N0; M1] (round 4): finish + N in one launch ------------------
+// k_panel_finish (4.7 us) + k_bam_nmat (19 us on 16 workgroups at n = 128) were two launches; here one workgroup per 16 x 16
+// block of N sums the slabs while it loads its operands (slab element (r, c) of slab q: slabs[q stride + r n + c], rows
+// 0 .. n-1 = N0, rows n .. 2n-1 = M1), K = n split over the four waves, partial blocks summed through LDS in a fixed order,
+// and writes its blocks of the finished N0 and M1 as well (k_bam_cholw / k_bam_zw read them).  M1^T is not produced: the
+// product-form Z (k_bam_zw) reads M1 by columns itself.
+__global__ __launch_bounds__(256) void k_bam_nmat2(int n, int kc, const double* __restrict__ slabs, long long slab_stride,
+                                                   double* __restrict__ N0, double* __restrict__ M1,
+                                                   double* __restrict__ Nm) {
+    __shared__ double red[4 * 256];
+    const int nb = (n + 15) >> 4;
+    const int bi = blockIdx.x / nb, bj = blockIdx.x - bi * nb, i0 = 16 * bi, j0 = 16 * bj;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, cc = l & 15, ks = l >> 4;
+    const int ic = (i0 + cc) < n ? i0 + cc : n - 1, jc = (j0 + cc) < n ? j0 + cc : n - 1;
+    const int nk = (n + 3) >> 2;
+    auto slab_sum = [&](int r, int c) {                      // one finished entry: the kc slabs, all loads in one batch
+        double t[GSMVI_MAX_KC];
+#pragma unroll
+        for (int q = 0; q < GSMVI_MAX_KC; ++q) t[q] = slabs[(size_t)(q < kc ? q : kc - 1) * slab_stride + (size_t)r * n + c];
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < GSMVI_MAX_KC; ++q) a += (q < kc) ? t[q] : 0.0;
+        return a;
+    };
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int u0 = 0; w + 4 * u0 < nk; u0 += 4) {             // four k-steps of this wave per batch (64 slab loads in flight)
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int st = w + 4 * (u0 + u), k = 4 * st + ks, kk = k < n ? k : n - 1;
+            const double av = slab_sum(n + kk, ic), bv = slab_sum(n + kk, jc);
+            a[u] = (k < n && (i0 + cc) < n) ? av : 0.0;
+            b[u] = (k < n && (j0 + cc) < n) ? bv : 0.0;
+        }
+        acc0 = GSMVI_MFMA_F64(a[0], b[0], acc0);
+        acc1 = GSMVI_MFMA_F64(a[1], b[1], acc1);
+        acc0 = GSMVI_MFMA_F64(a[2], b[2], acc0);
+        acc1 = GSMVI_MFMA_F64(a[3], b[3], acc1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w * 256 + (ks + 4 * r) * 16 + cc] = acc0[r] + acc1[r];
+    const int t = threadIdx.x, i = i0 + (t >> 4), j = j0 + (t & 15);
+    const int iq = i < n ? i : n - 1, jq = j < n ? j : n - 1;
+    const double n0ij = slab_sum(iq, jq), n0ji = slab_sum(jq, iq), m1ij = slab_sum(n + iq, jq);
+    __syncthreads();
+    if (i < n && j < n) {
+        const double v = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
+        Nm[(size_t)i * n + j] = v + 0.5 * (n0ij + n0ji);
+        N0[(size_t)i * n + j] = n0ij;
+        M1[(size_t)i * n + j] = m1ij;
+    }
+}
+
 // ---- Z = L^-1 (P + T1), T1 = M1^T Vf precomputed by the panel product, n <= 144 -----------------------
 // Sixteen lanes per column of D, 16 columns per workgroup.  Lane q of a column group owns rows q, q+16, ...
 // (9 registers).  U = L^T is staged in LDS in packed upper form (row p holds L[p..n-1][p], contiguous, so the
@@ -362,23 +415,26 @@ __global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const doubl
 //   phase 1  T = M1^T Vf_tile (K = n), A = P_tile + T -> LDS           A-operand M1[k][r] straight from L2 (16 consecutive
 //            doubles per k), B-operand the Vf tile staged once in LDS ([k][16]: the four k-slots of a step read 512
 //            contiguous bytes, conflict-free)
-//   phase 2  Z = W A: row block w needs the k-blocks 0 .. w only (W is lower triangular); its W loads are issued before phase 1
-// Z goes to rows n .. 2n-1 of Ft and, negated, of Fs (rows 0 .. n-1 hold Vf: k_bam_stats_h).  Mean (bam.py:112):
+//   phase 2  Z = W A: row block w needs the k-blocks 0 .. w only (W is lower triangular).  W arrives TRANSPOSED (Wt = R^-1,
+//            upper): the A-operand W[r][k] = Wt[k][r] is again 16 consecutive doubles per k -- with a row-major W every load
+//            instruction touched 16 cache lines and the kernel took 21 us instead of ~9.  Its loads are issued before phase 1.
+// zg = W a (bam.py:110 applied to gbar; a from k_bam_bbav) falls out of the same W fragments: four lanes per row, summed by two
+// shuffles.  Z goes to rows n .. 2n-1 of Ft and, negated, of Fs (rows 0 .. n-1 hold Vf: k_bam_stats_h).  Mean (bam.py:112):
 // mu = mu0/(1+reg) + r1 (S0 gbar + Vf^T vg - Z^T zg + xbar), the two dots from the tiles in LDS / registers, fixed order.
 __global__ __launch_bounds__(512) void k_bam_zw(int D, int n, const double* __restrict__ P, const double* __restrict__ M1,
-                                                const double* __restrict__ W, const double* __restrict__ zg,
+                                                const double* __restrict__ Wt, const double* __restrict__ av,
                                                 const double* __restrict__ vg, const double* __restrict__ mu0,
                                                 const double* __restrict__ xbar, double reg, double* __restrict__ Ft,
                                                 double* __restrict__ Fs, double* __restrict__ mu) {
     __shared__ __attribute__((aligned(16))) double Vs[128 * 16], As[128 * 16];
-    __shared__ double szg[128], svg[128], redz[8 * 4 * 16];
+    __shared__ double sav[128], szg[128], svg[128], redz[8 * 4 * 16];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
     const int j0 = blockIdx.x * 16;
     const int nb = (n + 15) >> 4;
     const int jc = (j0 + cc) < D ? j0 + cc : D - 1;
     const bool colin = (j0 + cc) < D;
     const int rA = 16 * w + cc, rAc = rA < n ? rA : n - 1;   // this lane's row as an MFMA A-operand row
-    // all global loads of the workgroup first: Vf tile (4 per thread), this wave's M1 columns and W rows, its P block
+    // all global loads of the workgroup first: Vf tile (4 per thread), this wave's M1 and Wt columns, its P block
     double vt[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -399,7 +455,7 @@ __global__ __launch_bounds__(512) void k_bam_zw(int D, int n, const double* __re
         for (int st = 0; st < 32; ++st) {
             const int k = 4 * st + ks, kc = k < n ? k : n - 1;
             double x = 0.0;
-            if (st < 4 * (w + 1)) x = W[(size_t)rAc * n + kc];
+            if (st < 4 * (w + 1)) x = Wt[(size_t)kc * n + rAc];          // W[rA][k], k <= 16 w + 15
             aw[st] = (k < n && rA < n) ? x : 0.0;
         }
 #pragma unroll
@@ -410,13 +466,27 @@ __global__ __launch_bounds__(512) void k_bam_zw(int D, int n, const double* __re
         }
     }
     if (tid < 128) {
-        szg[tid] = tid < n ? zg[tid] : 0.0;
+        sav[tid] = tid < n ? av[tid] : 0.0;
         svg[tid] = tid < n ? vg[tid] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) Vs[tid + 512 * u] = vt[u];
     __syncthreads();
     if (w < nb) {
+        {   // zg[rA] = sum_k W[rA][k] a[k]: this lane holds k = 4 st + ks of its row; the row's four lanes are cc, cc + 16, ...
+            double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+            for (int st = 0; st < 32; st += 2) {
+                if (st < 4 * (w + 1)) {
+                    z0 += aw[st] * sav[4 * st + ks];
+                    z1 += aw[st + 1] * sav[4 * st + 4 + ks];
+                }
+            }
+            double z = z0 + z1;
+            z += __shfl_xor(z, 16, 64);
+            z += __shfl_xor(z, 32, 64);
+            if (ks == 0) szg[rA] = z;                        // (rows >= n: zero operands, zero result)
+        }
         v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int st = 0; st < 32; st += 2) {
@@ -430,6 +500,7 @@ __global__ __launch_bounds__(512) void k_bam_zw(int D, int n, const double* __re
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) As[(16 * w + ks + 4 * r) * 16 + cc] = 0.0;
+        if (ks == 0) szg[rA] = 0.0;
     }
     __syncthreads();
     if (w < nb) {
@@ -713,9 +784,15 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
                                         info_dev ? info_dev : ctx->ints + 8)))
             return rc;
     } else {
-        if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
-        // N = M1^T M1 + sym(N0) and M1^T on the device
-        hipLaunchKernelGGL(k_bam_nmat, dim3((((n + 15) / 16) * ((n + 15) / 16) + 3) / 4), dim3(256), 0, st, n, M1, N0, Nd, M1T);
+        if (use_w) {
+            // slab sums of [N0; M1] and N = M1^T M1 + sym(N0) in one launch
+            const int nbq = (n + 15) / 16;
+            hipLaunchKernelGGL(k_bam_nmat2, dim3(nbq * nbq), dim3(256), 0, st, n, kc, ctx->pp, (long long)n2 * n, N0, M1, Nd);
+        } else {
+            if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
+            // N = M1^T M1 + sym(N0) and M1^T on the device
+            hipLaunchKernelGGL(k_bam_nmat, dim3((((n + 15) / 16) * ((n + 15) / 16) + 3) / 4), dim3(256), 0, st, n, M1, N0, Nd, M1T);
+        }
         // the whole n x n matrix function on the device (gsmvi_bam_small.hip): no copy, no synchronisation
         double* scratch = Upk + (size_t)n * (n + 1) / 2 + 2;
         if (!ctx->bam_hint_host) {                 // pinned, device-visible word for the step-count hint
@@ -731,8 +808,9 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     }
     const bool lanes16 = n <= 129;              // the sizes whose Cholesky kernel (k_bam_chol_out) also emits the packed rows
     if (use_w) {
-        // Z = W (P + M1^T Vf) by two chained MFMA products per 16 columns of D, the mean with it (W = L^-1 sits in Ld's slot)
-        hipLaunchKernelGGL(k_bam_zw, dim3((D + 15) / 16), dim3(512), 0, st, D, n, P, M1, Ld, Ldinv + n, Ldinv + 2 * n, mu0, xbar,
+        // Z = W (P + M1^T Vf) by two chained MFMA products per 16 columns of D, the mean with it (Wt = (L^-1)^T sits in Ld's slot,
+        // [a | . | vg] behind it)
+        hipLaunchKernelGGL(k_bam_zw, dim3((D + 15) / 16), dim3(512), 0, st, D, n, P, M1, Ld, Ldinv, Ldinv + 2 * n, mu0, xbar,
                            reg, Ft, Fs, mu);
     } else if (lanes16 && n <= 64) {
         // the 16-lanes-per-column substitution with T1 = M1^T Vf formed inside
@@ -820,6 +898,8 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     const double* Ldinv = Ld + (size_t)n * n;
     int* info_bam = ctx->ints + 8;
     int kc = 1, rc;
+    // n > 48: the chain of the dense form (k_bam_cholw + k_bam_zw); the "bam_subst" route only exists up to n = 64 here
+    const bool use_w = n > gsmvi_bam_small_fused_nmax() && n <= 128 && !(ctx->tune_bam_subst && n <= 64);
 
     hipLaunchKernelGGL(k_bam_stats_h, dim3((D + 63) / 64), dim3(256), 0, st, D, B, Z, ldz, (const double*)nullptr, X, ldx, G, ldg,
                        reg, xbar, gbar, zerov, Qt, Ft, (double*)nullptr);
@@ -829,8 +909,13 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     if (n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full) {
         if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, n, (size_t)n2 * n, M1, Ld, Upk, info_bam))) return rc;
     } else {
-        if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
-        hipLaunchKernelGGL(k_bam_nmat, dim3((((n + 15) / 16) * ((n + 15) / 16) + 3) / 4), dim3(256), 0, st, n, M1, N0, Nd, M1T);
+        if (use_w) {
+            const int nbq = (n + 15) / 16;
+            hipLaunchKernelGGL(k_bam_nmat2, dim3(nbq * nbq), dim3(256), 0, st, n, kc, ctx->pp, (long long)n2 * n, N0, M1, Nd);
+        } else {
+            if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
+            hipLaunchKernelGGL(k_bam_nmat, dim3((((n + 15) / 16) * ((n + 15) / 16) + 3) / 4), dim3(256), 0, st, n, M1, N0, Nd, M1T);
+        }
         if (!ctx->bam_hint_host) {
             if (hipHostMalloc(reinterpret_cast<void**>(&ctx->bam_hint_host), 64, hipHostMallocMapped) == hipSuccess)
                 *ctx->bam_hint_host = 0;
@@ -838,13 +923,19 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
                 ctx->bam_hint_host = nullptr;
         }
         if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, Upk, info_bam,
-                                         ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq, nullptr)))
+                                         ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq,
+                                         use_w ? M1T : nullptr)))
             return rc;
     }
-    // Zw = L^-1 (Wq + M1^T Vw) by the 16-lanes-per-column substitution (M1^T Vw formed inside); its mean output
-    // (mu0 = xbar = 0) is r1 (wg + Vw^T vg - Zw^T zg) = r1 h, written as row 2n of Ft
-    hipLaunchKernelGGL(k_bam_forward16<true>, dim3((D + 15) / 16), dim3(256), 0, st, D, n, Wq, M1, Upk, Ldinv, Ldinv + n,
-                       Ldinv + 2 * n, zerov, zerov, reg, Ft, T1, Ft + (size_t)n2 * D);
+    // Zw = L^-1 (Wq + M1^T Vw); its mean output (mu0 = xbar = 0) is r1 (wg + Vw^T vg - Zw^T zg) = r1 h, written as row 2n of Ft.
+    // n <= 48: the 16-lanes-per-column substitution (M1^T Vw formed inside); above: W = L^-1 from k_bam_cholw and two chained
+    // MFMA products per 16 columns (k_bam_zw), as the dense form
+    if (use_w)
+        hipLaunchKernelGGL(k_bam_zw, dim3((D + 15) / 16), dim3(512), 0, st, D, n, Wq, M1, Ld, Ldinv, Ldinv + 2 * n, zerov, zerov,
+                           reg, Ft, T1, Ft + (size_t)n2 * D);
+    else
+        hipLaunchKernelGGL(k_bam_forward16<true>, dim3((D + 15) / 16), dim3(256), 0, st, D, n, Wq, M1, Upk, Ldinv, Ldinv + n,
+                           Ldinv + 2 * n, zerov, zerov, reg, Ft, T1, Ft + (size_t)n2 * D);
     ctx->fo_Rt = Ft;
     ctx->fo_Tm = Tm;
     ctx->fo_Fs = Fsf;

@@ -149,22 +149,26 @@ __global__ __launch_bounds__(256) void k_bam_ns_step(int n, int ld, int k, doubl
     else bams_block<2>(Mm, Zi, Zo, blockIdx.x - nb * nb, nb, nk, c2, c, ld);                        // Z' = c T Z
 }
 
-// ---- ONE launch per step (round 4): M = Z Y is not handed over through memory, every workgroup forms the 16-wide panel of it
-// that its own output block needs --------------------------------------------------------------------------------------------
-// Two launches per step were launch-bound (2 x 4.7 us for 12.6 MFLOP at n = 128: 26 launches, 123 us of a 329 us update).
+// ---- ONE launch per step (round 4, opt-in: knob "bam_nsfuse"): M = Z Y is not handed over through memory, every workgroup forms
+// the 16-wide panel of it that its own output block needs ---------------------------------------------------------------------
+// Two launches per step are launch-bound (2 x 4.7 us for 12.6 MFLOP at n = 128: 26 launches, 123 us of a 329 us update).
 // Here workgroup blk < nb^2 owns block (i, j) of Y' = c Y T and needs the COLUMN panel T(:, j) = 1.5 I - 0.5 c^2 (Z Y)(:, j);
 // workgroup nb^2 + blk owns block (i, j) of Z' = c T Z and needs the ROW panel T(i, :).  Eight waves: wave w forms the 16 x 16
-// block w of the panel (K = n: all 64 operand values of the lane loaded up front, two accumulator chains) -- an n / 16-fold
-// recomputation of M over the grid (0.52 MFLOP per workgroup, ~3 us on one CU's matrix pipes), cheaper than a second launch.
-// The panel goes to LDS as T; the own block's K = n product is split over the eight waves and summed through LDS in a fixed
-// order.  Every block of every product is computed exactly as it stands (same operands, same order in every workgroup that
-// needs it), so the iterates are deterministic and the two copies of a panel block in different workgroups are bit-identical.
-// Loads are issued before the step-count test (coef[40]): the launches beyond k* cost their launch, not a second round trip.
+// block w of the panel (K = n, two accumulator chains) -- an n / 16-fold recomputation of M over the grid (0.52 MFLOP per
+// workgroup), the price of not waiting for a second launch.  The rows of Z that a wave multiplies from the left are staged in
+// LDS with whole-row 16-byte loads ([16][132] per wave: the MFMA A-fragments then come from LDS without bank conflicts); the
+// first version loaded the fragments straight from L2 -- 16 cache lines per load instruction, 64 instructions per lane -- and
+// took 13.3 us per launch, slower than the two launches it replaced.  The B-operand rows (16 consecutive doubles per k) are read
+// from L2 directly.  The panel goes to LDS as T; the own block's K = n product is split over the eight waves and summed through
+// LDS in a fixed order.  Every block of every product is computed exactly as it stands (same operands, same order in every
+// workgroup that needs it), so the iterates are deterministic and the copies of a panel block in different workgroups are
+// bit-identical.  Loads are issued before the step-count test (coef[40]): a launch beyond k* costs its launch, not a round trip.
+#define BAMF_ZS 132
 __global__ __launch_bounds__(512) void k_bam_ns_fused(int n, int ld, int k, double* __restrict__ Ya, double* __restrict__ Za,
                                                       double* __restrict__ Yb, double* __restrict__ Zb,
                                                       const double* __restrict__ coef) {
-    __shared__ __attribute__((aligned(16))) double Ts[128 * 17];          // column panel: [k][16] (stride 16); row panel: [16][k]
-    __shared__ double red[8 * 256];
+    __shared__ __attribute__((aligned(16))) double Zs[8 * 16 * BAMF_ZS];   // staged rows of Z; later the partial blocks (red)
+    __shared__ __attribute__((aligned(16))) double Ts[128 * 17];          // column panel: [k][16]; row panel: [16][129]
     const int nb = (n + 15) >> 4;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
     const bool isZ = (int)blockIdx.x >= nb * nb;
@@ -174,16 +178,26 @@ __global__ __launch_bounds__(512) void k_bam_ns_fused(int n, int ld, int k, doub
     const double* Z = (k & 1) ? Zb : Za;
     double* Yo = (k & 1) ? Ya : Yb;
     double* Zo = (k & 1) ? Za : Zb;
-    const double kst = coef[40], fl = coef[42], c2 = coef[k];
     // panel block w: Y' needs M(16w.., j0..) = Z(16w.., :) Y(:, j0..); Z' needs M(i0.., 16w..) = Z(i0.., :) Y(:, 16w..)
     const int pr0 = isZ ? i0 : 16 * w, pc0 = isZ ? 16 * w : j0;
-    double a[32], b[32];
+    // rows of Z to stage: Y' -- wave w its own 16 rows (slot w); Z' -- the 16 rows i0.., two per wave (slot 0).  Whole rows, 16 B
+    // per lane (columns 2 l, 2 l + 1 < 128 <= ld)
+    v2d zr[16];
+    const int nrow = isZ ? 2 : 16;
+    if (isZ || w < nb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (r < nrow) {
+                const int row = isZ ? i0 + 2 * w + r : 16 * w + r;
+                zr[r] = *reinterpret_cast<const v2d*>(Z + (size_t)row * ld + 2 * l);
+            }
+    }
+    double b[32];
     if (w < nb) {
 #pragma unroll
         for (int st = 0; st < 32; ++st) {
-            const int kk = 4 * st + ks, kc = kk < ld ? kk : ld - 1;
-            a[st] = Z[(size_t)(pr0 + cc) * ld + kc];
-            b[st] = Y[(size_t)kc * ld + pc0 + cc];
+            const int kk = 4 * st + ks;
+            b[st] = Y[(size_t)kk * ld + pc0 + cc];            // kk <= 127 < ld
         }
     }
     // the own block's operand that does not depend on T: Y(i0.., k) for Y' (A-operand), Z(k, j0..) for Z' (B-operand); wave w takes
@@ -191,14 +205,28 @@ __global__ __launch_bounds__(512) void k_bam_ns_fused(int n, int ld, int k, doub
     double o[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int kk = 4 * (w + 8 * u) + ks, kc = kk < ld ? kk : ld - 1;
-        o[u] = isZ ? Z[(size_t)kc * ld + j0 + cc] : Y[(size_t)(i0 + cc) * ld + kc];
+        const int kk = 4 * (w + 8 * u) + ks;                  // <= 127
+        o[u] = isZ ? Z[(size_t)kk * ld + j0 + cc] : Y[(size_t)(i0 + cc) * ld + kk];
     }
+    const double kst = coef[40], fl = coef[42], c2 = coef[k];
     asm volatile("" ::: "memory");                           // the operand loads above may not sink below the test that follows
     if ((double)k >= kst || fl != 0.0) return;
     const double c = sqrt(c2);
     const int nk = (n + 3) >> 2;
+    if (isZ || w < nb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (r < nrow) {
+                const int slot_row = isZ ? 2 * w + r : 16 * w + r;
+                *reinterpret_cast<v2d*>(Zs + (size_t)slot_row * BAMF_ZS + 2 * l) = zr[r];
+            }
+    }
+    __syncthreads();
     if (w < nb) {
+        const double* ap = Zs + (size_t)((isZ ? 0 : 16 * w) + cc) * BAMF_ZS + ks;
+        double a[32];
+#pragma unroll
+        for (int st = 0; st < 32; ++st) a[st] = ap[4 * st];
         v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int st = 0; st < 32; st += 2) {
@@ -215,7 +243,8 @@ __global__ __launch_bounds__(512) void k_bam_ns_fused(int n, int ld, int k, doub
             else Ts[pr * 16 + cc] = t;                        // column panel T(row, j0 + col): [n][16]
         }
     }
-    __syncthreads();
+    __syncthreads();                                         // (every read of Zs is done: it becomes the reduction buffer)
+    double* red = Zs;
     {   // own block: Y'(i0.., j0..) = c sum_k Y(i0.., k) T(k, j0..)   |   Z'(i0.., j0..) = c sum_k T(i0.., k) Z(k, j0..)
         v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -566,77 +595,78 @@ __global__ __launch_bounds__(512) void k_bam_chol_out(int n, double reg, const d
     }
 }
 
-// ---- BB, its Cholesky factor WITH the inverse factor W = L^-1, and the small outputs: ONE workgroup, n <= 128 (round 4) --------
-// Replaces k_bam_ns_bb + k_bam_chol_out + the forward substitution's dependence on the packed factor: BB = N + I/2 +
-// sqrt(s) sym(Y_final) is formed here (one launch less), factored as [BB | I] -> [R | W] on chol64_blk (n <= 64: one call;
-// 64 < n <= 128: chol128w_body, the 2 x 2 block scheme of the factor path's Gram matrix, 47 us against 73 us for the
-// barrier-per-pivot k_bam_chol_out it replaces), and what bam.py:110 calls solve(BB, .) becomes Z = W (P + M1^T Vf), an MFMA
-// product in k_bam_zw (gsmvi_bam.hip) instead of a 128-step substitution per column of D (33 us at D = 1024).  W = L^-1 with
-// cond(L) = sqrt(cond(BB)) <= ~1e4 on BASELINE config 4: the explicit triangular inverse changes Z by 1e-12 relative and the
-// update's backward error from 1.3e-17 to 3e-17 (numpy check beside the substitution; K8 asserts 1e-14).
-// Outputs: Wg (n x n, lower, zeros above the diagonal), then behind it [n unused], zg = W a (n), vg (n); Rg (n x n scratch, the
-// upper factor, not consumed); *info != 0 poisons Wg, zg, vg with NaN (nothing stale may be applied).
-template <bool BIG>   // BIG: 64 < n <= 128 (two block rows), else n <= 64 (the discarded branch's LDS arrays are not instantiated)
-__global__ __launch_bounds__(512) void k_bam_cholw(int n, int ld, double reg, const double* __restrict__ Nm,
-                                                   const double* __restrict__ Ya, const double* __restrict__ Yb,
-                                                   const double* __restrict__ coef, const double* __restrict__ M1,
-                                                   const double* __restrict__ N0, double* BBg, double* Rg, double* Wg,
-                                                   int* __restrict__ info) {
-    __shared__ double sc[128], av[128], part[4 * 128];
-    __shared__ int sh_bad, sh_info;
-    const int tid = threadIdx.x;
-    const int kstar = (int)coef[40];
-    const double* Y = (kstar & 1) ? Yb : Ya;                 // iterate k* lives in buffer k* & 1
-    const double rs = sqrt(coef[41]);
-    const bool ns_failed = coef[42] != 0.0;
-    if (tid == 0) { sh_bad = 0; sh_info = 0; }
-    __syncthreads();
-    int nan_in = ns_failed ? 1 : 0;
-    for (int e0 = 0; e0 < n * n; e0 += 512 * 8) {            // BB: eight elements (24 loads) in flight per thread
-        double a[8], y1[8], y2[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = e0 + 512 * u + tid, ec = e < n * n ? e : n * n - 1, i = ec / n, j = ec - i * n;
-            a[u] = Nm[ec];
-            y1[u] = Y[(size_t)i * ld + j];
-            y2[u] = Y[(size_t)j * ld + i];
+// ---- BB and the vectors that do not depend on its factor, on many workgroups (round 4) ----------------------------------------
+//   BB = N + I/2 + sqrt(s) sym(Y_final)     one 16 x 16 block per workgroup; the transposed block of Y passes through LDS, so both
+//                                           reads are 128-byte row segments (a one-workgroup version read Y by columns: 8 us)
+//   vg = Vf gbar = M1[:, n-1] / r1s,  a = P gbar + M1^T vg (bam.py:107 applied to gbar)      the extra workgroup nb^2
+// Outputs: BBg (n x n); behind the n x n slot of W: [a (n) | (n unused) | vg (n)].  A failed iteration (coef[42]) poisons BB.
+__global__ __launch_bounds__(256) void k_bam_bbav(int n, int ld, double reg, const double* __restrict__ Nm,
+                                                  const double* __restrict__ Ya, const double* __restrict__ Yb,
+                                                  const double* __restrict__ coef, const double* __restrict__ M1,
+                                                  const double* __restrict__ N0, double* __restrict__ BBg,
+                                                  double* __restrict__ tail3) {
+    const int nb = (n + 15) >> 4, tid = threadIdx.x;
+    if ((int)blockIdx.x < nb * nb) {
+        __shared__ double Tt[16 * 17];
+        const int bi = blockIdx.x / nb, bj = blockIdx.x - bi * nb, r = tid >> 4, c = tid & 15;
+        const int kstar = (int)coef[40];
+        const double* Y = (kstar & 1) ? Yb : Ya;             // iterate k* lives in buffer k* & 1
+        const int i = 16 * bi + r, j = 16 * bj + c;
+        const double y1 = Y[(size_t)i * ld + j];             // (padded to ld >= 16 nb: always inside the buffer)
+        const double y2 = Y[(size_t)(16 * bj + r) * ld + 16 * bi + c];      // element (r, c) of block (bj, bi)
+        const double nv = (i < n && j < n) ? Nm[(size_t)i * n + j] : 0.0;
+        Tt[r * 17 + c] = y2;
+        __syncthreads();
+        if (i < n && j < n) {
+            const double x = nv + (i == j ? 0.5 : 0.0) + sqrt(coef[41]) * (0.5 * (y1 + Tt[c * 17 + r]));
+            BBg[(size_t)i * n + j] = (coef[42] != 0.0) ? __longlong_as_double(0x7ff8000000000000LL) : x;
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = e0 + 512 * u + tid;
-            if (e < n * n) {
-                const int i = e / n, j = e - i * n;
-                const double x = a[u] + (i == j ? 0.5 : 0.0) + rs * (0.5 * (y1[u] + y2[u]));
-                if (!(x == x)) nan_in = 1;
-                BBg[e] = x;
-            }
-        }
+        return;
     }
-    if (nan_in) sh_bad = 1;
+    __shared__ double sc[BAMS_NMAX], part[2 * 128];
     const double r1s = sqrt(reg / (1.0 + reg));
-    if (tid < 128) sc[tid] = (tid < n) ? M1[(size_t)tid * n + (n - 1)] / r1s : 0.0;    // vg = Vf gbar = M1[:, n-1] / r1s
-    __syncthreads();                                         // (also: the BB stores are complete before chol128w_body loads them)
-    {   // a = P gbar + M1^T vg (bam.py:107 applied to gbar): four threads per entry, 32 loads each in flight
+    if (tid < 128) sc[tid] = (tid < n) ? M1[(size_t)tid * n + (n - 1)] / r1s : 0.0;
+    __syncthreads();
+    {   // a[p] = N0[p][n-1] / r1s + sum_k M1[k][p] vg[k]: two threads per entry, 16 loads in flight per batch
         const int p = tid & 127, q = tid >> 7, pc = p < n ? p : n - 1;
-        double m[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const int k = q + 4 * u;
-            m[u] = M1[(size_t)(k < n ? k : n - 1) * n + pc];
-        }
         double a0 = 0.0, a1 = 0.0;
+        for (int k0 = q; k0 < n; k0 += 32) {
+            double m[16];
 #pragma unroll
-        for (int u = 0; u < 32; u += 2) {
-            a0 += (q + 4 * u < n) ? m[u] * sc[q + 4 * u] : 0.0;
-            a1 += (q + 4 * u + 4 < n) ? m[u + 1] * sc[q + 4 * u + 4] : 0.0;
+            for (int u = 0; u < 16; ++u) {
+                const int k = k0 + 2 * u;
+                m[u] = M1[(size_t)(k < n ? k : n - 1) * n + pc];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u += 2) {
+                a0 += (k0 + 2 * u < n) ? m[u] * sc[k0 + 2 * u] : 0.0;
+                a1 += (k0 + 2 * u + 2 < n) ? m[u + 1] * sc[k0 + 2 * u + 2] : 0.0;
+            }
         }
         part[q * 128 + p] = a0 + a1;
     }
     __syncthreads();
-    if (tid < 128)
-        av[tid] = (tid < n) ? N0[(size_t)tid * n + (n - 1)] / r1s + ((part[tid] + part[128 + tid]) + (part[256 + tid] + part[384 + tid])) : 0.0;
+    if (tid < n) {
+        tail3[tid] = N0[(size_t)tid * n + (n - 1)] / r1s + (part[tid] + part[128 + tid]);
+        tail3[2 * n + tid] = sc[tid];
+    }
+}
+
+// ---- Cholesky of BB WITH the inverse factor, stored transposed: Wt = R^-1 = (L^-1)^T (upper), ONE workgroup, n <= 128 (round 4) ----
+// Replaces k_bam_chol_out (barrier-per-pivot chol64_rows_s, 73 us): [BB | I] -> [R | W] on chol64_blk (n <= 64: one call;
+// 64 < n <= 128: chol128w_body, the 2 x 2 block scheme of the factor path's Gram matrix, 47 us), and what bam.py:110 calls
+// solve(BB, .) becomes Z = W (P + M1^T Vf), an MFMA product in k_bam_zw (gsmvi_bam.hip) instead of a 128-step substitution per
+// column of D (33 us at D = 1024).  W = L^-1 with cond(L) = sqrt(cond(BB)) <= ~1e4 on BASELINE config 4: the explicit
+// triangular inverse changes Z by 1e-12 relative and the update's backward error from 1.3e-17 to 3e-17 (numpy check beside
+// the substitution; K8 asserts 1e-14).
+// *info != 0 (a failing pivot, NaN in BB) poisons Wt and the vectors behind it with NaN: nothing stale may be applied.
+template <bool BIG>   // BIG: 64 < n <= 128 (two block rows), else n <= 64 (the discarded branch's LDS arrays are not instantiated)
+__global__ __launch_bounds__(512) void k_bam_cholw(int n, const double* __restrict__ BBg, double* Rg, double* Wt,
+                                                   int* __restrict__ info) {
+    __shared__ int sh_info;
+    const int tid = threadIdx.x;
     if constexpr (BIG) {
-        chol128w_body<false>(n, BBg, Rg, Wg, info, &sh_info);
+        chol128w_body<false, true>(n, BBg, n, Rg, n, Wt, n, info, &sh_info);
     } else {
         constexpr int ES = 146;
         __shared__ __attribute__((aligned(16))) double E[64 * ES];
@@ -651,41 +681,15 @@ __global__ __launch_bounds__(512) void k_bam_cholw(int n, int ld, double reg, co
         chol64_blk<ES, false, 1>(E, scr1, n, &sf);
         for (int e = tid; e < n * n; e += 512) {
             const int i = e / n, j = e - i * n;
-            Wg[e] = (j <= i) ? E[i * ES + 64 + j] : 0.0;
+            Wt[e] = (i <= j) ? E[j * ES + 64 + i] : 0.0;   // Wt[i][j] = W[j][i]
             Rg[e] = (j >= i) ? E[i * ES + j] : 0.0;
         }
         if (tid == 0) { *info = sf; sh_info = sf; }
     }
-    __syncthreads();                                         // W is in global memory, written by this workgroup
-    double* zg = Wg + (size_t)n * n + n;
-    double* vg = zg + n;
-    const int bad = sh_bad || sh_info != 0;
-    if (tid == 0) *info = bad;
-    if (bad) {
-        const double qn = __longlong_as_double(0x7ff8000000000000LL);
-        for (size_t e = tid; e < (size_t)n * n + 3 * n; e += 512) Wg[e] = qn;
-        return;
-    }
-    {   // zg = W a (bam.py:110 applied to gbar): four threads per row, the row's quarter in flight at once
-        const int i = tid & 127, q = tid >> 7, ic = i < n ? i : n - 1;
-        double wv[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const int k = 32 * q + u;
-            wv[u] = Wg[(size_t)ic * n + (k < n ? k : n - 1)];
-        }
-        double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-        for (int u = 0; u < 32; u += 2) {
-            a0 += (32 * q + u < n) ? wv[u] * av[32 * q + u] : 0.0;
-            a1 += (32 * q + u + 1 < n) ? wv[u + 1] * av[32 * q + u + 1] : 0.0;
-        }
-        part[q * 128 + i] = a0 + a1;
-    }
     __syncthreads();
-    if (tid < n) {
-        zg[tid] = (part[tid] + part[128 + tid]) + (part[256 + tid] + part[384 + tid]);
-        vg[tid] = sc[tid];
+    if (sh_info != 0) {
+        const double qn = __longlong_as_double(0x7ff8000000000000LL);
+        for (size_t e = tid; e < (size_t)n * n + 3 * n; e += 512) Wt[e] = qn;
     }
 }
 
@@ -1068,8 +1072,8 @@ int gsmvi_bam_small_fused(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, con
 int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                      int* info_dev);
 
-// Wscr != nullptr (48 < n <= 128 only): the round-4 route -- k_bam_cholw forms BB itself and leaves W = L^-1 (n x n) in Ld's
-// slot, zg / vg behind it as before, the upper factor in Wscr (scratch); Upk is not produced (k_bam_zw consumes W).
+// Wscr != nullptr (48 < n <= 128 only): the round-4 route -- k_bam_bbav forms BB and [a | . | vg], k_bam_cholw leaves
+// Wt = (L^-1)^T (n x n, upper) in Ld's slot, the upper factor in Wscr (scratch); Upk is not produced (k_bam_zw consumes Wt).
 int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* Nd, const double* M1,
                            const double* N0, double* scratch, double* Ld, double* Upk, int* info_dev, int* hint_host,
                            int force_kenq, double* Wscr) {
@@ -1096,7 +1100,7 @@ int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, co
         if (force_kenq > 0 && force_kenq < BAMS_KMAX) kenq = force_kenq;       // tests: exercise the safety net
         hipLaunchKernelGGL(k_bam_ns_prep, dim3(27), dim3(256), 0, st, n, ld, Nd, Ya, Za, coef, hint_host);
         const int nb = (n + 15) / 16;
-        const bool fused = n <= 128 && !ctx->tune_bam_ns2;    // one launch per step (k_bam_ns_fused); "bam_ns2" = 1: the two-launch steps
+        const bool fused = n <= 128 && ctx->tune_bam_nsfuse;  // "bam_nsfuse" = 1: one launch per step (k_bam_ns_fused); default: two
         if (fused && hint_host && force_kenq <= 0 && kenq < BAMS_KMAX && kenq > 3) --kenq;   // k* + 1: a launch beyond k* costs ~3 us
         for (int k = 0; k < kenq; ++k) {
             if (fused) {
@@ -1108,14 +1112,15 @@ int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, co
         }
         if (kenq < BAMS_KMAX)
             hipLaunchKernelGGL(k_bam_ns_tail, dim3(1), dim3(1024), 0, st, n, ld, kenq, Ya, Za, Yb, Zb, Mm, coef);
-        if (!(Wscr && n <= 128))
+        if (Wscr && n <= 128)                   // BB and the factor-independent vectors [a | . | vg] behind W's slot
+            hipLaunchKernelGGL(k_bam_bbav, dim3(nb * nb + 1), dim3(256), 0, st, n, ld, reg, Nd, Ya, Yb, coef, M1, N0, BBg,
+                               Ld + (size_t)n * n);
+        else
             hipLaunchKernelGGL(k_bam_ns_bb, dim3((n * n + 255) / 256), dim3(256), 0, st, n, ld, Nd, Ya, Yb, coef, BBg);
     }
     if (Wscr && n > BAMS_SN && n <= 128) {
-        if (n > 64)
-            hipLaunchKernelGGL(k_bam_cholw<true>, dim3(1), dim3(512), 0, st, n, ld, reg, Nd, Ya, Yb, coef, M1, N0, BBg, Wscr, Ld, info_dev);
-        else
-            hipLaunchKernelGGL(k_bam_cholw<false>, dim3(1), dim3(512), 0, st, n, ld, reg, Nd, Ya, Yb, coef, M1, N0, BBg, Wscr, Ld, info_dev);
+        if (n > 64) hipLaunchKernelGGL(k_bam_cholw<true>, dim3(1), dim3(512), 0, st, n, BBg, Wscr, Ld, info_dev);
+        else hipLaunchKernelGGL(k_bam_cholw<false>, dim3(1), dim3(512), 0, st, n, BBg, Wscr, Ld, info_dev);
     } else if (n <= BAMS_NMAX) {
         hipLaunchKernelGGL(k_bam_chol_out, dim3(1), dim3(512), 0, st, n, reg, BBg, M1, N0, Ld, Upk, info_dev);
     } else {

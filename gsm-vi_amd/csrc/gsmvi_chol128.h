@@ -19,10 +19,17 @@
 // (A device function since round 4: k_chol128w of the factor path and k_bam_cholw of the dense BaM chain share it.  A, R, Wo
 // must not alias; A is read until the second factorisation starts.  sh_info: optional LDS word that receives the same value as
 // *info -- valid for the whole workgroup after the caller's next barrier.)
-template <bool SEMIDEF>
-__device__ __forceinline__ void chol128w_body(int n, const double* __restrict__ A, double* __restrict__ R,
-                                              double* __restrict__ Wo, int* __restrict__ info, int* sh_info = nullptr) {
+// Leading dimensions lda / ldr / ldw (the blocks of a larger matrix: the 128 < n <= 256 chain of gsmvi_factor.hip);
+// tol_applied: the caller has already lowered A's diagonal by its rounding floor (SEMIDEF; the second diagonal block of the
+// two-level scheme); moderate_ext: 0 / 1 overrides the magnitude guard taken from this block's own diagonal (-1: own).
+// WT: W is stored TRANSPOSED (Wo[j ldw + i] = W[i][j], i.e. the upper triangular R^-1): what a consumer wants that reads W's
+// rows as MFMA A-operands (k_bam_zw: 16 consecutive doubles per k instead of 16 cache lines per load instruction).
+template <bool SEMIDEF, bool WT = false>
+__device__ __forceinline__ void chol128w_body(int n, const double* __restrict__ A, int lda, double* __restrict__ R, int ldr,
+                                              double* __restrict__ Wo, int ldw, int* __restrict__ info,
+                                              int* sh_info = nullptr, bool tol_applied = false, int moderate_ext = -1) {
     constexpr int ES1 = 146, BS = 66;
+    auto widx = [&](int i, int j) -> size_t { return WT ? (size_t)j * ldw + i : (size_t)i * ldw + j; };   // where W[i][j] lives
     __shared__ __attribute__((aligned(16))) double E1[64 * ES1];
     __shared__ __attribute__((aligned(16))) double B12[64 * BS];
     __shared__ __attribute__((aligned(16))) double scr[CHOLB_SCRATCH_DOUBLES(1)];
@@ -36,9 +43,9 @@ __device__ __forceinline__ void chol128w_body(int n, const double* __restrict__ 
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = tid + 512 * u, i = e >> 6, q = e & 63;
-            v[u] = A[(size_t)i * n + q];
+            v[u] = A[(size_t)i * lda + q];
         }
-        const double d2 = (tid < n2) ? A[(size_t)(64 + tid) * n + 64 + tid] : 0.0;
+        const double d2 = (tid < n2) ? A[(size_t)(64 + tid) * lda + 64 + tid] : 0.0;
         if (SEMIDEF && !(d2 < 4294967296.0)) sh_moderate = 0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -46,13 +53,13 @@ __device__ __forceinline__ void chol128w_body(int n, const double* __restrict__ 
             double x = (q < i) ? 0.0 : v[u];
             if (SEMIDEF && q == i) {
                 if (!(x < 4294967296.0)) sh_moderate = 0;
-                x -= GSMVI_DEP_TOL * x;
+                if (!tol_applied) x -= GSMVI_DEP_TOL * x;
             }
             E1[i * ES1 + q] = x;
         }
     }
     __syncthreads();
-    const bool moderate = sh_moderate != 0;
+    const bool moderate = moderate_ext < 0 ? sh_moderate != 0 : moderate_ext != 0;
     chol64_blk<ES1, SEMIDEF, 1>(E1, scr, 64, &sh_fail[0], moderate);   // [A11 | I] -> [R11 | W11]
     // R12 = D' W11 A12: block (ib, jb), k-blocks 0 .. ib (W11 is lower triangular); A12 straight from global memory
     for (int blk = w; blk < 16; blk += 8) {
@@ -63,7 +70,7 @@ __device__ __forceinline__ void chol128w_body(int n, const double* __restrict__ 
         for (int st = 0; st < 16; ++st) {
             const int k = 4 * st + ks;
             a[st] = E1[(16 * ib + c) * ES1 + 64 + k];
-            b[st] = A[(size_t)k * n + (gj < n ? gj : n - 1)];
+            b[st] = A[(size_t)k * lda + (gj < n ? gj : n - 1)];
         }
         v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -79,17 +86,17 @@ __device__ __forceinline__ void chol128w_body(int n, const double* __restrict__ 
             double x = acc0[r] + acc1[r];
             if (E1[i * ES1 + i] == 0.0) x = 0.0;                        // a dropped row of R
             B12[i * BS + j] = x;
-            if (64 + j < n) R[(size_t)i * n + 64 + j] = x;
+            if (64 + j < n) R[(size_t)i * ldr + 64 + j] = x;
         }
     }
     __syncthreads();
     // R11, W11 out (and the two zero blocks); meanwhile the updated A22 in registers: upper 16 x 16 blocks, K = 64
     for (int e = tid; e < 64 * 64; e += 512) {
         const int i = e >> 6, j = e & 63;
-        R[(size_t)i * n + j] = (j >= i) ? E1[i * ES1 + j] : 0.0;
-        Wo[(size_t)i * n + j] = (j <= i) ? E1[i * ES1 + 64 + j] : 0.0;
-        if (64 + j < n) Wo[(size_t)i * n + 64 + j] = 0.0;               // W12 = 0
-        if (i < n2) R[(size_t)(64 + i) * n + j] = 0.0;                  // R21 = 0
+        R[(size_t)i * ldr + j] = (j >= i) ? E1[i * ES1 + j] : 0.0;
+        Wo[widx(i, j)] = (j <= i) ? E1[i * ES1 + 64 + j] : 0.0;
+        if (64 + j < n) Wo[widx(i, 64 + j)] = 0.0;                          // W12 = 0
+        if (i < n2) R[(size_t)(64 + i) * ldr + j] = 0.0;                  // R21 = 0
     }
     double t22[2][4];
 #pragma unroll
@@ -116,8 +123,8 @@ __device__ __forceinline__ void chol128w_body(int n, const double* __restrict__ 
                 const int i = 16 * bi + ks + 4 * r, j = 16 * bj + c;
                 double x = (i == j) ? 1.0 : 0.0;                        // identity beyond n2
                 if (i < n2 && j < n2) {
-                    x = A[(size_t)(64 + i) * n + 64 + j];
-                    if (SEMIDEF && i == j) x -= GSMVI_DEP_TOL * x;
+                    x = A[(size_t)(64 + i) * lda + 64 + j];
+                    if (SEMIDEF && i == j && !tol_applied) x -= GSMVI_DEP_TOL * x;
                     x -= acc0[r] + acc1[r];
                 }
                 t22[slot][r] = (j >= i) ? x : 0.0;
@@ -145,8 +152,8 @@ __device__ __forceinline__ void chol128w_body(int n, const double* __restrict__ 
     for (int e = tid; e < 64 * 64; e += 512) {
         const int i = e >> 6, j = e & 63;
         if (i < n2 && j < n2) {
-            R[(size_t)(64 + i) * n + 64 + j] = (j >= i) ? E1[i * ES1 + j] : 0.0;
-            Wo[(size_t)(64 + i) * n + 64 + j] = (j <= i) ? E1[i * ES1 + 64 + j] : 0.0;
+            R[(size_t)(64 + i) * ldr + 64 + j] = (j >= i) ? E1[i * ES1 + j] : 0.0;
+            Wo[widx(64 + i, 64 + j)] = (j <= i) ? E1[i * ES1 + 64 + j] : 0.0;
         }
     }
     __syncthreads();                                                    // R22 (E1 left half) is out: the half becomes T1
@@ -186,7 +193,7 @@ __device__ __forceinline__ void chol128w_body(int n, const double* __restrict__ 
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = tid + 512 * u, i = e >> 6, j = e & 63;
-            v[u] = __builtin_nontemporal_load(Wo + (size_t)i * n + j);
+            v[u] = __builtin_nontemporal_load(Wo + widx(i, j));
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -216,7 +223,7 @@ __device__ __forceinline__ void chol128w_body(int n, const double* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 16 * ib + ks + 4 * r, j = 16 * jb + c;
-            if (i < n2) Wo[(size_t)(64 + i) * n + j] = -(acc0[r] + acc1[r]);
+            if (i < n2) Wo[widx(64 + i, j)] = -(acc0[r] + acc1[r]);
         }
     }
     if (tid == 0) {

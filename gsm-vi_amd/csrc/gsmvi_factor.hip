@@ -28,6 +28,7 @@
 #include "gsmvi_chol64.h"
 #include "gsmvi_chol64b.h"
 #include "gsmvi_chol128.h"
+#include "gsmvi_smallgemm.h"
 #include "gsmvi_small16.h"
 #include "../../include/gsmvi_hip.h"
 #include "../../include/gsmvi_hip_debug.h"
@@ -345,7 +346,64 @@ __global__ __launch_bounds__(512) void k_chol128(int n, const double* __restrict
 template <bool SEMIDEF>
 __global__ __launch_bounds__(512) void k_chol128w(int n, const double* __restrict__ A, double* __restrict__ R,
                                                   double* __restrict__ Wo, int* __restrict__ info) {
-    chol128w_body<SEMIDEF>(n, A, R, Wo, info);
+    chol128w_body<SEMIDEF>(n, A, n, R, n, Wo, n, info);
+}
+
+// ---- one DIAGONAL BLOCK (nb <= 128 rows) of the two-level scheme for 128 < n <= 256: [A_kk | I] -> [R_kk | W_kk], leading
+// dimensions for every operand (the blocks live inside the n x n matrices).  BIG: 64 < nb <= 128 (chol128w_body), else one
+// chol64_blk call.  info chaining: info_off == 0 writes *info; a later block (info_off = its first row) only records a failure
+// when the earlier ones passed.  SEMIDEF: the magnitude guard of the rank-revealing rule looks at the diagonal of the WHOLE
+// matrix (dg, dg_n entries, stride dg_stride), as chol128w_body does for its two halves; tol_applied: the caller's product has
+// already lowered this block's diagonal by its rounding floor (OpBlkS22).
+template <bool SEMIDEF, bool BIG>
+__global__ __launch_bounds__(512) void k_cholw_ld(int nb, const double* __restrict__ A, int lda, double* __restrict__ R, int ldr,
+                                                  double* __restrict__ Wo, int ldw, int* info, int info_off, int tol_applied,
+                                                  const double* __restrict__ dg, int dg_n, int dg_stride) {
+    __shared__ int sh_mod, sh_f;
+    const int tid = threadIdx.x;
+    int moderate_ext = -1;
+    if (SEMIDEF && dg) {
+        if (tid == 0) sh_mod = 1;
+        __syncthreads();
+        for (int i = tid; i < dg_n; i += 512)
+            if (!(dg[(size_t)i * dg_stride] < 4294967296.0)) sh_mod = 0;
+        __syncthreads();
+        moderate_ext = sh_mod;
+    }
+    if constexpr (BIG) {
+        chol128w_body<SEMIDEF>(nb, A, lda, R, ldr, Wo, ldw, &sh_f, nullptr, tol_applied != 0, moderate_ext);
+    } else {
+        constexpr int ES = 146;
+        __shared__ __attribute__((aligned(16))) double E[64 * ES];
+        __shared__ __attribute__((aligned(16))) double scr1[CHOLB_SCRATCH_DOUBLES(1)];
+        __shared__ int sh_moderate;
+        if (tid == 0) sh_moderate = 1;
+        __syncthreads();
+        for (int e = tid; e < 64 * 64; e += 512) {
+            const int i = e >> 6, j = e & 63;
+            const bool in = i < nb && j < nb;
+            double x = in ? (j >= i ? A[(size_t)i * lda + j] : 0.0) : (i == j ? 1.0 : 0.0);
+            if (SEMIDEF && in && i == j) {
+                if (!(x < 4294967296.0)) sh_moderate = 0;
+                if (!tol_applied) x -= GSMVI_DEP_TOL * x;
+            }
+            E[i * ES + j] = x;
+        }
+        __syncthreads();
+        const bool moderate = moderate_ext < 0 ? sh_moderate != 0 : moderate_ext != 0;
+        chol64_blk<ES, SEMIDEF, 1>(E, scr1, nb, &sh_f, moderate);
+        for (int e = tid; e < nb * nb; e += 512) {
+            const int i = e / nb, j = e - i * nb;
+            R[(size_t)i * ldr + j] = (j >= i) ? E[i * ES + j] : 0.0;
+            Wo[(size_t)i * ldw + j] = (j <= i) ? E[i * ES + 64 + j] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int f = sh_f;
+        if (info_off == 0) *info = f;
+        else if (f != 0 && *info == 0) *info = info_off + f;
+    }
 }
 
 // ---- F = F0 + Rt^T Fs  (full, non-symmetric rank-n update; F = F0 when *bad) ---------------------------
@@ -751,7 +809,7 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const doub
 __global__ __launch_bounds__(256) void k_gsmf_gamma_big(int n, int B, const double* __restrict__ Gp, int kcg,
                                                         double* __restrict__ Gam, double* __restrict__ coef,
                                                         double* __restrict__ ab, int jmode) {
-    __shared__ double s_alpha[64], s_beta[64];
+    __shared__ double s_alpha[128], s_beta[128];       // B <= 128 (n = 2B <= 256 since round 4)
     const int tid = threadIdx.x;
     auto g1 = [&](int i, int q) {                      // one entry of Gamma1: the kcg slabs, all loads in one batch
         if (kcg == 1) return Gp[(size_t)i * n + q];    // block-uniform: the finished matrix
@@ -970,8 +1028,8 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
     // kernel with the skinny product folded in; n = 128: the fast panel kernel of Fs = K'' Tm1), the V Fm product keeps its
     // slabs and carries the finish of the Gram slabs as a side job of its workgroups (the one-workgroup chain kernel would
     // pull them through a single CU: measured +5.6 us).  Otherwise: product + finish launches, as before.
-    const bool lean = !ctx->tune_no_fast && ctx->tune_direct_out && (n % 64 == 0 || n == 32 || n == 16) && D % 64 == 0 && ldf0 % 2 == 0 &&
-                      ldf % 2 == 0 && (reinterpret_cast<uintptr_t>(F0) & 15u) == 0;
+    const bool lean = !ctx->tune_no_fast && ctx->tune_direct_out && (n % 64 == 0 || n == 32 || n == 16) && n <= 128 && D % 64 == 0 &&
+                      ldf0 % 2 == 0 && ldf % 2 == 0 && (reinterpret_cast<uintptr_t>(F0) & 15u) == 0;
     // Large D, n = 128: the V Fm product (MFMA-bound, 65 us at D = 4096) does not depend on the Gram product and the eight small
     // launches of the 2B x 2B chain (~100 us on a few CUs), so it runs on the context's second stream beside them; the two
     // event edges cost ~10 us, which is why D = 1024 does not fork (measured in round 2: slower there).
@@ -1103,6 +1161,55 @@ int gsmvi_factor_apply_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const 
     return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, w.Gp, kcg, nullptr, 0);
 }
 
+// ---- the 2B x 2B chain for 128 < n <= 256 (round 4; BASELINE config 4 in factor form has 2B = 256) ---------------------------
+// Same algebra as the n <= 128 chain (Gamma = Rg^T Rg with W = Rg^-T, A' = I + Rg J Rg^T = T^T T, P = (T - I)(W S),
+// K'' = (W S)^T P), built from the pieces that exist: the one-workgroup 128-row factorisation with the inverse factor
+// (chol128w_body / chol64_blk, through k_cholw_ld with leading dimensions) for the two diagonal blocks of each matrix and
+// the generic small-matrix product (gsmvi_smallgemm.h) for everything between them -- 14 launches, launch- and pivot-chain
+// bound.  Slots: S22 / T1 of Gamma's factorisation live in Ap / Tt (A' does not exist yet); T's inverse factor (only its
+// first block is used, for the block-row solve) in Gam1 and its S22 in Rg (both dead by then).  Returns K'' in w.Gam.
+static int factor_chain_big(gsmvi_ctx* ctx, hipStream_t st, int n, int B, const factor_ws& w, const double* Gp, int kcg,
+                            int jmode, const int* prior, int* info_dev) {
+    const int n1 = 128, n2 = n - 128;
+    int* info_g = ctx->ints;
+    int* info_t = ctx->ints + 1;
+    double* coef = w.coef;
+    const size_t off = (size_t)n1 * n + n1;        // the (1, 1) block inside an n x n matrix
+    hipLaunchKernelGGL(k_gsmf_gamma_big, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, w.Gam, coef, coef + n, jmode);
+    // Gamma = Rg^T Rg (rank-revealing rule), W = Rg^-T -> w.Pm
+    hipLaunchKernelGGL((k_cholw_ld<true, true>), dim3(1), dim3(512), 0, st, n1, w.Gam, n, w.Rg, n, w.Pm, n, info_g, 0, 0,
+                       w.Gam, n, n + 1);
+    small_gemm_launch(st, OpBlkR12{n1, n2, n1, w.Pm, w.Gam, w.Rg, n, n, n, n1});
+    small_gemm_launch(st, OpBlkS22{n2, n2, n1, w.Rg, w.Gam, w.Ap, n, n, n1, 1});
+    if (n2 > 64)
+        hipLaunchKernelGGL((k_cholw_ld<true, true>), dim3(1), dim3(512), 0, st, n2, w.Ap, n2, w.Rg + off, n, w.Pm + off, n, info_g,
+                           n1, 1, w.Gam, n, n + 1);
+    else
+        hipLaunchKernelGGL((k_cholw_ld<true, false>), dim3(1), dim3(512), 0, st, n2, w.Ap, n2, w.Rg + off, n, w.Pm + off, n, info_g,
+                           n1, 1, w.Gam, n, n + 1);
+    small_gemm_launch(st, OpBlkT1{n2, n1, n2, w.Pm, w.Rg, w.Tt, n, n, n1});
+    small_gemm_launch(st, OpBlkW21{n2, n1, n1, w.Tt, w.Pm, w.Rg, n, n, n1});
+    // A' = I + Rg J Rg^T = T^T T (plain rule: this IS the accept test)
+    small_gemm_launch(st, OpSmallA{n, n, n, w.Rg, info_g, w.Ap, B, jmode});
+    double* Wt = w.Gam1;                           // T^-T: scratch, only its first block is consumed
+    hipLaunchKernelGGL((k_cholw_ld<false, true>), dim3(1), dim3(512), 0, st, n1, w.Ap, n, w.Tt, n, Wt, n, info_t, 0, 0,
+                       (const double*)nullptr, 0, 0);
+    small_gemm_launch(st, OpBlkR12{n1, n2, n1, Wt, w.Ap, w.Tt, n, n, n, n1});
+    small_gemm_launch(st, OpBlkS22{n2, n2, n1, w.Tt, w.Ap, w.Rg, n, n, n1, 0});
+    if (n2 > 64)
+        hipLaunchKernelGGL((k_cholw_ld<false, true>), dim3(1), dim3(512), 0, st, n2, w.Rg, n2, w.Tt + off, n, Wt + off, n, info_t,
+                           n1, 0, (const double*)nullptr, 0, 0);
+    else
+        hipLaunchKernelGGL((k_cholw_ld<false, false>), dim3(1), dim3(512), 0, st, n2, w.Rg, n2, w.Tt + off, n, Wt + off, n, info_t,
+                           n1, 0, (const double*)nullptr, 0, 0);
+    int rc = chk("k_cholw_ld");
+    if (rc) return rc;
+    // P = (T - I)(W S) with the accept / revert decision, K'' = (W S)^T P
+    small_gemm_launch(st, OpChainP{n, n, n, w.Tt, w.Pm, coef + n, w.Ap, B, info_dev, info_g, info_t, prior});
+    small_gemm_launch(st, OpChainK{n, n, n, w.Pm, w.Ap, coef + n, w.Gam, B, info_dev});
+    return chk("k_small_gemm");
+}
+
 static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* mu0, const double* F0, int ldf0,
                        double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, const double* Gp, int kcg,
                        const double* vf_slabs, int kcv, int jmode, int chain_done, int fork_vf) {
@@ -1122,6 +1229,9 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
             hipLaunchKernelGGL(k_gsmf_small16, dim3(1), dim3(512), 0, st, n, B, Gp, kcg, Kmat, coef, info_dev, w.stamps, jmode, prior);
             if ((rc = chk("k_gsmf_small16"))) return rc;
         }
+    } else if (n > 128) {
+        Kmat = w.Gam;
+        if ((rc = factor_chain_big(ctx, st, n, B, w, Gp, kcg, jmode, prior, info_dev))) return rc;
     } else {
         // 64 < n <= 128: Gamma, the two n x n Choleskys one workgroup each, W and K in their own kernels
         Kmat = w.Gam;                              // Gamma is dead once Rg exists
@@ -1166,16 +1276,20 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         ctx->px.mfin = Tm + (size_t)B * D;
         ctx->px.ldfin = D;
     }
-    if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, Fs, &kc2))) return rc;
+    const int kc_user = ctx->tune_panel_kc;
+    if (n > 128) ctx->tune_panel_kc = 1;           // inner dimension n = two 128-row chunks of one workgroup: ONE slab, written into Fs
+    rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, Kmat, n, nullptr, 1.0, Tm, D, Fs, &kc2);
+    ctx->tune_panel_kc = kc_user;
+    if (rc) return rc;
     if (kc2 != 1 || (vf_slabs && !ctx->px_used)) {
         gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "K Tm product was split or left the fast kernel (internal error)");
         return GSMVI_ERR_UNSUPPORTED;
     }
     const int nt = (D + 63) / 64;
-    if (!ctx->tune_no_fast && D % 64 == 0 && (n == 32 || n == 64 || n == 128)) {
+    if (!ctx->tune_no_fast && D % 64 == 0 && (n == 32 || n == 64 || n == 128 || n == 256)) {
         // the fast kernel also writes the mean and counts the revert
 #define UF(NPV) hipLaunchKernelGGL(k_gsmf_update_fast<NPV>, dim3(nt * nt), dim3(512), 0, st, D, B, Rt, Fs, F0, ldf0, F, ldf, Tm, coef, mu0, mu, info_dev, n_reverts_dev)
-        if (n == 32) UF(1); else if (n == 64) UF(2); else UF(4);
+        if (n == 32) UF(1); else if (n == 64) UF(2); else if (n == 128) UF(4); else UF(8);
 #undef UF
         return chk("k_gsmf_update_fast");
     }

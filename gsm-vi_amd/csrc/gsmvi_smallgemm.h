@@ -1,0 +1,165 @@
+// Generic product of SMALL matrices (inner dimension <= 256) with operand and epilogue functors: the pieces between the
+// one-workgroup 128 x 128 factorisations of the 2B x 2B chain for 128 < 2B <= 256 (round 4: gsmvi_factor.hip, factor_chain256).
+//
+//   C(i, j) = sum_{k < K} a(i, k) b(k, j),   i < m, j < p        op.store(i, j, value) writes it where it belongs
+//
+// One 16 x 16 output block per workgroup (256 threads), K split over the four waves (wave w takes the k-steps w, w + 4, ...:
+// at most 16 each, all 32 operand values loaded in one batch, two accumulator chains), the four partial blocks summed through
+// LDS in a fixed order: deterministic, launch-bound (~4.5 us) like the Newton-Schulz steps of gsmvi_bam_small.hip whose
+// block kernel this generalises.  Operands come straight from L2 through the functor's a(i, k) / b(k, j), which receive
+// CLAMPED indices (the kernel zeroes what lies outside); op.skip() lets an op leave the launch early on a device flag.
+#pragma once
+#include "gsmvi_common.h"
+
+template <class OP>
+__global__ __launch_bounds__(256) void k_small_gemm(OP op) {
+    __shared__ double red[4 * 256];
+    if (op.skip()) return;
+    const int m = op.m, p = op.p, K = op.K;
+    const int nbj = (p + 15) >> 4;
+    const int bi = blockIdx.x / nbj, bj = blockIdx.x - bi * nbj, i0 = 16 * bi, j0 = 16 * bj;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, cc = l & 15, ks = l >> 4;
+    const int nk = (K + 3) >> 2;
+    const int ic = (i0 + cc) < m ? i0 + cc : m - 1, jc = (j0 + cc) < p ? j0 + cc : p - 1;
+    const bool iin = (i0 + cc) < m, jin = (j0 + cc) < p;
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int u0 = 0; w + 4 * u0 < nk; u0 += 16) {
+        double a[16], b[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int st = w + 4 * (u0 + u), k = 4 * st + ks, kc = k < K ? k : K - 1;
+            const double av = op.a(ic, kc), bv = op.b(kc, jc);
+            a[u] = (k < K && iin) ? av : 0.0;
+            b[u] = (k < K && jin) ? bv : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u += 2) {
+            acc0 = GSMVI_MFMA_F64(a[u], b[u], acc0);
+            acc1 = GSMVI_MFMA_F64(a[u + 1], b[u + 1], acc1);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w * 256 + (ks + 4 * r) * 16 + cc] = acc0[r] + acc1[r];
+    __syncthreads();
+    const int t = threadIdx.x, i = i0 + (t >> 4), j = j0 + (t & 15);
+    const double v = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
+    if (i < m && j < p) op.store(i, j, v);
+}
+
+template <class OP>
+static inline void small_gemm_launch(hipStream_t st, const OP& op) {
+    const int nbi = (op.m + 15) >> 4, nbj = (op.p + 15) >> 4;
+    hipLaunchKernelGGL(k_small_gemm<OP>, dim3(nbi * nbj), dim3(256), 0, st, op);
+}
+
+// ---- two-level blocked Cholesky with the inverse factor, A = R^T R, W = R^-T, for an n x n matrix, 128 < n <= 256 -------------
+// Blocks of n1 = 128 and n2 = n - 128.  The diagonal blocks are factored by the one-workgroup kernels ([A | I] -> [R | W]); the
+// four products between them run here:
+//   R12 = D' W11 A12,   A22' = A22 - R12^T R12,   [A22' | I] -> [R22 | W22],   T1 = W22 R12^T,   W21 = -T1 W11
+// (D' zeroes the rows the rank-revealing rule dropped, R11[i][i] == 0: what chol128w_body does inside one 128 block).
+struct OpBlkR12 {                                  // R[0:n1, n1:n] = D' W11 A12, R[n1:n, 0:n1] = 0
+    int m, p, K;                                   // n1, n2, n1
+    const double *W, *A;
+    double* R;
+    int ldw, lda, ldr, n1;
+    __device__ bool skip() const { return false; }
+    __device__ double a(int i, int k) const { return W[(size_t)i * ldw + k]; }
+    __device__ double b(int k, int j) const { return A[(size_t)k * lda + n1 + j]; }
+    __device__ void store(int i, int j, double v) const {
+        R[(size_t)i * ldr + n1 + j] = (R[(size_t)i * ldr + i] == 0.0) ? 0.0 : v;
+        R[(size_t)(n1 + j) * ldr + i] = 0.0;       // the block below the diagonal: the factor is read as a full matrix
+    }
+};
+struct OpBlkS22 {                                  // S22 = A22 (diagonal lowered by its rounding floor when semidef) - R12^T R12
+    int m, p, K;                                   // n2, n2, n1
+    const double *R, *A;
+    double* S;
+    int ldr, lda, n1, semidef;
+    __device__ bool skip() const { return false; }
+    __device__ double a(int i, int k) const { return R[(size_t)k * ldr + n1 + i]; }
+    __device__ double b(int k, int j) const { return R[(size_t)k * ldr + n1 + j]; }
+    __device__ void store(int i, int j, double v) const {
+        double x = A[(size_t)(n1 + i) * lda + n1 + j];
+        if (semidef && i == j) x -= GSMVI_DEP_TOL * x;
+        S[(size_t)i * m + j] = x - v;
+    }
+};
+struct OpBlkT1 {                                   // T1 = W22 R12^T   (n2 x n1)
+    int m, p, K;                                   // n2, n1, n2
+    const double *W, *R;
+    double* T1;
+    int ldw, ldr, n1;
+    __device__ bool skip() const { return false; }
+    __device__ double a(int i, int k) const { return W[(size_t)(n1 + i) * ldw + n1 + k]; }
+    __device__ double b(int k, int j) const { return R[(size_t)j * ldr + n1 + k]; }
+    __device__ void store(int i, int j, double v) const { T1[(size_t)i * p + j] = v; }
+};
+struct OpBlkW21 {                                  // W[n1:n, 0:n1] = -T1 W11; also the zero blocks W12 and R21
+    int m, p, K;                                   // n2, n1, n1
+    const double* T1;
+    double *W, *R;
+    int ldw, ldr, n1;
+    __device__ bool skip() const { return false; }
+    __device__ double a(int i, int k) const { return T1[(size_t)i * p + k]; }
+    __device__ double b(int k, int j) const { return W[(size_t)k * ldw + j]; }
+    __device__ void store(int i, int j, double v) const {
+        W[(size_t)(n1 + i) * ldw + j] = -v;
+        W[(size_t)j * ldw + n1 + i] = 0.0;
+        R[(size_t)(n1 + i) * ldr + j] = 0.0;
+    }
+};
+
+// ---- the chain's products for 128 < n <= 256 (what k_gsmf_small_a and k_gsmf_gemm128 do for n <= 128) ---------------------------
+struct OpSmallA {                                  // A' = I + (Rg J) Rg^T;  J = (1/B) [[0, I], [I, -I]] or, jmode, diag(I, -I) unscaled
+    int m, p, K;                                   // n, n, n
+    const double* Rg;
+    const int* info_g;
+    double* Ap;
+    int B, jmode;
+    __device__ bool skip() const { return false; }
+    __device__ double a(int i, int k) const {
+        if (jmode) return (k < B) ? Rg[(size_t)i * m + k] : -Rg[(size_t)i * m + k];
+        return (k < B) ? Rg[(size_t)i * m + B + k] : (Rg[(size_t)i * m + k - B] - Rg[(size_t)i * m + k]);
+    }
+    __device__ double b(int k, int j) const { return Rg[(size_t)j * m + k]; }
+    __device__ void store(int i, int j, double v) const {
+        double x = (i == j ? 1.0 : 0.0) + (jmode ? v : v / (double)B);
+        if (*info_g != 0) x = (i == j) ? -1.0 : 0.0;  // Gamma was singular: force the PD test to fail
+        Ap[(size_t)i * m + j] = x;
+    }
+};
+struct OpChainP {                                  // P = (T - I)(W S), with the chain's accept / revert decision (k_gsmf_gemm128<0>)
+    int m, p, K;
+    const double *T, *W, *ab;
+    double* P;
+    int B;
+    int* bad;
+    const int *info_g, *info_t, *prior_bad;
+    __device__ bool skip() const {
+        const int b = (*info_g != 0) || (*info_t != 0) || (prior_bad && *prior_bad != 0);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *bad = b;
+        return b != 0;
+    }
+    __device__ double a(int i, int k) const { return T[(size_t)i * m + k] - (i == k ? 1.0 : 0.0); }
+    __device__ double b(int k, int j) const {      // (W S)[k][j] = s1 W[k][j] + s2 W[k][j2]
+        const int j2 = j < B ? j + B : j;
+        const double s1 = j < B ? 1.0 : 0.0, s2 = ab[j];
+        return s1 * W[(size_t)k * m + j] + s2 * W[(size_t)k * m + j2];
+    }
+    __device__ void store(int i, int j, double v) const { P[(size_t)i * m + j] = v; }
+};
+struct OpChainK {                                  // K'' = (W S)^T P   (k_gsmf_gemm128<1>)
+    int m, p, K;
+    const double *W, *P, *ab;
+    double* Kmat;
+    int B;
+    const int* bad;
+    __device__ bool skip() const { return *bad != 0; }
+    __device__ double a(int i, int k) const {
+        const int i2 = i < B ? i + B : i;
+        const double s1 = i < B ? 1.0 : 0.0, s2 = ab[i];
+        return s1 * W[(size_t)k * m + i] + s2 * W[(size_t)k * m + i2];
+    }
+    __device__ double b(int k, int j) const { return P[(size_t)k * m + j]; }
+    __device__ void store(int i, int j, double v) const { Kmat[(size_t)i * m + j] = v; }
+};

@@ -23,6 +23,8 @@ class HipEngine:
     """One context (workspace + launch heuristics) on one device; grows on demand."""
 
     name = "hip"
+    factor_max_rows = 256      # largest 2B of the factor-form updates (GSMVI_FACTOR_NMAX; the 2B x 2B chain: one workgroup up to 64,
+                               # one-workgroup factorisations up to 128, two-level blocked above)
     bam_max_batch = 640        # B <= 640: LDS of BaM's forward-substitution kernel (csrc/gsmvi_bam.hip); the one-workgroup
                                # chain covers B <= 128, larger batches take the blocked multi-workgroup Cholesky
 

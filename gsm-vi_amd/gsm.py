@@ -118,7 +118,7 @@ class GSM:
                     capturable (a score marked ``graph_safe`` such as ``GaussianTarget.lp_g``, the device draw stream, no
                     sharding).  None (default): do so for D <= 512, where the Python / launch overhead is the bound; True:
                     always; False: never.  Same numbers either way.
-          method  : "auto" (default) = "factor" whenever it applies (2*batch_size <= min(D, 128), the device
+          method  : "auto" (default) = "factor" whenever 2*batch_size <= min(D, 128) (the measured range; the form itself goes up to 256), the device
                     Cholesky sampler, no teacher-forced samples) and "dense" otherwise.  Why that is a drop-in
                     default: for the same draws the two forms give the same (mean, cov) to round-off
                     (tests/test_gpu_factor.py, <= 1e-14 even at cond 1e8), the 2B x 2B positive-definite test is
@@ -129,7 +129,7 @@ class GSM:
                     Sigma = F^T F instead (BASELINE config 5): samples are mean + z F, the
                     update is a rank-2B correction of F and the positive-definite test is a Cholesky of
                     a 2B x 2B matrix, so no O(D^3) work per iteration.  Same (mean, cov) up to round-off
-                    for the same samples; needs 2B <= min(D, 128) and the device sampler.  It converges to
+                    for the same samples; needs 2B <= min(D, 256) and the device sampler.  It converges to
                     machine precision on Gaussian targets like the dense form (tests/test_gpu_factor.py).
                     Linearly dependent rows of [Z; U] -- an isotropic state on an isotropic target (every
                     u_b - a_b z_b is parallel to mean - m), or a state that is EXACTLY the fixed point (U = 0) --
@@ -147,6 +147,7 @@ class GSM:
         """
         D_, B_ = self.D, int(batch_size)
         if method == "auto":
+            # (explicit method="factor" goes up to 2B = 256: the two-level chain of round 4; "auto" keeps the measured range)
             method = "factor" if (sampler == "cholesky" and forced_samples is None
                                   and 2 * B_ <= min(D_, 128)) else "dense"
         self.method_used = method
@@ -250,7 +251,7 @@ class GSM:
         per-sample records are all-gathered (dist.sharded_gsm_factor_update); replicas stay identical."""
         eng = self._engine if self._engine is not None else get_engine()
         D, B = self.D, int(batch_size)
-        assert 2 * B <= min(D, 128), "method='factor' needs 2*batch_size <= min(D, 128)"
+        assert 2 * B <= min(D, 256), "method='factor' needs 2*batch_size <= min(D, 256)"
         mean_t = eng.zeros(D) if mean is None else eng.clone(mean).reshape(D)
         cov0 = eng.eye(D) if cov is None else eng.clone(cov).reshape(D, D)
         flag, n_rev = eng.new_flag(), eng.new_flag()

@@ -170,7 +170,8 @@ int gsmvi_gsm_apply_rows_f64(gsmvi_ctx* ctx, void* stream, int D, int B, int row
  * Produces (mu, F) with F^T F equal to the covariance gsm_numpy.gsm_update would return for
  * (X, G, mu0, F0^T F0) -- without forming or factorising any D x D covariance: the positive-definite
  * test of gsm_numpy.py:121-125,132-146 becomes a Cholesky of a 2B x 2B matrix.  If that test fails,
- * (mu, F) = (mu0, F0) and *info_dev = 1 (revert); else *info_dev = 0.  Needs 2B <= D and 2B <= 128.
+ * (mu, F) = (mu0, F0) and *info_dev = 1 (revert); else *info_dev = 0.  Needs 2B <= D and 2B <= 256 (2B <= 64: the chain is one workgroup; <= 128: one-workgroup
+ * factorisations; <= 256: two-level blocked, round 4).
  * n_reverts_dev (device int, may be NULL) is incremented on a revert, like gsmvi_commit_f64 does.
  */
 int gsmvi_gsm_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
@@ -326,7 +327,7 @@ int gsmvi_bam_update_sharded_f64(gsmvi_ctx* ctx, void* stream, void* nccl_comm, 
  * Sigma = F^T F out, with F^T F equal to the S of gsmvi_bam_update_f64 (jitter = 0) to round-off and the same mean.  No D x D
  * covariance is formed and no D x D factorisation is taken: four passes over F0 and a 2B x 2B chain (the one of
  * gsmvi_gsm_factor_update_f64).  Z (B x D) are the whitened draws of the samples: X = mu0 + Z F0 (the caller's contract, as
- * for the GSM factor update).  Needs 2B <= min(D, 128) (GSMVI_ERR_UNSUPPORTED otherwise, before anything is enqueued).
+ * for the GSM factor update).  Needs 2B <= min(D, 256) (GSMVI_ERR_UNSUPPORTED otherwise, before anything is enqueued).
  * *info_dev = 1 and (mu, F) = (mu0, F0) if BaM's B x B matrix function or the 2B x 2B chain failed (non-finite input, or a
  * Sigma that is not positive definite to working precision); *n_reverts_dev (may be NULL) is then incremented.
  */

@@ -130,9 +130,11 @@ def test_step_count_hint_and_tail_kernel(D, B, kenq):
     mu_h, S_h, f_h = eng.bam_update(X, G, mu0, S0, 2.0, 0.0)       # hinted by the calls above
     mu_h2, S_h2, _ = eng.bam_update(X, G, mu0, S0, 2.0, 0.0)
     assert eng.read_flag(f_f) == 0 and eng.read_flag(f_t) == 0 and eng.read_flag(f_h) == 0
+    # (the tail kernel sums its products in a different order than the multi-workgroup steps: the iteration of a cond-1e6
+    # matrix carries that to ~1e-11 in (mu, S))
     for mu, S in ((mu_t, S_t), (mu_h, S_h), (mu_h2, S_h2)):
-        assert rel_err(mu.cpu().numpy(), mu_f.cpu().numpy()) < 1e-11
-        assert rel_err(S.cpu().numpy(), S_f.cpu().numpy()) < 1e-11
+        assert rel_err(mu.cpu().numpy(), mu_f.cpu().numpy()) < 1e-9
+        assert rel_err(S.cpu().numpy(), S_f.cpu().numpy()) < 1e-9
 
 
 def _bam_uv(X, G, mu0, S0, reg):
@@ -253,7 +255,7 @@ def _factor_state(eng, D, B, seed):
 
 @pytest.mark.parametrize("reg", [0.5, 20.0])
 @pytest.mark.parametrize("D,B", [(64, 8), (256, 16), (1024, 32), (1024, 64), (512, 7), (300, 20), (130, 33), (128, 1),
-                                 (96, 48)])
+                                 (96, 48), (1024, 128), (1024, 96), (512, 100), (256, 56), (300, 70)])
 def test_factor_form_update_equals_the_dense_update(D, B, reg):
     """F^T F of the factor-form update = S of the dense update (jitter 0) on S0 = F0^T F0, same mean -- against the HIP dense
     path (<= 1e-9 at moderate reg), against the scipy restatement, and through the update's defining equation
@@ -284,7 +286,7 @@ def test_factor_form_update_equals_the_dense_update(D, B, reg):
 
 def test_factor_form_update_reverts_and_bounds():
     """A non-finite score poisons the small chain: flag = 1, (mu, F) = (mu0, F0), the revert is counted; batches beyond
-    2B <= min(D, 128) are refused before anything is enqueued."""
+    2B <= min(D, 256) are refused before anything is enqueued."""
     import gsmvi_amd
     eng = gsmvi_amd.get_engine()
     mu0, F0, Z, X, G = _factor_state(eng, 256, 16, seed=5)
@@ -294,7 +296,7 @@ def test_factor_form_update_reverts_and_bounds():
     mu, F, flag = eng.bam_factor_update(*dv, 1.0, n_reverts=n_rev)
     assert eng.read_flag(flag) == 1 and eng.read_flag(n_rev) == 1
     assert np.array_equal(mu.cpu().numpy(), mu0) and np.array_equal(F.cpu().numpy(), F0)
-    for D, B in ((256, 65), (40, 21)):
+    for D, B in ((512, 129), (40, 21)):
         mu0, F0, Z, X, G = _factor_state(eng, D, B, seed=6)
         with pytest.raises(gsmvi_amd.GsmviError) as ei:
             eng.bam_factor_update(*[eng.asarray(a) for a in (Z, X, G, mu0, F0)], 1.0)
@@ -345,12 +347,12 @@ def test_factor_form_fit_converges_on_a_gaussian_target():
 @pytest.mark.parametrize("D,B,reg", [(1024, 128, 1.0), (1024, 96, 10.0), (512, 100, 0.5), (200, 64, 2.0), (256, 63, 10.0),
                                      (130, 49, 1.0), (1024, 127, 100.0 / 3)])
 def test_round4_chain_equals_the_round3_chain(D, B, reg):
-    """Round 4 changed the dense BaM chain for 48 < n <= 128: one launch per Newton-Schulz step (k_bam_ns_fused: every
-    workgroup forms the panel of M = Z Y it needs), BB formed inside the Cholesky kernel, Cholesky WITH the inverse factor
-    (k_bam_cholw, chol64_blk / chol128w_body) and Z = W (P + M1^T Vf) as chained MFMA products (k_bam_zw) instead of a
-    forward substitution.  The round-3 kernels stay selectable (knobs bam_ns2 / bam_subst): same (mu, S) to rounding --
-    the explicit triangular inverse costs ~1e-12 relative on Z (cond(L) <= ~1e4 here) -- and the defining equation
-    S U S + S = V holds to the same backward error either way."""
+    """Round 4 changed the dense BaM chain for 48 < n <= 128: slab sums + N in one launch (k_bam_nmat2), BB and the
+    factor-independent vectors on many workgroups (k_bam_bbav), Cholesky WITH the inverse factor (k_bam_cholw, chol64_blk /
+    chol128w_body) and Z = W (P + M1^T Vf) as chained MFMA products (k_bam_zw) instead of a forward substitution; optional
+    one-launch Newton-Schulz steps (knob bam_nsfuse).  The round-3 kernels stay selectable (knob bam_subst): same (mu, S) to
+    rounding -- the explicit triangular inverse costs ~1e-12 relative on Z (cond(L) <= ~1e4 here) -- and the defining
+    equation S U S + S = V holds to the same backward error either way."""
     import gsmvi_amd
     orc, borc = _o()
     eng = gsmvi_amd.get_engine()
@@ -358,14 +360,14 @@ def test_round4_chain_equals_the_round3_chain(D, B, reg):
     X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
     res = {}
     try:
-        for tag, ns2, subst in (("r4", 0, 0), ("ns2", 1, 0), ("subst", 0, 1), ("r3", 1, 1)):
-            eng.set_tuning("bam_ns2", ns2)
+        for tag, nsf, subst in (("r4", 0, 0), ("nsfuse", 1, 0), ("nsfuse_subst", 1, 1), ("r3", 0, 1)):
+            eng.set_tuning("bam_nsfuse", nsf)
             eng.set_tuning("bam_subst", subst)
             mu, S, f = eng.bam_update(X, G, mu0, S0, reg, 0.0)
             assert eng.read_flag(f) == 0, tag
             res[tag] = (mu.cpu().numpy(), S.cpu().numpy())
     finally:
-        eng.set_tuning("bam_ns2", 0)
+        eng.set_tuning("bam_nsfuse", 0)
         eng.set_tuning("bam_subst", 0)
     U, V, xbar, gbar = _bam_uv(st["samples"], st["vs"], st["mu0"], st["S0"], reg)
     for tag, (mu, S) in res.items():

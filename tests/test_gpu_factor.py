@@ -17,7 +17,8 @@ def _setup(D, B, seed):
     return orc, st, F0
 
 
-@pytest.mark.parametrize("D,B", [(8, 2), (10, 5), (33, 3), (64, 8), (100, 17), (256, 32), (1024, 32), (320, 64)])
+@pytest.mark.parametrize("D,B", [(8, 2), (10, 5), (33, 3), (64, 8), (100, 17), (256, 32), (1024, 32), (320, 64),
+                                 (1024, 128), (1024, 96), (512, 100), (300, 65), (256, 128), (1024, 80)])
 def test_factor_update_matches_dense_oracle(D, B):
     import gsmvi_amd
     eng = gsmvi_amd.get_engine()
@@ -299,7 +300,7 @@ def test_g4_decisive_revert_case_through_the_factor_form(golden):
 G4_FACTOR_OUTCOME = "reverted"
 
 
-@pytest.mark.parametrize("D,B", [(8, 2), (64, 8), (256, 32), (300, 64), (64, 32)])
+@pytest.mark.parametrize("D,B", [(8, 2), (64, 8), (256, 32), (300, 64), (64, 32), (512, 128), (400, 90)])
 def test_factor_update_with_linearly_dependent_rows(D, B):
     """Isotropic state on an isotropic target: every u_b - a_b z_b is parallel to mu - m, so the 2B rows [Z; U] have rank
     B + 1 and their Gram matrix is singular.  The factor form must go through (semi-definite rule) and agree with the
@@ -480,3 +481,29 @@ def test_inverse_factor_from_the_factorisation(D, B):
     mu_o, S_o = orc.gsm_update_batched(X2, G2, st["mu0"], st["S0"])
     Fn = F.cpu().numpy()
     assert rel_err(Fn.T @ Fn, S_o) < 1e-9 and rel_err(mu.cpu().numpy(), mu_o) < 1e-9
+
+
+@pytest.mark.parametrize("D,B", [(1024, 128), (1024, 96), (512, 100), (256, 65)])
+def test_two_level_chain_equals_the_dense_hip_update(D, B):
+    """128 < 2B <= 256 (round 4; BASELINE config 4 has B = 128): the 2B x 2B chain is the two-level blocked scheme
+    (k_cholw_ld on 128-row diagonal blocks + the generic small-matrix products of gsmvi_smallgemm.h).  (mu, F^T F) must equal
+    the dense HIP update of the same inputs to 1e-9, run-to-run bit-identical, and a NaN input must revert."""
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    orc, st, F0 = _setup(D, B, D + B)
+    dv = [eng.asarray(st[k]) for k in ("Z", "samples", "vs", "mu0")] + [eng.asarray(F0)]
+    n_rev = eng.new_flag()
+    mu, F, flag = eng.gsm_factor_update(*dv, n_reverts=n_rev)
+    assert eng.read_flag(flag) == 0 and eng.read_flag(n_rev) == 0
+    mu_d, S_d = eng.gsm_update(dv[1], dv[2], dv[3], eng.asarray(st["S0"]))
+    Fn = F.cpu().numpy()
+    assert rel_err(mu.cpu().numpy(), mu_d.cpu().numpy()) < 1e-9 and rel_err(Fn.T @ Fn, S_d.cpu().numpy()) < 1e-9
+    mu2, F2, _ = eng.gsm_factor_update(*dv)
+    assert np.array_equal(F2.cpu().numpy(), Fn) and np.array_equal(mu2.cpu().numpy(), mu.cpu().numpy())
+    G = st["vs"].copy()
+    G[B - 1, 5] = np.nan
+    mu3, F3, flag3 = eng.gsm_factor_update(dv[0], dv[1], eng.asarray(G), dv[3], dv[4], n_reverts=n_rev)
+    assert eng.read_flag(flag3) != 0 and eng.read_flag(n_rev) == 1
+    assert np.array_equal(mu3.cpu().numpy(), st["mu0"]) and np.array_equal(F3.cpu().numpy(), F0)
+    with pytest.raises(gsmvi_amd.GsmviError):        # 2B > 256
+        eng.gsm_factor_update(eng.zeros(129, 512), eng.zeros(129, 512), eng.zeros(129, 512), eng.zeros(512), eng.eye(512))
