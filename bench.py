@@ -463,17 +463,37 @@ def main():
     # covariance kernel's algorithmic count) -- torch's copy kernel, plumbing, not the product path.
     if rank == 0:
         try:
+            # the yardstick is this library's OWN streaming copy (16 B per lane, non-temporal: gsmvi_debug_stream_copy_f64 of the
+            # debug build -- calibration, not the product path; until round 3 torch's copy_ kernel stood here and read 5.0 TB/s
+            # where MI355X_MICROARCH.md's float4 copy reaches 6.29); torch's figure is kept beside it
+            import ctypes as _C
+            from gsmvi_amd import _lib as _gl
+            dbg = _C.CDLL(_gl.library_path(debug=True))
+            dbg.gsmvi_debug_stream_copy_f64.restype = _C.c_int
+            dbg.gsmvi_debug_stream_copy_f64.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_size_t]
             big = torch.empty(2, 2 ** 27, dtype=torch.float64, device=eng.device)
             big[0].fill_(1.0)
-            for _ in range(2):
-                big[1].copy_(big[0])
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                big[1].copy_(big[0])
-            e1.record()
-            e1.synchronize()
-            attain = 5 * 2.0 * big[0].numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            st_ = _C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+            def own_copy():
+                rc_ = dbg.gsmvi_debug_stream_copy_f64(st_, _C.c_void_p(big[1].data_ptr()), _C.c_void_p(big[0].data_ptr()),
+                                                      big[0].numel())
+                assert rc_ == 0
+
+            rates = {}
+            for name, fn in (("own", own_copy), ("torch", lambda: big[1].copy_(big[0]))):
+                for _ in range(2):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    fn()
+                e1.record()
+                e1.synchronize()
+                rates[name] = 5 * 2.0 * big[0].numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            assert torch.equal(big[1], big[0])
+            attain = max(rates.values())
+            roofline["attainable_peak_by_kernel"] = rates
             del big
             gcp = torch.cuda.CUDAGraph()
             for it in inst:

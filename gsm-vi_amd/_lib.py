@@ -100,6 +100,7 @@ _DEBUG_SIGS = {
     "gsmvi_debug_workspace_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "gsmvi_debug_chol128": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_dp, _c_dp, _c_dp, _c_dp]),
     "gsmvi_debug_read_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]),
+    "gsmvi_debug_stream_copy_f64": (C.c_int, [C.c_void_p, _c_dp, _c_dp, C.c_size_t]),
 }
 
 

@@ -101,6 +101,20 @@ static int check_launch(const char* what) {
     return GSMVI_OK;
 }
 
+typedef double v2d_abi __attribute__((ext_vector_type(2)));
+// calibration copy kernel of gsmvi_debug_stream_copy_f64 (below)
+__global__ __launch_bounds__(256) void k_stream_copy(const v2d_abi* __restrict__ src, v2d_abi* __restrict__ dst, size_t n2) {
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n2; i += stride) {
+        v2d_abi a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = (i + 256 * u < n2) ? __builtin_nontemporal_load(src + i + 256 * u) : (v2d_abi){0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + 256 * u < n2) __builtin_nontemporal_store(a[u], dst + i + 256 * u);
+    }
+}
+
 extern "C" {
 
 int gsmvi_abi_version(void) { return GSMVI_ABI_VERSION; }
@@ -269,6 +283,18 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
         return GSMVI_ERR_BAD_ARG;
     }
     return GSMVI_OK;
+}
+
+/* Calibration (bench.py, SURVEY 8(d) "attainable peak"): a plain streaming copy of n doubles, 16 bytes per lane, four
+ * independent loads in flight per thread, grid-stride over 2048 workgroups -- this library's own yardstick for what a kernel
+ * that only moves bytes reaches on the box (torch's copy_ kernel, used until round 3, was slower than the guide's float4
+ * copy).  dst and src 16-byte aligned, n even.  Exported by the debug library only. */
+int gsmvi_debug_stream_copy_f64(void* stream, double* dst, const double* src, size_t n) {
+    BAD_ARG(!dst || !src || n < 2 || (n & 1) || (reinterpret_cast<uintptr_t>(dst) & 15u) || (reinterpret_cast<uintptr_t>(src) & 15u),
+            "bad argument (16-byte aligned pointers, even n)");
+    hipLaunchKernelGGL(k_stream_copy, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const v2d_abi*>(src), reinterpret_cast<v2d_abi*>(dst), n / 2);
+    return hipGetLastError() == hipSuccess ? GSMVI_OK : GSMVI_ERR_HIP;
 }
 
 /* Diagnostic: copies n 64-bit words from the start of the panel-partial slab (where the cov_dbg=16

@@ -242,6 +242,9 @@ __global__ __launch_bounds__(256) void k_bam_nmat2(int n, int kc, const double* 
         for (int q = 0; q < GSMVI_MAX_KC; ++q) a += (q < kc) ? t[q] : 0.0;
         return a;
     };
+    const int t = threadIdx.x, i = i0 + (t >> 4), j = j0 + (t & 15);
+    const int iq = i < n ? i : n - 1, jq = j < n ? j : n - 1;
+    const double n0ij = slab_sum(iq, jq), n0ji = slab_sum(jq, iq), m1ij = slab_sum(n + iq, jq);   // (issued first: not a tail)
     v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     for (int u0 = 0; w + 4 * u0 < nk; u0 += 4) {             // four k-steps of this wave per batch (64 slab loads in flight)
         double a[4], b[4];
@@ -259,9 +262,6 @@ __global__ __launch_bounds__(256) void k_bam_nmat2(int n, int kc, const double* 
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[w * 256 + (ks + 4 * r) * 16 + cc] = acc0[r] + acc1[r];
-    const int t = threadIdx.x, i = i0 + (t >> 4), j = j0 + (t & 15);
-    const int iq = i < n ? i : n - 1, jq = j < n ? j : n - 1;
-    const double n0ij = slab_sum(iq, jq), n0ji = slab_sum(jq, iq), m1ij = slab_sum(n + iq, jq);
     __syncthreads();
     if (i < n && j < n) {
         const double v = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
@@ -530,20 +530,29 @@ __global__ __launch_bounds__(512) void k_bam_zw(int D, int n, const double* __re
         redz[(w * 4 + ks) * 16 + cc] = 0.0;
     }
     __syncthreads();
-    if (tid < 16 && (j0 + tid) < D) {
-        double dz = 0.0;
-        for (int q = 0; q < 32; ++q) dz += redz[q * 16 + tid];
-        double d0 = 0.0, d1 = 0.0;
-        int k = 0;
-        for (; k + 1 < n; k += 2) {
-            d0 += Vs[k * 16 + tid] * svg[k];
-            d1 += Vs[(k + 1) * 16 + tid] * svg[k + 1];
+    {   // Vf^T vg - Z^T zg per column: 32 partials per column (thread = (part, column)), shuffles inside the wave (its four
+        // parts), then eight wave partials through LDS -- fixed order; a 16-thread serial loop here cost ~4 us
+        const int col = tid & 15, part = tid >> 4;           // part = 4 w + ks
+        double d = -redz[part * 16 + col];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = part + 32 * u;
+            d += (k < n) ? Vs[k * 16 + col] * svg[k] : 0.0;
         }
-        if (k < n) d0 += Vs[k * 16 + tid] * svg[k];
+        d += __shfl_xor(d, 16, 64);
+        d += __shfl_xor(d, 32, 64);
+        __syncthreads();                                     // every read of redz is done: it takes the wave partials
+        if (ks == 0) redz[w * 16 + col] = d;
+    }
+    __syncthreads();
+    if (tid < 16 && (j0 + tid) < D) {
+        double dd = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dd += redz[q * 16 + tid];
         const int j = j0 + tid;
         const double r1 = reg / (1.0 + reg);
         const double s0g = P[(size_t)(n - 1) * D + j] / sqrt(r1);          // (S0 gbar)_j = P[n-1][j]/sqrt(r1)
-        mu[j] = mu0[j] / (1.0 + reg) + r1 * (s0g + (d0 + d1) - dz + xbar[j]);
+        mu[j] = mu0[j] / (1.0 + reg) + r1 * (s0g + dd + xbar[j]);
     }
 }
 

@@ -38,9 +38,10 @@
 // Every workgroup sums the diagonal itself (n loads) and fills its share of Y0 / Z0; workgroup 0 also runs the scalar
 // recurrence.  A NaN / inf anywhere in N needs no flag of its own: it propagates through the products into BB, where
 // k_bam_chol_out rejects it.
+// Mm also receives Y0: the first step's M = Z0 Y0 = I Y0 is Y0 exactly, so the launch k_bam_ns_zy(k = 0) is not enqueued.
 __global__ __launch_bounds__(256) void k_bam_ns_prep(int n, int ld, const double* __restrict__ Nm, double* __restrict__ Y,
-                                                     double* __restrict__ Z, double* __restrict__ coef,
-                                                     int* __restrict__ hint_host) {
+                                                     double* __restrict__ Z, double* __restrict__ Mm,
+                                                     double* __restrict__ coef, int* __restrict__ hint_host) {
     __shared__ double red[4];
     const int tid = threadIdx.x;
     double tr = 0.0;
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256) void k_bam_ns_prep(int n, int ld, const double
         const bool in = i < n && j < n;
         const double v = in ? Nm[(size_t)i * n + j] + (i == j ? 0.25 : 0.0) : 0.0;
         Y[e] = v * sinv;
+        Mm[e] = v * sinv;
         Z[e] = (in && i == j) ? 1.0 : 0.0;
     }
     if (blockIdx.x == 0 && tid == 0) {
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void k_bam_ns_prep(int n, int ld, const double
 template <int MODE>
 __device__ __forceinline__ void bams_block(const double* __restrict__ A, const double* __restrict__ Bm,
                                            double* __restrict__ Out, int blk, int nb, int nk, double c2, double scale,
-                                           int ld) {
+                                           int ld, bool active = true) {
     // one WORKGROUP per 16 x 16 block; wave w takes the k-steps w, w + 4, ... in batches of nine (one batch for ld = 144),
     // every load of a batch issued together; the four partial blocks are summed through LDS in a fixed order
     __shared__ double red[4 * 256];
@@ -119,34 +121,36 @@ __device__ __forceinline__ void bams_block(const double* __restrict__ A, const d
     __syncthreads();
     const int t = threadIdx.x;                               // element (t >> 4, t & 15) of the block
     const double v = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
-    Out[(size_t)(i0 + (t >> 4)) * ld + j0 + (t & 15)] = scale * v;
+    if (active) Out[(size_t)(i0 + (t >> 4)) * ld + j0 + (t & 15)] = scale * v;
 }
 
 // M = Z Y (the scaling enters through T in the step kernel)
+// Round 4: no early return on the step count -- the operand loads do not wait for coef[40] (two dependent L2 round trips
+// per launch became one: 26 launches per update); a launch beyond k* does its arithmetic and stores nothing.
 __global__ __launch_bounds__(256) void k_bam_ns_zy(int n, int ld, int k, const double* __restrict__ Ya,
                                                    const double* __restrict__ Za, const double* __restrict__ Yb,
                                                    const double* __restrict__ Zb, double* __restrict__ Mm,
                                                    const double* __restrict__ coef) {
-    if ((double)k >= coef[40] || coef[42] != 0.0) return;
+    const bool active = (double)k < coef[40] && coef[42] == 0.0;
     const double* Y = (k & 1) ? Yb : Ya;
     const double* Z = (k & 1) ? Zb : Za;
     const int nb = (n + 15) >> 4, nk = (n + 3) >> 2;
-    bams_block<0>(Z, Y, Mm, blockIdx.x, nb, nk, 0.0, 1.0, ld);
+    bams_block<0>(Z, Y, Mm, blockIdx.x, nb, nk, 0.0, 1.0, ld, active);
 }
 
 // Y' = c Y T and Z' = c T Z (in THIS order), T = 1.5 I - 0.5 c^2 M.  Blocks [0, nb^2) -> Y', the rest -> Z'.
 __global__ __launch_bounds__(256) void k_bam_ns_step(int n, int ld, int k, double* __restrict__ Ya, double* __restrict__ Za,
                                                      double* __restrict__ Yb, double* __restrict__ Zb,
                                                      const double* __restrict__ Mm, const double* __restrict__ coef) {
-    if ((double)k >= coef[40] || coef[42] != 0.0) return;
-    const double c2 = coef[k], c = sqrt(c2);
+    const bool active = (double)k < coef[40] && coef[42] == 0.0;
+    const double c2 = coef[k < BAMS_KMAX ? k : BAMS_KMAX - 1], c = sqrt(c2);
     const double* Yi = (k & 1) ? Yb : Ya;
     const double* Zi = (k & 1) ? Zb : Za;
     double* Yo = (k & 1) ? Ya : Yb;
     double* Zo = (k & 1) ? Za : Zb;
     const int nb = (n + 15) >> 4, nk = (n + 3) >> 2;
-    if ((int)blockIdx.x < nb * nb) bams_block<1>(Yi, Mm, Yo, blockIdx.x, nb, nk, c2, c, ld);         // Y' = c Y T
-    else bams_block<2>(Mm, Zi, Zo, blockIdx.x - nb * nb, nb, nk, c2, c, ld);                        // Z' = c T Z
+    if ((int)blockIdx.x < nb * nb) bams_block<1>(Yi, Mm, Yo, blockIdx.x, nb, nk, c2, c, ld, active);         // Y' = c Y T
+    else bams_block<2>(Mm, Zi, Zo, blockIdx.x - nb * nb, nb, nk, c2, c, ld, active);                        // Z' = c T Z
 }
 
 // ---- ONE launch per step (round 4, opt-in: knob "bam_nsfuse"): M = Z Y is not handed over through memory, every workgroup forms
@@ -598,7 +602,7 @@ __global__ __launch_bounds__(512) void k_bam_chol_out(int n, double reg, const d
 // ---- BB and the vectors that do not depend on its factor, on many workgroups (round 4) ----------------------------------------
 //   BB = N + I/2 + sqrt(s) sym(Y_final)     one 16 x 16 block per workgroup; the transposed block of Y passes through LDS, so both
 //                                           reads are 128-byte row segments (a one-workgroup version read Y by columns: 8 us)
-//   vg = Vf gbar = M1[:, n-1] / r1s,  a = P gbar + M1^T vg (bam.py:107 applied to gbar)      the extra workgroup nb^2
+//   vg = Vf gbar = M1[:, n-1] / r1s,  a = P gbar + M1^T vg (bam.py:107 applied to gbar)      nb extra workgroups, 16 entries each
 // Outputs: BBg (n x n); behind the n x n slot of W: [a (n) | (n unused) | vg (n)].  A failed iteration (coef[42]) poisons BB.
 __global__ __launch_bounds__(256) void k_bam_bbav(int n, int ld, double reg, const double* __restrict__ Nm,
                                                   const double* __restrict__ Ya, const double* __restrict__ Yb,
@@ -623,32 +627,32 @@ __global__ __launch_bounds__(256) void k_bam_bbav(int n, int ld, double reg, con
         }
         return;
     }
-    __shared__ double sc[BAMS_NMAX], part[2 * 128];
+    // workgroups nb^2 .. nb^2 + nb - 1: sixteen entries of a (and of vg) each; sixteen threads per entry, eight loads in flight each
+    __shared__ double part[16 * 17];
+    const int e = blockIdx.x - nb * nb, p = 16 * e + (tid & 15), q = tid >> 4, pc = p < n ? p : n - 1;
     const double r1s = sqrt(reg / (1.0 + reg));
-    if (tid < 128) sc[tid] = (tid < n) ? M1[(size_t)tid * n + (n - 1)] / r1s : 0.0;
-    __syncthreads();
-    {   // a[p] = N0[p][n-1] / r1s + sum_k M1[k][p] vg[k]: two threads per entry, 16 loads in flight per batch
-        const int p = tid & 127, q = tid >> 7, pc = p < n ? p : n - 1;
-        double a0 = 0.0, a1 = 0.0;
-        for (int k0 = q; k0 < n; k0 += 32) {
-            double m[16];
+    double m[8], v[8];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int k = k0 + 2 * u;
-                m[u] = M1[(size_t)(k < n ? k : n - 1) * n + pc];
-            }
-#pragma unroll
-            for (int u = 0; u < 16; u += 2) {
-                a0 += (k0 + 2 * u < n) ? m[u] * sc[k0 + 2 * u] : 0.0;
-                a1 += (k0 + 2 * u + 2 < n) ? m[u + 1] * sc[k0 + 2 * u + 2] : 0.0;
-            }
-        }
-        part[q * 128 + p] = a0 + a1;
+    for (int u = 0; u < 8; ++u) {
+        const int k = q + 16 * u, kc = k < n ? k : n - 1;
+        m[u] = M1[(size_t)kc * n + pc];
+        v[u] = M1[(size_t)kc * n + (n - 1)];                 // vg[k] r1s
     }
+    const double n0 = N0[(size_t)pc * n + (n - 1)], vgp = M1[(size_t)pc * n + (n - 1)];
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+        a0 += (q + 16 * u < n) ? m[u] * (v[u] / r1s) : 0.0;
+        a1 += (q + 16 * u + 16 < n) ? m[u + 1] * (v[u + 1] / r1s) : 0.0;
+    }
+    part[q * 17 + (tid & 15)] = a0 + a1;
     __syncthreads();
-    if (tid < n) {
-        tail3[tid] = N0[(size_t)tid * n + (n - 1)] / r1s + (part[tid] + part[128 + tid]);
-        tail3[2 * n + tid] = sc[tid];
+    if (tid < 16 && p < n) {
+        double sum = 0.0;
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) sum += part[qq * 17 + tid];
+        tail3[p] = n0 / r1s + sum;
+        tail3[2 * n + p] = vgp / r1s;
     }
 }
 
@@ -1093,27 +1097,26 @@ int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, co
         // steps to enqueue: the previous call's k* + 2 when known (pinned host word, read without synchronising),
         // everything otherwise; k_bam_ns_tail makes up for a guess that turns out too small
         int kenq = BAMS_KMAX;
-        if (hint_host) {
-            const int h = *reinterpret_cast<volatile int*>(hint_host);
-            if (h > 0 && h + 2 < BAMS_KMAX) kenq = h + 2;
+        if (hint_host) {                                     // k* + 1 (round 4; + 2 before): a step beyond k* costs two launches,
+            const int h = *reinterpret_cast<volatile int*>(hint_host);   // and k* moves by at most one between neighbouring calls
+            if (h > 0 && h + 1 < BAMS_KMAX) kenq = h + 1;
         }
         if (force_kenq > 0 && force_kenq < BAMS_KMAX) kenq = force_kenq;       // tests: exercise the safety net
-        hipLaunchKernelGGL(k_bam_ns_prep, dim3(27), dim3(256), 0, st, n, ld, Nd, Ya, Za, coef, hint_host);
+        hipLaunchKernelGGL(k_bam_ns_prep, dim3(27), dim3(256), 0, st, n, ld, Nd, Ya, Za, Mm, coef, hint_host);
         const int nb = (n + 15) / 16;
         const bool fused = n <= 128 && ctx->tune_bam_nsfuse;  // "bam_nsfuse" = 1: one launch per step (k_bam_ns_fused); default: two
-        if (fused && hint_host && force_kenq <= 0 && kenq < BAMS_KMAX && kenq > 3) --kenq;   // k* + 1: a launch beyond k* costs ~3 us
         for (int k = 0; k < kenq; ++k) {
             if (fused) {
                 hipLaunchKernelGGL(k_bam_ns_fused, dim3(2 * nb * nb), dim3(512), 0, st, n, ld, k, Ya, Za, Yb, Zb, coef);
             } else {
-                hipLaunchKernelGGL(k_bam_ns_zy, dim3(nb * nb), dim3(256), 0, st, n, ld, k, Ya, Za, Yb, Zb, Mm, coef);
+                if (k > 0) hipLaunchKernelGGL(k_bam_ns_zy, dim3(nb * nb), dim3(256), 0, st, n, ld, k, Ya, Za, Yb, Zb, Mm, coef);
                 hipLaunchKernelGGL(k_bam_ns_step, dim3(2 * nb * nb), dim3(256), 0, st, n, ld, k, Ya, Za, Yb, Zb, Mm, coef);
             }
         }
         if (kenq < BAMS_KMAX)
             hipLaunchKernelGGL(k_bam_ns_tail, dim3(1), dim3(1024), 0, st, n, ld, kenq, Ya, Za, Yb, Zb, Mm, coef);
         if (Wscr && n <= 128)                   // BB and the factor-independent vectors [a | . | vg] behind W's slot
-            hipLaunchKernelGGL(k_bam_bbav, dim3(nb * nb + 1), dim3(256), 0, st, n, ld, reg, Nd, Ya, Yb, coef, M1, N0, BBg,
+            hipLaunchKernelGGL(k_bam_bbav, dim3(nb * nb + nb), dim3(256), 0, st, n, ld, reg, Nd, Ya, Yb, coef, M1, N0, BBg,
                                Ld + (size_t)n * n);
         else
             hipLaunchKernelGGL(k_bam_ns_bb, dim3((n * n + 255) / 256), dim3(256), 0, st, n, ld, Nd, Ya, Yb, coef, BBg);

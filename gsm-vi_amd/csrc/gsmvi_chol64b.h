@@ -76,6 +76,13 @@ __device__ __forceinline__ void cholb_panel_half(double* E, int k0, int col, boo
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = ep[i * ES];
     }
+#ifdef CHOLB_TEST_CORRUPT_REPLICA
+    // test hook: the harness must notice a replica that does NOT hold the diagonal block (validates the test itself)
+    if (diag_lane && !write_back) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += 0.25;
+    }
+#endif
     // Every LDS read below is issued ONE PIVOT before its values are used (explicit software pipelining): a wave issues in
     // order, so an s_waitcnt in front of an elimination FMA also holds back the reciprocal chain of the next pivot behind
     // it -- with the reads issued at their point of use the LDS round trip (~130 cycles) sat on the chain of every pivot.
@@ -232,7 +239,10 @@ __device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, i
 #ifdef CHOLB_TEST_REPLICA_DELAY
             // test hook (scripts/chol64b_test.hip, tests/test_gpu_aux.py): hold the replica sets' waves back for several
             // microseconds, the schedule under which an in-place write-back of the diagonal block by set 0 would be loaded
-            if (set > 0)
+            // (the branch must be SCALAR: s_sleep is a scalar instruction and ignores the exec mask -- with `if (set > 0)` on
+            // a per-lane value the compiler only masked lanes and EVERY panel wave slept, which is why round 3's version of
+            // this hook could not reproduce anything)
+            if (__builtin_amdgcn_readfirstlane(set) > 0)
                 for (int d_ = 0; d_ < CHOLB_TEST_REPLICA_DELAY; ++d_) __builtin_amdgcn_s_sleep(127);
             asm volatile("s_nop 0" ::: "memory");     // the panel's LDS loads must not be scheduled in front of the delay
 #endif
@@ -241,7 +251,7 @@ __device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, i
             // finished this panel (a counter in the spare word of set 0's scratch) -- the latest legal schedule, forced.  With
             // CHOLB_TEST_OLD_WRITEBACK this is exactly the interleaving the round-3 fix removes: the replicas load factored rows.
             volatile int* order_flag = reinterpret_cast<volatile int*>(scratch + 16 * 64 + 8 * 64 + 17);
-            if (set > 0) {
+            if (__builtin_amdgcn_readfirstlane(set) > 0) {
                 while (__builtin_amdgcn_readfirstlane(*order_flag) < 2 * (k + 1)) __builtin_amdgcn_s_sleep(1);
                 asm volatile("s_nop 0" ::: "memory");
             }

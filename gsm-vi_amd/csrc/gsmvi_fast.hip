@@ -479,6 +479,202 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
 #undef STAMP
 }
 
+// =====================================================================================
+// PERSISTENT form of k_gsm_cov_sym for large D (round 4).  Same tiles, same arithmetic, same results bit for bit: a work ITEM
+// is what one workgroup of k_gsm_cov_sym does (row block I of 32 rows x two adjacent column tiles, or a lone diagonal tile).
+// At D = 4096 there are 4160 items and the one-item kernel ran them as 4160 workgroups, two resident per CU, each a serial
+// chain load (16 KB of S0 from HBM + 48 KB of record tiles from L2) -> LDS -> MFMA -> stores (32 KB): 53.9 us for 201 MB =
+// 3.7 TB/s, 0.59 of what a plain copy reaches on the box -- the memory pipes of a CU idle while its workgroups compute.
+// Here 2 workgroups per CU stay resident and walk the item list (item = blockIdx.x, + gridDim.x, ...); the NEXT item's global
+// loads (8 v2d per thread: two S0 units, six record units) are issued as soon as the current item's record tiles have gone
+// to LDS, so they are in flight during the current item's operand reads, MFMAs, LDS round trips and stores (loads and stores
+// share the in-order vmcnt counter: the next iteration waits for the loads only, the stores behind them stay in flight).
+// =====================================================================================
+template <int SB>
+__global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, const double* __restrict__ rec, int ldrec,
+                                                       const double* __restrict__ mu0,
+                                                       const double* __restrict__ S0, int lds0,
+                                                       double* __restrict__ S, int lds,
+                                                       double* __restrict__ mu_out) {
+    constexpr int RS = 48;
+    constexpr int NPASS = (SB > 32) ? SB / 32 : 1;
+    constexpr int SBP = SB / NPASS;
+    constexpr int TILE = SBP * RS;
+    constexpr int NU = SB * 16;
+    constexpr int UPT = (6 * NU) / 512;
+    static_assert((6 * NU) % 512 == 0, "tile units must divide over 512 threads");
+    __shared__ __attribute__((aligned(16))) double smem[6 * TILE >= 2 * 32 * 33 ? 6 * TILE : 2 * 32 * 33];
+    const int nt = D >> 5;
+    const int n_two = ((nt >> 1) * ((nt + 1) >> 1));
+    const int n_items = n_two + ((nt + 1) >> 1);             // + one lone diagonal tile per row with an odd tile count
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+    const int t = w >> 2;
+    const int wr = (w >> 1) & 1, wc = w & 1;
+    const int tl = tid & 255;
+    constexpr double invB = 1.0 / (double)SB;
+
+    struct Item { int ti, tj0; bool two; };
+    // incremental decode of the two-tile items (row ti holds (nt - ti) >> 1 of them): the scan continues where the last one stopped
+    int scan_ti = 0, scan_base = 0;                          // scan_base = first item index of row scan_ti
+    auto decode = [&](int item) -> Item {
+        Item it;
+        if (item < n_two) {
+            for (;;) {
+                const int inrow = (nt - scan_ti) >> 1;
+                if (item - scan_base < inrow) break;
+                scan_base += inrow;
+                ++scan_ti;
+            }
+            it.ti = scan_ti;
+            it.tj0 = scan_ti + ((nt - scan_ti) & 1) + 2 * (item - scan_base);
+            it.two = true;
+        } else {
+            const int k = item - n_two;
+            it.ti = ((nt & 1) ? 0 : 1) + 2 * k;
+            it.tj0 = it.ti;
+            it.two = false;
+        }
+        return it;
+    };
+    v2d s0v[2], stg[UPT];
+    double dmuv[SB / 8];                                     // (kept as loaded: summing here would wait for the loads just issued)
+    auto issue_loads = [&](const Item& it, v2d (&s0)[2], double (&dmu)[SB / 8]) {
+        const int I0 = it.ti * 32, J0 = it.tj0 * 32;
+        const int Jt = J0 + 32 * ((t == 1 && it.two) ? 1 : 0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int unit = q * 256 + tl, i = unit >> 4, j2 = unit & 15;
+            s0[q] = *reinterpret_cast<const v2d*>(S0 + (size_t)(I0 + i) * lds0 + Jt + 2 * j2);
+        }
+        __builtin_amdgcn_sched_barrier(0);                   // the HBM loads of S0 ahead of the L2-resident record loads
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) {
+            const int g = q * 512 + tid;
+            const int tile = g / NU, u = g % NU;
+            const int b = u >> 4, c2 = 2 * (u & 15);
+            const int colbase = (tile < 2) ? I0 : (J0 + ((tile >= 4 && it.two) ? 32 : 0));
+            stg[q] = (it.two || tile < 4) ? *reinterpret_cast<const v2d*>(rec + (size_t)b * ldrec + (tile & 1) * D + colbase + c2)
+                                          : (v2d){0.0, 0.0};
+        }
+#pragma unroll
+        for (int k = 0; k < SB / 8; ++k) dmu[k] = 0.0;
+        if (it.tj0 == it.ti && tid < 256) {
+#pragma unroll
+            for (int k = 0; k < SB / 8; ++k)
+                dmu[k] = rec[(size_t)((tid >> 5) + 8 * k) * ldrec + 2 * D + I0 + (tid & 31)];
+        }
+    };
+    int item = blockIdx.x;
+    if (item >= n_items) return;
+    Item cur = decode(item);
+    issue_loads(cur, s0v, dmuv);
+    while (true) {
+        const bool two = cur.two, diag = (cur.tj0 == cur.ti);
+        const int I0 = cur.ti * 32, J0 = cur.tj0 * 32;
+        const int Jt = J0 + 32 * ((t == 1 && two) ? 1 : 0);
+        const bool mine = (t == 0) || two;
+        constexpr int NS = SBP / 4;
+        v4d accd = {0.0, 0.0, 0.0, 0.0}, acce = {0.0, 0.0, 0.0, 0.0};
+        const int nxt = item + gridDim.x;
+        Item nx = cur;
+        v2d s0n[2] = {s0v[0], s0v[1]};
+        double dmun[SB / 8];
+#pragma unroll
+        for (int k = 0; k < SB / 8; ++k) dmun[k] = 0.0;
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            if (pass > 0) __syncthreads();
+#pragma unroll
+            for (int q = 0; q < UPT; ++q) {
+                const int g = q * 512 + tid;
+                const int tile = g / NU, u = g % NU;
+                const int b = u >> 4;
+                if (b / SBP == pass && (two || tile < 4))
+                    *reinterpret_cast<v2d*>(smem + tile * TILE + (b % SBP) * RS + 2 * (u & 15)) = stg[q];
+            }
+            __syncthreads();
+            if (pass == NPASS - 1 && nxt < n_items) {        // the staging registers are free: the next item's loads go out now
+                nx = decode(nxt);
+                issue_loads(nx, s0n, dmun);
+            }
+            double ad[NS], ae[NS], bd[NS], be[NS];
+            if (mine) {
+                const double* adp = smem + ks * RS + 16 * wr + c;
+                const double* aep = adp + TILE;
+                const double* bdp = smem + (2 + 2 * t) * TILE + ks * RS + 16 * wc + c;
+                const double* bep = bdp + TILE;
+#pragma unroll
+                for (int sI = 0; sI < NS; ++sI) {
+                    ad[sI] = adp[4 * sI * RS];
+                    ae[sI] = aep[4 * sI * RS];
+                    bd[sI] = bdp[4 * sI * RS];
+                    be[sI] = bep[4 * sI * RS];
+                }
+#pragma unroll
+                for (int sI = 0; sI < NS; ++sI) {
+                    accd = GSMVI_MFMA_F64(ad[sI], bd[sI], accd);
+                    acce = GSMVI_MFMA_F64(ae[sI], be[sI], acce);
+                }
+            }
+        }
+        __syncthreads();                                     // everyone is done reading the factor tiles
+        double* LW = smem + t * 32 * 33;
+        if (mine) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) LW[(16 * wr + ks + 4 * r) * 33 + 16 * wc + c] = (accd[r] - acce[r]) * invB;
+        }
+        __syncthreads();
+        if (mine) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int unit = q * 256 + tl, i = unit >> 4, j2 = unit & 15;
+                v2d wv2;
+                wv2.x = s0v[q].x + LW[i * 33 + 2 * j2];
+                wv2.y = s0v[q].y + LW[i * 33 + 2 * j2 + 1];
+                *reinterpret_cast<v2d*>(S + (size_t)(I0 + i) * lds + Jt + 2 * j2) = wv2;
+                LW[i * 33 + 2 * j2] = wv2.x;
+                LW[i * 33 + 2 * j2 + 1] = wv2.y;
+            }
+        }
+        const bool need = mine && !(t == 0 && diag);
+        __syncthreads();
+        if (need) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int unit = q * 256 + tl, j = unit >> 4, i2 = unit & 15;
+                v2d m2;
+                m2.x = LW[(2 * i2) * 33 + j];
+                m2.y = LW[(2 * i2 + 1) * 33 + j];
+                *reinterpret_cast<v2d*>(S + (size_t)(Jt + j) * lds + I0 + 2 * i2) = m2;
+            }
+        }
+        if (diag) {                                          // (block-uniform)
+            __syncthreads();
+            if (tid < 256) {
+                double dsum = 0.0;
+#pragma unroll
+                for (int k = 0; k < SB / 8; ++k) dsum += dmuv[k];
+                smem[tid] = dsum;
+            }
+            __syncthreads();
+            if (tid < 32) {
+                double sm_ = 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sm_ += smem[q * 32 + tid];
+                mu_out[I0 + tid] = mu0[I0 + tid] + sm_ * invB;
+            }
+        }
+        if (nxt >= n_items) break;
+        __syncthreads();                                     // the LDS tiles of this item are dead: the next item may stage
+        item = nxt;
+        cur = nx;
+        s0v[0] = s0n[0];
+        s0v[1] = s0n[1];
+#pragma unroll
+        for (int k = 0; k < SB / 8; ++k) dmuv[k] = dmun[k];
+    }
+}
+
 // ---- launch helpers ------------------------------------------------------------------------
 void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int nrows, const double* A,
                              int lda, const double* shift, double alpha, const double* M, int ldm, double* Pp,
@@ -544,6 +740,21 @@ static int cov_sym_grid(int nt) {
 bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, const double* rec, int ldrec,
                               const double* mu0, const double* S0, int lds0, double* S, int lds, double* mu_out,
                               int dbg, unsigned long long* stamps) {
+    // large D: the persistent form (2 resident workgroups per CU walk the item list, the next item's loads in flight during
+    // the current item's MFMAs and stores); "cov_dbg" bit 512 keeps the one-item-per-workgroup kernel for A/B runs
+    const int n_items = cov_sym_grid(D / 32);
+    if (n_items >= 2048 && !(dbg & 512) && !stamps && (dbg & 1023) == 0) {
+        const dim3 pgrid(512);
+#define CSP(SBV) GSMVI_LAUNCH(k_gsm_cov_sym_p<SBV>, pgrid, dim3(512), 0, st, ev, D, rec, ldrec, mu0, S0, lds0, S, lds, mu_out)
+        switch (B) {
+            case 16: CSP(16); return true;
+            case 32: CSP(32); return true;
+            case 64: CSP(64); return true;
+            default: return false;
+        }
+#undef CSP
+    }
+    if (dbg & 512) dbg &= ~512;
     const dim3 grid(cov_sym_grid(D / 32));
 #define CS(SBV)                                                                                             \
     GSMVI_LAUNCH(k_gsm_cov_sym<SBV>, grid, dim3(512), 0, st, ev, D, rec, ldrec, mu0, S0, lds0, S, lds, mu_out, dbg, \

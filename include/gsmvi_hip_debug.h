@@ -27,6 +27,10 @@ int gsmvi_debug_workspace_ptr(gsmvi_ctx* ctx, int region, double** out);
  * For soak / determinism scripts. */
 int gsmvi_debug_chol128(void* stream, int n, int with_inverse, const double* A, double* R, double* W, int* info_dev);
 
+/* Calibration for bench.py: a plain streaming copy of n doubles on `stream` (16 bytes per lane, non-temporal) -- the rate a
+ * kernel that only moves bytes reaches on this box, the yardstick beside the 8 TB/s specification. */
+int gsmvi_debug_stream_copy_f64(void* stream, double* dst, const double* src, size_t n);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

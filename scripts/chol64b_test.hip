@@ -91,7 +91,9 @@ static int run(const char* name, int n, const std::vector<double>& A, int expect
                     einv = fmax(einv, fabs(s - (i == j ? 1.0 : 0.0)));
                 }
         }
-        if (erec > 1e-13 || elow != 0.0) bad = 1;
+        // (round 4: the inverse factor is part of the verdict -- until then |W R^T - I| was printed but never tested, so a
+        // build whose replicas held the wrong diagonal block still ended in "ALL OK")
+        if (erec > 1e-13 || elow != 0.0 || (AUG && !(einv < 1e-10))) bad = 1;
     }
     printf("%-28s n=%2d fail=%d (expect %d)  recon %.1e  vs host %.1e  |W R^T - I| %.1e  lower %.1e  total %.2f us %s\n", name, n,
            fail, expect_fail, erec, eref, einv, elow, (st[15] - st[0]) / 100.0, bad ? "  <-- BAD" : "");

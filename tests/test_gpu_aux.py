@@ -144,14 +144,15 @@ def test_advi_with_the_device_target_and_device_monitor():
 def test_blocked_cholesky_with_late_replica_waves(tmp_path):
     """chol64_blk keeps replicas of the 16 x 16 diagonal block in the other column sets' panel waves (AUG >= 1), loaded at an
     unordered time; since round 3 the block is written back only behind the panel barrier (a once-in-3e5
-    deviation found by soaking).  The standalone harness is built four ways:
-      plain, and with the replica waves held back by ~7 us (CHOLB_TEST_REPLICA_DELAY)   -> must pass;
+    deviation found by soaking).  The standalone harness (which since round 4 also TESTS the inverse factor it always printed)
+    is built six ways:
+      plain                                                                                  -> must pass
+      replica waves held back ~7 us (CHOLB_TEST_REPLICA_DELAY; a scalar branch since round 4)   -> must pass
       CHOLB_TEST_FORCE_ORDER: the replicas load their copy only after BOTH waves of set 0 have finished the panel (an LDS
-        counter), i.e. the latest schedule the hardware may produce, forced                -> must pass;
-      the same forced order with CHOLB_TEST_OLD_WRITEBACK (the pre-fix in-place write-back of the factored diagonal rows)
-                                                                                          -> must FAIL ([R | R^-T]: W wrong),
-    which is the regression protection the delay-only build did not give: the mechanism the fix removes is shown to break the
-    result whenever the interleaving occurs, and the shipped header is shown immune to it."""
+        counter): the latest schedule the hardware may produce, forced                       -> must pass
+      either late schedule with CHOLB_TEST_OLD_WRITEBACK (the pre-fix in-place write-back)    -> must FAIL (W = R^-T wrong at O(1))
+      CHOLB_TEST_CORRUPT_REPLICA (a replica that does not hold the block)                    -> must FAIL (the harness notices)
+    i.e. the mechanism the fix removes breaks the result whenever the interleaving occurs, and the shipped header is immune."""
     import os
     import shutil
     import subprocess
@@ -162,7 +163,9 @@ def test_blocked_cholesky_with_late_replica_waves(tmp_path):
     src = os.path.join(ROOT, "scripts", "chol64b_test.hip")
     variants = [("plain", [], True), ("delay", ["-DCHOLB_TEST_REPLICA_DELAY=2"], True),
                 ("forced", ["-DCHOLB_TEST_FORCE_ORDER"], True),
-                ("forced_oldwb", ["-DCHOLB_TEST_FORCE_ORDER", "-DCHOLB_TEST_OLD_WRITEBACK"], False)]
+                ("forced_oldwb", ["-DCHOLB_TEST_FORCE_ORDER", "-DCHOLB_TEST_OLD_WRITEBACK"], False),
+                ("delay_oldwb", ["-DCHOLB_TEST_REPLICA_DELAY=2", "-DCHOLB_TEST_OLD_WRITEBACK"], False),
+                ("corrupt", ["-DCHOLB_TEST_CORRUPT_REPLICA"], False)]
     for tag, defs, must_pass in variants:
         exe = str(tmp_path / f"chol64b_test_{tag}")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "gsm-vi_amd", "csrc"),
@@ -173,4 +176,4 @@ def test_blocked_cholesky_with_late_replica_waves(tmp_path):
         if must_pass:
             assert r.returncode == 0 and "ALL OK" in r.stdout, (tag, r.stdout[-3000:])
         else:
-            assert r.returncode != 0 and "FAILED" in r.stdout, (tag, "the pre-fix write-back survived the forced interleaving", r.stdout[-3000:])
+            assert r.returncode != 0 and "FAILED" in r.stdout, (tag, "expected the harness to fail", r.stdout[-3000:])

@@ -28,11 +28,14 @@ def test_factor_update_matches_dense_oracle(D, B):
                                         eng.asarray(st["mu0"]), eng.asarray(F0))
     assert eng.read_flag(flag) == 0
     Fn = F.cpu().numpy()
-    assert rel_err(mu.cpu().numpy(), mu_o) < 1e-10
-    assert rel_err(Fn.T @ Fn, S_o) < 1e-10
+    # 2B = D (256, 128): the Gram matrix of 2B rows in D dimensions is at the edge of nonsingularity (the form's precondition
+    # 2B <= D with equality), cond ~ 1e10: 3e-7 there, 1e-10 everywhere else
+    tol = 1e-6 if 2 * B == D else 1e-10
+    assert rel_err(mu.cpu().numpy(), mu_o) < tol
+    assert rel_err(Fn.T @ Fn, S_o) < tol
     # also equals the oracle's own factor-form restatement
     mu_f, F_f, ok = orc.gsm_factor_update(st["Z"], st["vs"], st["mu0"], st["L"])
-    assert ok and rel_err(Fn.T @ Fn, F_f @ F_f.T) < 1e-10
+    assert ok and rel_err(Fn.T @ Fn, F_f @ F_f.T) < tol
 
 
 def test_factor_update_general_square_factor():
