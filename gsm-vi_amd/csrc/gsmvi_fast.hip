@@ -308,6 +308,9 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
     do {                                                                                  \
         if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
+    // (Round 4 tried LDS-only barriers here -- s_waitcnt lgkmcnt(0); s_barrier instead of __syncthreads(), whose workgroup fence
+    // also drains the vector-memory counter: 6.45 against 6.38 us at D = 1024, B = 32, no effect; they matter in the persistent
+    // form below, where loads of the next item are in flight across the barriers.)
     if (blockIdx.x >= GSMVI_STAMP_WG) stamps = nullptr;          // timeline diagnostic: slot capacity (D >= 2048 has more workgroups)
     STAMP(0);
     constexpr int RS = 48;                       // LDS row stride (doubles): 32 columns + 16 pad
@@ -496,6 +499,12 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, const double* __re
                                                        const double* __restrict__ S0, int lds0,
                                                        double* __restrict__ S, int lds,
                                                        double* __restrict__ mu_out) {
+    // Workgroup barrier that waits for this wave's LDS operations ONLY.  __syncthreads() carries a workgroup-scope fence, which
+    // on gfx950 drains the vector-memory counter as well (s_waitcnt vmcnt(0)): every one of the five barriers of an item would
+    // wait for the NEXT item's loads issued in front of it -- the first version of this kernel did exactly that and ran 27 %
+    // slower than the one-item kernel.  No thread of the workgroup reads global data another thread of it wrote, so the barriers
+    // only have to order LDS.
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
     constexpr int RS = 48;
     constexpr int NPASS = (SB > 32) ? SB / 32 : 1;
     constexpr int SBP = SB / NPASS;
@@ -583,7 +592,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, const double* __re
         for (int k = 0; k < SB / 8; ++k) dmun[k] = 0.0;
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
-            if (pass > 0) __syncthreads();
+            if (pass > 0) LDS_BARRIER();
 #pragma unroll
             for (int q = 0; q < UPT; ++q) {
                 const int g = q * 512 + tid;
@@ -592,7 +601,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, const double* __re
                 if (b / SBP == pass && (two || tile < 4))
                     *reinterpret_cast<v2d*>(smem + tile * TILE + (b % SBP) * RS + 2 * (u & 15)) = stg[q];
             }
-            __syncthreads();
+            LDS_BARRIER();
             if (pass == NPASS - 1 && nxt < n_items) {        // the staging registers are free: the next item's loads go out now
                 nx = decode(nxt);
                 issue_loads(nx, s0n, dmun);
@@ -617,13 +626,13 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, const double* __re
                 }
             }
         }
-        __syncthreads();                                     // everyone is done reading the factor tiles
+        LDS_BARRIER();                                     // everyone is done reading the factor tiles
         double* LW = smem + t * 32 * 33;
         if (mine) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) LW[(16 * wr + ks + 4 * r) * 33 + 16 * wc + c] = (accd[r] - acce[r]) * invB;
         }
-        __syncthreads();
+        LDS_BARRIER();
         if (mine) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -637,7 +646,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, const double* __re
             }
         }
         const bool need = mine && !(t == 0 && diag);
-        __syncthreads();
+        LDS_BARRIER();
         if (need) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -649,14 +658,14 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, const double* __re
             }
         }
         if (diag) {                                          // (block-uniform)
-            __syncthreads();
+            LDS_BARRIER();
             if (tid < 256) {
                 double dsum = 0.0;
 #pragma unroll
                 for (int k = 0; k < SB / 8; ++k) dsum += dmuv[k];
                 smem[tid] = dsum;
             }
-            __syncthreads();
+            LDS_BARRIER();
             if (tid < 32) {
                 double sm_ = 0.0;
 #pragma unroll
@@ -665,7 +674,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, const double* __re
             }
         }
         if (nxt >= n_items) break;
-        __syncthreads();                                     // the LDS tiles of this item are dead: the next item may stage
+        LDS_BARRIER();                                     // the LDS tiles of this item are dead: the next item may stage
         item = nxt;
         cur = nx;
         s0v[0] = s0n[0];
@@ -674,6 +683,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, const double* __re
         for (int k = 0; k < SB / 8; ++k) dmuv[k] = dmun[k];
     }
 }
+#undef LDS_BARRIER
 
 // ---- launch helpers ------------------------------------------------------------------------
 void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, int D, int nrows, const double* A,
@@ -743,7 +753,7 @@ bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, cons
     // large D: the persistent form (2 resident workgroups per CU walk the item list, the next item's loads in flight during
     // the current item's MFMAs and stores); "cov_dbg" bit 512 keeps the one-item-per-workgroup kernel for A/B runs
     const int n_items = cov_sym_grid(D / 32);
-    if (n_items >= 2048 && !(dbg & 512) && !stamps && (dbg & 1023) == 0) {
+    if (n_items >= 2048 && B <= 32 && !stamps && dbg == 0) {    // (B = 64: two staging passes, MFMA-bound -- the one-item kernel is faster there)
         const dim3 pgrid(512);
 #define CSP(SBV) GSMVI_LAUNCH(k_gsm_cov_sym_p<SBV>, pgrid, dim3(512), 0, st, ev, D, rec, ldrec, mu0, S0, lds0, S, lds, mu_out)
         switch (B) {
