@@ -267,8 +267,6 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     else if (!strcmp(name, "gram_mt")) ctx->tune_gram_mt = value > 0 ? value : 4;
     else if (!strcmp(name, "bam_full")) ctx->tune_bam_full = value;
     else if (!strcmp(name, "bam_kenq")) ctx->tune_bam_kenq = value;
-    else if (!strcmp(name, "bam_subst")) ctx->tune_bam_subst = value;
-    else if (!strcmp(name, "bam_nsfuse")) ctx->tune_bam_nsfuse = value;
     else if (!strcmp(name, "scalars_nt")) ctx->tune_scalars_nt = value;
     else if (!strcmp(name, "cov_dbg")) ctx->tune_cov_dbg = value;   // ablation bits, timing experiments only
     else if (!strcmp(name, "timeline")) {                           // whole-update timeline stamps (diagnostic)

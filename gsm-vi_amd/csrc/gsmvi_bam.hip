@@ -271,15 +271,13 @@ __global__ __launch_bounds__(256) void k_bam_nmat2(int n, int kc, const double* 
     }
 }
 
-// ---- Z = L^-1 (P + T1), T1 = M1^T Vf precomputed by the panel product, n <= 144 -----------------------
+// ---- Z = L^-1 (P + M1^T Vf) by substitution, n <= 64 (the n <= 48 sizes whose chain is the one-workgroup k_bam_small48) -------
 // Sixteen lanes per column of D, 16 columns per workgroup.  Lane q of a column group owns rows q, q+16, ...
-// (9 registers).  U = L^T is staged in LDS in packed upper form (row p holds L[p..n-1][p], contiguous, so the
-// lanes of a group read consecutive words); pivot p is broadcast inside the group with one shuffle.
-// T1 arrives in rows n..2n-1 of Fs and is overwritten there with -Z by the lane that read it.
-// INLINE_T1 (n <= 64): T1 is not read but formed here, M1 (n x n, [k][r]) staged in LDS and the column's Vf values passed round
-// the 16-lane group by shuffles -- n^2 / 16 multiply-adds per lane instead of a skinny panel product + finish launch pair.
+// U = L^T is staged in LDS in packed upper form (row p holds L[p..n-1][p], contiguous, so the lanes of a group read
+// consecutive words); pivot p is broadcast inside the group with one shuffle.  T1 = M1^T Vf is formed here: M1 (n x n, [k][r])
+// staged in LDS and the column's Vf values passed round the 16-lane group by shuffles -- n^2 / 16 multiply-adds per lane.
+// -Z goes to rows n..2n-1 of Fs.  (Larger n: k_bam_zw above, a product with the explicit inverse factor.)
 #define BAMF_NMAX 144
-template <bool INLINE_T1>
 __global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const double* __restrict__ P,
                                                        const double* __restrict__ M1,
                                                        const double* __restrict__ Upk,
@@ -291,7 +289,7 @@ __global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const doubl
                                                        double* __restrict__ mu) {
     __shared__ __attribute__((aligned(16))) double U[BAMF_NMAX * (BAMF_NMAX + 1) / 2];
     __shared__ double sdi[BAMF_NMAX], szg[BAMF_NMAX], svg[BAMF_NMAX];
-    __shared__ double sM1[INLINE_T1 ? 64 * 64 : 1];
+    __shared__ double sM1[64 * 64];
     const int tid = threadIdx.x, c = tid >> 4, q = tid & 15, grp = tid & 48;
     const int j = blockIdx.x * 16 + c, jc = j < D ? j : D - 1;
     const int npk = n * (n + 1) / 2;
@@ -323,11 +321,10 @@ __global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const doubl
     for (int i = 0; i < 9; ++i) {
         const int r = q + 16 * i, rc = r < n ? r : n - 1;
         double a = P[(size_t)rc * D + jc];
-        if (!INLINE_T1) a += Fs[(size_t)(n + rc) * D + jc];
         x[i] = r < n ? a : 0.0;
         vf[i] = r < n ? Ft[(size_t)rc * D + jc] : 0.0;
     }
-    if (INLINE_T1) {
+    {
         double mv[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -341,7 +338,7 @@ __global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const doubl
         }
     }
     __syncthreads();
-    if (INLINE_T1) {                                   // x += M1^T vf: vf_k lives in lane k & 15 of the group, register k >> 4
+    {                                                  // x += M1^T vf: vf_k lives in lane k & 15 of the group, register k >> 4
 #pragma unroll
         for (int ik = 0; ik < 4; ++ik) {
             if (16 * ik >= n) break;                   // uniform
@@ -741,8 +738,8 @@ __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, cons
     } while (0)
 
 int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* Nd, const double* M1,
-                           const double* N0, double* scratch, double* Ld, double* Upk, int* info_dev, int* hint_host,
-                           int force_kenq, double* Wscr);
+                           const double* N0, double* scratch, double* Ld, int* info_dev, int* hint_host, int force_kenq,
+                           double* Rscr);
 int gsmvi_bam_small_nmax();
 size_t gsmvi_bam_small_scratch_doubles(int n);
 int gsmvi_panel_t_product(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* A, int lda, const double* M,
@@ -784,54 +781,37 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     double* M1T = Nd + (size_t)n * n;              // n x n
     double* Upk = M1T + (size_t)n * n;             // n(n+1)/2: packed rows of L^T
     const double* Ldinv = Ld + (size_t)n * n;
-    // 48 < n <= 128 (round 4): Cholesky with the inverse factor + product-form Z (k_bam_cholw, k_bam_zw); "bam_subst" = 1 keeps
-    // the round-3 route (k_bam_chol_out + forward substitution) for A/B runs
-    const bool use_w = n > gsmvi_bam_small_fused_nmax() && n <= 128 && !ctx->tune_bam_subst;
-    if (n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full) {
-        // n <= 48: slab sum, N, the matrix function, its Cholesky factor and the small outputs in ONE one-workgroup launch
-        if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, n, (size_t)n2 * n, M1, Ld, Upk,
-                                        info_dev ? info_dev : ctx->ints + 8)))
-            return rc;
-    } else {
-        if (use_w) {
-            // slab sums of [N0; M1] and N = M1^T M1 + sym(N0) in one launch
-            const int nbq = (n + 15) / 16;
-            hipLaunchKernelGGL(k_bam_nmat2, dim3(nbq * nbq), dim3(256), 0, st, n, kc, ctx->pp, (long long)n2 * n, N0, M1, Nd);
-        } else {
-            if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
-            // N = M1^T M1 + sym(N0) and M1^T on the device
-            hipLaunchKernelGGL(k_bam_nmat, dim3((((n + 15) / 16) * ((n + 15) / 16) + 3) / 4), dim3(256), 0, st, n, M1, N0, Nd, M1T);
-        }
-        // the whole n x n matrix function on the device (gsmvi_bam_small.hip): no copy, no synchronisation
-        double* scratch = Upk + (size_t)n * (n + 1) / 2 + 2;
-        if (!ctx->bam_hint_host) {                 // pinned, device-visible word for the step-count hint
-            if (hipHostMalloc(reinterpret_cast<void**>(&ctx->bam_hint_host), 64, hipHostMallocMapped) == hipSuccess)
-                *ctx->bam_hint_host = 0;
-            else
-                ctx->bam_hint_host = nullptr;
-        }
-        if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, Upk, info_dev ? info_dev : ctx->ints + 8,
-                                         ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq,
-                                         use_w ? M1T : nullptr)))
-            return rc;
+    // n <= 48: the whole small chain in ONE one-workgroup launch (k_bam_small48) + the 16-lanes-per-column substitution;
+    // 48 < n <= 128 (and n <= 48 under the "bam_full" test knob): slab sums + N (k_bam_nmat2), the multi-workgroup Newton-Schulz
+    // steps, BB / Cholesky with the inverse factor (k_bam_bbav, k_bam_cholw) and the product-form Z (k_bam_zw); n > 128: blocked
+    // multi-workgroup Cholesky and the generic forward substitution.
+    const bool fused48 = n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full;
+    const bool use_w = !fused48 && n <= 128;
+    if (!fused48 && !ctx->bam_hint_host) {         // pinned, device-visible word for the step-count hint
+        if (hipHostMalloc(reinterpret_cast<void**>(&ctx->bam_hint_host), 64, hipHostMallocMapped) == hipSuccess)
+            *ctx->bam_hint_host = 0;
+        else
+            ctx->bam_hint_host = nullptr;
     }
-    const bool lanes16 = n <= 129;              // the sizes whose Cholesky kernel (k_bam_chol_out) also emits the packed rows
-    if (use_w) {
+    double* scratch = Upk + (size_t)n * (n + 1) / 2 + 2;
+    int* info_p = info_dev ? info_dev : ctx->ints + 8;
+    int* hint = ctx->tune_bam_full ? nullptr : ctx->bam_hint_host;
+    if (fused48) {
+        if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, n, (size_t)n2 * n, M1, Ld, Upk, info_p))) return rc;
+        hipLaunchKernelGGL(k_bam_forward16, dim3((D + 15) / 16), dim3(256), 0, st, D, n, P, M1, Upk, Ldinv, Ldinv + n,
+                           Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu);
+    } else if (use_w) {
+        const int nbq = (n + 15) / 16;
+        hipLaunchKernelGGL(k_bam_nmat2, dim3(nbq * nbq), dim3(256), 0, st, n, kc, ctx->pp, (long long)n2 * n, N0, M1, Nd);
+        if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_p, hint, ctx->tune_bam_kenq, M1T))) return rc;
         // Z = W (P + M1^T Vf) by two chained MFMA products per 16 columns of D, the mean with it (Wt = (L^-1)^T sits in Ld's slot,
         // [a | . | vg] behind it)
         hipLaunchKernelGGL(k_bam_zw, dim3((D + 15) / 16), dim3(512), 0, st, D, n, P, M1, Ld, Ldinv, Ldinv + 2 * n, mu0, xbar,
                            reg, Ft, Fs, mu);
-    } else if (lanes16 && n <= 64) {
-        // the 16-lanes-per-column substitution with T1 = M1^T Vf formed inside
-        hipLaunchKernelGGL(k_bam_forward16<true>, dim3((D + 15) / 16), dim3(256), 0, st, D, n, P, M1, Upk, Ldinv, Ldinv + n,
-                           Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu);
-    } else if (lanes16) {
-        // T1 = M1^T Vf into rows n..2n-1 of Fs, then the 16-lanes-per-column substitution
-        if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, n, D, n, M1T, n, nullptr, 1.0, Ft, D, ctx->pp, &kc))) return rc;
-        if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, Fs + (size_t)n * D, D))) return rc;
-        hipLaunchKernelGGL(k_bam_forward16<false>, dim3((D + 15) / 16), dim3(256), 0, st, D, n, P, M1, Upk, Ldinv, Ldinv + n,
-                           Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu);
     } else {
+        if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
+        hipLaunchKernelGGL(k_bam_nmat, dim3((((n + 15) / 16) * ((n + 15) / 16) + 3) / 4), dim3(256), 0, st, n, M1, N0, Nd, M1T);
+        if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_p, hint, ctx->tune_bam_kenq, nullptr))) return rc;
 #define BFW(CV) hipLaunchKernelGGL(k_bam_forward<CV>, dim3((D + CV - 1) / CV), dim3(CV), sizeof(double) * 2 * n * CV, st, D, n, P, M1, Ld, Ldinv, Ldinv + n, Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu)
         if (n <= 160) BFW(64); else if (n <= 320) BFW(32); else BFW(16);
 #undef BFW
@@ -907,44 +887,35 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     const double* Ldinv = Ld + (size_t)n * n;
     int* info_bam = ctx->ints + 8;
     int kc = 1, rc;
-    // n > 48: the chain of the dense form (k_bam_cholw + k_bam_zw); the "bam_subst" route only exists up to n = 64 here
-    const bool use_w = n > gsmvi_bam_small_fused_nmax() && n <= 128 && !(ctx->tune_bam_subst && n <= 64);
+    // n <= 48: one one-workgroup launch for the small chain + the 16-lanes-per-column substitution; above: the chain of the
+    // dense form (k_bam_nmat2, Newton-Schulz steps, k_bam_bbav, k_bam_cholw) and the product-form Zw (k_bam_zw).
+    // Zw = L^-1 (Wq + M1^T Vw); the mean output of either kernel (mu0 = xbar = 0) is r1 (wg + Vw^T vg - Zw^T zg) = r1 h, row 2n of Ft
+    const bool fused48 = n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full;
 
     hipLaunchKernelGGL(k_bam_stats_h, dim3((D + 63) / 64), dim3(256), 0, st, D, B, Z, ldz, (const double*)nullptr, X, ldx, G, ldg,
                        reg, xbar, gbar, zerov, Qt, Ft, (double*)nullptr);
     if ((rc = gsmvi_panel_t_product(ctx, st, D, n, Qt, D, F0, ldf0, D, ctx->pp, &kc))) return rc;
     if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, Wq, D))) return rc;
     if ((rc = gsmvi_panel_t_product(ctx, st, D, n2, Wq, D, Wq, D, n, ctx->pp, &kc))) return rc;
-    if (n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full) {
+    if (fused48) {
         if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, n, (size_t)n2 * n, M1, Ld, Upk, info_bam))) return rc;
+        hipLaunchKernelGGL(k_bam_forward16, dim3((D + 15) / 16), dim3(256), 0, st, D, n, Wq, M1, Upk, Ldinv, Ldinv + n,
+                           Ldinv + 2 * n, zerov, zerov, reg, Ft, T1, Ft + (size_t)n2 * D);
     } else {
-        if (use_w) {
-            const int nbq = (n + 15) / 16;
-            hipLaunchKernelGGL(k_bam_nmat2, dim3(nbq * nbq), dim3(256), 0, st, n, kc, ctx->pp, (long long)n2 * n, N0, M1, Nd);
-        } else {
-            if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
-            hipLaunchKernelGGL(k_bam_nmat, dim3((((n + 15) / 16) * ((n + 15) / 16) + 3) / 4), dim3(256), 0, st, n, M1, N0, Nd, M1T);
-        }
         if (!ctx->bam_hint_host) {
             if (hipHostMalloc(reinterpret_cast<void**>(&ctx->bam_hint_host), 64, hipHostMallocMapped) == hipSuccess)
                 *ctx->bam_hint_host = 0;
             else
                 ctx->bam_hint_host = nullptr;
         }
-        if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, Upk, info_bam,
-                                         ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq,
-                                         use_w ? M1T : nullptr)))
+        const int nbq = (n + 15) / 16;
+        hipLaunchKernelGGL(k_bam_nmat2, dim3(nbq * nbq), dim3(256), 0, st, n, kc, ctx->pp, (long long)n2 * n, N0, M1, Nd);
+        if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_bam,
+                                         ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq, M1T)))
             return rc;
-    }
-    // Zw = L^-1 (Wq + M1^T Vw); its mean output (mu0 = xbar = 0) is r1 (wg + Vw^T vg - Zw^T zg) = r1 h, written as row 2n of Ft.
-    // n <= 48: the 16-lanes-per-column substitution (M1^T Vw formed inside); above: W = L^-1 from k_bam_cholw and two chained
-    // MFMA products per 16 columns (k_bam_zw), as the dense form
-    if (use_w)
         hipLaunchKernelGGL(k_bam_zw, dim3((D + 15) / 16), dim3(512), 0, st, D, n, Wq, M1, Ld, Ldinv, Ldinv + 2 * n, zerov, zerov,
                            reg, Ft, T1, Ft + (size_t)n2 * D);
-    else
-        hipLaunchKernelGGL(k_bam_forward16<true>, dim3((D + 15) / 16), dim3(256), 0, st, D, n, Wq, M1, Upk, Ldinv, Ldinv + n,
-                           Ldinv + 2 * n, zerov, zerov, reg, Ft, T1, Ft + (size_t)n2 * D);
+    }
     ctx->fo_Rt = Ft;
     ctx->fo_Tm = Tm;
     ctx->fo_Fs = Fsf;

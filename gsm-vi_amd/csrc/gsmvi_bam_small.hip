@@ -13,12 +13,15 @@
 // the lower bound is KNOWN, the scaling c^2 = 3 / (1 + sqrt(l) + l) (Chen & Chow's scaled Newton-Schulz, written
 // for mu = sigma^2) is computed from a scalar recurrence alone: small eigenvalues grow ~6.75x per step instead of
 // 2.25x, 12-15 steps instead of ~27 at cond(A) ~ 1e7.  The recurrence (and hence the number of steps k*) depends
-// on s, which lives on the device: k_bam_ns_prep runs it once and stores c_k^2 and k*; the host enqueues the
-// launches of BAMS_KMAX steps and the ones beyond k* return at once.  Two launches per step on many workgroups:
-// M = Z Y, then Y' and Z' together (one 16 x 16 block per wave, fp64 MFMA, operands straight from L2).  Then BB
-// (symmetrised), its Cholesky factor in ONE workgroup
-// (two 64 x 64 blocks as in the factor path, plus one bordered column for n = 129) and the small outputs that
-// k_bam_forward16 consumes.  No host synchronisation, no host arithmetic.
+// on s, which lives on the device: k_bam_ns_prep runs it once and stores c_k^2 and k*; the host enqueues the launches of
+// k* + 1 steps (k* of the previous call, a pinned word read without synchronising) and the ones beyond k* return at once;
+// k_bam_ns_tail makes up for a stale guess.  Two launches per step on many workgroups: M = Z Y, then Y' and Z' together
+// (one 16 x 16 block per workgroup, K split over its four waves, fp64 MFMA, operands straight from L2); the first M = Z0 Y0 = Y0
+// comes from k_bam_ns_prep.  Round 4 measured a ONE-launch step (every workgroup recomputing the 16-wide panel of M it needs,
+// rows of Z staged in LDS): 9.2 us against 2 x 4.55 us -- the n/16-fold recomputation costs what the second launch costs, so it
+// was not kept (profiles/r04/c4_chain_ab.txt).  Then, n <= 128: BB (symmetrised) and the factor-independent vectors on many
+// workgroups (k_bam_bbav), the Cholesky factorisation WITH the inverse factor in one workgroup (k_bam_cholw: chol64_blk /
+// chol128w_body), and Z = L^-1 (...) as an MFMA product in k_bam_zw (gsmvi_bam.hip).  No host synchronisation, no host arithmetic.
 #include "gsmvi_common.h"
 #include "gsmvi_ctx.h"
 #include "gsmvi_chol64.h"
@@ -26,9 +29,9 @@
 #include "gsmvi_chol128.h"
 #include "../../include/gsmvi_hip.h"
 
-#define BAMS_NMAX 129                // largest n of the one-workgroup Cholesky k_bam_chol_out; above it: blocked potrf + k_bam_post_big
+#define BAMS_NMAX 128                // largest n of the one-workgroup Cholesky k_bam_cholw; above it: blocked potrf + k_bam_post_big
 #define BAMS_NBIG 640                // largest n altogether (LDS of the forward substitution kernel, 16 columns per workgroup)
-#define BAMS_LD 144                  // padded leading dimension of the iteration matrices for n <= 129 (9 blocks of 16);
+#define BAMS_LD 144                  // padded leading dimension of the iteration matrices for n <= 128 (9 blocks of 16: n = B + 1 <= 129 until round 3);
                                      // larger n: n rounded up to 16 (passed to the kernels as `ld`)
 #define BAMS_KMAX 32                 // launches enqueued; k* <= BAMS_KMAX is checked on the device (else flagged)
 // coef layout (doubles): [0..KMAX) c_k^2, [40] k*, [41] s, [42] 1 if s is not finite or the bound did not close in KMAX steps
@@ -37,7 +40,7 @@
 // ---- s = trace(N + I/4) >= lambda_max, Y0 = (N + I/4)/s, Z0 = I (padded to BAMS_LD), the scaling recurrence -------
 // Every workgroup sums the diagonal itself (n loads) and fills its share of Y0 / Z0; workgroup 0 also runs the scalar
 // recurrence.  A NaN / inf anywhere in N needs no flag of its own: it propagates through the products into BB, where
-// k_bam_chol_out rejects it.
+// k_bam_cholw rejects it.
 // Mm also receives Y0: the first step's M = Z0 Y0 = I Y0 is Y0 exactly, so the launch k_bam_ns_zy(k = 0) is not enqueued.
 __global__ __launch_bounds__(256) void k_bam_ns_prep(int n, int ld, const double* __restrict__ Nm, double* __restrict__ Y,
                                                      double* __restrict__ Z, double* __restrict__ Mm,
@@ -153,235 +156,6 @@ __global__ __launch_bounds__(256) void k_bam_ns_step(int n, int ld, int k, doubl
     else bams_block<2>(Mm, Zi, Zo, blockIdx.x - nb * nb, nb, nk, c2, c, ld);                        // Z' = c T Z
 }
 
-// ---- ONE launch per step (round 4, opt-in: knob "bam_nsfuse"): M = Z Y is not handed over through memory, every workgroup forms
-// the 16-wide panel of it that its own output block needs ---------------------------------------------------------------------
-// Two launches per step are launch-bound (2 x 4.7 us for 12.6 MFLOP at n = 128: 26 launches, 123 us of a 329 us update).
-// Here workgroup blk < nb^2 owns block (i, j) of Y' = c Y T and needs the COLUMN panel T(:, j) = 1.5 I - 0.5 c^2 (Z Y)(:, j);
-// workgroup nb^2 + blk owns block (i, j) of Z' = c T Z and needs the ROW panel T(i, :).  Eight waves: wave w forms the 16 x 16
-// block w of the panel (K = n, two accumulator chains) -- an n / 16-fold recomputation of M over the grid (0.52 MFLOP per
-// workgroup), the price of not waiting for a second launch.  The rows of Z that a wave multiplies from the left are staged in
-// LDS with whole-row 16-byte loads ([16][132] per wave: the MFMA A-fragments then come from LDS without bank conflicts); the
-// first version loaded the fragments straight from L2 -- 16 cache lines per load instruction, 64 instructions per lane -- and
-// took 13.3 us per launch, slower than the two launches it replaced.  The B-operand rows (16 consecutive doubles per k) are read
-// from L2 directly.  The panel goes to LDS as T; the own block's K = n product is split over the eight waves and summed through
-// LDS in a fixed order.  Every block of every product is computed exactly as it stands (same operands, same order in every
-// workgroup that needs it), so the iterates are deterministic and the copies of a panel block in different workgroups are
-// bit-identical.  Loads are issued before the step-count test (coef[40]): a launch beyond k* costs its launch, not a round trip.
-#define BAMF_ZS 132
-__global__ __launch_bounds__(512) void k_bam_ns_fused(int n, int ld, int k, double* __restrict__ Ya, double* __restrict__ Za,
-                                                      double* __restrict__ Yb, double* __restrict__ Zb,
-                                                      const double* __restrict__ coef) {
-    __shared__ __attribute__((aligned(16))) double Zs[8 * 16 * BAMF_ZS];   // staged rows of Z; later the partial blocks (red)
-    __shared__ __attribute__((aligned(16))) double Ts[128 * 17];          // column panel: [k][16]; row panel: [16][129]
-    const int nb = (n + 15) >> 4;
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
-    const bool isZ = (int)blockIdx.x >= nb * nb;
-    const int blk = isZ ? blockIdx.x - nb * nb : blockIdx.x;
-    const int bi = blk / nb, bj = blk - bi * nb, i0 = 16 * bi, j0 = 16 * bj;
-    const double* Y = (k & 1) ? Yb : Ya;
-    const double* Z = (k & 1) ? Zb : Za;
-    double* Yo = (k & 1) ? Ya : Yb;
-    double* Zo = (k & 1) ? Za : Zb;
-    // panel block w: Y' needs M(16w.., j0..) = Z(16w.., :) Y(:, j0..); Z' needs M(i0.., 16w..) = Z(i0.., :) Y(:, 16w..)
-    const int pr0 = isZ ? i0 : 16 * w, pc0 = isZ ? 16 * w : j0;
-    // rows of Z to stage: Y' -- wave w its own 16 rows (slot w); Z' -- the 16 rows i0.., two per wave (slot 0).  Whole rows, 16 B
-    // per lane (columns 2 l, 2 l + 1 < 128 <= ld)
-    v2d zr[16];
-    const int nrow = isZ ? 2 : 16;
-    if (isZ || w < nb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (r < nrow) {
-                const int row = isZ ? i0 + 2 * w + r : 16 * w + r;
-                zr[r] = *reinterpret_cast<const v2d*>(Z + (size_t)row * ld + 2 * l);
-            }
-    }
-    double b[32];
-    if (w < nb) {
-#pragma unroll
-        for (int st = 0; st < 32; ++st) {
-            const int kk = 4 * st + ks;
-            b[st] = Y[(size_t)kk * ld + pc0 + cc];            // kk <= 127 < ld
-        }
-    }
-    // the own block's operand that does not depend on T: Y(i0.., k) for Y' (A-operand), Z(k, j0..) for Z' (B-operand); wave w takes
-    // the k-steps st = w, w + 8, ... (K = n <= 128: at most four)
-    double o[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int kk = 4 * (w + 8 * u) + ks;                  // <= 127
-        o[u] = isZ ? Z[(size_t)kk * ld + j0 + cc] : Y[(size_t)(i0 + cc) * ld + kk];
-    }
-    const double kst = coef[40], fl = coef[42], c2 = coef[k];
-    asm volatile("" ::: "memory");                           // the operand loads above may not sink below the test that follows
-    if ((double)k >= kst || fl != 0.0) return;
-    const double c = sqrt(c2);
-    const int nk = (n + 3) >> 2;
-    if (isZ || w < nb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (r < nrow) {
-                const int slot_row = isZ ? 2 * w + r : 16 * w + r;
-                *reinterpret_cast<v2d*>(Zs + (size_t)slot_row * BAMF_ZS + 2 * l) = zr[r];
-            }
-    }
-    __syncthreads();
-    if (w < nb) {
-        const double* ap = Zs + (size_t)((isZ ? 0 : 16 * w) + cc) * BAMF_ZS + ks;
-        double a[32];
-#pragma unroll
-        for (int st = 0; st < 32; ++st) a[st] = ap[4 * st];
-        v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int st = 0; st < 32; st += 2) {
-            if (st < nk) {                                   // block-uniform
-                acc0 = GSMVI_MFMA_F64(a[st], b[st], acc0);
-                acc1 = GSMVI_MFMA_F64(a[st + 1], b[st + 1], acc1);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int pr = pr0 + ks + 4 * r, pc = pc0 + cc;   // element (pr, pc) of M
-            const double t = (pr == pc ? 1.5 : 0.0) - 0.5 * c2 * (acc0[r] + acc1[r]);
-            if (isZ) Ts[(ks + 4 * r) * 129 + pc] = t;          // row panel  T(i0 + row, col):  [16][129]
-            else Ts[pr * 16 + cc] = t;                        // column panel T(row, j0 + col): [n][16]
-        }
-    }
-    __syncthreads();                                         // (every read of Zs is done: it becomes the reduction buffer)
-    double* red = Zs;
-    {   // own block: Y'(i0.., j0..) = c sum_k Y(i0.., k) T(k, j0..)   |   Z'(i0.., j0..) = c sum_k T(i0.., k) Z(k, j0..)
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int st = w + 8 * u, kk = 4 * st + ks;
-            if (st < nk) {                                   // wave-uniform
-                const double tv = isZ ? Ts[cc * 129 + kk] : Ts[kk * 16 + cc];
-                acc = isZ ? GSMVI_MFMA_F64(tv, o[u], acc) : GSMVI_MFMA_F64(o[u], tv, acc);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[w * 256 + (ks + 4 * r) * 16 + cc] = acc[r];
-    }
-    __syncthreads();
-    if (tid < 256) {
-        const int t = tid;                                   // element (t >> 4, t & 15) of the block
-        const double v = ((red[t] + red[256 + t]) + (red[512 + t] + red[768 + t])) +
-                         ((red[1024 + t] + red[1280 + t]) + (red[1536 + t] + red[1792 + t]));
-        (isZ ? Zo : Yo)[(size_t)(i0 + (t >> 4)) * ld + j0 + (t & 15)] = c * v;
-    }
-}
-
-// ---- n <= 48: the whole iteration in ONE workgroup, matrices in LDS, exactly k* steps --------------------------------
-// Nine waves, wave (bi, bj) owns the 16 x 16 block (bi, bj) of every product; Y, Z ping-pong between two LDS buffers.
-// Same arithmetic as the multi-workgroup chain (same scaling recurrence, same product order); writes BB directly.
-#define BAMS_SN 48
-#define BAMS_SLD 50
-__global__ __launch_bounds__(576) void k_bam_ns_small(int n, const double* __restrict__ Nm, double* __restrict__ BBg) {
-    __shared__ double Yb_[2][BAMS_SN * BAMS_SLD], Zb_[2][BAMS_SN * BAMS_SLD], Ms[BAMS_SN * BAMS_SLD];
-    __shared__ double coefs[BAMS_KMAX + 4];
-    __shared__ double red[9];
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
-    const int bi = w / 3, bj = w % 3, i0 = 16 * bi, j0 = 16 * bj;
-    double tr = 0.0;
-    for (int i = tid; i < n; i += 576) tr += Nm[(size_t)i * n + i] + 0.25;
-    tr = wave_sum(tr);
-    if (l == 0) red[w] = tr;
-    __syncthreads();
-    double s = 0.0;
-#pragma unroll
-    for (int u = 0; u < 9; ++u) s += red[u];
-    const double sinv = 1.0 / s;
-    for (int e = tid; e < BAMS_SN * BAMS_SN; e += 576) {
-        const int i = e / BAMS_SN, j = e % BAMS_SN;
-        const bool in = i < n && j < n;
-        Yb_[0][i * BAMS_SLD + j] = in ? (Nm[(size_t)i * n + j] + (i == j ? 0.25 : 0.0)) * sinv : 0.0;
-        Zb_[0][i * BAMS_SLD + j] = (in && i == j) ? 1.0 : 0.0;
-    }
-    if (tid == 0) {
-        double lb = 0.25 * sinv;
-        const bool s_ok = (s == s) && s > 0.0 && s < 1e300;
-        if (!(lb > 0.0) || lb > 1.0) lb = 1.0;
-        int kstar = BAMS_KMAX + 1;
-        for (int k = 0; k < BAMS_KMAX; ++k) {
-            const double c2 = (lb < 0.25) ? 3.0 / (1.0 + sqrt(lb) + lb) : 1.0;
-            coefs[k] = c2;
-            const double x = c2 * lb;
-            lb = x * (3.0 - x) * (3.0 - x) * 0.25;
-            if (lb > 1.0) lb = 1.0;
-            if (1.0 - lb < 5e-9 && kstar > BAMS_KMAX) kstar = k + 2;
-        }
-        coefs[BAMS_KMAX + 1] = (!s_ok || kstar > BAMS_KMAX) ? 1.0 : 0.0;
-        if (kstar > BAMS_KMAX) kstar = BAMS_KMAX;
-        coefs[BAMS_KMAX] = (double)kstar;
-    }
-    __syncthreads();
-    const int kstar = (int)coefs[BAMS_KMAX];
-    const bool failed = coefs[BAMS_KMAX + 1] != 0.0;
-    const int nk = (n + 3) >> 2;
-    for (int k = 0; k < kstar && !failed; ++k) {
-        const double* Y = Yb_[k & 1];
-        const double* Z = Zb_[k & 1];
-        double* Yo = Yb_[(k & 1) ^ 1];
-        double* Zo = Zb_[(k & 1) ^ 1];
-        const double c2 = coefs[k], c = sqrt(c2);
-        constexpr int NST = BAMS_SN / 4;                     // up to 12 k-steps (nk = ceil(n / 4) of them are non-zero)
-        {   // M = Z Y
-            double a[NST], b[NST];
-#pragma unroll
-            for (int st = 0; st < NST; ++st) {
-                const int kk = 4 * st + ks;
-                a[st] = Z[(i0 + cc) * BAMS_SLD + kk];
-                b[st] = Y[kk * BAMS_SLD + j0 + cc];
-            }
-            v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int st = 0; st < NST; st += 2) {
-                if (st < nk) {                               // block-uniform: the padded k-steps are skipped
-                    acc0 = GSMVI_MFMA_F64(a[st], b[st], acc0);
-                    acc1 = GSMVI_MFMA_F64(a[st + 1], b[st + 1], acc1);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Ms[(i0 + ks + 4 * r) * BAMS_SLD + j0 + cc] = acc0[r] + acc1[r];
-        }
-        __syncthreads();
-        {   // Y' = c Y T,  Z' = c T Z,  T = 1.5 I - 0.5 c2 M
-            double ya[NST], tb[NST], ta[NST], zb[NST];
-#pragma unroll
-            for (int st = 0; st < NST; ++st) {
-                const int kk = 4 * st + ks;
-                tb[st] = (kk == j0 + cc ? 1.5 : 0.0) - 0.5 * c2 * Ms[kk * BAMS_SLD + j0 + cc];      // T[kk][j]
-                ta[st] = (kk == i0 + cc ? 1.5 : 0.0) - 0.5 * c2 * Ms[(i0 + cc) * BAMS_SLD + kk];    // T[i][kk]
-                ya[st] = Y[(i0 + cc) * BAMS_SLD + kk];
-                zb[st] = Z[kk * BAMS_SLD + j0 + cc];
-            }
-            v4d ay0 = {0.0, 0.0, 0.0, 0.0}, ay1 = ay0, az0 = ay0, az1 = ay0;
-#pragma unroll
-            for (int st = 0; st < NST; st += 2) {
-                if (st < nk) {
-                    ay0 = GSMVI_MFMA_F64(ya[st], tb[st], ay0);
-                    az0 = GSMVI_MFMA_F64(ta[st], zb[st], az0);
-                    ay1 = GSMVI_MFMA_F64(ya[st + 1], tb[st + 1], ay1);
-                    az1 = GSMVI_MFMA_F64(ta[st + 1], zb[st + 1], az1);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                Yo[(i0 + ks + 4 * r) * BAMS_SLD + j0 + cc] = c * (ay0[r] + ay1[r]);
-                Zo[(i0 + ks + 4 * r) * BAMS_SLD + j0 + cc] = c * (az0[r] + az1[r]);
-            }
-        }
-        __syncthreads();
-    }
-    const double* Yf = Yb_[kstar & 1];
-    const double rs = sqrt(s);
-    for (int e = tid; e < n * n; e += 576) {
-        const int i = e / n, j = e % n;
-        const double y = 0.5 * (Yf[i * BAMS_SLD + j] + Yf[j * BAMS_SLD + i]);
-        BBg[e] = failed ? __longlong_as_double(0x7ff8000000000000LL) : Nm[e] + (i == j ? 0.5 : 0.0) + rs * y;
-    }
-}
-
 // ---- safety net behind the enqueued steps --------------------------------------------------------------------------
 // The host enqueues kenq <= BAMS_KMAX multi-workgroup steps, guessed from the k* of the previous call (a pinned host
 // word written by k_bam_ns_prep: no synchronisation, possibly stale).  If this call's k* turns out larger, the missing
@@ -452,153 +226,6 @@ __global__ __launch_bounds__(256) void k_bam_ns_bb(int n, int ld, const double* 
     BBg[e] = (coef[42] != 0.0) ? __longlong_as_double(0x7ff8000000000000LL) : Nm[e] + (i == j ? 0.5 : 0.0) + rs * y;
 }
 
-// ---- Cholesky of BB (n <= 129) in ONE workgroup and the small outputs ---------------------------------------------
-// The leading min(n, 128) rows/columns: two 64 x 64 diagonal blocks (chol64), the 64-column block row by the quad
-// substitution, the rank-64 update of the second block on the VALU (as k_chol128 in the factor path).  n = 129: the
-// last column is bordered on: r = R11^-T a by one wave, rho = sqrt(alpha - r.r).
-// Outputs: Ld (n x n, lower L = R^T), Ldinv (n), zg (n), vg (n) behind it, Upk (packed rows of R from the diagonal).
-__global__ __launch_bounds__(512) void k_bam_chol_out(int n, double reg, const double* __restrict__ BBg,
-                                                      const double* __restrict__ M1, const double* __restrict__ N0,
-                                                      double* __restrict__ Ld, double* __restrict__ Upk,
-                                                      int* __restrict__ info) {
-    constexpr int MS = 130;
-    __shared__ __attribute__((aligned(16))) double M[128 * MS];
-    __shared__ double rinv[128], sc[BAMS_NMAX + 3], av[BAMS_NMAX + 3];
-    __shared__ double rho_s;
-    __shared__ int sh_fail[2], sh_bad;
-    const int tid = threadIdx.x;
-    const int n1 = n < 128 ? n : 128;                        // size of the blocked part
-    double* Ldinv = Ld + (size_t)n * n;
-    double* zg = Ldinv + n;
-    double* vg = zg + n;
-    // Eight waves since round 2: waves 0-3 ("team") run everything written for 256 threads; waves 4-7 only help in the
-    // blocked part -- the block row R12 one pivot behind the factorisation of A11 and the MFMA rank-64 update (the shared
-    // pieces of gsmvi_chol64.h, as k_chol128 of the factor path) -- match the barriers of the second factorisation and
-    // leave (a finished wave no longer takes part in the workgroup's barriers).
-    const bool team = tid < 256;
-    // load the upper triangle of the leading block (identity beyond n1) and, for n = 129, the border column
-    int nan_in = 0;
-    if (team) {
-#pragma unroll 1
-        for (int e0 = 0; e0 < 128 * 128; e0 += 256 * 16) {      // sixteen clamped loads in flight per thread
-            double v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int e = e0 + 256 * u + tid, i = e >> 7, j = e & 127;
-                v[u] = BBg[(size_t)(i < n1 ? i : n1 - 1) * n + (j < n1 ? j : n1 - 1)];
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int e = e0 + 256 * u + tid, i = e >> 7, j = e & 127;
-                const bool in = i < n1 && j < n1;
-                if (in && !(v[u] == v[u])) nan_in = 1;
-                M[i * MS + j] = in ? (j >= i ? v[u] : 0.0) : (i == j ? 1.0 : 0.0);
-            }
-        }
-    }
-    if (n > 128 && tid < 128) M[tid * MS + 128] = BBg[(size_t)tid * n + 128];
-    if (tid < 128) rinv[tid] = 1.0;
-    if (tid == 0) { sh_bad = 0; sh_fail[0] = sh_fail[1] = 0; rho_s = 1.0; }
-    __syncthreads();
-    if (nan_in) sh_bad = 1;
-    __syncthreads();
-    if (n1 > 64) {
-        if (team) chol64_rows_s<MS>(M, rinv, 64, &sh_fail[0]);
-        else chol128_helper_rowsolve<MS>(M);            // R12 = R11^-T A12 (64 columns), one pivot behind
-        __syncthreads();
-        chol128_rank64_update<MS>(M);                    // A22 -= R12^T R12 on the MFMA pipe
-        __syncthreads();
-        if (team) chol64_rows_s<MS>(M + 64 * MS + 64, rinv + 64, n1 - 64, &sh_fail[1]);
-        else chol64_helper_idle<MS>(n1 - 64);
-    } else {
-        if (team) chol64_rows_s<MS>(M, rinv, n1, &sh_fail[0]);
-        else chol64_helper_idle<MS>(n1);
-    }
-    if (!team) return;
-    __syncthreads();
-
-    // vg = Vf gbar = M1[:, n-1] / r1s and a = P gbar + M1^T vg (bam.py:107 applied to gbar) do not depend on the factor:
-    // they are computed by waves 1-3 while wave 0 runs the border substitution (n = 129), eight loads in flight
-    const double r1s = sqrt(reg / (1.0 + reg));
-    for (int p = tid; p < n; p += 256) sc[p] = M1[(size_t)p * n + (n - 1)] / r1s;
-    __syncthreads();
-    const bool border = n > 128;
-    if (border && tid < 64) {
-        // border column: r = R11^-T a, column-oriented forward substitution in one wave
-        double a0 = M[tid * MS + 128], a1 = M[(tid + 64) * MS + 128];
-        for (int p = 0; p < 128; ++p) {
-            const double cur = (p < 64) ? a0 : a1;
-            const double rp = __shfl(cur, p & 63, 64) * rinv[p];
-            if (tid == (p & 63)) { if (p < 64) a0 = rp; else a1 = rp; }
-            const double r0 = M[p * MS + tid], r1 = M[p * MS + tid + 64];
-            if (tid > p) a0 -= r0 * rp;
-            if (tid + 64 > p) a1 -= r1 * rp;
-        }
-        M[tid * MS + 128] = a0;
-        M[(tid + 64) * MS + 128] = a1;
-        double ss = wave_sum(a0 * a0 + a1 * a1);
-        if (tid == 0) {
-            const double d = BBg[(size_t)128 * n + 128] - ss;
-            if (!(d > 0.0) || !(d < 1.7976931348623157e308)) sh_bad = 1;
-            rho_s = sqrt(d > 0.0 ? d : 1.0);
-        }
-    } else {
-        const int t0 = border ? tid - 64 : tid, nt = border ? 192 : 256;
-        for (int p = t0; p < n; p += nt) {
-            double a0 = N0[(size_t)p * n + (n - 1)] / r1s, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            int kk = 0;
-            for (; kk + 8 <= n; kk += 8) {
-                double m[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) m[u] = M1[(size_t)(kk + u) * n + p];
-                a0 += m[0] * sc[kk] + m[4] * sc[kk + 4];
-                a1 += m[1] * sc[kk + 1] + m[5] * sc[kk + 5];
-                a2 += m[2] * sc[kk + 2] + m[6] * sc[kk + 6];
-                a3 += m[3] * sc[kk + 3] + m[7] * sc[kk + 7];
-            }
-            for (; kk < n; ++kk) a0 += M1[(size_t)kk * n + p] * sc[kk];
-            av[p] = (a0 + a1) + (a2 + a3);
-        }
-    }
-    __syncthreads();
-    const int bad = sh_bad || sh_fail[0] != 0 || sh_fail[1] != 0;
-    if (tid == 0) *info = bad;
-    const size_t npk = (size_t)n * (n + 1) / 2;
-    if (bad) {                                               // poison: nothing stale may be applied
-        const double qn = __longlong_as_double(0x7ff8000000000000LL);
-        for (size_t e = tid; e < (size_t)n * n + 3 * n; e += 256) Ld[e] = qn;
-        for (size_t e = tid; e < npk; e += 256) Upk[e] = qn;
-        return;
-    }
-    // R(i, j), i <= j
-    auto Rel = [&](int i, int j) -> double { return (j < 128) ? M[i * MS + j] : (i < 128 ? M[i * MS + 128] : rho_s); };
-    for (int e = tid; e < n * n; e += 256) {
-        const int i = e / n, j = e % n;                      // L[i][j] = R[j][i], j <= i
-        Ld[e] = (j <= i) ? Rel(j, i) : 0.0;
-        if (j >= i) Upk[(size_t)i * n - ((size_t)i * (i - 1)) / 2 - i + j] = Rel(i, j);
-    }
-    for (int p = tid; p < n; p += 256) Ldinv[p] = 1.0 / Rel(p, p);
-    // zg = L^-1 a   (bam.py:110 applied to gbar)
-    for (int p = tid; p < n; p += 256) vg[p] = sc[p];
-    if (tid < 64) {                                          // forward substitution with L = R^T, one wave, 3 rows per lane
-        double a0 = (tid < n) ? av[tid] : 0.0, a1 = (tid + 64 < n) ? av[tid + 64] : 0.0;
-        double a2 = (tid == 0 && n > 128) ? av[128] : 0.0;   // row 128 lives in lane 0
-        const int nlead = n < 128 ? n : 128;
-        for (int pp = 0; pp < nlead; ++pp) {
-            const double cur = (pp < 64) ? a0 : a1;
-            const double zk = __shfl(cur, pp & 63, 64) * rinv[pp];
-            if (tid == (pp & 63)) { if (pp < 64) a0 = zk; else a1 = zk; }
-            const double r0 = M[pp * MS + tid], r1 = M[pp * MS + tid + 64], r2 = M[pp * MS + 128];
-            if (tid > pp) a0 -= r0 * zk;
-            if (tid + 64 > pp && tid + 64 < 128) a1 -= r1 * zk;
-            if (tid == 0) a2 -= r2 * zk;                     // R[pp][128]: the border column (unused when n <= 128)
-        }
-        if (tid < n) zg[tid] = a0;
-        if (tid + 64 < nlead) zg[tid + 64] = a1;
-        if (tid == 0 && n > 128) zg[128] = a2 / rho_s;
-    }
-}
-
 // ---- BB and the vectors that do not depend on its factor, on many workgroups (round 4) ----------------------------------------
 //   BB = N + I/2 + sqrt(s) sym(Y_final)     one 16 x 16 block per workgroup; the transposed block of Y passes through LDS, so both
 //                                           reads are 128-byte row segments (a one-workgroup version read Y by columns: 8 us)
@@ -657,7 +284,7 @@ __global__ __launch_bounds__(256) void k_bam_bbav(int n, int ld, double reg, con
 }
 
 // ---- Cholesky of BB WITH the inverse factor, stored transposed: Wt = R^-1 = (L^-1)^T (upper), ONE workgroup, n <= 128 (round 4) ----
-// Replaces k_bam_chol_out (barrier-per-pivot chol64_rows_s, 73 us): [BB | I] -> [R | W] on chol64_blk (n <= 64: one call;
+// Replaced round 3's k_bam_chol_out (barrier-per-pivot chol64_rows_s, 73 us): [BB | I] -> [R | W] on chol64_blk (n <= 64: one call;
 // 64 < n <= 128: chol128w_body, the 2 x 2 block scheme of the factor path's Gram matrix, 47 us), and what bam.py:110 calls
 // solve(BB, .) becomes Z = W (P + M1^T Vf), an MFMA product in k_bam_zw (gsmvi_bam.hip) instead of a 128-step substitution per
 // column of D (33 us at D = 1024).  W = L^-1 with cond(L) = sqrt(cond(BB)) <= ~1e4 on BASELINE config 4: the explicit
@@ -700,7 +327,7 @@ __global__ __launch_bounds__(512) void k_bam_cholw(int n, const double* __restri
 // ---- n > 129: the small outputs from the blocked Cholesky factor of BB (gsmvi_potrf_impl: BB = R^T R) ------------------
 // One workgroup: Ld = R^T (lower), Ldinv, vg = Vf gbar = M1[:, n-1] / r1s, zg = L^-1 (P gbar + M1^T vg) by a column-oriented
 // forward substitution (row pp of R is contiguous; eight rows' loads in flight).  A failed factorisation (or a NaN in it)
-// poisons every output, as k_bam_chol_out does.
+// poisons every output, as k_bam_cholw does.
 __global__ __launch_bounds__(1024) void k_bam_post_big(int n, double reg, const double* __restrict__ Rb,
                                                        const int* __restrict__ info_p, const double* __restrict__ M1,
                                                        const double* __restrict__ N0, double* __restrict__ Ld,
@@ -767,7 +394,7 @@ __global__ __launch_bounds__(1024) void k_bam_post_big(int n, double reg, const 
 
 // ---- n <= 48: the WHOLE small chain in one workgroup (round 3) ---------------------------------------------------------
 // From the split-K slabs of the stacked Gram product [N0; M1] to everything the substitution kernel consumes: slab sum,
-// N = M1^T M1 + sym(N0), the scaled Newton-Schulz iteration (same recurrence, same product order as k_bam_ns_small), BB, its
+// N = M1^T M1 + sym(N0), the scaled Newton-Schulz iteration (same recurrence, same product order as the multi-workgroup steps), BB, its
 // Cholesky factor (chol64_blk, gsmvi_chol64b.h) and the small outputs -- one launch instead of finish + nmat + iteration +
 // Cholesky (4 launches, 77 + 10 us at n = 32).  fp64 MFMA throughput of ONE CU is the bound of the iteration (a 16x16x4 fp64
 // MFMA occupies a SIMD for ~107 cycles): only the nb x nb blocks that exist are computed (the round-2 kernel always ran nine
@@ -1076,11 +703,12 @@ int gsmvi_bam_small_fused(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, con
 int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                      int* info_dev);
 
-// Wscr != nullptr (48 < n <= 128 only): the round-4 route -- k_bam_bbav forms BB and [a | . | vg], k_bam_cholw leaves
-// Wt = (L^-1)^T (n x n, upper) in Ld's slot, the upper factor in Wscr (scratch); Upk is not produced (k_bam_zw consumes Wt).
+// n <= 128: k_bam_bbav forms BB and [a | . | vg] behind W's slot, k_bam_cholw leaves Wt = (L^-1)^T (n x n, upper) in Ld's slot and
+// the upper factor in Rscr (scratch); k_bam_zw (gsmvi_bam.hip) consumes Wt.  n > 128: blocked multi-workgroup Cholesky + the
+// small outputs of k_bam_post_big (Ld = L, Ldinv, zg, vg) for the generic forward-substitution kernel.
 int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* Nd, const double* M1,
-                           const double* N0, double* scratch, double* Ld, double* Upk, int* info_dev, int* hint_host,
-                           int force_kenq, double* Wscr) {
+                           const double* N0, double* scratch, double* Ld, int* info_dev, int* hint_host, int force_kenq,
+                           double* Rscr) {
     const int ld = n <= BAMS_NMAX ? BAMS_LD : ((n + 15) / 16) * 16;
     const size_t LL = (size_t)ld * ld;
     double* Ya = scratch;
@@ -1090,46 +718,32 @@ int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, co
     double* Mm = Zb + LL;
     double* coef = Mm + LL;
     double* BBg = coef + 64;
-    if (n <= BAMS_SN) {
-        // small problems: the whole iteration in one workgroup, exactly k* steps, no skipped launches
-        hipLaunchKernelGGL(k_bam_ns_small, dim3(1), dim3(576), 0, st, n, Nd, BBg);
-    } else {
-        // steps to enqueue: the previous call's k* + 2 when known (pinned host word, read without synchronising),
-        // everything otherwise; k_bam_ns_tail makes up for a guess that turns out too small
-        int kenq = BAMS_KMAX;
-        if (hint_host) {                                     // k* + 1 (round 4; + 2 before): a step beyond k* costs two launches,
-            const int h = *reinterpret_cast<volatile int*>(hint_host);   // and k* moves by at most one between neighbouring calls
-            if (h > 0 && h + 1 < BAMS_KMAX) kenq = h + 1;
-        }
-        if (force_kenq > 0 && force_kenq < BAMS_KMAX) kenq = force_kenq;       // tests: exercise the safety net
-        hipLaunchKernelGGL(k_bam_ns_prep, dim3(27), dim3(256), 0, st, n, ld, Nd, Ya, Za, Mm, coef, hint_host);
-        const int nb = (n + 15) / 16;
-        const bool fused = n <= 128 && ctx->tune_bam_nsfuse;  // "bam_nsfuse" = 1: one launch per step (k_bam_ns_fused); default: two
-        for (int k = 0; k < kenq; ++k) {
-            if (fused) {
-                hipLaunchKernelGGL(k_bam_ns_fused, dim3(2 * nb * nb), dim3(512), 0, st, n, ld, k, Ya, Za, Yb, Zb, coef);
-            } else {
-                if (k > 0) hipLaunchKernelGGL(k_bam_ns_zy, dim3(nb * nb), dim3(256), 0, st, n, ld, k, Ya, Za, Yb, Zb, Mm, coef);
-                hipLaunchKernelGGL(k_bam_ns_step, dim3(2 * nb * nb), dim3(256), 0, st, n, ld, k, Ya, Za, Yb, Zb, Mm, coef);
-            }
-        }
-        if (kenq < BAMS_KMAX)
-            hipLaunchKernelGGL(k_bam_ns_tail, dim3(1), dim3(1024), 0, st, n, ld, kenq, Ya, Za, Yb, Zb, Mm, coef);
-        if (Wscr && n <= 128)                   // BB and the factor-independent vectors [a | . | vg] behind W's slot
-            hipLaunchKernelGGL(k_bam_bbav, dim3(nb * nb + nb), dim3(256), 0, st, n, ld, reg, Nd, Ya, Yb, coef, M1, N0, BBg,
-                               Ld + (size_t)n * n);
-        else
-            hipLaunchKernelGGL(k_bam_ns_bb, dim3((n * n + 255) / 256), dim3(256), 0, st, n, ld, Nd, Ya, Yb, coef, BBg);
+    // steps to enqueue: the previous call's k* + 1 when known (pinned host word, read without synchronising), everything
+    // otherwise; k_bam_ns_tail makes up for a guess that turns out too small
+    int kenq = BAMS_KMAX;
+    if (hint_host) {                                         // k* + 1 (round 4; + 2 before): a step beyond k* costs two launches,
+        const int h = *reinterpret_cast<volatile int*>(hint_host);   // and k* moves by at most one between neighbouring calls
+        if (h > 0 && h + 1 < BAMS_KMAX) kenq = h + 1;
     }
-    if (Wscr && n > BAMS_SN && n <= 128) {
-        if (n > 64) hipLaunchKernelGGL(k_bam_cholw<true>, dim3(1), dim3(512), 0, st, n, BBg, Wscr, Ld, info_dev);
-        else hipLaunchKernelGGL(k_bam_cholw<false>, dim3(1), dim3(512), 0, st, n, BBg, Wscr, Ld, info_dev);
-    } else if (n <= BAMS_NMAX) {
-        hipLaunchKernelGGL(k_bam_chol_out, dim3(1), dim3(512), 0, st, n, reg, BBg, M1, N0, Ld, Upk, info_dev);
+    if (force_kenq > 0 && force_kenq < BAMS_KMAX) kenq = force_kenq;       // tests: exercise the safety net
+    hipLaunchKernelGGL(k_bam_ns_prep, dim3(27), dim3(256), 0, st, n, ld, Nd, Ya, Za, Mm, coef, hint_host);
+    const int nb = (n + 15) / 16;
+    for (int k = 0; k < kenq; ++k) {                         // (k = 0: M = Z0 Y0 = Y0 came from k_bam_ns_prep)
+        if (k > 0) hipLaunchKernelGGL(k_bam_ns_zy, dim3(nb * nb), dim3(256), 0, st, n, ld, k, Ya, Za, Yb, Zb, Mm, coef);
+        hipLaunchKernelGGL(k_bam_ns_step, dim3(2 * nb * nb), dim3(256), 0, st, n, ld, k, Ya, Za, Yb, Zb, Mm, coef);
+    }
+    if (kenq < BAMS_KMAX)
+        hipLaunchKernelGGL(k_bam_ns_tail, dim3(1), dim3(1024), 0, st, n, ld, kenq, Ya, Za, Yb, Zb, Mm, coef);
+    if (n <= BAMS_NMAX) {
+        // BB and the factor-independent vectors [a | . | vg] behind W's slot, then the factorisation with the inverse factor
+        hipLaunchKernelGGL(k_bam_bbav, dim3(nb * nb + nb), dim3(256), 0, st, n, ld, reg, Nd, Ya, Yb, coef, M1, N0, BBg,
+                           Ld + (size_t)n * n);
+        if (n > 64) hipLaunchKernelGGL(k_bam_cholw<true>, dim3(1), dim3(512), 0, st, n, BBg, Rscr, Ld, info_dev);
+        else hipLaunchKernelGGL(k_bam_cholw<false>, dim3(1), dim3(512), 0, st, n, BBg, Rscr, Ld, info_dev);
     } else {
         // beyond the one-workgroup Cholesky: the blocked multi-workgroup factorisation of the D x D path (its workspace is
-        // the idle panel-partial slab), then the small outputs in one workgroup.  Upk is not produced: these sizes take
-        // the generic forward-substitution kernel, which reads Ld.
+        // the idle panel-partial slab), then the small outputs in one workgroup for the generic forward-substitution kernel
+        hipLaunchKernelGGL(k_bam_ns_bb, dim3((n * n + 255) / 256), dim3(256), 0, st, n, ld, Nd, Ya, Yb, coef, BBg);
         double* Rb = Mm;                                     // the iterates are dead once BB exists
         int* info_p = ctx->ints + 9;
         int rc = gsmvi_potrf_impl(ctx, st, n, BBg, n, Rb, n, info_p);

@@ -1,6 +1,6 @@
 // Blocked in-LDS Cholesky of a 64 x 64 block WITHOUT a workgroup barrier on the pivot chain (round 3).
 //
-// chol64_rows_s (gsmvi_chol64.h) pays one LDS round trip and one s_barrier per pivot: ~190 ns x 64 pivots = 12-15 us for
+// The barrier-per-pivot factorisation this replaced (chol64_rows_s, deleted in round 4) paid one LDS round trip and one s_barrier per pivot: ~190 ns x 64 pivots = 12-15 us for
 // one 64 x 64 factorisation on one CU.  Here the matrix is processed in four block rows of 16:
 //   panel    : the 16 x (columns to the right) block row is held a column per lane, and its 16 pivots run in registers: the
 //              pivot and the next row's multiplier are broadcast with v_readlane, the other multipliers come back from an
@@ -27,7 +27,7 @@
 // below the diagonal BLOCKS must be zero on entry if the caller wants a clean upper factor; padded with the identity
 // beyond nb), columns 64..127 = W (AUG; initialised here).  ES % 4 == 2 and (2 ES) % 64 == 36 (ES = 146, 82) make both
 // operand shapes of the MFMA phases bank-conflict free.
-// Semantics = chol64_rows_s: *sh_fail = 1-based index of the first bad pivot (<= 0, NaN, inf) or 0; SEMIDEF (the caller has
+// Semantics: *sh_fail = 1-based index of the first bad pivot (<= 0, NaN, inf) or 0; SEMIDEF (the caller has
 // lowered the diagonal by its rounding floor, see gsmvi_chol64.h) turns a pivot <= 0 into a DROPPED row -- zero row and
 // zero diagonal in R, unit pivot in W -- unless allow_dep is false.
 // Needs 512 threads (eight waves); every thread of the workgroup must call it.

@@ -66,8 +66,6 @@ struct gsmvi_ctx {
     int tune_no_fast = 0;      // 1 = force the guarded generic kernels (tests)
     int* bam_hint_host = nullptr;       // pinned word: k* of the last device BaM chain (step-count hint, never synchronised on)
     int tune_bam_kenq = 0;     // > 0: enqueue exactly this many multi-workgroup steps (tests of the tail kernel)
-    int tune_bam_nsfuse = 0;   // 1 = one launch per Newton-Schulz step for n <= 128 (k_bam_ns_fused); default: k_bam_ns_zy + k_bam_ns_step
-    int tune_bam_subst = 0;    // 1 = dense BaM update, 48 < n <= 128: the round-3 route (k_bam_chol_out + forward substitution), A/B runs
     int tune_bam_full = 0;     // 1 = always enqueue every Newton-Schulz step (ignore the hint; tests)
     int profiling = 0;         // when set, the update kernels are launched with dispatch-timestamp events
     hipStream_t side = nullptr;         // second stream of the factor path at large D (V Fm beside the 2B x 2B chain), with its

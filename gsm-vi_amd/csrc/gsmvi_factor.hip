@@ -252,9 +252,11 @@ __global__ __launch_bounds__(256) void k_gsmf_small_a(int n, int B, const double
 // then A22 is factored.  Round 2 ran chol64_rows_s (one barrier per pivot) with a helper-wave row solve: 46 us per call.
 // *info = 1-based index of the first bad pivot (0 = ok); R gets the upper factor with a zero strictly-lower triangle.
 // SEMIDEF: the rank-revealing rule for Gram matrices (gsmvi_chol64.h), off when a diagonal entry reaches 2^32.
+// ldr: leading dimension of R (n for a stand-alone matrix; the (1, 1) block of an n' x n' factor in the two-level chain);
+// info_off > 0: a later diagonal block -- a failure is recorded as info_off + pivot, and only if the earlier blocks passed.
 template <bool SEMIDEF>
-__global__ __launch_bounds__(512) void k_chol128(int n, const double* __restrict__ A, double* __restrict__ R,
-                                                 int* __restrict__ info) {
+__global__ __launch_bounds__(512) void k_chol128(int n, const double* __restrict__ A, double* __restrict__ R, int ldr,
+                                                 int* info, int info_off) {
     constexpr int ES1 = 146, ES2 = 82;
     __shared__ __attribute__((aligned(16))) double E1[64 * ES1];
     __shared__ __attribute__((aligned(16))) double E2[64 * ES2];
@@ -337,9 +339,13 @@ __global__ __launch_bounds__(512) void k_chol128(int n, const double* __restrict
         double x = 0.0;
         if (i < 64) x = (j >= i) ? E1[i * ES1 + j] : 0.0;        // [R11 | R12]: columns 64.. sit at E1[:, 64 + (j - 64)]
         else if (j >= i) x = E2[(i - 64) * ES2 + (j - 64)];
-        R[e] = x;
+        R[(size_t)i * ldr + j] = x;
     }
-    if (tid == 0) *info = sh_fail[0] != 0 ? sh_fail[0] : (sh_fail[1] != 0 ? 64 + sh_fail[1] : 0);
+    if (tid == 0) {
+        const int f = sh_fail[0] != 0 ? sh_fail[0] : (sh_fail[1] != 0 ? 64 + sh_fail[1] : 0);
+        if (info_off == 0) *info = f;
+        else if (f != 0 && *info == 0) *info = info_off + f;
+    }
 }
 
 // ---- A = R^T R and W = R^-T (lower triangular), 64 < n <= 128, one workgroup: chol128w_body (gsmvi_chol128.h) -----------------
@@ -860,7 +866,7 @@ extern "C" int gsmvi_debug_chol128(void* stream, int n, int with_inverse, const 
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (with_inverse) hipLaunchKernelGGL(k_chol128w<true>, dim3(1), dim3(512), 0, st, n, A, R, W, info_dev);
-    else hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n, A, R, info_dev);
+    else hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n, A, R, n, info_dev, 0);
     return hipGetLastError() == hipSuccess ? GSMVI_OK : GSMVI_ERR_HIP;
 }
 
@@ -1115,7 +1121,8 @@ int gsmvi_factor_signed_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, int*
         px.rd_stamps = w.stamps;
         px.rd_jmode = 1;
         px.rd_prior = ctx->ints + 8;               // the flag of BaM's (B x B) chain
-    } else if (*kcg > 1) {
+    } else if (*kcg > 1 && n <= 128) {             // (n > 128: no side job -- it would keep the caller's 2B + 1-row product off the
+                                                   // 64 x 64-tile kernel, 36 us instead of ~15; k_gsmf_gamma_big sums the slabs itself)
         ctx->px.sj_src = w.Gp;
         ctx->px.sj_kc = *kcg;
         ctx->px.sj_stride = (size_t)n * n;
@@ -1128,7 +1135,7 @@ int gsmvi_factor_signed_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, int*
 int gsmvi_factor_signed_back(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, const double* mu0, const double* F0, int ldf0,
                              double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, int kcg, int rides, int taken) {
     const factor_ws w = factor_carve(ctx, D, 2 * Bh);
-    const int finished = !rides && taken;
+    const int finished = !rides && taken && 2 * Bh <= 128;
     return factor_back(ctx, st, D, Bh, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, (kcg > 1 && finished) ? w.Gam1 : w.Gp,
                        finished ? 1 : kcg, nullptr, 0, 1, (rides && taken) ? 1 : 0);
 }
@@ -1196,9 +1203,8 @@ static int factor_chain_big(gsmvi_ctx* ctx, hipStream_t st, int n, int B, const 
                        (const double*)nullptr, 0, 0);
     small_gemm_launch(st, OpBlkR12{n1, n2, n1, Wt, w.Ap, w.Tt, n, n, n, n1});
     small_gemm_launch(st, OpBlkS22{n2, n2, n1, w.Tt, w.Ap, w.Rg, n, n, n1, 0});
-    if (n2 > 64)
-        hipLaunchKernelGGL((k_cholw_ld<false, true>), dim3(1), dim3(512), 0, st, n2, w.Rg, n2, w.Tt + off, n, Wt + off, n, info_t,
-                           n1, 0, (const double*)nullptr, 0, 0);
+    if (n2 > 64)                                   // (the last block needs no inverse factor: the plain 128-row kernel, 32 us against 39)
+        hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n2, w.Rg, w.Tt + off, n, info_t, n1);
     else
         hipLaunchKernelGGL((k_cholw_ld<false, false>), dim3(1), dim3(512), 0, st, n2, w.Rg, n2, w.Tt + off, n, Wt + off, n, info_t,
                            n1, 0, (const double*)nullptr, 0, 0);
@@ -1244,7 +1250,7 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         // Gram matrix: semi-definite rule; W = Rg^-T comes out of the same factorisation (no substitution launch)
         hipLaunchKernelGGL(k_chol128w<true>, dim3(1), dim3(512), 0, st, n, w.Gam, w.Rg, w.Pm, info_g);
         hipLaunchKernelGGL(k_gsmf_small_a, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, st, n, B, w.Rg, info_g, w.Ap, jmode);
-        hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n, w.Ap, w.Tt, info_t);
+        hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n, w.Ap, w.Tt, n, info_t, 0);
         if ((rc = chk("k_chol128"))) return rc;
         double* Pmat = w.Ap;                       // A' is dead once T exists
         const int nb = (n + 15) / 16, gw = (nb * nb + 3) / 4;

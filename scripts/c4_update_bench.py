@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config 4 (BaM update, D=1024, B=128, reg=1): time of one dense update (HIP events, median / min over the trials,
-eager and replayed from a hipGraph) for the round-4 chain and, A/B, for the round-3 kernels it replaced (knobs bam_nsfuse /
-bam_subst).  usage: c4_update_bench.py [D B] [prof]   -- `prof`: 60 plain updates only (for rocprofv3 --kernel-trace)."""
+eager and replayed from a hipGraph).  (The A/B against the round-3 kernels this chain replaced, and against a one-launch
+Newton-Schulz step, is recorded in profiles/r04/c4_chain_ab.txt; those kernels were deleted afterwards.)  usage: c4_update_bench.py [D B] [prof]   -- `prof`: 60 plain updates only (for rocprofv3 --kernel-trace)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gsmvi_amd
@@ -14,8 +14,6 @@ X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
 out = (eng.empty(D), eng.empty(D, D)); flag = eng.new_flag()
 call = lambda: eng.bam_update(X, G, mu0, S0, 1.0, 1e-6, out=out, flag=flag)
 if "prof" in sys.argv:
-    if os.environ.get("C4_NSFUSE"):
-        eng.set_tuning("bam_nsfuse", 1)
     for _ in range(60): call()
     torch.cuda.synchronize()
     sys.exit(0)
@@ -38,8 +36,4 @@ def measure(tag):
     assert eng.read_flag(flag) == 0
     print(f"{tag:28s} D={D} B={B}: eager median {np.median(ts):7.1f} us  min {np.min(ts):7.1f} us   replayed {tg:7.1f} us", flush=True)
 
-measure("round 4 (default)")
-for tag, nsf, subst in (("one-launch NS steps (nsfuse)", 1, 0), ("round 3 chain (bam_subst)", 0, 1)):
-    eng.set_tuning("bam_nsfuse", nsf); eng.set_tuning("bam_subst", subst)
-    measure(tag)
-eng.set_tuning("bam_nsfuse", 0); eng.set_tuning("bam_subst", 0)
+measure("dense BaM update")

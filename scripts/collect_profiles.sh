@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats and, in separate passes, the HBM
 # traffic counters for the bench workload.  Output: gpurun_out/prof_$1/ (copy summaries to profiles/).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT
@@ -17,15 +17,34 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- 
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $ARGS --no-graph > $OUT/pmc_mfma.log 2>&1
 # the >= 0.50 HBM-roofline point of the covariance kernel (D=4096, B=32) and the fit-iteration kernel tables
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_d4096 -- python3 $ROOT/bench.py --D 4096 --B 32 --steps 60 --warmup 12 --no-cpu-baseline > $OUT/trace_d4096.log 2>&1
-for cfg in "1024 32 factor" "1024 32 dense" "4096 64 factor" "256 8 factor" "1024 32 bam" "1024 32 bamf"; do
+for cfg in "1024 32 factor" "1024 32 dense" "4096 64 factor" "256 8 factor" "1024 32 bam" "1024 32 bamf" "1024 128 bam" "1024 128 bamf"; do
   tag=$(echo $cfg | tr ' ' '_')
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fit_$tag -- python3 $ROOT/scripts/factor_prof.py $cfg > $OUT/fit_$tag.log 2>&1
   echo "== fit iteration kernels, D B method = $cfg (41 iterations; name, calls, avg ns, % of GPU time)" >> $OUT/fit_iteration_kernels.txt
   python3 $ROOT/scripts/prof_top.py $OUT/fit_$tag 18 >> $OUT/fit_iteration_kernels.txt 2>&1
 done
+# BASELINE config 4 (BaM update, D=1024, B=128): per-kernel table of 60 plain updates
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_update -- python3 $ROOT/scripts/c4_update_bench.py prof > $OUT/c4_update.log 2>&1
+echo "== scripts/c4_update_bench.py prof: 60 dense BaM updates at D=1024, B=128 (name, calls, avg ns, % of GPU time)" > $OUT/c4_update_kernels.txt
+python3 $ROOT/scripts/prof_top.py $OUT/c4_update 24 >> $OUT/c4_update_kernels.txt 2>&1
 echo "== bench.py --D 4096 --B 32 (kernel-trace stats)" > $OUT/d4096_b32_kernels.txt
 python3 $ROOT/scripts/prof_top.py $OUT/trace_d4096 8 >> $OUT/d4096_b32_kernels.txt 2>&1
 cd $ROOT
+# un-profiled figures of the same commit: every BASELINE config, the c4 update, the persistent-kernel A/B, the chol64_blk
+# harness variants and the in-pipeline race check, bench.py at its default flags
+python3 scripts/configs_bench.py $OUT/configs.json > $OUT/configs.log 2>&1
+python3 scripts/c4_update_bench.py > $OUT/c4_update.txt 2>&1
+python3 scripts/cov_p_ab.py > $OUT/cov_persistent_ab.txt 2>&1
+python3 scripts/race_pipeline_check.py > $OUT/race_pipeline_check.txt 2>&1
+: > $OUT/chol64b_variants.txt
+for v in "" "-DCHOLB_TEST_REPLICA_DELAY=2" "-DCHOLB_TEST_FORCE_ORDER" "-DCHOLB_TEST_FORCE_ORDER -DCHOLB_TEST_OLD_WRITEBACK" "-DCHOLB_TEST_REPLICA_DELAY=2 -DCHOLB_TEST_OLD_WRITEBACK" "-DCHOLB_TEST_CORRUPT_REPLICA"; do
+  echo "=== scripts/chol64b_test.hip built with [$v]" >> $OUT/chol64b_variants.txt
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I gsm-vi_amd/csrc scripts/chol64b_test.hip -o /tmp/cbt $v 2>/dev/null
+  timeout 60 /tmp/cbt 2>&1 | grep -v "half [01]" >> $OUT/chol64b_variants.txt
+  echo "exit code ${PIPESTATUS[0]}" >> $OUT/chol64b_variants.txt
+done
+python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+python3 bench.py --steps 20 --warmup 3 > $OUT/bench_driver_flags.json 2>> $OUT/bench.err
 python3 - "$OUT" <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]

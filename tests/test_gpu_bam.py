@@ -345,42 +345,42 @@ def test_factor_form_fit_converges_on_a_gaussian_target():
 
 
 @pytest.mark.parametrize("D,B,reg", [(1024, 128, 1.0), (1024, 96, 10.0), (512, 100, 0.5), (200, 64, 2.0), (256, 63, 10.0),
-                                     (130, 49, 1.0), (1024, 127, 100.0 / 3)])
-def test_round4_chain_equals_the_round3_chain(D, B, reg):
-    """Round 4 changed the dense BaM chain for 48 < n <= 128: slab sums + N in one launch (k_bam_nmat2), BB and the
-    factor-independent vectors on many workgroups (k_bam_bbav), Cholesky WITH the inverse factor (k_bam_cholw, chol64_blk /
-    chol128w_body) and Z = W (P + M1^T Vf) as chained MFMA products (k_bam_zw) instead of a forward substitution; optional
-    one-launch Newton-Schulz steps (knob bam_nsfuse).  The round-3 kernels stay selectable (knob bam_subst): same (mu, S) to
-    rounding -- the explicit triangular inverse costs ~1e-12 relative on Z (cond(L) <= ~1e4 here) -- and the defining
-    equation S U S + S = V holds to the same backward error either way."""
+                                     (130, 49, 1.0), (1024, 127, 100.0 / 3), (96, 20, 1.0)])
+def test_round4_dense_chain(D, B, reg):
+    """Round 4 rebuilt the dense BaM chain for 48 < n <= 128: slab sums + N in one launch (k_bam_nmat2), BB and the
+    factor-independent vectors on many workgroups (k_bam_bbav), Cholesky WITH the inverse factor (k_bam_cholw on chol64_blk /
+    chol128w_body) and Z = W (P + M1^T Vf) as chained MFMA products (k_bam_zw) instead of a forward substitution.  The round-3
+    kernels it replaced were deleted after an A/B on the GPU (profiles/r04/c4_chain_ab.txt: same (mu, S) to 2e-9, 318 -> 261 us at
+    D = 1024, B = 128); what stays testable is the update itself: the defining equation S U S + S = V to backward error 1e-14,
+    the scipy restatement, exact symmetry, run-to-run identity, and -- (96, 20) under the "bam_full" knob -- the same chain at
+    n <= 48 against the one-workgroup kernel that normally serves those sizes."""
     import gsmvi_amd
     orc, borc = _o()
     eng = gsmvi_amd.get_engine()
     st = orc.make_update_state(D, B, seed=D + B)
     X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
-    res = {}
-    eng.bam_update(X, G, mu0, S0, reg, 0.0)        # settles the step-count hint (a stale one sends the last steps to the tail
-    try:                                            # kernel, whose sums run in another order: ~1e-13, not bit-identical)
-        for tag, nsf, subst in (("r4", 0, 0), ("nsfuse", 1, 0), ("nsfuse_subst", 1, 1), ("r3", 0, 1)):
-            eng.set_tuning("bam_nsfuse", nsf)
-            eng.set_tuning("bam_subst", subst)
-            mu, S, f = eng.bam_update(X, G, mu0, S0, reg, 0.0)
-            assert eng.read_flag(f) == 0, tag
-            res[tag] = (mu.cpu().numpy(), S.cpu().numpy())
+    small = B <= 48
+    if small:
+        mu_s, S_s, f_s = eng.bam_update(X, G, mu0, S0, reg, 0.0)             # the one-workgroup chain (k_bam_small48)
+        eng.set_tuning("bam_full", 1)
+    try:
+        eng.bam_update(X, G, mu0, S0, reg, 0.0)    # settles the step-count hint (a stale one sends the last steps to the tail
+        mu, S, f = eng.bam_update(X, G, mu0, S0, reg, 0.0)                   # kernel, whose sums run in another order: ~1e-13)
+        mu2, S2, _ = eng.bam_update(X, G, mu0, S0, reg, 0.0)
     finally:
-        eng.set_tuning("bam_nsfuse", 0)
-        eng.set_tuning("bam_subst", 0)
+        if small:
+            eng.set_tuning("bam_full", 0)
+    assert eng.read_flag(f) == 0
+    mu_n, S_n = mu.cpu().numpy(), S.cpu().numpy()
     U, V, xbar, gbar = _bam_uv(st["samples"], st["vs"], st["mu0"], st["S0"], reg)
-    for tag, (mu, S) in res.items():
-        assert np.array_equal(S, S.T), tag
-        assert _backward_error(S, U, V) < 1e-14, (tag, _backward_error(S, U, V))
-        tol = 1e-9 if reg <= 1.0 else 2e-8          # (as the factor-form comparison below: S gbar from the factors at large reg)
-        assert rel_err(S, res["r3"][1]) < tol and rel_err(mu, res["r3"][0]) < tol, (tag, rel_err(S, res["r3"][1]))
+    assert np.array_equal(S_n, S_n.T)
+    assert _backward_error(S_n, U, V) < 1e-14, _backward_error(S_n, U, V)
     mu_o, S_o = borc.bam_lowrank_update_exact(st["samples"], st["vs"], st["mu0"], st["S0"], reg)
-    assert rel_err(res["r4"][1], 0.5 * (S_o + S_o.T)) < 1e-7 and rel_err(res["r4"][0], mu_o) < 1e-7
-    # run-to-run identity of the new launch structure (fixed summation orders, no atomics)
-    mu2, S2, _ = eng.bam_update(X, G, mu0, S0, reg, 0.0)
-    assert np.array_equal(S2.cpu().numpy(), res["r4"][1]) and np.array_equal(mu2.cpu().numpy(), res["r4"][0])
+    assert rel_err(S_n, 0.5 * (S_o + S_o.T)) < 1e-7 and rel_err(mu_n, mu_o) < 1e-7
+    assert np.array_equal(S2.cpu().numpy(), S_n) and np.array_equal(mu2.cpu().numpy(), mu_n)     # run-to-run identity
+    if small:
+        tol = 1e-9 if reg <= 1.0 else 2e-8
+        assert rel_err(S_n, S_s.cpu().numpy()) < tol and rel_err(mu_n, mu_s.cpu().numpy()) < tol
 
 
 def test_round4_chain_rejects_nan_and_indefinite_inputs():

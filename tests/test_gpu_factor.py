@@ -510,3 +510,43 @@ def test_two_level_chain_equals_the_dense_hip_update(D, B):
     assert np.array_equal(mu3.cpu().numpy(), st["mu0"]) and np.array_equal(F3.cpu().numpy(), F0)
     with pytest.raises(gsmvi_amd.GsmviError):        # 2B > 256
         eng.gsm_factor_update(eng.zeros(129, 512), eng.zeros(129, 512), eng.zeros(129, 512), eng.zeros(512), eng.eye(512))
+
+
+@pytest.mark.parametrize("D,B", [(4096, 64), (1024, 32)])
+def test_soak_factor_updates_are_bit_identical_run_to_run(D, B):
+    """A short soak inside the suite (the long ones live in profiles/r04/soak_*.txt): GSM and BaM factor-form updates
+    called back to back for ~6 s each, eagerly and from a replayed hipGraph, every (mu, F, flag) compared bit for bit with
+    the first.  gsm_numpy.py:27-55 is a pure function: so is this.  (Round 3 found a once-in-3e5 deviation this way: a
+    replica of the diagonal block read at an unordered time in chol64_blk; see test_blocked_cholesky_with_late_replica_waves.)"""
+    import time
+    import torch
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    orc, st, F0 = _setup(D, B, D + B)
+    dv = [eng.asarray(st[k]) for k in ("Z", "samples", "vs", "mu0")] + [eng.asarray(F0)]
+    total = 0
+    for kind in ("gsm", "bam"):
+        mu, F, flag = eng.empty(D), eng.empty(D, D), eng.new_flag()
+        call = (lambda: eng.gsm_factor_update(*dv, out=(mu, F), flag=flag)) if kind == "gsm" else \
+               (lambda: eng.bam_factor_update(*dv, 1.0, out=(mu, F), flag=flag))
+        call()
+        torch.cuda.synchronize()
+        ref = (mu.clone(), F.clone(), int(flag.item()))
+        assert ref[2] == 0
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            call()
+        t0, n, rnd = time.perf_counter(), 0, 0
+        while time.perf_counter() - t0 < 6.0:
+            for _ in range(16):
+                if rnd & 1:
+                    mu.zero_(); F.zero_()
+                    g.replay()
+                else:
+                    call()
+                assert torch.equal(F, ref[1]) and torch.equal(mu, ref[0]) and int(flag.item()) == 0, (kind, n)
+                n += 1
+            rnd += 1
+        total += n
+    print(f"soak D={D} B={B}: {total} calls bit-identical")
+    assert total > 200
