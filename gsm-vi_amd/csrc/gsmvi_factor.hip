@@ -206,46 +206,6 @@ __global__ __launch_bounds__(256) void k_gsmf_prep(int D, int B, int KC, const d
     Tm1[(size_t)b * D + i] = x - m;
 }
 
-// ---- A' = I + Rg J Rg^T  (n x n, 64 < n <= 128),  J = (1/B) [[0, I], [I, -I]],  Rg upper triangular ----
-//   (Rg J)[i][k] = (1/B) * ( k <  B : Rg[i][B+k]
-//                            k >= B : Rg[i][k-B] - Rg[i][k] )
-// 16 x 16 outputs per workgroup; the 16 rows of (Rg J) and the 16 rows of Rg it needs are staged in LDS
-// ([row][130]: reading one row per lane is conflict-free).
-__global__ __launch_bounds__(256) void k_gsmf_small_a(int n, int B, const double* __restrict__ Rg,
-                                                      const int* __restrict__ info_g, double* __restrict__ Ap, int jmode) {
-    __shared__ double RJ[16 * 130];
-    __shared__ double RR[16 * 130];
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
-    for (int e = tid; e < 16 * 128; e += 256) {
-        const int r = e >> 7, k = e & 127;
-        const int gi = i0 + r, gj = j0 + r;
-        double vj = 0.0, vr = 0.0;
-        if (k < n) {
-            if (gi < n) {
-                if (jmode) vj = (k < B) ? Rg[(size_t)gi * n + k] : -Rg[(size_t)gi * n + k];       // J = diag(I, -I), unscaled
-                else vj = (k < B) ? Rg[(size_t)gi * n + B + k] : (Rg[(size_t)gi * n + k - B] - Rg[(size_t)gi * n + k]);
-            }
-            if (gj < n) vr = Rg[(size_t)gj * n + k];
-        }
-        RJ[r * 130 + k] = vj;
-        RR[r * 130 + k] = vr;
-    }
-    __syncthreads();
-    double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < 128; k += 2) {
-        s0 += RJ[ty * 130 + k] * RR[tx * 130 + k];
-        s1 += RJ[ty * 130 + k + 1] * RR[tx * 130 + k + 1];
-    }
-    const int i = i0 + ty, j = j0 + tx;
-    if (i < n && j < n) {
-        double v = (i == j ? 1.0 : 0.0) + (jmode ? (s0 + s1) : (s0 + s1) / (double)B);
-        if (*info_g != 0) v = (i == j) ? -1.0 : 0.0;     // Gamma was singular: force the PD test to fail
-        Ap[(size_t)i * n + j] = v;
-    }
-}
-
 // ---- Cholesky A = R^T R of one n x n matrix, 64 < n <= 128, in ONE workgroup ----------------------------
 // 2 x 2 blocks of 64 on chol64_blk (gsmvi_chol64b.h): the first block row [A11 | A12] is factored AND solved in one call
 // (AUG = 2: the columns of A12 ride in the panel waves, [R11 | R12] comes out), A22 -= R12^T R12 runs on the MFMA pipe,
@@ -579,61 +539,9 @@ __global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double
     gsmf_small16_body(lds, n, B, Gp, kcg, Kmat, coef, bad_out, stamps, jmode, prior_bad);
 }
 
-// ---- K = Rg^-1 (T - I) Rg^-T = W^T (T - I) W, W = Rg^-T, for 64 < n <= 128 -----------------------------------
-// W comes out of the Gram matrix's factorisation itself (k_chol128w); the two products run on the MFMA pipe
-// (k_gsmf_gemm128).  (Round 2's 128-step substitution launch k_gsmf_kmat_big was removed in round 3: 25 us.)
-// ---- P = (T - I) (W S) and K'' = (W S)^T P for n x n matrices (n <= 128), one 16 x 16 block per wave ------------------
-//   MODE 0:  C = (A - I) (W S)     A = T upper triangular, W = Rg^-T as k_chol128w left it
-//   MODE 1:  C = (W S)^T B         B = P
-// The column operation W S (S = [[I, 0], [diag beta, diag alpha]]: column b <- W[:, b] + beta_b W[:, B+b], column B+b <-
-// alpha_b W[:, B+b]; ab = [beta; alpha] from k_gsmf_gamma_big) is applied while W is loaded -- it was a launch of its own.
-// MODE 0 also takes the chain's accept / revert decision from the two factorisations' flags (and BaM's, prior_bad): every
-// workgroup derives it, workgroup 0 publishes it for MODE 1 and the update kernel.
-// All operand fragments of a block are loaded from L2 in one batch, then one MFMA chain of n/4 steps.
-template <int MODE>
-__global__ __launch_bounds__(256) void k_gsmf_gemm128(int n, int B, const double* __restrict__ A,
-                                                      const double* __restrict__ Bm, double* __restrict__ Cm,
-                                                      const double* __restrict__ ab, int* __restrict__ bad,
-                                                      const int* __restrict__ info_g, const int* __restrict__ info_t,
-                                                      const int* __restrict__ prior_bad) {
-    if (MODE == 0) {
-        const int b = (*info_g != 0) || (*info_t != 0) || (prior_bad && *prior_bad != 0);
-        if (blockIdx.x == 0 && threadIdx.x == 0) *bad = b;
-        if (b) return;
-    } else if (*bad) return;
-    const int nb = (n + 15) >> 4;
-    const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blk >= nb * nb) return;                                  // wave-uniform
-    const int i0 = (blk / nb) * 16, j0 = (blk % nb) * 16;
-    const int l = threadIdx.x & 63, cc = l & 15, ks = l >> 4;
-    const double* Wsrc = MODE == 0 ? Bm : A;                     // the operand that is W
-    const int wc = MODE == 0 ? ((j0 + cc) < n ? j0 + cc : n - 1) : ((i0 + cc) < n ? i0 + cc : n - 1);   // this lane's column of W
-    const int wc2 = wc < B ? wc + B : wc;                        // its partner column (itself for the alpha columns)
-    const double s1 = wc < B ? 1.0 : 0.0, s2 = ab[wc];           // (W S)[:, c] = s1 W[:, c] + s2 W[:, c2]: beta_c for c < B, alpha_{c-B} above
-    double a[32], b[32];
-#pragma unroll
-    for (int s = 0; s < 32; ++s) {
-        const int k = 4 * s + ks;
-        const int kc = k < n ? k : n - 1, ic = (i0 + cc) < n ? i0 + cc : n - 1, jc = (j0 + cc) < n ? j0 + cc : n - 1;
-        const double ws = s1 * Wsrc[(size_t)kc * n + wc] + s2 * Wsrc[(size_t)kc * n + wc2];
-        const double av = MODE == 0 ? A[(size_t)ic * n + kc] - (ic == kc ? 1.0 : 0.0) : ws;
-        const double bv = MODE == 0 ? ws : Bm[(size_t)kc * n + jc];
-        const bool in = k < n && (i0 + cc) < n;
-        a[s] = in ? av : 0.0;
-        b[s] = (k < n && (j0 + cc) < n) ? bv : 0.0;
-    }
-    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int s = 0; s < 32; s += 2) {
-        acc0 = GSMVI_MFMA_F64(a[s], b[s], acc0);
-        acc1 = GSMVI_MFMA_F64(a[s + 1], b[s + 1], acc1);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = i0 + ks + 4 * r, j = j0 + cc;
-        if (i < n && j < n) Cm[(size_t)i * n + j] = acc0[r] + acc1[r];
-    }
-}
+// ---- K'' = (W S)^T (T - I) (W S), W = Rg^-T, for n > 64: W comes out of the Gram matrix's factorisation itself (k_chol128w /
+// k_cholw_ld); the products P = (T - I)(W S) and K'' = (W S)^T P -- with the column operation W S applied while W is loaded and
+// the chain's accept / revert decision taken by the first of them -- are OpChainP / OpChainK of gsmvi_smallgemm.h.
 
 // ---- new mean and the revert passthrough for the K-matrix path -----------------------------------------
 __global__ __launch_bounds__(256) void k_gsmf_mean(int D, int B, const double* __restrict__ Tm,
@@ -835,7 +743,7 @@ __global__ __launch_bounds__(256) void k_gsmf_gamma_big(int n, int B, const doub
         if (blockIdx.x == 0) {
             coef[tid] = jmode ? 0.0 : be / (double)B;
             coef[B + tid] = jmode ? 0.0 : al / (double)B;
-            ab[tid] = be;                              // for k_gsmf_gemm128 (W S)
+            ab[tid] = be;                              // for OpChainP / OpChainK (the column operation W S)
             ab[B + tid] = al;
         }
     }
@@ -1249,15 +1157,17 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         }
         // Gram matrix: semi-definite rule; W = Rg^-T comes out of the same factorisation (no substitution launch)
         hipLaunchKernelGGL(k_chol128w<true>, dim3(1), dim3(512), 0, st, n, w.Gam, w.Rg, w.Pm, info_g);
-        hipLaunchKernelGGL(k_gsmf_small_a, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, st, n, B, w.Rg, info_g, w.Ap, jmode);
+        // A' = I + Rg J Rg^T, then its plain factorisation T -- the accept / revert test.  (Round 4: the three n x n products of
+        // this chain run on the generic MFMA block kernel of gsmvi_smallgemm.h, 64 workgroups each; the VALU dot-product
+        // kernel k_gsmf_small_a (14.4 us) and the 16-workgroup k_gsmf_gemm128 (16.5 + 13 us) they replace were deleted.)
+        small_gemm_launch(st, OpSmallA{n, n, n, w.Rg, info_g, w.Ap, B, jmode});
         hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n, w.Ap, w.Tt, n, info_t, 0);
         if ((rc = chk("k_chol128"))) return rc;
         double* Pmat = w.Ap;                       // A' is dead once T exists
-        const int nb = (n + 15) / 16, gw = (nb * nb + 3) / 4;
         // P = (T - I) (W S), with the chain's accept / revert decision; then K'' = (W S)^T P
-        hipLaunchKernelGGL(k_gsmf_gemm128<0>, dim3(gw), dim3(256), 0, st, n, B, w.Tt, Wm, Pmat, coef + n, info_dev, info_g, info_t, prior);
-        hipLaunchKernelGGL(k_gsmf_gemm128<1>, dim3(gw), dim3(256), 0, st, n, B, Wm, Pmat, Kmat, coef + n, info_dev, info_g, info_t, prior);
-        if ((rc = chk("k_gsmf_gemm128"))) return rc;
+        small_gemm_launch(st, OpChainP{n, n, n, w.Tt, Wm, coef + n, Pmat, B, info_dev, info_g, info_t, prior});
+        small_gemm_launch(st, OpChainK{n, n, n, Wm, Pmat, coef + n, Kmat, B, info_dev});
+        if ((rc = chk("k_small_gemm"))) return rc;
     }
     if (!ctx->tune_no_fast && ctx->tune_direct_out && D % 64 == 0 && (n == 16 || n == 32 || n == 64) && ldf0 % 2 == 0 &&
         ldf % 2 == 0) {

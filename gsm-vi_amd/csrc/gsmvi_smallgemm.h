@@ -1,5 +1,5 @@
 // Generic product of SMALL matrices (inner dimension <= 256) with operand and epilogue functors: the pieces between the
-// one-workgroup 128 x 128 factorisations of the 2B x 2B chain for 128 < 2B <= 256 (round 4: gsmvi_factor.hip, factor_chain256).
+// one-workgroup factorisations of the 2B x 2B chain for 2B > 64 (round 4: gsmvi_factor.hip, factor_back / factor_chain_big).
 //
 //   C(i, j) = sum_{k < K} a(i, k) b(k, j),   i < m, j < p        op.store(i, j, value) writes it where it belongs
 //
@@ -109,7 +109,7 @@ struct OpBlkW21 {                                  // W[n1:n, 0:n1] = -T1 W11; a
     }
 };
 
-// ---- the chain's products for 128 < n <= 256 (what k_gsmf_small_a and k_gsmf_gemm128 do for n <= 128) ---------------------------
+// ---- the n x n products of the 2B x 2B chain, 64 < n <= 256 -----------------------------------------------------------------
 struct OpSmallA {                                  // A' = I + (Rg J) Rg^T;  J = (1/B) [[0, I], [I, -I]] or, jmode, diag(I, -I) unscaled
     int m, p, K;                                   // n, n, n
     const double* Rg;
@@ -128,7 +128,7 @@ struct OpSmallA {                                  // A' = I + (Rg J) Rg^T;  J =
         Ap[(size_t)i * m + j] = x;
     }
 };
-struct OpChainP {                                  // P = (T - I)(W S), with the chain's accept / revert decision (k_gsmf_gemm128<0>)
+struct OpChainP {                                  // P = (T - I)(W S), with the chain's accept / revert decision
     int m, p, K;
     const double *T, *W, *ab;
     double* P;
@@ -148,7 +148,7 @@ struct OpChainP {                                  // P = (T - I)(W S), with the
     }
     __device__ void store(int i, int j, double v) const { P[(size_t)i * m + j] = v; }
 };
-struct OpChainK {                                  // K'' = (W S)^T P   (k_gsmf_gemm128<1>)
+struct OpChainK {                                  // K'' = (W S)^T P
     int m, p, K;
     const double *W, *P, *ab;
     double* Kmat;
