@@ -28,7 +28,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_upda
 echo "== scripts/c4_update_bench.py prof: 60 dense BaM updates at D=1024, B=128 (name, calls, avg ns, % of GPU time)" > $OUT/c4_update_kernels.txt
 python3 $ROOT/scripts/prof_top.py $OUT/c4_update 24 >> $OUT/c4_update_kernels.txt 2>&1
 echo "== bench.py --D 4096 --B 32 (kernel-trace stats)" > $OUT/d4096_b32_kernels.txt
-python3 $ROOT/scripts/prof_top.py $OUT/trace_d4096 8 >> $OUT/d4096_b32_kernels.txt 2>&1
+python3 $ROOT/scripts/prof_top.py $OUT/trace_d4096 14 >> $OUT/d4096_b32_kernels.txt 2>&1
 cd $ROOT
 # un-profiled figures of the same commit: every BASELINE config, the c4 update, the persistent-kernel A/B, the chol64_blk
 # harness variants and the in-pipeline race check, bench.py at its default flags
