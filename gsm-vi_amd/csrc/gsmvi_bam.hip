@@ -28,19 +28,21 @@
 // Qt (B x D): rows k-1 = sqrt(reg/B) helmert_k(g), k = 1 .. B-1, row B-1 = sqrt(reg/(1+reg)) gbar; Vout the same for the
 // source V (the samples X with shift = mu0 in the dense form: last row sqrt(r1)(mu0 - xbar); the whitened draws Z with
 // shift = NULL in the factor form: last row -sqrt(r1) zbar), where helmert_k(v) = (sum_{j<k} c_j - k c_k)/sqrt(k(k+1)), c = v - mean.
-// Workgroup = 64 columns x 4 sample groups; group g owns the rows k in [k0, k1) (and the samples of that range: two passes
+// Workgroup = 256 / NG columns x NG sample groups (NG = 4 or 16); group g owns the rows k in [k0, k1) (and the samples of that range: two passes
 // over them, the second served by L2), its starting prefix sum comes from the other groups' partial sums.  Any B >= 1.
+template <int NG>   // sample groups per workgroup: 256 / NG columns x NG groups (4 for B <= 32, 16 above: round 4)
 __global__ __launch_bounds__(256) void k_bam_stats_h(int D, int B, const double* __restrict__ V, int ldv,
                                                      const double* __restrict__ shift, const double* __restrict__ X,
                                                      int ldx, const double* __restrict__ G, int ldg, double reg,
                                                      double* __restrict__ xbar, double* __restrict__ gbar,
                                                      double* __restrict__ zerov, double* __restrict__ Qt,
                                                      double* __restrict__ Vout, double* __restrict__ Vout2) {
-    __shared__ double red[3][4][64];
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + c, ic = i < D ? i : D - 1;
-    const int k0 = 1 + (g * (B - 1)) / 4, k1 = 1 + ((g + 1) * (B - 1)) / 4;   // rows k in [k0, k1)
-    const int s0 = g == 0 ? 0 : k0;                                          // samples [s0, k1) are summed by this group
+    constexpr int NC = 256 / NG;
+    __shared__ double red[3][NG][NC];
+    const int c = threadIdx.x % NC, g = threadIdx.x / NC;
+    const int i = blockIdx.x * NC + c, ic = i < D ? i : D - 1;
+    const int k0 = 1 + (g * (B - 1)) / NG, k1 = 1 + ((g + 1) * (B - 1)) / NG;   // rows k in [k0, k1)
+    const int s0 = g == 0 ? 0 : k0;                                            // samples [s0, k1) are summed by this group
     double sv = 0.0, sg = 0.0, sx = 0.0;
     {
         int b = s0;
@@ -65,12 +67,14 @@ __global__ __launch_bounds__(256) void k_bam_stats_h(int D, int B, const double*
     red[1][g][c] = sg;
     red[2][g][c] = sx;
     __syncthreads();
-    const double vb = ((red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c])) / B;
-    const double gb = ((red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c])) / B;
+    double tv_ = 0.0, tg_ = 0.0, tx_ = 0.0;                  // fixed order over the groups
+#pragma unroll
+    for (int q = 0; q < NG; ++q) { tv_ += red[0][q][c]; tg_ += red[1][q][c]; tx_ += red[2][q][c]; }
+    const double vb = tv_ / B, gb = tg_ / B;
     const double a = sqrt(reg / B), r1s = sqrt(reg / (1.0 + reg));
     __syncthreads();                                         // the raw sums have been read by everybody: red is reused below
     if (g == 0 && i < D) {
-        const double xb = X ? ((red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c])) / B : vb;
+        const double xb = X ? tx_ / B : vb;
         xbar[i] = xb;
         gbar[i] = gb;
         if (zerov) zerov[i] = 0.0;
@@ -136,6 +140,19 @@ __global__ __launch_bounds__(256) void k_bam_stats_h(int D, int B, const double*
         pv += cv;
         pg += cg;
     }
+}
+
+// launch: 4 sample groups x 64 columns for small batches (the round-3 shape), 16 x 16 above (B = 128: 16 workgroups of four
+// 32-sample groups became 64 workgroups of sixteen 8-sample groups: every group's loads in one batch)
+static inline void bam_stats_launch(hipStream_t st, int D, int B, const double* V, int ldv, const double* shift, const double* X,
+                                    int ldx, const double* G, int ldg, double reg, double* xbar, double* gbar, double* zerov,
+                                    double* Qt, double* Vout, double* Vout2) {
+    if (B <= 32)
+        hipLaunchKernelGGL(k_bam_stats_h<4>, dim3((D + 63) / 64), dim3(256), 0, st, D, B, V, ldv, shift, X, ldx, G, ldg, reg, xbar,
+                           gbar, zerov, Qt, Vout, Vout2);
+    else
+        hipLaunchKernelGGL(k_bam_stats_h<16>, dim3((D + 15) / 16), dim3(256), 0, st, D, B, V, ldv, shift, X, ldx, G, ldg, reg, xbar,
+                           gbar, zerov, Qt, Vout, Vout2);
 }
 
 // ---- Z = L^-1 (P + M1^T Vf), the new mean, and the signed factor panel -------------------------
@@ -769,8 +786,7 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
         gsmvi_set_error("%s: %s", "gsmvi_bam_update_f64", "B > 640 exceeds the device chain (LDS of the forward substitution)");
         return GSMVI_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(k_bam_stats_h, dim3((D + 63) / 64), dim3(256), 0, st, D, B, X, ldx, mu0, (const double*)nullptr, 0, G, ldg,
-                       reg, xbar, gbar, (double*)nullptr, Qt, Ft, Fs);
+    bam_stats_launch(st, D, B, X, ldx, mu0, (const double*)nullptr, 0, G, ldg, reg, xbar, gbar, (double*)nullptr, Qt, Ft, Fs);
     int kc = 1, rc;
     if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, D, n, Qt, D, nullptr, 1.0, S0, lds0, ctx->pp, &kc))) return rc;
     if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, P, D))) return rc;
@@ -892,8 +908,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     // Zw = L^-1 (Wq + M1^T Vw); the mean output of either kernel (mu0 = xbar = 0) is r1 (wg + Vw^T vg - Zw^T zg) = r1 h, row 2n of Ft
     const bool fused48 = n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full;
 
-    hipLaunchKernelGGL(k_bam_stats_h, dim3((D + 63) / 64), dim3(256), 0, st, D, B, Z, ldz, (const double*)nullptr, X, ldx, G, ldg,
-                       reg, xbar, gbar, zerov, Qt, Ft, (double*)nullptr);
+    bam_stats_launch(st, D, B, Z, ldz, (const double*)nullptr, X, ldx, G, ldg, reg, xbar, gbar, zerov, Qt, Ft, (double*)nullptr);
     if ((rc = gsmvi_panel_t_product(ctx, st, D, n, Qt, D, F0, ldf0, D, ctx->pp, &kc))) return rc;
     if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, Wq, D))) return rc;
     if ((rc = gsmvi_panel_t_product(ctx, st, D, n2, Wq, D, Wq, D, n, ctx->pp, &kc))) return rc;

@@ -3,39 +3,65 @@
 //
 //   C(i, j) = sum_{k < K} a(i, k) b(k, j),   i < m, j < p        op.store(i, j, value) writes it where it belongs
 //
-// One 16 x 16 output block per workgroup (256 threads), K split over the four waves (wave w takes the k-steps w, w + 4, ...:
-// at most 16 each, all 32 operand values loaded in one batch, two accumulator chains), the four partial blocks summed through
-// LDS in a fixed order: deterministic, launch-bound (~4.5 us) like the Newton-Schulz steps of gsmvi_bam_small.hip whose
-// block kernel this generalises.  Operands come straight from L2 through the functor's a(i, k) / b(k, j), which receive
+// One 16 x 16 output block per workgroup (256 threads): both operand tiles (16 x K and K x 16) are staged in LDS by all threads,
+// along the direction in which their source is contiguous; K is split over the four waves (wave w takes the k-steps w, w + 4, ...,
+// two accumulator chains), the four partial blocks are summed through LDS in a fixed order: deterministic, launch-bound like the
+// Newton-Schulz steps of gsmvi_bam_small.hip whose block kernel this generalises.  The functor's a(i, k) / b(k, j) receive
 // CLAMPED indices (the kernel zeroes what lies outside); op.skip() lets an op leave the launch early on a device flag.
 #pragma once
 #include "gsmvi_common.h"
 
 template <class OP>
 __global__ __launch_bounds__(256) void k_small_gemm(OP op) {
+    constexpr int SA = 260, SB = 17, KMAX = 256;             // LDS strides: A [16][260] (260 = 4 mod 32: conflict-free fragment reads),
+    __shared__ double As[16 * SA], Bs[KMAX * SB];            // B [k][17]
     __shared__ double red[4 * 256];
     if (op.skip()) return;
     const int m = op.m, p = op.p, K = op.K;
     const int nbj = (p + 15) >> 4;
     const int bi = blockIdx.x / nbj, bj = blockIdx.x - bi * nbj, i0 = 16 * bi, j0 = 16 * bj;
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, cc = l & 15, ks = l >> 4;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
     const int nk = (K + 3) >> 2;
-    const int ic = (i0 + cc) < m ? i0 + cc : m - 1, jc = (j0 + cc) < p ? j0 + cc : p - 1;
-    const bool iin = (i0 + cc) < m, jin = (j0 + cc) < p;
-    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-    for (int u0 = 0; w + 4 * u0 < nk; u0 += 16) {
-        double a[16], b[16];
+    // ---- both operand tiles through LDS, loaded along the direction in which the SOURCE is contiguous (OP::A_KMAJOR /
+    // OP::B_KMAJOR): an MFMA fragment read straight from a row-major matrix touches 16 cache lines per load instruction
+    // (the first version of this kernel did that: 8.7 - 12.9 us per launch at K = 128 ... 256) ----
+    const int K4 = 4 * nk;                                   // K rounded up to the MFMA step (<= 256)
+    for (int e0 = 0; e0 < 16 * K4; e0 += 256 * 8) {
+        double va[8], vb[8];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int st = w + 4 * (u0 + u), k = 4 * st + ks, kc = k < K ? k : K - 1;
-            const double av = op.a(ic, kc), bv = op.b(kc, jc);
-            a[u] = (k < K && iin) ? av : 0.0;
-            b[u] = (k < K && jin) ? bv : 0.0;
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 256 * u + tid;
+            int row, k;
+            if (OP::A_KMAJOR) { row = e / K4; k = e - row * K4; } else { k = e >> 4; row = e & 15; }
+            const bool in = e < 16 * K4 && k < K && (i0 + row) < m;
+            const double v = op.a((i0 + row) < m ? i0 + row : m - 1, k < K ? k : K - 1);
+            va[u] = in ? v : 0.0;
+            int kb, col;
+            if (OP::B_KMAJOR) { col = e / K4; kb = e - col * K4; } else { kb = e >> 4; col = e & 15; }
+            const bool inb = e < 16 * K4 && kb < K && (j0 + col) < p;
+            const double vv = op.b(kb < K ? kb : K - 1, (j0 + col) < p ? j0 + col : p - 1);
+            vb[u] = inb ? vv : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 16; u += 2) {
-            acc0 = GSMVI_MFMA_F64(a[u], b[u], acc0);
-            acc1 = GSMVI_MFMA_F64(a[u + 1], b[u + 1], acc1);
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 256 * u + tid;
+            if (e < 16 * K4) {
+                int row, k, kb, col;
+                if (OP::A_KMAJOR) { row = e / K4; k = e - row * K4; } else { k = e >> 4; row = e & 15; }
+                if (OP::B_KMAJOR) { col = e / K4; kb = e - col * K4; } else { kb = e >> 4; col = e & 15; }
+                As[row * SA + k] = va[u];
+                Bs[kb * SB + col] = vb[u];
+            }
+        }
+    }
+    __syncthreads();
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int st = w; st < nk; st += 8) {                      // wave w: k-steps w, w + 4, ... (two accumulator chains)
+        const int k0 = 4 * st + ks;
+        acc0 = GSMVI_MFMA_F64(As[cc * SA + k0], Bs[k0 * SB + cc], acc0);
+        if (st + 4 < nk) {
+            const int k1 = k0 + 16;
+            acc1 = GSMVI_MFMA_F64(As[cc * SA + k1], Bs[k1 * SB + cc], acc1);
         }
     }
 #pragma unroll
@@ -58,6 +84,7 @@ static inline void small_gemm_launch(hipStream_t st, const OP& op) {
 //   R12 = D' W11 A12,   A22' = A22 - R12^T R12,   [A22' | I] -> [R22 | W22],   T1 = W22 R12^T,   W21 = -T1 W11
 // (D' zeroes the rows the rank-revealing rule dropped, R11[i][i] == 0: what chol128w_body does inside one 128 block).
 struct OpBlkR12 {                                  // R[0:n1, n1:n] = D' W11 A12, R[n1:n, 0:n1] = 0
+    static constexpr bool A_KMAJOR = true, B_KMAJOR = false;   // which index the SOURCE of a(i, k) / b(k, j) is contiguous in
     int m, p, K;                                   // n1, n2, n1
     const double *W, *A;
     double* R;
@@ -71,6 +98,7 @@ struct OpBlkR12 {                                  // R[0:n1, n1:n] = D' W11 A12
     }
 };
 struct OpBlkS22 {                                  // S22 = A22 (diagonal lowered by its rounding floor when semidef) - R12^T R12
+    static constexpr bool A_KMAJOR = false, B_KMAJOR = false;   // which index the SOURCE of a(i, k) / b(k, j) is contiguous in
     int m, p, K;                                   // n2, n2, n1
     const double *R, *A;
     double* S;
@@ -85,6 +113,7 @@ struct OpBlkS22 {                                  // S22 = A22 (diagonal lowere
     }
 };
 struct OpBlkT1 {                                   // T1 = W22 R12^T   (n2 x n1)
+    static constexpr bool A_KMAJOR = true, B_KMAJOR = true;   // which index the SOURCE of a(i, k) / b(k, j) is contiguous in
     int m, p, K;                                   // n2, n1, n2
     const double *W, *R;
     double* T1;
@@ -95,6 +124,7 @@ struct OpBlkT1 {                                   // T1 = W22 R12^T   (n2 x n1)
     __device__ void store(int i, int j, double v) const { T1[(size_t)i * p + j] = v; }
 };
 struct OpBlkW21 {                                  // W[n1:n, 0:n1] = -T1 W11; also the zero blocks W12 and R21
+    static constexpr bool A_KMAJOR = true, B_KMAJOR = false;   // which index the SOURCE of a(i, k) / b(k, j) is contiguous in
     int m, p, K;                                   // n2, n1, n1
     const double* T1;
     double *W, *R;
@@ -111,6 +141,7 @@ struct OpBlkW21 {                                  // W[n1:n, 0:n1] = -T1 W11; a
 
 // ---- the n x n products of the 2B x 2B chain, 64 < n <= 256 -----------------------------------------------------------------
 struct OpSmallA {                                  // A' = I + (Rg J) Rg^T;  J = (1/B) [[0, I], [I, -I]] or, jmode, diag(I, -I) unscaled
+    static constexpr bool A_KMAJOR = true, B_KMAJOR = true;   // which index the SOURCE of a(i, k) / b(k, j) is contiguous in
     int m, p, K;                                   // n, n, n
     const double* Rg;
     const int* info_g;
@@ -129,6 +160,7 @@ struct OpSmallA {                                  // A' = I + (Rg J) Rg^T;  J =
     }
 };
 struct OpChainP {                                  // P = (T - I)(W S), with the chain's accept / revert decision
+    static constexpr bool A_KMAJOR = true, B_KMAJOR = false;   // which index the SOURCE of a(i, k) / b(k, j) is contiguous in
     int m, p, K;
     const double *T, *W, *ab;
     double* P;
@@ -149,6 +181,7 @@ struct OpChainP {                                  // P = (T - I)(W S), with the
     __device__ void store(int i, int j, double v) const { P[(size_t)i * m + j] = v; }
 };
 struct OpChainK {                                  // K'' = (W S)^T P
+    static constexpr bool A_KMAJOR = false, B_KMAJOR = false;   // which index the SOURCE of a(i, k) / b(k, j) is contiguous in
     int m, p, K;
     const double *W, *P, *ab;
     double* Kmat;
