@@ -241,9 +241,11 @@ __global__ __launch_bounds__(256) void k_bam_nmat(int n, const double* __restric
 // 0 .. n-1 = N0, rows n .. 2n-1 = M1), K = n split over the four waves, partial blocks summed through LDS in a fixed order,
 // and writes its blocks of the finished N0 and M1 as well (k_bam_cholw / k_bam_zw read them).  M1^T is not produced: the
 // product-form Z (k_bam_zw) reads M1 by columns itself.
-__global__ __launch_bounds__(256) void k_bam_nmat2(int n, int kc, const double* __restrict__ slabs, long long slab_stride,
+// ldp: row length of the slabs (n; 2n when the product also holds [.; Vw] Vw^T -- G11 then receives the finished Vw Vw^T, the
+// first diagonal block of the factor-form chain's Gram matrix, which is factored beside k_bam_cholw).
+__global__ __launch_bounds__(256) void k_bam_nmat2(int n, int kc, const double* __restrict__ slabs, long long slab_stride, int ldp,
                                                    double* __restrict__ N0, double* __restrict__ M1,
-                                                   double* __restrict__ Nm) {
+                                                   double* __restrict__ Nm, double* __restrict__ G11) {
     __shared__ double red[4 * 256];
     const int nb = (n + 15) >> 4;
     const int bi = blockIdx.x / nb, bj = blockIdx.x - bi * nb, i0 = 16 * bi, j0 = 16 * bj;
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256) void k_bam_nmat2(int n, int kc, const double* 
     auto slab_sum = [&](int r, int c) {                      // one finished entry: the kc slabs, all loads in one batch
         double t[GSMVI_MAX_KC];
 #pragma unroll
-        for (int q = 0; q < GSMVI_MAX_KC; ++q) t[q] = slabs[(size_t)(q < kc ? q : kc - 1) * slab_stride + (size_t)r * n + c];
+        for (int q = 0; q < GSMVI_MAX_KC; ++q) t[q] = slabs[(size_t)(q < kc ? q : kc - 1) * slab_stride + (size_t)r * ldp + c];
         double a = 0.0;
 #pragma unroll
         for (int q = 0; q < GSMVI_MAX_KC; ++q) a += (q < kc) ? t[q] : 0.0;
@@ -262,6 +264,7 @@ __global__ __launch_bounds__(256) void k_bam_nmat2(int n, int kc, const double* 
     const int t = threadIdx.x, i = i0 + (t >> 4), j = j0 + (t & 15);
     const int iq = i < n ? i : n - 1, jq = j < n ? j : n - 1;
     const double n0ij = slab_sum(iq, jq), n0ji = slab_sum(jq, iq), m1ij = slab_sum(n + iq, jq);   // (issued first: not a tail)
+    const double g11 = G11 ? slab_sum(n + iq, n + jq) : 0.0;
     v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     for (int u0 = 0; w + 4 * u0 < nk; u0 += 4) {             // four k-steps of this wave per batch (64 slab loads in flight)
         double a[4], b[4];
@@ -285,6 +288,7 @@ __global__ __launch_bounds__(256) void k_bam_nmat2(int n, int kc, const double* 
         Nm[(size_t)i * n + j] = v + 0.5 * (n0ij + n0ji);
         N0[(size_t)i * n + j] = n0ij;
         M1[(size_t)i * n + j] = m1ij;
+        if (G11) G11[(size_t)i * n + j] = g11;
     }
 }
 
@@ -754,9 +758,10 @@ __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, cons
         }                                                                     \
     } while (0)
 
+#include "gsmvi_chol128.h"   // cholw_job
 int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* Nd, const double* M1,
                            const double* N0, double* scratch, double* Ld, int* info_dev, int* hint_host, int force_kenq,
-                           double* Rscr);
+                           double* Rscr, const cholw_job* beside);
 int gsmvi_bam_small_nmax();
 size_t gsmvi_bam_small_scratch_doubles(int n);
 int gsmvi_panel_t_product(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* A, int lda, const double* M,
@@ -818,8 +823,10 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
                            Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu);
     } else if (use_w) {
         const int nbq = (n + 15) / 16;
-        hipLaunchKernelGGL(k_bam_nmat2, dim3(nbq * nbq), dim3(256), 0, st, n, kc, ctx->pp, (long long)n2 * n, N0, M1, Nd);
-        if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_p, hint, ctx->tune_bam_kenq, M1T))) return rc;
+        hipLaunchKernelGGL(k_bam_nmat2, dim3(nbq * nbq), dim3(256), 0, st, n, kc, ctx->pp, (long long)n2 * n, n, N0, M1, Nd,
+                           (double*)nullptr);
+        if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_p, hint, ctx->tune_bam_kenq, M1T, nullptr)))
+            return rc;
         // Z = W (P + M1^T Vf) by two chained MFMA products per 16 columns of D, the mean with it (Wt = (L^-1)^T sits in Ld's slot,
         // [a | . | vg] behind it)
         hipLaunchKernelGGL(k_bam_zw, dim3((D + 15) / 16), dim3(512), 0, st, D, n, P, M1, Ld, Ldinv, Ldinv + 2 * n, mu0, xbar,
@@ -827,7 +834,8 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     } else {
         if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
         hipLaunchKernelGGL(k_bam_nmat, dim3((((n + 15) / 16) * ((n + 15) / 16) + 3) / 4), dim3(256), 0, st, n, M1, N0, Nd, M1T);
-        if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_p, hint, ctx->tune_bam_kenq, nullptr))) return rc;
+        if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_p, hint, ctx->tune_bam_kenq, nullptr, nullptr)))
+            return rc;
 #define BFW(CV) hipLaunchKernelGGL(k_bam_forward<CV>, dim3((D + CV - 1) / CV), dim3(CV), sizeof(double) * 2 * n * CV, st, D, n, P, M1, Ld, Ldinv, Ldinv + n, Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu)
         if (n <= 160) BFW(64); else if (n <= 320) BFW(32); else BFW(16);
 #undef BFW
@@ -911,7 +919,13 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     bam_stats_launch(st, D, B, Z, ldz, (const double*)nullptr, X, ldx, G, ldg, reg, xbar, gbar, zerov, Qt, Ft, (double*)nullptr);
     if ((rc = gsmvi_panel_t_product(ctx, st, D, n, Qt, D, F0, ldf0, D, ctx->pp, &kc))) return rc;
     if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, Wq, D))) return rc;
-    if ((rc = gsmvi_panel_t_product(ctx, st, D, n2, Wq, D, Wq, D, n, ctx->pp, &kc))) return rc;
+    // Two-level 2B x 2B chain ahead (64 < B <= 128): its first diagonal block Gamma11 = Vw Vw^T does not depend on the B x B
+    // chain, so the Gram product below is taken against [Wq; Vw] (2n columns instead of n: the slabs then hold Vw Vw^T as well)
+    // and [Gamma11 | I] -> [R11 | W11] runs as the second workgroup of k_bam_cholw's launch (ctx->early; factor_chain_big).
+    ctx->early_ready = 0;
+    const bool early = !fused48 && n > 64 && n <= 128 && ctx->tune_chain_pair && ctx->early;
+    const int gcols = early ? n2 : n;
+    if ((rc = gsmvi_panel_t_product(ctx, st, D, n2, Wq, D, Wq, D, gcols, ctx->pp, &kc))) return rc;
     if (fused48) {
         if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, n, (size_t)n2 * n, M1, Ld, Upk, info_bam))) return rc;
         hipLaunchKernelGGL(k_bam_forward16, dim3((D + 15) / 16), dim3(256), 0, st, D, n, Wq, M1, Upk, Ldinv, Ldinv + n,
@@ -924,10 +938,18 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
                 ctx->bam_hint_host = nullptr;
         }
         const int nbq = (n + 15) / 16;
-        hipLaunchKernelGGL(k_bam_nmat2, dim3(nbq * nbq), dim3(256), 0, st, n, kc, ctx->pp, (long long)n2 * n, N0, M1, Nd);
+        double* G11 = ctx->early;                  // n x n each, compact
+        double* R11 = ctx->early + 128 * 128;
+        double* W11 = ctx->early + 2 * 128 * 128;
+        hipLaunchKernelGGL(k_bam_nmat2, dim3(nbq * nbq), dim3(256), 0, st, n, kc, ctx->pp, (long long)n2 * gcols, gcols, N0, M1, Nd,
+                           early ? G11 : (double*)nullptr);
+        // (the magnitude guard of the rank-revealing rule sees this block's own diagonal: the second block's is not known yet)
+        const cholw_job beside{n, G11, n, R11, n, W11, n, ctx->ints, 0, 0, nullptr, 0, 0};
         if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_bam,
-                                         ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq, M1T)))
+                                         ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq, M1T,
+                                         early ? &beside : nullptr)))
             return rc;
+        ctx->early_ready = early ? 1 : 0;
         hipLaunchKernelGGL(k_bam_zw, dim3((D + 15) / 16), dim3(512), 0, st, D, n, Wq, M1, Ld, Ldinv, Ldinv + 2 * n, zerov, zerov,
                            reg, Ft, T1, Ft + (size_t)n2 * D);
     }

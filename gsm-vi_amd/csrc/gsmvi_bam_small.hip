@@ -324,6 +324,28 @@ __global__ __launch_bounds__(512) void k_bam_cholw(int n, const double* __restri
     }
 }
 
+// The same with a second, independent job beside it (round 4): workgroup 0 is k_bam_cholw<true>, workgroup 1 factors
+// [Gamma11 | I] -> [R11 | W11] of the factor-form chain's Gram matrix under the rank-revealing rule (gsmvi_factor.hip,
+// factor_chain_big: Gamma11 = Vw Vw^T is known before the B x B chain starts) -- two ~45 us one-CU pivot chains in the time of one.
+__global__ __launch_bounds__(512) void k_bam_cholw_pair(int n, const double* __restrict__ BBg, double* Rg, double* Wt,
+                                                        int* __restrict__ info, cholw_job g) {
+    CHOL128W_LDS(E1, B12, scr, sh_fail, sh_moderate);
+    __shared__ int sh_info;
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 1) {
+        chol128w_core<true, false>(E1, B12, scr, sh_fail, &sh_moderate, g.nb, g.A, g.lda, g.R, g.ldr, g.W, g.ldw, &sh_info);
+        __syncthreads();
+        if (tid == 0) *g.info = sh_info;
+        return;
+    }
+    chol128w_core<false, true>(E1, B12, scr, sh_fail, &sh_moderate, n, BBg, n, Rg, n, Wt, n, info, &sh_info);
+    __syncthreads();
+    if (sh_info != 0) {
+        const double qn = __longlong_as_double(0x7ff8000000000000LL);
+        for (size_t e = tid; e < (size_t)n * n + 3 * n; e += 512) Wt[e] = qn;
+    }
+}
+
 // ---- n > 129: the small outputs from the blocked Cholesky factor of BB (gsmvi_potrf_impl: BB = R^T R) ------------------
 // One workgroup: Ld = R^T (lower), Ldinv, vg = Vf gbar = M1[:, n-1] / r1s, zg = L^-1 (P gbar + M1^T vg) by a column-oriented
 // forward substitution (row pp of R is contiguous; eight rows' loads in flight).  A failed factorisation (or a NaN in it)
@@ -708,7 +730,7 @@ int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double*
 // small outputs of k_bam_post_big (Ld = L, Ldinv, zg, vg) for the generic forward-substitution kernel.
 int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* Nd, const double* M1,
                            const double* N0, double* scratch, double* Ld, int* info_dev, int* hint_host, int force_kenq,
-                           double* Rscr) {
+                           double* Rscr, const cholw_job* beside) {
     const int ld = n <= BAMS_NMAX ? BAMS_LD : ((n + 15) / 16) * 16;
     const size_t LL = (size_t)ld * ld;
     double* Ya = scratch;
@@ -738,7 +760,9 @@ int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, co
         // BB and the factor-independent vectors [a | . | vg] behind W's slot, then the factorisation with the inverse factor
         hipLaunchKernelGGL(k_bam_bbav, dim3(nb * nb + nb), dim3(256), 0, st, n, ld, reg, Nd, Ya, Yb, coef, M1, N0, BBg,
                            Ld + (size_t)n * n);
-        if (n > 64) hipLaunchKernelGGL(k_bam_cholw<true>, dim3(1), dim3(512), 0, st, n, BBg, Rscr, Ld, info_dev);
+        if (n > 64 && beside)                               // a second one-workgroup factorisation shares the launch
+            hipLaunchKernelGGL(k_bam_cholw_pair, dim3(2), dim3(512), 0, st, n, BBg, Rscr, Ld, info_dev, *beside);
+        else if (n > 64) hipLaunchKernelGGL(k_bam_cholw<true>, dim3(1), dim3(512), 0, st, n, BBg, Rscr, Ld, info_dev);
         else hipLaunchKernelGGL(k_bam_cholw<false>, dim3(1), dim3(512), 0, st, n, BBg, Rscr, Ld, info_dev);
     } else {
         // beyond the one-workgroup Cholesky: the blocked multi-workgroup factorisation of the D x D path (its workspace is

@@ -24,16 +24,23 @@
 // two-level scheme); moderate_ext: 0 / 1 overrides the magnitude guard taken from this block's own diagonal (-1: own).
 // WT: W is stored TRANSPOSED (Wo[j ldw + i] = W[i][j], i.e. the upper triangular R^-1): what a consumer wants that reads W's
 // rows as MFMA A-operands (k_bam_zw: 16 consecutive doubles per k instead of 16 cache lines per load instruction).
+// LDS of one factorisation (one set per KERNEL: chol128w_core takes it as arguments, so a kernel whose workgroups run
+// different instantiations -- the paired launches of gsmvi_factor.hip / gsmvi_bam_small.hip -- allocates it once).
+#define CHOL128W_ES1 146
+#define CHOL128W_BS 66
+#define CHOL128W_LDS(E1, B12, scr, shf, shm)                                    \
+    __shared__ __attribute__((aligned(16))) double E1[64 * CHOL128W_ES1];       \
+    __shared__ __attribute__((aligned(16))) double B12[64 * CHOL128W_BS];       \
+    __shared__ __attribute__((aligned(16))) double scr[CHOLB_SCRATCH_DOUBLES(1)]; \
+    __shared__ int shf[2], shm
 template <bool SEMIDEF, bool WT = false>
-__device__ __forceinline__ void chol128w_body(int n, const double* __restrict__ A, int lda, double* __restrict__ R, int ldr,
+__device__ __forceinline__ void chol128w_core(double* E1, double* B12, double* scr, int* sh_fail, int* sh_moderate_p, int n,
+                                              const double* __restrict__ A, int lda, double* __restrict__ R, int ldr,
                                               double* __restrict__ Wo, int ldw, int* __restrict__ info,
                                               int* sh_info = nullptr, bool tol_applied = false, int moderate_ext = -1) {
-    constexpr int ES1 = 146, BS = 66;
+    constexpr int ES1 = CHOL128W_ES1, BS = CHOL128W_BS;
     auto widx = [&](int i, int j) -> size_t { return WT ? (size_t)j * ldw + i : (size_t)i * ldw + j; };   // where W[i][j] lives
-    __shared__ __attribute__((aligned(16))) double E1[64 * ES1];
-    __shared__ __attribute__((aligned(16))) double B12[64 * BS];
-    __shared__ __attribute__((aligned(16))) double scr[CHOLB_SCRATCH_DOUBLES(1)];
-    __shared__ int sh_fail[2], sh_moderate;
+    int& sh_moderate = *sh_moderate_p;
     const int tid = threadIdx.x, n2 = n - 64;
     const int w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
     if (tid == 0) sh_moderate = 1;
@@ -232,3 +239,30 @@ __device__ __forceinline__ void chol128w_body(int n, const double* __restrict__ 
         if (sh_info) *sh_info = f;
     }
 }
+
+template <bool SEMIDEF, bool WT = false>
+__device__ __forceinline__ void chol128w_body(int n, const double* __restrict__ A, int lda, double* __restrict__ R, int ldr,
+                                              double* __restrict__ Wo, int ldw, int* __restrict__ info,
+                                              int* sh_info = nullptr, bool tol_applied = false, int moderate_ext = -1) {
+    CHOL128W_LDS(E1, B12, scr, sh_fail, sh_moderate);
+    chol128w_core<SEMIDEF, WT>(E1, B12, scr, sh_fail, &sh_moderate, n, A, lda, R, ldr, Wo, ldw, info, sh_info, tol_applied,
+                               moderate_ext);
+}
+
+// One diagonal-block job of a PAIRED launch (round 4): two independent one-workgroup factorisations with the inverse factor,
+// 64 < nb <= 128 each, run as the two workgroups of one launch instead of two launches behind each other (each is a
+// ~40 us chain of 128 pivots on one CU; 254 CUs idle either way).  info chaining as k_cholw_ld: info_off == 0 writes *info,
+// a later block records its failure only when the earlier ones passed.
+struct cholw_job {
+    int nb;
+    const double* A;
+    int lda;
+    double* R;
+    int ldr;
+    double* W;
+    int ldw;
+    int* info;
+    int info_off, tol_applied;
+    const double* dg;                  // SEMIDEF jobs: diagonal the magnitude guard looks at (dg_n entries, stride dg_stride), or null
+    int dg_n, dg_stride;
+};

@@ -67,6 +67,10 @@ struct gsmvi_ctx {
     int* bam_hint_host = nullptr;       // pinned word: k* of the last device BaM chain (step-count hint, never synchronised on)
     int tune_bam_kenq = 0;     // > 0: enqueue exactly this many multi-workgroup steps (tests of the tail kernel)
     int tune_bam_full = 0;     // 1 = always enqueue every Newton-Schulz step (ignore the hint; tests)
+    int tune_chain_pair = 1;   // two-level chain (128 < 2B <= 256): independent one-workgroup factorisations share a launch (0: A/B runs)
+    double* early = nullptr;   // [Gamma11 | R11 | W11], 128 x 128 each: the first diagonal block of the factor-form BaM chain's Gram
+                               // matrix (Vw Vw^T, known before the B x B chain) and its factors, produced beside k_bam_cholw
+    int early_ready = 0;       // set by gsmvi_bam_factor_impl when that job was launched; consumed by factor_chain_big
     int profiling = 0;         // when set, the update kernels are launched with dispatch-timestamp events
     hipStream_t side = nullptr;         // second stream of the factor path at large D (V Fm beside the 2B x 2B chain), with its
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // fork / join events (no timing)

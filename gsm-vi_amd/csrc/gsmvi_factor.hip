@@ -372,6 +372,38 @@ __global__ __launch_bounds__(512) void k_cholw_ld(int nb, const double* __restri
     }
 }
 
+// ---- two diagonal-block jobs in ONE launch (64 < nb <= 128 each): workgroup 0 = job a under the rank-revealing rule,
+// workgroup 1 = job b under the plain rule.  Used by the two-level chain (factor_chain_big): [S22 | I] -> [R22 | W22] of Gamma
+// beside [A'11 | I] -> [T11 | W_T11] -- A'11 = I + (Rg J Rg^T)_11 needs only the first block row [R11 R12] of Rg.
+__global__ __launch_bounds__(512) void k_cholw_pair(cholw_job a, cholw_job b) {
+    CHOL128W_LDS(E1, B12, scr, sh_fail, sh_moderate);
+    __shared__ int sh_mod, sh_f;
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {
+        int moderate_ext = -1;
+        if (a.dg) {
+            if (tid == 0) sh_mod = 1;
+            __syncthreads();
+            for (int i = tid; i < a.dg_n; i += 512)
+                if (!(a.dg[(size_t)i * a.dg_stride] < 4294967296.0)) sh_mod = 0;
+            __syncthreads();
+            moderate_ext = sh_mod;
+        }
+        chol128w_core<true>(E1, B12, scr, sh_fail, &sh_moderate, a.nb, a.A, a.lda, a.R, a.ldr, a.W, a.ldw, &sh_f, nullptr,
+                            a.tol_applied != 0, moderate_ext);
+    } else {
+        chol128w_core<false>(E1, B12, scr, sh_fail, &sh_moderate, b.nb, b.A, b.lda, b.R, b.ldr, b.W, b.ldw, &sh_f);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int f = sh_f;
+        int* info = blockIdx.x == 0 ? a.info : b.info;
+        const int off = blockIdx.x == 0 ? a.info_off : b.info_off;
+        if (off == 0) *info = f;
+        else if (f != 0 && *info == 0) *info = off + f;
+    }
+}
+
 // ---- F = F0 + Rt^T Fs  (full, non-symmetric rank-n update; F = F0 when *bad) ---------------------------
 __global__ __launch_bounds__(256) void k_gsmf_update(int D, int KF, const double* __restrict__ Ft,
                                                      const double* __restrict__ Fs, const double* __restrict__ F0,
@@ -1085,36 +1117,70 @@ int gsmvi_factor_apply_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const 
 // first block is used, for the block-row solve) in Gam1 and its S22 in Rg (both dead by then).  Returns K'' in w.Gam.
 static int factor_chain_big(gsmvi_ctx* ctx, hipStream_t st, int n, int B, const factor_ws& w, const double* Gp, int kcg,
                             int jmode, const int* prior, int* info_dev) {
-    const int n1 = 128, n2 = n - 128;
+    // block split: 128 + (n - 128); the factor-form BaM chain (jmode, 64 < B <= 128) splits at B -- its first diagonal block
+    // Gamma11 = Vw Vw^T is then known before the B x B chain and may have been factored beside it (ctx->early_ready)
+    const int n1 = jmode ? B : 128, n2 = n - n1;
     int* info_g = ctx->ints;
     int* info_t = ctx->ints + 1;
     double* coef = w.coef;
     const size_t off = (size_t)n1 * n + n1;        // the (1, 1) block inside an n x n matrix
+    const bool early = jmode && ctx->early_ready != 0;
+    ctx->early_ready = 0;
+    // paired launches (round 4): both diagonal blocks on the 128-row kernel, and the knob on
+    const bool pair = ctx->tune_chain_pair && n1 > 64 && n2 > 64;
     hipLaunchKernelGGL(k_gsmf_gamma_big, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, w.Gam, coef, coef + n, jmode);
     // Gamma = Rg^T Rg (rank-revealing rule), W = Rg^-T -> w.Pm
-    hipLaunchKernelGGL((k_cholw_ld<true, true>), dim3(1), dim3(512), 0, st, n1, w.Gam, n, w.Rg, n, w.Pm, n, info_g, 0, 0,
-                       w.Gam, n, n + 1);
-    small_gemm_launch(st, OpBlkR12{n1, n2, n1, w.Pm, w.Gam, w.Rg, n, n, n, n1});
-    small_gemm_launch(st, OpBlkS22{n2, n2, n1, w.Rg, w.Gam, w.Ap, n, n, n1, 1});
-    if (n2 > 64)
-        hipLaunchKernelGGL((k_cholw_ld<true, true>), dim3(1), dim3(512), 0, st, n2, w.Ap, n2, w.Rg + off, n, w.Pm + off, n, info_g,
+    if (early) {
+        // [Gamma11 | I] -> [R11 | W11] ran as the second workgroup of k_bam_cholw's launch (compact, ld n1); the R12 product
+        // reads W11 / R11 there and copies them into the n x n matrices
+        const double* R11 = ctx->early + 128 * 128;
+        const double* W11 = ctx->early + 2 * 128 * 128;
+        small_gemm_launch(st, OpBlkR12{n1, n2, n1, W11, w.Gam, w.Rg, n1, n, n, n1, R11, n1, w.Pm, n});
+    } else {
+        if (n1 > 64)
+            hipLaunchKernelGGL((k_cholw_ld<true, true>), dim3(1), dim3(512), 0, st, n1, w.Gam, n, w.Rg, n, w.Pm, n, info_g, 0, 0,
+                               w.Gam, n, n + 1);
+        else
+            hipLaunchKernelGGL((k_cholw_ld<true, false>), dim3(1), dim3(512), 0, st, n1, w.Gam, n, w.Rg, n, w.Pm, n, info_g, 0, 0,
+                               w.Gam, n, n + 1);
+        small_gemm_launch(st, OpBlkR12{n1, n2, n1, w.Pm, w.Gam, w.Rg, n, n, n, n1});
+    }
+    // slots while Gamma is factored: S22 and T1 in Gam1 (free until the end of the chain); A'11 -> Ap, T11 -> Tt, T's inverse
+    // factor (only its first block exists and is used: the block-row solve) compact in the upper half of the coefficient slot
+    double* S22g = w.Gam1;
+    double* T1g = w.Gam1 + (size_t)n2 * n2;
+    double* Wt = pair ? w.coef + (size_t)n * n / 2 : w.Gam1;   // n1 x n1, ld n1 (unpaired: Gam1 is free again by then)
+    small_gemm_launch(st, OpBlkS22{n2, n2, n1, w.Rg, w.Gam, S22g, n, n, n1, 1});
+    if (pair) {
+        // A'11 = I + (Rg J Rg^T)_11 needs only [R11 R12]: its factorisation runs beside Gamma's second block, one launch
+        small_gemm_launch(st, OpSmallA{n1, n1, n, w.Rg, info_g, w.Ap, B, jmode, n});
+        const cholw_job ja{n2, S22g, n2, w.Rg + off, n, w.Pm + off, n, info_g, n1, 1, w.Gam, n, n + 1};
+        const cholw_job jb{n1, w.Ap, n, w.Tt, n, Wt, n1, info_t, 0, 0, nullptr, 0, 0};
+        hipLaunchKernelGGL(k_cholw_pair, dim3(2), dim3(512), 0, st, ja, jb);
+    } else if (n2 > 64)
+        hipLaunchKernelGGL((k_cholw_ld<true, true>), dim3(1), dim3(512), 0, st, n2, S22g, n2, w.Rg + off, n, w.Pm + off, n, info_g,
                            n1, 1, w.Gam, n, n + 1);
     else
-        hipLaunchKernelGGL((k_cholw_ld<true, false>), dim3(1), dim3(512), 0, st, n2, w.Ap, n2, w.Rg + off, n, w.Pm + off, n, info_g,
+        hipLaunchKernelGGL((k_cholw_ld<true, false>), dim3(1), dim3(512), 0, st, n2, S22g, n2, w.Rg + off, n, w.Pm + off, n, info_g,
                            n1, 1, w.Gam, n, n + 1);
-    small_gemm_launch(st, OpBlkT1{n2, n1, n2, w.Pm, w.Rg, w.Tt, n, n, n1});
-    small_gemm_launch(st, OpBlkW21{n2, n1, n1, w.Tt, w.Pm, w.Rg, n, n, n1});
+    small_gemm_launch(st, OpBlkT1{n2, n1, n2, w.Pm, w.Rg, T1g, n, n, n1});
+    small_gemm_launch(st, OpBlkW21{n2, n1, n1, T1g, w.Pm, w.Rg, n, n, n1});
     // A' = I + Rg J Rg^T = T^T T (plain rule: this IS the accept test)
-    small_gemm_launch(st, OpSmallA{n, n, n, w.Rg, info_g, w.Ap, B, jmode});
-    double* Wt = w.Gam1;                           // T^-T: scratch, only its first block is consumed
-    hipLaunchKernelGGL((k_cholw_ld<false, true>), dim3(1), dim3(512), 0, st, n1, w.Ap, n, w.Tt, n, Wt, n, info_t, 0, 0,
-                       (const double*)nullptr, 0, 0);
-    small_gemm_launch(st, OpBlkR12{n1, n2, n1, Wt, w.Ap, w.Tt, n, n, n, n1});
+    small_gemm_launch(st, OpSmallA{n, n, n, w.Rg, info_g, w.Ap, B, jmode, n});
+    if (!pair) {
+        if (n1 > 64)
+            hipLaunchKernelGGL((k_cholw_ld<false, true>), dim3(1), dim3(512), 0, st, n1, w.Ap, n, w.Tt, n, Wt, n1, info_t, 0, 0,
+                               (const double*)nullptr, 0, 0);
+        else
+            hipLaunchKernelGGL((k_cholw_ld<false, false>), dim3(1), dim3(512), 0, st, n1, w.Ap, n, w.Tt, n, Wt, n1, info_t, 0, 0,
+                               (const double*)nullptr, 0, 0);
+    }
+    small_gemm_launch(st, OpBlkR12{n1, n2, n1, Wt, w.Ap, w.Tt, n1, n, n, n1});
     small_gemm_launch(st, OpBlkS22{n2, n2, n1, w.Tt, w.Ap, w.Rg, n, n, n1, 0});
     if (n2 > 64)                                   // (the last block needs no inverse factor: the plain 128-row kernel, 32 us against 39)
         hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n2, w.Rg, w.Tt + off, n, info_t, n1);
     else
-        hipLaunchKernelGGL((k_cholw_ld<false, false>), dim3(1), dim3(512), 0, st, n2, w.Rg, n2, w.Tt + off, n, Wt + off, n, info_t,
+        hipLaunchKernelGGL((k_cholw_ld<false, false>), dim3(1), dim3(512), 0, st, n2, w.Rg, n2, w.Tt + off, n, w.Gam1, n2, info_t,
                            n1, 0, (const double*)nullptr, 0, 0);
     int rc = chk("k_cholw_ld");
     if (rc) return rc;
@@ -1160,7 +1226,7 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         // A' = I + Rg J Rg^T, then its plain factorisation T -- the accept / revert test.  (Round 4: the three n x n products of
         // this chain run on the generic MFMA block kernel of gsmvi_smallgemm.h, 64 workgroups each; the VALU dot-product
         // kernel k_gsmf_small_a (14.4 us) and the 16-workgroup k_gsmf_gemm128 (16.5 + 13 us) they replace were deleted.)
-        small_gemm_launch(st, OpSmallA{n, n, n, w.Rg, info_g, w.Ap, B, jmode});
+        small_gemm_launch(st, OpSmallA{n, n, n, w.Rg, info_g, w.Ap, B, jmode, n});
         hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n, w.Ap, w.Tt, n, info_t, 0);
         if ((rc = chk("k_chol128"))) return rc;
         double* Pmat = w.Ap;                       // A' is dead once T exists

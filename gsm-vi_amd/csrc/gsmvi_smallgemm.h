@@ -89,12 +89,24 @@ struct OpBlkR12 {                                  // R[0:n1, n1:n] = D' W11 A12
     const double *W, *A;
     double* R;
     int ldw, lda, ldr, n1;
+    // early first block (factor-form BaM: [Gamma11 | I] -> [R11 | W11] was factored beside k_bam_cholw into compact buffers):
+    // W above is that W11 (ldw), Rsrc that R11 (ldrs); this launch also copies both into the n x n matrices (R, Wdst)
+    const double* Rsrc;
+    int ldrs;
+    double* Wdst;
+    int ldwd;
     __device__ bool skip() const { return false; }
     __device__ double a(int i, int k) const { return W[(size_t)i * ldw + k]; }
     __device__ double b(int k, int j) const { return A[(size_t)k * lda + n1 + j]; }
     __device__ void store(int i, int j, double v) const {
-        R[(size_t)i * ldr + n1 + j] = (R[(size_t)i * ldr + i] == 0.0) ? 0.0 : v;
+        const double rii = Rsrc ? Rsrc[(size_t)i * ldrs + i] : R[(size_t)i * ldr + i];
+        R[(size_t)i * ldr + n1 + j] = (rii == 0.0) ? 0.0 : v;
         R[(size_t)(n1 + j) * ldr + i] = 0.0;       // the block below the diagonal: the factor is read as a full matrix
+        if (Rsrc)
+            for (int jj = j; jj < n1; jj += p) {
+                R[(size_t)i * ldr + jj] = Rsrc[(size_t)i * ldrs + jj];
+                Wdst[(size_t)i * ldwd + jj] = W[(size_t)i * ldw + jj];
+            }
     }
 };
 struct OpBlkS22 {                                  // S22 = A22 (diagonal lowered by its rounding floor when semidef) - R12^T R12
@@ -142,21 +154,21 @@ struct OpBlkW21 {                                  // W[n1:n, 0:n1] = -T1 W11; a
 // ---- the n x n products of the 2B x 2B chain, 64 < n <= 256 -----------------------------------------------------------------
 struct OpSmallA {                                  // A' = I + (Rg J) Rg^T;  J = (1/B) [[0, I], [I, -I]] or, jmode, diag(I, -I) unscaled
     static constexpr bool A_KMAJOR = true, B_KMAJOR = true;   // which index the SOURCE of a(i, k) / b(k, j) is contiguous in
-    int m, p, K;                                   // n, n, n
-    const double* Rg;
+    int m, p, K;                                   // n, n, n -- or n1, n1, n: the leading block A'11 alone (it needs only the
+    const double* Rg;                              // first block row of Rg; the two-level chain factors it early)
     const int* info_g;
     double* Ap;
-    int B, jmode;
+    int B, jmode, ld;                              // ld: leading dimension of Rg and A' (n)
     __device__ bool skip() const { return false; }
     __device__ double a(int i, int k) const {
-        if (jmode) return (k < B) ? Rg[(size_t)i * m + k] : -Rg[(size_t)i * m + k];
-        return (k < B) ? Rg[(size_t)i * m + B + k] : (Rg[(size_t)i * m + k - B] - Rg[(size_t)i * m + k]);
+        if (jmode) return (k < B) ? Rg[(size_t)i * ld + k] : -Rg[(size_t)i * ld + k];
+        return (k < B) ? Rg[(size_t)i * ld + B + k] : (Rg[(size_t)i * ld + k - B] - Rg[(size_t)i * ld + k]);
     }
-    __device__ double b(int k, int j) const { return Rg[(size_t)j * m + k]; }
+    __device__ double b(int k, int j) const { return Rg[(size_t)j * ld + k]; }
     __device__ void store(int i, int j, double v) const {
         double x = (i == j ? 1.0 : 0.0) + (jmode ? v : v / (double)B);
         if (*info_g != 0) x = (i == j) ? -1.0 : 0.0;  // Gamma was singular: force the PD test to fail
-        Ap[(size_t)i * m + j] = x;
+        Ap[(size_t)i * ld + j] = x;
     }
 };
 struct OpChainP {                                  // P = (T - I)(W S), with the chain's accept / revert decision

@@ -284,6 +284,45 @@ def test_factor_form_update_equals_the_dense_update(D, B, reg):
     assert rel_err(mu_f.cpu().numpy(), mu_def) < (1e-8 if reg <= 1.0 else 1e-7)   # S gbar from the factors: ||S|| ||gbar|| >> result
 
 
+@pytest.mark.parametrize("D,B", [(1024, 128), (1024, 96), (512, 100), (256, 65)])
+def test_paired_chain_launches_equal_the_sequential_chain(D, B):
+    """Two-level 2B x 2B chain (64 < B <= 128): with the "chain_pair" knob (default) Gamma11 = Vw Vw^T is factored as the
+    second workgroup of k_bam_cholw's launch and A'11 beside Gamma's second block (k_cholw_pair); with the knob off every
+    one-workgroup factorisation has its own launch.  Same algebra, same block split: (mu, F) agree to rounding of the one
+    different input (Gamma11 summed from the early Gram slabs), F^T F to 1e-11; run-to-run bit-identical either way; a
+    non-finite score reverts either way.  The GSM chain (no early block) pairs A'11 only."""
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    mu0, F0, Z, X, G = _factor_state(eng, D, B, seed=D + 3 * B)
+    dv = [eng.asarray(a) for a in (Z, X, G, mu0, F0)]
+    res = {}
+    try:
+        for pair in (1, 0):
+            eng.set_tuning("chain_pair", pair)
+            n_rev = eng.new_flag()
+            eng.bam_factor_update(*dv, 1.0)          # settles the Newton-Schulz step-count hint for THIS problem (a stale
+            mu, F, flag = eng.bam_factor_update(*dv, 1.0, n_reverts=n_rev)   # hint moves steps into the tail kernel: other rounding)
+            assert eng.read_flag(flag) == 0 and eng.read_flag(n_rev) == 0
+            Fn, mun = F.cpu().numpy(), mu.cpu().numpy()
+            for _ in range(50):                      # the paired workgroups share nothing: run-to-run bit-identical
+                mu2, F2, _ = eng.bam_factor_update(*dv, 1.0)
+                assert np.array_equal(F2.cpu().numpy(), Fn) and np.array_equal(mu2.cpu().numpy(), mun)
+            gm, gF, gflag = eng.gsm_factor_update(*dv)
+            assert eng.read_flag(gflag) == 0
+            Gn = G.copy()
+            Gn[B // 2, 3] = np.nan
+            mu3, F3, flag3 = eng.bam_factor_update(dv[0], dv[1], eng.asarray(Gn), dv[3], dv[4], 1.0, n_reverts=n_rev)
+            assert eng.read_flag(flag3) != 0 and eng.read_flag(n_rev) == 1
+            assert np.array_equal(mu3.cpu().numpy(), mu0) and np.array_equal(F3.cpu().numpy(), F0)
+            res[pair] = (mu.cpu().numpy(), F.cpu().numpy(), gm.cpu().numpy(), gF.cpu().numpy())
+    finally:
+        eng.set_tuning("chain_pair", 1)
+    for k in (0, 2):
+        assert rel_err(res[1][k], res[0][k]) < 1e-11
+    for k in (1, 3):
+        assert rel_err(res[1][k].T @ res[1][k], res[0][k].T @ res[0][k]) < 1e-11
+
+
 def test_factor_form_update_reverts_and_bounds():
     """A non-finite score poisons the small chain: flag = 1, (mu, F) = (mu0, F0), the revert is counted; batches beyond
     2B <= min(D, 256) are refused before anything is enqueued."""
