@@ -1118,7 +1118,9 @@ int gsmvi_factor_apply_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const 
 static int factor_chain_big(gsmvi_ctx* ctx, hipStream_t st, int n, int B, const factor_ws& w, const double* Gp, int kcg,
                             int jmode, const int* prior, int* info_dev) {
     // block split: 128 + (n - 128); the factor-form BaM chain (jmode, 64 < B <= 128) splits at B -- its first diagonal block
-    // Gamma11 = Vw Vw^T is then known before the B x B chain and may have been factored beside it (ctx->early_ready)
+    // Gamma11 = Vw Vw^T is then known before the B x B chain and may have been factored beside it (ctx->early_ready).
+    // (The same scheme on 64-row blocks for 64 < n <= 128 was measured and dropped: 14 launches instead of 6 cost more than
+    // the shorter pivot chains save -- c5 317 us against 288, profiles/r04/c4_pair_ab.txt.)
     const int n1 = jmode ? B : 128, n2 = n - n1;
     int* info_g = ctx->ints;
     int* info_t = ctx->ints + 1;
@@ -1128,6 +1130,15 @@ static int factor_chain_big(gsmvi_ctx* ctx, hipStream_t st, int n, int B, const 
     ctx->early_ready = 0;
     // paired launches (round 4): both diagonal blocks on the 128-row kernel, and the knob on
     const bool pair = ctx->tune_chain_pair && n1 > 64 && n2 > 64;
+    // one diagonal block [A | I] -> [R | W] in its own launch
+    auto cholw = [&](bool semidef, int nb, const double* A, int lda, double* R, int ldr, double* Wo, int ldw, int* info, int ioff,
+                     int tol, const double* dg) {
+        const int dgn = dg ? n : 0, dgs = dg ? n + 1 : 0;
+#define CW(SD, BG) hipLaunchKernelGGL((k_cholw_ld<SD, BG>), dim3(1), dim3(512), 0, st, nb, A, lda, R, ldr, Wo, ldw, info, ioff, tol, dg, dgn, dgs)
+        if (semidef) { if (nb > 64) CW(true, true); else CW(true, false); }
+        else { if (nb > 64) CW(false, true); else CW(false, false); }
+#undef CW
+    };
     hipLaunchKernelGGL(k_gsmf_gamma_big, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, w.Gam, coef, coef + n, jmode);
     // Gamma = Rg^T Rg (rank-revealing rule), W = Rg^-T -> w.Pm
     if (early) {
@@ -1137,12 +1148,7 @@ static int factor_chain_big(gsmvi_ctx* ctx, hipStream_t st, int n, int B, const 
         const double* W11 = ctx->early + 2 * 128 * 128;
         small_gemm_launch(st, OpBlkR12{n1, n2, n1, W11, w.Gam, w.Rg, n1, n, n, n1, R11, n1, w.Pm, n});
     } else {
-        if (n1 > 64)
-            hipLaunchKernelGGL((k_cholw_ld<true, true>), dim3(1), dim3(512), 0, st, n1, w.Gam, n, w.Rg, n, w.Pm, n, info_g, 0, 0,
-                               w.Gam, n, n + 1);
-        else
-            hipLaunchKernelGGL((k_cholw_ld<true, false>), dim3(1), dim3(512), 0, st, n1, w.Gam, n, w.Rg, n, w.Pm, n, info_g, 0, 0,
-                               w.Gam, n, n + 1);
+        cholw(true, n1, w.Gam, n, w.Rg, n, w.Pm, n, info_g, 0, 0, w.Gam);
         small_gemm_launch(st, OpBlkR12{n1, n2, n1, w.Pm, w.Gam, w.Rg, n, n, n, n1});
     }
     // slots while Gamma is factored: S22 and T1 in Gam1 (free until the end of the chain); A'11 -> Ap, T11 -> Tt, T's inverse
@@ -1157,31 +1163,19 @@ static int factor_chain_big(gsmvi_ctx* ctx, hipStream_t st, int n, int B, const 
         const cholw_job ja{n2, S22g, n2, w.Rg + off, n, w.Pm + off, n, info_g, n1, 1, w.Gam, n, n + 1};
         const cholw_job jb{n1, w.Ap, n, w.Tt, n, Wt, n1, info_t, 0, 0, nullptr, 0, 0};
         hipLaunchKernelGGL(k_cholw_pair, dim3(2), dim3(512), 0, st, ja, jb);
-    } else if (n2 > 64)
-        hipLaunchKernelGGL((k_cholw_ld<true, true>), dim3(1), dim3(512), 0, st, n2, S22g, n2, w.Rg + off, n, w.Pm + off, n, info_g,
-                           n1, 1, w.Gam, n, n + 1);
-    else
-        hipLaunchKernelGGL((k_cholw_ld<true, false>), dim3(1), dim3(512), 0, st, n2, S22g, n2, w.Rg + off, n, w.Pm + off, n, info_g,
-                           n1, 1, w.Gam, n, n + 1);
+    } else
+        cholw(true, n2, S22g, n2, w.Rg + off, n, w.Pm + off, n, info_g, n1, 1, w.Gam);
     small_gemm_launch(st, OpBlkT1{n2, n1, n2, w.Pm, w.Rg, T1g, n, n, n1});
     small_gemm_launch(st, OpBlkW21{n2, n1, n1, T1g, w.Pm, w.Rg, n, n, n1});
     // A' = I + Rg J Rg^T = T^T T (plain rule: this IS the accept test)
     small_gemm_launch(st, OpSmallA{n, n, n, w.Rg, info_g, w.Ap, B, jmode, n});
-    if (!pair) {
-        if (n1 > 64)
-            hipLaunchKernelGGL((k_cholw_ld<false, true>), dim3(1), dim3(512), 0, st, n1, w.Ap, n, w.Tt, n, Wt, n1, info_t, 0, 0,
-                               (const double*)nullptr, 0, 0);
-        else
-            hipLaunchKernelGGL((k_cholw_ld<false, false>), dim3(1), dim3(512), 0, st, n1, w.Ap, n, w.Tt, n, Wt, n1, info_t, 0, 0,
-                               (const double*)nullptr, 0, 0);
-    }
+    if (!pair) cholw(false, n1, w.Ap, n, w.Tt, n, Wt, n1, info_t, 0, 0, nullptr);
     small_gemm_launch(st, OpBlkR12{n1, n2, n1, Wt, w.Ap, w.Tt, n1, n, n, n1});
     small_gemm_launch(st, OpBlkS22{n2, n2, n1, w.Tt, w.Ap, w.Rg, n, n, n1, 0});
     if (n2 > 64)                                   // (the last block needs no inverse factor: the plain 128-row kernel, 32 us against 39)
         hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n2, w.Rg, w.Tt + off, n, info_t, n1);
     else
-        hipLaunchKernelGGL((k_cholw_ld<false, false>), dim3(1), dim3(512), 0, st, n2, w.Rg, n2, w.Tt + off, n, w.Gam1, n2, info_t,
-                           n1, 0, (const double*)nullptr, 0, 0);
+        cholw(false, n2, w.Rg, n2, w.Tt + off, n, w.Gam1, n2, info_t, n1, 0, nullptr);
     int rc = chk("k_cholw_ld");
     if (rc) return rc;
     // P = (T - I)(W S) with the accept / revert decision, K'' = (W S)^T P

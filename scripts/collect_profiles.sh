@@ -35,6 +35,7 @@ cd $ROOT
 python3 scripts/configs_bench.py $OUT/configs.json > $OUT/configs.log 2>&1
 python3 scripts/c4_update_bench.py > $OUT/c4_update.txt 2>&1
 python3 scripts/cov_p_ab.py > $OUT/cov_persistent_ab.txt 2>&1
+python3 scripts/c4_pair_ab.py > $OUT/c4_pair_ab.txt 2>&1
 python3 scripts/race_pipeline_check.py > $OUT/race_pipeline_check.txt 2>&1
 : > $OUT/chol64b_variants.txt
 for v in "" "-DCHOLB_TEST_REPLICA_DELAY=2" "-DCHOLB_TEST_FORCE_ORDER" "-DCHOLB_TEST_FORCE_ORDER -DCHOLB_TEST_OLD_WRITEBACK" "-DCHOLB_TEST_REPLICA_DELAY=2 -DCHOLB_TEST_OLD_WRITEBACK" "-DCHOLB_TEST_CORRUPT_REPLICA"; do
