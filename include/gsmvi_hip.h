@@ -70,7 +70,9 @@ int gsmvi_create(gsmvi_ctx** out, int device, int max_D, int max_B);
 int gsmvi_destroy(gsmvi_ctx* ctx);
 /* Launch-heuristic knobs for tests and A/B measurements: "panel_kc" (split-K count of the panel products; <= 0 = auto),
  * "no_fast" (1 = force the guarded generic kernels), "direct_out" (0 = always product + finish pass), "update_sb",
- * "scalars_nt", "bam_full", "bam_kenq"; diagnostics "timeline", "cov_dbg" (see gsmvi_hip_debug.h). */
+ * "scalars_nt", "bam_full", "bam_kenq", "rider", "wide", "wide_kc", "gram_mt", "fork_min_D", "potrf_split_m", "chain_pair"
+ * (0 = one launch per one-workgroup factorisation of the 128 < 2B <= 256 chain); diagnostics "timeline", "cov_dbg"
+ * (see gsmvi_hip_debug.h). */
 int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value);
 
 /*
