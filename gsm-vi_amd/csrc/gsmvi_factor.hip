@@ -1117,11 +1117,12 @@ int gsmvi_factor_apply_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const 
 // first block is used, for the block-row solve) in Gam1 and its S22 in Rg (both dead by then).  Returns K'' in w.Gam.
 static int factor_chain_big(gsmvi_ctx* ctx, hipStream_t st, int n, int B, const factor_ws& w, const double* Gp, int kcg,
                             int jmode, const int* prior, int* info_dev) {
-    // block split: 128 + (n - 128); the factor-form BaM chain (jmode, 64 < B <= 128) splits at B -- its first diagonal block
-    // Gamma11 = Vw Vw^T is then known before the B x B chain and may have been factored beside it (ctx->early_ready).
+    // block split: B + B (n = 2B, 64 < B <= 128: both diagonal blocks on the 128-row one-workgroup kernel, which is what lets
+    // independent ones share a launch).  In the factor-form BaM chain (jmode) the first diagonal block Gamma11 = Vw Vw^T is known
+    // before the B x B chain and may have been factored beside it (ctx->early_ready).
     // (The same scheme on 64-row blocks for 64 < n <= 128 was measured and dropped: 14 launches instead of 6 cost more than
     // the shorter pivot chains save -- c5 317 us against 288, profiles/r04/c4_pair_ab.txt.)
-    const int n1 = jmode ? B : 128, n2 = n - n1;
+    const int n1 = B, n2 = n - n1;
     int* info_g = ctx->ints;
     int* info_t = ctx->ints + 1;
     double* coef = w.coef;
@@ -1156,21 +1157,29 @@ static int factor_chain_big(gsmvi_ctx* ctx, hipStream_t st, int n, int B, const 
     double* S22g = w.Gam1;
     double* T1g = w.Gam1 + (size_t)n2 * n2;
     double* Wt = pair ? w.coef + (size_t)n * n / 2 : w.Gam1;   // n1 x n1, ld n1 (unpaired: Gam1 is free again by then)
-    small_gemm_launch(st, OpBlkS22{n2, n2, n1, w.Rg, w.Gam, S22g, n, n, n1, 1});
+    const OpBlkS22 op_s22g{n2, n2, n1, w.Rg, w.Gam, S22g, n, n, n1, 1};
+    const OpBlkT1 op_t1{n2, n1, n2, w.Pm, w.Rg, T1g, n, n, n1};
+    const OpBlkW21 op_w21{n2, n1, n1, T1g, w.Pm, w.Rg, n, n, n1};
+    const OpSmallA op_a{n, n, n, w.Rg, info_g, w.Ap, B, jmode, n};     // A' = I + Rg J Rg^T = T^T T (plain rule: this IS the accept test)
+    const OpBlkR12 op_r12t{n1, n2, n1, Wt, w.Ap, w.Tt, n1, n, n, n1};
     if (pair) {
-        // A'11 = I + (Rg J Rg^T)_11 needs only [R11 R12]: its factorisation runs beside Gamma's second block, one launch
-        small_gemm_launch(st, OpSmallA{n1, n1, n, w.Rg, info_g, w.Ap, B, jmode, n});
+        // A'11 = I + (Rg J Rg^T)_11 needs only [R11 R12]: its factorisation runs beside Gamma's second block, one launch.
+        // Independent PRODUCTS share launches too (k_small_gemm2): S22 with A'11, T1 with A', W21 with T's R12.
+        small_gemm_launch2(st, op_s22g, OpSmallA{n1, n1, n, w.Rg, info_g, w.Ap, B, jmode, n});
         const cholw_job ja{n2, S22g, n2, w.Rg + off, n, w.Pm + off, n, info_g, n1, 1, w.Gam, n, n + 1};
         const cholw_job jb{n1, w.Ap, n, w.Tt, n, Wt, n1, info_t, 0, 0, nullptr, 0, 0};
         hipLaunchKernelGGL(k_cholw_pair, dim3(2), dim3(512), 0, st, ja, jb);
-    } else
+        small_gemm_launch2(st, op_t1, op_a);
+        small_gemm_launch2(st, op_w21, op_r12t);
+    } else {
+        small_gemm_launch(st, op_s22g);
         cholw(true, n2, S22g, n2, w.Rg + off, n, w.Pm + off, n, info_g, n1, 1, w.Gam);
-    small_gemm_launch(st, OpBlkT1{n2, n1, n2, w.Pm, w.Rg, T1g, n, n, n1});
-    small_gemm_launch(st, OpBlkW21{n2, n1, n1, T1g, w.Pm, w.Rg, n, n, n1});
-    // A' = I + Rg J Rg^T = T^T T (plain rule: this IS the accept test)
-    small_gemm_launch(st, OpSmallA{n, n, n, w.Rg, info_g, w.Ap, B, jmode, n});
-    if (!pair) cholw(false, n1, w.Ap, n, w.Tt, n, Wt, n1, info_t, 0, 0, nullptr);
-    small_gemm_launch(st, OpBlkR12{n1, n2, n1, Wt, w.Ap, w.Tt, n1, n, n, n1});
+        small_gemm_launch(st, op_t1);
+        small_gemm_launch(st, op_w21);
+        small_gemm_launch(st, op_a);
+        cholw(false, n1, w.Ap, n, w.Tt, n, Wt, n1, info_t, 0, 0, nullptr);
+        small_gemm_launch(st, op_r12t);
+    }
     small_gemm_launch(st, OpBlkS22{n2, n2, n1, w.Tt, w.Ap, w.Rg, n, n, n1, 0});
     if (n2 > 64)                                   // (the last block needs no inverse factor: the plain 128-row kernel, 32 us against 39)
         hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n2, w.Rg, w.Tt + off, n, info_t, n1);

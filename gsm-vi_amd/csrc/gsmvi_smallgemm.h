@@ -11,15 +11,15 @@
 #pragma once
 #include "gsmvi_common.h"
 
+#define SMALLGEMM_SA 260                                     // LDS strides: A [16][260] (260 = 4 mod 32: conflict-free fragment reads),
+#define SMALLGEMM_SB 17                                      // B [k][17]
 template <class OP>
-__global__ __launch_bounds__(256) void k_small_gemm(OP op) {
-    constexpr int SA = 260, SB = 17, KMAX = 256;             // LDS strides: A [16][260] (260 = 4 mod 32: conflict-free fragment reads),
-    __shared__ double As[16 * SA], Bs[KMAX * SB];            // B [k][17]
-    __shared__ double red[4 * 256];
+__device__ __forceinline__ void small_gemm_block(const OP& op, int blk, double* As, double* Bs, double* red) {
+    constexpr int SA = SMALLGEMM_SA, SB = SMALLGEMM_SB;
     if (op.skip()) return;
     const int m = op.m, p = op.p, K = op.K;
     const int nbj = (p + 15) >> 4;
-    const int bi = blockIdx.x / nbj, bj = blockIdx.x - bi * nbj, i0 = 16 * bi, j0 = 16 * bj;
+    const int bi = blk / nbj, bj = blk - bi * nbj, i0 = 16 * bi, j0 = 16 * bj;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
     const int nk = (K + 3) >> 2;
     // ---- both operand tiles through LDS, loaded along the direction in which the SOURCE is contiguous (OP::A_KMAJOR /
@@ -73,9 +73,28 @@ __global__ __launch_bounds__(256) void k_small_gemm(OP op) {
 }
 
 template <class OP>
+__global__ __launch_bounds__(256) void k_small_gemm(OP op) {
+    __shared__ double As[16 * SMALLGEMM_SA], Bs[256 * SMALLGEMM_SB], red[4 * 256];
+    small_gemm_block(op, (int)blockIdx.x, As, Bs, red);
+}
+// two INDEPENDENT products in one launch (a dependent launch costs ~2 us before its first instruction: scripts/nsbench.hip):
+// workgroups [0, nblk1) run op1, the rest op2
+template <class OP1, class OP2>
+__global__ __launch_bounds__(256) void k_small_gemm2(OP1 op1, OP2 op2, int nblk1) {
+    __shared__ double As[16 * SMALLGEMM_SA], Bs[256 * SMALLGEMM_SB], red[4 * 256];
+    if ((int)blockIdx.x < nblk1) small_gemm_block(op1, (int)blockIdx.x, As, Bs, red);
+    else small_gemm_block(op2, (int)blockIdx.x - nblk1, As, Bs, red);
+}
+
+template <class OP>
 static inline void small_gemm_launch(hipStream_t st, const OP& op) {
     const int nbi = (op.m + 15) >> 4, nbj = (op.p + 15) >> 4;
     hipLaunchKernelGGL(k_small_gemm<OP>, dim3(nbi * nbj), dim3(256), 0, st, op);
+}
+template <class OP1, class OP2>
+static inline void small_gemm_launch2(hipStream_t st, const OP1& op1, const OP2& op2) {
+    const int n1 = ((op1.m + 15) >> 4) * ((op1.p + 15) >> 4), n2 = ((op2.m + 15) >> 4) * ((op2.p + 15) >> 4);
+    hipLaunchKernelGGL((k_small_gemm2<OP1, OP2>), dim3(n1 + n2), dim3(256), 0, st, op1, op2, n1);
 }
 
 // ---- two-level blocked Cholesky with the inverse factor, A = R^T R, W = R^-T, for an n x n matrix, 128 < n <= 256 -------------
