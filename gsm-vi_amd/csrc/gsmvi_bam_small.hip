@@ -13,11 +13,11 @@
 // the lower bound is KNOWN, the scaling c^2 = 3 / (1 + sqrt(l) + l) (Chen & Chow's scaled Newton-Schulz, written
 // for mu = sigma^2) is computed from a scalar recurrence alone: small eigenvalues grow ~6.75x per step instead of
 // 2.25x, 12-15 steps instead of ~27 at cond(A) ~ 1e7.  The recurrence (and hence the number of steps k*) depends
-// on s, which lives on the device: k_bam_ns_prep runs it once and stores c_k^2 and k*; the host enqueues the launches of
+// on s, which lives on the device: workgroup 0 of step 0 (k_bam_ns_step0) runs it once and stores c_k^2 and k*; the host enqueues the launches of
 // k* + 1 steps (k* of the previous call, a pinned word read without synchronising) and the ones beyond k* return at once;
 // k_bam_ns_tail makes up for a stale guess.  Two launches per step on many workgroups: M = Z Y, then Y' and Z' together
 // (one 16 x 16 block per workgroup, K split over its four waves, fp64 MFMA, operands straight from L2); the first M = Z0 Y0 = Y0
-// comes from k_bam_ns_prep.  Round 4 measured a ONE-launch step (every workgroup recomputing the 16-wide panel of M it needs,
+// is never materialised (k_bam_ns_step0).  Round 4 measured a ONE-launch step (every workgroup recomputing the 16-wide panel of M it needs,
 // rows of Z staged in LDS): 9.2 us against 2 x 4.55 us -- the n/16-fold recomputation costs what the second launch costs, so it
 // was not kept (profiles/r04/c4_chain_ab.txt).  Then, n <= 128: BB (symmetrised) and the factor-independent vectors on many
 // workgroups (k_bam_bbav), the Cholesky factorisation WITH the inverse factor in one workgroup (k_bam_cholw: chol64_blk /
@@ -36,52 +36,6 @@
 #define BAMS_KMAX 32                 // launches enqueued; k* <= BAMS_KMAX is checked on the device (else flagged)
 // coef layout (doubles): [0..KMAX) c_k^2, [40] k*, [41] s, [42] 1 if s is not finite or the bound did not close in KMAX steps
 // (KMAX = 32 scaled steps cover cond(A) up to ~1e20, beyond what fp64 can represent in N + I/4)
-
-// ---- s = trace(N + I/4) >= lambda_max, Y0 = (N + I/4)/s, Z0 = I (padded to BAMS_LD), the scaling recurrence -------
-// Every workgroup sums the diagonal itself (n loads) and fills its share of Y0 / Z0; workgroup 0 also runs the scalar
-// recurrence.  A NaN / inf anywhere in N needs no flag of its own: it propagates through the products into BB, where
-// k_bam_cholw rejects it.
-// Mm also receives Y0: the first step's M = Z0 Y0 = I Y0 is Y0 exactly, so the launch k_bam_ns_zy(k = 0) is not enqueued.
-__global__ __launch_bounds__(256) void k_bam_ns_prep(int n, int ld, const double* __restrict__ Nm, double* __restrict__ Y,
-                                                     double* __restrict__ Z, double* __restrict__ Mm,
-                                                     double* __restrict__ coef, int* __restrict__ hint_host) {
-    __shared__ double red[4];
-    const int tid = threadIdx.x;
-    double tr = 0.0;
-    for (int i = tid; i < n; i += 256) tr += Nm[(size_t)i * n + i] + 0.25;
-    tr = wave_sum(tr);
-    if ((tid & 63) == 0) red[tid >> 6] = tr;
-    __syncthreads();
-    const double s = (red[0] + red[1]) + (red[2] + red[3]);
-    const double sinv = 1.0 / s;
-    for (int e = blockIdx.x * 256 + tid; e < ld * ld; e += gridDim.x * 256) {
-        const int i = e / ld, j = e % ld;
-        const bool in = i < n && j < n;
-        const double v = in ? Nm[(size_t)i * n + j] + (i == j ? 0.25 : 0.0) : 0.0;
-        Y[e] = v * sinv;
-        Mm[e] = v * sinv;
-        Z[e] = (in && i == j) ? 1.0 : 0.0;
-    }
-    if (blockIdx.x == 0 && tid == 0) {
-        double l = 0.25 * sinv;                              // lower bound of the eigenvalues of Z Y (A >= I/4)
-        const bool s_ok = (s == s) && s > 0.0 && s < 1e300;
-        if (!(l > 0.0) || l > 1.0) l = 1.0;
-        int kstar = BAMS_KMAX + 1;
-        for (int k = 0; k < BAMS_KMAX; ++k) {
-            const double c2 = (l < 0.25) ? 3.0 / (1.0 + sqrt(l) + l) : 1.0;      // scale only while it pays
-            coef[k] = c2;
-            const double x = c2 * l;
-            l = x * (3.0 - x) * (3.0 - x) * 0.25;
-            if (l > 1.0) l = 1.0;
-            if (1.0 - l < 5e-9 && kstar > BAMS_KMAX) kstar = k + 2;              // e -> 0.75 e^2: one more step gives < 1e-16
-        }
-        coef[42] = (!s_ok || kstar > BAMS_KMAX) ? 1.0 : 0.0;  // cond(A) beyond ~1e12: not reachable in BAMS_KMAX steps
-        if (kstar > BAMS_KMAX) kstar = BAMS_KMAX;
-        coef[40] = (double)kstar;
-        coef[41] = s;
-        if (hint_host) *hint_host = kstar;                   // pinned host word: how many steps the NEXT call should enqueue
-    }
-}
 
 // ---- one 16 x 16 block per wave of  C = op(A) op(B)  on BAMS_LD x BAMS_LD matrices ----------------------------------
 //   MODE 0: C = A B      MODE 1: C = A T(B)      MODE 2: C = T(A) B,     T(M) = 1.5 I - 0.5 c2 M  applied on the fly.
@@ -127,6 +81,86 @@ __device__ __forceinline__ void bams_block(const double* __restrict__ A, const d
     Out[(size_t)(i0 + (t >> 4)) * ld + j0 + (t & 15)] = scale * v;
 }
 
+// ---- step 0 WITHOUT a launch in front of it (round 4): s, Y0 = (N + I/4)/s, Z0 = I and M0 = Z0 Y0 = Y0 are not materialised --
+// A preparation kernel used to write Y0, Z0 and M0 and run the scalar recurrence, then step 0 read them back: one dependent launch (2 us before
+// its first instruction + 1 us for its stores, scripts/nsbench.hip) for 3 ld^2 doubles nobody else reads.  Here every workgroup
+// of step 0 sums the diagonal itself (as the prep kernel's workgroups did), forms Y0 and T0 = 1.5 I - 0.5 c0^2 Y0 in its operand
+// loads, and Z1 = c0 T0 Z0 = c0 T0 is an elementwise write (the product T0 I adds exact zeros: same bits); workgroup 0 also runs
+// the recurrence and writes coef / the host hint for the launches behind it.  Same operations in the same order as
+// that pair of launches: bit-identical iterates.  s = trace(N + I/4) >= lambda_max is the scale (every workgroup can sum a
+// diagonal by itself); a NaN / inf anywhere in N needs no flag of its own: it propagates through the products into BB, where
+// k_bam_cholw rejects it.
+__global__ __launch_bounds__(256) void k_bam_ns_step0(int n, int ld, const double* __restrict__ Nm, double* __restrict__ Yo,
+                                                      double* __restrict__ Zo, double* __restrict__ coef,
+                                                      int* __restrict__ hint_host) {
+    __shared__ double red[4 * 256];
+    const int tid = threadIdx.x;
+    double tr = 0.0;
+    for (int i = tid; i < n; i += 256) tr += Nm[(size_t)i * n + i] + 0.25;
+    tr = wave_sum(tr);
+    if ((tid & 63) == 0) red[tid >> 6] = tr;
+    __syncthreads();
+    const double s = (red[0] + red[1]) + (red[2] + red[3]);
+    const double sinv = 1.0 / s;
+    __syncthreads();                                         // red is reused by the block reduction below
+    double l0 = 0.25 * sinv;                                 // lower bound of the eigenvalues of Z Y (A >= I/4)
+    if (!(l0 > 0.0) || l0 > 1.0) l0 = 1.0;
+    const double c2 = (l0 < 0.25) ? 3.0 / (1.0 + sqrt(l0) + l0) : 1.0, c = sqrt(c2);
+    if (blockIdx.x == 0 && tid == 0) {                       // the scaling recurrence
+        double l = l0;
+        const bool s_ok = (s == s) && s > 0.0 && s < 1e300;
+        int kstar = BAMS_KMAX + 1;
+        for (int k = 0; k < BAMS_KMAX; ++k) {
+            const double c2k = (l < 0.25) ? 3.0 / (1.0 + sqrt(l) + l) : 1.0;     // scale only while it pays
+            coef[k] = c2k;
+            const double x = c2k * l;
+            l = x * (3.0 - x) * (3.0 - x) * 0.25;
+            if (l > 1.0) l = 1.0;
+            if (1.0 - l < 5e-9 && kstar > BAMS_KMAX) kstar = k + 2;              // e -> 0.75 e^2: one more step gives < 1e-16
+        }
+        coef[42] = (!s_ok || kstar > BAMS_KMAX) ? 1.0 : 0.0;  // cond(A) beyond ~1e12: not reachable in BAMS_KMAX steps
+        if (kstar > BAMS_KMAX) kstar = BAMS_KMAX;
+        coef[40] = (double)kstar;
+        coef[41] = s;
+        if (hint_host) *hint_host = kstar;                   // pinned host word: how many steps the NEXT call should enqueue
+    }
+    const int nb = (n + 15) >> 4, nk = (n + 3) >> 2;
+    auto y0 = [&](int i, int k) { return (i < n && k < n) ? (Nm[(size_t)i * n + k] + (i == k ? 0.25 : 0.0)) * sinv : 0.0; };
+    if ((int)blockIdx.x >= nb * nb) {                        // Z1 = c0 T0 (Z0 = I), zero outside n x n
+        const int blk = blockIdx.x - nb * nb, i = (blk / nb) * 16 + (tid >> 4), j = (blk % nb) * 16 + (tid & 15);
+        const double t0 = (i == j ? 1.5 : 0.0) - 0.5 * c2 * y0(i, j);
+        Zo[(size_t)i * ld + j] = (i < n && j < n) ? c * t0 : 0.0;
+        return;
+    }
+    // Y1 = c0 Y0 T0: bams_block<1> with the operands formed from N (same batches, same accumulator chains, same reduction)
+    const int blk = blockIdx.x, i0 = (blk / nb) * 16, j0 = (blk % nb) * 16;
+    const int w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int u0 = 0; w + 4 * u0 < nk; u0 += 9) {
+        double a[9], b[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int st = w + 4 * (u0 + u);
+            const int k = 4 * st + ks;
+            const int kc = k < ld ? k : ld - 1;
+            a[u] = y0(i0 + cc, kc);
+            b[u] = (kc == j0 + cc ? 1.5 : 0.0) - 0.5 * c2 * y0(kc, j0 + cc);
+            if (st >= nk) { a[u] = 0.0; b[u] = 0.0; }
+        }
+#pragma unroll
+        for (int u = 0; u + 1 < 9; u += 2) {
+            acc0 = GSMVI_MFMA_F64(a[u], b[u], acc0);
+            acc1 = GSMVI_MFMA_F64(a[u + 1], b[u + 1], acc1);
+        }
+        acc0 = GSMVI_MFMA_F64(a[8], b[8], acc0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w * 256 + (ks + 4 * r) * 16 + cc] = acc0[r] + acc1[r];
+    __syncthreads();
+    const double v = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+    Yo[(size_t)(i0 + (tid >> 4)) * ld + j0 + (tid & 15)] = c * v;
+}
+
 // M = Z Y (the scaling enters through T in the step kernel)
 // (Round 4 tried dropping the early return -- operand loads issued before coef[40] is known, stores predicated: 4.70 / 5.05 us
 // per launch against 4.54 / 4.57 with it; kept.)
@@ -158,7 +192,7 @@ __global__ __launch_bounds__(256) void k_bam_ns_step(int n, int ld, int k, doubl
 
 // ---- safety net behind the enqueued steps --------------------------------------------------------------------------
 // The host enqueues kenq <= BAMS_KMAX multi-workgroup steps, guessed from the k* of the previous call (a pinned host
-// word written by k_bam_ns_prep: no synchronisation, possibly stale).  If this call's k* turns out larger, the missing
+// word written by k_bam_ns_step0: no synchronisation, possibly stale).  If this call's k* turns out larger, the missing
 // steps kenq .. k*-1 are executed HERE by one workgroup -- slow (one CU) but exact, so a stale guess costs time, never
 // correctness; normally the kernel returns at once.  Same products, same order, same ping-pong parity.
 template <int MODE>
@@ -504,7 +538,7 @@ __global__ __launch_bounds__(512) void k_bam_small48(int n, double reg, const do
     }
     if (w == 7) {
         // meanwhile, on the last wave: s = trace(N + I/4) = ||M1||_F^2 + trace(N0) + n/4 straight from the operands, and the
-        // scalar scaling recurrence (k_bam_ns_prep) -- ~120 ns per step of one lane, stopped at k*
+        // scalar scaling recurrence (as k_bam_ns_step0) -- ~120 ns per step of one lane, stopped at k*
         double tr = 0.0;
         if (l < n) {
             double t0 = Ms[l * BAMQ_LD + l] + 0.25, t1 = 0.0;
@@ -748,10 +782,11 @@ int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, co
         if (h > 0 && h + 1 < BAMS_KMAX) kenq = h + 1;
     }
     if (force_kenq > 0 && force_kenq < BAMS_KMAX) kenq = force_kenq;       // tests: exercise the safety net
-    hipLaunchKernelGGL(k_bam_ns_prep, dim3(27), dim3(256), 0, st, n, ld, Nd, Ya, Za, Mm, coef, hint_host);
     const int nb = (n + 15) / 16;
-    for (int k = 0; k < kenq; ++k) {                         // (k = 0: M = Z0 Y0 = Y0 came from k_bam_ns_prep)
-        if (k > 0) hipLaunchKernelGGL(k_bam_ns_zy, dim3(nb * nb), dim3(256), 0, st, n, ld, k, Ya, Za, Yb, Zb, Mm, coef);
+    // step 0 forms s, Y0, Z0 = I and M0 = Y0 in its own operand loads (k_bam_ns_step0): no preparation launch
+    hipLaunchKernelGGL(k_bam_ns_step0, dim3(2 * nb * nb), dim3(256), 0, st, n, ld, Nd, Yb, Zb, coef, hint_host);
+    for (int k = 1; k < kenq; ++k) {
+        hipLaunchKernelGGL(k_bam_ns_zy, dim3(nb * nb), dim3(256), 0, st, n, ld, k, Ya, Za, Yb, Zb, Mm, coef);
         hipLaunchKernelGGL(k_bam_ns_step, dim3(2 * nb * nb), dim3(256), 0, st, n, ld, k, Ya, Za, Yb, Zb, Mm, coef);
     }
     if (kenq < BAMS_KMAX)
