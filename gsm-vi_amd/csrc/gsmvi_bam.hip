@@ -885,7 +885,8 @@ int gsmvi_panel_t_product(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
                           int ldm, int mrows, double* Pp, int* kc_out);
 int gsmvi_factor_signed_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, int* kcg, int* info_dev, int* rides);
 int gsmvi_factor_signed_back(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, const double* mu0, const double* F0, int ldf0,
-                             double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, int kcg, int rides, int taken);
+                             double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, int kcg, int rides, int taken,
+                             int join);
 
 int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
                           const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double reg, double* mu,
@@ -957,12 +958,34 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     ctx->fo_Tm = Tm;
     ctx->fo_Fs = Fsf;
     int kcg = 1, rides = 0;
-    rc = gsmvi_factor_signed_gram(ctx, st, D, n, &kcg, info_dev, &rides);   // Gram slabs of [Vw; Zw]; the 2B x 2B chain rides in ...
-    if (!rc) rc = gsmvi_panel_product_out(ctx, st, D, D, n2 + 1, Ft, D, nullptr, 1.0, F0, ldf0, nullptr, Tm, D);   // ... this
-    const int taken = ctx->px_used;
-    ctx->px = gsmvi_panel_extras();
-    if (!rc)
-        rc = gsmvi_factor_signed_back(ctx, st, D, n, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, kcg, rides, taken);
+    // Large D, 64 < 2B <= 128 (the 2B x 2B chain is six small launches, ~115 us on a few CUs): the product Rt F0 (MFMA-bound,
+    // 92 us at D = 4096) depends on Ft only, so it runs on the context's second stream beside the Gram product and the chain and is
+    // joined in front of K'' Tm -- what the GSM factor update does with V Fm (gsmvi_factor.hip; same threshold: the two event
+    // edges cost ~10 us).  (4096, 64): 684 -> 595 us eager, 679 -> 654 replayed; (3072, 40): 523 -> 476.  Not for 2B > 128: there
+    // the 257-row product fills every CU for ~180 us and the chain's twenty small launches queue behind its workgroups (983 us
+    // against 971 at (4096, 128)).
+    const bool fork_tm = n2 > 64 && n2 <= 128 && ctx->side && ctx->tune_fork_min_D > 0 && D >= ctx->tune_fork_min_D && !ctx->tune_no_fast;
+    if (fork_tm) {
+        hipError_t fe = hipEventRecord(ctx->ev_fork, st);
+        if (fe == hipSuccess) fe = hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);
+        if (fe != hipSuccess) { gsmvi_set_error("%s: %s", "gsmvi_bam_factor_impl", "fork failed"); rc = GSMVI_ERR_HIP; }
+        if (!rc) rc = gsmvi_panel_product_out(ctx, ctx->side, D, D, n2 + 1, Ft, D, nullptr, 1.0, F0, ldf0, nullptr, Tm, D);
+        if (!rc && hipEventRecord(ctx->ev_join, ctx->side) != hipSuccess) {
+            gsmvi_set_error("%s: %s", "gsmvi_bam_factor_impl", "join failed");
+            rc = GSMVI_ERR_HIP;
+        }
+        if (!rc) rc = gsmvi_factor_signed_gram(ctx, st, D, n, &kcg, info_dev, &rides);
+        ctx->px = gsmvi_panel_extras();            // nothing rides in a panel launch here: the chain sums the Gram slabs itself
+        if (!rc)
+            rc = gsmvi_factor_signed_back(ctx, st, D, n, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, kcg, 0, 0, 1);
+    } else {
+        rc = gsmvi_factor_signed_gram(ctx, st, D, n, &kcg, info_dev, &rides);   // Gram slabs of [Vw; Zw]; the 2B x 2B chain rides in ...
+        if (!rc) rc = gsmvi_panel_product_out(ctx, st, D, D, n2 + 1, Ft, D, nullptr, 1.0, F0, ldf0, nullptr, Tm, D);   // ... this
+        const int taken = ctx->px_used;
+        ctx->px = gsmvi_panel_extras();
+        if (!rc)
+            rc = gsmvi_factor_signed_back(ctx, st, D, n, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, kcg, rides, taken, 0);
+    }
     ctx->fo_Rt = ctx->fo_Tm = ctx->fo_Fs = nullptr;
     if (rc) return rc;
     hipLaunchKernelGGL(k_bamf_commit, dim3((D + 255) / 256), dim3(256), 0, st, D, Tm + (size_t)n2 * D, mu0, xbar, reg, info_dev,

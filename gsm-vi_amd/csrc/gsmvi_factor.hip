@@ -1072,12 +1072,14 @@ int gsmvi_factor_signed_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, int*
     return GSMVI_OK;
 }
 // taken = ctx->px_used of the panel launch behind _gram: the chain has run (rides) / the Gram matrix is finished (side job)
+// join: the caller's Rt Fm product ran on the context's second stream (ctx->ev_join recorded there): waited for in front of K'' Tm
 int gsmvi_factor_signed_back(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, const double* mu0, const double* F0, int ldf0,
-                             double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, int kcg, int rides, int taken) {
+                             double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, int kcg, int rides, int taken,
+                             int join) {
     const factor_ws w = factor_carve(ctx, D, 2 * Bh);
     const int finished = !rides && taken && 2 * Bh <= 128;
     return factor_back(ctx, st, D, Bh, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, (kcg > 1 && finished) ? w.Gam1 : w.Gp,
-                       finished ? 1 : kcg, nullptr, 0, 1, (rides && taken) ? 1 : 0);
+                       finished ? 1 : kcg, nullptr, 0, 1, (rides && taken) ? 1 : 0, join ? 2 : 0);
 }
 
 // Batch-sharded form, stage 1: this rank's B_local samples -> records.

@@ -255,12 +255,13 @@ def _factor_state(eng, D, B, seed):
 
 @pytest.mark.parametrize("reg", [0.5, 20.0])
 @pytest.mark.parametrize("D,B", [(64, 8), (256, 16), (1024, 32), (1024, 64), (512, 7), (300, 20), (130, 33), (128, 1),
-                                 (96, 48), (1024, 128), (1024, 96), (512, 100), (256, 56), (300, 70)])
+                                 (96, 48), (1024, 128), (1024, 96), (512, 100), (256, 56), (300, 70), (3072, 40)])
 def test_factor_form_update_equals_the_dense_update(D, B, reg):
     """F^T F of the factor-form update = S of the dense update (jitter 0) on S0 = F0^T F0, same mean -- against the HIP dense
     path (<= 1e-9 at moderate reg), against the scipy restatement, and through the update's defining equation
     S U S + S = V (oracle-independent).  Sizes cover the one-workgroup 2B x 2B chain (2B = 16, 32, 64 with the folded
-    update kernel; ragged 2B = 14, 40, 66, 2), the 128-row chain (B = 64, 48) and D not a multiple of 64."""
+    update kernel; ragged 2B = 14, 40, 66, 2), the 128-row chain (B = 64, 48), D not a multiple of 64, and (3072, 40): the
+    product Rt F0 on the context's second stream beside the chain (D >= 3072, 2B > 64)."""
     import gsmvi_amd
     _, borc = _o()
     eng = gsmvi_amd.get_engine()
