@@ -14,8 +14,8 @@
 //                               rank-revealing rule dropped, which is what the riding columns of AUG = 2 would hold)
 //   A22' = A22 - R12^T R12,    [A22' | I] -> [R22 | W22]
 //   W21 = -(W22 R12^T) W11     (block inverse of a triangular matrix)
-// One workgroup, E1 [64][146] is used for both factorisations (R11, W11 go to global memory in between; W11 is read back
-// for the last product), B12 [64][66] holds R12, then W11.  Same dropped-row convention as k_gsmf_kmat_big's unit pivots.
+// One workgroup, E1 [64][146] is used for both factorisations (R11, W11 go to global memory in between; W11 also stays in
+// registers, 8 values per thread, for the last product), B12 [64][66] holds R12, then W11.  Same dropped-row convention as k_gsmf_kmat_big's unit pivots.
 // (A device function since round 4: k_chol128w of the factor path and k_bam_cholw of the dense BaM chain share it.  A, R, Wo
 // must not alias; A is read until the second factorisation starts.  sh_info: optional LDS word that receives the same value as
 // *info -- valid for the whole workgroup after the caller's next barrier.)
@@ -98,10 +98,13 @@ __device__ __forceinline__ void chol128w_core(double* E1, double* B12, double* s
     }
     __syncthreads();
     // R11, W11 out (and the two zero blocks); meanwhile the updated A22 in registers: upper 16 x 16 blocks, K = 64
-    for (int e = tid; e < 64 * 64; e += 512) {
-        const int i = e >> 6, j = e & 63;
+    double wkeep[8];                                                    // W11 stays in registers for the last product (round 4:
+#pragma unroll                                                          // it used to be read back from global memory, ~1.5 us)
+    for (int u = 0; u < 8; ++u) {
+        const int e = tid + 512 * u, i = e >> 6, j = e & 63;
+        wkeep[u] = (j <= i) ? E1[i * ES1 + 64 + j] : 0.0;
         R[(size_t)i * ldr + j] = (j >= i) ? E1[i * ES1 + j] : 0.0;
-        Wo[widx(i, j)] = (j <= i) ? E1[i * ES1 + 64 + j] : 0.0;
+        Wo[widx(i, j)] = wkeep[u];
         if (64 + j < n) Wo[widx(i, 64 + j)] = 0.0;                          // W12 = 0
         if (i < n2) R[(size_t)(64 + i) * ldr + j] = 0.0;                  // R21 = 0
     }
@@ -195,17 +198,11 @@ __device__ __forceinline__ void chol128w_core(double* E1, double* B12, double* s
 #pragma unroll
             for (int r = 0; r < 4; ++r) E1[(16 * ib + ks + 4 * r) * ES1 + 16 * jb + c] = t1[slot][r];
         }
-        // W11 back from global memory (written by this workgroup before two barriers) into B12
-        double v[8];
+        // W11 (kept in registers since it left E1) into B12
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = tid + 512 * u, i = e >> 6, j = e & 63;
-            v[u] = __builtin_nontemporal_load(Wo + widx(i, j));
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = tid + 512 * u, i = e >> 6, j = e & 63;
-            B12[i * BS + j] = v[u];
+            B12[i * BS + j] = wkeep[u];
         }
     }
     __syncthreads();
