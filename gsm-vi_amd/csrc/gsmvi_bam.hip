@@ -243,6 +243,9 @@ __global__ __launch_bounds__(256) void k_bam_nmat(int n, const double* __restric
 // product-form Z (k_bam_zw) reads M1 by columns itself.
 // ldp: row length of the slabs (n; 2n when the product also holds [.; Vw] Vw^T -- G11 then receives the finished Vw Vw^T, the
 // first diagonal block of the factor-form chain's Gram matrix, which is factored beside k_bam_cholw).
+// KCT: compile-time bound of the slab count (4 / 8 / GSMVI_MAX_KC): every entry costs KCT loads, so the bound matters -- with the
+// clamp-to-MAX_KC form 304 loads per lane were issued for kc = 8 (10.5 us at n = 128).
+template <int KCT>
 __global__ __launch_bounds__(256) void k_bam_nmat2(int n, int kc, const double* __restrict__ slabs, long long slab_stride, int ldp,
                                                    double* __restrict__ N0, double* __restrict__ M1,
                                                    double* __restrict__ Nm, double* __restrict__ G11) {
@@ -253,12 +256,12 @@ __global__ __launch_bounds__(256) void k_bam_nmat2(int n, int kc, const double* 
     const int ic = (i0 + cc) < n ? i0 + cc : n - 1, jc = (j0 + cc) < n ? j0 + cc : n - 1;
     const int nk = (n + 3) >> 2;
     auto slab_sum = [&](int r, int c) {                      // one finished entry: the kc slabs, all loads in one batch
-        double t[GSMVI_MAX_KC];
+        double t[KCT];
 #pragma unroll
-        for (int q = 0; q < GSMVI_MAX_KC; ++q) t[q] = slabs[(size_t)(q < kc ? q : kc - 1) * slab_stride + (size_t)r * ldp + c];
+        for (int q = 0; q < KCT; ++q) t[q] = slabs[(size_t)(q < kc ? q : kc - 1) * slab_stride + (size_t)r * ldp + c];
         double a = 0.0;
 #pragma unroll
-        for (int q = 0; q < GSMVI_MAX_KC; ++q) a += (q < kc) ? t[q] : 0.0;
+        for (int q = 0; q < KCT; ++q) a += (q < kc) ? t[q] : 0.0;
         return a;
     };
     const int t = threadIdx.x, i = i0 + (t >> 4), j = j0 + (t & 15);
@@ -762,6 +765,8 @@ __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, cons
 int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* Nd, const double* M1,
                            const double* N0, double* scratch, double* Ld, int* info_dev, int* hint_host, int force_kenq,
                            double* Rscr, const cholw_job* beside);
+int gsmvi_panel_t_product_few_slabs(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* A, int lda, const double* M,
+                                    int ldm, int mrows, double* Pp, int* kc_out);
 int gsmvi_bam_small_nmax();
 size_t gsmvi_bam_small_scratch_doubles(int n);
 int gsmvi_panel_t_product(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* A, int lda, const double* M,
@@ -770,6 +775,14 @@ int gsmvi_bam_small_fused_nmax();
 int gsmvi_bam_small_fused(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* slabs, int kc, int ldslab,
                           size_t slab_stride, double* M1, double* Ld, double* Upk, int* info_dev);
 
+#define BAM_NMAT2(KC, NBQ, N_, SL, STR, LDP, N0_, M1_, ND_, G11_)                                                        \
+    do {                                                                                                                \
+        if ((KC) <= 4)                                                                                                  \
+            hipLaunchKernelGGL(k_bam_nmat2<4>, dim3((NBQ) * (NBQ)), dim3(256), 0, st, N_, KC, SL, STR, LDP, N0_, M1_, ND_, G11_); \
+        else                                                                                                            \
+            hipLaunchKernelGGL(k_bam_nmat2<GSMVI_MAX_KC>, dim3((NBQ) * (NBQ)), dim3(256), 0, st, N_, KC, SL, STR, LDP, N0_, M1_, ND_, \
+                               G11_);                                                                                   \
+    } while (0)
 int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X, int ldx, const double* G,
                    int ldg, const double* mu0, const double* S0, int lds0, double reg, double jitter, double* mu,
                    double* S, int lds, int* info_dev) {
@@ -797,7 +810,10 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, P, D))) return rc;
     // M1 = Vf Qt^T and N0 = P Qt^T share the right operand; P and Vf (the first n rows of Ft) are adjacent in the workspace,
     // so both Gram matrices come from one 2n-row transposed panel product, finished into the adjacent [N0; M1]
-    if ((rc = gsmvi_panel_t_product(ctx, st, D, n2, P, D, Qt, D, n, ctx->pp, &kc))) return rc;
+    const bool fused48_d = n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full;
+    if (!fused48_d && n <= 128) {                  // k_bam_nmat2 sums the slabs in its operand loads: fewer slabs
+        if ((rc = gsmvi_panel_t_product_few_slabs(ctx, st, D, n2, P, D, Qt, D, n, ctx->pp, &kc))) return rc;
+    } else if ((rc = gsmvi_panel_t_product(ctx, st, D, n2, P, D, Qt, D, n, ctx->pp, &kc))) return rc;
     double* Nd = Ld + (size_t)n * n + 3 * n;       // n x n
     double* M1T = Nd + (size_t)n * n;              // n x n
     double* Upk = M1T + (size_t)n * n;             // n(n+1)/2: packed rows of L^T
@@ -823,8 +839,7 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
                            Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu);
     } else if (use_w) {
         const int nbq = (n + 15) / 16;
-        hipLaunchKernelGGL(k_bam_nmat2, dim3(nbq * nbq), dim3(256), 0, st, n, kc, ctx->pp, (long long)n2 * n, n, N0, M1, Nd,
-                           (double*)nullptr);
+        BAM_NMAT2(kc, nbq, n, ctx->pp, (long long)n2 * n, n, N0, M1, Nd, (double*)nullptr);
         if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_p, hint, ctx->tune_bam_kenq, M1T, nullptr)))
             return rc;
         // Z = W (P + M1^T Vf) by two chained MFMA products per 16 columns of D, the mean with it (Wt = (L^-1)^T sits in Ld's slot,
@@ -926,7 +941,9 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     ctx->early_ready = 0;
     const bool early = !fused48 && n > 64 && n <= 128 && ctx->tune_chain_pair && ctx->early;
     const int gcols = early ? n2 : n;
-    if ((rc = gsmvi_panel_t_product(ctx, st, D, n2, Wq, D, Wq, D, gcols, ctx->pp, &kc))) return rc;
+    if (!fused48 && n <= 128) {                    // k_bam_nmat2 sums the slabs in its operand loads: fewer slabs
+        if ((rc = gsmvi_panel_t_product_few_slabs(ctx, st, D, n2, Wq, D, Wq, D, gcols, ctx->pp, &kc))) return rc;
+    } else if ((rc = gsmvi_panel_t_product(ctx, st, D, n2, Wq, D, Wq, D, gcols, ctx->pp, &kc))) return rc;
     if (fused48) {
         if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, n, (size_t)n2 * n, M1, Ld, Upk, info_bam))) return rc;
         hipLaunchKernelGGL(k_bam_forward16, dim3((D + 15) / 16), dim3(256), 0, st, D, n, Wq, M1, Upk, Ldinv, Ldinv + n,
@@ -942,8 +959,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
         double* G11 = ctx->early;                  // n x n each, compact
         double* R11 = ctx->early + 128 * 128;
         double* W11 = ctx->early + 2 * 128 * 128;
-        hipLaunchKernelGGL(k_bam_nmat2, dim3(nbq * nbq), dim3(256), 0, st, n, kc, ctx->pp, (long long)n2 * gcols, gcols, N0, M1, Nd,
-                           early ? G11 : (double*)nullptr);
+        BAM_NMAT2(kc, nbq, n, ctx->pp, (long long)n2 * gcols, gcols, N0, M1, Nd, early ? G11 : (double*)nullptr);
         // (the magnitude guard of the rank-revealing rule sees this block's own diagonal: the second block's is not known yet)
         const cholw_job beside{n, G11, n, R11, n, W11, n, ctx->ints, 0, 0, nullptr, 0, 0};
         if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_bam,

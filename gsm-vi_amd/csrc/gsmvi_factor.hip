@@ -752,6 +752,7 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const doub
 
 // ---- 64 < n <= 128: Gamma = S Gamma1 S^T and the per-sample coefficients from the Gram slabs ---------------------------
 // 256 elements of Gamma per workgroup; every workgroup derives the B coefficient pairs itself (3 kcg loads per sample)
+template <int KCT>   // compile-time bound of the slab count: every entry of Gamma1 costs KCT loads
 __global__ __launch_bounds__(256) void k_gsmf_gamma_big(int n, int B, const double* __restrict__ Gp, int kcg,
                                                         double* __restrict__ Gam, double* __restrict__ coef,
                                                         double* __restrict__ ab, int jmode) {
@@ -759,12 +760,12 @@ __global__ __launch_bounds__(256) void k_gsmf_gamma_big(int n, int B, const doub
     const int tid = threadIdx.x;
     auto g1 = [&](int i, int q) {                      // one entry of Gamma1: the kcg slabs, all loads in one batch
         if (kcg == 1) return Gp[(size_t)i * n + q];    // block-uniform: the finished matrix
-        double t[GSMVI_MAX_KC];
+        double t[KCT];
 #pragma unroll
-        for (int kc = 0; kc < GSMVI_MAX_KC; ++kc) t[kc] = Gp[(size_t)(kc < kcg ? kc : kcg - 1) * n * n + (size_t)i * n + q];
+        for (int kc = 0; kc < KCT; ++kc) t[kc] = Gp[(size_t)(kc < kcg ? kc : kcg - 1) * n * n + (size_t)i * n + q];
         double a = 0.0;
 #pragma unroll
-        for (int kc = 0; kc < GSMVI_MAX_KC; ++kc) a += (kc < kcg) ? t[kc] : 0.0;
+        for (int kc = 0; kc < KCT; ++kc) a += (kc < kcg) ? t[kc] : 0.0;
         return a;
     };
     if (tid < B) {
@@ -825,6 +826,12 @@ static int gsmvi_panel_t_product_mt(gsmvi_ctx* ctx, hipStream_t st, int D, int B
 int gsmvi_panel_t_product(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* A, int lda, const double* M,
                           int ldm, int mrows, double* Pp, int* kc_out) {
     return gsmvi_panel_t_product_mt(ctx, st, D, B, A, lda, M, ldm, mrows, Pp, kc_out, 4);
+}
+// the same with 32-row blocks at most: half the split-K slabs at the same number of workgroups -- for consumers that sum the
+// slabs while they load their operands (k_bam_nmat2)
+int gsmvi_panel_t_product_few_slabs(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* A, int lda, const double* M,
+                                    int ldm, int mrows, double* Pp, int* kc_out) {
+    return gsmvi_panel_t_product_mt(ctx, st, D, B, A, lda, M, ldm, mrows, Pp, kc_out, ctx->tune_gram_mt >= 4 ? 4 : 2);
 }
 // mt_cap: largest row-block multiple (16 mt_cap rows per workgroup).  The chunk width is 256 columns for mt <= 2 and 128 for
 // mt = 4, so capping at 2 halves the number of split-K slabs a small product leaves behind (4 instead of 8 at D = 1024) at
@@ -1142,7 +1149,8 @@ static int factor_chain_big(gsmvi_ctx* ctx, hipStream_t st, int n, int B, const 
         else { if (nb > 64) CW(false, true); else CW(false, false); }
 #undef CW
     };
-    hipLaunchKernelGGL(k_gsmf_gamma_big, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, w.Gam, coef, coef + n, jmode);
+    if (kcg <= 4) hipLaunchKernelGGL(k_gsmf_gamma_big<4>, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, w.Gam, coef, coef + n, jmode);
+        else hipLaunchKernelGGL(k_gsmf_gamma_big<GSMVI_MAX_KC>, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, w.Gam, coef, coef + n, jmode);
     // Gamma = Rg^T Rg (rank-revealing rule), W = Rg^-T -> w.Pm
     if (early) {
         // [Gamma11 | I] -> [R11 | W11] ran as the second workgroup of k_bam_cholw's launch (compact, ld n1); the R12 product
@@ -1221,7 +1229,8 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         // 64 < n <= 128: Gamma, the two n x n Choleskys one workgroup each, W and K in their own kernels
         Kmat = w.Gam;                              // Gamma is dead once Rg exists
         double* Wm = w.Pm;
-        hipLaunchKernelGGL(k_gsmf_gamma_big, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, w.Gam, coef, coef + n, jmode);
+        if (kcg <= 4) hipLaunchKernelGGL(k_gsmf_gamma_big<4>, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, w.Gam, coef, coef + n, jmode);
+        else hipLaunchKernelGGL(k_gsmf_gamma_big<GSMVI_MAX_KC>, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, w.Gam, coef, coef + n, jmode);
         if (fork_vf == 1) {                        // V Fm on the second stream from here on: beside the one-workgroup kernels below
             if ((rc = factor_fork_vf(ctx, st, D, B, Rt, F0, ldf0, &kcv))) return rc;
             vf_slabs = ctx->pp;
