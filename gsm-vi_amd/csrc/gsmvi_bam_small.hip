@@ -246,6 +246,133 @@ __global__ __launch_bounds__(1024) void k_bam_ns_tail(int n, int ld, int kenq, d
     }
 }
 
+// ---- the whole iteration in ONE workgroup for n <= 64 (round 4) ------------------------------------------------------------------
+// Y, Z and M = Z Y fit in LDS together ([64][66] doubles each, 101 KB), so a 64 x 64 problem needs no launch per product: the
+// multi-workgroup form pays 2 launches x ~4.2 us per step whatever the size (scripts/nsbench.hip: n = 64 costs what n = 128
+// costs), 125 us for 15 steps; one CU does the three 64^3 products of a step in ~3.5 us.  Eight waves: M = Z Y two blocks per
+// wave; then waves 0-3 own a ROW panel of Y' = c Y T (its A fragments in registers, T from M in LDS) and waves 4-7 a COLUMN
+// panel of Z' = c T Z, so both are updated in place behind one barrier.  Same recurrence, same T, same product order (Y T and
+// T Z) as the multi-workgroup kernels; no step-count hint and no tail kernel: k* is known where the loop runs.  The final
+// iterate goes to the buffer its parity names (k_bam_bbav / k_bam_ns_bb read Y from (k* & 1) ? Yb : Ya), coef[40..42] as usual.
+__global__ __launch_bounds__(512) void k_bam_ns64(int n, int ld, const double* __restrict__ Nm, double* __restrict__ Ya,
+                                                  double* __restrict__ Yb, double* __restrict__ coef) {
+    constexpr int LS = 66;
+    __shared__ __attribute__((aligned(16))) double Ys[64 * LS], Zs[64 * LS], Ms[64 * LS];
+    __shared__ double red[8], cf[BAMS_KMAX + 4];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
+    double tr = 0.0;
+    if (tid < n) tr = Nm[(size_t)tid * n + tid] + 0.25;
+    tr = wave_sum(tr);
+    if (l == 0) red[w] = tr;
+    __syncthreads();
+    const double s = red[0];                                 // n <= 64: the diagonal lives in wave 0
+    const double sinv = 1.0 / s;
+    for (int e = tid; e < 64 * 64; e += 512) {
+        const int i = e >> 6, j = e & 63;
+        const bool in = i < n && j < n;
+        const double v = in ? (Nm[(size_t)i * n + j] + (i == j ? 0.25 : 0.0)) * sinv : 0.0;
+        Ys[i * LS + j] = v;
+        Ms[i * LS + j] = v;                                  // M0 = Z0 Y0 = Y0
+        Zs[i * LS + j] = (in && i == j) ? 1.0 : 0.0;
+    }
+    if (tid == 0) {                                          // the scaling recurrence (as k_bam_ns_step0)
+        double lq = 0.25 * sinv;
+        const bool s_ok = (s == s) && s > 0.0 && s < 1e300;
+        if (!(lq > 0.0) || lq > 1.0) lq = 1.0;
+        int kstar = BAMS_KMAX + 1;
+        for (int k = 0; k < BAMS_KMAX; ++k) {
+            const double c2k = (lq < 0.25) ? 3.0 / (1.0 + sqrt(lq) + lq) : 1.0;
+            cf[k] = c2k;
+            coef[k] = c2k;
+            const double x = c2k * lq;
+            lq = x * (3.0 - x) * (3.0 - x) * 0.25;
+            if (lq > 1.0) lq = 1.0;
+            if (1.0 - lq < 5e-9 && kstar > BAMS_KMAX) kstar = k + 2;
+        }
+        const double failed = (!s_ok || kstar > BAMS_KMAX) ? 1.0 : 0.0;
+        if (kstar > BAMS_KMAX) kstar = BAMS_KMAX;
+        cf[BAMS_KMAX] = (double)kstar;
+        cf[BAMS_KMAX + 1] = failed;
+        coef[40] = (double)kstar;
+        coef[41] = s;
+        coef[42] = failed;
+    }
+    __syncthreads();
+    const int kstar = (int)cf[BAMS_KMAX];
+    if (cf[BAMS_KMAX + 1] != 0.0) return;                    // flagged: k_bam_bbav poisons BB
+    for (int k = 0; k < kstar; ++k) {
+        const double c2 = cf[k], c = sqrt(c2);
+        if (k > 0) {                                         // M = Z Y: blocks (bi, 2 bjp), (bi, 2 bjp + 1)
+            const int bi = w >> 1, bj = 2 * (w & 1);
+            v4d m0 = {0.0, 0.0, 0.0, 0.0}, m1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                const double a = Zs[(16 * bi + cc) * LS + 4 * st + ks];
+                m0 = GSMVI_MFMA_F64(a, Ys[(4 * st + ks) * LS + 16 * bj + cc], m0);
+                m1 = GSMVI_MFMA_F64(a, Ys[(4 * st + ks) * LS + 16 * bj + 16 + cc], m1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Ms[(16 * bi + ks + 4 * r) * LS + 16 * bj + cc] = m0[r];
+                Ms[(16 * bi + ks + 4 * r) * LS + 16 * bj + 16 + cc] = m1[r];
+            }
+            __syncthreads();
+        }
+        v4d acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+        if (w < 4) {                                         // Y'(row panel w) = c Y T
+            double a[16];
+#pragma unroll
+            for (int st = 0; st < 16; ++st) a[st] = Ys[(16 * w + cc) * LS + 4 * st + ks];
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                const int kk = 4 * st + ks;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = 16 * q + cc;
+                    const double t = (kk == j ? 1.5 : 0.0) - 0.5 * c2 * Ms[kk * LS + j];
+                    acc[q] = GSMVI_MFMA_F64(a[st], t, acc[q]);
+                }
+            }
+        } else {                                             // Z'(column panel w - 4) = c T Z
+            const int cp = w - 4;
+            double b[16];
+#pragma unroll
+            for (int st = 0; st < 16; ++st) b[st] = Zs[(4 * st + ks) * LS + 16 * cp + cc];
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                const int kk = 4 * st + ks;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 16 * q + cc;
+                    const double t = (i == kk ? 1.5 : 0.0) - 0.5 * c2 * Ms[i * LS + kk];
+                    acc[q] = GSMVI_MFMA_F64(t, b[st], acc[q]);
+                }
+            }
+        }
+        __syncthreads();                                     // every read of Y, Z, M of this step is done
+        if (w < 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ys[(16 * w + ks + 4 * r) * LS + 16 * q + cc] = c * acc[q][r];
+        } else {
+            const int cp = w - 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Zs[(16 * q + ks + 4 * r) * LS + 16 * cp + cc] = c * acc[q][r];
+        }
+        __syncthreads();
+    }
+    double* Yo = (kstar & 1) ? Yb : Ya;
+    for (int e = tid; e < n * n; e += 512) {
+        const int i = e / n, j = e - i * n;
+        Yo[(size_t)i * ld + j] = Ys[i * LS + j];
+    }
+}
+
 // BB = N + I/2 + sqrt(s) sym(Y_final)   (n x n, row-major, ld n)
 __global__ __launch_bounds__(256) void k_bam_ns_bb(int n, int ld, const double* __restrict__ Nm, const double* __restrict__ Ya,
                                                    const double* __restrict__ Yb, const double* __restrict__ coef,
@@ -783,13 +910,18 @@ int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, co
     }
     if (force_kenq > 0 && force_kenq < BAMS_KMAX) kenq = force_kenq;       // tests: exercise the safety net
     const int nb = (n + 15) / 16;
+    const bool one_wg = n <= 64 && !ctx->tune_bam_full && force_kenq <= 0;   // the whole iteration in one workgroup (k_bam_ns64)
+    if (one_wg) {
+        hipLaunchKernelGGL(k_bam_ns64, dim3(1), dim3(512), 0, st, n, ld, Nd, Ya, Yb, coef);
+        kenq = 0;
+    } else
     // step 0 forms s, Y0, Z0 = I and M0 = Y0 in its own operand loads (k_bam_ns_step0): no preparation launch
     hipLaunchKernelGGL(k_bam_ns_step0, dim3(2 * nb * nb), dim3(256), 0, st, n, ld, Nd, Yb, Zb, coef, hint_host);
     for (int k = 1; k < kenq; ++k) {
         hipLaunchKernelGGL(k_bam_ns_zy, dim3(nb * nb), dim3(256), 0, st, n, ld, k, Ya, Za, Yb, Zb, Mm, coef);
         hipLaunchKernelGGL(k_bam_ns_step, dim3(2 * nb * nb), dim3(256), 0, st, n, ld, k, Ya, Za, Yb, Zb, Mm, coef);
     }
-    if (kenq < BAMS_KMAX)
+    if (!one_wg && kenq < BAMS_KMAX)
         hipLaunchKernelGGL(k_bam_ns_tail, dim3(1), dim3(1024), 0, st, n, ld, kenq, Ya, Za, Yb, Zb, Mm, coef);
     if (n <= BAMS_NMAX) {
         // BB and the factor-independent vectors [a | . | vg] behind W's slot, then the factorisation with the inverse factor
