@@ -607,7 +607,8 @@ __global__ __launch_bounds__(256) void k_gsmf_mean(int D, int B, const double* _
 // column -- 16 x 0.5 MFLOP at D = 1024, cheap beside a dependent launch.  Tile row 0 also writes the mean, workgroup 0 counts
 // the revert; *bad => F = F0, mu = mu0.
 // n = 2B may be smaller than N = 32 NP (n = 16, BASELINE config 2): rows and columns beyond n are loaded as zeros.
-template <int NP>
+// KCB: compile-time bound of the V Fm slab count (every 16-byte unit costs KCB loads).
+template <int NP, int KCB>
 __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const double* __restrict__ Rt,
                                                         const double* __restrict__ Kmat, const double* __restrict__ Tm,
                                                         const double* __restrict__ vf_slabs, int kcv,
@@ -653,13 +654,13 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const doub
             continue;
         }
         if (row >= B && vf_slabs != nullptr) {     // V Fm rows: sum of the kcv slabs (row is wave-uniform for B % 16 == 0)
-            v2d t[GSMVI_MAX_KC];
+            v2d t[KCB];
 #pragma unroll
-            for (int kq = 0; kq < GSMVI_MAX_KC; ++kq)
+            for (int kq = 0; kq < KCB; ++kq)
                 t[kq] = *reinterpret_cast<const v2d*>(vf_slabs + ((size_t)(kq < kcv ? kq : kcv - 1) * B + (row - B)) * D + J0 + c2);
             v2d a = {0.0, 0.0};
 #pragma unroll
-            for (int kq = 0; kq < GSMVI_MAX_KC; ++kq)
+            for (int kq = 0; kq < KCB; ++kq)
                 if (kq < kcv) { a.x += t[kq].x; a.y += t[kq].y; }
             gt[q] = a;
         } else {
@@ -1253,8 +1254,9 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         ldf % 2 == 0) {
         // n <= 64: the skinny product Fs = K'' Tm1 is folded into the update kernel (k_gsmf_update_fs): one launch less
         const int ntl = D / 64;
-#define UFS(NPV) hipLaunchKernelGGL(k_gsmf_update_fs<NPV>, dim3(ntl * ntl), dim3(512), 0, st, D, B, Rt, Kmat, Tm, vf_slabs, kcv, F0, ldf0, F, ldf, coef, mu0, mu, info_dev, n_reverts_dev)
-        if (n <= 32) UFS(1); else UFS(2);
+#define UFS(NPV, KCBV) hipLaunchKernelGGL((k_gsmf_update_fs<NPV, KCBV>), dim3(ntl * ntl), dim3(512), 0, st, D, B, Rt, Kmat, Tm, vf_slabs, kcv, F0, ldf0, F, ldf, coef, mu0, mu, info_dev, n_reverts_dev)
+        if (kcv <= 4) { if (n <= 32) UFS(1, 4); else UFS(2, 4); }
+        else { if (n <= 32) UFS(1, GSMVI_MAX_KC); else UFS(2, GSMVI_MAX_KC); }
 #undef UFS
         return chk("k_gsmf_update_fs");
     }
