@@ -110,18 +110,36 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
             // wave-uniform when msplit is a multiple of the wave's row count (it is for B % 16 == 0); rows come in steps of 4,
             // so ks >= ... holds for all s of this lane once it holds for s = 0
             const double* sp = px.msl + (size_t)((wave_in ? wbase : 0) + ks - px.msplit) * px.ldsl + j;
-            double t[NST][GSMVI_MAX_KC];
+            // (two compile-time bounds on the slab count, chosen block-uniformly: with the clamp to GSMVI_MAX_KC alone every
+            // entry cost 8 loads whatever the count)
+            if (px.kcm <= 4) {
+                double t[NST][4];
 #pragma unroll
-            for (int s = 0; s < NST; ++s)
+                for (int s = 0; s < NST; ++s)
 #pragma unroll
-                for (int q = 0; q < GSMVI_MAX_KC; ++q)
-                    t[s][q] = sp[(size_t)(q < px.kcm ? q : px.kcm - 1) * px.mstride + (size_t)(4 * s) * px.ldsl];
+                    for (int q = 0; q < 4; ++q)
+                        t[s][q] = sp[(size_t)(q < px.kcm ? q : px.kcm - 1) * px.mstride + (size_t)(4 * s) * px.ldsl];
 #pragma unroll
-            for (int s = 0; s < NST; ++s) {
-                double a = 0.0;
+                for (int s = 0; s < NST; ++s) {
+                    double a = 0.0;
 #pragma unroll
-                for (int q = 0; q < GSMVI_MAX_KC; ++q) a += (q < px.kcm) ? t[s][q] : 0.0;
-                m[s] = a;
+                    for (int q = 0; q < 4; ++q) a += (q < px.kcm) ? t[s][q] : 0.0;
+                    m[s] = a;
+                }
+            } else {
+                double t[NST][GSMVI_MAX_KC];
+#pragma unroll
+                for (int s = 0; s < NST; ++s)
+#pragma unroll
+                    for (int q = 0; q < GSMVI_MAX_KC; ++q)
+                        t[s][q] = sp[(size_t)(q < px.kcm ? q : px.kcm - 1) * px.mstride + (size_t)(4 * s) * px.ldsl];
+#pragma unroll
+                for (int s = 0; s < NST; ++s) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int q = 0; q < GSMVI_MAX_KC; ++q) a += (q < px.kcm) ? t[s][q] : 0.0;
+                    m[s] = a;
+                }
             }
             if (px.mfin != nullptr && blockIdx.z == 0 && wave_in) {
                 double* fp = px.mfin + (size_t)(wbase + ks - px.msplit) * px.ldfin + j;
