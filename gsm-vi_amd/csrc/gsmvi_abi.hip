@@ -40,7 +40,7 @@ bool gsmvi_launch_gsm_scalars_fast(hipStream_t st, hipEvent_t* ev, int D, int B,
                                    int ldrec, int nt, unsigned long long* stamps);
 bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, const double* rec, int ldrec,
                               const double* mu0, const double* S0, int lds0, double* S, int lds, double* mu_out,
-                              int dbg, unsigned long long* stamps);
+                              int dbg, unsigned long long* stamps, int num_cu);
 int gsmvi_panel_fast_chunk(int MT);
 int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                      int* info_dev);
@@ -329,6 +329,14 @@ int gsmvi_debug_workspace_ptr(gsmvi_ctx* ctx, int region, double** out) {
     return GSMVI_OK;
 }
 
+/* Which kernel families ran (GSMVI_PATH_* bits, include/gsmvi_hip.h) on this context since the last reset. */
+int gsmvi_last_path(gsmvi_ctx* ctx, unsigned* bits, int reset) {
+    BAD_ARG(!ctx || !bits, "NULL argument");
+    *bits = ctx->path;
+    if (reset) ctx->path = 0;
+    return GSMVI_OK;
+}
+
 int gsmvi_set_profiling(gsmvi_ctx* ctx, int on) {
     BAD_ARG(!ctx, "ctx is NULL");
     ctx->profiling = on ? 1 : 0;
@@ -365,8 +373,8 @@ int gsmvi_panel_product_out(gsmvi_ctx* ctx, hipStream_t st, int D, int ncols, in
     const int MT = nrows <= 16 ? 1 : (nrows <= 32 ? 2 : 4);
     const int zblocks = (nrows + 16 * MT - 1) / (16 * MT);
     const int a_vec_ok = (lda % 2 == 0) && aligned16(A);
-    const bool fast = !ctx->tune_no_fast && ctx->tune_direct_out && ncols % 16 == 0 && D % 64 == 0 && a_vec_ok &&
-                      (!shift || aligned16(shift));
+    const bool fast = !ctx->tune_no_fast && ctx->tune_direct_out && D % 2 == 0 && a_vec_ok &&
+                      (!shift || aligned16(shift)) && !(ctx->px.msl && D % 16 != 0);
     if (fast) {
         const int chw = gsmvi_panel_fast_chunk(MT);
         const int nchunks = (D + chw - 1) / chw;
@@ -387,6 +395,7 @@ int gsmvi_panel_product_out(gsmvi_ctx* ctx, hipStream_t st, int D, int ncols, in
                 ctx->px_used = 1;
                 gsmvi_launch_panel_fast(st, nullptr, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm,
                                         ctx->pp, cpw, ncols, ctx->timeline_stamps(0), Out, ldo, addvec, &px);
+                ctx->path |= GSMVI_PATH_PANEL_FAST;
                 return check_launch("k_panel_fast(out)");
             }
         }
@@ -405,10 +414,11 @@ int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D
     const int MT = nrows <= 16 ? 1 : (nrows <= 32 ? 2 : 4);
     const int zblocks = (nrows + 16 * MT - 1) / (16 * MT);
     const int a_vec_ok = (lda % 2 == 0) && aligned16(A);
-    const bool fast = !ctx->tune_no_fast && ncols % 16 == 0 && D % 64 == 0 && a_vec_ok && (!shift || aligned16(shift));
+    // any even inner dimension D and any ncols since round 5 (the kernel clamps); the slab-operand extra needs D % 16 == 0
+    const bool fast = !ctx->tune_no_fast && D % 2 == 0 && a_vec_ok && (!shift || aligned16(shift)) && !(ctx->px.msl && D % 16 != 0);
     // 64-row panels of a D-sized product are MFMA-bound: the 64 x 64-tile kernel (gsmvi_wide.hip).  Not with extras: those
     // launches (K'' Tm with slab-summed rows, side jobs, the rider) stay on the narrow kernel.
-    if (fast && MT == 4 && ctx->tune_wide && ncols % 64 == 0 && ncols >= 1024 && D >= 1024 && ldm % 2 == 0 && aligned16(M) &&
+    if (fast && MT == 4 && ctx->tune_wide && ncols % 64 == 0 && ncols >= 1024 && D >= 1024 && D % 64 == 0 && ldm % 2 == 0 && aligned16(M) &&
         !ctx->px.msl && !ctx->px.sj_src && !ctx->px.rd_on) {
         int kcw = 1, kper = D;
         gsmvi_panel_wide_split(D, (ncols / 64) * zblocks, ctx->num_cu, ctx->tune_wide_kc, &kcw, &kper);
@@ -416,6 +426,7 @@ int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D
         ctx->px = gsmvi_panel_extras();
         ctx->px_used = 1;
         gsmvi_launch_panel_wide(st, ev, false, D, nrows, A, lda, shift, alpha, M, ldm, Pp, kper, kcw, ncols);
+        ctx->path |= GSMVI_PATH_PANEL_WIDE;
         return check_launch("k_panel_wide");
     }
     const int chw = fast ? gsmvi_panel_fast_chunk(MT) : 256;       // rows of M per chunk
@@ -434,8 +445,10 @@ int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D
     if (fast) {
         gsmvi_launch_panel_fast(st, ev, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm, Pp,
                                 cpw, ncols, ctx->timeline_stamps(0), nullptr, 0, nullptr, &px);
+        ctx->path |= GSMVI_PATH_PANEL_FAST;
         return check_launch("k_panel_fast");
     }
+    ctx->path |= GSMVI_PATH_PANEL_GENERIC;
     gsmvi_launch_panel_partial(st, ev, MT, dim3(strips, kc, zblocks), D, ncols, nrows, A, lda, shift, alpha, M,
                                ldm, Pp, cpw, a_vec_ok);
     return check_launch("k_panel_partial");
@@ -496,8 +509,12 @@ static int gsm_apply(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, const double*
         gsmvi_launch_gsm_cov_sym(hs, ctx->stage_events(2), D, B, rec, ldrec, mu0, S0, lds0, S, lds, mu,
                                  ctx->tune_cov_dbg,
                                  ctx->timeline_stamps(2) ? ctx->timeline_stamps(2) :
-                                 (ctx->tune_cov_dbg & 16) ? reinterpret_cast<unsigned long long*>(ctx->pp) : nullptr))
+                                 (ctx->tune_cov_dbg & 16) ? reinterpret_cast<unsigned long long*>(ctx->pp) : nullptr,
+                                 ctx->num_cu)) {
+        ctx->path |= GSMVI_PATH_COV_SYM;
         return check_launch("k_gsm_cov_sym");
+    }
+    ctx->path |= GSMVI_PATH_COV_GENERIC;
     int SB = ctx->tune_update_sb > 0 ? ctx->tune_update_sb : ((B + 1) & ~1);
     if (SB > 64) SB = 64;
     SB = (SB + 1) & ~1;
@@ -511,8 +528,11 @@ static int gsm_records(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, int kc, con
                        const double* G, int ldg, const double* mu0, const double* Pp, double* rec, int ldrec) {
     if (!ctx->tune_no_fast && D <= 8192 &&
         gsmvi_launch_gsm_scalars_fast(hs, ctx->stage_events(1), D, B, kc, X, ldx, G, ldg, mu0, Pp, rec, ldrec,
-                                      ctx->tune_scalars_nt, ctx->timeline_stamps(1)))
+                                      ctx->tune_scalars_nt, ctx->timeline_stamps(1))) {
+        ctx->path |= GSMVI_PATH_SCALARS_FAST;
         return check_launch("k_gsm_scalars_fast");
+    }
+    ctx->path |= GSMVI_PATH_SCALARS_GENERIC;
     gsmvi_launch_gsm_scalars(hs, ctx->stage_events(1), D, B, kc, X, ldx, G, ldg, mu0, Pp, rec, ldrec);
     return check_launch("k_gsm_scalars");
 }
@@ -553,6 +573,7 @@ int gsmvi_gsm_update_general_f64(gsmvi_ctx* ctx, void* stream, int D, int B, con
     int SB = (B + 1) & ~1;
     if (SB > 64) SB = 64;
     const int s_vec_ok = (lds0 % 2 == 0) && (lds % 2 == 0) && aligned16(S0) && aligned16(S);
+    ctx->path |= GSMVI_PATH_COV_GENERIC;
     gsmvi_launch_gsm_cov_update(hs, nullptr, D, B, ctx->sg, ldrec, mu0, S0, lds0, S, lds, mu, SB, s_vec_ok, 0, D);
     return check_launch("k_gsm_cov_update(general)");
 }
@@ -619,6 +640,7 @@ int gsmvi_gsm_apply_rows_f64(gsmvi_ctx* ctx, void* stream, int D, int B, int row
     if (SB > 64) SB = 64;
     SB = (SB + 1) & ~1;
     const int s_vec_ok = (lds0 % 2 == 0) && (lds % 2 == 0) && aligned16(S0rows) && aligned16(Srows);
+    ctx->path |= GSMVI_PATH_COV_GENERIC;           // (the row-block kernel is the guarded one: a shard's rows need no mirror tiles)
     gsmvi_launch_gsm_cov_update(hs, ctx->stage_events(2), D, B, rec, ldrec, mu0, S0rows, lds0, Srows, lds, mu, SB,
                                 s_vec_ok, row0, nrows);
     return check_launch("k_gsm_cov_update(rows)");

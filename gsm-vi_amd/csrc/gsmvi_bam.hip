@@ -856,6 +856,7 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
 #undef BFW
     }
     const int nt = (D + 63) / 64;
+    ctx->path |= (!ctx->tune_no_fast && D % 64 == 0 && n2 <= 288) ? GSMVI_PATH_LOWRANK_FAST : GSMVI_PATH_LOWRANK_GENERIC;
     if (!ctx->tune_no_fast && D % 64 == 0 && n2 <= 288) {
         if (n2 <= 96)
             hipLaunchKernelGGL(k_lowrank_update_fast<3>, dim3(nt * nt), dim3(512), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds, jitter);

@@ -141,7 +141,8 @@ __global__ __launch_bounds__(512) void k_panel_t_fast(int D, int nrows, const do
                 ok = ok && gr < nrows;
                 src = A + (size_t)(gr < nrows ? gr : nrows - 1) * lda + colc;
             } else {
-                src = M + (size_t)(j0 + row - NR) * ldm + colc;            // mrows % 16 == 0: all 16 rows exist
+                const int gj = j0 + row - NR;                              // (any mrows, round 5: a row beyond the matrix is a clamped
+                src = M + (size_t)(gj < mrows ? gj : mrows - 1) * ldm + colc;   // re-read; it only feeds output columns that are not stored)
             }
             const v2d v = *reinterpret_cast<const v2d*>(src);
             st[q] = ok ? v : (v2d){0.0, 0.0};
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(512) void k_panel_t_fast(int D, int nrows, const do
     for (int idx = tid; idx < NR * 16; idx += 512) {
         const int rr = idx >> 4, cc = idx & 15;
         const int row = r0 + rr;
-        if (row < nrows) {
+        if (row < nrows && j0 + cc < mrows) {
             double s = 0.0;
 #pragma unroll
             for (int ww = 0; ww < 8; ww += 2) s += red[(ww * NR + rr) * 17 + cc] + red[((ww + 1) * NR + rr) * 17 + cc];
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(256) void k_gsmf_update(int D, int KF, const double
             }
 }
 
-// ---- fast rank-n update (D % 64 == 0, n = 32 NP): F = F0 + Rt^T Fs, the new mean, the revert passthrough ---
+// ---- fast rank-n update (D % 64 == 0, any even n <= 32 NP): F = F0 + Rt^T Fs, the new mean, the revert passthrough ---
 // One 512-thread workgroup per 64 x 64 tile (two waves per SIMD for the fp64 MFMA rate); wave w owns the
 // 16-row block w >> 1 and the two 16-column blocks of half w & 1.  Every global load of the workgroup -- the F0
 // tile in accumulator layout and all n rows of both operand tiles -- is issued in one batch; the operand rows
@@ -499,14 +500,20 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const do
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
         for (int r = 0; r < 4; ++r) f0[blk][r] = F0[(frow + 4 * r) * ldf0 + fcol + 16 * blk];
+    // (any n = 2B <= 32 NP, round 5: rows beyond n are clamped re-reads, zeroed when they are staged; a pass whose rows
+    // all lie beyond n is skipped -- np is block-uniform)
+    const int n = 2 * B, np = (n + KP - 1) / KP;
     v2d ga[NP][2], gb[NP][2];
 #pragma unroll
     for (int p = 0; p < NP; ++p)
+        if (p < np) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int u = q * 512 + tid, row = u >> 5, c2 = 2 * (u & 31);
-            ga[p][q] = *reinterpret_cast<const v2d*>(Rt + (size_t)(KP * p + row) * D + I0 + c2);
-            gb[p][q] = *reinterpret_cast<const v2d*>(Fs + (size_t)(KP * p + row) * D + J0 + c2);
+            for (int q = 0; q < 2; ++q) {
+                const int u = q * 512 + tid, row = KP * p + (u >> 5), c2 = 2 * (u & 31);
+                const int rc = row < n ? row : n - 1;
+                ga[p][q] = *reinterpret_cast<const v2d*>(Rt + (size_t)rc * D + I0 + c2);
+                gb[p][q] = *reinterpret_cast<const v2d*>(Fs + (size_t)rc * D + J0 + c2);
+            }
         }
     const int skip = *bad;
     double msum = 0.0;
@@ -518,27 +525,30 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const do
     v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        if (p > 0) __syncthreads();
+        if (p < np) {
+            if (p > 0) __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int u = q * 512 + tid, row = u >> 5, c2 = 2 * (u & 31);
-            *reinterpret_cast<v2d*>(sm + row * RS + c2) = ga[p][q];
-            *reinterpret_cast<v2d*>(sm + (KP + row) * RS + c2) = gb[p][q];
-        }
-        __syncthreads();
-        double a[8], b0[8], b1[8];
-        const double* ap = sm + ks * RS + 16 * wr + c;
-        const double* bp = sm + (KP + ks) * RS + 32 * wc + c;
+            for (int q = 0; q < 2; ++q) {
+                const int u = q * 512 + tid, row = u >> 5, c2 = 2 * (u & 31);
+                const bool in = KP * p + row < n;
+                *reinterpret_cast<v2d*>(sm + row * RS + c2) = in ? ga[p][q] : (v2d){0.0, 0.0};
+                *reinterpret_cast<v2d*>(sm + (KP + row) * RS + c2) = in ? gb[p][q] : (v2d){0.0, 0.0};
+            }
+            __syncthreads();
+            double a[8], b0[8], b1[8];
+            const double* ap = sm + ks * RS + 16 * wr + c;
+            const double* bp = sm + (KP + ks) * RS + 32 * wc + c;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            a[s] = ap[4 * s * RS];
-            b0[s] = bp[4 * s * RS];
-            b1[s] = bp[4 * s * RS + 16];
-        }
+            for (int s = 0; s < 8; ++s) {
+                a[s] = ap[4 * s * RS];
+                b0[s] = bp[4 * s * RS];
+                b1[s] = bp[4 * s * RS + 16];
+            }
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            acc0 = GSMVI_MFMA_F64(a[s], b0[s], acc0);
-            acc1 = GSMVI_MFMA_F64(a[s], b1[s], acc1);
+            for (int s = 0; s < 8; ++s) {
+                acc0 = GSMVI_MFMA_F64(a[s], b0[s], acc0);
+                acc1 = GSMVI_MFMA_F64(a[s], b1[s], acc1);
+            }
         }
     }
 #pragma unroll
@@ -842,7 +852,7 @@ static int gsmvi_panel_t_product_mt(gsmvi_ctx* ctx, hipStream_t st, int D, int B
     int MT = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
     if (MT > mt_cap) MT = mt_cap;
     const int CH = (MT == 4) ? 128 : 256;
-    const bool fast_t = !ctx->tune_no_fast && D % 64 == 0 && mrows % 16 == 0 && lda % 2 == 0 && ldm % 2 == 0 &&
+    const bool fast_t = !ctx->tune_no_fast && D % 64 == 0 && lda % 2 == 0 && ldm % 2 == 0 &&
                         (reinterpret_cast<uintptr_t>(A) & 15u) == 0 && (reinterpret_cast<uintptr_t>(M) & 15u) == 0;
     if (fast_t && MT == 4 && ctx->tune_wide && mrows % 64 == 0 && mrows >= 1024 && D >= 1024) {
         // 64-row panels of a D-sized product are MFMA-bound: the 64 x 64-tile kernel (gsmvi_wide.hip)
@@ -850,6 +860,7 @@ static int gsmvi_panel_t_product_mt(gsmvi_ctx* ctx, hipStream_t st, int D, int B
         gsmvi_panel_wide_split(D, (mrows / 64) * ((B + 63) / 64), ctx->num_cu, ctx->tune_wide_kc, &kcw, &kper);
         *kc_out = kcw;
         gsmvi_launch_panel_wide(st, nullptr, true, D, B, A, lda, nullptr, 1.0, M, ldm, Pp, kper, kcw, mrows);
+        ctx->path |= GSMVI_PATH_PANEL_WIDE;
         return chk("k_panel_wide");
     }
     const int strips = (mrows + 15) / 16, nchunks = (D + CH - 1) / CH, zb = (B + 16 * MT - 1) / (16 * MT);
@@ -861,6 +872,7 @@ static int gsmvi_panel_t_product_mt(gsmvi_ctx* ctx, hipStream_t st, int D, int B
     kc = (nchunks + cpw - 1) / cpw;
     *kc_out = kc;
     const dim3 grid(strips, kc, zb);
+    ctx->path |= fast_t ? GSMVI_PATH_PANEL_T_FAST : GSMVI_PATH_PANEL_T_GENERIC;
     if (fast_t) {
         if (MT == 1) hipLaunchKernelGGL((k_panel_t_fast<1, 256>), grid, dim3(512), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
         else if (MT == 2) hipLaunchKernelGGL((k_panel_t_fast<2, 256>), grid, dim3(512), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
@@ -982,7 +994,9 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
     // kernel with the skinny product folded in; n = 128: the fast panel kernel of Fs = K'' Tm1), the V Fm product keeps its
     // slabs and carries the finish of the Gram slabs as a side job of its workgroups (the one-workgroup chain kernel would
     // pull them through a single CU: measured +5.6 us).  Otherwise: product + finish launches, as before.
-    const bool lean = !ctx->tune_no_fast && ctx->tune_direct_out && (n % 64 == 0 || n == 32 || n == 16) && n <= 128 && D % 64 == 0 &&
+    // (any batch size since round 5: n <= 64 always; 64 < n <= 128 when B % 16 == 0 -- the K'' Tm product takes its V Fm rows
+    // from split-K slabs per wave, and a wave's 16 rows must lie on one side of row B)
+    const bool lean = !ctx->tune_no_fast && ctx->tune_direct_out && (n <= 64 || (n <= 128 && B % 16 == 0)) && D % 64 == 0 &&
                       ldf0 % 2 == 0 && ldf % 2 == 0 && (reinterpret_cast<uintptr_t>(F0) & 15u) == 0;
     // Large D, n = 128: the V Fm product (MFMA-bound, 65 us at D = 4096) does not depend on the Gram product and the eight small
     // launches of the 2B x 2B chain (~100 us on a few CUs), so it runs on the context's second stream beside them; the two
@@ -1250,8 +1264,8 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         small_gemm_launch(st, OpChainK{n, n, n, Wm, Pmat, coef + n, Kmat, B, info_dev});
         if ((rc = chk("k_small_gemm"))) return rc;
     }
-    if (!ctx->tune_no_fast && ctx->tune_direct_out && D % 64 == 0 && (n == 16 || n == 32 || n == 64) && ldf0 % 2 == 0 &&
-        ldf % 2 == 0) {
+    if (!ctx->tune_no_fast && ctx->tune_direct_out && D % 64 == 0 && n <= 64 && ldf0 % 2 == 0 && ldf % 2 == 0) {
+        ctx->path |= GSMVI_PATH_FUPD_FAST;
         // n <= 64: the skinny product Fs = K'' Tm1 is folded into the update kernel (k_gsmf_update_fs): one launch less
         const int ntl = D / 64;
 #define UFS(NPV, KCBV) hipLaunchKernelGGL((k_gsmf_update_fs<NPV, KCBV>), dim3(ntl * ntl), dim3(512), 0, st, D, B, Rt, Kmat, Tm, vf_slabs, kcv, F0, ldf0, F, ldf, coef, mu0, mu, info_dev, n_reverts_dev)
@@ -1284,13 +1298,15 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         return GSMVI_ERR_UNSUPPORTED;
     }
     const int nt = (D + 63) / 64;
-    if (!ctx->tune_no_fast && D % 64 == 0 && (n == 32 || n == 64 || n == 128 || n == 256)) {
-        // the fast kernel also writes the mean and counts the revert
+    if (!ctx->tune_no_fast && D % 64 == 0 && n <= 256 && ldf0 >= D && ldf >= D) {
+        // the fast kernel also writes the mean and counts the revert (any even n <= 256 since round 5)
 #define UF(NPV) hipLaunchKernelGGL(k_gsmf_update_fast<NPV>, dim3(nt * nt), dim3(512), 0, st, D, B, Rt, Fs, F0, ldf0, F, ldf, Tm, coef, mu0, mu, info_dev, n_reverts_dev)
-        if (n == 32) UF(1); else if (n == 64) UF(2); else if (n == 128) UF(4); else UF(8);
+        if (n <= 32) UF(1); else if (n <= 64) UF(2); else if (n <= 128) UF(4); else UF(8);
 #undef UF
+        ctx->path |= GSMVI_PATH_FUPD_FAST;
         return chk("k_gsmf_update_fast");
     }
+    ctx->path |= GSMVI_PATH_FUPD_GENERIC;
     hipLaunchKernelGGL(k_gsmf_mean, dim3((D + 255) / 256), dim3(256), 0, st, D, B, Tm, coef, mu0, mu, info_dev, n_reverts_dev);
     if ((rc = chk("k_gsmf_mean"))) return rc;
     hipLaunchKernelGGL(k_gsmf_update, dim3(nt * nt), dim3(256), 0, st, D, n, Rt, Fs, F0, ldf0, F, ldf, info_dev);

@@ -30,8 +30,9 @@
 // A[:, 256 rows] (16*MT x 256 doubles) is loaded by the whole workgroup with fully coalesced 16-B
 // accesses and staged in LDS ([row][258]: conflict-free ds_read_b64 for the MFMA A operand), because
 // fragment-shaped loads of it touch 64 cache lines per instruction.
-// D % 64 == 0: a wave's 32 rows are all inside or all outside the matrix.  M has ncols columns (a multiple of
-// 16; ncols = D for the square matrices, 2B for the factor path's Gram product); slabs are nrows x ncols.
+// Any even D (round 5; D % 64 == 0 until round 4): the one wave whose rows straddle row D re-reads row D - 1 for the rows
+// beyond it (the A chunk is staged with zeros there).  M has ncols columns (any; ncols = D for the square matrices);
+// slabs are nrows x ncols.
 // =====================================================================================
 // EXTRA = true adds the two optional pieces of gsmvi_panel_extras (gsmvi_ctx.h): right-operand rows taken from split-K slabs
 // of a previous product (summed while they are loaded, so that product needs no finish launch), and a slab-summing side
@@ -72,7 +73,10 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
         return;
     }
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
-    const int j = blockIdx.x * 16 + c;
+    // (round 5: any even D and any ncols -- a column beyond the matrix is a clamped re-read whose result is not stored, a
+    // row of M beyond D is a clamped re-read multiplied by the zeros the A chunk is staged with beyond D)
+    const int jx = blockIdx.x * 16 + c;
+    const int j = jx < ncols ? jx : ncols - 1;
     const int r0 = blockIdx.z * NR;
 
     v4d acc[MT];
@@ -109,6 +113,7 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
         if (EXTRA && px.msl != nullptr && (wave_in ? wbase : 0) + ks >= px.msplit) {
             // wave-uniform when msplit is a multiple of the wave's row count (it is for B % 16 == 0); rows come in steps of 4,
             // so ks >= ... holds for all s of this lane once it holds for s = 0
+            // (D % 16 == 0 on this path: the callers' K'' Tm product has D = 2B with B % 16 == 0)
             const double* sp = px.msl + (size_t)((wave_in ? wbase : 0) + ks - px.msplit) * px.ldsl + j;
             // (two compile-time bounds on the slab count, chosen block-uniformly: with the clamp to GSMVI_MAX_KC alone every
             // entry cost 8 loads whatever the count)
@@ -146,10 +151,16 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
 #pragma unroll
                 for (int s = 0; s < NST; ++s) fp[(size_t)(4 * s) * px.ldfin] = m[s];
             }
-        } else {
+        } else if (wbase + RW <= D || !wave_in) {  // wave-uniform: all RW rows of this wave exist (or none: the values are unused)
             const double* mp = M + (size_t)((wave_in ? wbase : 0) + ks) * ldm + j;
 #pragma unroll
             for (int s = 0; s < NST; ++s) m[s] = mp[(size_t)(4 * s) * ldm];
+        } else {                                   // the wave that straddles row D (D % RW != 0): clamped rows
+#pragma unroll
+            for (int s = 0; s < NST; ++s) {
+                const int r = wbase + ks + 4 * s;
+                m[s] = M[(size_t)(r < D ? r : D - 1) * ldm + j];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (ch > 0) __syncthreads();       // previous chunk's MFMA reads of As are done
@@ -194,7 +205,7 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
     for (int idx = tid; idx < NR * 16; idx += 512) {
         const int rr = idx >> 4, cc = idx & 15;
         const int row = r0 + rr;
-        if (row < nrows) {
+        if (row < nrows && (int)blockIdx.x * 16 + cc < ncols) {
             double s = 0.0;
 #pragma unroll
             for (int ww = 0; ww < 8; ww += 2) s += red[(ww * NR + rr) * 17 + cc] + red[((ww + 1) * NR + rr) * 17 + cc];
@@ -316,7 +327,7 @@ __global__ __launch_bounds__(NT) void k_gsm_scalars_fast(int D, int B, int KC, c
 // The workgroup whose first tile is diagonal also writes mu = mu0 + mean_b dmu_b.
 // =====================================================================================
 template <int SB>
-__global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __restrict__ rec, int ldrec,
+__global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, int B, double invB, const double* __restrict__ rec, int ldrec,
                                                      const double* __restrict__ mu0,
                                                      const double* __restrict__ S0, int lds0,
                                                      double* __restrict__ S, int lds,
@@ -372,7 +383,6 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
     const int t = w >> 2;                        // which tile this wave computes (two waves per SIMD)
     const int wr = (w >> 1) & 1, wc = w & 1;
-    constexpr double invB = 1.0 / (double)SB;
     const bool mine = (t == 0) || two;           // does this wave's tile exist
 
     // ---- every global load of this workgroup, in one batch --------------------------------
@@ -398,14 +408,21 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
         // the 16 single-tile workgroups (they share a CU with a two-tile one) neither load nor stage a second column
         // block, and their waves 4-7 issue no MFMA: 32 instead of 64 MFMAs per SIMD on those CUs (they were the
         // kernel's 0.9 us tail: profiles/r02/timeline_cold_three_launch.txt).  tile is wave-uniform.
-        stg[q] = (two || tile < 4) ? *reinterpret_cast<const v2d*>(rec + (size_t)b * ldrec + (tile & 1) * D + colbase + c2)
+        // (any B <= SB: sample rows b >= B do not exist -- the address is clamped and the unit is zeroed at staging time,
+        // so that no use of a loaded value sits between the loads)
+        stg[q] = (two || tile < 4) ? *reinterpret_cast<const v2d*>(rec + (size_t)(b < B ? b : B - 1) * ldrec + (tile & 1) * D + colbase + c2)
                                    : (v2d){0.0, 0.0};
     }
     double dmu_part = 0.0;
     if (diag && tid < 256) {                     // dmu tile for the new mean: column = tid & 31, samples tid>>5 + 8k
+        double dv[SB / 8];
 #pragma unroll
-        for (int k = 0; k < SB / 8; ++k)
-            dmu_part += rec[(size_t)((tid >> 5) + 8 * k) * ldrec + 2 * D + I0 + (tid & 31)];
+        for (int k = 0; k < SB / 8; ++k) {
+            const int b = (tid >> 5) + 8 * k;
+            dv[k] = rec[(size_t)(b < B ? b : B - 1) * ldrec + 2 * D + I0 + (tid & 31)];
+        }
+#pragma unroll
+        for (int k = 0; k < SB / 8; ++k) dmu_part += ((tid >> 5) + 8 * k < B) ? dv[k] : 0.0;
     }
     if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(1); }
 
@@ -422,7 +439,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
             const int tile = g / NU, u = g % NU;
             const int b = u >> 4;
             if (b / SBP == pass && (two || tile < 4))
-                *reinterpret_cast<v2d*>(smem + tile * TILE + (b % SBP) * RS + 2 * (u & 15)) = stg[q];
+                *reinterpret_cast<v2d*>(smem + tile * TILE + (b % SBP) * RS + 2 * (u & 15)) = (b < B) ? stg[q] : (v2d){0.0, 0.0};
         }
         __syncthreads();
         if (pass == 0) STAMP(2);
@@ -512,7 +529,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, const double* __rest
 // share the in-order vmcnt counter: the next iteration waits for the loads only, the stores behind them stay in flight).
 // =====================================================================================
 template <int SB>
-__global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, const double* __restrict__ rec, int ldrec,
+__global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, int B, double invB, const double* __restrict__ rec, int ldrec,
                                                        const double* __restrict__ mu0,
                                                        const double* __restrict__ S0, int lds0,
                                                        double* __restrict__ S, int lds,
@@ -538,7 +555,6 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, const double* __re
     const int t = w >> 2;
     const int wr = (w >> 1) & 1, wc = w & 1;
     const int tl = tid & 255;
-    constexpr double invB = 1.0 / (double)SB;
 
     struct Item { int ti, tj0; bool two; };
     // incremental decode of the two-tile items (row ti holds (nt - ti) >> 1 of them): the scan continues where the last one stopped
@@ -580,15 +596,17 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, const double* __re
             const int tile = g / NU, u = g % NU;
             const int b = u >> 4, c2 = 2 * (u & 15);
             const int colbase = (tile < 2) ? I0 : (J0 + ((tile >= 4 && it.two) ? 32 : 0));
-            stg[q] = (it.two || tile < 4) ? *reinterpret_cast<const v2d*>(rec + (size_t)b * ldrec + (tile & 1) * D + colbase + c2)
+            stg[q] = (it.two || tile < 4) ? *reinterpret_cast<const v2d*>(rec + (size_t)(b < B ? b : B - 1) * ldrec + (tile & 1) * D + colbase + c2)
                                           : (v2d){0.0, 0.0};
         }
 #pragma unroll
         for (int k = 0; k < SB / 8; ++k) dmu[k] = 0.0;
         if (it.tj0 == it.ti && tid < 256) {
 #pragma unroll
-            for (int k = 0; k < SB / 8; ++k)
-                dmu[k] = rec[(size_t)((tid >> 5) + 8 * k) * ldrec + 2 * D + I0 + (tid & 31)];
+            for (int k = 0; k < SB / 8; ++k) {
+                const int b = (tid >> 5) + 8 * k;
+                dmu[k] = rec[(size_t)(b < B ? b : B - 1) * ldrec + 2 * D + I0 + (tid & 31)];
+            }
         }
     };
     int item = blockIdx.x;
@@ -617,7 +635,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, const double* __re
                 const int tile = g / NU, u = g % NU;
                 const int b = u >> 4;
                 if (b / SBP == pass && (two || tile < 4))
-                    *reinterpret_cast<v2d*>(smem + tile * TILE + (b % SBP) * RS + 2 * (u & 15)) = stg[q];
+                    *reinterpret_cast<v2d*>(smem + tile * TILE + (b % SBP) * RS + 2 * (u & 15)) = (b < B) ? stg[q] : (v2d){0.0, 0.0};
             }
             LDS_BARRIER();
             if (pass == NPASS - 1 && nxt < n_items) {        // the staging registers are free: the next item's loads go out now
@@ -680,7 +698,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, const double* __re
             if (tid < 256) {
                 double dsum = 0.0;
 #pragma unroll
-                for (int k = 0; k < SB / 8; ++k) dsum += dmuv[k];
+                for (int k = 0; k < SB / 8; ++k) dsum += ((tid >> 5) + 8 * k < B) ? dmuv[k] : 0.0;
                 smem[tid] = dsum;
             }
             LDS_BARRIER();
@@ -767,31 +785,34 @@ static int cov_sym_grid(int nt) {
 
 bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, const double* rec, int ldrec,
                               const double* mu0, const double* S0, int lds0, double* S, int lds, double* mu_out,
-                              int dbg, unsigned long long* stamps) {
+                              int dbg, unsigned long long* stamps, int num_cu) {
+    // Any batch size up to 128 (round 5): the kernel is instantiated for SB = 16, 32, 64, 128 staged sample rows and takes the
+    // actual B and 1/B at run time -- rows b >= B are staged as zeros (they add nothing to either accumulator chain), so
+    // B = 20 runs the SB = 32 instance at the speed of B = 32.  (Until round 4: B in {16, 32, 64} only, everything else fell to
+    // the guarded kernel of gsmvi_kernels.hip.)
+    if (B < 1 || B > 128) return false;
+    const int SB = B <= 16 ? 16 : (B <= 32 ? 32 : (B <= 64 ? 64 : 128));
+    const double invB = 1.0 / (double)B;
     // large D: the persistent form (2 resident workgroups per CU walk the item list, the next item's loads in flight during
     // the current item's MFMAs and stores); "cov_dbg" bit 512 keeps the one-item-per-workgroup kernel for A/B runs
     const int n_items = cov_sym_grid(D / 32);
-    if (n_items >= 2048 && B <= 32 && !stamps && dbg == 0) {    // (B = 64: two staging passes, MFMA-bound -- the one-item kernel is faster there)
-        const dim3 pgrid(512);
-#define CSP(SBV) GSMVI_LAUNCH(k_gsm_cov_sym_p<SBV>, pgrid, dim3(512), 0, st, ev, D, rec, ldrec, mu0, S0, lds0, S, lds, mu_out)
-        switch (B) {
-            case 16: CSP(16); return true;
-            case 32: CSP(32); return true;
-            case 64: CSP(64); return true;
-            default: return false;
-        }
+    if (n_items >= 2048 && SB <= 32 && !stamps && dbg == 0) {    // (B = 64: two staging passes, MFMA-bound -- the one-item kernel is faster there)
+        const dim3 pgrid(2 * (num_cu > 0 ? num_cu : 256));       // two resident workgroups per CU of THIS device (a partitioned device has fewer)
+#define CSP(SBV) GSMVI_LAUNCH(k_gsm_cov_sym_p<SBV>, pgrid, dim3(512), 0, st, ev, D, B, invB, rec, ldrec, mu0, S0, lds0, S, lds, mu_out)
+        if (SB == 16) CSP(16); else CSP(32);
+        return true;
 #undef CSP
     }
     if (dbg & 512) dbg &= ~512;
     const dim3 grid(cov_sym_grid(D / 32));
 #define CS(SBV)                                                                                             \
-    GSMVI_LAUNCH(k_gsm_cov_sym<SBV>, grid, dim3(512), 0, st, ev, D, rec, ldrec, mu0, S0, lds0, S, lds, mu_out, dbg, \
+    GSMVI_LAUNCH(k_gsm_cov_sym<SBV>, grid, dim3(512), 0, st, ev, D, B, invB, rec, ldrec, mu0, S0, lds0, S, lds, mu_out, dbg, \
                  stamps)
-    switch (B) {
+    switch (SB) {
         case 16: CS(16); break;
         case 32: CS(32); break;
         case 64: CS(64); break;
-        default: return false;
+        default: CS(128); break;
     }
 #undef CS
     return true;

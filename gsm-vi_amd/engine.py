@@ -353,6 +353,20 @@ class HipEngine:
             pz, ldz, C.c_void_p(ld.data_ptr())))
         return Z, ld
 
+    # kernel-family bits of include/gsmvi_hip.h (GSMVI_PATH_*)
+    PATH_BITS = {"panel_fast": 0x1, "panel_wide": 0x2, "panel_generic": 0x4, "panel_t_fast": 0x8, "panel_t_generic": 0x10,
+                 "scalars_fast": 0x20, "scalars_generic": 0x40, "cov_sym": 0x80, "cov_generic": 0x100, "fupd_fast": 0x200,
+                 "fupd_generic": 0x400, "lowrank_fast": 0x800, "lowrank_generic": 0x1000}
+    PATH_GENERIC_MASK = 0x4 | 0x10 | 0x40 | 0x100 | 0x400 | 0x1000
+
+    def last_path(self, reset=True):
+        """Names of the kernel families launched on this context since the last reset (gsmvi_last_path): how tests and
+        profiles check that an off-grid shape stayed on the tuned kernels (no name ending in ``_generic``)."""
+        self._ensure(max(self._max_D, 1), max(self._max_B, 1))
+        bits = C.c_uint(0)
+        _lib.check("gsmvi_last_path", self.lib.gsmvi_last_path(self._ctx, C.byref(bits), int(bool(reset))))
+        return {k for k, v in self.PATH_BITS.items() if bits.value & v}
+
     def set_profiling(self, on):
         self._ensure(max(self._max_D, 1), max(self._max_B, 1))
         _lib.check("gsmvi_set_profiling", self.lib.gsmvi_set_profiling(self._ctx, int(bool(on))))

@@ -224,6 +224,31 @@ int gsmvi_set_profiling(gsmvi_ctx* ctx, int on);
 int gsmvi_get_profile(gsmvi_ctx* ctx, float* ms, int n);
 
 /*
+ * Which kernel families the calls on this context launched since the last reset (round 5).  The tuned kernels need
+ * D % 64 == 0, even leading dimensions and 16-byte aligned bases (any batch size); everything else runs the guarded
+ * kernels of the same arithmetic (csrc/gsmvi_kernels.hip), about half as fast.  The reference takes any (D, B)
+ * (gsm_numpy.py:27-55, bam.py:31-114); a caller that keeps its state padded to a multiple of 64 columns (zero border in
+ * mu, X, G, Z, F; identity border on the diagonal of Sigma -- INTEGRATION.md, "Off-grid dimensions") stays on the tuned
+ * kernels for every D, and this query is how tests and profiles prove that it did: *bits & GSMVI_PATH_GENERIC_MASK == 0.
+ * reset != 0 clears the record after reading it.
+ */
+#define GSMVI_PATH_PANEL_FAST 0x0001u      /* k_panel_fast: A M products (S0 G, score, sampler, V Fm, ...)          */
+#define GSMVI_PATH_PANEL_WIDE 0x0002u      /* k_panel_wide: the same on 64 x 64 tiles (64-row panels, D >= 1024)    */
+#define GSMVI_PATH_PANEL_GENERIC 0x0004u   /* k_panel_partial                                                       */
+#define GSMVI_PATH_PANEL_T_FAST 0x0008u    /* k_panel_t_fast: A M^T products (W = G F^T, Gram matrices)              */
+#define GSMVI_PATH_PANEL_T_GENERIC 0x0010u /* k_panel_t                                                             */
+#define GSMVI_PATH_SCALARS_FAST 0x0020u    /* k_gsm_scalars_fast                                                    */
+#define GSMVI_PATH_SCALARS_GENERIC 0x0040u /* k_gsm_scalars                                                         */
+#define GSMVI_PATH_COV_SYM 0x0080u         /* k_gsm_cov_sym / k_gsm_cov_sym_p: the headline covariance kernel       */
+#define GSMVI_PATH_COV_GENERIC 0x0100u     /* k_gsm_cov_update (also: non-symmetric S0, row-block shards)           */
+#define GSMVI_PATH_FUPD_FAST 0x0200u       /* k_gsmf_update_fs / k_gsmf_update_fast: F = F0 + Rt^T Fs               */
+#define GSMVI_PATH_FUPD_GENERIC 0x0400u    /* k_gsmf_update + k_gsmf_mean                                           */
+#define GSMVI_PATH_LOWRANK_FAST 0x0800u    /* k_lowrank_update_fast: BaM's S = S0 + Vf^T Vf - Z^T Z                 */
+#define GSMVI_PATH_LOWRANK_GENERIC 0x1000u /* k_lowrank_update                                                      */
+#define GSMVI_PATH_GENERIC_MASK (0x0004u | 0x0010u | 0x0040u | 0x0100u | 0x0400u | 0x1000u)
+int gsmvi_last_path(gsmvi_ctx* ctx, unsigned* bits, int reset);
+
+/*
  * Score of the Gaussian target N(m, P^-1) at the rows of X: G = -(X - 1 m^T) P.
  * Replaces the user callback of examples/example_gsm_numpy.py:24-29 (P symmetric precision matrix).
  */
