@@ -504,7 +504,7 @@ static int gsm_local_stage(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, const d
 
 static int gsm_apply(gsmvi_ctx* ctx, hipStream_t hs, int D, int B, const double* rec, int ldrec, const double* mu0,
                      const double* S0, int lds0, double* mu, double* S, int lds) {
-    if (!ctx->tune_no_fast && D % 32 == 0 && (ldrec % 2 == 0) && aligned16(rec) && lds0 % 2 == 0 && lds % 2 == 0 &&
+    if (!ctx->tune_no_fast && D % 2 == 0 && (ldrec % 2 == 0) && aligned16(rec) && lds0 % 2 == 0 && lds % 2 == 0 &&
         aligned16(S0) && aligned16(S) &&                         // 16-B loads of S0 and stores of S
         gsmvi_launch_gsm_cov_sym(hs, ctx->stage_events(2), D, B, rec, ldrec, mu0, S0, lds0, S, lds, mu,
                                  ctx->tune_cov_dbg,

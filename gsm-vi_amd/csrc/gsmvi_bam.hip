@@ -689,18 +689,21 @@ __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, cons
                                                              double* __restrict__ S, int lds, double jitter) {
     constexpr int RS = 80, KP = 32;
     __shared__ __attribute__((aligned(16))) double sm[2 * KP * RS];
-    const int nt = D >> 6, np = (KF + KP - 1) / KP;
+    const int nt = (D + 63) >> 6, np = (KF + KP - 1) / KP;    // any even D (round 5): edge tiles re-read clamped rows / columns
     const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
     const int I0 = ti * 64, J0 = tj * 64;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
     const int wr = w >> 1, wc = w & 1;
     double s0[2][4];
-    const size_t frow = (size_t)(I0 + 16 * wr + ks);
+    const int frow = I0 + 16 * wr + ks;
     const int fcol = J0 + 32 * wc + c;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s0[blk][r] = S0[(frow + 4 * r) * lds0 + fcol + 16 * blk];
+        for (int r = 0; r < 4; ++r) {
+            const int rr = frow + 4 * r < D ? frow + 4 * r : D - 1, cq = fcol + 16 * blk < D ? fcol + 16 * blk : D - 1;
+            s0[blk][r] = S0[(size_t)rr * lds0 + cq];
+        }
     v2d ga[NPMAX][2], gb[NPMAX][2];
 #pragma unroll
     for (int p = 0; p < NPMAX; ++p) {
@@ -709,8 +712,8 @@ __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, cons
             for (int q = 0; q < 2; ++q) {
                 const int u = q * 512 + tid, row = KP * p + (u >> 5), c2 = 2 * (u & 31);
                 const int rc = row < KF ? row : KF - 1;
-                const v2d a = *reinterpret_cast<const v2d*>(Ft + (size_t)rc * D + I0 + c2);
-                const v2d b = *reinterpret_cast<const v2d*>(Fs + (size_t)rc * D + J0 + c2);
+                const v2d a = *reinterpret_cast<const v2d*>(Ft + (size_t)rc * D + (I0 + c2 < D ? I0 + c2 : D - 2));
+                const v2d b = *reinterpret_cast<const v2d*>(Fs + (size_t)rc * D + (J0 + c2 < D ? J0 + c2 : D - 2));
                 ga[p][q] = row < KF ? a : (v2d){0.0, 0.0};
                 gb[p][q] = row < KF ? b : (v2d){0.0, 0.0};
             }
@@ -746,9 +749,9 @@ __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, cons
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const size_t row = frow + 4 * r;
-        S[row * lds + fcol] = s0[0][r] + acc0[r] + ((int)row == fcol ? jitter : 0.0);
-        S[row * lds + fcol + 16] = s0[1][r] + acc1[r] + ((int)row == fcol + 16 ? jitter : 0.0);
+        const int row = frow + 4 * r;
+        if (row < D && fcol < D) S[(size_t)row * lds + fcol] = s0[0][r] + acc0[r] + (row == fcol ? jitter : 0.0);
+        if (row < D && fcol + 16 < D) S[(size_t)row * lds + fcol + 16] = s0[1][r] + acc1[r] + (row == fcol + 16 ? jitter : 0.0);
     }
 }
 
@@ -856,8 +859,8 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
 #undef BFW
     }
     const int nt = (D + 63) / 64;
-    ctx->path |= (!ctx->tune_no_fast && D % 64 == 0 && n2 <= 288) ? GSMVI_PATH_LOWRANK_FAST : GSMVI_PATH_LOWRANK_GENERIC;
-    if (!ctx->tune_no_fast && D % 64 == 0 && n2 <= 288) {
+    ctx->path |= (!ctx->tune_no_fast && D % 2 == 0 && n2 <= 288) ? GSMVI_PATH_LOWRANK_FAST : GSMVI_PATH_LOWRANK_GENERIC;
+    if (!ctx->tune_no_fast && D % 2 == 0 && n2 <= 288) {
         if (n2 <= 96)
             hipLaunchKernelGGL(k_lowrank_update_fast<3>, dim3(nt * nt), dim3(512), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds, jitter);
         else

@@ -487,19 +487,22 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const do
                                                           const int* __restrict__ bad, int* __restrict__ n_reverts) {
     constexpr int RS = 80, KP = 32;
     __shared__ __attribute__((aligned(16))) double sm[2 * KP * RS];
-    const int nt = D >> 6;
+    const int nt = (D + 63) >> 6;                  // any even D (round 5): edge tiles re-read clamped rows / columns, store what lies inside
     const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
     const int I0 = ti * 64, J0 = tj * 64;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
     const int wr = w >> 1, wc = w & 1;
     // ---- all global loads ----
     double f0[2][4];
-    const size_t frow = (size_t)(I0 + 16 * wr + ks);
+    const int frow = I0 + 16 * wr + ks;
     const int fcol = J0 + 32 * wc + c;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) f0[blk][r] = F0[(frow + 4 * r) * ldf0 + fcol + 16 * blk];
+        for (int r = 0; r < 4; ++r) {
+            const int rr = frow + 4 * r < D ? frow + 4 * r : D - 1, cq = fcol + 16 * blk < D ? fcol + 16 * blk : D - 1;
+            f0[blk][r] = F0[(size_t)rr * ldf0 + cq];
+        }
     // (any n = 2B <= 32 NP, round 5: rows beyond n are clamped re-reads, zeroed when they are staged; a pass whose rows
     // all lie beyond n is skipped -- np is block-uniform)
     const int n = 2 * B, np = (n + KP - 1) / KP;
@@ -511,14 +514,14 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const do
             for (int q = 0; q < 2; ++q) {
                 const int u = q * 512 + tid, row = KP * p + (u >> 5), c2 = 2 * (u & 31);
                 const int rc = row < n ? row : n - 1;
-                ga[p][q] = *reinterpret_cast<const v2d*>(Rt + (size_t)rc * D + I0 + c2);
-                gb[p][q] = *reinterpret_cast<const v2d*>(Fs + (size_t)rc * D + J0 + c2);
+                ga[p][q] = *reinterpret_cast<const v2d*>(Rt + (size_t)rc * D + (I0 + c2 < D ? I0 + c2 : D - 2));
+                gb[p][q] = *reinterpret_cast<const v2d*>(Fs + (size_t)rc * D + (J0 + c2 < D ? J0 + c2 : D - 2));
             }
         }
     const int skip = *bad;
     double msum = 0.0;
     if (ti == 0) {                               // partial weighted column sums of rows g, g + 8, ... of Tm = [X - mu; V Fm]
-        const int g = tid >> 6, col = J0 + (tid & 63);
+        const int g = tid >> 6, col = J0 + (tid & 63) < D ? J0 + (tid & 63) : D - 1;
         for (int b = g; b < 2 * B; b += 8) msum += coef[b] * Tm[(size_t)b * D + col];
     }
     if (blockIdx.x == 0 && tid == 0 && skip && n_reverts) *n_reverts += 1;
@@ -553,14 +556,14 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const do
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        F[(frow + 4 * r) * ldf + fcol] = skip ? f0[0][r] : f0[0][r] + acc0[r];
-        F[(frow + 4 * r) * ldf + fcol + 16] = skip ? f0[1][r] : f0[1][r] + acc1[r];
+        if (frow + 4 * r < D && fcol < D) F[(size_t)(frow + 4 * r) * ldf + fcol] = skip ? f0[0][r] : f0[0][r] + acc0[r];
+        if (frow + 4 * r < D && fcol + 16 < D) F[(size_t)(frow + 4 * r) * ldf + fcol + 16] = skip ? f0[1][r] : f0[1][r] + acc1[r];
     }
     if (ti == 0) {
         __syncthreads();
         sm[tid] = msum;                          // [8][64]
         __syncthreads();
-        if (tid < 64) {
+        if (tid < 64 && J0 + tid < D) {
             double s = 0.0;
 #pragma unroll
             for (int g = 0; g < 8; ++g) s += sm[g * 64 + tid];
@@ -631,7 +634,7 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const doub
     __shared__ __attribute__((aligned(16))) double bufB[N * RS];      // Fs tile
     __shared__ __attribute__((aligned(16))) double bufK[N * KS];      // K''
     __shared__ double msm[8 * 64];
-    const int nt = D >> 6;
+    const int nt = (D + 63) >> 6;                  // any even D (round 5): edge tiles as in k_gsmf_update_fast
     const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
     const int I0 = ti * 64, J0 = tj * 64;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
@@ -640,12 +643,15 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const doub
     if (blockIdx.x == 0 && tid == 0 && skip && n_reverts) *n_reverts += 1;
     // ---- all global loads of the first phase: F0 tile (accumulator layout), K'', the Tm1 tile, the Rt1 tile ----
     double f0[2][4];
-    const size_t frow = (size_t)(I0 + 16 * wr + ks);
+    const int frow = I0 + 16 * wr + ks;
     const int fcol = J0 + 32 * wc + c;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) f0[blk][r] = F0[(frow + 4 * r) * ldf0 + fcol + 16 * blk];
+        for (int r = 0; r < 4; ++r) {
+            const int rr = frow + 4 * r < D ? frow + 4 * r : D - 1, cq = fcol + 16 * blk < D ? fcol + 16 * blk : D - 1;
+            f0[blk][r] = F0[(size_t)rr * ldf0 + cq];
+        }
     constexpr int KU = N * N / 2 / 512;            // 16-B units of K'' per thread (N = 64: 4, N = 32: 1)
     const int n = 2 * B;
     v2d gk[KU];
@@ -659,24 +665,25 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const doub
 #pragma unroll
     for (int q = 0; q < TU; ++q) {
         const int u = q * 512 + tid, row = u >> 5, c2 = 2 * (u & 31);
+        const int jc = J0 + c2 < D ? J0 + c2 : D - 2, icq = I0 + c2 < D ? I0 + c2 : D - 2;
         if (row >= n) {
             gt[q] = gr[q] = (v2d){0.0, 0.0};
             continue;
         }
-        if (row >= B && vf_slabs != nullptr) {     // V Fm rows: sum of the kcv slabs (row is wave-uniform for B % 16 == 0)
+        if (row >= B && vf_slabs != nullptr) {     // V Fm rows: sum of the kcv slabs (row is wave-uniform for B % 2 == 0)
             v2d t[KCB];
 #pragma unroll
             for (int kq = 0; kq < KCB; ++kq)
-                t[kq] = *reinterpret_cast<const v2d*>(vf_slabs + ((size_t)(kq < kcv ? kq : kcv - 1) * B + (row - B)) * D + J0 + c2);
+                t[kq] = *reinterpret_cast<const v2d*>(vf_slabs + ((size_t)(kq < kcv ? kq : kcv - 1) * B + (row - B)) * D + jc);
             v2d a = {0.0, 0.0};
 #pragma unroll
             for (int kq = 0; kq < KCB; ++kq)
                 if (kq < kcv) { a.x += t[kq].x; a.y += t[kq].y; }
             gt[q] = a;
         } else {
-            gt[q] = *reinterpret_cast<const v2d*>(Tm + (size_t)row * D + J0 + c2);
+            gt[q] = *reinterpret_cast<const v2d*>(Tm + (size_t)row * D + jc);
         }
-        gr[q] = *reinterpret_cast<const v2d*>(Rt + (size_t)row * D + I0 + c2);
+        gr[q] = *reinterpret_cast<const v2d*>(Rt + (size_t)row * D + icq);
     }
 #pragma unroll
     for (int q = 0; q < KU; ++q) {
@@ -746,13 +753,13 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const doub
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        F[(frow + 4 * r) * ldf + fcol] = skip ? f0[0][r] : f0[0][r] + acc0[r];
-        F[(frow + 4 * r) * ldf + fcol + 16] = skip ? f0[1][r] : f0[1][r] + acc1[r];
+        if (frow + 4 * r < D && fcol < D) F[(size_t)(frow + 4 * r) * ldf + fcol] = skip ? f0[0][r] : f0[0][r] + acc0[r];
+        if (frow + 4 * r < D && fcol + 16 < D) F[(size_t)(frow + 4 * r) * ldf + fcol + 16] = skip ? f0[1][r] : f0[1][r] + acc1[r];
     }
     if (ti == 0) {
         msm[tid] = msum;                           // [8][64]
         __syncthreads();
-        if (tid < 64) {
+        if (tid < 64 && J0 + tid < D) {
             double s = 0.0;
 #pragma unroll
             for (int g = 0; g < 8; ++g) s += msm[g * 64 + tid];
@@ -852,9 +859,10 @@ static int gsmvi_panel_t_product_mt(gsmvi_ctx* ctx, hipStream_t st, int D, int B
     int MT = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
     if (MT > mt_cap) MT = mt_cap;
     const int CH = (MT == 4) ? 128 : 256;
-    const bool fast_t = !ctx->tune_no_fast && D % 64 == 0 && lda % 2 == 0 && ldm % 2 == 0 &&
+    // (any even D since round 5: the staging of both operands zeroes what lies beyond column D)
+    const bool fast_t = !ctx->tune_no_fast && D % 2 == 0 && lda % 2 == 0 && ldm % 2 == 0 &&
                         (reinterpret_cast<uintptr_t>(A) & 15u) == 0 && (reinterpret_cast<uintptr_t>(M) & 15u) == 0;
-    if (fast_t && MT == 4 && ctx->tune_wide && mrows % 64 == 0 && mrows >= 1024 && D >= 1024) {
+    if (fast_t && MT == 4 && ctx->tune_wide && mrows % 64 == 0 && mrows >= 1024 && D >= 1024 && D % 64 == 0) {
         // 64-row panels of a D-sized product are MFMA-bound: the 64 x 64-tile kernel (gsmvi_wide.hip)
         int kcw = 1, kper = D;
         gsmvi_panel_wide_split(D, (mrows / 64) * ((B + 63) / 64), ctx->num_cu, ctx->tune_wide_kc, &kcw, &kper);
@@ -996,7 +1004,7 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
     // pull them through a single CU: measured +5.6 us).  Otherwise: product + finish launches, as before.
     // (any batch size since round 5: n <= 64 always; 64 < n <= 128 when B % 16 == 0 -- the K'' Tm product takes its V Fm rows
     // from split-K slabs per wave, and a wave's 16 rows must lie on one side of row B)
-    const bool lean = !ctx->tune_no_fast && ctx->tune_direct_out && (n <= 64 || (n <= 128 && B % 16 == 0)) && D % 64 == 0 &&
+    const bool lean = !ctx->tune_no_fast && ctx->tune_direct_out && (n <= 64 || (n <= 128 && B % 16 == 0)) && D % 2 == 0 &&
                       ldf0 % 2 == 0 && ldf % 2 == 0 && (reinterpret_cast<uintptr_t>(F0) & 15u) == 0;
     // Large D, n = 128: the V Fm product (MFMA-bound, 65 us at D = 4096) does not depend on the Gram product and the eight small
     // launches of the 2B x 2B chain (~100 us on a few CUs), so it runs on the context's second stream beside them; the two
@@ -1264,10 +1272,10 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         small_gemm_launch(st, OpChainK{n, n, n, Wm, Pmat, coef + n, Kmat, B, info_dev});
         if ((rc = chk("k_small_gemm"))) return rc;
     }
-    if (!ctx->tune_no_fast && ctx->tune_direct_out && D % 64 == 0 && n <= 64 && ldf0 % 2 == 0 && ldf % 2 == 0) {
+    if (!ctx->tune_no_fast && ctx->tune_direct_out && D % 2 == 0 && n <= 64 && ldf0 % 2 == 0 && ldf % 2 == 0) {
         ctx->path |= GSMVI_PATH_FUPD_FAST;
         // n <= 64: the skinny product Fs = K'' Tm1 is folded into the update kernel (k_gsmf_update_fs): one launch less
-        const int ntl = D / 64;
+        const int ntl = (D + 63) / 64;
 #define UFS(NPV, KCBV) hipLaunchKernelGGL((k_gsmf_update_fs<NPV, KCBV>), dim3(ntl * ntl), dim3(512), 0, st, D, B, Rt, Kmat, Tm, vf_slabs, kcv, F0, ldf0, F, ldf, coef, mu0, mu, info_dev, n_reverts_dev)
         if (kcv <= 4) { if (n <= 32) UFS(1, 4); else UFS(2, 4); }
         else { if (n <= 32) UFS(1, GSMVI_MAX_KC); else UFS(2, GSMVI_MAX_KC); }
@@ -1298,7 +1306,7 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         return GSMVI_ERR_UNSUPPORTED;
     }
     const int nt = (D + 63) / 64;
-    if (!ctx->tune_no_fast && D % 64 == 0 && n <= 256 && ldf0 >= D && ldf >= D) {
+    if (!ctx->tune_no_fast && D % 2 == 0 && n <= 256) {
         // the fast kernel also writes the mean and counts the revert (any even n <= 256 since round 5)
 #define UF(NPV) hipLaunchKernelGGL(k_gsmf_update_fast<NPV>, dim3(nt * nt), dim3(512), 0, st, D, B, Rt, Fs, F0, ldf0, F, ldf, Tm, coef, mu0, mu, info_dev, n_reverts_dev)
         if (n <= 32) UF(1); else if (n <= 64) UF(2); else if (n <= 128) UF(4); else UF(8);

@@ -357,8 +357,8 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, int B, double invB, 
     // m, one single-tile workgroup (its last tile).  The two-tile workgroups come FIRST in the grid
     // (exactly 256 of them at D = 1024: one per CU); the light single-tile ones are dispatched last
     // and share a CU with a resident workgroup without stretching the kernel's tail.
-    const int nt = D >> 5;
-    const int n_two = ((nt >> 1) * ((nt + 1) >> 1));             // sum_m floor(m/2), m = 1..nt
+    const int nt = (D + 31) >> 5;                                // any even D (round 5): edge tiles re-read clamped rows / columns
+    const int n_two = ((nt >> 1) * ((nt + 1) >> 1));             // sum_m floor(m/2), m = 1..nt   // and store only what lies inside
     int ti, tj0;
     bool two;
     if ((int)blockIdx.x < n_two) {
@@ -394,7 +394,8 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, int B, double invB, 
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int unit = q * 256 + tl, i = unit >> 4, j2 = unit & 15;
-        s0v[q] = (dbg & 2) ? (v2d){1.0, 1.0} : *reinterpret_cast<const v2d*>(S0 + (size_t)(I0 + i) * lds0 + Jt + 2 * j2);
+        const int gr = I0 + i < D ? I0 + i : D - 1, gc = Jt + 2 * j2 < D ? Jt + 2 * j2 : D - 2;
+        s0v[q] = (dbg & 2) ? (v2d){1.0, 1.0} : *reinterpret_cast<const v2d*>(S0 + (size_t)gr * lds0 + gc);
     }
     __builtin_amdgcn_sched_barrier(0);           // keep the HBM loads of S0 ahead of the L2-resident staging loads
     v2d stg[UPT];
@@ -405,12 +406,13 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, int B, double invB, 
         const int b = u >> 4, c2 = 2 * (u & 15);
         // tile 0,1: I block (d, e); 2,3: J0 block; 4,5: J1 block (= J0 again when there is no second tile)
         const int colbase = (tile < 2) ? I0 : (J0 + ((tile >= 4 && two) ? 32 : 0));
+        const int colc = colbase + c2 < D ? colbase + c2 : D - 2;   // (a column beyond D only feeds outputs that are not stored)
         // the 16 single-tile workgroups (they share a CU with a two-tile one) neither load nor stage a second column
         // block, and their waves 4-7 issue no MFMA: 32 instead of 64 MFMAs per SIMD on those CUs (they were the
         // kernel's 0.9 us tail: profiles/r02/timeline_cold_three_launch.txt).  tile is wave-uniform.
         // (any B <= SB: sample rows b >= B do not exist -- the address is clamped and the unit is zeroed at staging time,
         // so that no use of a loaded value sits between the loads)
-        stg[q] = (two || tile < 4) ? *reinterpret_cast<const v2d*>(rec + (size_t)(b < B ? b : B - 1) * ldrec + (tile & 1) * D + colbase + c2)
+        stg[q] = (two || tile < 4) ? *reinterpret_cast<const v2d*>(rec + (size_t)(b < B ? b : B - 1) * ldrec + (tile & 1) * D + colc)
                                    : (v2d){0.0, 0.0};
     }
     double dmu_part = 0.0;
@@ -418,8 +420,8 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, int B, double invB, 
         double dv[SB / 8];
 #pragma unroll
         for (int k = 0; k < SB / 8; ++k) {
-            const int b = (tid >> 5) + 8 * k;
-            dv[k] = rec[(size_t)(b < B ? b : B - 1) * ldrec + 2 * D + I0 + (tid & 31)];
+            const int b = (tid >> 5) + 8 * k, ci = I0 + (tid & 31);
+            dv[k] = rec[(size_t)(b < B ? b : B - 1) * ldrec + 2 * D + (ci < D ? ci : D - 1)];
         }
 #pragma unroll
         for (int k = 0; k < SB / 8; ++k) dmu_part += ((tid >> 5) + 8 * k < B) ? dv[k] : 0.0;
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, int B, double invB, 
             v2d wv2;
             wv2.x = s0v[q].x + LW[i * 33 + 2 * j2];
             wv2.y = s0v[q].y + LW[i * 33 + 2 * j2 + 1];
-            *reinterpret_cast<v2d*>(S + (size_t)(I0 + i) * lds + Jt + 2 * j2) = wv2;
+            if (I0 + i < D && Jt + 2 * j2 < D) *reinterpret_cast<v2d*>(S + (size_t)(I0 + i) * lds + Jt + 2 * j2) = wv2;
             LW[i * 33 + 2 * j2] = wv2.x;
             LW[i * 33 + 2 * j2 + 1] = wv2.y;
         }
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, int B, double invB, 
             v2d m2;
             m2.x = LW[(2 * i2) * 33 + j];
             m2.y = LW[(2 * i2 + 1) * 33 + j];
-            *reinterpret_cast<v2d*>(S + (size_t)(Jt + j) * lds + I0 + 2 * i2) = m2;
+            if (Jt + j < D && I0 + 2 * i2 < D) *reinterpret_cast<v2d*>(S + (size_t)(Jt + j) * lds + I0 + 2 * i2) = m2;
         }
     }
     if (diag) {
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, int B, double invB, 
             double s = 0.0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) s += smem[q * 32 + tid];
-            mu_out[I0 + tid] = mu0[I0 + tid] + s * invB;
+            if (I0 + tid < D) mu_out[I0 + tid] = mu0[I0 + tid] + s * invB;
         }
     }
     STAMP(4);
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, int B, double invB
     constexpr int UPT = (6 * NU) / 512;
     static_assert((6 * NU) % 512 == 0, "tile units must divide over 512 threads");
     __shared__ __attribute__((aligned(16))) double smem[6 * TILE >= 2 * 32 * 33 ? 6 * TILE : 2 * 32 * 33];
-    const int nt = D >> 5;
+    const int nt = (D + 31) >> 5;                            // (any even D: edge tiles as in k_gsm_cov_sym)
     const int n_two = ((nt >> 1) * ((nt + 1) >> 1));
     const int n_items = n_two + ((nt + 1) >> 1);             // + one lone diagonal tile per row with an odd tile count
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
@@ -587,7 +589,8 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, int B, double invB
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int unit = q * 256 + tl, i = unit >> 4, j2 = unit & 15;
-            s0[q] = *reinterpret_cast<const v2d*>(S0 + (size_t)(I0 + i) * lds0 + Jt + 2 * j2);
+            const int gr = I0 + i < D ? I0 + i : D - 1, gc = Jt + 2 * j2 < D ? Jt + 2 * j2 : D - 2;
+            s0[q] = *reinterpret_cast<const v2d*>(S0 + (size_t)gr * lds0 + gc);
         }
         __builtin_amdgcn_sched_barrier(0);                   // the HBM loads of S0 ahead of the L2-resident record loads
 #pragma unroll
@@ -596,7 +599,8 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, int B, double invB
             const int tile = g / NU, u = g % NU;
             const int b = u >> 4, c2 = 2 * (u & 15);
             const int colbase = (tile < 2) ? I0 : (J0 + ((tile >= 4 && it.two) ? 32 : 0));
-            stg[q] = (it.two || tile < 4) ? *reinterpret_cast<const v2d*>(rec + (size_t)(b < B ? b : B - 1) * ldrec + (tile & 1) * D + colbase + c2)
+            const int colc = colbase + c2 < D ? colbase + c2 : D - 2;
+            stg[q] = (it.two || tile < 4) ? *reinterpret_cast<const v2d*>(rec + (size_t)(b < B ? b : B - 1) * ldrec + (tile & 1) * D + colc)
                                           : (v2d){0.0, 0.0};
         }
 #pragma unroll
@@ -604,8 +608,8 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, int B, double invB
         if (it.tj0 == it.ti && tid < 256) {
 #pragma unroll
             for (int k = 0; k < SB / 8; ++k) {
-                const int b = (tid >> 5) + 8 * k;
-                dmu[k] = rec[(size_t)(b < B ? b : B - 1) * ldrec + 2 * D + I0 + (tid & 31)];
+                const int b = (tid >> 5) + 8 * k, ci = I0 + (tid & 31);
+                dmu[k] = rec[(size_t)(b < B ? b : B - 1) * ldrec + 2 * D + (ci < D ? ci : D - 1)];
             }
         }
     };
@@ -676,7 +680,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, int B, double invB
                 v2d wv2;
                 wv2.x = s0v[q].x + LW[i * 33 + 2 * j2];
                 wv2.y = s0v[q].y + LW[i * 33 + 2 * j2 + 1];
-                *reinterpret_cast<v2d*>(S + (size_t)(I0 + i) * lds + Jt + 2 * j2) = wv2;
+                if (I0 + i < D && Jt + 2 * j2 < D) *reinterpret_cast<v2d*>(S + (size_t)(I0 + i) * lds + Jt + 2 * j2) = wv2;
                 LW[i * 33 + 2 * j2] = wv2.x;
                 LW[i * 33 + 2 * j2 + 1] = wv2.y;
             }
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, int B, double invB
                 v2d m2;
                 m2.x = LW[(2 * i2) * 33 + j];
                 m2.y = LW[(2 * i2 + 1) * 33 + j];
-                *reinterpret_cast<v2d*>(S + (size_t)(Jt + j) * lds + I0 + 2 * i2) = m2;
+                if (Jt + j < D && I0 + 2 * i2 < D) *reinterpret_cast<v2d*>(S + (size_t)(Jt + j) * lds + I0 + 2 * i2) = m2;
             }
         }
         if (diag) {                                          // (block-uniform)
@@ -706,7 +710,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, int B, double invB
                 double sm_ = 0.0;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) sm_ += smem[q * 32 + tid];
-                mu_out[I0 + tid] = mu0[I0 + tid] + sm_ * invB;
+                if (I0 + tid < D) mu_out[I0 + tid] = mu0[I0 + tid] + sm_ * invB;
             }
         }
         if (nxt >= n_items) break;
@@ -795,7 +799,7 @@ bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, cons
     const double invB = 1.0 / (double)B;
     // large D: the persistent form (2 resident workgroups per CU walk the item list, the next item's loads in flight during
     // the current item's MFMAs and stores); "cov_dbg" bit 512 keeps the one-item-per-workgroup kernel for A/B runs
-    const int n_items = cov_sym_grid(D / 32);
+    const int n_items = cov_sym_grid((D + 31) / 32);
     if (n_items >= 2048 && SB <= 32 && !stamps && dbg == 0) {    // (B = 64: two staging passes, MFMA-bound -- the one-item kernel is faster there)
         const dim3 pgrid(2 * (num_cu > 0 ? num_cu : 256));       // two resident workgroups per CU of THIS device (a partitioned device has fewer)
 #define CSP(SBV) GSMVI_LAUNCH(k_gsm_cov_sym_p<SBV>, pgrid, dim3(512), 0, st, ev, D, B, invB, rec, ldrec, mu0, S0, lds0, S, lds, mu_out)
@@ -804,7 +808,7 @@ bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, cons
 #undef CSP
     }
     if (dbg & 512) dbg &= ~512;
-    const dim3 grid(cov_sym_grid(D / 32));
+    const dim3 grid(n_items);
 #define CS(SBV)                                                                                             \
     GSMVI_LAUNCH(k_gsm_cov_sym<SBV>, grid, dim3(512), 0, st, ev, D, B, invB, rec, ldrec, mu0, S0, lds0, S, lds, mu_out, dbg, \
                  stamps)

@@ -9,8 +9,8 @@ For every (D, B) of SHAPES and its neighbour (Dp, Bp) = (D rounded up to 64, B r
        oneshot : gsmvi_amd.gsm_update / bam_update on CUDA tensors (includes whatever padding copies the package makes)
   F  GSM.fit (auto, dense) and BaM.fit (dense, factor) marginal iteration rates with the built-in Gaussian score
 Timing: HIP events around single calls after warm-up (median), and a replayed hipGraph of back-to-back calls.
-Usage: offgrid_bench.py <label> <out.json>; the label ("before" = library of round 4, "after") keys the document, so both
-runs merge into one profiles/r05/offgrid.json.
+Usage: offgrid_bench.py <label> <out.json>; label "before" = the library of round 4 (GSMVI_HIP_LIB_VARIANT=r04 or a checkout
+of that commit), "after" = this tree.  scripts/offgrid_report.py merges the two documents into profiles/r05/offgrid.json.
 """
 import json
 import os
@@ -23,7 +23,7 @@ import torch  # noqa: E402
 import gsmvi_amd  # noqa: E402
 
 label = sys.argv[1] if len(sys.argv) > 1 else "after"
-out_path = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/offgrid.json"
+out_path = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/offgrid_{label}.json"
 quick = os.environ.get("OFFGRID_QUICK", "0") != "0"
 eng = gsmvi_amd.get_engine()
 dev = eng.device
@@ -215,11 +215,4 @@ for (D, B) in SHAPES:
         torch.cuda.empty_cache()
 
 os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
-prev = {}
-if os.path.exists(out_path):
-    try:
-        prev = json.load(open(out_path))
-    except Exception:  # noqa: BLE001
-        prev = {}
-prev[label] = doc
-json.dump(prev, open(out_path, "w"), indent=1)
+json.dump(doc, open(out_path, "w"), indent=1)

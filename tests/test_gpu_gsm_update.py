@@ -46,8 +46,16 @@ def test_ragged_sizes_against_oracle(eng, D, B):
     orc = _oracle()
     st = orc.make_update_state(D, B, seed=D + B)
     mu_o, S_o = orc.gsm_update_batched(st["samples"], st["vs"], st["mu0"], st["S0"])
+    eng.last_path()
     mu, S = gsmvi_amd.gsm_update(st["samples"], st["vs"], st["mu0"], st["S0"])
+    path = eng.last_path()
     assert rel_err(mu, mu_o) < TOL and rel_err(S, S_o) < TOL
+    # round 5: any even D and any B <= 128 stay on the tuned kernels (gsmvi_last_path); odd D (rows not 16-byte aligned) and
+    # larger batches run the guarded family
+    if D % 2 == 0 and B <= 128:
+        assert not [k for k in path if k.endswith("_generic")] and "cov_sym" in path, path
+    else:
+        assert "cov_generic" in path, path
     if D <= 64:
         mu_f, S_f = orc.gsm_update_faithful(st["samples"], st["vs"], st["mu0"], st["S0"])
         assert rel_err(mu, mu_f) < TOL and rel_err(S, S_f) < TOL
