@@ -43,15 +43,14 @@
 // order swapped -- Z T, equal in exact arithmetic -- rounding errors grow and the iteration diverges at
 // cond(A) ~ 1e6: checked in numpy and on the device).  A is read by rows (16 rows x 4 consecutive k per k-step:
 // 32-B segments, the matrices are L2-resident), B by rows of 16 consecutive columns (128-B segments).
+// The partial block of ONE wave: wave w of four takes the k-steps w, w + 4, ... in batches of nine (one batch for ld = 144),
+// every load of a batch issued together, two accumulator chains.  Shared by the multi-workgroup step kernels and the tail
+// kernel (round 5): the tail used its own single-wave sum, so a call whose stale step-count hint moved steps into the tail
+// gave other bits than a call with a fresh hint -- results depended on host / GPU timing (advisor, round 4).
 template <int MODE>
-__device__ __forceinline__ void bams_block(const double* __restrict__ A, const double* __restrict__ Bm,
-                                           double* __restrict__ Out, int blk, int nb, int nk, double c2, double scale,
-                                           int ld) {
-    // one WORKGROUP per 16 x 16 block; wave w takes the k-steps w, w + 4, ... in batches of nine (one batch for ld = 144),
-    // every load of a batch issued together; the four partial blocks are summed through LDS in a fixed order
-    __shared__ double red[4 * 256];
-    const int i0 = (blk / nb) * 16, j0 = (blk % nb) * 16;
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, cc = l & 15, ks = l >> 4;
+__device__ __forceinline__ v4d bams_partial(const double* __restrict__ A, const double* __restrict__ Bm, int i0, int j0, int w,
+                                            int nk, double c2, int ld) {
+    const int l = threadIdx.x & 63, cc = l & 15, ks = l >> 4;
     v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     for (int u0 = 0; w + 4 * u0 < nk; u0 += 9) {
         double a[9], b[9];
@@ -74,7 +73,21 @@ __device__ __forceinline__ void bams_block(const double* __restrict__ A, const d
         acc0 = GSMVI_MFMA_F64(a[8], b[8], acc0);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[w * 256 + (ks + 4 * r) * 16 + cc] = acc0[r] + acc1[r];
+    for (int r = 0; r < 4; ++r) acc0[r] += acc1[r];
+    return acc0;
+}
+
+template <int MODE>
+__device__ __forceinline__ void bams_block(const double* __restrict__ A, const double* __restrict__ Bm,
+                                           double* __restrict__ Out, int blk, int nb, int nk, double c2, double scale,
+                                           int ld) {
+    // one WORKGROUP per 16 x 16 block; the four waves' partial blocks are summed through LDS in a fixed order
+    __shared__ double red[4 * 256];
+    const int i0 = (blk / nb) * 16, j0 = (blk % nb) * 16;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, cc = l & 15, ks = l >> 4;
+    const v4d p = bams_partial<MODE>(A, Bm, i0, j0, w, nk, c2, ld);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w * 256 + (ks + 4 * r) * 16 + cc] = p[r];
     __syncthreads();
     const int t = threadIdx.x;                               // element (t >> 4, t & 15) of the block
     const double v = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
@@ -195,51 +208,59 @@ __global__ __launch_bounds__(256) void k_bam_ns_step(int n, int ld, int k, doubl
 // word written by k_bam_ns_step0: no synchronisation, possibly stale).  If this call's k* turns out larger, the missing
 // steps kenq .. k*-1 are executed HERE by one workgroup -- slow (one CU) but exact, so a stale guess costs time, never
 // correctness; normally the kernel returns at once.  Same products, same order, same ping-pong parity.
-template <int MODE>
-__device__ __forceinline__ void bams_block_wave(const double* A, const double* Bm, double* Out, int blk, int nb, int nk,
-                                                double c2, double scale, int ld) {
-    const int i0 = (blk / nb) * 16, j0 = (blk % nb) * 16;
-    const int l = threadIdx.x & 63, cc = l & 15, ks = l >> 4;
-    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-    for (int s0 = 0; s0 < nk; s0 += 12) {
-        double a[12], b[12];
+// Round 5: BIT-IDENTICAL to the multi-workgroup steps.  The 16 waves form four groups of four; a group plays one workgroup of
+// k_bam_ns_zy / k_bam_ns_step: wave q of the group computes the partial block of wave q there (bams_partial: same k-steps, same
+// batches, same accumulator chains), the four partials meet in the group's LDS slice and are summed in the same order.  So
+// (mu, S) no longer depend on how stale the hint was -- what the sharded fits' "replicas stay bit-identical" rests on.
+// (the barriers sit OUTSIDE every group-dependent branch: all 16 waves execute the same two barriers per block slot)
+__device__ __forceinline__ void bams_group_finish(const v4d& p, bool active, double* Out, int i0, int j0, double scale, int ld,
+                                                  double* red /* this group's 4 x 256 */) {
+    const int q = (threadIdx.x >> 6) & 3, l = threadIdx.x & 63, cc = l & 15, ks = l >> 4;
+    if (active) {
 #pragma unroll
-        for (int u = 0; u < 12; ++u) {
-            const int k = 4 * (s0 + u) + ks;
-            const int kc = k < ld ? k : ld - 1;
-            const double av = A[(size_t)(i0 + cc) * ld + kc];
-            const double bv = Bm[(size_t)kc * ld + j0 + cc];
-            a[u] = MODE == 2 ? ((kc == i0 + cc ? 1.5 : 0.0) - 0.5 * c2 * av) : av;
-            b[u] = MODE == 1 ? ((kc == j0 + cc ? 1.5 : 0.0) - 0.5 * c2 * bv) : bv;
-            if (s0 + u >= nk) { a[u] = 0.0; b[u] = 0.0; }
-        }
-#pragma unroll
-        for (int u = 0; u < 12; u += 2) {
-            acc0 = GSMVI_MFMA_F64(a[u], b[u], acc0);
-            acc1 = GSMVI_MFMA_F64(a[u + 1], b[u + 1], acc1);
-        }
+        for (int r = 0; r < 4; ++r) red[q * 256 + (ks + 4 * r) * 16 + cc] = p[r];
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Out[(size_t)(i0 + ks + 4 * r) * ld + j0 + cc] = scale * (acc0[r] + acc1[r]);
+    __syncthreads();
+    if (active) {
+        const int t = threadIdx.x & 255;
+        const double v = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
+        Out[(size_t)(i0 + (t >> 4)) * ld + j0 + (t & 15)] = scale * v;
+    }
+    __syncthreads();                                         // the slice is reused by the next block
 }
 
 __global__ __launch_bounds__(1024) void k_bam_ns_tail(int n, int ld, int kenq, double* Ya, double* Za, double* Yb, double* Zb,
                                                       double* Mm, const double* coef) {
     const int kstar = (int)coef[40];
     if (kenq >= kstar || coef[42] != 0.0) return;            // the usual case: nothing left to do
-    const int nb = (n + 15) >> 4, nk = (n + 3) >> 2, w = threadIdx.x >> 6;
+    __shared__ double red_all[4 * 4 * 256];
+    const int nb = (n + 15) >> 4, nk = (n + 3) >> 2, g = threadIdx.x >> 8, q = (threadIdx.x >> 6) & 3;
+    const int nb2 = nb * nb;
+    double* red = red_all + g * 1024;
     for (int k = kenq; k < kstar; ++k) {
         const double c2 = coef[k], c = sqrt(c2);
         double* Yi = (k & 1) ? Yb : Ya;
         double* Zi = (k & 1) ? Zb : Za;
         double* Yo = (k & 1) ? Ya : Yb;
         double* Zo = (k & 1) ? Za : Zb;
-        for (int blk = w; blk < nb * nb; blk += 16) bams_block_wave<0>(Zi, Yi, Mm, blk, nb, nk, 0.0, 1.0, ld);
+        for (int base = 0; base < nb2; base += 4) {          // M = Z Y   (block-uniform trip count: every wave reaches every barrier)
+            const int blk = base + g;
+            const bool act = blk < nb2;
+            const int i0 = (blk / nb) * 16, j0 = (blk % nb) * 16;
+            v4d p = {0.0, 0.0, 0.0, 0.0};
+            if (act) p = bams_partial<0>(Zi, Yi, i0, j0, q, nk, 0.0, ld);
+            bams_group_finish(p, act, Mm, i0, j0, 1.0, ld, red);
+        }
         __threadfence_block();
         __syncthreads();
-        for (int blk = w; blk < 2 * nb * nb; blk += 16) {
-            if (blk < nb * nb) bams_block_wave<1>(Yi, Mm, Yo, blk, nb, nk, c2, c, ld);
-            else bams_block_wave<2>(Mm, Zi, Zo, blk - nb * nb, nb, nk, c2, c, ld);
+        for (int base = 0; base < 2 * nb2; base += 4) {      // blocks [0, nb^2): Y' = c Y T, the rest: Z' = c T Z
+            const int blk = base + g;
+            const bool act = blk < 2 * nb2, isy = blk < nb2;
+            const int bq = isy ? blk : blk - nb2;
+            const int i0 = (bq / nb) * 16, j0 = (bq % nb) * 16;
+            v4d p = {0.0, 0.0, 0.0, 0.0};
+            if (act) p = isy ? bams_partial<1>(Yi, Mm, i0, j0, q, nk, c2, ld) : bams_partial<2>(Mm, Zi, i0, j0, q, nk, c2, ld);
+            bams_group_finish(p, act, isy ? Yo : Zo, i0, j0, c, ld, red);
         }
         __threadfence_block();
         __syncthreads();

@@ -110,10 +110,13 @@ def test_device_matrix_function_at_extreme_scales(B, scale, reg, well_posed):
     assert bwd < 1e-13 and np.array_equal(S, S.T) and np.all(np.isfinite(S))
 
 
-@pytest.mark.parametrize("D,B,kenq", [(200, 64, 3), (1024, 128, 5), (300, 100, 1)])
+@pytest.mark.parametrize("D,B,kenq", [(200, 64, 3), (1024, 128, 5), (300, 100, 1), (1000, 70, 2)])
 def test_step_count_hint_and_tail_kernel(D, B, kenq):
-    """The multi-workgroup Newton-Schulz chain enqueues as many steps as the previous call needed (+2); when that
-    guess is too small the single-workgroup tail kernel runs the missing steps: same result as the full chain."""
+    """The multi-workgroup Newton-Schulz chain enqueues as many steps as the previous call needed (+1); when that
+    guess is too small the single-workgroup tail kernel runs the missing steps.  Round 5 (advisor): the tail sums its
+    products exactly like the multi-workgroup steps (bams_partial), so the result is BIT-IDENTICAL to the full chain --
+    (mu, S) do not depend on how stale the hint was."""
+    import torch
     import gsmvi_amd
     orc, borc = _o()
     eng = gsmvi_amd.get_engine()
@@ -130,11 +133,38 @@ def test_step_count_hint_and_tail_kernel(D, B, kenq):
     mu_h, S_h, f_h = eng.bam_update(X, G, mu0, S0, 2.0, 0.0)       # hinted by the calls above
     mu_h2, S_h2, _ = eng.bam_update(X, G, mu0, S0, 2.0, 0.0)
     assert eng.read_flag(f_f) == 0 and eng.read_flag(f_t) == 0 and eng.read_flag(f_h) == 0
-    # (the tail kernel sums its products in a different order than the multi-workgroup steps: the iteration of a cond-1e6
-    # matrix carries that to ~1e-11 in (mu, S))
-    for mu, S in ((mu_t, S_t), (mu_h, S_h), (mu_h2, S_h2)):
-        assert rel_err(mu.cpu().numpy(), mu_f.cpu().numpy()) < 1e-9
-        assert rel_err(S.cpu().numpy(), S_f.cpu().numpy()) < 1e-9
+    assert torch.equal(mu_t, mu_f) and torch.equal(S_t, S_f)       # tail = multi-workgroup steps, bit for bit
+    assert torch.equal(mu_h, mu_h2) and torch.equal(S_h, S_h2)
+    if B > 64:                                                      # (n <= 64 runs the whole iteration in ONE workgroup by default,
+        assert torch.equal(mu_h, mu_f) and torch.equal(S_h, S_f)    # k_bam_ns64: no hint, no tail, its own summation order)
+    else:
+        assert rel_err(mu_h.cpu().numpy(), mu_f.cpu().numpy()) < 1e-9 and rel_err(S_h.cpu().numpy(), S_f.cpu().numpy()) < 1e-9
+
+
+@pytest.mark.parametrize("D,B", [(1024, 128), (512, 100)])
+def test_results_do_not_depend_on_a_stale_step_count_hint(D, B):
+    """k* CHANGES between calls (advisor, round 4): an easy problem (small scores: N ~ 0, few Newton-Schulz steps) leaves a
+    small hint behind, the next call needs many more steps and the tail kernel runs them; then the other way round.  Every
+    result equals, bit for bit, the one computed with all steps enqueued -- the property the sharded factor-form fit's
+    'replicas stay bit-identical' contract needs for B > 64 (BASELINE config 4)."""
+    import torch
+    import gsmvi_amd
+    orc, _ = _o()
+    eng = gsmvi_amd.get_engine()
+    st = orc.make_update_state(D, B, seed=3)
+    X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
+    F0, _ = eng.potrf(S0)
+    Zs = eng.asarray(np.linalg.solve(np.linalg.cholesky(st["S0"]), (st["samples"] - st["mu0"]).T).T)   # X = mu0 + Z F0
+    easy, hard = G * 1e-4, G * 30.0
+    eng.set_tuning("bam_full", 1)
+    ref = {}
+    for name, g in (("easy", easy), ("hard", hard)):
+        ref[name] = eng.bam_update(X, g, mu0, S0, 1.0, 0.0)[:2] + eng.bam_factor_update(Zs, X, g, mu0, F0, 1.0)[:2]
+    eng.set_tuning("bam_full", 0)
+    for name, g in (("easy", easy), ("hard", hard), ("easy", easy), ("hard", hard), ("hard", hard)):
+        got = eng.bam_update(X, g, mu0, S0, 1.0, 0.0)[:2] + eng.bam_factor_update(Zs, X, g, mu0, F0, 1.0)[:2]
+        for a, b in zip(got, ref[name]):
+            assert torch.equal(a, b), name
 
 
 def _bam_uv(X, G, mu0, S0, reg):
