@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-point", action="store_true", help="skip the D=4096 roofline point of the covariance kernel")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-callpath", action="store_true", help="skip the host / autograd score call-path rates")
     ap.add_argument("--tune", action="append", default=[], help="name=value launch knob (experiments)")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="also measure the throughput with this many independent updates in flight (one HIP stream "
@@ -147,6 +148,118 @@ def cpu_baseline(D, B, seconds):
             "value_1_core": one_core, "best_effort_blas3_value": nb / tb,
             "cpu_jax": "unavailable (jax/jaxlib are not installed on this image and there is no network; the "
                        "numpy port stands in for the north star's CPU-JAX baseline)"}
+
+
+def _marginal_rate(run, n):
+    """marginal iterations/s from fits of n and 3n iterations (fixed costs cancel), after a full-length warm-up fit (lazy
+    library initialisation inside the first long fit would inflate t(n) and with it the rate); best of two each"""
+    run(n - 1)
+    ts = {}
+    for k in (n, 3 * n):
+        best = None
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(k - 1)
+            torch.cuda.synchronize()
+            t = time.perf_counter() - t0
+            best = t if best is None or t < best else best
+        ts[k] = best
+    return 2 * n / (ts[3 * n] - ts[n])
+
+
+class _TimedCallable:
+    """wraps a host score callable and accumulates the time spent inside it"""
+
+    def __init__(self, fn):
+        self.fn, self.t, self.calls = fn, 0.0, 0
+
+    def __call__(self, x):
+        t0 = time.perf_counter()
+        r = self.fn(x)
+        self.t += time.perf_counter() - t0
+        self.calls += 1
+        return r
+
+
+def callpath_rates(D, B, methods=("auto",), n_fast=300, n_host=60, loop_variant=False):
+    """Fit-iteration rates through the DROP-IN call path (round-4 verdict, item 4): the score callables a user of the reference
+    brings, beside the built-in device score every other rate uses.
+      native                    GaussianTarget.lp_g (device kernel)
+      host_lp_g                 a numpy callable as examples/example_gsm_numpy.py:24-29 (vectorised over the rows): samples go
+                                device -> host and scores host -> device every iteration (gsm_numpy.py:117)
+      autograd_lp_g             score_from_logp of a torch log-density (examples/example_gsm.py:34-35: jit(grad(sum lp)))
+      autograd_lp_g_graph_safe  the same, marked capturable: forward + backward replay inside the fit's hipGraph blocks
+      *_diag_target             a target with DIAGONAL precision, whose host score is an elementwise product: there the engine's
+                                own share of a host iteration is not buried under numpy's GEMM (0.2 - 3 ms per call at c3)
+    host_fn_us = mean time inside the host callable during the timed fits; overhead_us = iteration_us - host_fn_us -
+    iteration_us of the native score on the same target."""
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    dev = eng.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(100)
+    kw = dict(dtype=torch.float64, device=dev, generator=g)
+    m = torch.rand(D, **kw)
+    L = torch.randn(D, D, **kw)
+    cov = L @ L.T + 1e-3 * torch.eye(D, dtype=torch.float64, device=dev)
+    P = torch.linalg.inv(cov)
+    P = (0.5 * (P + P.T)).contiguous()
+    mh, Ph = m.cpu().numpy(), P.cpu().numpy()
+    tgt = gsmvi_amd.GaussianTarget(mh, precision=Ph)
+    pdh = (0.5 + torch.rand(D, **kw)).cpu().numpy()
+    tgt_d = gsmvi_amd.GaussianTarget(mh, precision=np.diag(pdh))
+
+    def host_lp_g(x):                                   # examples/example_gsm_numpy.py:24-29, vectorised over the rows
+        assert len(x.shape) == 2
+        return -(x - mh) @ Ph
+
+    def host_lp_g_loop(x):                              # the example's literal per-row loop
+        assert len(x.shape) == 2
+        return np.array([-1.0 * np.dot(Ph, x[i] - mh) for i in range(x.shape[0])])
+
+    def host_lp_g_diag(x):
+        assert len(x.shape) == 2
+        return -(x - mh) * pdh
+
+    def logp(x):                                        # torch log-density, one value per row
+        r = x - m
+        return -0.5 * ((r @ P) * r).sum(-1)
+
+    scores = {"native": (tgt, tgt.lp_g), "host_lp_g": (tgt, host_lp_g),
+              "autograd_lp_g": (tgt, gsmvi_amd.score_from_logp(logp)),
+              "autograd_lp_g_graph_safe": (tgt, gsmvi_amd.score_from_logp(logp, graph_safe=True)),
+              "native_diag_target": (tgt_d, tgt_d.lp_g), "host_lp_g_diag_target": (tgt_d, host_lp_g_diag)}
+    if loop_variant:
+        scores["host_lp_g_loop"] = (tgt, host_lp_g_loop)
+    ent = {"D": D, "B": B}
+    for method in methods:
+        r = {}
+        for sname, (tg, fn) in scores.items():
+            host = sname.startswith("host")
+            f = _TimedCallable(fn) if host else fn
+            gsm = gsmvi_amd.GSM(D, tg.lp, f)
+            n = n_fast if method != "dense" else max(50, n_fast // 2)
+            if sname == "host_lp_g" and D >= 1024:
+                n = n_host
+            fkw = {"graph": True} if (sname.endswith("graph_safe") and method != "dense") else {}
+            try:
+                rate = _marginal_rate(lambda k: gsm.fit(1, niter=k, batch_size=B, verbose=False, method=method, **fkw), n)
+            except Exception as e:                      # reported, never hidden
+                r[sname] = {"error": f"{type(e).__name__}: {e}"[:200]}
+                continue
+            r[sname] = {"it_per_s": rate, "iteration_us": 1e6 / rate}
+            if host:
+                r[sname]["host_fn_us"] = f.t / max(f.calls, 1) * 1e6
+            if fkw:
+                r[sname]["graph_replays"] = int(getattr(gsm, "graph_replays", 0))
+        for sname, v in r.items():
+            base = r.get("native_diag_target" if sname.endswith("diag_target") else "native", {}).get("iteration_us")
+            if "iteration_us" not in v or base is None or sname.startswith("native"):
+                continue
+            v["overhead_us"] = v["iteration_us"] - v.get("host_fn_us", 0.0) - base
+        ent[method] = r
+    return ent
 
 
 def launch_ranks(n):
@@ -439,10 +552,10 @@ def main():
             mfma_util = next((v.get("util") for k, v in (tj.get("mfma_util") or {}).items() if "k_gsm_cov_sym" in k), None)
         except Exception:
             traffic = None
-    sym = D % 32 == 0 and B in (16, 32, 64)
+    sym = D % 2 == 0 and B <= 128
     # bytes the selected kernel really moves: the symmetric kernel reads only the upper triangle of S0
     # (4 D^2 + the diagonal tiles) and writes all of S (8 D^2); the generic one reads and writes 8 D^2 each
-    nt32 = D // 32
+    nt32 = (D + 31) // 32
     moved = ((nt32 * (nt32 + 1) // 2) * 32 * 32 * 8.0 + 8.0 * D * D + 16.0 * B * D) if sym else alg_bytes_update
     roofline = {"bound": "hbm", "kernel": "k_gsm_cov_sym" if sym else "k_gsm_cov_update",
                 "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -510,7 +623,8 @@ def main():
             torch.cuda.synchronize()
             copy_us = (time.perf_counter() - tc0) / (20 * n_inst) * 1e6
             roofline["attainable_peak"] = attain
-            roofline["frac_of_attainable"] = achieved / attain
+            # moved bytes against a moved-bytes copy rate (round-4 verdict: the former algorithmic / moved ratio could exceed 1)
+            roofline["frac_of_attainable_moved"] = roofline["achieved_moved"] / attain
             roofline["plain_copy_same_size_us"] = copy_us
         except Exception as e:                  # calibration only
             roofline["attainable_peak"] = f"failed: {type(e).__name__}"
@@ -534,9 +648,13 @@ def main():
             roofline["large_D_point"] = {"D": DL, "B": BL, "kernel": "k_gsm_cov_sym_p (persistent form of k_gsm_cov_sym)",
                                          "avg_kernel_us": tms * 1e3,
                                          "algorithmic_bytes_per_launch": bl, "achieved": bl / (tms * 1e-3) / 1e9,
-                                         "frac": bl / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                         "frac_of_attainable": (bl / (tms * 1e-3) / 1e9 / roofline["attainable_peak"])
-                                         if isinstance(roofline.get("attainable_peak"), float) else None}
+                                         "frac": bl / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            ntl = DL // 32
+            mvl = (ntl * (ntl + 1) // 2) * 32 * 32 * 8.0 + 8.0 * DL * DL + 16.0 * BL * DL      # upper triangle read, all of S written
+            roofline["large_D_point"]["moved_bytes_per_launch"] = mvl
+            roofline["large_D_point"]["achieved_moved"] = mvl / (tms * 1e-3) / 1e9
+            if isinstance(roofline.get("attainable_peak"), float):
+                roofline["large_D_point"]["frac_of_attainable_moved"] = mvl / (tms * 1e-3) / 1e9 / roofline["attainable_peak"]
             del li
             torch.cuda.empty_cache()
         except Exception as e:                  # secondary figure only
@@ -560,6 +678,19 @@ def main():
             except Exception as e:      # reported, never hidden
                 fit_rate[method] = f"failed: {type(e).__name__}: {e}"
 
+    # ---- the drop-in call path: host numpy score and torch-autograd score (round-4 verdict, item 4), c3 (this shape) and c2 ----
+    if fit_rate is not None and rank == 0 and not args.no_callpath:
+        try:
+            cp = {"here": callpath_rates(D, B, methods=("auto",), n_fast=200, n_host=40)}
+            if (D, B) != (256, 8):
+                cp["c2"] = callpath_rates(256, 8, methods=("auto",), n_fast=300)
+            for key in ("host_lp_g", "autograd_lp_g", "autograd_lp_g_graph_safe", "host_lp_g_diag_target"):
+                v = cp["here"]["auto"].get(key, {})
+                fit_rate[key] = v.get("it_per_s", v.get("error"))
+            fit_rate["call_path"] = cp
+        except Exception as e:                  # reported, never hidden
+            fit_rate["call_path"] = f"failed: {type(e).__name__}: {e}"
+
     # roofline of the DEFAULT fit iteration (factor form): F is streamed four times and written once per iteration --
     # sampler 8 D^2, score 8 D^2 (the precision matrix), W = G F^T 8 D^2, V F 8 D^2, update 16 D^2 = 48 D^2 bytes
     fit_roofline = None
@@ -573,8 +704,10 @@ def main():
            "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
-           "config": {"workload": f"BASELINE configs[2]: D={D} dense-cov Gaussian target, B={B}, one GSM update "
-                                  f"per step", "D": D, "B": B, "instances": n_inst,
+           "config": {"workload": (("BASELINE configs[2]: " if (D, B) == (1024, 32) else
+                                    "BASELINE configs[1]: " if (D, B) == (256, 8) else "not a BASELINE config: ") +
+                                   f"D={D} dense-cov Gaussian target, B={B}, one GSM update per step"),
+                      "D": D, "B": B, "instances": n_inst,
                       "ring_bytes": n_inst * per_inst, "launch": launch, "warmup_steps_run": warm_done,
                       "parallelism": "single GPU" if not use_dist else
                       (f"covariance row blocks x{world} + RCCL all-gather of SG column slices" if rows else

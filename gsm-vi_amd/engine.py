@@ -38,6 +38,8 @@ class HipEngine:
         self._max_B = 0
         self._tuning = {}
         self._retired = []         # outgrown contexts: kept alive, a captured hipGraph may still launch into their workspace
+        self._stage = {}           # shape -> [pinned staging tensor, event behind its last host -> device copy] (from_host)
+        self._hs = {}              # shape -> pinned buffers of the host-callable round trip (host_score)
         if max_D and max_B:
             self._ensure(max_D, max_B)
 
@@ -103,6 +105,87 @@ class HipEngine:
     def to_numpy(self, t):
         return t.detach().to("cpu").numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
 
+    # ---- the host-callable round trip of the fit loops (gsmvi/gsm_numpy.py:117: vs = self.lp_g(samples) on host arrays) ----
+    def to_host(self, t):
+        """A device tensor as a FRESH numpy array, through pinned memory: one non-blocking copy on the current stream and
+        one stream synchronisation (a pageable ``.cpu()`` stages through the driver's bounce buffer and blocks twice).  The
+        array owns its (pinned) storage -- torch's caching host allocator hands the block out again only after the array is
+        dropped -- so a callable that keeps its argument (a recording wrapper, say) is not overwritten by the next iteration."""
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t.detach(), non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return h.numpy()
+
+    def from_host(self, a, out=None):
+        """A host array as a float64 device tensor (``out`` when given), through a pinned staging buffer owned by the engine:
+        a host memcpy into the buffer, then ONE non-blocking copy on the current stream -- no host synchronisation.  The
+        buffer of a shape is reused; an event recorded behind its last copy is waited for before it is overwritten (the fit
+        loops never get there early: their next device -> host copy is ordered behind it on the same stream)."""
+        if isinstance(a, torch.Tensor):
+            a = a.detach().cpu().numpy()
+        a = np.asarray(a)
+        key = tuple(a.shape)
+        ent = self._stage.get(key)
+        if ent is None:
+            if len(self._stage) >= 8:                          # (a fit uses one or two shapes; do not hoard pinned memory)
+                self._stage.clear()
+            ent = self._stage[key] = [torch.empty(a.shape, dtype=torch.float64, pin_memory=True), None]
+        buf, ev = ent
+        if ev is not None:
+            ev.synchronize()
+        np.copyto(buf.numpy(), a, casting="unsafe")           # (also the float32 -> float64 conversion of gsm_numpy.py:47)
+        out = self.empty(*a.shape) if out is None else out
+        assert tuple(out.shape) == key, f"lp_g returned shape {key}, expected {tuple(out.shape)}"
+        out.copy_(buf, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        ent[1] = ev
+        return out
+
+    def host_score(self, lp_g, X, out=None):
+        """vs = lp_g(samples) for a HOST callable (gsm_numpy.py:117; examples/example_gsm_numpy.py:24-29): samples to the host,
+        the user's numpy code, scores back to the device.  Per call: one non-blocking device -> host copy into a pinned
+        buffer, ONE stream synchronisation, the callable, a host memcpy of its result into a pinned staging buffer and one
+        non-blocking host -> device copy -- no allocation, no event, no second synchronisation (round 5; before: pageable
+        ``.cpu()`` and ``.to(device)``, two blocking copies through the driver's bounce buffers).
+        Buffers are cached per shape.  The samples array handed to the callable comes from a small pool and is reused only
+        when nobody else holds a reference to it (a callable that records its argument keeps it intact); the score staging
+        buffer is overwritten only behind this call's own synchronisation, which orders it behind the previous upload on the
+        same stream (a different stream since the last call: a full device synchronisation first)."""
+        import sys
+        key = tuple(X.shape)
+        hs = self._hs.get(key)
+        if hs is None:
+            if len(self._hs) >= 8:
+                self._hs.clear()
+            gp = torch.empty(key, dtype=torch.float64, pin_memory=True)
+            hs = self._hs[key] = {"pool": [], "gpin": gp, "gnp": gp.numpy(), "stream": None}
+        stream = torch.cuda.current_stream(self.device)
+        if hs["stream"] is not None and hs["stream"] != stream.cuda_stream:
+            torch.cuda.synchronize(self.device)
+        hs["stream"] = stream.cuda_stream
+        ent = None
+        for e in hs["pool"]:
+            if sys.getrefcount(e[1]) <= 3:                    # the pool's list entry, `e[1]` here, getrefcount's argument
+                ent = e
+                break
+        if ent is None:
+            xp = torch.empty(key, dtype=torch.float64, pin_memory=True)
+            ent = (xp, xp.numpy())
+            if len(hs["pool"]) < 4:
+                hs["pool"].append(ent)
+        ent[0].copy_(X.detach(), non_blocking=True)
+        stream.synchronize()                                  # (polling an event instead was measured: no difference)
+        g = lp_g(ent[1])
+        if isinstance(g, torch.Tensor):
+            g = g.detach().cpu().numpy()
+        g = np.asarray(g)
+        out = self.empty(*key) if out is None else out
+        assert g.shape == key and tuple(out.shape) == key, f"lp_g returned shape {g.shape}, expected {key}"
+        np.copyto(hs["gnp"], g, casting="unsafe")             # (also float32 -> float64: gsm_numpy.py:47 returns float64)
+        out.copy_(hs["gpin"], non_blocking=True)
+        return out
+
     def empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float64, device=self.device)
 
@@ -120,7 +203,7 @@ class HipEngine:
 
     def normal_from_host(self, z_host):
         """Upload a host (B,D) array of standard normals (parity mode: numpy MT19937 stream)."""
-        return torch.as_tensor(z_host, dtype=torch.float64).to(self.device, non_blocking=False)
+        return self.from_host(z_host)
 
     def normal(self, B, D, seed, call=0, out=None, raw=None):
         """(B, D) standard normals from the counter-based device stream (csrc/gsmvi_rng.hip): a pure function of

@@ -215,10 +215,10 @@ class GSM:
                 rank = _dist.get_rank(group) if _dist.is_initialized() else 0
                 lo, hi = shard_bounds(B, world, rank)
                 Xl = X[lo:hi]
-                vl = self.lp_g(Xl) if native else eng.asarray(self.lp_g(eng.to_numpy(Xl)))
+                vl = self.lp_g(Xl) if native else eng.host_score(self.lp_g, Xl)
                 sharded_gsm_update(eng, Xl, vl, mean_t, cov_t, group=group, out=(mean_new, cov_new))
             else:
-                vs = self.lp_g(X) if native else eng.asarray(self.lp_g(eng.to_numpy(X)))
+                vs = self.lp_g(X) if native else eng.host_score(self.lp_g, X)
                 eng.gsm_update(X, vs, mean_t, cov_t, out=(mean_new, cov_new))
             nevals += B
             if shard and root_potrf:                              # opt-in: one rank factors, the others receive
@@ -315,7 +315,7 @@ class GSM:
             if native:
                 vs = self.lp_g(X, out=Gbuf) if takes_out else self.lp_g(X)
             else:
-                vs = eng.asarray(self.lp_g(eng.to_numpy(X)))
+                vs = eng.host_score(self.lp_g, X, out=Gbuf)
             if shard:
                 sharded_gsm_factor_update(eng, Zi, X, vs, mu_a, F_a, lo, group=group, out=(mu_b, F_b),
                                           flag=flag, n_reverts=n_rev)

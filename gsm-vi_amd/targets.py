@@ -24,8 +24,12 @@ def device_score(fn=None, *, graph_safe=False):
     return mark(fn) if fn is not None else mark
 
 
-def score_from_logp(logp):
-    """Score via torch autograd of a *summed* log-probability (examples/example_gsm.py:34-35)."""
+def score_from_logp(logp, graph_safe=False):
+    """Score via torch autograd of a *summed* log-probability (examples/example_gsm.py:34-35: jit(grad(sum lp))).
+    ``graph_safe=True`` promises that ``logp`` is capturable (stream-ordered torch ops of fixed shapes, no host
+    synchronisation, no data-dependent control flow): the factor-form fit then records forward AND backward of every
+    iteration of a block into its hipGraph -- the ~12 torch dispatches per score evaluation (90 - 160 us of host time at
+    D = 1024) replay as part of one graph launch, which is what jit does for the reference's JAX score."""
     def lp_g(x):
         xg = x.detach().clone().requires_grad_(True)
         with torch.enable_grad():
@@ -33,6 +37,7 @@ def score_from_logp(logp):
             (g,) = torch.autograd.grad(total, xg)
         return g.detach()
     lp_g.device_native = True
+    lp_g.graph_safe = bool(graph_safe)
     return lp_g
 
 

@@ -128,9 +128,33 @@ def test_bam_fit_converges_and_schedule_counts_calls():
     m, cov_t, P = orc.make_gaussian_target(D, 17)
     reg = Regularizers()
     bam = BaM(D, None, lambda x: orc.gaussian_score(x, m, P), use_lowrank=True, engine=OracleEngine())
-    mean, cov = bam.fit(99, regf=reg.custom(lambda i: 100 / (1 + i)), niter=100, batch_size=2, verbose=False)
-    assert reg.counter == 101
+    mean, cov = bam.fit(99, regf=reg.custom(lambda i: 100 / (1 + i)), niter=100, batch_size=2, verbose=False, method="dense")
+    assert reg.counter == 101 and bam.method_used == "dense"
     assert np.allclose(mean, m, atol=1e-3) and np.allclose(cov, cov_t, atol=1e-3, rtol=1e-3)
+
+
+def test_bam_default_method_rule():
+    """BaM.fit(method="auto") (opt-in; the default is the reference's dense loop): the factor form wherever it exists for the
+    call and the jitter is at most the reference's default (bam.py:140: 1e-6); anything else is the dense loop."""
+    D = 6
+    m, cov_t, P = orc.make_gaussian_target(D, 17)
+    lp_g = lambda x: orc.gaussian_score(x, m, P)      # noqa: E731
+    reg = Regularizers()
+
+    def used(**kw):
+        bam = BaM(D, None, lp_g, engine=OracleEngine())
+        bam.fit(3, regf=reg.constant(5.0), niter=2, verbose=False, **{"method": "auto", **kw})
+        return bam.method_used
+
+    assert BaM(D, None, lp_g, engine=OracleEngine()).fit(3, regf=reg.constant(5.0), niter=1, batch_size=3,
+                                                         verbose=False) is not None
+    assert used(batch_size=3) == "factor"                         # 2B <= D, default jitter
+    assert used(batch_size=3, jitter=0.0) == "factor"
+    assert used(batch_size=3, jitter=1e-3) == "dense"             # a larger jitter is a request for the shift itself
+    assert used(batch_size=4) == "dense"                          # 2B > D: the factor form does not exist
+    assert used(batch_size=2, sampler="svd") == "dense"           # the reference's legacy sampler needs the covariance
+    assert used(batch_size=2, forced_samples=[np.zeros((2, D))] * 3) == "dense"
+    assert used(batch_size=3, method="dense") == "dense"
 
 
 def test_bam_factor_fit_runs_the_same_loop():
