@@ -51,11 +51,10 @@ def root_potrf(eng, S, R, flag, group=None, root=0):
     if rank == root:
         eng.potrf(S, out=R, flag=flag)
     src = dist.get_global_rank(group, root) if group is not None else root
-    tR, tf = _as_torch(R), _as_torch(flag if not hasattr(flag, "v") else np.array([flag.v], dtype=np.int32))
+    tR, tf = _as_torch(R), eng.flag_tensor(flag)           # (the engine knows what its flags are: a device int32 tensor here)
     _broadcast(tR, src, group)
     _broadcast(tf, src, group)
-    if hasattr(flag, "v"):                       # the oracle-backed engine of the CPU tests keeps its flag in .v
-        flag.v = int(tf[0])
+    eng.flag_assign(flag, tf)
     return R, flag
 
 
@@ -143,7 +142,7 @@ def row_sharded_gsm_update(eng, X, G, mu0, S0_rows, group=None, out=None):
     return eng.gsm_apply_rows(rec, mu0, S0_rows, lo, out=out)
 
 
-def sharded_bam_update(eng, X_local, G_local, mu0, S0, reg, jitter=0.0, group=None, out=None, flag=None):
+def sharded_bam_update(eng, X_local, G_local, mu0, S0, reg, jitter=0.0, group=None, out=None, flag=None, stats=None):
     """(mu, S, flag) of the BaM update for the union of all ranks' samples (gsmvi/bam.py:72-114;
     BASELINE config 4: B=128 sharded 16 per GPU).  BaM's statistics couple all samples (batch means
     and the (B+1) x (B+1) matrix function), so ranks all-gather their (B/P, D) samples and scores
@@ -157,13 +156,17 @@ def sharded_bam_update(eng, X_local, G_local, mu0, S0, reg, jitter=0.0, group=No
     packed[:, :D] = X_local
     packed[:, D:] = G_local
     allp = eng.empty(Bl * world, 2 * D)
+    if stats is not None:                        # what this rank contributes to the ONE collective of the update (tests: SURVEY 8(e))
+        stats["bytes_per_rank"] = int(np.prod(packed.shape)) * 8
+        stats["collectives"] = stats.get("collectives", 0) + 1
     _all_gather(_as_torch(allp), _as_torch(packed), group)
     if not isinstance(allp, torch.Tensor):
         allp = _as_torch(allp).numpy()
     return eng.bam_update(allp[:, :D], allp[:, D:], mu0, S0, reg, jitter, out=out, flag=flag)
 
 
-def sharded_bam_factor_update(eng, Z, X_local, G_local, mu0, F0, reg, group=None, out=None, flag=None, n_reverts=None):
+def sharded_bam_factor_update(eng, Z, X_local, G_local, mu0, F0, reg, group=None, out=None, flag=None, n_reverts=None,
+                              stats=None):
     """(mu, F, flag) of the factor-form BaM update (Sigma = F^T F; engine.bam_factor_update) for the union of all ranks'
     samples -- BASELINE config 4 ("B=128 sharded 16/GPU") without a D x D covariance or a D^3 step on any rank.
     Z (B, D): the whitened draws of ALL samples, replicated (every rank draws the same counter-based stream);
@@ -178,6 +181,9 @@ def sharded_bam_factor_update(eng, Z, X_local, G_local, mu0, F0, reg, group=None
     packed[:, :D] = X_local
     packed[:, D:] = G_local
     allp = eng.empty(Bl * world, 2 * D)
+    if stats is not None:
+        stats["bytes_per_rank"] = int(np.prod(packed.shape)) * 8
+        stats["collectives"] = stats.get("collectives", 0) + 1
     _all_gather(_as_torch(allp), _as_torch(packed), group)
     if not isinstance(allp, torch.Tensor):
         allp = _as_torch(allp).numpy()

@@ -201,6 +201,14 @@ class HipEngine:
     def read_flag(self, flag):
         return int(flag.item())          # synchronises
 
+    def flag_tensor(self, flag):
+        """the tensor a collective moves for a flag (dist.root_potrf): the flag itself"""
+        return flag
+
+    def flag_assign(self, flag, t):
+        """adopt the received value (nothing to do: the collective wrote into the flag's own storage)"""
+        return flag
+
     def normal_from_host(self, z_host):
         """Upload a host (B,D) array of standard normals (parity mode: numpy MT19937 stream)."""
         return self.from_host(z_host)

@@ -47,6 +47,14 @@ class OracleEngine:
     def read_flag(self, f):
         return f.v
 
+    def flag_tensor(self, f):                    # what dist.root_potrf broadcasts for a flag
+        import torch
+        return torch.tensor([f.v], dtype=torch.int32)
+
+    def flag_assign(self, f, t):
+        f.v = int(t[0])
+        return f
+
     def normal_from_host(self, z):
         return np.asarray(z, dtype=np.float64)
 

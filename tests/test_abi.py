@@ -144,7 +144,7 @@ def test_plain_c_program_drives_the_abi(tmp_path, D, B):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("D,B", [(1024, 32), (100, 6)])
+@pytest.mark.parametrize("D,B", [(1024, 32), (100, 6), (1024, 128)])      # (1024, 128): BASELINE config 4's shape (world 1 here)
 def test_rccl_taking_entry_point_from_plain_c(tmp_path, D, B):
     """tests/abi_c/rccl_sharded.c: a C program owning the ncclComm_t drives gsmvi_gsm_update_sharded_f64,
     gsmvi_gsm_factor_update_sharded_f64 and gsmvi_bam_update_sharded_f64 (local stage -> ncclAllGather on the caller's

@@ -151,3 +151,95 @@ def test_two_hip_backed_ranks_share_one_gpu():
         assert o["method"] == "factor" and o["rows"] == [4]
         assert o["fit_err"] < 1e-9 and o["fit_err_dense"] < 1e-9 and o["bam_err"] < 1e-8, o
         assert o["bamf_err"] < 1e-9 and o["same_bamf"] and o["bamf_fit_err"] < 1e-8 and o["bam_root_err"] == 0.0, o
+
+
+def _worker_c4(rank, world, port, q):
+    """BASELINE config 4 at its NAMED partition: BaM update, D = 1024, B = 128 sharded 16 per rank across 8 ranks -- on the one
+    GPU the pool has (8 processes, 8 engine contexts on cuda:0, gloo rendezvous; RCCL refuses two ranks per device)."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    try:
+        import gsmvi_amd
+        from gsmvi_amd.dist import sharded_bam_update, sharded_bam_factor_update, shard_bounds
+        torch.cuda.set_device(0)
+        eng = gsmvi_amd.HipEngine(0)
+        D, B = 1024, 128
+        g = torch.Generator(device="cuda")
+        g.manual_seed(11)                                  # same state on every rank (replicated mu, Sigma / F; same draws)
+        kw = dict(dtype=torch.float64, device="cuda", generator=g)
+        A = torch.randn(D, D, **kw)
+        S0 = A @ A.T / D + 0.1 * torch.eye(D, dtype=torch.float64, device="cuda")
+        S0 = (0.5 * (S0 + S0.T)).contiguous()
+        F0, fl = eng.potrf(S0)
+        mu0 = torch.randn(D, **kw)
+        Z = eng.normal(B, D, 7, 0)
+        X = eng.sample(Z, mu0, F0)
+        Pm = torch.randn(D, D, **kw)
+        P = (Pm @ Pm.T / D + 0.5 * torch.eye(D, dtype=torch.float64, device="cuda")).contiguous()
+        G = eng.gaussian_score(X, torch.rand(D, **kw), 0.5 * (P + P.T))
+        lo, hi = shard_bounds(B, world, rank)
+        out["rows"] = hi - lo
+        # the single-rank HIP updates on the whole batch: what every replica must reproduce
+        mu_1, S_1, f1 = eng.bam_update(X, G, mu0, S0, 1.0, 0.0)
+        mu_f1, F_1, ff1 = eng.bam_factor_update(Z, X, G, mu0, F0, 1.0)
+        st_d, st_f = {}, {}
+        mu_s, S_s, fs = sharded_bam_update(eng, X[lo:hi], G[lo:hi], mu0, S0, 1.0, 0.0, stats=st_d)
+        mu_sf, F_s, fsf = sharded_bam_factor_update(eng, Z, X[lo:hi], G[lo:hi], mu0, F0, 1.0, stats=st_f)
+        assert eng.read_flag(f1) == 0 and eng.read_flag(ff1) == 0 and eng.read_flag(fs) == 0 and eng.read_flag(fsf) == 0
+        out["bytes"] = (st_d["bytes_per_rank"], st_f["bytes_per_rank"], st_d["collectives"], st_f["collectives"])
+        rel = lambda a, b: float((a - b).abs().max() / b.abs().max())      # noqa: E731
+        out["err_dense"] = max(rel(mu_s, mu_1), rel(S_s, S_1))
+        out["err_factor"] = max(rel(mu_sf, mu_f1), rel(F_s, F_1))
+        out["equal_single"] = bool(torch.equal(S_s, S_1) and torch.equal(mu_s, mu_1) and torch.equal(F_s, F_1)
+                                   and torch.equal(mu_sf, mu_f1))
+        t = torch.cat([mu_s, S_s.reshape(-1), mu_sf, F_s.reshape(-1)]).cpu()
+        gathered = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        out["replicas_identical"] = all(torch.equal(gathered[0], x) for x in gathered)
+        # a second call with other scores: k* of the Newton-Schulz chain moves, the hint of the first call is stale on every
+        # rank -- replicas must still agree bit for bit (advisor, round 4)
+        mu_s2, S_s2, _ = sharded_bam_update(eng, X[lo:hi], G[lo:hi] * 30.0, mu0, S0, 1.0, 0.0)
+        t2 = torch.cat([mu_s2, S_s2.reshape(-1)]).cpu()
+        g2 = [torch.empty_like(t2) for _ in range(world)]
+        dist.all_gather(g2, t2)
+        out["replicas_identical_2"] = all(torch.equal(g2[0], x) for x in g2)
+        out["ok"] = True
+    except Exception:                                        # noqa: BLE001
+        import traceback
+        out["ok"] = False
+        out["exc"] = traceback.format_exc()
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_config4_named_partition_eight_ranks_on_one_gpu():
+    """BASELINE config 4: "BaM update, D=1024, B=128 sharded 16/GPU across 8" (reference loop: bam.py:178-212).  Eight
+    HIP-backed ranks on the one GPU of the pool: each holds 16 rows, ONE all-gather per update moves 2 x 16 x 1024 doubles =
+    256 KiB per rank -- never a D x D matrix --, every replica reproduces the single-rank HIP update bit for bit
+    (the gathered rows ARE the batch) and the replicas are bit-identical, also when the step-count hint is stale."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 8
+    procs = [ctx.Process(target=_worker_c4, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    for r in range(world):
+        o = res[r]
+        assert o["ok"], o.get("exc")
+        assert o["rows"] == 16
+        assert o["bytes"] == (256 * 1024, 256 * 1024, 1, 1), o["bytes"]
+        assert o["err_dense"] <= 1e-12 and o["err_factor"] <= 1e-12, o
+        assert o["equal_single"] and o["replicas_identical"] and o["replicas_identical_2"], o
