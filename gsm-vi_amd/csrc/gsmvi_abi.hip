@@ -270,6 +270,7 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     else if (!strcmp(name, "bam_full")) ctx->tune_bam_full = value;
     else if (!strcmp(name, "bam_kenq")) ctx->tune_bam_kenq = value;
     else if (!strcmp(name, "chain_pair")) ctx->tune_chain_pair = value;
+    else if (!strcmp(name, "lowrank_kp")) ctx->tune_lowrank_kp = value;
     else if (!strcmp(name, "scalars_nt")) ctx->tune_scalars_nt = value;
     else if (!strcmp(name, "cov_dbg")) ctx->tune_cov_dbg = value;   // ablation bits, timing experiments only
     else if (!strcmp(name, "timeline")) {                           // whole-update timeline stamps (diagnostic)
@@ -322,7 +323,7 @@ int gsmvi_debug_read_workspace(gsmvi_ctx* ctx, int region, size_t offset, double
     return GSMVI_OK;
 }
 
-// device address of a workspace region (diagnostic scripts view intermediates in place: scripts/soak_c5_debug.py)
+// device address of a workspace region (diagnostic scripts view intermediates in place)
 int gsmvi_debug_workspace_ptr(gsmvi_ctx* ctx, int region, double** out) {
     BAD_ARG(!ctx || !out || region < 0 || region > 2, "bad argument");
     *out = region == 0 ? ctx->pp : (region == 1 ? ctx->sg : ctx->small);

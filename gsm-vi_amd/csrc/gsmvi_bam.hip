@@ -682,12 +682,20 @@ __global__ __launch_bounds__(256) void k_lowrank_update(int D, int KF, const dou
 // global load of the workgroup is issued first (S0 tile in accumulator layout, then all KF rows of both operand
 // tiles, rows beyond KF as zeros); operands pass through LDS 32 rows at a time ([k][80], conflict-free for both MFMA
 // operands).  Same structure as k_gsmf_update_fast in the factor path.
-template <int NPMAX>
+// Round 5: (i) the workgroup barriers wait for LDS only (s_waitcnt lgkmcnt(0); s_barrier).  __syncthreads() carries a
+// workgroup fence that drains the vector-memory counter, and ALL operand loads of the tile are issued up front: the first
+// barrier therefore waited for the last row of the last pass, and the load phase (256 KB per CU at KF = 256) and the
+// compute phase ran strictly one after the other.  No thread reads global data written by another thread of the workgroup, so
+// only LDS needs ordering (the rule of k_gsm_cov_sym_p).  (ii) KP rows per staging pass as a template
+// parameter: 64 for KF > 96 (BASELINE config 4: 256 rows in 4 passes instead of 8 -- half the barriers).
+template <int NPMAX, int KP>
 __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, const double* __restrict__ Ft,
                                                              const double* __restrict__ Fs,
                                                              const double* __restrict__ S0, int lds0,
                                                              double* __restrict__ S, int lds, double jitter) {
-    constexpr int RS = 80, KP = 32;
+#define LR_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    constexpr int RS = 80;
+    constexpr int UQ = KP * 32 / 512;              // 16-byte units per thread, operand and pass (KP = 32: 2, KP = 64: 4)
     __shared__ __attribute__((aligned(16))) double sm[2 * KP * RS];
     const int nt = (D + 63) >> 6, np = (KF + KP - 1) / KP;    // any even D (round 5): edge tiles re-read clamped rows / columns
     const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
@@ -704,18 +712,16 @@ __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, cons
             const int rr = frow + 4 * r < D ? frow + 4 * r : D - 1, cq = fcol + 16 * blk < D ? fcol + 16 * blk : D - 1;
             s0[blk][r] = S0[(size_t)rr * lds0 + cq];
         }
-    v2d ga[NPMAX][2], gb[NPMAX][2];
+    v2d ga[NPMAX][UQ], gb[NPMAX][UQ];
 #pragma unroll
     for (int p = 0; p < NPMAX; ++p) {
         if (p < np) {                                        // block-uniform
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < UQ; ++q) {
                 const int u = q * 512 + tid, row = KP * p + (u >> 5), c2 = 2 * (u & 31);
                 const int rc = row < KF ? row : KF - 1;
-                const v2d a = *reinterpret_cast<const v2d*>(Ft + (size_t)rc * D + (I0 + c2 < D ? I0 + c2 : D - 2));
-                const v2d b = *reinterpret_cast<const v2d*>(Fs + (size_t)rc * D + (J0 + c2 < D ? J0 + c2 : D - 2));
-                ga[p][q] = row < KF ? a : (v2d){0.0, 0.0};
-                gb[p][q] = row < KF ? b : (v2d){0.0, 0.0};
+                ga[p][q] = *reinterpret_cast<const v2d*>(Ft + (size_t)rc * D + (I0 + c2 < D ? I0 + c2 : D - 2));
+                gb[p][q] = *reinterpret_cast<const v2d*>(Fs + (size_t)rc * D + (J0 + c2 < D ? J0 + c2 : D - 2));
             }
         }
     }
@@ -723,27 +729,31 @@ __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, cons
 #pragma unroll
     for (int p = 0; p < NPMAX; ++p) {
         if (p < np) {
-            if (p > 0) __syncthreads();
+            if (p > 0) LR_LDS_BARRIER();                     // the previous pass's operand reads are done
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < UQ; ++q) {
                 const int u = q * 512 + tid, row = u >> 5, c2 = 2 * (u & 31);
-                *reinterpret_cast<v2d*>(sm + row * RS + c2) = ga[p][q];
-                *reinterpret_cast<v2d*>(sm + (KP + row) * RS + c2) = gb[p][q];
+                const bool in = KP * p + row < KF;           // (rows beyond KF: clamped re-reads, staged as zeros)
+                *reinterpret_cast<v2d*>(sm + row * RS + c2) = in ? ga[p][q] : (v2d){0.0, 0.0};
+                *reinterpret_cast<v2d*>(sm + (KP + row) * RS + c2) = in ? gb[p][q] : (v2d){0.0, 0.0};
             }
-            __syncthreads();
-            double a[8], b0[8], b1[8];
+            LR_LDS_BARRIER();
             const double* ap = sm + ks * RS + 16 * wr + c;
             const double* bp = sm + (KP + ks) * RS + 32 * wc + c;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                a[s] = ap[4 * s * RS];
-                b0[s] = bp[4 * s * RS];
-                b1[s] = bp[4 * s * RS + 16];
-            }
+            for (int h = 0; h < KP / 32; ++h) {              // 8 MFMA steps (32 rows) at a time: operands to registers first
+                double a[8], b0[8], b1[8];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                acc0 = GSMVI_MFMA_F64(a[s], b0[s], acc0);
-                acc1 = GSMVI_MFMA_F64(a[s], b1[s], acc1);
+                for (int s = 0; s < 8; ++s) {
+                    a[s] = ap[(32 * h + 4 * s) * RS];
+                    b0[s] = bp[(32 * h + 4 * s) * RS];
+                    b1[s] = bp[(32 * h + 4 * s) * RS + 16];
+                }
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    acc0 = GSMVI_MFMA_F64(a[s], b0[s], acc0);
+                    acc1 = GSMVI_MFMA_F64(a[s], b1[s], acc1);
+                }
             }
         }
     }
@@ -753,6 +763,7 @@ __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, cons
         if (row < D && fcol < D) S[(size_t)row * lds + fcol] = s0[0][r] + acc0[r] + (row == fcol ? jitter : 0.0);
         if (row < D && fcol + 16 < D) S[(size_t)row * lds + fcol + 16] = s0[1][r] + acc1[r] + (row == fcol + 16 ? jitter : 0.0);
     }
+#undef LR_LDS_BARRIER
 }
 
 #define HIPCHK(expr)                                                          \
@@ -861,10 +872,13 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     const int nt = (D + 63) / 64;
     ctx->path |= (!ctx->tune_no_fast && D % 2 == 0 && n2 <= 288) ? GSMVI_PATH_LOWRANK_FAST : GSMVI_PATH_LOWRANK_GENERIC;
     if (!ctx->tune_no_fast && D % 2 == 0 && n2 <= 288) {
-        if (n2 <= 96)
-            hipLaunchKernelGGL(k_lowrank_update_fast<3>, dim3(nt * nt), dim3(512), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds, jitter);
-        else
-            hipLaunchKernelGGL(k_lowrank_update_fast<9>, dim3(nt * nt), dim3(512), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds, jitter);
+        if (n2 <= 96 || ctx->tune_lowrank_kp == 32) {
+            if (n2 <= 96)
+                hipLaunchKernelGGL((k_lowrank_update_fast<3, 32>), dim3(nt * nt), dim3(512), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds, jitter);
+            else
+                hipLaunchKernelGGL((k_lowrank_update_fast<9, 32>), dim3(nt * nt), dim3(512), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds, jitter);
+        } else
+            hipLaunchKernelGGL((k_lowrank_update_fast<5, 64>), dim3(nt * nt), dim3(512), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds, jitter);
     } else {
         hipLaunchKernelGGL(k_lowrank_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds,
                            jitter);

@@ -1182,7 +1182,11 @@ static int factor_chain_big(gsmvi_ctx* ctx, hipStream_t st, int n, int B, const 
         const double* W11 = ctx->early + 2 * 128 * 128;
         small_gemm_launch(st, OpBlkR12{n1, n2, n1, W11, w.Gam, w.Rg, n1, n, n, n1, R11, n1, w.Pm, n});
     } else {
-        cholw(true, n1, w.Gam, n, w.Rg, n, w.Pm, n, info_g, 0, 0, w.Gam);
+        // (advisor, round 4) In the factor-form BaM chain (jmode) the early job above guards this block with ITS OWN diagonal
+        // (the second block's is not known yet when it runs); the in-chain factorisation does the same, so the accept / revert
+        // decision cannot depend on the "chain_pair" knob.  The second block is guarded with the whole diagonal in both modes:
+        // an absurd entry anywhere still switches the rank-revealing rule off where it decides (G4, tests/test_gpu_factor.py).
+        cholw(true, n1, w.Gam, n, w.Rg, n, w.Pm, n, info_g, 0, 0, jmode ? nullptr : w.Gam);
         small_gemm_launch(st, OpBlkR12{n1, n2, n1, w.Pm, w.Gam, w.Rg, n, n, n, n1});
     }
     // slots while Gamma is factored: S22 and T1 in Gam1 (free until the end of the chain); A'11 -> Ap, T11 -> Tt, T's inverse

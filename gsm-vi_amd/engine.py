@@ -38,6 +38,7 @@ class HipEngine:
         self._max_B = 0
         self._tuning = {}
         self._retired = []         # outgrown contexts: kept alive, a captured hipGraph may still launch into their workspace
+        self._ctx_captured = False  # has the current context been used under stream capture (a graph may hold its pointers)
         self._stage = {}           # shape -> [pinned staging tensor, event behind its last host -> device copy] (from_host)
         self._hs = {}              # shape -> pinned buffers of the host-callable round trip (host_score)
         if max_D and max_B:
@@ -52,8 +53,21 @@ class HipEngine:
             # The outgrown context is RETIRED, not destroyed: kernels enqueued on it may still be running and, worse, a hipGraph
             # captured earlier (GSM.fit's replayed blocks, a user's torch.cuda.graph around engine calls) holds raw pointers
             # into its workspace.  It costs its workspace (~100 MiB at D=4096) until release_retired() / close().
-            self._retired.append(self._ctx)
+            # (advisor, round 4) A long-lived engine that sweeps growing shapes must not hoard them: a context that was never
+            # used while a stream capture was active cannot be referenced by a graph -- it is destroyed behind a device
+            # synchronisation; and the workspace grows geometrically (at least 1.5x per regrow in the dimension that grew), so
+            # the retired list of an ever-growing sweep stays logarithmic.
+            if self._ctx_captured:
+                self._retired.append(self._ctx)
+            else:
+                torch.cuda.synchronize(self.device)
+                self.lib.gsmvi_destroy(self._ctx)
             self._ctx = C.c_void_p()
+            self._ctx_captured = False
+            if newD > self._max_D:
+                newD = max(newD, (3 * self._max_D + 1) // 2)
+            if newB > self._max_B:
+                newB = max(newB, (3 * self._max_B + 1) // 2)
         ctx = C.c_void_p()
         _lib.check("gsmvi_create", self.lib.gsmvi_create(C.byref(ctx), self.device.index, newD, newB))
         self._ctx, self._max_D, self._max_B = ctx, newD, newB
@@ -240,6 +254,8 @@ class HipEngine:
         return Z
 
     def _stream(self):
+        if not self._ctx_captured and torch.cuda.is_current_stream_capturing():
+            self._ctx_captured = True       # this context's workspace is now referenced by a graph: never destroy it on regrow
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     @staticmethod

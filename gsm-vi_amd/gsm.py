@@ -118,7 +118,7 @@ class GSM:
                     capturable (a score marked ``graph_safe`` such as ``GaussianTarget.lp_g``, the device draw stream, no
                     sharding).  None (default): do so for D <= 512, where the Python / launch overhead is the bound; True:
                     always; False: never.  Same numbers either way.
-          method  : "auto" (default) = "factor" whenever 2*batch_size <= min(D, 128) (the measured range; the form itself goes up to 256), the device
+          method  : "auto" (default) = "factor" whenever 2*batch_size <= min(D, 128) -- or <= 256 for D >= 1024 --, the device
                     Cholesky sampler, no teacher-forced samples) and "dense" otherwise.  Why that is a drop-in
                     default: for the same draws the two forms give the same (mean, cov) to round-off
                     (tests/test_gpu_factor.py, <= 1e-14 even at cond 1e8), the 2B x 2B positive-definite test is
@@ -147,9 +147,12 @@ class GSM:
         """
         D_, B_ = self.D, int(batch_size)
         if method == "auto":
-            # (explicit method="factor" goes up to 2B = 256: the two-level chain of round 4; "auto" keeps the measured range)
+            # 2B <= 128: always (the measured range of rounds 2-4).  128 < 2B <= 256 (two-level chain): where the dense loop's
+            # O(D^3) Cholesky costs more than the whole factor update -- measured at (1024, 128): factor update 271 us against
+            # 330 us for the Cholesky alone; at D = 512 the dense iteration (165 + ~40 us) still wins -- so from D = 1024 on.
+            nmax = 256 if D_ >= 1024 else 128
             method = "factor" if (sampler == "cholesky" and forced_samples is None
-                                  and 2 * B_ <= min(D_, 128)) else "dense"
+                                  and 2 * B_ <= min(D_, nmax)) else "dense"
         self.method_used = method
         if method == "factor":
             return self._fit_factor(key, mean, cov, batch_size, niter, nprint, verbose, monitor, rng, as_torch,
