@@ -18,7 +18,8 @@ kinds = os.environ.get("SOAK_KINDS", "gsm,bam").split(",")
 mode = os.environ.get("SOAK_MODE", "both")  # eager | graph | both
 bad = []
 cases = []
-for D, B in ((1024, 32), (256, 8), (4096, 64), (1024, 64), (1024, 128), (1024, 96)):   # the last two: two-level chain, paired launches (round 4)
+for D, B in ((1024, 32), (256, 8), (4096, 64), (1024, 64), (1024, 128), (1024, 96),      # (1024, 128 / 96): two-level chain, paired launches (round 4)
+             (1000, 30), (784, 50), (2000, 24)):                                            # off-grid shapes on the tuned kernels (round 5)
     if only and only != f"{D},{B}":
         continue
     rs = np.random.RandomState(D + B)
