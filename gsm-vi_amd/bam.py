@@ -17,8 +17,16 @@ def bam_lowrank_update(samples, vs, mu0, S0, reg, engine=None, jitter=0.0):
     assert len(vs.shape) == 2
     eng = engine if engine is not None else get_engine()
     want_torch = _is_torch(samples)
-    mu, S, _ = eng.bam_update(eng.asarray(samples), eng.asarray(vs), eng.asarray(mu0), eng.asarray(S0),
-                              float(reg), float(jitter))
+    Xd, Gd, m0, S0d = eng.asarray(samples), eng.asarray(vs), eng.asarray(mu0), eng.asarray(S0)
+    D = int(m0.shape[0])
+    if D % 2 == 1 and getattr(eng, "name", "") == "hip":
+        # odd D: the (D + 1)-dimensional problem with an inert last coordinate runs on the tuned kernels (_oddpad.py)
+        from . import _oddpad
+        mu, S, _ = eng.bam_update(_oddpad.pad_rows(eng, Xd, D), _oddpad.pad_rows(eng, Gd, D), _oddpad.pad_vec(eng, m0, D),
+                                  _oddpad.pad_mat(eng, S0d, D), float(reg), float(jitter))
+        mu, S = mu[:D].contiguous(), S[:D, :D].contiguous()
+    else:
+        mu, S, _ = eng.bam_update(Xd, Gd, m0, S0d, float(reg), float(jitter))
     return (mu, S) if want_torch else (eng.to_numpy(mu), eng.to_numpy(S))
 
 
@@ -74,7 +82,7 @@ class BaM:
     def fit(self, key, regf, mean=None, cov=None, batch_size=2, niter=5000, nprint=10, verbose=True,
             check_goodness=True, monitor=None, retries=10, jitter=1e-6, *, sampler="cholesky", rng="auto",
             as_torch=False, forced_samples=None, shard=False, group=None, check_update_flag=False, method="dense",
-            root_potrf=False):
+            root_potrf=False, _zero_cols_from=None):
         """gsmvi/bam.py:140-216.  Kept: niter+1 iterations (:178); nprint clamp (:177); reg = regf(i)
         per attempt (:196); jitter on the diagonal and symmetrisation (:198-199, done in-kernel);
         retry on any exception up to ``retries`` then re-raise (:189-206); Cholesky accept/revert of
@@ -114,6 +122,24 @@ class BaM:
         eng = self._engine if self._engine is not None else get_engine()
         D, B = self.D, int(batch_size)
         assert method in ("auto", "dense", "factor"), "method must be 'auto', 'dense' or 'factor'"
+        from . import _oddpad
+        if _zero_cols_from is None and _oddpad.applies(eng, D, sampler, forced_samples):
+            # odd D: the (D + 1)-dimensional problem with an inert last coordinate runs on the tuned kernels (_oddpad.py).
+            # (the corner of cov' picks up the jitter like every diagonal entry; it touches nothing else)
+            if method == "auto":
+                method = "factor" if (2 * B <= min(D, 256) and float(jitter) <= 1e-6) else "dense"
+            inner = BaM(D + 1, self.lp, _oddpad.wrap_score(eng, self.lp_g, D), use_lowrank=self.use_lowrank,
+                        jit_compile=self.jit_compile, engine=eng)
+            mp, cp = inner.fit(key, regf, mean=_oddpad.pad_vec(eng, mean, D), cov=_oddpad.pad_mat(eng, cov, D),
+                               batch_size=batch_size, niter=niter, nprint=nprint, verbose=verbose,
+                               check_goodness=check_goodness, monitor=_oddpad.wrap_monitor(monitor, self.lp, D),
+                               retries=retries, jitter=jitter, sampler=sampler, rng=rng, as_torch=True, shard=shard,
+                               group=group, check_update_flag=check_update_flag, method=method, root_potrf=root_potrf,
+                               _zero_cols_from=D)
+            self.method_used, self.n_reverts, self.padded_dim = inner.method_used, inner.n_reverts, D + 1
+            mean_o, cov_o = mp[:D].contiguous(), cp[:D, :D].contiguous()
+            return (mean_o, cov_o) if as_torch else (eng.to_numpy(mean_o), eng.to_numpy(cov_o))
+        self._zc = _zero_cols_from
         if method == "auto":
             # "auto" = the factor form wherever it exists (2B <= min(D, 256), the device Cholesky sampler, no teacher-forced
             # samples): 1.4x (c4) to 3.1x (B = 32) the dense loop's rate, no D^3 step per iteration.  It is NOT the default
@@ -196,10 +222,14 @@ class BaM:
                         if dev_rng:
                             if ndraw % KB == 0:
                                 eng.normal_batch(KB, B, D, seed, ndraw, out=Zblk)
+                                if self._zc is not None:
+                                    Zblk[:, :, self._zc:] = 0.0          # inert coordinates of an odd-D fit (_oddpad.py)
                             Z = Zblk[ndraw % KB]
                             ndraw += 1
                         else:
                             Z = eng.normal_from_host(rs.standard_normal((B, D)))
+                            if self._zc is not None:
+                                Z[:, self._zc:] = 0.0
                         X = eng.sample(Z[lo:hi], mean_t, R, out=Xbuf)     # only this rank's rows when sharded
                     err = None
                     try:
@@ -325,10 +355,14 @@ class BaM:
                     if dev_rng:
                         if ndraw % KB == 0:
                             eng.normal_batch(KB, B, D, seed, ndraw, out=Zblk)
+                            if self._zc is not None:
+                                Zblk[:, :, self._zc:] = 0.0              # inert coordinates of an odd-D fit (_oddpad.py)
                         Z = Zblk[ndraw % KB]
                         ndraw += 1
                     else:
                         Z = eng.normal_from_host(rs.standard_normal((B, D)))
+                        if self._zc is not None:
+                            Z[:, self._zc:] = 0.0
                     X = eng.sample(Z[lo:hi], mu_a, F_a, out=Xbuf)          # only this rank's rows when sharded
                     err = None
                     try:

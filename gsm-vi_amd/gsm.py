@@ -42,7 +42,15 @@ def gsm_update(samples, vs, mu0, S0, engine=None, assume_symmetric=None):
         else:
             assume_symmetric = bool(np.array_equal(np.asarray(S0), np.asarray(S0).T))
     Xd, Gd, m0, S0d = eng.asarray(samples), eng.asarray(vs), eng.asarray(mu0), eng.asarray(S0)
-    if assume_symmetric:
+    D = int(m0.shape[0])
+    if assume_symmetric and D % 2 == 1 and getattr(eng, "name", "") == "hip" and Xd.shape[0] <= 128:
+        # odd D: the (D + 1)-dimensional problem with an inert last coordinate runs on the tuned kernels (_oddpad.py); the
+        # padding copies ride on the uploads for host inputs
+        from . import _oddpad
+        mu, S = eng.gsm_update(_oddpad.pad_rows(eng, Xd, D), _oddpad.pad_rows(eng, Gd, D), _oddpad.pad_vec(eng, m0, D),
+                               _oddpad.pad_mat(eng, S0d, D))
+        mu, S = mu[:D].contiguous(), S[:D, :D].contiguous()
+    elif assume_symmetric:
         mu, S = eng.gsm_update(Xd, Gd, m0, S0d)
     else:
         mu, S = eng.gsm_update(Xd, Gd, m0, S0d, general=True)
@@ -80,7 +88,7 @@ class GSM:
     # ------------------------------------------------------------------------------
     def fit(self, key, mean=None, cov=None, batch_size=2, niter=5000, nprint=10, verbose=True,
             check_goodness=True, monitor=None, *, sampler="cholesky", rng="auto", as_torch=False,
-            forced_samples=None, method="auto", shard=False, group=None, graph=None, root_potrf=False):
+            forced_samples=None, method="auto", shard=False, group=None, graph=None, root_potrf=False, _zero_cols_from=None):
         """Fit N(mean, cov) to the target (gsmvi/gsm_numpy.py:77-129, gsmvi/gsm.py:79-133).
 
         Same arguments and return value as the reference.  Behaviour kept: ``niter + 1`` updates
@@ -146,6 +154,26 @@ class GSM:
                     for bit.
         """
         D_, B_ = self.D, int(batch_size)
+        from . import _oddpad
+        eng0 = self._engine if self._engine is not None else get_engine()
+        if _zero_cols_from is None and _oddpad.applies(eng0, D_, sampler, forced_samples):
+            # odd D: the (D + 1)-dimensional problem with an inert last coordinate runs on the tuned kernels (_oddpad.py)
+            if method == "auto":
+                nmax = 256 if D_ >= 1024 else 128
+                method = "factor" if 2 * B_ <= min(D_, nmax) else "dense"
+            inner = GSM(D_ + 1, self.lp, _oddpad.wrap_score(eng0, self.lp_g, D_), engine=eng0)
+            mp, cp = inner.fit(key, mean=_oddpad.pad_vec(eng0, mean, D_), cov=_oddpad.pad_mat(eng0, cov, D_),
+                               batch_size=batch_size, niter=niter, nprint=nprint, verbose=verbose,
+                               check_goodness=check_goodness, monitor=_oddpad.wrap_monitor(monitor, self.lp, D_),
+                               sampler=sampler, rng=rng, as_torch=True, method=method, shard=shard, group=group, graph=graph,
+                               root_potrf=root_potrf, _zero_cols_from=D_)
+            for a in ("method_used", "n_reverts", "graph_replays", "graph_fallback"):
+                if hasattr(inner, a):
+                    setattr(self, a, getattr(inner, a))
+            self.padded_dim = D_ + 1
+            mean_o, cov_o = mp[:D_].contiguous(), cp[:D_, :D_].contiguous()
+            return (mean_o, cov_o) if as_torch else (eng0.to_numpy(mean_o), eng0.to_numpy(cov_o))
+        self._zc = _zero_cols_from
         if method == "auto":
             # 2B <= 128: always (the measured range of rounds 2-4).  128 < 2B <= 256 (two-level chain): where the dense loop's
             # O(D^3) Cholesky costs more than the whole factor update -- measured at (1024, 128): factor update 271 us against
@@ -207,9 +235,13 @@ class GSM:
                 if dev_rng:                                     # a block of KB iterations' draws per launch (same stream)
                     if i % KB == 0:
                         eng.normal_batch(min(KB, niter + 1 - i), B, D, seed, i, out=Zblk[:min(KB, niter + 1 - i)])
+                        if self._zc is not None:
+                            Zblk[:, :, self._zc:] = 0.0                  # inert coordinates of an odd-D fit (_oddpad.py)
                     Z = Zblk[i % KB]
                 else:
                     Z = eng.normal_from_host(rs.standard_normal((B, D)))
+                    if self._zc is not None:
+                        Z[:, self._zc:] = 0.0
                 X = eng.sample(Z, mean_t, R, out=Xbuf)
             if shard:
                 from .dist import sharded_gsm_update, shard_bounds
@@ -338,6 +370,8 @@ class GSM:
                         for half in range(2):
                             eng.normal_batch(KB // 2, B, D, seed, 0, out=Zblk[half * (KB // 2):(half + 1) * (KB // 2)],
                                              call_in=ctr[half], call_out=ctr[1 - half])
+                            if self._zc is not None:
+                                Zblk[half * (KB // 2):(half + 1) * (KB // 2), :, self._zc:] = 0.0
                             for k in range(KB // 2):
                                 iteration(Zblk[half * (KB // 2) + k], k & 1)
                 torch.cuda.current_stream().wait_stream(side)
@@ -371,6 +405,8 @@ class GSM:
                 continue
             if dev_rng:
                 eng.normal_batch(blk_end - i, B, D, seed, i, out=Zblk[:blk_end - i])
+                if self._zc is not None:
+                    Zblk[:, :, self._zc:] = 0.0                          # inert coordinates of an odd-D fit (_oddpad.py)
             for j in range(i, blk_end):
                 mean_t, F = state_bufs[a]
                 if verbose and j % every == 0:
@@ -383,6 +419,8 @@ class GSM:
                     monitor(j, state(), self.lp, key, nevals=nevals)
                     nevals = 0
                 Zi = Zblk[j - i] if dev_rng else eng.normal_from_host(rs.standard_normal((B, D)))
+                if not dev_rng and self._zc is not None:
+                    Zi[:, self._zc:] = 0.0
                 iteration(Zi, a)
                 nevals += B
                 a = 1 - a                                       # the kernel already returned the reverted state when its PD

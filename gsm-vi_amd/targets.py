@@ -59,6 +59,22 @@ class GaussianTarget:
             return eng.gaussian_score(x, self.mean, self.P, out=out)
         lp_g.device_native = True
         lp_g.graph_safe = True          # one capturable kernel launch, no allocation when `out` is given, no host work
+
+        def padded(Dp):
+            """the score of the same target with (Dp - D) inert coordinates appended (zero rows / columns in the precision
+            matrix: g' = [g, 0] for x' = [x, anything]) -- what the fit loops use for odd D (gsm-vi_amd/_oddpad.py)"""
+            if getattr(self, "_padded", None) is None or self._padded[0] != Dp:
+                mp, Pp = eng.zeros(Dp), eng.zeros(Dp, Dp)
+                mp[:self.D] = self.mean
+                Pp[:self.D, :self.D] = self.P
+
+                def lp_g_p(x, out=None):
+                    return eng.gaussian_score(x, mp, Pp, out=out)
+                lp_g_p.device_native = True
+                lp_g_p.graph_safe = True
+                self._padded = (Dp, lp_g_p)
+            return self._padded[1]
+        lp_g.padded = padded
         self.lp_g = lp_g
 
     def lp(self, x):

@@ -2,7 +2,9 @@
 its own example is D = 5); until round 4 the tuned kernels here were gated to D % 64 == 0 and B in {8, 16, 32, 64, 128} and
 everything else took the guarded round-1 family.  Now any EVEN D (even leading dimensions, 16-byte aligned bases) and any
 batch size stay on the tuned kernels: parity against the pinned oracle, plus gsmvi_last_path() as the proof that no
-guarded kernel ran.  Odd D keeps the guarded family (rows of an odd-D matrix are not 16-byte aligned)."""
+guarded kernel ran.  Odd D: an engine call on the caller's own arrays keeps the guarded family (rows of an odd-D matrix are not
+16-byte aligned); the Python drop-ins (gsm_update, bam_update, GSM.fit, BaM.fit) run the (D + 1)-dimensional problem with an
+inert last coordinate on the tuned kernels (gsm-vi_amd/_oddpad.py)."""
 import numpy as np
 import pytest
 
@@ -160,8 +162,9 @@ def test_offgrid_outputs_are_written_only_inside_the_matrix(eng, D, B):
         assert bool(torch.isfinite(out).all()) and not bool((out == -7.0).all()), call
 
 
-def test_odd_d_keeps_the_guarded_family(eng):
-    """Rows of an odd-D matrix are not 16-byte aligned: those shapes run the guarded kernels (same arithmetic)."""
+def test_odd_d_engine_calls_keep_the_guarded_family(eng):
+    """Rows of an odd-D matrix are not 16-byte aligned: an ENGINE call (a C caller's own arrays) on such a shape runs the
+    guarded kernels (same arithmetic).  The Python drop-ins pad instead: tests below."""
     from oracle import gsm_oracle as orc
     s = _state(129, 16)
     mu_o, S_o = orc.gsm_update_batched(s["X"], s["G"], s["mu0"], s["S0"])
@@ -170,3 +173,87 @@ def test_odd_d_keeps_the_guarded_family(eng):
     path = eng.last_path()
     assert rel_err(S.cpu().numpy(), S_o) < TOL and rel_err(mu.cpu().numpy(), mu_o) < TOL
     assert "cov_generic" in path, path
+
+
+@pytest.mark.parametrize("D,B", [(5, 2), (129, 16), (785, 20), (1001, 32)])
+def test_odd_d_one_shot_updates_run_the_tuned_kernels(eng, D, B):
+    """gsm_update / bam_update (the drop-ins of gsm_numpy.py:27-55, bam.py:31-114) at ODD D: run as the (D + 1)-dimensional
+    problem with an inert last coordinate (gsm-vi_amd/_oddpad.py) -- oracle parity and no guarded kernel."""
+    import gsmvi_amd
+    from oracle import gsm_oracle as orc
+    from oracle import bam_oracle as borc
+    s = _state(D, B)
+    mu_o, S_o = orc.gsm_update_batched(s["X"], s["G"], s["mu0"], s["S0"])
+    eng.last_path()
+    mu, S = gsmvi_amd.gsm_update(s["X"], s["G"], s["mu0"], s["S0"])
+    path = eng.last_path()
+    assert mu.shape == (D,) and S.shape == (D, D)
+    assert rel_err(mu, mu_o) < TOL and rel_err(S, S_o) < TOL and np.array_equal(S, S.T)
+    assert not _generic(path) and "cov_sym" in path, path
+    mu_bo, S_bo = borc.bam_lowrank_update_exact(s["X"], s["G"], s["mu0"], s["S0"], 2.0)
+    eng.last_path()
+    mu_b, S_b = gsmvi_amd.bam_update(s["X"], s["G"], s["mu0"], s["S0"], 2.0)
+    path = eng.last_path()
+    assert rel_err(mu_b, mu_bo) < 1e-8 and rel_err(S_b, 0.5 * (S_bo + S_bo.T)) < 1e-8
+    assert not _generic(path) and "lowrank_fast" in path, path
+
+
+@pytest.mark.parametrize("D,B", [(5, 2), (33, 4), (129, 16)])
+def test_odd_d_fits_run_padded_and_converge(eng, D, B):
+    """GSM.fit / BaM.fit at odd D (the reference's own example is D = 5, examples/example_gsm_numpy.py:38): the fit runs on the
+    tuned kernels as the (D + 1)-dimensional problem; the inert coordinate stays EXACTLY inert (mean 0, unit corner, zero
+    border), the user's score and monitor see the original D, and the fits converge to the Gaussian target."""
+    import torch
+    import gsmvi_amd
+    from oracle import gsm_oracle as orc
+    m, cov_t, P = orc.make_gaussian_target(D, 5)
+    tgt = gsmvi_amd.GaussianTarget(m, precision=P)
+    shapes, mon_shapes = [], []
+
+    m_t, P_t = torch.as_tensor(m, device="cuda"), torch.as_tensor(np.asarray(P), device="cuda")
+
+    @gsmvi_amd.device_score
+    def lp_g(x):                                   # a user's device score in plain torch: sees (B, D)
+        shapes.append(tuple(x.shape))
+        return -(x - m_t) @ P_t
+
+    class Mon:
+        checkpoint = 50
+
+        def __call__(self, i, params, lp, key, nevals=1):
+            mon_shapes.append((params[0].shape, params[1].shape))
+
+    niter = 3000 if D <= 33 else 600
+    eng.last_path()
+    gsm = gsmvi_amd.GSM(D, tgt.lp, lp_g)
+    mean, cov = gsm.fit(3, niter=niter, batch_size=B, verbose=False, monitor=Mon())
+    path = eng.last_path()
+    assert gsm.padded_dim == D + 1 and not _generic(path), path
+    assert set(shapes) == {(B, D)} and set(mon_shapes) == {((D,), (D, D))}
+    assert mean.shape == (D,) and cov.shape == (D, D)
+    if D <= 33:
+        assert rel_err(mean, m) < 1e-6 and rel_err(cov, cov_t) < 1e-6
+    # the inert coordinate, looked at directly: the inner fit of the padded problem
+    inner = gsmvi_amd.GSM(D + 1, None, tgt.lp_g.padded(D + 1))
+    mp, cp = inner.fit(3, mean=torch.zeros(D + 1, dtype=torch.float64, device="cuda"),
+                       cov=torch.eye(D + 1, dtype=torch.float64, device="cuda"), niter=60, batch_size=B, verbose=False,
+                       as_torch=True, _zero_cols_from=D)
+    assert float(mp[D]) == 0.0 and float(cp[D, D]) == 1.0 and bool((cp[D, :D] == 0).all()) and bool((cp[:D, D] == 0).all())
+    # the same with a HOST score (numpy in, numpy out: gsm_numpy.py:117) and the built-in target (padded precision matrix)
+    Ph = np.asarray(P)
+    g2 = gsmvi_amd.GSM(D, None, lambda x: -(x - m) @ Ph)
+    mean_h, cov_h = g2.fit(3, niter=200, batch_size=B, verbose=False)
+    g3 = gsmvi_amd.GSM(D, None, tgt.lp_g)
+    mean_b, cov_b = g3.fit(3, niter=200, batch_size=B, verbose=False)
+    assert rel_err(mean_h, mean_b) < 1e-9 and rel_err(cov_h, cov_b) < 1e-9           # same draws, same scores
+    # BaM, both forms
+    for method in ("dense", "factor"):
+        if method == "factor" and 2 * B > D:
+            continue
+        bam = gsmvi_amd.BaM(D, None, tgt.lp_g)
+        eng.last_path()
+        mb, cb = bam.fit(3, gsmvi_amd.Regularizers().custom(lambda c: 100.0 / c), niter=150, batch_size=B, verbose=False,
+                         method=method, jitter=0.0)
+        path = eng.last_path()
+        assert bam.padded_dim == D + 1 and bam.method_used == method and not _generic(path), (method, path)
+        assert rel_err(mb, m) < 1e-3 and rel_err(cb, cov_t) < 1e-2, method
