@@ -131,8 +131,14 @@ def load_library():
     sigs = dict(_SIGS)
     if debug_build_selected():
         sigs.update(_DEBUG_SIGS)
+    variant = bool(os.environ.get("GSMVI_HIP_LIB_VARIANT", ""))
     for name, (res, args) in sigs.items():
-        fn = getattr(lib, name)     # AttributeError here = ABI mismatch, surface it
+        try:
+            fn = getattr(lib, name)     # AttributeError here = ABI mismatch, surface it
+        except AttributeError:
+            if variant:                 # a diagnostic build of an OLDER tree (A/B runs against a previous round's library)
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     if lib.gsmvi_abi_version() != 1:

@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256) void k_lowrank_update(int D, int KF, const dou
 // compute phase ran strictly one after the other.  No thread reads global data written by another thread of the workgroup, so
 // only LDS needs ordering (the rule of k_gsm_cov_sym_p).  (ii) KP rows per staging pass as a template
 // parameter: 64 for KF > 96 (BASELINE config 4: 256 rows in 4 passes instead of 8 -- half the barriers).
-template <int NPMAX, int KP>
+template <int NPMAX, int KP, bool RAG>    // RAG: D % 64 != 0 (edge tiles; round 5)
 __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, const double* __restrict__ Ft,
                                                              const double* __restrict__ Fs,
                                                              const double* __restrict__ S0, int lds0,
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, cons
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int rr = frow + 4 * r < D ? frow + 4 * r : D - 1, cq = fcol + 16 * blk < D ? fcol + 16 * blk : D - 1;
+            const int rr = (RAG && frow + 4 * r >= D) ? D - 1 : frow + 4 * r, cq = (RAG && fcol + 16 * blk >= D) ? D - 1 : fcol + 16 * blk;
             s0[blk][r] = S0[(size_t)rr * lds0 + cq];
         }
     v2d ga[NPMAX][UQ], gb[NPMAX][UQ];
@@ -720,8 +720,8 @@ __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, cons
             for (int q = 0; q < UQ; ++q) {
                 const int u = q * 512 + tid, row = KP * p + (u >> 5), c2 = 2 * (u & 31);
                 const int rc = row < KF ? row : KF - 1;
-                ga[p][q] = *reinterpret_cast<const v2d*>(Ft + (size_t)rc * D + (I0 + c2 < D ? I0 + c2 : D - 2));
-                gb[p][q] = *reinterpret_cast<const v2d*>(Fs + (size_t)rc * D + (J0 + c2 < D ? J0 + c2 : D - 2));
+                ga[p][q] = *reinterpret_cast<const v2d*>(Ft + (size_t)rc * D + ((RAG && I0 + c2 >= D) ? D - 2 : I0 + c2));
+                gb[p][q] = *reinterpret_cast<const v2d*>(Fs + (size_t)rc * D + ((RAG && J0 + c2 >= D) ? D - 2 : J0 + c2));
             }
         }
     }
@@ -760,8 +760,8 @@ __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, cons
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = frow + 4 * r;
-        if (row < D && fcol < D) S[(size_t)row * lds + fcol] = s0[0][r] + acc0[r] + (row == fcol ? jitter : 0.0);
-        if (row < D && fcol + 16 < D) S[(size_t)row * lds + fcol + 16] = s0[1][r] + acc1[r] + (row == fcol + 16 ? jitter : 0.0);
+        if (!RAG || (row < D && fcol < D)) S[(size_t)row * lds + fcol] = s0[0][r] + acc0[r] + (row == fcol ? jitter : 0.0);
+        if (!RAG || (row < D && fcol + 16 < D)) S[(size_t)row * lds + fcol + 16] = s0[1][r] + acc1[r] + (row == fcol + 16 ? jitter : 0.0);
     }
 #undef LR_LDS_BARRIER
 }
@@ -872,13 +872,14 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     const int nt = (D + 63) / 64;
     ctx->path |= (!ctx->tune_no_fast && D % 2 == 0 && n2 <= 288) ? GSMVI_PATH_LOWRANK_FAST : GSMVI_PATH_LOWRANK_GENERIC;
     if (!ctx->tune_no_fast && D % 2 == 0 && n2 <= 288) {
-        if (n2 <= 96 || ctx->tune_lowrank_kp == 32) {
-            if (n2 <= 96)
-                hipLaunchKernelGGL((k_lowrank_update_fast<3, 32>), dim3(nt * nt), dim3(512), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds, jitter);
-            else
-                hipLaunchKernelGGL((k_lowrank_update_fast<9, 32>), dim3(nt * nt), dim3(512), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds, jitter);
-        } else
-            hipLaunchKernelGGL((k_lowrank_update_fast<5, 64>), dim3(nt * nt), dim3(512), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds, jitter);
+#define LRU(NPV, KPV, RG) hipLaunchKernelGGL((k_lowrank_update_fast<NPV, KPV, RG>), dim3(nt * nt), dim3(512), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds, jitter)
+        // (KF > 96: 32-row staging passes as in round 4; 64-row passes -- half the barriers -- measured equal: knob "lowrank_kp" = 64)
+        if (D % 64 != 0) {
+            if (n2 <= 96) LRU(3, 32, true); else if (ctx->tune_lowrank_kp == 64) LRU(5, 64, true); else LRU(9, 32, true);
+        } else {
+            if (n2 <= 96) LRU(3, 32, false); else if (ctx->tune_lowrank_kp == 64) LRU(5, 64, false); else LRU(9, 32, false);
+        }
+#undef LRU
     } else {
         hipLaunchKernelGGL(k_lowrank_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds,
                            jitter);

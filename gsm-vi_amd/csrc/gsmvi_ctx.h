@@ -68,7 +68,7 @@ struct gsmvi_ctx {
     int* bam_hint_host = nullptr;       // pinned word: k* of the last device BaM chain (step-count hint, never synchronised on)
     int tune_bam_kenq = 0;     // > 0: enqueue exactly this many multi-workgroup steps (tests of the tail kernel)
     int tune_bam_full = 0;     // 1 = always enqueue every Newton-Schulz step (ignore the hint; tests)
-    int tune_lowrank_kp = 0;   // 32: BaM's low-rank update stages 32 rows per pass also for KF > 96 (the round-4 shape; A/B runs)
+    int tune_lowrank_kp = 0;   // 64: BaM's low-rank update stages 64 rows per pass for KF > 96 (A/B runs: measured equal to 32)
     int tune_chain_pair = 1;   // two-level chain (128 < 2B <= 256): independent one-workgroup factorisations share a launch (0: A/B runs)
     double* early = nullptr;   // [Gamma11 | R11 | W11], 128 x 128 each: the first diagonal block of the factor-form BaM chain's Gram
                                // matrix (Vw Vw^T, known before the B x B chain) and its factors, produced beside k_bam_cholw

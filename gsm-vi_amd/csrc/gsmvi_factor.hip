@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_panel_t(int D, int nrows, const double*
 // Same decomposition as k_panel_fast: 512 threads, 8 waves split the chunk's columns, every global load of a
 // chunk (A rows and the 16 M rows, both contiguous along i) issued in one batch as 16-B accesses, staged in
 // LDS [row][CHW+2], MFMA operands pulled to registers before the chain.
-template <int MT, int CHW>
+template <int MT, int CHW, bool RAG>     // RAG: mrows % 16 != 0 (clamped re-reads of M rows, guarded stores; round 5)
 __global__ __launch_bounds__(512) void k_panel_t_fast(int D, int nrows, const double* __restrict__ A, int lda,
                                                       const double* __restrict__ M, int ldm,
                                                       double* __restrict__ Pp, int chunks_per_wg, int mrows) {
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(512) void k_panel_t_fast(int D, int nrows, const do
                 src = A + (size_t)(gr < nrows ? gr : nrows - 1) * lda + colc;
             } else {
                 const int gj = j0 + row - NR;                              // (any mrows, round 5: a row beyond the matrix is a clamped
-                src = M + (size_t)(gj < mrows ? gj : mrows - 1) * ldm + colc;   // re-read; it only feeds output columns that are not stored)
+                src = M + (size_t)((RAG && gj >= mrows) ? mrows - 1 : gj) * ldm + colc;   // re-read; it only feeds output columns that are not stored)
             }
             const v2d v = *reinterpret_cast<const v2d*>(src);
             st[q] = ok ? v : (v2d){0.0, 0.0};
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512) void k_panel_t_fast(int D, int nrows, const do
     for (int idx = tid; idx < NR * 16; idx += 512) {
         const int rr = idx >> 4, cc = idx & 15;
         const int row = r0 + rr;
-        if (row < nrows && j0 + cc < mrows) {
+        if (row < nrows && (!RAG || j0 + cc < mrows)) {
             double s = 0.0;
 #pragma unroll
             for (int ww = 0; ww < 8; ww += 2) s += red[(ww * NR + rr) * 17 + cc] + red[((ww + 1) * NR + rr) * 17 + cc];
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void k_gsmf_update(int D, int KF, const double
 // then pass through LDS 32 at a time, [k][80] (64 columns + 16 pad: both MFMA operand reads conflict-free).
 // Tile row 0 also writes mu = mu0 + sum_b coef[b] Tm[b] (coef = [beta; alpha] / B from the small-matrix kernel: the mean of
 // the rows u_b Fm) for its 64 columns, and workgroup 0 counts the revert.  When *bad (the 2B x 2B positive-definite test failed) F = F0 and mu = mu0.
-template <int NP>
+template <int NP, bool RAG>               // RAG: D % 64 != 0 or 2B % 32 != 0 (edge tiles, partial staging pass; round 5)
 __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const double* __restrict__ Rt,
                                                           const double* __restrict__ Fs,
                                                           const double* __restrict__ F0, int ldf0,
@@ -500,12 +500,12 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const do
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int rr = frow + 4 * r < D ? frow + 4 * r : D - 1, cq = fcol + 16 * blk < D ? fcol + 16 * blk : D - 1;
+            const int rr = (RAG && frow + 4 * r >= D) ? D - 1 : frow + 4 * r, cq = (RAG && fcol + 16 * blk >= D) ? D - 1 : fcol + 16 * blk;
             f0[blk][r] = F0[(size_t)rr * ldf0 + cq];
         }
     // (any n = 2B <= 32 NP, round 5: rows beyond n are clamped re-reads, zeroed when they are staged; a pass whose rows
     // all lie beyond n is skipped -- np is block-uniform)
-    const int n = 2 * B, np = (n + KP - 1) / KP;
+    const int n = 2 * B, np = RAG ? (n + KP - 1) / KP : NP;    // (on the grid n = 32 NP: the pass count is a compile-time constant)
     v2d ga[NP][2], gb[NP][2];
 #pragma unroll
     for (int p = 0; p < NP; ++p)
@@ -513,15 +513,15 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const do
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int u = q * 512 + tid, row = KP * p + (u >> 5), c2 = 2 * (u & 31);
-                const int rc = row < n ? row : n - 1;
-                ga[p][q] = *reinterpret_cast<const v2d*>(Rt + (size_t)rc * D + (I0 + c2 < D ? I0 + c2 : D - 2));
-                gb[p][q] = *reinterpret_cast<const v2d*>(Fs + (size_t)rc * D + (J0 + c2 < D ? J0 + c2 : D - 2));
+                const int rc = (RAG && row >= n) ? n - 1 : row;
+                ga[p][q] = *reinterpret_cast<const v2d*>(Rt + (size_t)rc * D + ((RAG && I0 + c2 >= D) ? D - 2 : I0 + c2));
+                gb[p][q] = *reinterpret_cast<const v2d*>(Fs + (size_t)rc * D + ((RAG && J0 + c2 >= D) ? D - 2 : J0 + c2));
             }
         }
     const int skip = *bad;
     double msum = 0.0;
     if (ti == 0) {                               // partial weighted column sums of rows g, g + 8, ... of Tm = [X - mu; V Fm]
-        const int g = tid >> 6, col = J0 + (tid & 63) < D ? J0 + (tid & 63) : D - 1;
+        const int g = tid >> 6, col = (RAG && J0 + (tid & 63) >= D) ? D - 1 : J0 + (tid & 63);
         for (int b = g; b < 2 * B; b += 8) msum += coef[b] * Tm[(size_t)b * D + col];
     }
     if (blockIdx.x == 0 && tid == 0 && skip && n_reverts) *n_reverts += 1;
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const do
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int u = q * 512 + tid, row = u >> 5, c2 = 2 * (u & 31);
-                const bool in = KP * p + row < n;
+                const bool in = !RAG || KP * p + row < n;
                 *reinterpret_cast<v2d*>(sm + row * RS + c2) = in ? ga[p][q] : (v2d){0.0, 0.0};
                 *reinterpret_cast<v2d*>(sm + (KP + row) * RS + c2) = in ? gb[p][q] : (v2d){0.0, 0.0};
             }
@@ -556,14 +556,14 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const do
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        if (frow + 4 * r < D && fcol < D) F[(size_t)(frow + 4 * r) * ldf + fcol] = skip ? f0[0][r] : f0[0][r] + acc0[r];
-        if (frow + 4 * r < D && fcol + 16 < D) F[(size_t)(frow + 4 * r) * ldf + fcol + 16] = skip ? f0[1][r] : f0[1][r] + acc1[r];
+        if (!RAG || (frow + 4 * r < D && fcol < D)) F[(size_t)(frow + 4 * r) * ldf + fcol] = skip ? f0[0][r] : f0[0][r] + acc0[r];
+        if (!RAG || (frow + 4 * r < D && fcol + 16 < D)) F[(size_t)(frow + 4 * r) * ldf + fcol + 16] = skip ? f0[1][r] : f0[1][r] + acc1[r];
     }
     if (ti == 0) {
         __syncthreads();
         sm[tid] = msum;                          // [8][64]
         __syncthreads();
-        if (tid < 64 && J0 + tid < D) {
+        if (tid < 64 && (!RAG || J0 + tid < D)) {
             double s = 0.0;
 #pragma unroll
             for (int g = 0; g < 8; ++g) s += sm[g * 64 + tid];
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void k_gsmf_mean(int D, int B, const double* _
 // the revert; *bad => F = F0, mu = mu0.
 // n = 2B may be smaller than N = 32 NP (n = 16, BASELINE config 2): rows and columns beyond n are loaded as zeros.
 // KCB: compile-time bound of the V Fm slab count (every 16-byte unit costs KCB loads).
-template <int NP, int KCB>
+template <int NP, int KCB, bool RAG>      // RAG: D % 64 != 0 (edge tiles; round 5)
 __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const double* __restrict__ Rt,
                                                         const double* __restrict__ Kmat, const double* __restrict__ Tm,
                                                         const double* __restrict__ vf_slabs, int kcv,
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const doub
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int rr = frow + 4 * r < D ? frow + 4 * r : D - 1, cq = fcol + 16 * blk < D ? fcol + 16 * blk : D - 1;
+            const int rr = (RAG && frow + 4 * r >= D) ? D - 1 : frow + 4 * r, cq = (RAG && fcol + 16 * blk >= D) ? D - 1 : fcol + 16 * blk;
             f0[blk][r] = F0[(size_t)rr * ldf0 + cq];
         }
     constexpr int KU = N * N / 2 / 512;            // 16-B units of K'' per thread (N = 64: 4, N = 32: 1)
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const doub
 #pragma unroll
     for (int q = 0; q < TU; ++q) {
         const int u = q * 512 + tid, row = u >> 5, c2 = 2 * (u & 31);
-        const int jc = J0 + c2 < D ? J0 + c2 : D - 2, icq = I0 + c2 < D ? I0 + c2 : D - 2;
+        const int jc = (RAG && J0 + c2 >= D) ? D - 2 : J0 + c2, icq = (RAG && I0 + c2 >= D) ? D - 2 : I0 + c2;
         if (row >= n) {
             gt[q] = gr[q] = (v2d){0.0, 0.0};
             continue;
@@ -753,13 +753,13 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const doub
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        if (frow + 4 * r < D && fcol < D) F[(size_t)(frow + 4 * r) * ldf + fcol] = skip ? f0[0][r] : f0[0][r] + acc0[r];
-        if (frow + 4 * r < D && fcol + 16 < D) F[(size_t)(frow + 4 * r) * ldf + fcol + 16] = skip ? f0[1][r] : f0[1][r] + acc1[r];
+        if (!RAG || (frow + 4 * r < D && fcol < D)) F[(size_t)(frow + 4 * r) * ldf + fcol] = skip ? f0[0][r] : f0[0][r] + acc0[r];
+        if (!RAG || (frow + 4 * r < D && fcol + 16 < D)) F[(size_t)(frow + 4 * r) * ldf + fcol + 16] = skip ? f0[1][r] : f0[1][r] + acc1[r];
     }
     if (ti == 0) {
         msm[tid] = msum;                           // [8][64]
         __syncthreads();
-        if (tid < 64 && J0 + tid < D) {
+        if (tid < 64 && (!RAG || J0 + tid < D)) {
             double s = 0.0;
 #pragma unroll
             for (int g = 0; g < 8; ++g) s += msm[g * 64 + tid];
@@ -881,10 +881,14 @@ static int gsmvi_panel_t_product_mt(gsmvi_ctx* ctx, hipStream_t st, int D, int B
     *kc_out = kc;
     const dim3 grid(strips, kc, zb);
     ctx->path |= fast_t ? GSMVI_PATH_PANEL_T_FAST : GSMVI_PATH_PANEL_T_GENERIC;
-    if (fast_t) {
-        if (MT == 1) hipLaunchKernelGGL((k_panel_t_fast<1, 256>), grid, dim3(512), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
-        else if (MT == 2) hipLaunchKernelGGL((k_panel_t_fast<2, 256>), grid, dim3(512), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
-        else hipLaunchKernelGGL((k_panel_t_fast<4, 128>), grid, dim3(512), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
+    if (fast_t && mrows % 16 != 0) {
+        if (MT == 1) hipLaunchKernelGGL((k_panel_t_fast<1, 256, true>), grid, dim3(512), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
+        else if (MT == 2) hipLaunchKernelGGL((k_panel_t_fast<2, 256, true>), grid, dim3(512), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
+        else hipLaunchKernelGGL((k_panel_t_fast<4, 128, true>), grid, dim3(512), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
+    } else if (fast_t) {
+        if (MT == 1) hipLaunchKernelGGL((k_panel_t_fast<1, 256, false>), grid, dim3(512), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
+        else if (MT == 2) hipLaunchKernelGGL((k_panel_t_fast<2, 256, false>), grid, dim3(512), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
+        else hipLaunchKernelGGL((k_panel_t_fast<4, 128, false>), grid, dim3(512), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
     } else if (MT == 1) hipLaunchKernelGGL((k_panel_t<1, 256>), grid, dim3(256), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
     else if (MT == 2) hipLaunchKernelGGL((k_panel_t<2, 256>), grid, dim3(256), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
     else hipLaunchKernelGGL((k_panel_t<4, 128>), grid, dim3(256), 0, st, D, B, A, lda, M, ldm, Pp, cpw, mrows);
@@ -1280,9 +1284,14 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         ctx->path |= GSMVI_PATH_FUPD_FAST;
         // n <= 64: the skinny product Fs = K'' Tm1 is folded into the update kernel (k_gsmf_update_fs): one launch less
         const int ntl = (D + 63) / 64;
-#define UFS(NPV, KCBV) hipLaunchKernelGGL((k_gsmf_update_fs<NPV, KCBV>), dim3(ntl * ntl), dim3(512), 0, st, D, B, Rt, Kmat, Tm, vf_slabs, kcv, F0, ldf0, F, ldf, coef, mu0, mu, info_dev, n_reverts_dev)
-        if (kcv <= 4) { if (n <= 32) UFS(1, 4); else UFS(2, 4); }
-        else { if (n <= 32) UFS(1, GSMVI_MAX_KC); else UFS(2, GSMVI_MAX_KC); }
+#define UFS(NPV, KCBV, RG) hipLaunchKernelGGL((k_gsmf_update_fs<NPV, KCBV, RG>), dim3(ntl * ntl), dim3(512), 0, st, D, B, Rt, Kmat, Tm, vf_slabs, kcv, F0, ldf0, F, ldf, coef, mu0, mu, info_dev, n_reverts_dev)
+        if (D % 64 != 0) {
+            if (kcv <= 4) { if (n <= 32) UFS(1, 4, true); else UFS(2, 4, true); }
+            else { if (n <= 32) UFS(1, GSMVI_MAX_KC, true); else UFS(2, GSMVI_MAX_KC, true); }
+        } else {
+            if (kcv <= 4) { if (n <= 32) UFS(1, 4, false); else UFS(2, 4, false); }
+            else { if (n <= 32) UFS(1, GSMVI_MAX_KC, false); else UFS(2, GSMVI_MAX_KC, false); }
+        }
 #undef UFS
         return chk("k_gsmf_update_fs");
     }
@@ -1312,8 +1321,9 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
     const int nt = (D + 63) / 64;
     if (!ctx->tune_no_fast && D % 2 == 0 && n <= 256) {
         // the fast kernel also writes the mean and counts the revert (any even n <= 256 since round 5)
-#define UF(NPV) hipLaunchKernelGGL(k_gsmf_update_fast<NPV>, dim3(nt * nt), dim3(512), 0, st, D, B, Rt, Fs, F0, ldf0, F, ldf, Tm, coef, mu0, mu, info_dev, n_reverts_dev)
-        if (n <= 32) UF(1); else if (n <= 64) UF(2); else if (n <= 128) UF(4); else UF(8);
+#define UF(NPV, RG) hipLaunchKernelGGL((k_gsmf_update_fast<NPV, RG>), dim3(nt * nt), dim3(512), 0, st, D, B, Rt, Fs, F0, ldf0, F, ldf, Tm, coef, mu0, mu, info_dev, n_reverts_dev)
+        if (D % 64 != 0 || n % 32 != 0) { if (n <= 32) UF(1, true); else if (n <= 64) UF(2, true); else if (n <= 128) UF(4, true); else UF(8, true); }
+        else { if (n <= 32) UF(1, false); else if (n <= 64) UF(2, false); else if (n <= 128) UF(4, false); else UF(8, false); }
 #undef UF
         ctx->path |= GSMVI_PATH_FUPD_FAST;
         return chk("k_gsmf_update_fast");

@@ -42,7 +42,10 @@
 // CU) does not depend on this product, only the update kernel behind both does, so the product and one launch boundary
 // disappear from the iteration's critical path.  The chain's 142 KB of LDS become the launch's LDS size (one workgroup per
 // CU for the product: it finishes long before the chain either way).
-template <int MT, bool HAS_SHIFT, int CHW, bool EXTRA, bool RIDER = false>
+// RAG (round 5) = the clamped form for D % 64 != 0 or ncols % 16 != 0; RAG = false is the round-4 code, instruction for
+// instruction (the clamps and the straddling-wave branch cost 6 - 11 % on the grid shapes when they were unconditional:
+// scripts/cov_ab_rounds.py).
+template <int MT, bool HAS_SHIFT, int CHW, bool EXTRA, bool RIDER = false, bool RAG = false>
 __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const double* __restrict__ A, int lda,
                                                     const double* __restrict__ shift, double alpha,
                                                     const double* __restrict__ M, int ldm,
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
     // (round 5: any even D and any ncols -- a column beyond the matrix is a clamped re-read whose result is not stored, a
     // row of M beyond D is a clamped re-read multiplied by the zeros the A chunk is staged with beyond D)
     const int jx = blockIdx.x * 16 + c;
-    const int j = jx < ncols ? jx : ncols - 1;
+    const int j = (RAG && jx >= ncols) ? ncols - 1 : jx;
     const int r0 = blockIdx.z * NR;
 
     v4d acc[MT];
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
 #pragma unroll
                 for (int s = 0; s < NST; ++s) fp[(size_t)(4 * s) * px.ldfin] = m[s];
             }
-        } else if (wbase + RW <= D || !wave_in) {  // wave-uniform: all RW rows of this wave exist (or none: the values are unused)
+        } else if (!RAG || wbase + RW <= D || !wave_in) {  // wave-uniform: all RW rows of this wave exist (or none: the values are unused)
             const double* mp = M + (size_t)((wave_in ? wbase : 0) + ks) * ldm + j;
 #pragma unroll
             for (int s = 0; s < NST; ++s) m[s] = mp[(size_t)(4 * s) * ldm];
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
     for (int idx = tid; idx < NR * 16; idx += 512) {
         const int rr = idx >> 4, cc = idx & 15;
         const int row = r0 + rr;
-        if (row < nrows && (int)blockIdx.x * 16 + cc < ncols) {
+        if (row < nrows && (!RAG || (int)blockIdx.x * 16 + cc < ncols)) {
             double s = 0.0;
 #pragma unroll
             for (int ww = 0; ww < 8; ww += 2) s += red[(ww * NR + rr) * 17 + cc] + red[((ww + 1) * NR + rr) * 17 + cc];
@@ -326,7 +329,9 @@ __global__ __launch_bounds__(NT) void k_gsm_scalars_fast(int D, int B, int KC, c
 // Bytes moved: 4 D^2 read + 8 D^2 written (algorithmic count of SURVEY 8(d): 16 D^2).
 // The workgroup whose first tile is diagonal also writes mu = mu0 + mean_b dmu_b.
 // =====================================================================================
-template <int SB>
+// RAG (round 5) = edge tiles (D % 32 != 0) and / or fewer than SB samples (B < SB): clamped re-reads, zero-staged sample rows,
+// guarded stores.  RAG = false is the round-4 code plus the run-time 1/B (the clamps cost 6 % on the grid shapes when unconditional).
+template <int SB, bool RAG>
 __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, int B, double invB, const double* __restrict__ rec, int ldrec,
                                                      const double* __restrict__ mu0,
                                                      const double* __restrict__ S0, int lds0,
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, int B, double invB, 
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int unit = q * 256 + tl, i = unit >> 4, j2 = unit & 15;
-        const int gr = I0 + i < D ? I0 + i : D - 1, gc = Jt + 2 * j2 < D ? Jt + 2 * j2 : D - 2;
+        const int gr = (RAG && I0 + i >= D) ? D - 1 : I0 + i, gc = (RAG && Jt + 2 * j2 >= D) ? D - 2 : Jt + 2 * j2;
         s0v[q] = (dbg & 2) ? (v2d){1.0, 1.0} : *reinterpret_cast<const v2d*>(S0 + (size_t)gr * lds0 + gc);
     }
     __builtin_amdgcn_sched_barrier(0);           // keep the HBM loads of S0 ahead of the L2-resident staging loads
@@ -406,13 +411,13 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, int B, double invB, 
         const int b = u >> 4, c2 = 2 * (u & 15);
         // tile 0,1: I block (d, e); 2,3: J0 block; 4,5: J1 block (= J0 again when there is no second tile)
         const int colbase = (tile < 2) ? I0 : (J0 + ((tile >= 4 && two) ? 32 : 0));
-        const int colc = colbase + c2 < D ? colbase + c2 : D - 2;   // (a column beyond D only feeds outputs that are not stored)
+        const int colc = (RAG && colbase + c2 >= D) ? D - 2 : colbase + c2;   // (a column beyond D only feeds outputs that are not stored)
         // the 16 single-tile workgroups (they share a CU with a two-tile one) neither load nor stage a second column
         // block, and their waves 4-7 issue no MFMA: 32 instead of 64 MFMAs per SIMD on those CUs (they were the
         // kernel's 0.9 us tail: profiles/r02/timeline_cold_three_launch.txt).  tile is wave-uniform.
         // (any B <= SB: sample rows b >= B do not exist -- the address is clamped and the unit is zeroed at staging time,
         // so that no use of a loaded value sits between the loads)
-        stg[q] = (two || tile < 4) ? *reinterpret_cast<const v2d*>(rec + (size_t)(b < B ? b : B - 1) * ldrec + (tile & 1) * D + colc)
+        stg[q] = (two || tile < 4) ? *reinterpret_cast<const v2d*>(rec + (size_t)((RAG && b >= B) ? B - 1 : b) * ldrec + (tile & 1) * D + colc)
                                    : (v2d){0.0, 0.0};
     }
     double dmu_part = 0.0;
@@ -421,10 +426,10 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, int B, double invB, 
 #pragma unroll
         for (int k = 0; k < SB / 8; ++k) {
             const int b = (tid >> 5) + 8 * k, ci = I0 + (tid & 31);
-            dv[k] = rec[(size_t)(b < B ? b : B - 1) * ldrec + 2 * D + (ci < D ? ci : D - 1)];
+            dv[k] = rec[(size_t)((RAG && b >= B) ? B - 1 : b) * ldrec + 2 * D + ((RAG && ci >= D) ? D - 1 : ci)];
         }
 #pragma unroll
-        for (int k = 0; k < SB / 8; ++k) dmu_part += ((tid >> 5) + 8 * k < B) ? dv[k] : 0.0;
+        for (int k = 0; k < SB / 8; ++k) dmu_part += (!RAG || (tid >> 5) + 8 * k < B) ? dv[k] : 0.0;
     }
     if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(1); }
 
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, int B, double invB, 
             const int tile = g / NU, u = g % NU;
             const int b = u >> 4;
             if (b / SBP == pass && (two || tile < 4))
-                *reinterpret_cast<v2d*>(smem + tile * TILE + (b % SBP) * RS + 2 * (u & 15)) = (b < B) ? stg[q] : (v2d){0.0, 0.0};
+                *reinterpret_cast<v2d*>(smem + tile * TILE + (b % SBP) * RS + 2 * (u & 15)) = (!RAG || b < B) ? stg[q] : (v2d){0.0, 0.0};
         }
         __syncthreads();
         if (pass == 0) STAMP(2);
@@ -485,7 +490,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, int B, double invB, 
             v2d wv2;
             wv2.x = s0v[q].x + LW[i * 33 + 2 * j2];
             wv2.y = s0v[q].y + LW[i * 33 + 2 * j2 + 1];
-            if (I0 + i < D && Jt + 2 * j2 < D) *reinterpret_cast<v2d*>(S + (size_t)(I0 + i) * lds + Jt + 2 * j2) = wv2;
+            if (!RAG || (I0 + i < D && Jt + 2 * j2 < D)) *reinterpret_cast<v2d*>(S + (size_t)(I0 + i) * lds + Jt + 2 * j2) = wv2;
             LW[i * 33 + 2 * j2] = wv2.x;
             LW[i * 33 + 2 * j2 + 1] = wv2.y;
         }
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, int B, double invB, 
             v2d m2;
             m2.x = LW[(2 * i2) * 33 + j];
             m2.y = LW[(2 * i2 + 1) * 33 + j];
-            if (Jt + j < D && I0 + 2 * i2 < D) *reinterpret_cast<v2d*>(S + (size_t)(Jt + j) * lds + I0 + 2 * i2) = m2;
+            if (!RAG || (Jt + j < D && I0 + 2 * i2 < D)) *reinterpret_cast<v2d*>(S + (size_t)(Jt + j) * lds + I0 + 2 * i2) = m2;
         }
     }
     if (diag) {
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, int B, double invB, 
             double s = 0.0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) s += smem[q * 32 + tid];
-            if (I0 + tid < D) mu_out[I0 + tid] = mu0[I0 + tid] + s * invB;
+            if (!RAG || I0 + tid < D) mu_out[I0 + tid] = mu0[I0 + tid] + s * invB;
         }
     }
     STAMP(4);
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym(int D, int B, double invB, 
 // to LDS, so they are in flight during the current item's operand reads, MFMAs, LDS round trips and stores (loads and stores
 // share the in-order vmcnt counter: the next iteration waits for the loads only, the stores behind them stay in flight).
 // =====================================================================================
-template <int SB>
+template <int SB, bool RAG>
 __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, int B, double invB, const double* __restrict__ rec, int ldrec,
                                                        const double* __restrict__ mu0,
                                                        const double* __restrict__ S0, int lds0,
@@ -589,7 +594,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, int B, double invB
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int unit = q * 256 + tl, i = unit >> 4, j2 = unit & 15;
-            const int gr = I0 + i < D ? I0 + i : D - 1, gc = Jt + 2 * j2 < D ? Jt + 2 * j2 : D - 2;
+            const int gr = (RAG && I0 + i >= D) ? D - 1 : I0 + i, gc = (RAG && Jt + 2 * j2 >= D) ? D - 2 : Jt + 2 * j2;
             s0[q] = *reinterpret_cast<const v2d*>(S0 + (size_t)gr * lds0 + gc);
         }
         __builtin_amdgcn_sched_barrier(0);                   // the HBM loads of S0 ahead of the L2-resident record loads
@@ -599,8 +604,8 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, int B, double invB
             const int tile = g / NU, u = g % NU;
             const int b = u >> 4, c2 = 2 * (u & 15);
             const int colbase = (tile < 2) ? I0 : (J0 + ((tile >= 4 && it.two) ? 32 : 0));
-            const int colc = colbase + c2 < D ? colbase + c2 : D - 2;
-            stg[q] = (it.two || tile < 4) ? *reinterpret_cast<const v2d*>(rec + (size_t)(b < B ? b : B - 1) * ldrec + (tile & 1) * D + colc)
+            const int colc = (RAG && colbase + c2 >= D) ? D - 2 : colbase + c2;
+            stg[q] = (it.two || tile < 4) ? *reinterpret_cast<const v2d*>(rec + (size_t)((RAG && b >= B) ? B - 1 : b) * ldrec + (tile & 1) * D + colc)
                                           : (v2d){0.0, 0.0};
         }
 #pragma unroll
@@ -609,7 +614,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, int B, double invB
 #pragma unroll
             for (int k = 0; k < SB / 8; ++k) {
                 const int b = (tid >> 5) + 8 * k, ci = I0 + (tid & 31);
-                dmu[k] = rec[(size_t)(b < B ? b : B - 1) * ldrec + 2 * D + (ci < D ? ci : D - 1)];
+                dmu[k] = rec[(size_t)((RAG && b >= B) ? B - 1 : b) * ldrec + 2 * D + ((RAG && ci >= D) ? D - 1 : ci)];
             }
         }
     };
@@ -639,7 +644,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, int B, double invB
                 const int tile = g / NU, u = g % NU;
                 const int b = u >> 4;
                 if (b / SBP == pass && (two || tile < 4))
-                    *reinterpret_cast<v2d*>(smem + tile * TILE + (b % SBP) * RS + 2 * (u & 15)) = (b < B) ? stg[q] : (v2d){0.0, 0.0};
+                    *reinterpret_cast<v2d*>(smem + tile * TILE + (b % SBP) * RS + 2 * (u & 15)) = (!RAG || b < B) ? stg[q] : (v2d){0.0, 0.0};
             }
             LDS_BARRIER();
             if (pass == NPASS - 1 && nxt < n_items) {        // the staging registers are free: the next item's loads go out now
@@ -680,7 +685,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, int B, double invB
                 v2d wv2;
                 wv2.x = s0v[q].x + LW[i * 33 + 2 * j2];
                 wv2.y = s0v[q].y + LW[i * 33 + 2 * j2 + 1];
-                if (I0 + i < D && Jt + 2 * j2 < D) *reinterpret_cast<v2d*>(S + (size_t)(I0 + i) * lds + Jt + 2 * j2) = wv2;
+                if (!RAG || (I0 + i < D && Jt + 2 * j2 < D)) *reinterpret_cast<v2d*>(S + (size_t)(I0 + i) * lds + Jt + 2 * j2) = wv2;
                 LW[i * 33 + 2 * j2] = wv2.x;
                 LW[i * 33 + 2 * j2 + 1] = wv2.y;
             }
@@ -694,7 +699,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, int B, double invB
                 v2d m2;
                 m2.x = LW[(2 * i2) * 33 + j];
                 m2.y = LW[(2 * i2 + 1) * 33 + j];
-                if (Jt + j < D && I0 + 2 * i2 < D) *reinterpret_cast<v2d*>(S + (size_t)(Jt + j) * lds + I0 + 2 * i2) = m2;
+                if (!RAG || (Jt + j < D && I0 + 2 * i2 < D)) *reinterpret_cast<v2d*>(S + (size_t)(Jt + j) * lds + I0 + 2 * i2) = m2;
             }
         }
         if (diag) {                                          // (block-uniform)
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, int B, double invB
             if (tid < 256) {
                 double dsum = 0.0;
 #pragma unroll
-                for (int k = 0; k < SB / 8; ++k) dsum += ((tid >> 5) + 8 * k < B) ? dmuv[k] : 0.0;
+                for (int k = 0; k < SB / 8; ++k) dsum += (!RAG || (tid >> 5) + 8 * k < B) ? dmuv[k] : 0.0;
                 smem[tid] = dsum;
             }
             LDS_BARRIER();
@@ -710,7 +715,7 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, int B, double invB
                 double sm_ = 0.0;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) sm_ += smem[q * 32 + tid];
-                if (I0 + tid < D) mu_out[I0 + tid] = mu0[I0 + tid] + sm_ * invB;
+                if (!RAG || I0 + tid < D) mu_out[I0 + tid] = mu0[I0 + tid] + sm_ * invB;
             }
         }
         if (nxt >= n_items) break;
@@ -734,19 +739,25 @@ void gsmvi_launch_panel_fast(hipStream_t st, hipEvent_t* ev, int MT, dim3 grid, 
     const bool rider = px && px->rd_on && !shift;
     const bool extra = px && (px->msl || px->sj_src || rider);
     const gsmvi_panel_extras pxv = extra ? *px : none;
+    const bool rag = D % 64 != 0 || ncols % 16 != 0;           // off the grid: the clamped instantiation (round 5)
     if (rider) {
         grid.x += 1;
-#define PFR(MTV, CW)                                                                                                 \
-    GSMVI_LAUNCH((k_panel_fast<MTV, false, CW, true, true>), grid, dim3(512), 0, st, ev, D, nrows, A, lda, shift, alpha, M, \
+#define PFR(MTV, CW, RG)                                                                                                 \
+    GSMVI_LAUNCH((k_panel_fast<MTV, false, CW, true, true, RG>), grid, dim3(512), 0, st, ev, D, nrows, A, lda, shift, alpha, M, \
                  ldm, Pp, chunks_per_wg, ncols, stamps, Out, ldo, addvec, pxv)
-        if (MT == 1) PFR(1, 256); else if (MT == 2) PFR(2, 256); else PFR(4, 128);
+        if (rag) { if (MT == 1) PFR(1, 256, true); else if (MT == 2) PFR(2, 256, true); else PFR(4, 128, true); }
+        else { if (MT == 1) PFR(1, 256, false); else if (MT == 2) PFR(2, 256, false); else PFR(4, 128, false); }
 #undef PFR
         return;
     }
-#define PF(MTV, HS, CW, EX)                                                                                          \
-    GSMVI_LAUNCH((k_panel_fast<MTV, HS, CW, EX>), grid, dim3(512), 0, st, ev, D, nrows, A, lda, shift, alpha, M, ldm, \
+#define PF(MTV, HS, CW, EX, RG)                                                                                          \
+    GSMVI_LAUNCH((k_panel_fast<MTV, HS, CW, EX, false, RG>), grid, dim3(512), 0, st, ev, D, nrows, A, lda, shift, alpha, M, ldm, \
                  Pp, chunks_per_wg, ncols, stamps, Out, ldo, addvec, pxv)
-#define PFE(MTV, HS, CW) do { if (extra) PF(MTV, HS, CW, true); else PF(MTV, HS, CW, false); } while (0)
+#define PFE(MTV, HS, CW)                                                                \
+    do {                                                                                \
+        if (rag) { if (extra) PF(MTV, HS, CW, true, true); else PF(MTV, HS, CW, false, true); } \
+        else { if (extra) PF(MTV, HS, CW, true, false); else PF(MTV, HS, CW, false, false); }   \
+    } while (0)
     if (shift) {
         if (MT == 1) PFE(1, true, 256); else if (MT == 2) PFE(2, true, 256); else PFE(4, true, 128);
     } else {
@@ -797,26 +808,37 @@ bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, cons
     if (B < 1 || B > 128) return false;
     const int SB = B <= 16 ? 16 : (B <= 32 ? 32 : (B <= 64 ? 64 : 128));
     const double invB = 1.0 / (double)B;
+    const bool rag = D % 32 != 0 || B != SB;                     // off the grid: the clamped instantiation
     // large D: the persistent form (2 resident workgroups per CU walk the item list, the next item's loads in flight during
     // the current item's MFMAs and stores); "cov_dbg" bit 512 keeps the one-item-per-workgroup kernel for A/B runs
     const int n_items = cov_sym_grid((D + 31) / 32);
     if (n_items >= 2048 && SB <= 32 && !stamps && dbg == 0) {    // (B = 64: two staging passes, MFMA-bound -- the one-item kernel is faster there)
         const dim3 pgrid(2 * (num_cu > 0 ? num_cu : 256));       // two resident workgroups per CU of THIS device (a partitioned device has fewer)
-#define CSP(SBV) GSMVI_LAUNCH(k_gsm_cov_sym_p<SBV>, pgrid, dim3(512), 0, st, ev, D, B, invB, rec, ldrec, mu0, S0, lds0, S, lds, mu_out)
-        if (SB == 16) CSP(16); else CSP(32);
+#define CSP(SBV, RG) GSMVI_LAUNCH((k_gsm_cov_sym_p<SBV, RG>), pgrid, dim3(512), 0, st, ev, D, B, invB, rec, ldrec, mu0, S0, lds0, S, lds, mu_out)
+        if (rag) { if (SB == 16) CSP(16, true); else CSP(32, true); }
+        else { if (SB == 16) CSP(16, false); else CSP(32, false); }
         return true;
 #undef CSP
     }
     if (dbg & 512) dbg &= ~512;
     const dim3 grid(n_items);
-#define CS(SBV)                                                                                             \
-    GSMVI_LAUNCH(k_gsm_cov_sym<SBV>, grid, dim3(512), 0, st, ev, D, B, invB, rec, ldrec, mu0, S0, lds0, S, lds, mu_out, dbg, \
+#define CS(SBV, RG)                                                                                         \
+    GSMVI_LAUNCH((k_gsm_cov_sym<SBV, RG>), grid, dim3(512), 0, st, ev, D, B, invB, rec, ldrec, mu0, S0, lds0, S, lds, mu_out, dbg, \
                  stamps)
-    switch (SB) {
-        case 16: CS(16); break;
-        case 32: CS(32); break;
-        case 64: CS(64); break;
-        default: CS(128); break;
+    if (rag) {
+        switch (SB) {
+            case 16: CS(16, true); break;
+            case 32: CS(32, true); break;
+            case 64: CS(64, true); break;
+            default: CS(128, true); break;
+        }
+    } else {
+        switch (SB) {
+            case 16: CS(16, false); break;
+            case 32: CS(32, false); break;
+            case 64: CS(64, false); break;
+            default: CS(128, false); break;
+        }
     }
 #undef CS
     return true;

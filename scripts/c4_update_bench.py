@@ -37,7 +37,7 @@ def measure(tag):
     print(f"{tag:28s} D={D} B={B}: eager median {np.median(ts):7.1f} us  min {np.min(ts):7.1f} us   replayed {tg:7.1f} us", flush=True)
 
 measure("dense BaM update")
-# round 5 A/B: the low-rank update with 32-row staging passes (the round-4 shape, now with LDS-only barriers) against 64-row passes
-eng.set_tuning("lowrank_kp", 32)
-measure("  lowrank_kp=32 (8 passes)")
+# round 5 A/B: the low-rank update with 64-row staging passes (4 passes, half the barriers) against the default 32-row passes
+eng.set_tuning("lowrank_kp", 64)
+measure("  lowrank_kp=64 (4 passes)")
 eng.set_tuning("lowrank_kp", 0)

@@ -28,6 +28,8 @@ quick = os.environ.get("OFFGRID_QUICK", "0") != "0"
 eng = gsmvi_amd.get_engine()
 dev = eng.device
 SHAPES = [(1000, 32), (1024, 20), (1000, 30), (784, 50), (500, 10), (2000, 24)]
+if os.environ.get("OFFGRID_SHAPES"):                      # e.g. OFFGRID_SHAPES=2000x64,3000x64 (ad-hoc runs)
+    SHAPES = [tuple(int(v) for v in t.split("x")) for t in os.environ["OFFGRID_SHAPES"].split(",")]
 
 
 def up64(D):
