@@ -776,6 +776,7 @@ __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, cons
     } while (0)
 
 #include "gsmvi_chol128.h"   // cholw_job
+#include "gsmvi_smallgemm.h"
 int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* Nd, const double* M1,
                            const double* N0, double* scratch, double* Ld, int* info_dev, int* hint_host, int force_kenq,
                            double* Rscr, const cholw_job* beside);
@@ -922,6 +923,37 @@ int gsmvi_factor_signed_back(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, cons
                              double* mu, double* F, int ldf, int* info_dev, int* n_reverts_dev, int kcg, int rides, int taken,
                              int join);
 
+// ---- the orthogonal-basis form (round 5, knob "bam_basis"): small pieces ----------------------------------------------------------
+// vg' = vg - Pi^T zg with zg = W a (the true Zw gbar-vector of bam.py:110) and Pi^T = Dm W^T: the mean of bam.py:112 needs
+// Zw^T zg = Zt^T zg + Vw^T Pi^T zg, and k_bam_zw forms Vw^T vg - Z^T zg from the Z it computes (Zt here).  One workgroup, n <= 128.
+__global__ __launch_bounds__(256) void k_bamf_vgfix(int n, const double* __restrict__ Wt, const double* __restrict__ Dm,
+                                                    const double* __restrict__ av, double* __restrict__ vg) {
+    __shared__ double sa[128], zg[128], t2[128];
+    const int tid = threadIdx.x;
+    if (tid < 128) sa[tid] = tid < n ? av[tid] : 0.0;
+    __syncthreads();
+    if (tid < n) {                                 // zg[r] = sum_k W[r][k] a[k] = sum_k Wt[k][r] a[k]   (W lower: k <= r)
+        double z = 0.0;
+        for (int k = 0; k <= tid; ++k) z += Wt[(size_t)k * n + tid] * sa[k];
+        zg[tid] = z;
+    }
+    __syncthreads();
+    if (tid < n) {                                 // t2[k] = sum_r Wt[k][r] zg[r]                        (Wt upper: r >= k)
+        double t = 0.0;
+        for (int r = tid; r < n; ++r) t += Wt[(size_t)tid * n + r] * zg[r];
+        t2[tid] = t;
+    }
+    __syncthreads();
+    if (tid < n) {                                 // vg'[i] = vg[i] - sum_k Dm[i][k] t2[k]
+        double d = 0.0;
+        for (int k = 0; k < n; ++k) d += Dm[(size_t)tid * n + k] * t2[k];
+        vg[tid] -= d;
+    }
+}
+// [A | I] -> [R | W] of one n x n matrix (n <= 64) in its own launch: the first diagonal block Gvv = Vw Vw^T when there is no
+// k_bam_cholw launch to ride beside (n <= 64); plain positive-definite rule (dependent draws are a failure, not a drop)
+int gsmvi_cholw_small(hipStream_t st, int n, const double* A, double* R, double* W, int* info, int info_off);
+
 int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
                           const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double reg, double* mu,
                           double* F, int ldf, int* info_dev, int* n_reverts_dev) {
@@ -949,7 +981,11 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     // n <= 48: one one-workgroup launch for the small chain + the 16-lanes-per-column substitution; above: the chain of the
     // dense form (k_bam_nmat2, Newton-Schulz steps, k_bam_bbav, k_bam_cholw) and the product-form Zw (k_bam_zw).
     // Zw = L^-1 (Wq + M1^T Vw); the mean output of either kernel (mu0 = xbar = 0) is r1 (wg + Vw^T vg - Zw^T zg) = r1 h, row 2n of Ft
-    const bool fused48 = n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full;
+    // Orthogonal-basis form (round 5, "bam_basis"): Rt = [Vw; Zt] with Zt the part of Zw orthogonal to the whitened draws -- no
+    // linearly dependent rows when the fit sits on the fixed point of a Gaussian target.  It needs the explicit
+    // W = L^-1 and Gvv = Vw Vw^T, i.e. the multi-kernel chain also for n <= 48.
+    const bool basis = ctx->tune_bam_basis != 0 && n <= 128 && ctx->basis != nullptr;
+    const bool fused48 = n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full && !basis;
 
     bam_stats_launch(st, D, B, Z, ldz, (const double*)nullptr, X, ldx, G, ldg, reg, xbar, gbar, zerov, Qt, Ft, (double*)nullptr);
     if ((rc = gsmvi_panel_t_product(ctx, st, D, n, Qt, D, F0, ldf0, D, ctx->pp, &kc))) return rc;
@@ -958,8 +994,8 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     // chain, so the Gram product below is taken against [Wq; Vw] (2n columns instead of n: the slabs then hold Vw Vw^T as well)
     // and [Gamma11 | I] -> [R11 | W11] runs as the second workgroup of k_bam_cholw's launch (ctx->early; factor_chain_big).
     ctx->early_ready = 0;
-    const bool early = !fused48 && n > 64 && n <= 128 && ctx->tune_chain_pair && ctx->early;
-    const int gcols = early ? n2 : n;
+    const bool early = !fused48 && n > 64 && n <= 128 && (ctx->tune_chain_pair || basis) && ctx->early;
+    const int gcols = (early || basis) ? n2 : n;
     if (!fused48 && n <= 128) {                    // k_bam_nmat2 sums the slabs in its operand loads: fewer slabs
         if ((rc = gsmvi_panel_t_product_few_slabs(ctx, st, D, n2, Wq, D, Wq, D, gcols, ctx->pp, &kc))) return rc;
     } else if ((rc = gsmvi_panel_t_product(ctx, st, D, n2, Wq, D, Wq, D, gcols, ctx->pp, &kc))) return rc;
@@ -978,7 +1014,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
         double* G11 = ctx->early;                  // n x n each, compact
         double* R11 = ctx->early + 128 * 128;
         double* W11 = ctx->early + 2 * 128 * 128;
-        BAM_NMAT2(kc, nbq, n, ctx->pp, (long long)n2 * gcols, gcols, N0, M1, Nd, early ? G11 : (double*)nullptr);
+        BAM_NMAT2(kc, nbq, n, ctx->pp, (long long)n2 * gcols, gcols, N0, M1, Nd, (early || basis) ? G11 : (double*)nullptr);
         // (the magnitude guard of the rank-revealing rule sees this block's own diagonal: the second block's is not known yet)
         const cholw_job beside{n, G11, n, R11, n, W11, n, ctx->ints, 0, 0, nullptr, 0, 0};
         if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_bam,
@@ -986,7 +1022,28 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
                                          early ? &beside : nullptr)))
             return rc;
         ctx->early_ready = early ? 1 : 0;
-        hipLaunchKernelGGL(k_bam_zw, dim3((D + 15) / 16), dim3(512), 0, st, D, n, Wq, M1, Ld, Ldinv, Ldinv + 2 * n, zerov, zerov,
+        const double* M1z = M1;                    // the n x n matrix k_bam_zw multiplies Vw with: M1, or M1' in the orthogonal basis
+        ctx->chain_jp = nullptr;
+        if (basis) {
+            const size_t R2 = (size_t)ctx->rmax * ctx->rmax, q2 = (size_t)(ctx->rmax / 2) * (ctx->rmax / 2);
+            double* Jp = ctx->basis;               // n2 x n2
+            double* RJ = Jp + R2;                  // n2 x n2
+            double* Tb = RJ + R2;                  // n x n each: T, M1', Dm = M1 - M1', Pi
+            double* M1p = Tb + q2;
+            double* Dm = M1p + q2;
+            double* Pi = Dm + q2;
+            // n <= 64: no launch to ride beside.  A failure (dependent draws) joins the flag of BaM's own chain: the update reverts
+            if (!early && (rc = gsmvi_cholw_small(st, n, G11, R11, W11, info_bam, 1000))) return rc;
+            small_gemm_launch(st, OpBasisT{n, n, n, W11, M1, Tb, n});
+            small_gemm_launch(st, OpBasisM1p{n, n, n, W11, Tb, M1, M1p, Dm, n});
+            small_gemm_launch(st, OpBasisPi{n, n, n, Ld, Dm, Pi, Jp});
+            small_gemm_launch(st, OpBasisJ11{n, n, n, Pi, Jp});
+            hipLaunchKernelGGL(k_bamf_vgfix, dim3(1), dim3(256), 0, st, n, Ld, Dm, Ldinv, const_cast<double*>(Ldinv) + 2 * n);
+            M1z = M1p;
+            ctx->chain_jp = Jp;
+            ctx->chain_rj = RJ;
+        }
+        hipLaunchKernelGGL(k_bam_zw, dim3((D + 15) / 16), dim3(512), 0, st, D, n, Wq, M1z, Ld, Ldinv, Ldinv + 2 * n, zerov, zerov,
                            reg, Ft, T1, Ft + (size_t)n2 * D);
     }
     ctx->fo_Rt = Ft;
@@ -1022,6 +1079,8 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
             rc = gsmvi_factor_signed_back(ctx, st, D, n, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, kcg, rides, taken, 0);
     }
     ctx->fo_Rt = ctx->fo_Tm = ctx->fo_Fs = nullptr;
+    ctx->chain_jp = nullptr;
+    ctx->chain_rj = nullptr;
     if (rc) return rc;
     hipLaunchKernelGGL(k_bamf_commit, dim3((D + 255) / 256), dim3(256), 0, st, D, Tm + (size_t)n2 * D, mu0, xbar, reg, info_dev,
                        mu);

@@ -1079,7 +1079,9 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
 int gsmvi_factor_signed_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, int* kcg, int* info_dev, int* rides) {
     const int n = 2 * Bh;
     const factor_ws w = factor_carve(ctx, D, n);
-    *rides = (ctx->tune_rider && n <= 64 && !ctx->tune_no_fast) ? 1 : 0;
+    // (a dense signature matrix J' -- the orthogonal-basis form of gsmvi_bam.hip, ctx->chain_jp -- takes the multi-launch chain:
+    // the one-workgroup rider has no room for J' in LDS)
+    *rides = (ctx->tune_rider && n <= 64 && !ctx->tune_no_fast && !ctx->chain_jp) ? 1 : 0;
     int rc = factor_gram(ctx, st, D, n, w, kcg, *rides ? ctx->tune_gram_mt : 4);
     if (rc) return rc;
     if (*rides) {                                  // the chain rides in the caller's next fast panel launch (k_panel_fast<.., RIDER>)
@@ -1113,7 +1115,15 @@ int gsmvi_factor_signed_back(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, cons
     const factor_ws w = factor_carve(ctx, D, 2 * Bh);
     const int finished = !rides && taken && 2 * Bh <= 128;
     return factor_back(ctx, st, D, Bh, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, (kcg > 1 && finished) ? w.Gam1 : w.Gp,
-                       finished ? 1 : kcg, nullptr, 0, 1, (rides && taken) ? 1 : 0, join ? 2 : 0);
+                       finished ? 1 : kcg, nullptr, 0, ctx->chain_jp ? 2 : 1, (rides && taken) ? 1 : 0, join ? 2 : 0);
+}
+
+// [A | I] -> [R | W] of one n x n matrix, n <= 64, plain positive-definite rule, compact leading dimension n (gsmvi_bam.hip)
+// info_off > 0: a failure is ADDED to *info (recorded only when nothing failed before; an earlier flag stays)
+int gsmvi_cholw_small(hipStream_t st, int n, const double* A, double* R, double* W, int* info, int info_off) {
+    hipLaunchKernelGGL((k_cholw_ld<false, false>), dim3(1), dim3(512), 0, st, n, A, n, R, n, W, n, info, info_off, 0,
+                       (const double*)nullptr, 0, 0);
+    return chk("k_cholw_ld");
 }
 
 // Batch-sharded form, stage 1: this rank's B_local samples -> records.
@@ -1203,21 +1213,38 @@ static int factor_chain_big(gsmvi_ctx* ctx, hipStream_t st, int n, int B, const 
     const OpBlkW21 op_w21{n2, n1, n1, T1g, w.Pm, w.Rg, n, n, n1};
     const OpSmallA op_a{n, n, n, w.Rg, info_g, w.Ap, B, jmode, n};     // A' = I + Rg J Rg^T = T^T T (plain rule: this IS the accept test)
     const OpBlkR12 op_r12t{n1, n2, n1, Wt, w.Ap, w.Tt, n1, n, n, n1};
+    // jmode 2 (dense J', gsmvi_bam.hip): A' = I + (Rg J') Rg^T; the rows of Rg J' come a block row at a time, as Rg does
+    const OpChainRJ op_rj1{n1, n, n, w.Rg, ctx->chain_jp, ctx->chain_rj, n, 0}, op_rj2{n2, n, n, w.Rg, ctx->chain_jp, ctx->chain_rj, n, n1};
+    const OpSmallA2 op_a2{n, n, n, ctx->chain_rj, w.Rg, info_g, w.Ap, n};
     if (pair) {
         // A'11 = I + (Rg J Rg^T)_11 needs only [R11 R12]: its factorisation runs beside Gamma's second block, one launch.
         // Independent PRODUCTS share launches too (k_small_gemm2): S22 with A'11, T1 with A', W21 with T's R12.
-        small_gemm_launch2(st, op_s22g, OpSmallA{n1, n1, n, w.Rg, info_g, w.Ap, B, jmode, n});
+        if (jmode == 2) {
+            small_gemm_launch2(st, op_s22g, op_rj1);
+            small_gemm_launch(st, OpSmallA2{n1, n1, n, ctx->chain_rj, w.Rg, info_g, w.Ap, n});
+        } else
+            small_gemm_launch2(st, op_s22g, OpSmallA{n1, n1, n, w.Rg, info_g, w.Ap, B, jmode, n});
         const cholw_job ja{n2, S22g, n2, w.Rg + off, n, w.Pm + off, n, info_g, n1, 1, w.Gam, n, n + 1};
         const cholw_job jb{n1, w.Ap, n, w.Tt, n, Wt, n1, info_t, 0, 0, nullptr, 0, 0};
         hipLaunchKernelGGL(k_cholw_pair, dim3(2), dim3(512), 0, st, ja, jb);
-        small_gemm_launch2(st, op_t1, op_a);
-        small_gemm_launch2(st, op_w21, op_r12t);
+        if (jmode == 2) {
+            small_gemm_launch2(st, op_t1, op_rj2);
+            small_gemm_launch2(st, op_w21, op_a2);
+            small_gemm_launch(st, op_r12t);
+        } else {
+            small_gemm_launch2(st, op_t1, op_a);
+            small_gemm_launch2(st, op_w21, op_r12t);
+        }
     } else {
         small_gemm_launch(st, op_s22g);
         cholw(true, n2, S22g, n2, w.Rg + off, n, w.Pm + off, n, info_g, n1, 1, w.Gam);
         small_gemm_launch(st, op_t1);
         small_gemm_launch(st, op_w21);
-        small_gemm_launch(st, op_a);
+        if (jmode == 2) {
+            small_gemm_launch(st, OpChainRJ{n, n, n, w.Rg, ctx->chain_jp, ctx->chain_rj, n, 0});
+            small_gemm_launch(st, op_a2);
+        } else
+            small_gemm_launch(st, op_a);
         cholw(false, n1, w.Ap, n, w.Tt, n, Wt, n1, info_t, 0, 0, nullptr);
         small_gemm_launch(st, op_r12t);
     }
@@ -1246,7 +1273,7 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
     double* Kmat;
     const int* prior = jmode ? ctx->ints + 8 : nullptr;      // the flag of BaM's (B x B) chain
 
-    if (n <= 64) {
+    if (n <= 64 && jmode != 2) {
         // everything small in one workgroup
         Kmat = w.Rg;
         if (!chain_done) {                         // (chain_done: it ran as the rider workgroup of the caller's panel product)
@@ -1267,12 +1294,20 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
             vf_slabs = ctx->pp;
         }
         // Gram matrix: semi-definite rule; W = Rg^-T comes out of the same factorisation (no substitution launch)
-        hipLaunchKernelGGL(k_chol128w<true>, dim3(1), dim3(512), 0, st, n, w.Gam, w.Rg, w.Pm, info_g);
+        if (n > 64) hipLaunchKernelGGL(k_chol128w<true>, dim3(1), dim3(512), 0, st, n, w.Gam, w.Rg, w.Pm, info_g);
+        else hipLaunchKernelGGL((k_cholw_ld<true, false>), dim3(1), dim3(512), 0, st, n, w.Gam, n, w.Rg, n, w.Pm, n, info_g, 0, 0,
+                                (const double*)nullptr, 0, 0);           // (n <= 64 comes here only with a dense J': jmode 2)
         // A' = I + Rg J Rg^T, then its plain factorisation T -- the accept / revert test.  (Round 4: the three n x n products of
         // this chain run on the generic MFMA block kernel of gsmvi_smallgemm.h, 64 workgroups each; the VALU dot-product
         // kernel k_gsmf_small_a (14.4 us) and the 16-workgroup k_gsmf_gemm128 (16.5 + 13 us) they replace were deleted.)
-        small_gemm_launch(st, OpSmallA{n, n, n, w.Rg, info_g, w.Ap, B, jmode, n});
-        hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n, w.Ap, w.Tt, n, info_t, 0);
+        if (jmode == 2) {                          // dense J' (gsmvi_bam.hip, orthogonal-basis form): Rg J' first, then (Rg J') Rg^T
+            small_gemm_launch(st, OpChainRJ{n, n, n, w.Rg, ctx->chain_jp, ctx->chain_rj, n, 0});
+            small_gemm_launch(st, OpSmallA2{n, n, n, ctx->chain_rj, w.Rg, info_g, w.Ap, n});
+        } else
+            small_gemm_launch(st, OpSmallA{n, n, n, w.Rg, info_g, w.Ap, B, jmode, n});
+        if (n > 64) hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n, w.Ap, w.Tt, n, info_t, 0);
+        else hipLaunchKernelGGL((k_cholw_ld<false, false>), dim3(1), dim3(512), 0, st, n, w.Ap, n, w.Tt, n, w.Gam1, n, info_t, 0, 0,
+                                (const double*)nullptr, 0, 0);           // (its inverse factor is not used: Gam1 is free here)
         if ((rc = chk("k_chol128"))) return rc;
         double* Pmat = w.Ap;                       // A' is dead once T exists
         // P = (T - I) (W S), with the chain's accept / revert decision; then K'' = (W S)^T P

@@ -227,3 +227,88 @@ struct OpChainK {                                  // K'' = (W S)^T P
     __device__ double b(int k, int j) const { return P[(size_t)k * m + j]; }
     __device__ void store(int i, int j, double v) const { Kmat[(size_t)i * m + j] = v; }
 };
+
+// ---- factor-form BaM in the basis [Vw; Zt] (round 5; gsmvi_bam.hip, "bam_basis") ---------------------------------------------
+// With Gvv = Vw Vw^T = R11^T R11, W11 = R11^-T (the early first block of the chain's Gram matrix), M1 = Vw Wq^T and W^T = (L^-1)^T:
+//   T   = W11 M1                 M1' = -Gvv^-1 M1 = -W11^T T          Dm = M1 - M1'
+//   Zt  = L^-1 (Wq + M1'^T Vw)   = the part of Zw = L^-1 (Wq + M1^T Vw) orthogonal to the rows of Vw        (k_bam_zw with M1')
+//   Pi  = L^-1 Dm^T              Zw = Zt + Pi Vw
+//   M   = I + Vw^T Vw - Zw^T Zw = I + [Vw; Zt]^T J' [Vw; Zt],   J' = [[I - Pi^T Pi, -Pi^T], [-Pi, -I]]
+struct OpBasisT {                                  // T = W11 M1
+    static constexpr bool A_KMAJOR = true, B_KMAJOR = false;
+    int m, p, K;
+    const double *W11, *M1;
+    double* T;
+    int ldw;
+    __device__ bool skip() const { return false; }
+    __device__ double a(int i, int k) const { return W11[(size_t)i * ldw + k]; }
+    __device__ double b(int k, int j) const { return M1[(size_t)k * p + j]; }
+    __device__ void store(int i, int j, double v) const { T[(size_t)i * p + j] = v; }
+};
+struct OpBasisM1p {                                // M1' = -W11^T T, Dm = M1 - M1'
+    static constexpr bool A_KMAJOR = false, B_KMAJOR = false;
+    int m, p, K;
+    const double *W11, *T, *M1;
+    double *M1p, *Dm;
+    int ldw;
+    __device__ bool skip() const { return false; }
+    __device__ double a(int i, int k) const { return W11[(size_t)k * ldw + i]; }
+    __device__ double b(int k, int j) const { return T[(size_t)k * p + j]; }
+    __device__ void store(int i, int j, double v) const {
+        M1p[(size_t)i * p + j] = -v;
+        Dm[(size_t)i * p + j] = M1[(size_t)i * p + j] + v;
+    }
+};
+struct OpBasisPi {                                 // Pi = W Dm^T (W = L^-1 given as Wt = W^T); the off-diagonal and (2,2) blocks of J'
+    static constexpr bool A_KMAJOR = false, B_KMAJOR = true;
+    int m, p, K;                                   // n, n, n
+    const double *Wt, *Dm;
+    double *Pi, *Jp;
+    __device__ bool skip() const { return false; }
+    __device__ double a(int i, int k) const { return Wt[(size_t)k * m + i]; }
+    __device__ double b(int k, int j) const { return Dm[(size_t)j * m + k]; }
+    __device__ void store(int i, int j, double v) const {
+        const int n = m, n2 = 2 * m;
+        Pi[(size_t)i * n + j] = v;
+        Jp[(size_t)(n + i) * n2 + j] = -v;                       // -Pi
+        Jp[(size_t)j * n2 + n + i] = -v;                         // -Pi^T
+        Jp[(size_t)(n + i) * n2 + n + j] = (i == j) ? -1.0 : 0.0;
+    }
+};
+struct OpBasisJ11 {                                // J'[0:n, 0:n] = I - Pi^T Pi
+    static constexpr bool A_KMAJOR = false, B_KMAJOR = false;
+    int m, p, K;
+    const double* Pi;
+    double* Jp;
+    __device__ bool skip() const { return false; }
+    __device__ double a(int i, int k) const { return Pi[(size_t)k * m + i]; }
+    __device__ double b(int k, int j) const { return Pi[(size_t)k * m + j]; }
+    __device__ void store(int i, int j, double v) const { Jp[(size_t)i * (2 * m) + j] = (i == j ? 1.0 : 0.0) - v; }
+};
+struct OpChainRJ {                                 // (Rg J')[row0 + i][j] for a block of rows of Rg
+    static constexpr bool A_KMAJOR = true, B_KMAJOR = false;
+    int m, p, K;                                   // rows, n2, n2
+    const double *Rg, *Jp;
+    double* RJ;
+    int ld, row0;
+    __device__ bool skip() const { return false; }
+    __device__ double a(int i, int k) const { return Rg[(size_t)(row0 + i) * ld + k]; }
+    __device__ double b(int k, int j) const { return Jp[(size_t)k * p + j]; }
+    __device__ void store(int i, int j, double v) const { RJ[(size_t)(row0 + i) * p + j] = v; }
+};
+struct OpSmallA2 {                                 // A' = I + (Rg J') Rg^T for a dense J' (jmode 2); the leading m x m block when m < n
+    static constexpr bool A_KMAJOR = true, B_KMAJOR = true;
+    int m, p, K;
+    const double *RJ, *Rg;
+    const int* info_g;
+    double* Ap;
+    int ld;                                        // leading dimension of Rg, RJ and A' (n2)
+    __device__ bool skip() const { return false; }
+    __device__ double a(int i, int k) const { return RJ[(size_t)i * ld + k]; }
+    __device__ double b(int k, int j) const { return Rg[(size_t)j * ld + k]; }
+    __device__ void store(int i, int j, double v) const {
+        double x = (i == j ? 1.0 : 0.0) + v;
+        if (*info_g != 0) x = (i == j) ? -1.0 : 0.0;  // Gamma was singular: force the PD test to fail
+        Ap[(size_t)i * ld + j] = x;
+    }
+};
