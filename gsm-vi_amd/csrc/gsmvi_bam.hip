@@ -950,6 +950,92 @@ __global__ __launch_bounds__(256) void k_bamf_vgfix(int n, const double* __restr
         vg[tid] -= d;
     }
 }
+// ---- n <= 48 (the one-launch BaM chain k_bam_small48 gives L, not L^-1): G11 from the Gram slabs, then everything the
+// orthogonal basis needs in ONE workgroup.  Small matrices in LDS ([48][49]), plain loops: ~1e5 multiply-adds per product.
+//   T = W11 M1;  M1' = -W11^T T (-> global);  Dm = M1 - M1';  Pi = L^-1 Dm^T (forward substitution, one column per thread);
+//   J' = [[I - Pi^T Pi, -Pi^T], [-Pi, -I]] (-> global);  vg <- vg - Dm (L^-T zg)  (back substitution inside wave 0)
+__global__ __launch_bounds__(256) void k_bamf_g11(int n, int kc, const double* __restrict__ slabs, long long stride, int ldp,
+                                                  double* __restrict__ G11) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * n) return;
+    const int i = e / n, j = e - i * n;
+    double t[GSMVI_MAX_KC];
+#pragma unroll
+    for (int q = 0; q < GSMVI_MAX_KC; ++q) t[q] = slabs[(size_t)(q < kc ? q : kc - 1) * stride + (size_t)(n + i) * ldp + n + j];
+    double a = 0.0;
+#pragma unroll
+    for (int q = 0; q < GSMVI_MAX_KC; ++q) a += (q < kc) ? t[q] : 0.0;
+    G11[e] = a;
+}
+#define BAMB_SN 48
+#define BAMB_LS 49
+__global__ __launch_bounds__(512) void k_bamf_basis48(int n, const double* __restrict__ W11, const double* __restrict__ M1,
+                                                      const double* __restrict__ L, const double* __restrict__ Ldinv,
+                                                      const double* __restrict__ zg, double* __restrict__ vg,
+                                                      double* __restrict__ M1p, double* __restrict__ Pi,
+                                                      double* __restrict__ Jp) {
+    constexpr int LS = BAMB_LS, MS = BAMB_SN * BAMB_LS;
+    __shared__ double Ws[MS], Ms[MS], Ts[MS], Lsm[MS], Ps[MS], sdi[BAMB_SN], szg[BAMB_SN], st2[BAMB_SN];
+    const int tid = threadIdx.x, n2 = 2 * n;
+    for (int e = tid; e < n * n; e += 512) {
+        const int i = e / n, j = e - i * n;
+        Ws[i * LS + j] = W11[e];                       // lower triangular (R11^-T)
+        Ms[i * LS + j] = M1[e];
+        Lsm[i * LS + j] = L[e];
+    }
+    if (tid < n) { sdi[tid] = Ldinv[tid]; szg[tid] = zg[tid]; }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 512) {           // T = W11 M1 (k <= i)
+        const int i = e / n, j = e - i * n;
+        double a = 0.0;
+        for (int k = 0; k <= i; ++k) a += Ws[i * LS + k] * Ms[k * LS + j];
+        Ts[i * LS + j] = a;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 512) {           // M1' = -W11^T T (k >= i), Dm = M1 - M1' (in place of M1)
+        const int i = e / n, j = e - i * n;
+        double a = 0.0;
+        for (int k = i; k < n; ++k) a += Ws[k * LS + i] * Ts[k * LS + j];
+        M1p[e] = -a;
+        Ms[i * LS + j] += a;
+    }
+    __syncthreads();
+    if (tid < n) {                                     // Pi[:, j] = L^-1 Dm[j, :]^T: column j = this thread
+        const int j = tid;
+        for (int i = 0; i < n; ++i) {
+            double a = Ms[j * LS + i];
+            for (int k = 0; k < i; ++k) a -= Lsm[i * LS + k] * Ps[k * LS + j];
+            Ps[i * LS + j] = a * sdi[i];
+        }
+    } else if (tid >= 64 && tid < 128) {               // wave 1: t2 = L^-T zg by column-oriented back substitution in registers
+        const int k = tid - 64;
+        double y = k < n ? szg[k] : 0.0;
+        for (int i = n - 1; i >= 0; --i) {
+            const double ti = __shfl(y, i, 64) * sdi[i];
+            if (k == i) y = ti;                        // (lane i keeps t_i)
+            else if (k < i) y -= Lsm[i * LS + k] * ti;
+        }
+        if (k < n) st2[k] = y;
+    }
+    __syncthreads();
+    if (tid < n) {                                     // vg' = vg - Dm t2
+        double d = 0.0;
+        for (int k = 0; k < n; ++k) d += Ms[tid * LS + k] * st2[k];
+        vg[tid] -= d;
+    }
+    for (int e = tid; e < n * n; e += 512) {           // Pi and the blocks of J'
+        const int i = e / n, j = e - i * n;
+        const double pij = Ps[i * LS + j];
+        Pi[e] = pij;
+        Jp[(size_t)(n + i) * n2 + j] = -pij;
+        Jp[(size_t)j * n2 + n + i] = -pij;
+        Jp[(size_t)(n + i) * n2 + n + j] = (i == j) ? -1.0 : 0.0;
+        double a = 0.0;
+        for (int k = 0; k < n; ++k) a += Ps[k * LS + i] * Ps[k * LS + j];
+        Jp[(size_t)i * n2 + j] = (i == j ? 1.0 : 0.0) - a;
+    }
+}
+
 // [A | I] -> [R | W] of one n x n matrix (n <= 64) in its own launch: the first diagonal block Gvv = Vw Vw^T when there is no
 // k_bam_cholw launch to ride beside (n <= 64); plain positive-definite rule (dependent draws are a failure, not a drop)
 int gsmvi_cholw_small(hipStream_t st, int n, const double* A, double* R, double* W, int* info, int info_off);
@@ -985,7 +1071,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     // linearly dependent rows when the fit sits on the fixed point of a Gaussian target.  It needs the explicit
     // W = L^-1 and Gvv = Vw Vw^T, i.e. the multi-kernel chain also for n <= 48.
     const bool basis = ctx->tune_bam_basis != 0 && n <= 128 && ctx->basis != nullptr;
-    const bool fused48 = n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full && !basis;
+    const bool fused48 = n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full;
 
     bam_stats_launch(st, D, B, Z, ldz, (const double*)nullptr, X, ldx, G, ldg, reg, xbar, gbar, zerov, Qt, Ft, (double*)nullptr);
     if ((rc = gsmvi_panel_t_product(ctx, st, D, n, Qt, D, F0, ldf0, D, ctx->pp, &kc))) return rc;
@@ -1000,8 +1086,28 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
         if ((rc = gsmvi_panel_t_product_few_slabs(ctx, st, D, n2, Wq, D, Wq, D, gcols, ctx->pp, &kc))) return rc;
     } else if ((rc = gsmvi_panel_t_product(ctx, st, D, n2, Wq, D, Wq, D, gcols, ctx->pp, &kc))) return rc;
     if (fused48) {
-        if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, n, (size_t)n2 * n, M1, Ld, Upk, info_bam))) return rc;
-        hipLaunchKernelGGL(k_bam_forward16, dim3((D + 15) / 16), dim3(256), 0, st, D, n, Wq, M1, Upk, Ldinv, Ldinv + n,
+        if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, gcols, (size_t)n2 * gcols, M1, Ld, Upk, info_bam))) return rc;
+        const double* M1z = M1;
+        ctx->chain_jp = nullptr;
+        ctx->chain_pi = nullptr;
+        if (basis) {                               // orthogonal basis with the one-launch chain: L is known, not L^-1 (k_bamf_basis48)
+            const size_t R2 = (size_t)ctx->rmax * ctx->rmax, q2 = (size_t)(ctx->rmax / 2) * (ctx->rmax / 2);
+            double* Jp = ctx->basis;
+            double* M1p = Jp + 2 * R2 + q2;
+            double* Pi = M1p + 2 * q2;
+            double* G11 = ctx->early;
+            double* R11 = ctx->early + 128 * 128;
+            double* W11 = ctx->early + 2 * 128 * 128;
+            hipLaunchKernelGGL(k_bamf_g11, dim3((n * n + 255) / 256), dim3(256), 0, st, n, kc, ctx->pp, (long long)n2 * gcols, gcols, G11);
+            if ((rc = gsmvi_cholw_small(st, n, G11, R11, W11, info_bam, 1000))) return rc;
+            hipLaunchKernelGGL(k_bamf_basis48, dim3(1), dim3(512), 0, st, n, W11, M1, Ld, Ldinv, Ldinv + n,
+                               const_cast<double*>(Ldinv) + 2 * n, M1p, Pi, Jp);
+            M1z = M1p;
+            ctx->chain_jp = Jp;
+            ctx->chain_rj = Jp + R2;
+            ctx->chain_pi = Pi;
+        }
+        hipLaunchKernelGGL(k_bam_forward16, dim3((D + 15) / 16), dim3(256), 0, st, D, n, Wq, M1z, Upk, Ldinv, Ldinv + n,
                            Ldinv + 2 * n, zerov, zerov, reg, Ft, T1, Ft + (size_t)n2 * D);
     } else {
         if (!ctx->bam_hint_host) {
@@ -1024,6 +1130,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
         ctx->early_ready = early ? 1 : 0;
         const double* M1z = M1;                    // the n x n matrix k_bam_zw multiplies Vw with: M1, or M1' in the orthogonal basis
         ctx->chain_jp = nullptr;
+        ctx->chain_pi = nullptr;
         if (basis) {
             const size_t R2 = (size_t)ctx->rmax * ctx->rmax, q2 = (size_t)(ctx->rmax / 2) * (ctx->rmax / 2);
             double* Jp = ctx->basis;               // n2 x n2
@@ -1042,6 +1149,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
             M1z = M1p;
             ctx->chain_jp = Jp;
             ctx->chain_rj = RJ;
+            ctx->chain_pi = Pi;
         }
         hipLaunchKernelGGL(k_bam_zw, dim3((D + 15) / 16), dim3(512), 0, st, D, n, Wq, M1z, Ld, Ldinv, Ldinv + 2 * n, zerov, zerov,
                            reg, Ft, T1, Ft + (size_t)n2 * D);
@@ -1081,6 +1189,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     ctx->fo_Rt = ctx->fo_Tm = ctx->fo_Fs = nullptr;
     ctx->chain_jp = nullptr;
     ctx->chain_rj = nullptr;
+    ctx->chain_pi = nullptr;
     if (rc) return rc;
     hipLaunchKernelGGL(k_bamf_commit, dim3((D + 255) / 256), dim3(256), 0, st, D, Tm + (size_t)n2 * D, mu0, xbar, reg, info_dev,
                        mu);

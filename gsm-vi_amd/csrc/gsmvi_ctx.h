@@ -33,6 +33,7 @@ struct gsmvi_panel_extras {
     int* rd_bad = nullptr;
     unsigned long long* rd_stamps = nullptr;
     const int* rd_prior = nullptr;
+    const double* rd_Pi = nullptr;          // jmode 2: the B x B coupling matrix of the orthogonal-basis BaM form (gsmvi_small16.h)
 };
 
 struct gsmvi_ctx {
@@ -70,11 +71,13 @@ struct gsmvi_ctx {
     int tune_bam_full = 0;     // 1 = always enqueue every Newton-Schulz step (ignore the hint; tests)
     int tune_lowrank_kp = 0;   // 64: BaM's low-rank update stages 64 rows per pass for KF > 96 (A/B runs: measured equal to 32)
     int tune_chain_pair = 1;   // two-level chain (128 < 2B <= 256): independent one-workgroup factorisations share a launch (0: A/B runs)
-    int tune_bam_basis = 0;    // 1 = factor-form BaM in the basis [Vw; Zt], Zt = the part of Zw orthogonal to the whitened draws (round 5;
-                               // no dependent rows at the fixed point of a Gaussian target: DESIGN 8.2 item 3)
+    int tune_bam_basis = 1;    // 1 (default) = factor-form BaM in the basis [Vw; Zt], Zt = the part of Zw orthogonal to the whitened draws
+                               // (round 5: no dependent rows at the fixed point of a Gaussian target); 0 = the
+                               // round-4 basis [Vw; Zw] (A/B runs)
     double* basis = nullptr;   // workspace of that form: [J' (R x R) | Rg J' (R x R) | T, M1', M1 - M1', Pi (four (R/2)^2 slots)]
     const double* chain_jp = nullptr;   // set for ONE 2B x 2B chain: the dense signature matrix J' (jmode 2) ...
     double* chain_rj = nullptr;         // ... and where Rg J' goes
+    const double* chain_pi = nullptr;   // ... and the B x B block Pi it is built from (the one-workgroup chain takes Pi itself)
     double* early = nullptr;   // [Gamma11 | R11 | W11], 128 x 128 each: the first diagonal block of the factor-form BaM chain's Gram
                                // matrix (Vw Vw^T, known before the B x B chain) and its factors, produced beside k_bam_cholw
     int early_ready = 0;       // set by gsmvi_bam_factor_impl when that job was launched; consumed by factor_chain_big

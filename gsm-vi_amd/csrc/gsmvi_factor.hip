@@ -579,9 +579,9 @@ __global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double
                                                       double* __restrict__ Kmat, double* __restrict__ coef,
                                                       int* __restrict__ bad_out,
                                                       unsigned long long* __restrict__ stamps, int jmode,
-                                                      const int* __restrict__ prior_bad) {
+                                                      const int* __restrict__ prior_bad, const double* __restrict__ Pi) {
     __shared__ __attribute__((aligned(16))) double lds[GSMF_SMALL16_LDS];
-    gsmf_small16_body(lds, n, B, Gp, kcg, Kmat, coef, bad_out, stamps, jmode, prior_bad);
+    gsmf_small16_body(lds, n, B, Gp, kcg, Kmat, coef, bad_out, stamps, jmode, prior_bad, Pi);
 }
 
 // ---- K'' = (W S)^T (T - I) (W S), W = Rg^-T, for n > 64: W comes out of the Gram matrix's factorisation itself (k_chol128w /
@@ -1079,9 +1079,7 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
 int gsmvi_factor_signed_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, int* kcg, int* info_dev, int* rides) {
     const int n = 2 * Bh;
     const factor_ws w = factor_carve(ctx, D, n);
-    // (a dense signature matrix J' -- the orthogonal-basis form of gsmvi_bam.hip, ctx->chain_jp -- takes the multi-launch chain:
-    // the one-workgroup rider has no room for J' in LDS)
-    *rides = (ctx->tune_rider && n <= 64 && !ctx->tune_no_fast && !ctx->chain_jp) ? 1 : 0;
+    *rides = (ctx->tune_rider && n <= 64 && !ctx->tune_no_fast) ? 1 : 0;
     int rc = factor_gram(ctx, st, D, n, w, kcg, *rides ? ctx->tune_gram_mt : 4);
     if (rc) return rc;
     if (*rides) {                                  // the chain rides in the caller's next fast panel launch (k_panel_fast<.., RIDER>)
@@ -1095,7 +1093,8 @@ int gsmvi_factor_signed_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, int*
         px.rd_coef = w.coef;
         px.rd_bad = info_dev;
         px.rd_stamps = w.stamps;
-        px.rd_jmode = 1;
+        px.rd_jmode = ctx->chain_pi ? 2 : 1;       // (2: the orthogonal-basis form, dense J' = S'^T diag(I, -I) S' given by Pi)
+        px.rd_Pi = ctx->chain_pi;
         px.rd_prior = ctx->ints + 8;               // the flag of BaM's (B x B) chain
     } else if (*kcg > 1 && n <= 128) {             // (n > 128: no side job -- it would keep the caller's 2B + 1-row product off the
                                                    // 64 x 64-tile kernel, 36 us instead of ~15; k_gsmf_gamma_big sums the slabs itself)
@@ -1273,11 +1272,12 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
     double* Kmat;
     const int* prior = jmode ? ctx->ints + 8 : nullptr;      // the flag of BaM's (B x B) chain
 
-    if (n <= 64 && jmode != 2) {
+    if (n <= 64) {
         // everything small in one workgroup
         Kmat = w.Rg;
         if (!chain_done) {                         // (chain_done: it ran as the rider workgroup of the caller's panel product)
-            hipLaunchKernelGGL(k_gsmf_small16, dim3(1), dim3(512), 0, st, n, B, Gp, kcg, Kmat, coef, info_dev, w.stamps, jmode, prior);
+            hipLaunchKernelGGL(k_gsmf_small16, dim3(1), dim3(512), 0, st, n, B, Gp, kcg, Kmat, coef, info_dev, w.stamps, jmode, prior,
+                               jmode == 2 ? ctx->chain_pi : (const double*)nullptr);
             if ((rc = chk("k_gsmf_small16"))) return rc;
         }
     } else if (n > 128) {
@@ -1357,7 +1357,8 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
     if (!ctx->tune_no_fast && D % 2 == 0 && n <= 256) {
         // the fast kernel also writes the mean and counts the revert (any even n <= 256 since round 5)
 #define UF(NPV, RG) hipLaunchKernelGGL((k_gsmf_update_fast<NPV, RG>), dim3(nt * nt), dim3(512), 0, st, D, B, Rt, Fs, F0, ldf0, F, ldf, Tm, coef, mu0, mu, info_dev, n_reverts_dev)
-        if (D % 64 != 0 || n % 32 != 0) { if (n <= 32) UF(1, true); else if (n <= 64) UF(2, true); else if (n <= 128) UF(4, true); else UF(8, true); }
+        const int npsel = n <= 32 ? 1 : (n <= 64 ? 2 : (n <= 128 ? 4 : 8));       // instantiated pass counts; RAG unless n fills them all
+        if (D % 64 != 0 || n != 32 * npsel) { if (n <= 32) UF(1, true); else if (n <= 64) UF(2, true); else if (n <= 128) UF(4, true); else UF(8, true); }
         else { if (n <= 32) UF(1, false); else if (n <= 64) UF(2, false); else if (n <= 128) UF(4, false); else UF(8, false); }
 #undef UF
         ctx->path |= GSMVI_PATH_FUPD_FAST;

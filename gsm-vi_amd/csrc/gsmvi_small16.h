@@ -59,7 +59,8 @@ __device__ __forceinline__ void gsmf_sum_gram_slabs(const double* __restrict__ G
 __device__ __forceinline__ void gsmf_small16_body(double* __restrict__ lds, int n, int B, const double* __restrict__ Gp,
                                                   int kcg, double* __restrict__ Kmat, double* __restrict__ coef,
                                                   int* __restrict__ bad_out, unsigned long long* __restrict__ stamps,
-                                                  int jmode, const int* __restrict__ prior_bad) {
+                                                  int jmode, const int* __restrict__ prior_bad,
+                                                  const double* __restrict__ Pi = nullptr) {
 #define SMALL_STAMP(k)                                                                      \
     do {                                                                                    \
         if (stamps && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memrealtime();        \
@@ -171,6 +172,27 @@ __device__ __forceinline__ void gsmf_small16_body(double* __restrict__ lds, int 
         for (int r = 0; r < 4; ++r) acc[r] += acc1[r];
         return acc;
     };
+    // jmode 2 (round 5, factor-form BaM in the orthogonal basis [Vw; Zt], gsmvi_bam.hip): M = I + Rt^T J' Rt with the DENSE
+    // J' = S'^T diag(I, -I) S', S' = [[I, 0], [Pi, I]].  A' = I + Rg J' Rg^T = I + (Rg S'^T) diag(I, -I) (Rg S'^T)^T, and
+    // Rg S'^T differs from Rg in its (1, 2) block only: R12 + R11 Pi^T -- still upper triangular.  So that block is updated in
+    // place (Rg is read by the A' phase alone; K is built from W = Rg^-T, which is untouched) and everything below runs as jmode 1.
+    if (jmode == 2) {                                  // block-uniform
+        double upd[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                  // B <= 32: at most 1024 entries, two per thread
+            const int e = tid + 512 * u, i = e / B, j = e - i * B;
+            double acc = 0.0;
+            if (e < B * B)
+                for (int k = i; k < B; ++k) acc += E1[i * ES1 + k] * Pi[(size_t)j * B + k];
+            upd[u] = acc;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 512 * u, i = e / B, j = e - i * B;
+            if (e < B * B) E1[i * ES1 + B + j] += upd[u];     // (reads above touch columns < B only, writes columns >= B)
+        }
+        __syncthreads();
+    }
     // W <- W S (column operations on the right half of E1; the A' phase below reads only the left half, so both share this
     // barrier interval): K'' = S^T K S = (W S)^T (T - I) (W S)
     for (int e = tid; e < 64 * 32; e += 512) {

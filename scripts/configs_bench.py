@@ -156,12 +156,12 @@ for name, D, B in (("c4", 1024, 128), ("c4_B32", 1024, 32)):
     tgt = gsmvi_amd.GaussianTarget(st["m"].cpu().numpy(), precision=st["P"].cpu().numpy())
     bam = gsmvi_amd.BaM(D, tgt.lp, tgt.lp_g)
     sched = lambda i: 100.0 / (1 + i)                             # examples/example_bam.py:58
-    bam.fit(1, sched, niter=3, batch_size=B, verbose=False, rng="device")
+    bam.fit(1, sched, niter=3, batch_size=B, verbose=False, rng="device", method="dense")
     torch.cuda.synchronize()
     n, t0 = 60, time.perf_counter()
-    bam.fit(1, sched, niter=n - 1, batch_size=B, verbose=False, rng="device")
+    bam.fit(1, sched, niter=n - 1, batch_size=B, verbose=False, rng="device", method="dense")
     torch.cuda.synchronize()
-    r["F_fit_bam"] = {"it_per_s": n / (time.perf_counter() - t0), "n": n}
+    r["F_fit_bam"] = {"it_per_s": n / (time.perf_counter() - t0), "n": n, "method": "dense (the reference's loop incl. jitter)"}
     if 2 * B <= 256:                                              # factor form: Sigma = F^T F, no D^3 step per iteration (2B <= 256 since round 4)
         F0, _ = eng.potrf(st["S0"])
         Z = eng.normal(B, D, 5, 0)
@@ -176,7 +176,8 @@ for name, D, B in (("c4", 1024, 128), ("c4_B32", 1024, 32)):
         n, t0 = (400 if B <= 64 else 150), time.perf_counter()
         bam.fit(1, sched, niter=n - 1, batch_size=B, verbose=False, rng="device", method="factor")
         torch.cuda.synchronize()
-        r["F_fit_bam_factor"] = {"it_per_s": n / (time.perf_counter() - t0), "n": n, "n_reverts": bam.n_reverts}
+        r["F_fit_bam_factor"] = {"it_per_s": n / (time.perf_counter() - t0), "n": n, "n_reverts": bam.n_reverts,
+                                 "method": "factor (= the default, method='auto', since round 5)"}
     h = {k: st[k].cpu().numpy() for k in ("X", "G", "mu0", "S0")}
     r["cpu_lowrank_update"] = cpu_time(lambda: borc.bam_lowrank_update_exact(h["X"], h["G"], h["mu0"], h["S0"], 1.0), 4.0)
     res["configs"][name] = r

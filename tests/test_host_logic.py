@@ -134,8 +134,8 @@ def test_bam_fit_converges_and_schedule_counts_calls():
 
 
 def test_bam_default_method_rule():
-    """BaM.fit(method="auto") (opt-in; the default is the reference's dense loop): the factor form wherever it exists for the
-    call and the jitter is at most the reference's default (bam.py:140: 1e-6); anything else is the dense loop."""
+    """BaM.fit(method="auto"), the default since round 5: the factor form wherever it exists for the call and the jitter is at
+    most the reference's default (bam.py:140: 1e-6); anything else is the reference's dense loop."""
     D = 6
     m, cov_t, P = orc.make_gaussian_target(D, 17)
     lp_g = lambda x: orc.gaussian_score(x, m, P)      # noqa: E731
@@ -143,11 +143,9 @@ def test_bam_default_method_rule():
 
     def used(**kw):
         bam = BaM(D, None, lp_g, engine=OracleEngine())
-        bam.fit(3, regf=reg.constant(5.0), niter=2, verbose=False, **{"method": "auto", **kw})
+        bam.fit(3, regf=reg.constant(5.0), niter=2, verbose=False, **kw)
         return bam.method_used
 
-    assert BaM(D, None, lp_g, engine=OracleEngine()).fit(3, regf=reg.constant(5.0), niter=1, batch_size=3,
-                                                         verbose=False) is not None
     assert used(batch_size=3) == "factor"                         # 2B <= D, default jitter
     assert used(batch_size=3, jitter=0.0) == "factor"
     assert used(batch_size=3, jitter=1e-3) == "dense"             # a larger jitter is a request for the shift itself
