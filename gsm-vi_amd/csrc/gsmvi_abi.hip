@@ -164,9 +164,9 @@ static void ws_sizes(int D, int B, size_t* n_pp, size_t* n_sg, size_t* n_small, 
     // BaM's Newton-Schulz iterates: five ld x ld matrices, ld = 144 for B + 1 <= 129, else B + 1 rounded up to 16 (R/2 + 16 covers it)
     const size_t ldb = (R / 2 + 16 > 144) ? (size_t)(R / 2 + 16) : 144;
     // + three 128 x 128 slots in front of the Gram slabs: the early first block of the factor-form BaM chain (ctx->early)
-    // + three R x R slots behind everything: the orthogonal-basis form of the factor-form BaM update (ctx->basis; round 5)
+    // + 2 R^2 doubles behind everything (five (R/2)^2 slots): the orthogonal-basis form of the factor-form BaM update (ctx->basis; round 5)
     *n_small = (size_t)8 * R + (size_t)7 * R * R + 4096 + (size_t)5 * ldb * ldb + 64 + ldb * ldb + 64 + 3 * 128 * 128 +
-               (size_t)GSMVI_MAX_KC * R * R + 16 + (size_t)3 * R * R;
+               (size_t)GSMVI_MAX_KC * R * R + 16 + (size_t)2 * R * R;
 }
 
 size_t gsmvi_workspace_bytes(int max_D, int max_B) {
@@ -212,7 +212,7 @@ int gsmvi_create(gsmvi_ctx** out, int device, int max_D, int max_B) {
     c->sg = c->pp + n_pp;
     c->small = c->sg + n_sg;
     c->ints = reinterpret_cast<int*>(c->small + n_small);
-    c->basis = c->small + n_small - (size_t)3 * c->rmax * c->rmax;
+    c->basis = c->small + n_small - (size_t)2 * c->rmax * c->rmax;
     c->gram_slabs = c->basis - ((size_t)GSMVI_MAX_KC * c->rmax * c->rmax + 16);
     c->early = c->gram_slabs - 3 * 128 * 128;
     e = hipMemset(c->ws, 0, c->ws_bytes);

@@ -22,6 +22,7 @@
 
 #include "gsmvi_common.h"
 #include "gsmvi_ctx.h"
+#include "gsmvi_chol64.h"      // readlane_f64
 #include "../../include/gsmvi_hip.h"
 
 // ---- column means and the Helmert factor panels (both BaM forms) ------------------------------------------------------
@@ -953,7 +954,7 @@ __global__ __launch_bounds__(256) void k_bamf_vgfix(int n, const double* __restr
 // ---- n <= 48 (the one-launch BaM chain k_bam_small48 gives L, not L^-1): G11 from the Gram slabs, then everything the
 // orthogonal basis needs in ONE workgroup.  Small matrices in LDS ([48][49]), plain loops: ~1e5 multiply-adds per product.
 //   T = W11 M1;  M1' = -W11^T T (-> global);  Dm = M1 - M1';  Pi = L^-1 Dm^T (forward substitution, one column per thread);
-//   J' = [[I - Pi^T Pi, -Pi^T], [-Pi, -I]] (-> global);  vg <- vg - Dm (L^-T zg)  (back substitution inside wave 0)
+//   Pi -> global (the chain applies J' = S'^T diag(I, -I) S' through it);  vg <- vg - Dm (L^-T zg)  (back substitution in one wave)
 __global__ __launch_bounds__(256) void k_bamf_g11(int n, int kc, const double* __restrict__ slabs, long long stride, int ldp,
                                                   double* __restrict__ G11) {
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -972,11 +973,10 @@ __global__ __launch_bounds__(256) void k_bamf_g11(int n, int kc, const double* _
 __global__ __launch_bounds__(512) void k_bamf_basis48(int n, const double* __restrict__ W11, const double* __restrict__ M1,
                                                       const double* __restrict__ L, const double* __restrict__ Ldinv,
                                                       const double* __restrict__ zg, double* __restrict__ vg,
-                                                      double* __restrict__ M1p, double* __restrict__ Pi,
-                                                      double* __restrict__ Jp) {
+                                                      double* __restrict__ M1p, double* __restrict__ Pi) {
     constexpr int LS = BAMB_LS, MS = BAMB_SN * BAMB_LS;
     __shared__ double Ws[MS], Ms[MS], Ts[MS], Lsm[MS], Ps[MS], sdi[BAMB_SN], szg[BAMB_SN], st2[BAMB_SN];
-    const int tid = threadIdx.x, n2 = 2 * n;
+    const int tid = threadIdx.x;
     for (int e = tid; e < n * n; e += 512) {
         const int i = e / n, j = e - i * n;
         Ws[i * LS + j] = W11[e];                       // lower triangular (R11^-T)
@@ -985,33 +985,56 @@ __global__ __launch_bounds__(512) void k_bamf_basis48(int n, const double* __res
     }
     if (tid < n) { sdi[tid] = Ldinv[tid]; szg[tid] = zg[tid]; }
     __syncthreads();
-    for (int e = tid; e < n * n; e += 512) {           // T = W11 M1 (k <= i)
+    for (int e = tid; e < n * n; e += 512) {           // T = W11 M1 (k <= i); four independent partial sums per entry
         const int i = e / n, j = e - i * n;
-        double a = 0.0;
-        for (int k = 0; k <= i; ++k) a += Ws[i * LS + k] * Ms[k * LS + j];
-        Ts[i * LS + j] = a;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        int k = 0;
+        for (; k + 3 <= i; k += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += Ws[i * LS + k + u] * Ms[(k + u) * LS + j];
+        }
+        for (; k <= i; ++k) a[0] += Ws[i * LS + k] * Ms[k * LS + j];
+        Ts[i * LS + j] = (a[0] + a[1]) + (a[2] + a[3]);
     }
     __syncthreads();
     for (int e = tid; e < n * n; e += 512) {           // M1' = -W11^T T (k >= i), Dm = M1 - M1' (in place of M1)
         const int i = e / n, j = e - i * n;
-        double a = 0.0;
-        for (int k = i; k < n; ++k) a += Ws[k * LS + i] * Ts[k * LS + j];
-        M1p[e] = -a;
-        Ms[i * LS + j] += a;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        int k = i;
+        for (; k + 3 < n; k += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += Ws[(k + u) * LS + i] * Ts[(k + u) * LS + j];
+        }
+        for (; k < n; ++k) a[0] += Ws[k * LS + i] * Ts[k * LS + j];
+        const double v = (a[0] + a[1]) + (a[2] + a[3]);
+        M1p[e] = -v;
+        Ms[i * LS + j] += v;
     }
     __syncthreads();
-    if (tid < n) {                                     // Pi[:, j] = L^-1 Dm[j, :]^T: column j = this thread
-        const int j = tid;
-        for (int i = 0; i < n; ++i) {
-            double a = Ms[j * LS + i];
-            for (int k = 0; k < i; ++k) a -= Lsm[i * LS + k] * Ps[k * LS + j];
-            Ps[i * LS + j] = a * sdi[i];
+    {   // Pi[:, j] = L^-1 Dm[j, :]^T by forward substitution, SIXTEEN lanes per column (lane q keeps x_k for k = q, q + 16,
+        // q + 32 in registers; the row's partial dots meet in a DPP row sum) instead of a 1200-step serial loop per thread
+        const int grp = tid >> 4, q = tid & 15;
+        for (int j = grp; j < n; j += 32) {
+            double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+            for (int i = 0; i < n; ++i) {
+                double a = 0.0;
+                if (q < i) a += Lsm[i * LS + q] * x0;
+                if (q + 16 < i) a += Lsm[i * LS + q + 16] * x1;
+                if (q + 32 < i) a += Lsm[i * LS + q + 32] * x2;
+                a = row16_sum(a);                      // DPP (pure VALU): a ds_bpermute butterfly put ~500 cycles on every row
+                const double xi = (Ms[j * LS + i] - a) * sdi[i];
+                if ((i & 15) == q) {
+                    if (i < 16) x0 = xi; else if (i < 32) x1 = xi; else x2 = xi;
+                    Ps[i * LS + j] = xi;
+                }
+            }
         }
-    } else if (tid >= 64 && tid < 128) {               // wave 1: t2 = L^-T zg by column-oriented back substitution in registers
-        const int k = tid - 64;
+    }
+    if (tid < 64) {                                    // wave 0: t2 = L^-T zg by column-oriented back substitution in registers
+        const int k = tid;
         double y = k < n ? szg[k] : 0.0;
         for (int i = n - 1; i >= 0; --i) {
-            const double ti = __shfl(y, i, 64) * sdi[i];
+            const double ti = readlane_f64(y, i) * sdi[i];   // (i is wave-uniform: v_readlane, not ds_bpermute)
             if (k == i) y = ti;                        // (lane i keeps t_i)
             else if (k < i) y -= Lsm[i * LS + k] * ti;
         }
@@ -1019,21 +1042,16 @@ __global__ __launch_bounds__(512) void k_bamf_basis48(int n, const double* __res
     }
     __syncthreads();
     if (tid < n) {                                     // vg' = vg - Dm t2
-        double d = 0.0;
-        for (int k = 0; k < n; ++k) d += Ms[tid * LS + k] * st2[k];
-        vg[tid] -= d;
+        double d0 = 0.0, d1 = 0.0;
+        int k = 0;
+        for (; k + 1 < n; k += 2) {
+            d0 += Ms[tid * LS + k] * st2[k];
+            d1 += Ms[tid * LS + k + 1] * st2[k + 1];
+        }
+        if (k < n) d0 += Ms[tid * LS + k] * st2[k];
+        vg[tid] -= d0 + d1;
     }
-    for (int e = tid; e < n * n; e += 512) {           // Pi and the blocks of J'
-        const int i = e / n, j = e - i * n;
-        const double pij = Ps[i * LS + j];
-        Pi[e] = pij;
-        Jp[(size_t)(n + i) * n2 + j] = -pij;
-        Jp[(size_t)j * n2 + n + i] = -pij;
-        Jp[(size_t)(n + i) * n2 + n + j] = (i == j) ? -1.0 : 0.0;
-        double a = 0.0;
-        for (int k = 0; k < n; ++k) a += Ps[k * LS + i] * Ps[k * LS + j];
-        Jp[(size_t)i * n2 + j] = (i == j ? 1.0 : 0.0) - a;
-    }
+    for (int e = tid; e < n * n; e += 512) Pi[e] = Ps[(e / n) * LS + (e % n)];
 }
 
 // [A | I] -> [R | W] of one n x n matrix (n <= 64) in its own launch: the first diagonal block Gvv = Vw Vw^T when there is no
@@ -1088,24 +1106,21 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     if (fused48) {
         if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, gcols, (size_t)n2 * gcols, M1, Ld, Upk, info_bam))) return rc;
         const double* M1z = M1;
-        ctx->chain_jp = nullptr;
         ctx->chain_pi = nullptr;
         if (basis) {                               // orthogonal basis with the one-launch chain: L is known, not L^-1 (k_bamf_basis48)
-            const size_t R2 = (size_t)ctx->rmax * ctx->rmax, q2 = (size_t)(ctx->rmax / 2) * (ctx->rmax / 2);
-            double* Jp = ctx->basis;
-            double* M1p = Jp + 2 * R2 + q2;
-            double* Pi = M1p + 2 * q2;
+            const size_t q2 = (size_t)(ctx->rmax / 2) * (ctx->rmax / 2);
+            double* M1p = ctx->basis + q2;
+            double* Pi = ctx->basis + 3 * q2;
             double* G11 = ctx->early;
             double* R11 = ctx->early + 128 * 128;
             double* W11 = ctx->early + 2 * 128 * 128;
             hipLaunchKernelGGL(k_bamf_g11, dim3((n * n + 255) / 256), dim3(256), 0, st, n, kc, ctx->pp, (long long)n2 * gcols, gcols, G11);
             if ((rc = gsmvi_cholw_small(st, n, G11, R11, W11, info_bam, 1000))) return rc;
             hipLaunchKernelGGL(k_bamf_basis48, dim3(1), dim3(512), 0, st, n, W11, M1, Ld, Ldinv, Ldinv + n,
-                               const_cast<double*>(Ldinv) + 2 * n, M1p, Pi, Jp);
+                               const_cast<double*>(Ldinv) + 2 * n, M1p, Pi);
             M1z = M1p;
-            ctx->chain_jp = Jp;
-            ctx->chain_rj = Jp + R2;
             ctx->chain_pi = Pi;
+            ctx->chain_x = ctx->basis + 4 * q2;
         }
         hipLaunchKernelGGL(k_bam_forward16, dim3((D + 15) / 16), dim3(256), 0, st, D, n, Wq, M1z, Upk, Ldinv, Ldinv + n,
                            Ldinv + 2 * n, zerov, zerov, reg, Ft, T1, Ft + (size_t)n2 * D);
@@ -1129,13 +1144,10 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
             return rc;
         ctx->early_ready = early ? 1 : 0;
         const double* M1z = M1;                    // the n x n matrix k_bam_zw multiplies Vw with: M1, or M1' in the orthogonal basis
-        ctx->chain_jp = nullptr;
         ctx->chain_pi = nullptr;
         if (basis) {
-            const size_t R2 = (size_t)ctx->rmax * ctx->rmax, q2 = (size_t)(ctx->rmax / 2) * (ctx->rmax / 2);
-            double* Jp = ctx->basis;               // n2 x n2
-            double* RJ = Jp + R2;                  // n2 x n2
-            double* Tb = RJ + R2;                  // n x n each: T, M1', Dm = M1 - M1', Pi
+            const size_t q2 = (size_t)(ctx->rmax / 2) * (ctx->rmax / 2);
+            double* Tb = ctx->basis;               // n x n each: T, M1', Dm = M1 - M1', Pi, X
             double* M1p = Tb + q2;
             double* Dm = M1p + q2;
             double* Pi = Dm + q2;
@@ -1143,13 +1155,11 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
             if (!early && (rc = gsmvi_cholw_small(st, n, G11, R11, W11, info_bam, 1000))) return rc;
             small_gemm_launch(st, OpBasisT{n, n, n, W11, M1, Tb, n});
             small_gemm_launch(st, OpBasisM1p{n, n, n, W11, Tb, M1, M1p, Dm, n});
-            small_gemm_launch(st, OpBasisPi{n, n, n, Ld, Dm, Pi, Jp});
-            small_gemm_launch(st, OpBasisJ11{n, n, n, Pi, Jp});
+            small_gemm_launch(st, OpBasisPi{n, n, n, Ld, Dm, Pi});
             hipLaunchKernelGGL(k_bamf_vgfix, dim3(1), dim3(256), 0, st, n, Ld, Dm, Ldinv, const_cast<double*>(Ldinv) + 2 * n);
             M1z = M1p;
-            ctx->chain_jp = Jp;
-            ctx->chain_rj = RJ;
             ctx->chain_pi = Pi;
+            ctx->chain_x = Pi + q2;
         }
         hipLaunchKernelGGL(k_bam_zw, dim3((D + 15) / 16), dim3(512), 0, st, D, n, Wq, M1z, Ld, Ldinv, Ldinv + 2 * n, zerov, zerov,
                            reg, Ft, T1, Ft + (size_t)n2 * D);
@@ -1187,9 +1197,8 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
             rc = gsmvi_factor_signed_back(ctx, st, D, n, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, kcg, rides, taken, 0);
     }
     ctx->fo_Rt = ctx->fo_Tm = ctx->fo_Fs = nullptr;
-    ctx->chain_jp = nullptr;
-    ctx->chain_rj = nullptr;
     ctx->chain_pi = nullptr;
+    ctx->chain_x = nullptr;
     if (rc) return rc;
     hipLaunchKernelGGL(k_bamf_commit, dim3((D + 255) / 256), dim3(256), 0, st, D, Tm + (size_t)n2 * D, mu0, xbar, reg, info_dev,
                        mu);

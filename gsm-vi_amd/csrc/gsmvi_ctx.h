@@ -74,10 +74,9 @@ struct gsmvi_ctx {
     int tune_bam_basis = 1;    // 1 (default) = factor-form BaM in the basis [Vw; Zt], Zt = the part of Zw orthogonal to the whitened draws
                                // (round 5: no dependent rows at the fixed point of a Gaussian target); 0 = the
                                // round-4 basis [Vw; Zw] (A/B runs)
-    double* basis = nullptr;   // workspace of that form: [J' (R x R) | Rg J' (R x R) | T, M1', M1 - M1', Pi (four (R/2)^2 slots)]
-    const double* chain_jp = nullptr;   // set for ONE 2B x 2B chain: the dense signature matrix J' (jmode 2) ...
-    double* chain_rj = nullptr;         // ... and where Rg J' goes
-    const double* chain_pi = nullptr;   // ... and the B x B block Pi it is built from (the one-workgroup chain takes Pi itself)
+    double* basis = nullptr;   // workspace of that form: five (R/2)^2 slots -- T, M1', M1 - M1', Pi, X
+    const double* chain_pi = nullptr;   // set for ONE 2B x 2B chain (jmode 2): the B x B block Pi of the dense signature J' ...
+    double* chain_x = nullptr;          // ... and where X = R11 Pi^T goes (the multi-launch chains)
     double* early = nullptr;   // [Gamma11 | R11 | W11], 128 x 128 each: the first diagonal block of the factor-form BaM chain's Gram
                                // matrix (Vw Vw^T, known before the B x B chain) and its factors, produced beside k_bam_cholw
     int early_ready = 0;       // set by gsmvi_bam_factor_impl when that job was launched; consumed by factor_chain_big

@@ -1114,7 +1114,7 @@ int gsmvi_factor_signed_back(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, cons
     const factor_ws w = factor_carve(ctx, D, 2 * Bh);
     const int finished = !rides && taken && 2 * Bh <= 128;
     return factor_back(ctx, st, D, Bh, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, (kcg > 1 && finished) ? w.Gam1 : w.Gp,
-                       finished ? 1 : kcg, nullptr, 0, ctx->chain_jp ? 2 : 1, (rides && taken) ? 1 : 0, join ? 2 : 0);
+                       finished ? 1 : kcg, nullptr, 0, ctx->chain_pi ? 2 : 1, (rides && taken) ? 1 : 0, join ? 2 : 0);
 }
 
 // [A | I] -> [R | W] of one n x n matrix, n <= 64, plain positive-definite rule, compact leading dimension n (gsmvi_bam.hip)
@@ -1193,14 +1193,18 @@ static int factor_chain_big(gsmvi_ctx* ctx, hipStream_t st, int n, int B, const 
         // reads W11 / R11 there and copies them into the n x n matrices
         const double* R11 = ctx->early + 128 * 128;
         const double* W11 = ctx->early + 2 * 128 * 128;
-        small_gemm_launch(st, OpBlkR12{n1, n2, n1, W11, w.Gam, w.Rg, n1, n, n, n1, R11, n1, w.Pm, n});
+        const OpBlkR12 op_r12{n1, n2, n1, W11, w.Gam, w.Rg, n1, n, n, n1, R11, n1, w.Pm, n};
+        if (jmode == 2) small_gemm_launch2(st, op_r12, OpChainX{B, B, B, R11, ctx->chain_pi, ctx->chain_x, n1});   // X = R11 Pi^T rides along
+        else small_gemm_launch(st, op_r12);
     } else {
         // (advisor, round 4) In the factor-form BaM chain (jmode) the early job above guards this block with ITS OWN diagonal
         // (the second block's is not known yet when it runs); the in-chain factorisation does the same, so the accept / revert
         // decision cannot depend on the "chain_pair" knob.  The second block is guarded with the whole diagonal in both modes:
         // an absurd entry anywhere still switches the rank-revealing rule off where it decides (G4, tests/test_gpu_factor.py).
         cholw(true, n1, w.Gam, n, w.Rg, n, w.Pm, n, info_g, 0, 0, jmode ? nullptr : w.Gam);
-        small_gemm_launch(st, OpBlkR12{n1, n2, n1, w.Pm, w.Gam, w.Rg, n, n, n, n1});
+        const OpBlkR12 op_r12{n1, n2, n1, w.Pm, w.Gam, w.Rg, n, n, n, n1};
+        if (jmode == 2) small_gemm_launch2(st, op_r12, OpChainX{B, B, B, w.Rg, ctx->chain_pi, ctx->chain_x, n});
+        else small_gemm_launch(st, op_r12);
     }
     // slots while Gamma is factored: S22 and T1 in Gam1 (free until the end of the chain); A'11 -> Ap, T11 -> Tt, T's inverse
     // factor (only its first block exists and is used: the block-row solve) compact in the upper half of the coefficient slot
@@ -1210,40 +1214,23 @@ static int factor_chain_big(gsmvi_ctx* ctx, hipStream_t st, int n, int B, const 
     const OpBlkS22 op_s22g{n2, n2, n1, w.Rg, w.Gam, S22g, n, n, n1, 1};
     const OpBlkT1 op_t1{n2, n1, n2, w.Pm, w.Rg, T1g, n, n, n1};
     const OpBlkW21 op_w21{n2, n1, n1, T1g, w.Pm, w.Rg, n, n, n1};
-    const OpSmallA op_a{n, n, n, w.Rg, info_g, w.Ap, B, jmode, n};     // A' = I + Rg J Rg^T = T^T T (plain rule: this IS the accept test)
+    const OpSmallA op_a{n, n, n, w.Rg, info_g, w.Ap, B, jmode, n, ctx->chain_x};   // A' = I + Rg J Rg^T = T^T T (plain rule: this IS the accept test)
     const OpBlkR12 op_r12t{n1, n2, n1, Wt, w.Ap, w.Tt, n1, n, n, n1};
-    // jmode 2 (dense J', gsmvi_bam.hip): A' = I + (Rg J') Rg^T; the rows of Rg J' come a block row at a time, as Rg does
-    const OpChainRJ op_rj1{n1, n, n, w.Rg, ctx->chain_jp, ctx->chain_rj, n, 0}, op_rj2{n2, n, n, w.Rg, ctx->chain_jp, ctx->chain_rj, n, n1};
-    const OpSmallA2 op_a2{n, n, n, ctx->chain_rj, w.Rg, info_g, w.Ap, n};
     if (pair) {
         // A'11 = I + (Rg J Rg^T)_11 needs only [R11 R12]: its factorisation runs beside Gamma's second block, one launch.
         // Independent PRODUCTS share launches too (k_small_gemm2): S22 with A'11, T1 with A', W21 with T's R12.
-        if (jmode == 2) {
-            small_gemm_launch2(st, op_s22g, op_rj1);
-            small_gemm_launch(st, OpSmallA2{n1, n1, n, ctx->chain_rj, w.Rg, info_g, w.Ap, n});
-        } else
-            small_gemm_launch2(st, op_s22g, OpSmallA{n1, n1, n, w.Rg, info_g, w.Ap, B, jmode, n});
+        small_gemm_launch2(st, op_s22g, OpSmallA{n1, n1, n, w.Rg, info_g, w.Ap, B, jmode, n, ctx->chain_x});
         const cholw_job ja{n2, S22g, n2, w.Rg + off, n, w.Pm + off, n, info_g, n1, 1, w.Gam, n, n + 1};
         const cholw_job jb{n1, w.Ap, n, w.Tt, n, Wt, n1, info_t, 0, 0, nullptr, 0, 0};
         hipLaunchKernelGGL(k_cholw_pair, dim3(2), dim3(512), 0, st, ja, jb);
-        if (jmode == 2) {
-            small_gemm_launch2(st, op_t1, op_rj2);
-            small_gemm_launch2(st, op_w21, op_a2);
-            small_gemm_launch(st, op_r12t);
-        } else {
-            small_gemm_launch2(st, op_t1, op_a);
-            small_gemm_launch2(st, op_w21, op_r12t);
-        }
+        small_gemm_launch2(st, op_t1, op_a);
+        small_gemm_launch2(st, op_w21, op_r12t);
     } else {
         small_gemm_launch(st, op_s22g);
         cholw(true, n2, S22g, n2, w.Rg + off, n, w.Pm + off, n, info_g, n1, 1, w.Gam);
         small_gemm_launch(st, op_t1);
         small_gemm_launch(st, op_w21);
-        if (jmode == 2) {
-            small_gemm_launch(st, OpChainRJ{n, n, n, w.Rg, ctx->chain_jp, ctx->chain_rj, n, 0});
-            small_gemm_launch(st, op_a2);
-        } else
-            small_gemm_launch(st, op_a);
+        small_gemm_launch(st, op_a);
         cholw(false, n1, w.Ap, n, w.Tt, n, Wt, n1, info_t, 0, 0, nullptr);
         small_gemm_launch(st, op_r12t);
     }
@@ -1300,11 +1287,9 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         // A' = I + Rg J Rg^T, then its plain factorisation T -- the accept / revert test.  (Round 4: the three n x n products of
         // this chain run on the generic MFMA block kernel of gsmvi_smallgemm.h, 64 workgroups each; the VALU dot-product
         // kernel k_gsmf_small_a (14.4 us) and the 16-workgroup k_gsmf_gemm128 (16.5 + 13 us) they replace were deleted.)
-        if (jmode == 2) {                          // dense J' (gsmvi_bam.hip, orthogonal-basis form): Rg J' first, then (Rg J') Rg^T
-            small_gemm_launch(st, OpChainRJ{n, n, n, w.Rg, ctx->chain_jp, ctx->chain_rj, n, 0});
-            small_gemm_launch(st, OpSmallA2{n, n, n, ctx->chain_rj, w.Rg, info_g, w.Ap, n});
-        } else
-            small_gemm_launch(st, OpSmallA{n, n, n, w.Rg, info_g, w.Ap, B, jmode, n});
+        if (jmode == 2)                            // dense J' (gsmvi_bam.hip, orthogonal-basis form): X = R11 Pi^T joins Rg's (1, 2) block
+            small_gemm_launch(st, OpChainX{B, B, B, w.Rg, ctx->chain_pi, ctx->chain_x, n});
+        small_gemm_launch(st, OpSmallA{n, n, n, w.Rg, info_g, w.Ap, B, jmode, n, ctx->chain_x});
         if (n > 64) hipLaunchKernelGGL(k_chol128<false>, dim3(1), dim3(512), 0, st, n, w.Ap, w.Tt, n, info_t, 0);
         else hipLaunchKernelGGL((k_cholw_ld<false, false>), dim3(1), dim3(512), 0, st, n, w.Ap, n, w.Tt, n, w.Gam1, n, info_t, 0, 0,
                                 (const double*)nullptr, 0, 0);           // (its inverse factor is not used: Gam1 is free here)

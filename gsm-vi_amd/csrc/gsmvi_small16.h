@@ -177,14 +177,24 @@ __device__ __forceinline__ void gsmf_small16_body(double* __restrict__ lds, int 
     // Rg S'^T differs from Rg in its (1, 2) block only: R12 + R11 Pi^T -- still upper triangular.  So that block is updated in
     // place (Rg is read by the A' phase alone; K is built from W = Rg^-T, which is untouched) and everything below runs as jmode 1.
     if (jmode == 2) {                                  // block-uniform
+        // Pi (B x B <= 8 KB) through E2 first (the raw Gram matrix there is dead, A' is not written yet): one coalesced pass
+        // instead of B dependent-address global loads per entry (that form cost the rider ~8 us)
+        for (int e = tid; e < B * B; e += 512) E2[(e / B) * ES2 + (e % B)] = Pi[e];
+        __syncthreads();
         double upd[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {                  // B <= 32: at most 1024 entries, two per thread
             const int e = tid + 512 * u, i = e / B, j = e - i * B;
-            double acc = 0.0;
-            if (e < B * B)
-                for (int k = i; k < B; ++k) acc += E1[i * ES1 + k] * Pi[(size_t)j * B + k];
-            upd[u] = acc;
+            double a0 = 0.0, a1 = 0.0;
+            if (e < B * B) {
+                int k = i;
+                for (; k + 1 < B; k += 2) {
+                    a0 += E1[i * ES1 + k] * E2[j * ES2 + k];
+                    a1 += E1[i * ES1 + k + 1] * E2[j * ES2 + k + 1];
+                }
+                if (k < B) a0 += E1[i * ES1 + k] * E2[j * ES2 + k];
+            }
+            upd[u] = a0 + a1;
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {

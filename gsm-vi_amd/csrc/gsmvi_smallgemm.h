@@ -178,12 +178,20 @@ struct OpSmallA {                                  // A' = I + (Rg J) Rg^T;  J =
     const int* info_g;
     double* Ap;
     int B, jmode, ld;                              // ld: leading dimension of Rg and A' (n)
+    // jmode 2 (round 5, factor-form BaM in the orthogonal basis, gsmvi_bam.hip): the dense signature J' = S'^T diag(I, -I) S',
+    // S' = [[I, 0], [Pi, I]], is applied through Rt = Rg S'^T, which differs from Rg in its (1, 2) block only:
+    // Rt12 = R12 + X, X = R11 Pi^T (B x B, OpChainX).  Rg itself stays what W = Rg^-T and the block factorisation need.
+    const double* X = nullptr;
+    __device__ double rt(int i, int k) const {
+        const double r = Rg[(size_t)i * ld + k];
+        return (jmode == 2 && i < B && k >= B) ? r + X[(size_t)i * B + (k - B)] : r;
+    }
     __device__ bool skip() const { return false; }
     __device__ double a(int i, int k) const {
-        if (jmode) return (k < B) ? Rg[(size_t)i * ld + k] : -Rg[(size_t)i * ld + k];
+        if (jmode) return (k < B) ? rt(i, k) : -rt(i, k);
         return (k < B) ? Rg[(size_t)i * ld + B + k] : (Rg[(size_t)i * ld + k - B] - Rg[(size_t)i * ld + k]);
     }
-    __device__ double b(int k, int j) const { return Rg[(size_t)j * ld + k]; }
+    __device__ double b(int k, int j) const { return jmode == 2 ? rt(j, k) : Rg[(size_t)j * ld + k]; }
     __device__ void store(int i, int j, double v) const {
         double x = (i == j ? 1.0 : 0.0) + (jmode ? v : v / (double)B);
         if (*info_g != 0) x = (i == j) ? -1.0 : 0.0;  // Gamma was singular: force the PD test to fail
@@ -233,7 +241,8 @@ struct OpChainK {                                  // K'' = (W S)^T P
 //   T   = W11 M1                 M1' = -Gvv^-1 M1 = -W11^T T          Dm = M1 - M1'
 //   Zt  = L^-1 (Wq + M1'^T Vw)   = the part of Zw = L^-1 (Wq + M1^T Vw) orthogonal to the rows of Vw        (k_bam_zw with M1')
 //   Pi  = L^-1 Dm^T              Zw = Zt + Pi Vw
-//   M   = I + Vw^T Vw - Zw^T Zw = I + [Vw; Zt]^T J' [Vw; Zt],   J' = [[I - Pi^T Pi, -Pi^T], [-Pi, -I]]
+//   M   = I + Vw^T Vw - Zw^T Zw = I + [Vw; Zt]^T J' [Vw; Zt],   J' = [[I - Pi^T Pi, -Pi^T], [-Pi, -I]] = S'^T diag(I, -I) S',
+//   S' = [[I, 0], [Pi, I]]: the chain applies it through Rg S'^T (OpSmallA jmode 2, gsmf_small16_body), J' is never formed
 struct OpBasisT {                                  // T = W11 M1
     static constexpr bool A_KMAJOR = true, B_KMAJOR = false;
     int m, p, K;
@@ -259,56 +268,24 @@ struct OpBasisM1p {                                // M1' = -W11^T T, Dm = M1 - 
         Dm[(size_t)i * p + j] = M1[(size_t)i * p + j] + v;
     }
 };
-struct OpBasisPi {                                 // Pi = W Dm^T (W = L^-1 given as Wt = W^T); the off-diagonal and (2,2) blocks of J'
+struct OpBasisPi {                                 // Pi = W Dm^T (W = L^-1 given as Wt = W^T)
     static constexpr bool A_KMAJOR = false, B_KMAJOR = true;
     int m, p, K;                                   // n, n, n
     const double *Wt, *Dm;
-    double *Pi, *Jp;
+    double* Pi;
     __device__ bool skip() const { return false; }
     __device__ double a(int i, int k) const { return Wt[(size_t)k * m + i]; }
     __device__ double b(int k, int j) const { return Dm[(size_t)j * m + k]; }
-    __device__ void store(int i, int j, double v) const {
-        const int n = m, n2 = 2 * m;
-        Pi[(size_t)i * n + j] = v;
-        Jp[(size_t)(n + i) * n2 + j] = -v;                       // -Pi
-        Jp[(size_t)j * n2 + n + i] = -v;                         // -Pi^T
-        Jp[(size_t)(n + i) * n2 + n + j] = (i == j) ? -1.0 : 0.0;
-    }
+    __device__ void store(int i, int j, double v) const { Pi[(size_t)i * m + j] = v; }
 };
-struct OpBasisJ11 {                                // J'[0:n, 0:n] = I - Pi^T Pi
-    static constexpr bool A_KMAJOR = false, B_KMAJOR = false;
-    int m, p, K;
-    const double* Pi;
-    double* Jp;
-    __device__ bool skip() const { return false; }
-    __device__ double a(int i, int k) const { return Pi[(size_t)k * m + i]; }
-    __device__ double b(int k, int j) const { return Pi[(size_t)k * m + j]; }
-    __device__ void store(int i, int j, double v) const { Jp[(size_t)i * (2 * m) + j] = (i == j ? 1.0 : 0.0) - v; }
-};
-struct OpChainRJ {                                 // (Rg J')[row0 + i][j] for a block of rows of Rg
-    static constexpr bool A_KMAJOR = true, B_KMAJOR = false;
-    int m, p, K;                                   // rows, n2, n2
-    const double *Rg, *Jp;
-    double* RJ;
-    int ld, row0;
-    __device__ bool skip() const { return false; }
-    __device__ double a(int i, int k) const { return Rg[(size_t)(row0 + i) * ld + k]; }
-    __device__ double b(int k, int j) const { return Jp[(size_t)k * p + j]; }
-    __device__ void store(int i, int j, double v) const { RJ[(size_t)(row0 + i) * p + j] = v; }
-};
-struct OpSmallA2 {                                 // A' = I + (Rg J') Rg^T for a dense J' (jmode 2); the leading m x m block when m < n
+struct OpChainX {                                  // X = R11 Pi^T (B x B; R11 upper triangular with leading dimension ldr)
     static constexpr bool A_KMAJOR = true, B_KMAJOR = true;
-    int m, p, K;
-    const double *RJ, *Rg;
-    const int* info_g;
-    double* Ap;
-    int ld;                                        // leading dimension of Rg, RJ and A' (n2)
+    int m, p, K;                                   // B, B, B
+    const double *R11, *Pi;
+    double* X;
+    int ldr;
     __device__ bool skip() const { return false; }
-    __device__ double a(int i, int k) const { return RJ[(size_t)i * ld + k]; }
-    __device__ double b(int k, int j) const { return Rg[(size_t)j * ld + k]; }
-    __device__ void store(int i, int j, double v) const {
-        double x = (i == j ? 1.0 : 0.0) + v;
-        if (*info_g != 0) x = (i == j) ? -1.0 : 0.0;  // Gamma was singular: force the PD test to fail
-        Ap[(size_t)i * ld + j] = x;
-    }
+    __device__ double a(int i, int k) const { return k >= i ? R11[(size_t)i * ldr + k] : 0.0; }
+    __device__ double b(int k, int j) const { return Pi[(size_t)j * m + k]; }
+    __device__ void store(int i, int j, double v) const { X[(size_t)i * m + j] = v; }
 };
