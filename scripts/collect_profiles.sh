@@ -19,8 +19,10 @@ def sh(cmd):
         return f"failed: {e}"
 lib = os.path.join(root, "gsm-vi_amd", "libgsmvi_hip.so")
 box = {"hostname": platform.node(), "utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
-       "gpu_unique_id": sh("/opt/rocm/bin/rocm-smi --showuniqueid 2>/dev/null | grep -i 'unique id' | head -1"),
-       "gpu_name": sh("/opt/rocm/bin/rocminfo 2>/dev/null | grep -m1 'Marketing Name.*MI' "),
+       "gpu_unique_id": sh("/opt/rocm/bin/rocm-smi --showuniqueid 2>/dev/null | grep 'GPU\\[' | head -2 | tr -s ' \\t' ' '"),
+       "gpu_serial": sh("/opt/rocm/bin/rocm-smi --showserial 2>/dev/null | grep 'GPU\\[' | head -2 | tr -s ' \\t' ' '"),
+       "gpu_name": sh("/opt/rocm/bin/rocminfo 2>/dev/null | grep -i 'marketing name' | grep -i -m1 'instinct\\|MI3' | tr -s ' ' ' '"),
+       "gpu_uuid": sh("/opt/rocm/bin/rocminfo 2>/dev/null | grep -i -m2 'uuid' | tail -1 | tr -s ' ' ' '"),
        "rocm": sh("cat /opt/rocm/.info/version 2>/dev/null"), "kernel": platform.release(), "cpus": os.cpu_count(),
        "library_sha256_on_box": hashlib.sha256(open(lib, "rb").read()).hexdigest()}
 json.dump(box, open(os.path.join(out, "box.json"), "w"), indent=1)
@@ -57,6 +59,8 @@ python3 scripts/cov_p_ab.py > $OUT/cov_persistent_ab.txt 2>&1
 python3 scripts/offgrid_bench.py after $OUT/offgrid_after.json > $OUT/offgrid_after.log 2>&1
 python3 scripts/callpath_bench.py $OUT/callpath.json > $OUT/callpath.log 2>&1
 python3 scripts/fit_kc_ab.py 1024 32 2>&1 | grep -v amdgpu.ids > $OUT/fit_kc_ab.txt
+python3 scripts/bam_basis_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/bam_basis_ab.txt
+python3 scripts/cov_ab_rounds.py 2>&1 | grep -v amdgpu.ids > $OUT/cov_ab_rounds.txt
 python3 scripts/soak_round3.py 120 > $OUT/soak.txt 2>&1
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 bench.py --steps 20 --warmup 3 > $OUT/bench_driver_flags.json 2>> $OUT/bench.err

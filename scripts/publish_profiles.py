@@ -61,6 +61,8 @@ plain = {
     "d4096_b32_kernels.txt": "kernel table of bench.py --D 4096 --B 32",
     "fit_kc_ab.txt": "scripts/fit_kc_ab.py: factor-form fit rate by the split-K count of the panel products",
     "cov_persistent_ab.txt": "scripts/cov_p_ab.py",
+    "bam_basis_ab.txt": "scripts/bam_basis_ab.py: factor-form BaM update in the orthogonal basis (default) against the round-4 basis",
+    "cov_ab_rounds.txt": "scripts/cov_ab_rounds.py: the dense update's three kernels, this tree against the round-4 library, same box",
     "traffic.json": "HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes + MFMA pipe utilisation",
     "rocprof_summary.json": "per-kernel stats and raw counters of the bench passes (summary.json of the collection)",
     "soak.txt": "run-to-run bit-identity soak over the (case, kind) pairs, library of this pass",
