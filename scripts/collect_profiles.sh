@@ -124,3 +124,18 @@ if cov:
 json.dump(res, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])
 PY
+# what THIS pass produced, with hashes: scripts/publish_profiles.py publishes only files listed here (the local gpurun_out/ keeps
+# files of earlier passes: gpurun merges, it does not mirror)
+python3 - "$OUT" <<'PYLIST'
+import hashlib, json, os, sys
+out = sys.argv[1]
+files = {}
+for root, _, names in os.walk(out):
+    for n in names:
+        if n == "files.json":
+            continue
+        p = os.path.join(root, n)
+        files[os.path.relpath(p, out)] = {"sha256": hashlib.sha256(open(p, "rb").read()).hexdigest(), "bytes": os.path.getsize(p)}
+json.dump(files, open(os.path.join(out, "files.json"), "w"), indent=1)
+print(len(files), "files listed")
+PYLIST

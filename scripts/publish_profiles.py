@@ -27,6 +27,7 @@ def sha256(path):
     return h.hexdigest()
 
 
+listed = json.load(open(os.path.join(src, "files.json")))      # what the LAST pass on the box wrote (collect_profiles.sh), with hashes
 box = json.load(open(os.path.join(src, "box.json")))
 build = json.load(open(os.path.join(src, "BUILD_INFO.json")))
 if box.get("library_sha256_on_box") != build["libraries"].get("libgsmvi_hip.so"):
@@ -36,8 +37,10 @@ manifest = {"tag": tag, "build": build, "box": box, "files": {}}
 
 def publish(src_rel, dst_name, note):
     sp = os.path.join(src, src_rel)
-    if not os.path.exists(sp):
-        return False
+    if src_rel not in listed or not os.path.exists(sp):
+        return False                             # not part of the last pass (a leftover of an earlier one in the local scratch)
+    if sha256(sp) != listed[src_rel]["sha256"]:
+        sys.exit(f"{src_rel}: local copy differs from what the box wrote")
     shutil.copyfile(sp, os.path.join(dst, dst_name))
     manifest["files"][dst_name] = {"source": os.path.join(f"gpurun_out/prof_{tag}", src_rel), "bytes": os.path.getsize(sp),
                                    "sha256": sha256(sp), "what": note}
@@ -45,7 +48,9 @@ def publish(src_rel, dst_name, note):
 
 
 def first(pattern):
-    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True))
+    hits = sorted(h for h in glob.glob(os.path.join(src, pattern), recursive=True) if os.path.relpath(h, src) in listed)
+    if len(hits) > 1:
+        sys.exit(f"{pattern}: more than one file of the last pass matches: {hits}")
     return os.path.relpath(hits[0], src) if hits else None
 
 
@@ -68,6 +73,9 @@ plain = {
     "soak.txt": "run-to-run bit-identity soak over the (case, kind) pairs, library of this pass",
     "pytest_gpu.txt": "python -m pytest tests -m gpu -q (tail)",
 }
+for stale in os.listdir(dst):                     # the directory is rebuilt from the last pass alone (offgrid.json is re-merged afterwards)
+    if stale not in ("offgrid.json",):
+        os.remove(os.path.join(dst, stale))
 for name, note in plain.items():
     publish("summary.json" if name == "rocprof_summary.json" else name, name, note)
 ks = first("trace/**/*kernel_stats.csv")
