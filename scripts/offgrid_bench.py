@@ -150,17 +150,21 @@ def fit_rates(D, B, st):
     res = {}
 
     def marginal(run, n):
-        run(5)
+        run(3 * n - 1)                               # full-length warm-up (lazy buffers, graph capture of the iteration)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run(n - 1)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        run(3 * n - 1)
-        torch.cuda.synchronize()
-        t3 = time.perf_counter() - t0
-        return {"it_per_s": n / t1, "it_per_s_marginal": 2 * n / (t3 - t1), "n": n}
+        seen = []
+        for _ in range(2):                           # best of two: one host hiccup in a ~50 ms region moves a single pass by 30 %
+            t0 = time.perf_counter()
+            run(n - 1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            run(3 * n - 1)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter() - t0
+            seen.append({"it_per_s": n / t1, "it_per_s_marginal": 2 * n / (t3 - t1)})
+        best = max(seen, key=lambda r: r["it_per_s_marginal"])
+        return {**best, "n": n, "passes": seen}
 
     n = 60 if quick else 200
     for method in ("auto", "dense"):
