@@ -4,7 +4,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gsmvi_amd
-from oracle import gsm_oracle as orc
+import _inputs as orc
 eng = gsmvi_amd.get_engine()
 for D, B in ((256, 8), (1024, 32), (1024, 64), (1024, 128), (4096, 64)):
     st = orc.make_update_state(D, B, 1) if D <= 1024 else None

@@ -1,7 +1,7 @@
 import sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np, gsmvi_amd
-from oracle import gsm_oracle as orc
+import _inputs as orc
 for D, B, n in ((64, 8, 4000), (200, 40, 1500), (300, 100, 600)):
     m, cov_t, P = orc.make_gaussian_target(D, 11)
     tgt = gsmvi_amd.GaussianTarget(m, precision=P)

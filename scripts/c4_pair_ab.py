@@ -5,7 +5,7 @@ one-workgroup factorisation (0).  HIP events, median / min of 200 eager calls, a
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gsmvi_amd
-from oracle import gsm_oracle as orc
+import _inputs as orc
 cases = [(1024, 128), (1024, 96), (2048, 128)] if len(sys.argv) < 3 else [(int(sys.argv[1]), int(sys.argv[2]))]
 eng = gsmvi_amd.get_engine()
 for D, B in cases:

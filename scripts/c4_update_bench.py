@@ -5,7 +5,7 @@ Newton-Schulz step, is recorded in profiles/r04/c4_chain_ab.txt; those kernels w
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gsmvi_amd
-from oracle import gsm_oracle as orc
+import _inputs as orc
 args = [a for a in sys.argv[1:] if a != "prof"]
 D, B = (int(args[0]), int(args[1])) if len(args) > 1 else (1024, 128)
 eng = gsmvi_amd.get_engine()

@@ -3,7 +3,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gsmvi_amd
-from oracle import gsm_oracle as orc
+import _inputs as orc
 D, B = 4096, 64
 eng = gsmvi_amd.get_engine()
 m, cov, P = orc.make_gaussian_target(D, 0, cond=1e8)

@@ -1,7 +1,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gsmvi_amd
-from oracle import gsm_oracle as orc
+import _inputs as orc
 D, B = int(sys.argv[1]), int(sys.argv[2])
 m, cov_t, P = orc.make_gaussian_target(D, 0)
 tgt = gsmvi_amd.GaussianTarget(m, precision=P)
@@ -10,7 +10,8 @@ if method == "bamf":
     gsmvi_amd.BaM(D, tgt.lp, tgt.lp_g).fit(1, gsmvi_amd.Regularizers().constant(1.0), niter=40, batch_size=B, verbose=False,
                                           method="factor")
 elif method == "bam":
-    gsmvi_amd.BaM(D, tgt.lp, tgt.lp_g).fit(1, gsmvi_amd.Regularizers().constant(1.0), niter=40, batch_size=B, verbose=False)
+    gsmvi_amd.BaM(D, tgt.lp, tgt.lp_g).fit(1, gsmvi_amd.Regularizers().constant(1.0), niter=40, batch_size=B, verbose=False,
+                                          method="dense")
 else:
     # graph=False: every launch of every iteration goes through the profiler's kernel trace
     gsmvi_amd.GSM(D, tgt.lp, tgt.lp_g).fit(1, niter=40, batch_size=B, verbose=False, rng="device", method=method, graph=False)

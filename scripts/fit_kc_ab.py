@@ -4,7 +4,7 @@ In the fit the factor is cache-warm, unlike in scripts/ab_panel_kc.py's HBM-cold
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gsmvi_amd
-from oracle import gsm_oracle as orc
+import _inputs as orc
 D, B = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1024, 32)
 eng = gsmvi_amd.get_engine()
 m, cov, P = orc.make_gaussian_target(D, 1)

@@ -19,7 +19,7 @@ VARIANTS = ["", "delay", "oldwb", "oldwb_delay"]
 
 def child(out_path):
     import numpy as np, torch, gsmvi_amd
-    from oracle import gsm_oracle as orc
+    import _inputs as orc
     eng = gsmvi_amd.get_engine()
     res = {}
     for D, B in ((4096, 64), (1024, 64), (1024, 32)):

@@ -4,7 +4,7 @@ import os as _os; _os.environ.setdefault("GSMVI_HIP_DEBUG_LIB", "1")   # gsmvi_d
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gsmvi_amd
-from oracle import gsm_oracle as orc
+import _inputs as orc
 D, B = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1024, 32)
 eng = gsmvi_amd.get_engine()
 g = torch.Generator(device="cuda"); g.manual_seed(0)

@@ -7,7 +7,7 @@ if os.environ.get("SOAK_STAGES"):
     os.environ.setdefault("GSMVI_HIP_DEBUG_LIB", "1")   # the stage views need gsmvi_debug_workspace_ptr (libgsmvi_hip_debug.so)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, gsmvi_amd
-from oracle import gsm_oracle as orc
+import _inputs as orc
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 eng = gsmvi_amd.get_engine()
 for kv in sys.argv[2:]:                     # knob=value ...
