@@ -303,6 +303,54 @@ __global__ __launch_bounds__(256) void k_bam_nmat2(int n, int kc, const double* 
 // staged in LDS and the column's Vf values passed round the 16-lane group by shuffles -- n^2 / 16 multiply-adds per lane.
 // -Z goes to rows n..2n-1 of Fs.  (Larger n: k_bam_zw above, a product with the explicit inverse factor.)
 #define BAMF_NMAX 144
+// Orthogonal basis of the factor form (n <= 48, gsmvi_bam_factor_impl): what depends on the chain's L rides in this launch.
+//   prologue of every workgroup:  vg' = vg - Dm t2   (t2 = L^-T zg from k_bam_small48, Dm from its side workgroup; the mean of
+//                                 bam.py:112 needs Zw^T zg = Zt^T zg + Vw^T Pi^T zg and this kernel forms Vw^T vg - Z^T zg)
+//   one more workgroup (the last): Pi = L^-1 Dm^T by forward substitution, sixteen lanes per column (lane q keeps x_k for
+//                                 k = q, q + 16, q + 32 in registers; the row's partial dots meet in a DPP row sum), and the
+//                                 flag of Gvv's factorisation joins the flag of the chain (a dependent draw reverts the update)
+struct bamf_fix {
+    const double* Dm;                  // null: plain substitution (dense form, bam_basis = 0)
+    const double* t2;
+    const double* Ld;                  // n x n lower
+    double* Pi;
+    int* info;
+    const int* info1;
+};
+#define BAMB_SN 48
+#define BAMB_LS 49
+__device__ __forceinline__ void bamf_pi_rider(int n, const bamf_fix& fx, const double* __restrict__ Ldinv, double* Lsm, double* sdi) {
+    constexpr int LS = BAMB_LS, MS = BAMB_SN * BAMB_LS;
+    double* Ms = Lsm + MS;
+    double* Ps = Ms + MS;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, j = e - i * n;
+        Lsm[i * LS + j] = fx.Ld[e];
+        Ms[i * LS + j] = fx.Dm[e];
+    }
+    if (tid < n) sdi[tid] = Ldinv[tid];
+    if (tid == 0 && *fx.info == 0 && *fx.info1 != 0) *fx.info = 1000 + *fx.info1;
+    __syncthreads();
+    const int grp = tid >> 4, q = tid & 15;
+    for (int j = grp; j < n; j += 16) {                      // Pi[:, j] = L^-1 Dm[j, :]^T
+        double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double a = 0.0;
+            if (q < i) a += Lsm[i * LS + q] * x0;
+            if (q + 16 < i) a += Lsm[i * LS + q + 16] * x1;
+            if (q + 32 < i) a += Lsm[i * LS + q + 32] * x2;
+            a = row16_sum(a);                                // DPP (pure VALU): a ds_bpermute butterfly put ~500 cycles on every row
+            const double xi = (Ms[j * LS + i] - a) * sdi[i];
+            if ((i & 15) == q) {
+                if (i < 16) x0 = xi; else if (i < 32) x1 = xi; else x2 = xi;
+                Ps[i * LS + j] = xi;
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 256) fx.Pi[e] = Ps[(e / n) * LS + (e % n)];
+}
 __global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const double* __restrict__ P,
                                                        const double* __restrict__ M1,
                                                        const double* __restrict__ Upk,
@@ -311,10 +359,15 @@ __global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const doubl
                                                        const double* __restrict__ mu0,
                                                        const double* __restrict__ xbar, double reg,
                                                        double* __restrict__ Ft, double* __restrict__ Fs,
-                                                       double* __restrict__ mu) {
+                                                       double* __restrict__ mu, bamf_fix fx) {
     __shared__ __attribute__((aligned(16))) double U[BAMF_NMAX * (BAMF_NMAX + 1) / 2];
     __shared__ double sdi[BAMF_NMAX], szg[BAMF_NMAX], svg[BAMF_NMAX];
     __shared__ double sM1[64 * 64];
+    static_assert(3 * BAMB_SN * BAMB_LS <= BAMF_NMAX * (BAMF_NMAX + 1) / 2, "the rider's matrices overlay U");
+    if (fx.Dm && blockIdx.x == (unsigned)((D + 15) / 16)) {      // block-uniform: the workgroup behind the column tiles
+        bamf_pi_rider(n, fx, Ldinv, U, sdi);
+        return;
+    }
     const int tid = threadIdx.x, c = tid >> 4, q = tid & 15, grp = tid & 48;
     const int j = blockIdx.x * 16 + c, jc = j < D ? j : D - 1;
     const int npk = n * (n + 1) / 2;
@@ -341,6 +394,15 @@ __global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const doubl
             svg[tid] = tid < n ? vg[r] : 0.0;
         }
     }
+    double vgfix = 0.0;
+    if (fx.Dm) {                                       // vg' = vg - Dm t2 (n <= 48: four lanes per row, k = part, part + 4, ...)
+        const int row = tid >> 2, part = tid & 3, rc = row < n ? row : n - 1;
+        double d = 0.0;
+        for (int k = part; k < n; k += 4) d += fx.Dm[(size_t)rc * n + k] * fx.t2[k];
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        vgfix = d;
+    }
     double x[9], vf[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -363,6 +425,10 @@ __global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const doubl
         }
     }
     __syncthreads();
+    if (fx.Dm) {                                       // (svg is read after the substitution: the barrier below orders it)
+        if ((tid & 3) == 0 && (tid >> 2) < n) svg[tid >> 2] -= vgfix;
+        __syncthreads();
+    }
     {                                                  // x += M1^T vf: vf_k lives in lane k & 15 of the group, register k >> 4
 #pragma unroll
         for (int ik = 0; ik < 4; ++ik) {
@@ -789,7 +855,7 @@ int gsmvi_panel_t_product(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
                           int ldm, int mrows, double* Pp, int* kc_out);
 int gsmvi_bam_small_fused_nmax();
 int gsmvi_bam_small_fused(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* slabs, int kc, int ldslab,
-                          size_t slab_stride, double* M1, double* Ld, double* Upk, int* info_dev);
+                          size_t slab_stride, double* M1, double* Ld, double* Upk, int* info_dev, const bamq_side* side);
 
 #define BAM_NMAT2(KC, NBQ, N_, SL, STR, LDP, N0_, M1_, ND_, G11_)                                                        \
     do {                                                                                                                \
@@ -850,9 +916,9 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     int* info_p = info_dev ? info_dev : ctx->ints + 8;
     int* hint = ctx->tune_bam_full ? nullptr : ctx->bam_hint_host;
     if (fused48) {
-        if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, n, (size_t)n2 * n, M1, Ld, Upk, info_p))) return rc;
+        if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, n, (size_t)n2 * n, M1, Ld, Upk, info_p, nullptr))) return rc;
         hipLaunchKernelGGL(k_bam_forward16, dim3((D + 15) / 16), dim3(256), 0, st, D, n, P, M1, Upk, Ldinv, Ldinv + n,
-                           Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu);
+                           Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu, bamf_fix{});
     } else if (use_w) {
         const int nbq = (n + 15) / 16;
         BAM_NMAT2(kc, nbq, n, ctx->pp, (long long)n2 * n, n, N0, M1, Nd, (double*)nullptr);
@@ -951,109 +1017,6 @@ __global__ __launch_bounds__(256) void k_bamf_vgfix(int n, const double* __restr
         vg[tid] -= d;
     }
 }
-// ---- n <= 48 (the one-launch BaM chain k_bam_small48 gives L, not L^-1): G11 from the Gram slabs, then everything the
-// orthogonal basis needs in ONE workgroup.  Small matrices in LDS ([48][49]), plain loops: ~1e5 multiply-adds per product.
-//   T = W11 M1;  M1' = -W11^T T (-> global);  Dm = M1 - M1';  Pi = L^-1 Dm^T (forward substitution, one column per thread);
-//   Pi -> global (the chain applies J' = S'^T diag(I, -I) S' through it);  vg <- vg - Dm (L^-T zg)  (back substitution in one wave)
-__global__ __launch_bounds__(256) void k_bamf_g11(int n, int kc, const double* __restrict__ slabs, long long stride, int ldp,
-                                                  double* __restrict__ G11) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n * n) return;
-    const int i = e / n, j = e - i * n;
-    double t[GSMVI_MAX_KC];
-#pragma unroll
-    for (int q = 0; q < GSMVI_MAX_KC; ++q) t[q] = slabs[(size_t)(q < kc ? q : kc - 1) * stride + (size_t)(n + i) * ldp + n + j];
-    double a = 0.0;
-#pragma unroll
-    for (int q = 0; q < GSMVI_MAX_KC; ++q) a += (q < kc) ? t[q] : 0.0;
-    G11[e] = a;
-}
-#define BAMB_SN 48
-#define BAMB_LS 49
-__global__ __launch_bounds__(512) void k_bamf_basis48(int n, const double* __restrict__ W11, const double* __restrict__ M1,
-                                                      const double* __restrict__ L, const double* __restrict__ Ldinv,
-                                                      const double* __restrict__ zg, double* __restrict__ vg,
-                                                      double* __restrict__ M1p, double* __restrict__ Pi) {
-    constexpr int LS = BAMB_LS, MS = BAMB_SN * BAMB_LS;
-    __shared__ double Ws[MS], Ms[MS], Ts[MS], Lsm[MS], Ps[MS], sdi[BAMB_SN], szg[BAMB_SN], st2[BAMB_SN];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < n * n; e += 512) {
-        const int i = e / n, j = e - i * n;
-        Ws[i * LS + j] = W11[e];                       // lower triangular (R11^-T)
-        Ms[i * LS + j] = M1[e];
-        Lsm[i * LS + j] = L[e];
-    }
-    if (tid < n) { sdi[tid] = Ldinv[tid]; szg[tid] = zg[tid]; }
-    __syncthreads();
-    for (int e = tid; e < n * n; e += 512) {           // T = W11 M1 (k <= i); four independent partial sums per entry
-        const int i = e / n, j = e - i * n;
-        double a[4] = {0.0, 0.0, 0.0, 0.0};
-        int k = 0;
-        for (; k + 3 <= i; k += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] += Ws[i * LS + k + u] * Ms[(k + u) * LS + j];
-        }
-        for (; k <= i; ++k) a[0] += Ws[i * LS + k] * Ms[k * LS + j];
-        Ts[i * LS + j] = (a[0] + a[1]) + (a[2] + a[3]);
-    }
-    __syncthreads();
-    for (int e = tid; e < n * n; e += 512) {           // M1' = -W11^T T (k >= i), Dm = M1 - M1' (in place of M1)
-        const int i = e / n, j = e - i * n;
-        double a[4] = {0.0, 0.0, 0.0, 0.0};
-        int k = i;
-        for (; k + 3 < n; k += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] += Ws[(k + u) * LS + i] * Ts[(k + u) * LS + j];
-        }
-        for (; k < n; ++k) a[0] += Ws[k * LS + i] * Ts[k * LS + j];
-        const double v = (a[0] + a[1]) + (a[2] + a[3]);
-        M1p[e] = -v;
-        Ms[i * LS + j] += v;
-    }
-    __syncthreads();
-    {   // Pi[:, j] = L^-1 Dm[j, :]^T by forward substitution, SIXTEEN lanes per column (lane q keeps x_k for k = q, q + 16,
-        // q + 32 in registers; the row's partial dots meet in a DPP row sum) instead of a 1200-step serial loop per thread
-        const int grp = tid >> 4, q = tid & 15;
-        for (int j = grp; j < n; j += 32) {
-            double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-            for (int i = 0; i < n; ++i) {
-                double a = 0.0;
-                if (q < i) a += Lsm[i * LS + q] * x0;
-                if (q + 16 < i) a += Lsm[i * LS + q + 16] * x1;
-                if (q + 32 < i) a += Lsm[i * LS + q + 32] * x2;
-                a = row16_sum(a);                      // DPP (pure VALU): a ds_bpermute butterfly put ~500 cycles on every row
-                const double xi = (Ms[j * LS + i] - a) * sdi[i];
-                if ((i & 15) == q) {
-                    if (i < 16) x0 = xi; else if (i < 32) x1 = xi; else x2 = xi;
-                    Ps[i * LS + j] = xi;
-                }
-            }
-        }
-    }
-    if (tid < 64) {                                    // wave 0: t2 = L^-T zg by column-oriented back substitution in registers
-        const int k = tid;
-        double y = k < n ? szg[k] : 0.0;
-        for (int i = n - 1; i >= 0; --i) {
-            const double ti = readlane_f64(y, i) * sdi[i];   // (i is wave-uniform: v_readlane, not ds_bpermute)
-            if (k == i) y = ti;                        // (lane i keeps t_i)
-            else if (k < i) y -= Lsm[i * LS + k] * ti;
-        }
-        if (k < n) st2[k] = y;
-    }
-    __syncthreads();
-    if (tid < n) {                                     // vg' = vg - Dm t2
-        double d0 = 0.0, d1 = 0.0;
-        int k = 0;
-        for (; k + 1 < n; k += 2) {
-            d0 += Ms[tid * LS + k] * st2[k];
-            d1 += Ms[tid * LS + k + 1] * st2[k + 1];
-        }
-        if (k < n) d0 += Ms[tid * LS + k] * st2[k];
-        vg[tid] -= d0 + d1;
-    }
-    for (int e = tid; e < n * n; e += 512) Pi[e] = Ps[(e / n) * LS + (e % n)];
-}
-
 // [A | I] -> [R | W] of one n x n matrix (n <= 64) in its own launch: the first diagonal block Gvv = Vw Vw^T when there is no
 // k_bam_cholw launch to ride beside (n <= 64); plain positive-definite rule (dependent draws are a failure, not a drop)
 int gsmvi_cholw_small(hipStream_t st, int n, const double* A, double* R, double* W, int* info, int info_off);
@@ -1104,26 +1067,22 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
         if ((rc = gsmvi_panel_t_product_few_slabs(ctx, st, D, n2, Wq, D, Wq, D, gcols, ctx->pp, &kc))) return rc;
     } else if ((rc = gsmvi_panel_t_product(ctx, st, D, n2, Wq, D, Wq, D, gcols, ctx->pp, &kc))) return rc;
     if (fused48) {
-        if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, gcols, (size_t)n2 * gcols, M1, Ld, Upk, info_bam))) return rc;
-        const double* M1z = M1;
-        ctx->chain_pi = nullptr;
-        if (basis) {                               // orthogonal basis with the one-launch chain: L is known, not L^-1 (k_bamf_basis48)
-            const size_t q2 = (size_t)(ctx->rmax / 2) * (ctx->rmax / 2);
-            double* M1p = ctx->basis + q2;
-            double* Pi = ctx->basis + 3 * q2;
-            double* G11 = ctx->early;
-            double* R11 = ctx->early + 128 * 128;
-            double* W11 = ctx->early + 2 * 128 * 128;
-            hipLaunchKernelGGL(k_bamf_g11, dim3((n * n + 255) / 256), dim3(256), 0, st, n, kc, ctx->pp, (long long)n2 * gcols, gcols, G11);
-            if ((rc = gsmvi_cholw_small(st, n, G11, R11, W11, info_bam, 1000))) return rc;
-            hipLaunchKernelGGL(k_bamf_basis48, dim3(1), dim3(512), 0, st, n, W11, M1, Ld, Ldinv, Ldinv + n,
-                               const_cast<double*>(Ldinv) + 2 * n, M1p, Pi);
-            M1z = M1p;
-            ctx->chain_pi = Pi;
-            ctx->chain_x = ctx->basis + 4 * q2;
-        }
-        hipLaunchKernelGGL(k_bam_forward16, dim3((D + 15) / 16), dim3(256), 0, st, D, n, Wq, M1z, Upk, Ldinv, Ldinv + n,
-                           Ldinv + 2 * n, zerov, zerov, reg, Ft, T1, Ft + (size_t)n2 * D);
+        // orthogonal basis with the one-launch chain: everything that does not need the chain's L is the launch's second
+        // workgroup (bamq_side), what does rides in the substitution launch (bamf_fix)
+        const size_t q2 = (size_t)(ctx->rmax / 2) * (ctx->rmax / 2);
+        double* M1p = ctx->basis + q2;
+        double* Dm = ctx->basis + 2 * q2;
+        double* Pi = ctx->basis + 3 * q2;
+        double* t2 = ctx->basis;                   // (the T block: T lives in the side workgroup's LDS here)
+        const bamq_side side{M1p, Dm, t2, ctx->ints + 10};
+        if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, gcols, (size_t)n2 * gcols, M1, Ld, Upk, info_bam,
+                                        basis ? &side : nullptr)))
+            return rc;
+        ctx->chain_pi = basis ? Pi : nullptr;
+        ctx->chain_x = basis ? ctx->basis + 4 * q2 : nullptr;
+        const bamf_fix fx = basis ? bamf_fix{Dm, t2, Ld, Pi, info_bam, ctx->ints + 10} : bamf_fix{};
+        hipLaunchKernelGGL(k_bam_forward16, dim3((D + 15) / 16 + (basis ? 1 : 0)), dim3(256), 0, st, D, n, Wq, basis ? M1p : M1, Upk,
+                           Ldinv, Ldinv + n, Ldinv + 2 * n, zerov, zerov, reg, Ft, T1, Ft + (size_t)n2 * D, fx);
     } else {
         if (!ctx->bam_hint_host) {
             if (hipHostMalloc(reinterpret_cast<void**>(&ctx->bam_hint_host), 64, hipHostMallocMapped) == hipSuccess)

@@ -608,11 +608,101 @@ __global__ __launch_bounds__(1024) void k_bam_post_big(int n, double reg, const 
 #define BAMQ_SN 48
 #define BAMQ_LD 50
 #define BAMQ_ES 82
-template <int NB>
+// The orthogonal basis of the factor form (gsmvi_bam.hip, "bam_basis") needs, next to this chain and INDEPENDENT of it:
+//   Gvv = Vw Vw^T (rows and columns n .. 2n-1 of the same Gram slabs), [Gvv | I] -> [R11 | W11],  T = W11 M1,
+//   M1' = -W11^T T = -Gvv^-1 M1,  Dm = M1 - M1'.
+// They are the SECOND workgroup of the launch (PAIR): ~12 us beside the ~30 us chain on another CU instead of three launches
+// (slab sum 4.8 + factorisation 9.2 + products 8 us, round-5 first form) behind it.  The side workgroup sums the M1 slabs itself,
+// in the chain's order (the same bits as M1g), so nothing crosses between the two workgroups.  What does depend on the chain's L
+// -- Pi = L^-1 Dm^T and the correction of vg -- moves into k_bam_forward16's launch (its prologue and one more workgroup).
+#define BAMQ_SIDE_ES 146
+#define BAMQ_SIDE_LS 49
+__device__ __forceinline__ void bamq_side_body(int n, const double* __restrict__ slabs, int kc, int ldslab, long long slab_stride,
+                                               double* sm, double* scr, int* sh_f, const bamq_side& sd) {
+    constexpr int ES = BAMQ_SIDE_ES, LS = BAMQ_SIDE_LS;
+    double* E = sm;                                          // 64 x 146: [Gvv | I] -> [R11 | W11]
+    double* Ms = sm + 64 * ES;                               // M1, then Dm
+    double* Ts = Ms + BAMQ_SN * LS;
+    const int tid = threadIdx.x;
+    for (int e0 = 0; e0 < 64 * 64; e0 += 512 * 2) {          // Gvv: the upper triangle of the slab sums, identity beyond n
+        double t[2][GSMVI_MAX_KC];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = e0 + 512 * u + tid, i = e >> 6, j = e & 63;
+            const int ic = i < n ? i : n - 1, jc = j < n ? j : n - 1;
+#pragma unroll
+            for (int k = 0; k < GSMVI_MAX_KC; ++k)
+                t[u][k] = slabs[(size_t)(k < kc ? k : kc - 1) * slab_stride + (size_t)(n + ic) * ldslab + n + jc];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = e0 + 512 * u + tid, i = e >> 6, j = e & 63;
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < GSMVI_MAX_KC; ++k) a += (k < kc) ? t[u][k] : 0.0;
+            E[i * ES + j] = (i < n && j < n) ? (j >= i ? a : 0.0) : (i == j ? 1.0 : 0.0);
+        }
+    }
+    for (int e0 = 0; e0 < n * n; e0 += 512 * 2) {            // M1: rows n .. 2n-1, columns 0 .. n-1 (the chain's summation order)
+        double t[2][GSMVI_MAX_KC];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int e = e0 + 512 * u + tid;
+            if (e >= n * n) e = n * n - 1;
+            const int r = e / n, c = e - r * n;
+#pragma unroll
+            for (int k = 0; k < GSMVI_MAX_KC; ++k)
+                t[u][k] = slabs[(size_t)(k < kc ? k : kc - 1) * slab_stride + (size_t)(n + r) * ldslab + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = e0 + 512 * u + tid;
+            if (e < n * n) {
+                const int r = e / n, c = e - r * n;
+                double a = 0.0;
+#pragma unroll
+                for (int k = 0; k < GSMVI_MAX_KC; ++k) a += (k < kc) ? t[u][k] : 0.0;
+                Ms[r * LS + c] = a;
+            }
+        }
+    }
+    __syncthreads();
+    chol64_blk<ES, false, 1>(E, scr, n, sh_f);               // (plain rule: dependent draws are a failure, not a drop)
+    __syncthreads();
+    if (tid == 0) *sd.info1 = *sh_f;
+    for (int e = tid; e < n * n; e += 512) {                 // T = W11 M1 (W11 lower: k <= i); four independent partial sums
+        const int i = e / n, j = e - i * n;
+        const double* wr = E + i * ES + 64;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        int k = 0;
+        for (; k + 3 <= i; k += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += wr[k + u] * Ms[(k + u) * LS + j];
+        }
+        for (; k <= i; ++k) a[0] += wr[k] * Ms[k * LS + j];
+        Ts[i * LS + j] = (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 512) {                 // M1' = -W11^T T (k >= i), Dm = M1 - M1'
+        const int i = e / n, j = e - i * n;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        int k = i;
+        for (; k + 3 < n; k += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += E[(k + u) * ES + 64 + i] * Ts[(k + u) * LS + j];
+        }
+        for (; k < n; ++k) a[0] += E[k * ES + 64 + i] * Ts[k * LS + j];
+        const double v = (a[0] + a[1]) + (a[2] + a[3]);
+        sd.M1p[e] = -v;
+        sd.Dm[e] = Ms[i * LS + j] + v;
+    }
+}
+template <int NB, bool PAIR>
 __global__ __launch_bounds__(512) void k_bam_small48(int n, double reg, const double* __restrict__ slabs, int kc, int ldslab,
                                                      long long slab_stride, double* __restrict__ M1g,
                                                      double* __restrict__ Ld, double* __restrict__ Upk,
-                                                     int* __restrict__ info, unsigned long long* __restrict__ stamps) {
+                                                     int* __restrict__ info, unsigned long long* __restrict__ stamps,
+                                                     bamq_side sd) {
 #define Q_STAMP(k)                                                                          \
     do {                                                                                    \
         if (stamps && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memrealtime();        \
@@ -621,9 +711,14 @@ __global__ __launch_bounds__(512) void k_bam_small48(int n, double reg, const do
     if (stamps && (threadIdx.x & 63) == 0) stamps[8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg(2308);   // HW_ID.SIMD_ID
     constexpr int MSZ = BAMQ_SN * BAMQ_LD;                   // 2400 doubles per matrix
     __shared__ __attribute__((aligned(16))) double sm[7 * MSZ];
-    __shared__ __attribute__((aligned(16))) double scr[CHOLB_SCRATCH_DOUBLES(0)];
+    __shared__ __attribute__((aligned(16))) double scr[CHOLB_SCRATCH_DOUBLES(PAIR ? 1 : 0)];
     __shared__ double coefs[BAMS_KMAX + 4], n0c[BAMQ_SN], sc[BAMQ_SN], av[BAMQ_SN], red[8];
     __shared__ int sh_fail, sh_bad;
+    static_assert(64 * BAMQ_SIDE_ES + 2 * BAMQ_SN * BAMQ_SIDE_LS <= 7 * MSZ, "the side workgroup's matrices overlay sm");
+    if (PAIR && blockIdx.x == 1) {                           // block-uniform
+        bamq_side_body(n, slabs, kc, ldslab, slab_stride, sm, scr, &sh_fail, sd);
+        return;
+    }
     double* Ms = sm + 4 * MSZ;
     double* M1s = sm + 5 * MSZ;
     double* Nm = sm + 6 * MSZ;
@@ -874,6 +969,18 @@ __global__ __launch_bounds__(512) void k_bam_small48(int n, double reg, const do
             Ldinv[l] = rinv;
             vg[l] = sc[l];
         }
+        if (PAIR) {                                          // t2 = L^-T zg = R^-1 zg: column-oriented back substitution, the lane's
+            double y = (l < n) ? a0 : 0.0;                   // ROW of R read from LDS as the pivots come (i is wave-uniform: v_readlane)
+#pragma unroll
+            for (int pp = 16 * NB - 1; pp >= 0; --pp) {
+                if (pp < n) {                                // uniform
+                    const double ti = readlane_f64(y, pp) * readlane_f64(rinv, pp);
+                    if (l == pp) y = ti;
+                    else if (l < pp) y -= E[l * BAMQ_ES + pp] * ti;
+                }
+            }
+            if (l < n) sd.t2[l] = y;
+        }
     } else {
         for (int e = tid - 64; e < n * n; e += 448) {
             const int i = e / n, j = e - i * n;              // L[i][j] = R[j][i], j <= i
@@ -889,12 +996,13 @@ int gsmvi_bam_small_fused_nmax() { return BAMQ_SN; }
 
 // n <= 48: slabs of [N0; M1] in, everything out (see k_bam_small48)
 int gsmvi_bam_small_fused(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* slabs, int kc, int ldslab,
-                          size_t slab_stride, double* M1, double* Ld, double* Upk, int* info_dev) {
+                          size_t slab_stride, double* M1, double* Ld, double* Upk, int* info_dev, const bamq_side* side) {
     unsigned long long* stamps = (ctx->tune_cov_dbg & 256)           // diagnostic (scripts/bam48_timeline.py): phase stamps
                                      ? reinterpret_cast<unsigned long long*>(ctx->gram_slabs + (size_t)GSMVI_MAX_KC * ctx->rmax * ctx->rmax)
                                      : nullptr;
-#define SMALL48(NBV) hipLaunchKernelGGL(k_bam_small48<NBV>, dim3(1), dim3(512), 0, st, n, reg, slabs, kc, ldslab, (long long)slab_stride, M1, Ld, Upk, info_dev, stamps)
-    if (n <= 16) SMALL48(1); else if (n <= 32) SMALL48(2); else SMALL48(3);
+#define SMALL48(NBV, PR) hipLaunchKernelGGL((k_bam_small48<NBV, PR>), dim3(PR ? 2 : 1), dim3(512), 0, st, n, reg, slabs, kc, ldslab, (long long)slab_stride, M1, Ld, Upk, info_dev, stamps, PR ? *side : bamq_side{})
+    if (side) { if (n <= 16) SMALL48(1, true); else if (n <= 32) SMALL48(2, true); else SMALL48(3, true); }
+    else { if (n <= 16) SMALL48(1, false); else if (n <= 32) SMALL48(2, false); else SMALL48(3, false); }
 #undef SMALL48
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -115,3 +115,11 @@ int gsmvi_panel_finish_cols(hipStream_t st, int ncols_in, int ncols_out, int nro
 void gsmvi_set_error(const char* fmt, const char* a, const char* b);
 int gsmvi_panel_product(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D, int nrows, const double* A, int lda,
                         const double* shift, double alpha, const double* M, int ldm, double* Pp, int* kc_out);
+
+// the side workgroup of k_bam_small48 (gsmvi_bam_small.hip; orthogonal basis of the factor-form BaM update, n <= 48)
+struct bamq_side {
+    double* M1p;                       // n x n: M1' = -Gvv^-1 M1 (what the substitution multiplies Vw with)
+    double* Dm;                        // n x n: M1 - M1'
+    double* t2;                        // n: L^-T zg (written by the CHAIN workgroup: wave 0, behind zg)
+    int* info1;                        // 0 or the 1-based failing pivot of Gvv's factorisation (dependent draws)
+};
