@@ -991,34 +991,90 @@ int gsmvi_factor_signed_back(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, cons
                              int join);
 
 // ---- the orthogonal-basis form (round 5, knob "bam_basis"): small pieces ----------------------------------------------------------
+// Pi = W Dm^T (one 16 x 16 block per workgroup, gsmvi_smallgemm.h) and, in ONE more workgroup of the same launch,
 // vg' = vg - Pi^T zg with zg = W a (the true Zw gbar-vector of bam.py:110) and Pi^T = Dm W^T: the mean of bam.py:112 needs
-// Zw^T zg = Zt^T zg + Vw^T Pi^T zg, and k_bam_zw forms Vw^T vg - Z^T zg from the Z it computes (Zt here).  One workgroup, n <= 128.
-__global__ __launch_bounds__(256) void k_bamf_vgfix(int n, const double* __restrict__ Wt, const double* __restrict__ Dm,
-                                                    const double* __restrict__ av, double* __restrict__ vg) {
-    __shared__ double sa[128], zg[128], t2[128];
-    const int tid = threadIdx.x;
-    if (tid < 128) sa[tid] = tid < n ? av[tid] : 0.0;
-    __syncthreads();
-    if (tid < n) {                                 // zg[r] = sum_k W[r][k] a[k] = sum_k Wt[k][r] a[k]   (W lower: k <= r)
-        double z = 0.0;
-        for (int k = 0; k <= tid; ++k) z += Wt[(size_t)k * n + tid] * sa[k];
-        zg[tid] = z;
+// Zw^T zg = Zt^T zg + Vw^T Pi^T zg, and k_bam_zw forms Vw^T vg - Z^T zg from the Z it computes (Zt here).  n <= 128.
+// The three matrix-vector products take a WAVE per row where the row is contiguous (first form: a thread per row walking it
+// with stride n -- 24 us at n = 128) and a thread per column where the column is.  The same workgroup joins the flag of Gvv's
+// factorisation (info1, when that ran beside the chain on the second stream) to the flag of the chain.
+// y[i] = sum_k M[i][k] x[k] (UPPER: k >= i only) for a row-major n x n matrix in global memory, n <= 128, 256 threads: eight
+// lanes per row (lane `part` takes k = part, part + 8, ...: the eight lanes of a row read 64 contiguous bytes), 32 rows per pass,
+// all 64 loads of a thread in flight at once; the eight partial sums meet in three DPP steps (fixed order).  x, y in LDS.
+template <bool UPPER>
+__device__ __forceinline__ void bamf_matvec_rows(int n, const double* __restrict__ M, const double* xs, double* ys) {
+    const int row0 = threadIdx.x >> 3, part = threadIdx.x & 7;
+    double v[4][16];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int i = row0 + 32 * p, ic = i < n ? i : n - 1;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = part + 8 * u;
+            v[p][u] = M[(size_t)ic * n + (k < n ? k : n - 1)];
+        }
     }
-    __syncthreads();
-    if (tid < n) {                                 // t2[k] = sum_r Wt[k][r] zg[r]                        (Wt upper: r >= k)
-        double t = 0.0;
-        for (int r = tid; r < n; ++r) t += Wt[(size_t)tid * n + r] * zg[r];
-        t2[tid] = t;
-    }
-    __syncthreads();
-    if (tid < n) {                                 // vg'[i] = vg[i] - sum_k Dm[i][k] t2[k]
-        double d = 0.0;
-        for (int k = 0; k < n; ++k) d += Dm[(size_t)tid * n + k] * t2[k];
-        vg[tid] -= d;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int i = row0 + 32 * p;
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; u += 2) {
+            const int k = part + 8 * u;
+            a0 += (k < n && (!UPPER || k >= i)) ? v[p][u] * xs[k < n ? k : 0] : 0.0;
+            a1 += (k + 8 < n && (!UPPER || k + 8 >= i)) ? v[p][u + 1] * xs[k + 8 < n ? k + 8 : 0] : 0.0;
+        }
+        double sacc = a0 + a1;
+        sacc += dpp_f64<0xB1>(sacc);              // neighbour
+        sacc += dpp_f64<0x4E>(sacc);              // other pair of the quad
+        sacc += dpp_f64<0x141>(sacc);             // row_half_mirror: the other quad of the eight
+        if (part == 0 && i < n) ys[i] = sacc;
     }
 }
-// [A | I] -> [R | W] of one n x n matrix (n <= 64) in its own launch: the first diagonal block Gvv = Vw Vw^T when there is no
-// k_bam_cholw launch to ride beside (n <= 64); plain positive-definite rule (dependent draws are a failure, not a drop)
+__global__ __launch_bounds__(256) void k_bamf_pi_vg(OpBasisPi op, int nblk, const double* __restrict__ av, double* __restrict__ vg,
+                                                    int* info, const int* info1) {
+    __shared__ double As[16 * SMALLGEMM_SA], Bs[256 * SMALLGEMM_SB], red[4 * 256];
+    if ((int)blockIdx.x < nblk) {
+        small_gemm_block(op, (int)blockIdx.x, As, Bs, red);
+        return;
+    }
+    const int n = op.m, tid = threadIdx.x;
+    const double *Wt = op.Wt, *Dm = op.Dm;
+    double *sa = As, *zg = As + 128, *t2 = As + 256, *part = As + 384;
+    if (tid == 0 && info1 && *info == 0 && *info1 != 0) *info = 1000 + *info1;
+    if (tid < 128) sa[tid] = tid < n ? av[tid] : 0.0;
+    __syncthreads();
+    // All global loads of a product are issued before its first multiply (a load per iteration behind a dependent reduction costs
+    // an L2 round trip per row: 37 us for this workgroup at n = 128 when first written; a wave per row with 64 wave-wide
+    // reductions per wave still 20 us): the two row-access products take EIGHT lanes per row (bamf_matvec_rows).
+    {   // zg[r] = sum_k W[r][k] a[k] = sum_{k <= r} Wt[k][r] a[k]: thread (h, r) walks half a column, coalesced over r
+        const int r = tid & 127, h = tid >> 7, rc = r < n ? r : n - 1;
+        double v[64];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) {
+            const int k = 64 * h + u;
+            v[u] = Wt[(size_t)(k < n ? k : n - 1) * n + rc];
+        }
+        double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < 64; u += 2) {
+            const int k = 64 * h + u;
+            z0 += (k <= r && k < n) ? v[u] * sa[k] : 0.0;
+            z1 += (k + 1 <= r && k + 1 < n) ? v[u + 1] * sa[k + 1] : 0.0;
+        }
+        part[tid] = z0 + z1;
+    }
+    __syncthreads();
+    if (tid < 128) zg[tid] = tid < n ? part[tid] + part[tid + 128] : 0.0;
+    __syncthreads();
+    bamf_matvec_rows<true>(n, Wt, zg, t2);        // t2[k] = sum_{r >= k} Wt[k][r] zg[r]
+    __syncthreads();
+    bamf_matvec_rows<false>(n, Dm, t2, part);     // vg'[i] = vg[i] - sum_k Dm[i][k] t2[k]
+    __syncthreads();
+    if (tid < n) vg[tid] -= part[tid];
+}
+
+// [A | I] -> [R | W] of one n x n matrix (n <= 128) in its own launch: the first diagonal block Gvv = Vw Vw^T; plain
+// positive-definite rule (dependent draws are a failure, not a drop)
 int gsmvi_cholw_small(hipStream_t st, int n, const double* A, double* R, double* W, int* info, int info_off);
 
 int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
@@ -1095,27 +1151,53 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
         double* R11 = ctx->early + 128 * 128;
         double* W11 = ctx->early + 2 * 128 * 128;
         BAM_NMAT2(kc, nbq, n, ctx->pp, (long long)n2 * gcols, gcols, N0, M1, Nd, (early || basis) ? G11 : (double*)nullptr);
+        const size_t q2 = (size_t)(ctx->rmax / 2) * (ctx->rmax / 2);
+        double* Tb = ctx->basis;                   // n x n each: T, M1', Dm = M1 - M1', Pi, X
+        double* M1p = Tb + q2;
+        double* Dm = M1p + q2;
+        double* Pi = Dm + q2;
+        int* info_side = n > 64 ? ctx->ints : ctx->ints + 10;   // n > 64: the 2B x 2B chain takes [R11 | W11] and this flag as its first block
+        // Orthogonal basis: Gvv = Vw Vw^T, its factor and M1' = -Gvv^-1 M1 do not depend on BaM's B x B chain (~100 us of small
+        // launches at n = 128): they run BESIDE it on the context's second stream (one 12 - 40 us one-workgroup factorisation and two
+        // small products) and are joined in front of Pi.  (bam_basis = 2: behind the chain on the one stream, as first built.)
+        const bool beside_chain = basis && ctx->tune_bam_basis == 1 && ctx->side != nullptr;
+        auto basis_front = [&](hipStream_t s2) -> int {
+            if (int r2 = gsmvi_cholw_small(s2, n, G11, R11, W11, info_side, 0)) return r2;
+            small_gemm_launch(s2, OpBasisT{n, n, n, W11, M1, Tb, n});
+            small_gemm_launch(s2, OpBasisM1p{n, n, n, W11, Tb, M1, M1p, Dm, n});
+            return GSMVI_OK;
+        };
+        if (beside_chain) {
+            hipError_t fe = hipEventRecord(ctx->ev_fork, st);
+            if (fe == hipSuccess) fe = hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);
+            if (fe != hipSuccess) { gsmvi_set_error("%s: %s", "gsmvi_bam_factor_impl", "fork failed"); return GSMVI_ERR_HIP; }
+            if ((rc = basis_front(ctx->side))) return rc;
+            if (hipEventRecord(ctx->ev_join, ctx->side) != hipSuccess) {
+                gsmvi_set_error("%s: %s", "gsmvi_bam_factor_impl", "join failed");
+                return GSMVI_ERR_HIP;
+            }
+        }
         // (the magnitude guard of the rank-revealing rule sees this block's own diagonal: the second block's is not known yet)
         const cholw_job beside{n, G11, n, R11, n, W11, n, ctx->ints, 0, 0, nullptr, 0, 0};
+        const bool pair = early && !basis;         // (basis: the first block is factored by basis_front)
         if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_bam,
                                          ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq, M1T,
-                                         early ? &beside : nullptr)))
+                                         pair ? &beside : nullptr)))
             return rc;
         ctx->early_ready = early ? 1 : 0;
         const double* M1z = M1;                    // the n x n matrix k_bam_zw multiplies Vw with: M1, or M1' in the orthogonal basis
         ctx->chain_pi = nullptr;
         if (basis) {
-            const size_t q2 = (size_t)(ctx->rmax / 2) * (ctx->rmax / 2);
-            double* Tb = ctx->basis;               // n x n each: T, M1', Dm = M1 - M1', Pi, X
-            double* M1p = Tb + q2;
-            double* Dm = M1p + q2;
-            double* Pi = Dm + q2;
-            // n <= 64: no launch to ride beside.  A failure (dependent draws) joins the flag of BaM's own chain: the update reverts
-            if (!early && (rc = gsmvi_cholw_small(st, n, G11, R11, W11, info_bam, 1000))) return rc;
-            small_gemm_launch(st, OpBasisT{n, n, n, W11, M1, Tb, n});
-            small_gemm_launch(st, OpBasisM1p{n, n, n, W11, Tb, M1, M1p, Dm, n});
-            small_gemm_launch(st, OpBasisPi{n, n, n, Ld, Dm, Pi});
-            hipLaunchKernelGGL(k_bamf_vgfix, dim3(1), dim3(256), 0, st, n, Ld, Dm, Ldinv, const_cast<double*>(Ldinv) + 2 * n);
+            if (beside_chain) {
+                if (hipStreamWaitEvent(st, ctx->ev_join, 0) != hipSuccess) {
+                    gsmvi_set_error("%s: %s", "gsmvi_bam_factor_impl", "join failed");
+                    return GSMVI_ERR_HIP;
+                }
+            } else if ((rc = basis_front(st))) return rc;
+            const int nblk = ((n + 15) >> 4) * ((n + 15) >> 4);
+            // a failure of Gvv's factorisation (dependent draws) joins the flag of BaM's own chain for n <= 64: the update reverts
+            hipLaunchKernelGGL(k_bamf_pi_vg, dim3(nblk + 1), dim3(256), 0, st, OpBasisPi{n, n, n, Ld, Dm, Pi}, nblk, Ldinv,
+                               const_cast<double*>(Ldinv) + 2 * n, info_bam, n > 64 ? (const int*)nullptr : info_side);
             M1z = M1p;
             ctx->chain_pi = Pi;
             ctx->chain_x = Pi + q2;

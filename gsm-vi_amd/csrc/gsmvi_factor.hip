@@ -1120,8 +1120,12 @@ int gsmvi_factor_signed_back(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, cons
 // [A | I] -> [R | W] of one n x n matrix, n <= 64, plain positive-definite rule, compact leading dimension n (gsmvi_bam.hip)
 // info_off > 0: a failure is ADDED to *info (recorded only when nothing failed before; an earlier flag stays)
 int gsmvi_cholw_small(hipStream_t st, int n, const double* A, double* R, double* W, int* info, int info_off) {
-    hipLaunchKernelGGL((k_cholw_ld<false, false>), dim3(1), dim3(512), 0, st, n, A, n, R, n, W, n, info, info_off, 0,
-                       (const double*)nullptr, 0, 0);
+    if (n > 64)
+        hipLaunchKernelGGL((k_cholw_ld<false, true>), dim3(1), dim3(512), 0, st, n, A, n, R, n, W, n, info, info_off, 0,
+                           (const double*)nullptr, 0, 0);
+    else
+        hipLaunchKernelGGL((k_cholw_ld<false, false>), dim3(1), dim3(512), 0, st, n, A, n, R, n, W, n, info, info_off, 0,
+                           (const double*)nullptr, 0, 0);
     return chk("k_cholw_ld");
 }
 
