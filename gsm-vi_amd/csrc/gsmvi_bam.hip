@@ -846,7 +846,8 @@ __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, cons
 #include "gsmvi_smallgemm.h"
 int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* Nd, const double* M1,
                            const double* N0, double* scratch, double* Ld, int* info_dev, int* hint_host, int force_kenq,
-                           double* Rscr, const cholw_job* beside);
+                           double* Rscr, const cholw_job* beside, const bamq_side* side64, const double* G11);
+int gsmvi_bam_small_one_wg(const gsmvi_ctx* ctx, int n);
 int gsmvi_panel_t_product_few_slabs(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* A, int lda, const double* M,
                                     int ldm, int mrows, double* Pp, int* kc_out);
 int gsmvi_bam_small_nmax();
@@ -922,7 +923,7 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     } else if (use_w) {
         const int nbq = (n + 15) / 16;
         BAM_NMAT2(kc, nbq, n, ctx->pp, (long long)n2 * n, n, N0, M1, Nd, (double*)nullptr);
-        if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_p, hint, ctx->tune_bam_kenq, M1T, nullptr)))
+        if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_p, hint, ctx->tune_bam_kenq, M1T, nullptr, nullptr, nullptr)))
             return rc;
         // Z = W (P + M1^T Vf) by two chained MFMA products per 16 columns of D, the mean with it (Wt = (L^-1)^T sits in Ld's slot,
         // [a | . | vg] behind it)
@@ -931,7 +932,7 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     } else {
         if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
         hipLaunchKernelGGL(k_bam_nmat, dim3((((n + 15) / 16) * ((n + 15) / 16) + 3) / 4), dim3(256), 0, st, n, M1, N0, Nd, M1T);
-        if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_p, hint, ctx->tune_bam_kenq, nullptr, nullptr)))
+        if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_p, hint, ctx->tune_bam_kenq, nullptr, nullptr, nullptr, nullptr)))
             return rc;
 #define BFW(CV) hipLaunchKernelGGL(k_bam_forward<CV>, dim3((D + CV - 1) / CV), dim3(CV), sizeof(double) * 2 * n * CV, st, D, n, P, M1, Ld, Ldinv, Ldinv + n, Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu)
         if (n <= 160) BFW(64); else if (n <= 320) BFW(32); else BFW(16);
@@ -1156,48 +1157,34 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
         double* M1p = Tb + q2;
         double* Dm = M1p + q2;
         double* Pi = Dm + q2;
-        int* info_side = n > 64 ? ctx->ints : ctx->ints + 10;   // n > 64: the 2B x 2B chain takes [R11 | W11] and this flag as its first block
-        // Orthogonal basis: Gvv = Vw Vw^T, its factor and M1' = -Gvv^-1 M1 do not depend on BaM's B x B chain (~100 us of small
-        // launches at n = 128): they run BESIDE it on the context's second stream (one 12 - 40 us one-workgroup factorisation and two
-        // small products) and are joined in front of Pi.  (bam_basis = 2: behind the chain on the one stream, as first built.)
-        const bool beside_chain = basis && ctx->tune_bam_basis == 1 && ctx->side != nullptr;
-        auto basis_front = [&](hipStream_t s2) -> int {
-            if (int r2 = gsmvi_cholw_small(s2, n, G11, R11, W11, info_side, 0)) return r2;
-            small_gemm_launch(s2, OpBasisT{n, n, n, W11, M1, Tb, n});
-            small_gemm_launch(s2, OpBasisM1p{n, n, n, W11, Tb, M1, M1p, Dm, n});
-            return GSMVI_OK;
-        };
-        if (beside_chain) {
-            hipError_t fe = hipEventRecord(ctx->ev_fork, st);
-            if (fe == hipSuccess) fe = hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);
-            if (fe != hipSuccess) { gsmvi_set_error("%s: %s", "gsmvi_bam_factor_impl", "fork failed"); return GSMVI_ERR_HIP; }
-            if ((rc = basis_front(ctx->side))) return rc;
-            if (hipEventRecord(ctx->ev_join, ctx->side) != hipSuccess) {
-                gsmvi_set_error("%s: %s", "gsmvi_bam_factor_impl", "join failed");
-                return GSMVI_ERR_HIP;
-            }
-        }
+        // Orthogonal basis: Gvv = Vw Vw^T, its factor [R11 | W11] and M1' = -Gvv^-1 M1 do not depend on BaM's B x B chain.
+        //   n <= 64 (the iteration is ONE workgroup, k_bam_ns64): all of it is the second workgroup of that launch (bamq_side_body);
+        //   n  > 64: the factorisation is the second workgroup of k_bam_cholw's launch (the 2B x 2B chain takes [R11 | W11] as its
+        //            first block), the two products T = W11 M1, M1' = -W11^T T follow it.
+        // (Measured and dropped: the three pieces on the context's second stream beside the Newton-Schulz launches.  An update
+        // timed alone gained 15 us at (1024, 128), but back-to-back updates -- a fit -- LOST 8 us, 503 against 495 us: the two
+        // cross-queue waits cost more than the 50 us of work they hide once both queues are busy.  scripts/bamf_trace.py.)
+        const bool side64 = basis && gsmvi_bam_small_one_wg(ctx, n);
+        int* info_side = ctx->ints + 10;           // n <= 64: joined to BaM's flag by k_bamf_pi_vg (a dependent draw reverts the update)
+        const bamq_side sd{M1p, Dm, nullptr, info_side};
         // (the magnitude guard of the rank-revealing rule sees this block's own diagonal: the second block's is not known yet)
         const cholw_job beside{n, G11, n, R11, n, W11, n, ctx->ints, 0, 0, nullptr, 0, 0};
-        const bool pair = early && !basis;         // (basis: the first block is factored by basis_front)
         if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_bam,
                                          ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq, M1T,
-                                         pair ? &beside : nullptr)))
+                                         early ? &beside : nullptr, side64 ? &sd : nullptr, G11)))
             return rc;
         ctx->early_ready = early ? 1 : 0;
         const double* M1z = M1;                    // the n x n matrix k_bam_zw multiplies Vw with: M1, or M1' in the orthogonal basis
         ctx->chain_pi = nullptr;
         if (basis) {
-            if (beside_chain) {
-                if (hipStreamWaitEvent(st, ctx->ev_join, 0) != hipSuccess) {
-                    gsmvi_set_error("%s: %s", "gsmvi_bam_factor_impl", "join failed");
-                    return GSMVI_ERR_HIP;
-                }
-            } else if ((rc = basis_front(st))) return rc;
+            if (!side64) {
+                if (!early && (rc = gsmvi_cholw_small(st, n, G11, R11, W11, info_side, 0))) return rc;
+                small_gemm_launch(st, OpBasisT{n, n, n, W11, M1, Tb, n});
+                small_gemm_launch(st, OpBasisM1p{n, n, n, W11, Tb, M1, M1p, Dm, n});
+            }
             const int nblk = ((n + 15) >> 4) * ((n + 15) >> 4);
-            // a failure of Gvv's factorisation (dependent draws) joins the flag of BaM's own chain for n <= 64: the update reverts
             hipLaunchKernelGGL(k_bamf_pi_vg, dim3(nblk + 1), dim3(256), 0, st, OpBasisPi{n, n, n, Ld, Dm, Pi}, nblk, Ldinv,
-                               const_cast<double*>(Ldinv) + 2 * n, info_bam, n > 64 ? (const int*)nullptr : info_side);
+                               const_cast<double*>(Ldinv) + 2 * n, info_bam, early ? (const int*)nullptr : info_side);
             M1z = M1p;
             ctx->chain_pi = Pi;
             ctx->chain_x = Pi + q2;

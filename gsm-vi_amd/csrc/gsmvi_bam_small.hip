@@ -267,6 +267,105 @@ __global__ __launch_bounds__(1024) void k_bam_ns_tail(int n, int ld, int kenq, d
     }
 }
 
+// ---- the side workgroup of the one-workgroup chains (n <= 64; orthogonal basis of the factor-form BaM update, gsmvi_bam.hip) ----
+// Next to BaM's B x B chain and INDEPENDENT of it the basis needs
+//   Gvv = Vw Vw^T,  [Gvv | I] -> [R11 | W11],  T = W11 M1,  M1' = -W11^T T = -Gvv^-1 M1,  Dm = M1 - M1'.
+// For n <= 64 the chain is ONE workgroup (k_bam_small48, k_bam_ns64: 30 - 100 us on one CU), so this runs as the SECOND workgroup
+// of its launch, ~12 - 25 us on another CU, instead of three launches behind the chain (factorisation 9 - 17 us + two products,
+// round-5 first form).  Nothing crosses between the two workgroups: the side workgroup reads Gvv and M1 from what the launch
+// BEFORE produced (SRC: the Gram slabs for k_bam_small48, summed in the chain's order so that M1 has the chain's bits; the
+// finished matrices of k_bam_nmat2 for k_bam_ns64).  What depends on the chain's L (Pi = L^-1 Dm^T, the correction of vg)
+// comes later (k_bam_forward16's launch / k_bamf_pi_vg).
+#define BAMQ_SIDE_ES 146
+#define BAMQ_SIDE_LS 65
+#define BAMQ_SIDE_DOUBLES (64 * BAMQ_SIDE_ES + 64 * BAMQ_SIDE_LS)
+struct bamq_src_slabs {                                      // element (r, c) of the stacked product = sum of kc slabs
+    const double* slabs;
+    int kc, ldslab, n;
+    long long stride;
+    __device__ __forceinline__ double at(int r, int c) const {
+        double t[GSMVI_MAX_KC];
+#pragma unroll
+        for (int k = 0; k < GSMVI_MAX_KC; ++k) t[k] = slabs[(size_t)(k < kc ? k : kc - 1) * stride + (size_t)r * ldslab + c];
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < GSMVI_MAX_KC; ++k) a += (k < kc) ? t[k] : 0.0;
+        return a;
+    }
+    __device__ __forceinline__ double gvv(int i, int j) const { return at(n + i, n + j); }
+    __device__ __forceinline__ double m1(int i, int j) const { return at(n + i, j); }
+};
+struct bamq_src_mats {                                       // finished n x n matrices (k_bam_nmat2)
+    const double *G11, *M1;
+    int n;
+    __device__ __forceinline__ double gvv(int i, int j) const { return G11[(size_t)i * n + j]; }
+    __device__ __forceinline__ double m1(int i, int j) const { return M1[(size_t)i * n + j]; }
+};
+template <class SRC>
+__device__ __forceinline__ void bamq_side_body(int n, const SRC& src, double* sm, double* scr, int* sh_f, const bamq_side& sd) {
+    constexpr int ES = BAMQ_SIDE_ES, LS = BAMQ_SIDE_LS;
+    double* E = sm;                                          // 64 x 146: [Gvv | I] -> [R11 | W11]; then M1 / Dm over R11
+    double* Ts = sm + 64 * ES;
+    const int tid = threadIdx.x;
+    for (int e0 = 0; e0 < 64 * 64; e0 += 512 * 4) {          // Gvv: the upper triangle, identity beyond n
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 512 * u + tid, i = e >> 6, j = e & 63;
+            v[u] = src.gvv(i < n ? i : n - 1, j < n ? j : n - 1);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 512 * u + tid, i = e >> 6, j = e & 63;
+            E[i * ES + j] = (i < n && j < n) ? (j >= i ? v[u] : 0.0) : (i == j ? 1.0 : 0.0);
+        }
+    }
+    __syncthreads();
+    chol64_blk<ES, false, 1>(E, scr, n, sh_f);               // (plain rule: dependent draws are a failure, not a drop)
+    __syncthreads();
+    if (tid == 0) *sd.info1 = *sh_f;
+    for (int e0 = 0; e0 < 64 * 64; e0 += 512 * 4) {          // M1 over R11 (which nobody reads for n <= 64)
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 512 * u + tid, i = e >> 6, j = e & 63;
+            v[u] = src.m1(i < n ? i : n - 1, j < n ? j : n - 1);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 512 * u + tid, i = e >> 6, j = e & 63;
+            E[i * ES + j] = v[u];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 512) {                 // T = W11 M1 (W11 lower: k <= i); four independent partial sums
+        const int i = e / n, j = e - i * n;
+        const double* wr = E + i * ES + 64;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        int k = 0;
+        for (; k + 3 <= i; k += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += wr[k + u] * E[(k + u) * ES + j];
+        }
+        for (; k <= i; ++k) a[0] += wr[k] * E[k * ES + j];
+        Ts[i * LS + j] = (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 512) {                 // M1' = -W11^T T (k >= i), Dm = M1 - M1'
+        const int i = e / n, j = e - i * n;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        int k = i;
+        for (; k + 3 < n; k += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += E[(k + u) * ES + 64 + i] * Ts[(k + u) * LS + j];
+        }
+        for (; k < n; ++k) a[0] += E[k * ES + 64 + i] * Ts[k * LS + j];
+        const double v = (a[0] + a[1]) + (a[2] + a[3]);
+        sd.M1p[e] = -v;
+        sd.Dm[e] = E[i * ES + j] + v;
+    }
+}
+
 // ---- the whole iteration in ONE workgroup for n <= 64 (round 4) ------------------------------------------------------------------
 // Y, Z and M = Z Y fit in LDS together ([64][66] doubles each, 101 KB), so a 64 x 64 problem needs no launch per product: the
 // multi-workgroup form pays 2 launches x ~4.2 us per step whatever the size (scripts/nsbench.hip: n = 64 costs what n = 128
@@ -275,11 +374,21 @@ __global__ __launch_bounds__(1024) void k_bam_ns_tail(int n, int ld, int kenq, d
 // panel of Z' = c T Z, so both are updated in place behind one barrier.  Same recurrence, same T, same product order (Y T and
 // T Z) as the multi-workgroup kernels; no step-count hint and no tail kernel: k* is known where the loop runs.  The final
 // iterate goes to the buffer its parity names (k_bam_bbav / k_bam_ns_bb read Y from (k* & 1) ? Yb : Ya), coef[40..42] as usual.
+template <bool PAIR>   // PAIR: a second workgroup runs bamq_side_body on the matrices of k_bam_nmat2
 __global__ __launch_bounds__(512) void k_bam_ns64(int n, int ld, const double* __restrict__ Nm, double* __restrict__ Ya,
-                                                  double* __restrict__ Yb, double* __restrict__ coef) {
+                                                  double* __restrict__ Yb, double* __restrict__ coef, bamq_src_mats src,
+                                                  bamq_side sd) {
     constexpr int LS = 66;
-    __shared__ __attribute__((aligned(16))) double Ys[64 * LS], Zs[64 * LS], Ms[64 * LS];
+    constexpr int SMD = (PAIR && BAMQ_SIDE_DOUBLES > 3 * 64 * LS) ? BAMQ_SIDE_DOUBLES : 3 * 64 * LS;
+    __shared__ __attribute__((aligned(16))) double sm[SMD];
+    __shared__ __attribute__((aligned(16))) double scr1[PAIR ? CHOLB_SCRATCH_DOUBLES(1) : 2];
     __shared__ double red[8], cf[BAMS_KMAX + 4];
+    __shared__ int sh_f;
+    if (PAIR && blockIdx.x == 1) {                           // block-uniform
+        bamq_side_body(n, src, sm, scr1, &sh_f, sd);
+        return;
+    }
+    double *Ys = sm, *Zs = sm + 64 * LS, *Ms = sm + 2 * 64 * LS;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
     double tr = 0.0;
     if (tid < n) tr = Nm[(size_t)tid * n + tid] + 0.25;
@@ -608,95 +717,8 @@ __global__ __launch_bounds__(1024) void k_bam_post_big(int n, double reg, const 
 #define BAMQ_SN 48
 #define BAMQ_LD 50
 #define BAMQ_ES 82
-// The orthogonal basis of the factor form (gsmvi_bam.hip, "bam_basis") needs, next to this chain and INDEPENDENT of it:
-//   Gvv = Vw Vw^T (rows and columns n .. 2n-1 of the same Gram slabs), [Gvv | I] -> [R11 | W11],  T = W11 M1,
-//   M1' = -W11^T T = -Gvv^-1 M1,  Dm = M1 - M1'.
-// They are the SECOND workgroup of the launch (PAIR): ~12 us beside the ~30 us chain on another CU instead of three launches
-// (slab sum 4.8 + factorisation 9.2 + products 8 us, round-5 first form) behind it.  The side workgroup sums the M1 slabs itself,
-// in the chain's order (the same bits as M1g), so nothing crosses between the two workgroups.  What does depend on the chain's L
-// -- Pi = L^-1 Dm^T and the correction of vg -- moves into k_bam_forward16's launch (its prologue and one more workgroup).
-#define BAMQ_SIDE_ES 146
-#define BAMQ_SIDE_LS 49
-__device__ __forceinline__ void bamq_side_body(int n, const double* __restrict__ slabs, int kc, int ldslab, long long slab_stride,
-                                               double* sm, double* scr, int* sh_f, const bamq_side& sd) {
-    constexpr int ES = BAMQ_SIDE_ES, LS = BAMQ_SIDE_LS;
-    double* E = sm;                                          // 64 x 146: [Gvv | I] -> [R11 | W11]
-    double* Ms = sm + 64 * ES;                               // M1, then Dm
-    double* Ts = Ms + BAMQ_SN * LS;
-    const int tid = threadIdx.x;
-    for (int e0 = 0; e0 < 64 * 64; e0 += 512 * 2) {          // Gvv: the upper triangle of the slab sums, identity beyond n
-        double t[2][GSMVI_MAX_KC];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int e = e0 + 512 * u + tid, i = e >> 6, j = e & 63;
-            const int ic = i < n ? i : n - 1, jc = j < n ? j : n - 1;
-#pragma unroll
-            for (int k = 0; k < GSMVI_MAX_KC; ++k)
-                t[u][k] = slabs[(size_t)(k < kc ? k : kc - 1) * slab_stride + (size_t)(n + ic) * ldslab + n + jc];
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int e = e0 + 512 * u + tid, i = e >> 6, j = e & 63;
-            double a = 0.0;
-#pragma unroll
-            for (int k = 0; k < GSMVI_MAX_KC; ++k) a += (k < kc) ? t[u][k] : 0.0;
-            E[i * ES + j] = (i < n && j < n) ? (j >= i ? a : 0.0) : (i == j ? 1.0 : 0.0);
-        }
-    }
-    for (int e0 = 0; e0 < n * n; e0 += 512 * 2) {            // M1: rows n .. 2n-1, columns 0 .. n-1 (the chain's summation order)
-        double t[2][GSMVI_MAX_KC];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            int e = e0 + 512 * u + tid;
-            if (e >= n * n) e = n * n - 1;
-            const int r = e / n, c = e - r * n;
-#pragma unroll
-            for (int k = 0; k < GSMVI_MAX_KC; ++k)
-                t[u][k] = slabs[(size_t)(k < kc ? k : kc - 1) * slab_stride + (size_t)(n + r) * ldslab + c];
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int e = e0 + 512 * u + tid;
-            if (e < n * n) {
-                const int r = e / n, c = e - r * n;
-                double a = 0.0;
-#pragma unroll
-                for (int k = 0; k < GSMVI_MAX_KC; ++k) a += (k < kc) ? t[u][k] : 0.0;
-                Ms[r * LS + c] = a;
-            }
-        }
-    }
-    __syncthreads();
-    chol64_blk<ES, false, 1>(E, scr, n, sh_f);               // (plain rule: dependent draws are a failure, not a drop)
-    __syncthreads();
-    if (tid == 0) *sd.info1 = *sh_f;
-    for (int e = tid; e < n * n; e += 512) {                 // T = W11 M1 (W11 lower: k <= i); four independent partial sums
-        const int i = e / n, j = e - i * n;
-        const double* wr = E + i * ES + 64;
-        double a[4] = {0.0, 0.0, 0.0, 0.0};
-        int k = 0;
-        for (; k + 3 <= i; k += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] += wr[k + u] * Ms[(k + u) * LS + j];
-        }
-        for (; k <= i; ++k) a[0] += wr[k] * Ms[k * LS + j];
-        Ts[i * LS + j] = (a[0] + a[1]) + (a[2] + a[3]);
-    }
-    __syncthreads();
-    for (int e = tid; e < n * n; e += 512) {                 // M1' = -W11^T T (k >= i), Dm = M1 - M1'
-        const int i = e / n, j = e - i * n;
-        double a[4] = {0.0, 0.0, 0.0, 0.0};
-        int k = i;
-        for (; k + 3 < n; k += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] += E[(k + u) * ES + 64 + i] * Ts[(k + u) * LS + j];
-        }
-        for (; k < n; ++k) a[0] += E[k * ES + 64 + i] * Ts[k * LS + j];
-        const double v = (a[0] + a[1]) + (a[2] + a[3]);
-        sd.M1p[e] = -v;
-        sd.Dm[e] = Ms[i * LS + j] + v;
-    }
-}
+// PAIR: the launch's second workgroup is the side workgroup of the orthogonal basis (bamq_side_body above); wave 0 of the
+// chain adds t2 = L^-T zg behind zg.
 template <int NB, bool PAIR>
 __global__ __launch_bounds__(512) void k_bam_small48(int n, double reg, const double* __restrict__ slabs, int kc, int ldslab,
                                                      long long slab_stride, double* __restrict__ M1g,
@@ -714,9 +736,9 @@ __global__ __launch_bounds__(512) void k_bam_small48(int n, double reg, const do
     __shared__ __attribute__((aligned(16))) double scr[CHOLB_SCRATCH_DOUBLES(PAIR ? 1 : 0)];
     __shared__ double coefs[BAMS_KMAX + 4], n0c[BAMQ_SN], sc[BAMQ_SN], av[BAMQ_SN], red[8];
     __shared__ int sh_fail, sh_bad;
-    static_assert(64 * BAMQ_SIDE_ES + 2 * BAMQ_SN * BAMQ_SIDE_LS <= 7 * MSZ, "the side workgroup's matrices overlay sm");
-    if (PAIR && blockIdx.x == 1) {                           // block-uniform
-        bamq_side_body(n, slabs, kc, ldslab, slab_stride, sm, scr, &sh_fail, sd);
+    static_assert(BAMQ_SIDE_DOUBLES <= 7 * MSZ, "the side workgroup's matrices overlay sm");
+    if (PAIR && blockIdx.x == 1) {                           // block-uniform (bamq_side_body above)
+        bamq_side_body(n, bamq_src_slabs{slabs, kc, ldslab, n, slab_stride}, sm, scr, &sh_fail, sd);
         return;
     }
     double* Ms = sm + 4 * MSZ;
@@ -1020,7 +1042,7 @@ int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double*
 // small outputs of k_bam_post_big (Ld = L, Ldinv, zg, vg) for the generic forward-substitution kernel.
 int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* Nd, const double* M1,
                            const double* N0, double* scratch, double* Ld, int* info_dev, int* hint_host, int force_kenq,
-                           double* Rscr, const cholw_job* beside) {
+                           double* Rscr, const cholw_job* beside, const bamq_side* side64, const double* G11) {
     const int ld = n <= BAMS_NMAX ? BAMS_LD : ((n + 15) / 16) * 16;
     const size_t LL = (size_t)ld * ld;
     double* Ya = scratch;
@@ -1041,7 +1063,10 @@ int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, co
     const int nb = (n + 15) / 16;
     const bool one_wg = n <= 64 && !ctx->tune_bam_full && force_kenq <= 0;   // the whole iteration in one workgroup (k_bam_ns64)
     if (one_wg) {
-        hipLaunchKernelGGL(k_bam_ns64, dim3(1), dim3(512), 0, st, n, ld, Nd, Ya, Yb, coef);
+        if (side64)                                          // (the caller asked gsmvi_bam_small_one_wg first)
+            hipLaunchKernelGGL(k_bam_ns64<true>, dim3(2), dim3(512), 0, st, n, ld, Nd, Ya, Yb, coef, bamq_src_mats{G11, M1, n}, *side64);
+        else
+            hipLaunchKernelGGL(k_bam_ns64<false>, dim3(1), dim3(512), 0, st, n, ld, Nd, Ya, Yb, coef, bamq_src_mats{}, bamq_side{});
         kenq = 0;
     } else
     // step 0 forms s, Y0, Z0 = I and M0 = Y0 in its own operand loads (k_bam_ns_step0): no preparation launch
@@ -1078,6 +1103,8 @@ int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, co
     return GSMVI_OK;
 }
 
+// whether gsmvi_bam_small_device runs the iteration as ONE workgroup (k_bam_ns64), i.e. can carry the side workgroup
+int gsmvi_bam_small_one_wg(const gsmvi_ctx* ctx, int n) { return n <= 64 && !ctx->tune_bam_full && ctx->tune_bam_kenq <= 0; }
 int gsmvi_bam_small_nmax() { return BAMS_NBIG; }
 size_t gsmvi_bam_small_scratch_doubles(int n) {
     const size_t ld = n <= BAMS_NMAX ? BAMS_LD : ((n + 15) / 16) * 16;

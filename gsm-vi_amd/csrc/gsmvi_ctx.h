@@ -71,7 +71,7 @@ struct gsmvi_ctx {
     int tune_bam_full = 0;     // 1 = always enqueue every Newton-Schulz step (ignore the hint; tests)
     int tune_lowrank_kp = 0;   // 64: BaM's low-rank update stages 64 rows per pass for KF > 96 (A/B runs: measured equal to 32)
     int tune_chain_pair = 1;   // two-level chain (128 < 2B <= 256): independent one-workgroup factorisations share a launch (0: A/B runs)
-    int tune_bam_basis = 1;    // 1 (default) = factor-form BaM in the basis [Vw; Zt], Zt = the part of Zw orthogonal to the whitened draws
+    int tune_bam_basis = 1;    // 1 (default) = factor-form BaM in the basis [Vw; Zt], Zt = the part of Zw orthogonal to the whitened draws; 0 = [Vw; Zw]
                                // (round 5: no dependent rows at the fixed point of a Gaussian target); 0 = the
                                // round-4 basis [Vw; Zw] (A/B runs)
     double* basis = nullptr;   // workspace of that form: five (R/2)^2 slots -- T, M1', M1 - M1', Pi, X
