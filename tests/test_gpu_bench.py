@@ -66,14 +66,16 @@ def test_bench_driver_flags_time_the_graph_path_they_name():
     assert d["steps"] == 20 and d["warmup"] == 5
     assert d["config"]["launch"] == "hipGraph(1 x 20 updates/replay)", d["config"]["launch"]
     assert d["config"]["warmup_steps_run"] >= 5
-    # (advisor, round 4) a RELATIVE guard in place of an absolute rate: the same command with eager launches, same box, same run
-    # (eager gave 36.5k, the replayed graph 53-65k on the boxes of rounds 2-4; an absolute threshold once failed on a slow host)
-    # (at 210 steps, ~4 ms of timed region each: the 20-step region is one 0.4 ms replay, too short for a ratio -- a first
-    # version of this guard compared those and failed at 41.4k against 40.6k on a noisy box)
+    # (advisor, round 4) a RELATIVE guard in place of an absolute rate: the same command with eager launches, same box, same run.
+    # What it can assert is bounded by the host: three launches per 18 us update are within reach of a fast host, so eager
+    # has been seen anywhere from 36.5k (rounds 2-4) to 55.7k updates/s (round 5: ABOVE the replayed graph's 52.4k of the same
+    # run) while the graph stays at 51-55k.  The guard therefore says "the replayed path is not grossly slower than eager
+    # launches" (a graph that re-instantiates or serialises would be), at 210 steps (~4 ms of timed region: the 20-step region
+    # is one 0.4 ms replay, too short for any ratio); that the timed steps ARE replays is what the launch label asserts.
     dg = _run({}, "--steps", "210", "--warmup", "21", "--no-cpu-baseline", "--no-callpath", "--no-large-point")
     de = _run({}, "--steps", "210", "--warmup", "21", "--no-cpu-baseline", "--no-callpath", "--no-graph", "--no-large-point")
     assert "hipGraph" in dg["config"]["launch"] and "hipGraph" not in de["config"]["launch"], (dg["config"]["launch"], de["config"]["launch"])
-    assert dg["value"] > 1.05 * de["value"], (dg["value"], de["value"])
+    assert dg["value"] > 0.8 * de["value"], (dg["value"], de["value"])
     d = _run({}, "--steps", "50", "--warmup", "5", "--no-cpu-baseline", "--no-callpath")
     assert d["config"]["launch"] == "hipGraph(2 x 21 updates/replay + 1 x 8)", d["config"]["launch"]
     assert "traffic_source" in d["roofline"] and d["roofline"]["moved_bytes_per_launch"] < \
