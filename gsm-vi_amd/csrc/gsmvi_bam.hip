@@ -31,13 +31,17 @@
 // shift = NULL in the factor form: last row -sqrt(r1) zbar), where helmert_k(v) = (sum_{j<k} c_j - k c_k)/sqrt(k(k+1)), c = v - mean.
 // Workgroup = 256 / NG columns x NG sample groups (NG = 4 or 16); group g owns the rows k in [k0, k1) (and the samples of that range: two passes
 // over them, the second served by L2), its starting prefix sum comes from the other groups' partial sums.  Any B >= 1.
-template <int NG>   // sample groups per workgroup: 256 / NG columns x NG groups (4 for B <= 32, 16 above: round 4)
+// XT (factor form): a third track -- the same Helmert rows of the SAMPLES X go to Xh (last row -sqrt(r1)(xbar - xshift)).  With
+// x_b = mu0 + z_b F0 they are Vw F0, the first n rows of Rt F0: the update's MFMA-bound product then takes the n + 1 rows
+// [Zt; r1 h] only (what the GSM factor update does with its records [x - mu0 | v | v F0]).
+template <int NG, bool XT = false>   // sample groups per workgroup: 256 / NG columns x NG groups (4 for B <= 32, 16 above: round 4)
 __global__ __launch_bounds__(256) void k_bam_stats_h(int D, int B, const double* __restrict__ V, int ldv,
                                                      const double* __restrict__ shift, const double* __restrict__ X,
                                                      int ldx, const double* __restrict__ G, int ldg, double reg,
                                                      double* __restrict__ xbar, double* __restrict__ gbar,
                                                      double* __restrict__ zerov, double* __restrict__ Qt,
-                                                     double* __restrict__ Vout, double* __restrict__ Vout2) {
+                                                     double* __restrict__ Vout, double* __restrict__ Vout2,
+                                                     const double* __restrict__ xshift, double* __restrict__ Xh) {
     constexpr int NC = 256 / NG;
     __shared__ double red[3][NG][NC];
     const int c = threadIdx.x % NC, g = threadIdx.x / NC;
@@ -83,63 +87,85 @@ __global__ __launch_bounds__(256) void k_bam_stats_h(int D, int B, const double*
         Qt[(size_t)(B - 1) * D + i] = r1s * gb;
         Vout[(size_t)(B - 1) * D + i] = vl;
         if (Vout2) Vout2[(size_t)(B - 1) * D + i] = vl;
+        if (XT) Xh[(size_t)(B - 1) * D + i] = -r1s * (xb - xshift[i]);
     }
+    const double xbm = XT ? tx_ / B : 0.0;
     // prefix of the CENTRED values in front of this group's samples: a second pass over the own samples (centred partial sums:
     // sum(raw) - k mean would cancel badly when the mean is large beside the spread), then the groups in front are added up
     {
-        double cv = 0.0, cg = 0.0;
+        double cv = 0.0, cg = 0.0, cx = 0.0;
         int b = s0;
         for (; b + 7 < k1; b += 8) {
-            double tv[8], tg[8];
+            double tv[8], tg[8], tx[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 tv[u] = V[(size_t)(b + u) * ldv + ic];
                 tg[u] = G[(size_t)(b + u) * ldg + ic];
+                if (XT) tx[u] = X[(size_t)(b + u) * ldx + ic];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { cv += tv[u] - vb; cg += tg[u] - gb; }
+            for (int u = 0; u < 8; ++u) {
+                cv += tv[u] - vb;
+                cg += tg[u] - gb;
+                if (XT) cx += tx[u] - xbm;
+            }
         }
-        for (; b < k1; ++b) { cv += V[(size_t)b * ldv + ic] - vb; cg += G[(size_t)b * ldg + ic] - gb; }
+        for (; b < k1; ++b) {
+            cv += V[(size_t)b * ldv + ic] - vb;
+            cg += G[(size_t)b * ldg + ic] - gb;
+            if (XT) cx += X[(size_t)b * ldx + ic] - xbm;
+        }
         red[0][g][c] = cv;
         red[1][g][c] = cg;
+        if (XT) red[2][g][c] = cx;
     }
     __syncthreads();
-    double pv = 0.0, pg = 0.0;
-    for (int q = 0; q < g; ++q) { pv += red[0][q][c]; pg += red[1][q][c]; }
+    double pv = 0.0, pg = 0.0, px = 0.0;
+    for (int q = 0; q < g; ++q) {
+        pv += red[0][q][c];
+        pg += red[1][q][c];
+        if (XT) px += red[2][q][c];
+    }
     int k = s0;
     for (; k + 7 < k1; k += 8) {
-        double tv[8], tg[8];
+        double tv[8], tg[8], tx[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             tv[u] = V[(size_t)(k + u) * ldv + ic];
             tg[u] = G[(size_t)(k + u) * ldg + ic];
+            if (XT) tx[u] = X[(size_t)(k + u) * ldx + ic];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int kk = k + u;
-            const double cv = tv[u] - vb, cg = tg[u] - gb;
+            const double cv = tv[u] - vb, cg = tg[u] - gb, cx = XT ? tx[u] - xbm : 0.0;
             if (kk >= 1 && i < D) {
                 const double sc = a / sqrt((double)kk * (double)(kk + 1));
                 const double ov = sc * (pv - kk * cv);
                 Qt[(size_t)(kk - 1) * D + i] = sc * (pg - kk * cg);
                 Vout[(size_t)(kk - 1) * D + i] = ov;
                 if (Vout2) Vout2[(size_t)(kk - 1) * D + i] = ov;
+                if (XT) Xh[(size_t)(kk - 1) * D + i] = sc * (px - kk * cx);
             }
             pv += cv;
             pg += cg;
+            if (XT) px += cx;
         }
     }
     for (; k < k1; ++k) {
         const double cv = V[(size_t)k * ldv + ic] - vb, cg = G[(size_t)k * ldg + ic] - gb;
+        const double cx = XT ? X[(size_t)k * ldx + ic] - xbm : 0.0;
         if (k >= 1 && i < D) {
             const double sc = a / sqrt((double)k * (double)(k + 1));
             const double ov = sc * (pv - k * cv);
             Qt[(size_t)(k - 1) * D + i] = sc * (pg - k * cg);
             Vout[(size_t)(k - 1) * D + i] = ov;
             if (Vout2) Vout2[(size_t)(k - 1) * D + i] = ov;
+            if (XT) Xh[(size_t)(k - 1) * D + i] = sc * (px - k * cx);
         }
         pv += cv;
         pg += cg;
+        if (XT) px += cx;
     }
 }
 
@@ -147,13 +173,11 @@ __global__ __launch_bounds__(256) void k_bam_stats_h(int D, int B, const double*
 // 32-sample groups became 64 workgroups of sixteen 8-sample groups: every group's loads in one batch)
 static inline void bam_stats_launch(hipStream_t st, int D, int B, const double* V, int ldv, const double* shift, const double* X,
                                     int ldx, const double* G, int ldg, double reg, double* xbar, double* gbar, double* zerov,
-                                    double* Qt, double* Vout, double* Vout2) {
-    if (B <= 32)
-        hipLaunchKernelGGL(k_bam_stats_h<4>, dim3((D + 63) / 64), dim3(256), 0, st, D, B, V, ldv, shift, X, ldx, G, ldg, reg, xbar,
-                           gbar, zerov, Qt, Vout, Vout2);
-    else
-        hipLaunchKernelGGL(k_bam_stats_h<16>, dim3((D + 15) / 16), dim3(256), 0, st, D, B, V, ldv, shift, X, ldx, G, ldg, reg, xbar,
-                           gbar, zerov, Qt, Vout, Vout2);
+                                    double* Qt, double* Vout, double* Vout2, const double* xshift = nullptr, double* Xh = nullptr) {
+#define STATS(NGV, XTV, GX) hipLaunchKernelGGL((k_bam_stats_h<NGV, XTV>), dim3(GX), dim3(256), 0, st, D, B, V, ldv, shift, X, ldx, G, ldg, reg, xbar, gbar, zerov, Qt, Vout, Vout2, xshift, Xh)
+    if (B <= 32) { if (Xh) STATS(4, true, (D + 63) / 64); else STATS(4, false, (D + 63) / 64); }
+    else { if (Xh) STATS(16, true, (D + 15) / 16); else STATS(16, false, (D + 15) / 16); }
+#undef STATS
 }
 
 // ---- Z = L^-1 (P + M1^T Vf), the new mean, and the signed factor panel -------------------------
@@ -1111,7 +1135,8 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     const bool basis = ctx->tune_bam_basis != 0 && n <= 128 && ctx->basis != nullptr;
     const bool fused48 = n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full;
 
-    bam_stats_launch(st, D, B, Z, ldz, (const double*)nullptr, X, ldx, G, ldg, reg, xbar, gbar, zerov, Qt, Ft, (double*)nullptr);
+    // (Tm rows 0 .. n-1 = Vw F0 = the Helmert rows of the samples themselves: the stats kernel's third track)
+    bam_stats_launch(st, D, B, Z, ldz, (const double*)nullptr, X, ldx, G, ldg, reg, xbar, gbar, zerov, Qt, Ft, (double*)nullptr, mu0, Tm);
     if ((rc = gsmvi_panel_t_product(ctx, st, D, n, Qt, D, F0, ldf0, D, ctx->pp, &kc))) return rc;
     if ((rc = gsmvi_panel_finish(st, D, n, kc, ctx->pp, nullptr, Wq, D))) return rc;
     // Two-level 2B x 2B chain ahead (64 < B <= 128): its first diagonal block Gamma11 = Vw Vw^T does not depend on the B x B
@@ -1207,7 +1232,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
         hipError_t fe = hipEventRecord(ctx->ev_fork, st);
         if (fe == hipSuccess) fe = hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);
         if (fe != hipSuccess) { gsmvi_set_error("%s: %s", "gsmvi_bam_factor_impl", "fork failed"); rc = GSMVI_ERR_HIP; }
-        if (!rc) rc = gsmvi_panel_product_out(ctx, ctx->side, D, D, n2 + 1, Ft, D, nullptr, 1.0, F0, ldf0, nullptr, Tm, D);
+        if (!rc) rc = gsmvi_panel_product_out(ctx, ctx->side, D, D, n + 1, Ft + (size_t)n * D, D, nullptr, 1.0, F0, ldf0, nullptr, Tm + (size_t)n * D, D);
         if (!rc && hipEventRecord(ctx->ev_join, ctx->side) != hipSuccess) {
             gsmvi_set_error("%s: %s", "gsmvi_bam_factor_impl", "join failed");
             rc = GSMVI_ERR_HIP;
@@ -1218,7 +1243,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
             rc = gsmvi_factor_signed_back(ctx, st, D, n, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, kcg, 0, 0, 1);
     } else {
         rc = gsmvi_factor_signed_gram(ctx, st, D, n, &kcg, info_dev, &rides);   // Gram slabs of [Vw; Zw]; the 2B x 2B chain rides in ...
-        if (!rc) rc = gsmvi_panel_product_out(ctx, st, D, D, n2 + 1, Ft, D, nullptr, 1.0, F0, ldf0, nullptr, Tm, D);   // ... this
+        if (!rc) rc = gsmvi_panel_product_out(ctx, st, D, D, n + 1, Ft + (size_t)n * D, D, nullptr, 1.0, F0, ldf0, nullptr, Tm + (size_t)n * D, D);   // ... this
         const int taken = ctx->px_used;
         ctx->px = gsmvi_panel_extras();
         if (!rc)

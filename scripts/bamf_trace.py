@@ -9,6 +9,9 @@ D, B = int(sys.argv[1]), int(sys.argv[2])
 eng = gsmvi_amd.get_engine()
 if len(sys.argv) > 3 and sys.argv[3].isdigit():
     eng.set_tuning("bam_basis", int(sys.argv[3]))
+for kv in sys.argv[4:]:
+    if "=" in kv:
+        eng.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 if "cfg" in sys.argv:                              # the inputs of scripts/configs_bench.py (a raw L L^T + 1e-3 I target: large scores)
     g = torch.Generator(device=eng.device); g.manual_seed(101)
     kw = dict(dtype=torch.float64, device=eng.device, generator=g)
