@@ -1055,23 +1055,14 @@ __device__ __forceinline__ void bamf_matvec_rows(int n, const double* __restrict
         if (part == 0 && i < n) ys[i] = sacc;
     }
 }
-__global__ __launch_bounds__(256) void k_bamf_pi_vg(OpBasisPi op, int nblk, const double* __restrict__ av, double* __restrict__ vg,
-                                                    int* info, const int* info1) {
-    __shared__ double As[16 * SMALLGEMM_SA], Bs[256 * SMALLGEMM_SB], red[4 * 256];
-    if ((int)blockIdx.x < nblk) {
-        small_gemm_block(op, (int)blockIdx.x, As, Bs, red);
-        return;
-    }
-    const int n = op.m, tid = threadIdx.x;
-    const double *Wt = op.Wt, *Dm = op.Dm;
-    double *sa = As, *zg = As + 128, *t2 = As + 256, *part = As + 384;
-    if (tid == 0 && info1 && *info == 0 && *info1 != 0) *info = 1000 + *info1;
+// t2 = W^T (W a) for the vg' correction below: zg[r] = sum_{k <= r} Wt[k][r] a[k] (thread (h, r) walks half a column, coalesced
+// over r), then t2[k] = sum_{r >= k} Wt[k][r] zg[r].  256 threads, n <= 128; sa, zg, part: LDS scratch (128, 128, 256); t2 -> LDS.
+__device__ __forceinline__ void bamf_t2_body(int n, const double* __restrict__ Wt, const double* __restrict__ av, double* sa,
+                                             double* zg, double* part, double* t2) {
+    const int tid = threadIdx.x;
     if (tid < 128) sa[tid] = tid < n ? av[tid] : 0.0;
     __syncthreads();
-    // All global loads of a product are issued before its first multiply (a load per iteration behind a dependent reduction costs
-    // an L2 round trip per row: 37 us for this workgroup at n = 128 when first written; a wave per row with 64 wave-wide
-    // reductions per wave still 20 us): the two row-access products take EIGHT lanes per row (bamf_matvec_rows).
-    {   // zg[r] = sum_k W[r][k] a[k] = sum_{k <= r} Wt[k][r] a[k]: thread (h, r) walks half a column, coalesced over r
+    {
         const int r = tid & 127, h = tid >> 7, rc = r < n ? r : n - 1;
         double v[64];
 #pragma unroll
@@ -1091,9 +1082,40 @@ __global__ __launch_bounds__(256) void k_bamf_pi_vg(OpBasisPi op, int nblk, cons
     __syncthreads();
     if (tid < 128) zg[tid] = tid < n ? part[tid] + part[tid + 128] : 0.0;
     __syncthreads();
-    bamf_matvec_rows<true>(n, Wt, zg, t2);        // t2[k] = sum_{r >= k} Wt[k][r] zg[r]
+    bamf_matvec_rows<true>(n, Wt, zg, t2);
     __syncthreads();
-    bamf_matvec_rows<false>(n, Dm, t2, part);     // vg'[i] = vg[i] - sum_k Dm[i][k] t2[k]
+}
+// T = W11 M1 (one 16 x 16 block per workgroup) and, in one more workgroup, t2 (n > 64: this launch follows k_bam_cholw's)
+__global__ __launch_bounds__(256) void k_bamf_t_t2(OpBasisT op, int nblk, const double* __restrict__ Wt,
+                                                   const double* __restrict__ av, double* __restrict__ t2g) {
+    __shared__ double As[16 * SMALLGEMM_SA], Bs[256 * SMALLGEMM_SB], red[4 * 256];
+    if ((int)blockIdx.x < nblk) {
+        small_gemm_block(op, (int)blockIdx.x, As, Bs, red);
+        return;
+    }
+    const int n = op.m;
+    bamf_t2_body(n, Wt, av, As, As + 128, As + 384, As + 256);
+    if ((int)threadIdx.x < n) t2g[threadIdx.x] = As[256 + threadIdx.x];
+}
+// All global loads of a product are issued before its first multiply (a load per iteration behind a dependent reduction costs
+// an L2 round trip per row: 37 us for this workgroup at n = 128 when first written; a wave per row with 64 wave-wide
+// reductions per wave still 20 us): the two row-access products take EIGHT lanes per row (bamf_matvec_rows).
+__global__ __launch_bounds__(256) void k_bamf_pi_vg(OpBasisPi op, int nblk, const double* __restrict__ av, double* __restrict__ vg,
+                                                    int* info, const int* info1, const double* __restrict__ t2g) {
+    __shared__ double As[16 * SMALLGEMM_SA], Bs[256 * SMALLGEMM_SB], red[4 * 256];
+    if ((int)blockIdx.x < nblk) {
+        small_gemm_block(op, (int)blockIdx.x, As, Bs, red);
+        return;
+    }
+    const int n = op.m, tid = threadIdx.x;
+    double *t2 = As + 256, *part = As + 384;
+    if (tid == 0 && info1 && *info == 0 && *info1 != 0) *info = 1000 + *info1;
+    if (t2g) {                                     // (t2 came with the T launch)
+        if (tid < 128) t2[tid] = tid < n ? t2g[tid] : 0.0;
+        __syncthreads();
+    } else
+        bamf_t2_body(n, op.Wt, av, As, As + 128, part, t2);
+    bamf_matvec_rows<false>(n, op.Dm, t2, part);  // vg'[i] = vg[i] - sum_k Dm[i][k] t2[k]
     __syncthreads();
     if (tid < n) vg[tid] -= part[tid];
 }
@@ -1202,14 +1224,17 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
         const double* M1z = M1;                    // the n x n matrix k_bam_zw multiplies Vw with: M1, or M1' in the orthogonal basis
         ctx->chain_pi = nullptr;
         if (basis) {
+            const int nblk = ((n + 15) >> 4) * ((n + 15) >> 4);
+            double* t2g = Pi + 2 * q2;             // n doubles behind X
             if (!side64) {
                 if (!early && (rc = gsmvi_cholw_small(st, n, G11, R11, W11, info_side, 0))) return rc;
-                small_gemm_launch(st, OpBasisT{n, n, n, W11, M1, Tb, n});
+                hipLaunchKernelGGL(k_bamf_t_t2, dim3(nblk + 1), dim3(256), 0, st, OpBasisT{n, n, n, W11, M1, Tb, n}, nblk, Ld, Ldinv,
+                                   t2g);
                 small_gemm_launch(st, OpBasisM1p{n, n, n, W11, Tb, M1, M1p, Dm, n});
             }
-            const int nblk = ((n + 15) >> 4) * ((n + 15) >> 4);
             hipLaunchKernelGGL(k_bamf_pi_vg, dim3(nblk + 1), dim3(256), 0, st, OpBasisPi{n, n, n, Ld, Dm, Pi}, nblk, Ldinv,
-                               const_cast<double*>(Ldinv) + 2 * n, info_bam, early ? (const int*)nullptr : info_side);
+                               const_cast<double*>(Ldinv) + 2 * n, info_bam, early ? (const int*)nullptr : info_side,
+                               side64 ? (const double*)nullptr : t2g);
             M1z = M1p;
             ctx->chain_pi = Pi;
             ctx->chain_x = Pi + q2;
