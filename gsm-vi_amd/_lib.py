@@ -73,6 +73,7 @@ _SIGS = {
     "gsmvi_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "gsmvi_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "gsmvi_last_path": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.c_int]),
+    "gsmvi_bam_set_reg_source": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gsmvi_gaussian_score_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp,
                                            _c_dp, C.c_int, _c_dp, C.c_int]),
     "gsmvi_potrf_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int, _c_dp]),

@@ -82,7 +82,7 @@ class BaM:
     def fit(self, key, regf, mean=None, cov=None, batch_size=2, niter=5000, nprint=10, verbose=True,
             check_goodness=True, monitor=None, retries=10, jitter=1e-6, *, sampler="cholesky", rng="auto",
             as_torch=False, forced_samples=None, shard=False, group=None, check_update_flag=False, method="auto",
-            root_potrf=False, _zero_cols_from=None):
+            root_potrf=False, graph=None, _zero_cols_from=None):
         """gsmvi/bam.py:140-216.  Kept: niter+1 iterations (:178); nprint clamp (:177); reg = regf(i)
         per attempt (:196); jitter on the diagonal and symmetrisation (:198-199, done in-kernel);
         retry on any exception up to ``retries`` then re-raise (:189-206); Cholesky accept/revert of
@@ -135,8 +135,9 @@ class BaM:
                                check_goodness=check_goodness, monitor=_oddpad.wrap_monitor(monitor, self.lp, D),
                                retries=retries, jitter=jitter, sampler=sampler, rng=rng, as_torch=True, shard=shard,
                                group=group, check_update_flag=check_update_flag, method=method, root_potrf=root_potrf,
-                               _zero_cols_from=D)
+                               graph=graph, _zero_cols_from=D)
             self.method_used, self.n_reverts, self.padded_dim = inner.method_used, inner.n_reverts, D + 1
+            self.graph_replays, self.graph_fallback = getattr(inner, "graph_replays", 0), getattr(inner, "graph_fallback", None)
             mean_o, cov_o = mp[:D].contiguous(), cp[:D, :D].contiguous()
             return (mean_o, cov_o) if as_torch else (eng.to_numpy(mean_o), eng.to_numpy(cov_o))
         self._zc = _zero_cols_from
@@ -158,7 +159,7 @@ class BaM:
             assert sampler == "cholesky" and forced_samples is None, \
                 "method='factor' samples with its own factor (sampler='cholesky', no forced samples)"
             return self._fit_factor(eng, key, regf, mean, cov, B, niter, nprint, verbose, monitor, retries, rng, as_torch,
-                                    check_update_flag, shard, group)
+                                    check_update_flag, shard, group, graph)
         bmax = getattr(eng, "bam_max_batch", None)
         if bmax is not None and B > bmax:               # deterministic: raised here, not inside the retry loop
             raise ValueError(f"BaM.fit: batch_size {B} exceeds the device update's limit of {bmax}")
@@ -293,7 +294,7 @@ class BaM:
 
     # ------------------------------------------------------------------------------
     def _fit_factor(self, eng, key, regf, mean, cov, B, niter, nprint, verbose, monitor, retries, rng, as_torch,
-                    check_update_flag, shard=False, group=None):
+                    check_update_flag, shard=False, group=None, graph=None):
         """Factor-form BaM fit (see ``fit(method="factor")``): the loop of gsmvi/bam.py:140-216 on the state (mean, F).
         ``shard=True``: every rank draws the same Z, samples and scores only its batch_size/world rows; the (x_b, g_b) rows
         are all-gathered and every replica applies the identical factor update (dist.sharded_bam_factor_update)."""
@@ -335,66 +336,162 @@ class BaM:
             nprint = niter
         every = max(1, niter // nprint) if nprint > 0 else 1
         reverts_seen = 0
-        i = 0
-        for i in range(niter + 1):
-            if verbose and i % every == 0:
-                print(f"Iteration {i} of {niter}")
-                r = eng.read_flag(n_rev)
-                if r > reverts_seen:
-                    print(f"Bad update for covariance matrix. Revert ({r - reverts_seen} since last print)")
-                    reverts_seen = r
-            if monitor is not None and i % monitor.checkpoint == 0:
-                monitor(i, state(), self.lp, key, nevals=nevals)
-                nevals = 0
-            mu_a, F_a = state_bufs[a]
-            mu_b, F_b = state_bufs[1 - a]
-            j = 0
-            while True:
+        # Blocks of KB iterations replayed as ONE hipGraph (as GSM.fit): the launches must all be capturable (a `graph_safe`
+        # device score, the counter-based draw stream, no collective, no per-iteration flag read) and the one number that changes
+        # between iterations -- reg = regf(i), evaluated on the host by the reference (bam.py:196) -- is read by the kernels from
+        # a device word at execution time (engine.bam_reg_source / gsmvi_bam_set_reg_source): iteration k of the block reads word k
+        # of a KB-word table that is refilled (regf(i) .. regf(i + KB - 1), one small copy) before every replay.  Blocks with a
+        # print or a monitor call, the first block and the tail run eagerly with the by-value argument -- same kernels, same
+        # numbers.  Default: where launch overhead is the bound (D <= 512, or B <= 48 where the update is a short chain of
+        # small launches: 148 us eager against 139 us replayed at D = 1024, B = 32); graph=True forces, graph=False forbids.
+        use_graph = ((graph is True or (graph is None and (D <= 512 or B <= 48))) and dev_rng and native and not shard
+                     and not check_update_flag and niter + 1 >= 3 * KB and bool(getattr(self.lp_g, "graph_safe", False)))
+        takes_out = False
+        if native:
+            import inspect
+            try:
+                takes_out = "out" in inspect.signature(self.lp_g).parameters
+            except (TypeError, ValueError):
+                takes_out = False
+        self.graph_replays = 0
+        self.graph_fallback = None
+        gstate = {"graph": None}
+        if use_graph:
+            import torch
+            ctr = [torch.zeros(1, dtype=torch.int64, device=Zblk.device) for _ in range(2)]
+            reg_blk = torch.zeros(KB, dtype=torch.float64, device=Zblk.device)
+            reg_host = [torch.zeros(KB, dtype=torch.float64).pin_memory() for _ in range(4)]
+            reg_done = [None] * 4
+            Gbuf = eng.empty(hi - lo, D)
+
+        def graph_block(i_first):
+            """KB iterations (KB even: the ping-pong state ends where it started) as one replayed graph; the draw counter and
+            the regulariser table live on the device."""
+            if gstate["graph"] is None:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                g = torch.cuda.CUDAGraph()
                 try:
-                    if dev_rng:
-                        if ndraw % KB == 0:
-                            eng.normal_batch(KB, B, D, seed, ndraw, out=Zblk)
-                            if self._zc is not None:
-                                Zblk[:, :, self._zc:] = 0.0              # inert coordinates of an odd-D fit (_oddpad.py)
-                        Z = Zblk[ndraw % KB]
-                        ndraw += 1
-                    else:
-                        Z = eng.normal_from_host(rs.standard_normal((B, D)))
-                        if self._zc is not None:
-                            Z[:, self._zc:] = 0.0
-                    X = eng.sample(Z[lo:hi], mu_a, F_a, out=Xbuf)          # only this rank's rows when sharded
-                    err = None
+                    with torch.cuda.stream(side):
+                        torch.cuda.synchronize()
+                        with torch.cuda.graph(g, stream=side):
+                            for half in range(2):
+                                h0 = half * (KB // 2)
+                                eng.normal_batch(KB // 2, B, D, seed, 0, out=Zblk[h0:h0 + KB // 2], call_in=ctr[half],
+                                                 call_out=ctr[1 - half])
+                                if self._zc is not None:
+                                    Zblk[h0:h0 + KB // 2, :, self._zc:] = 0.0
+                                for k in range(KB // 2):
+                                    eng.bam_reg_source(reg_blk[h0 + k:h0 + k + 1])
+                                    mu_a, F_a = state_bufs[k & 1]
+                                    mu_b, F_b = state_bufs[1 - (k & 1)]
+                                    Zk = Zblk[h0 + k]
+                                    Xk = eng.sample(Zk, mu_a, F_a, out=Xbuf)
+                                    vk = self.lp_g(Xk, out=Gbuf) if takes_out else self.lp_g(Xk)
+                                    eng.bam_factor_update(Zk, Xk, vk, mu_a, F_a, 1.0, out=(mu_b, F_b), flag=flag, n_reverts=n_rev)   # (reg: ignored, word k is read)
+                finally:
+                    eng.bam_reg_source(None)
+                torch.cuda.current_stream().wait_stream(side)
+                gstate["graph"] = g
+            slot = self.graph_replays % 4
+            if reg_done[slot] is not None:
+                reg_done[slot].synchronize()                    # the copy that last read this pinned slot has run
+            for k in range(KB):
+                rk = float(regf(i_first + k))
+                if not rk > 0.0:                                 # (what the by-value entry point checks on the host)
+                    raise ValueError(f"BaM.fit: regf({i_first + k}) = {rk}: reg must be positive")
+                reg_host[slot][k] = rk
+            reg_blk.copy_(reg_host[slot], non_blocking=True)
+            reg_done[slot] = torch.cuda.Event()
+            reg_done[slot].record()
+            ctr[0].fill_(ndraw)
+            gstate["graph"].replay()
+
+        i = 0
+        while i <= niter:
+            blk_end = min(i + KB, niter + 1)
+            eventful = any((verbose and j % every == 0) or (monitor is not None and j % monitor.checkpoint == 0)
+                           for j in range(i, blk_end))
+            # (the first block always runs eagerly: every kernel has been launched, and the context sized, before a capture)
+            if use_graph and i > 0 and a == 0 and not eventful and blk_end - i == KB and ndraw % KB == 0:
+                try:
+                    graph_block(i)
+                except Exception as exc:                        # noqa: BLE001 -- capture unsupported here: stay eager
+                    if gstate["graph"] is not None:
+                        raise
+                    import warnings
+                    warnings.warn(f"BaM.fit: hipGraph capture of an iteration block failed ({type(exc).__name__}: {exc}); "
+                                  "the fit continues with eager launches (same numbers, more launch overhead)", RuntimeWarning)
+                    self.graph_fallback = exc
+                    use_graph = False
+                    torch.cuda.synchronize()
+                    continue
+                self.graph_replays += 1
+                ndraw += KB
+                nevals += B * KB
+                i = blk_end
+                continue
+            for i in range(i, blk_end):
+                if verbose and i % every == 0:
+                    print(f"Iteration {i} of {niter}")
+                    r = eng.read_flag(n_rev)
+                    if r > reverts_seen:
+                        print(f"Bad update for covariance matrix. Revert ({r - reverts_seen} since last print)")
+                        reverts_seen = r
+                if monitor is not None and i % monitor.checkpoint == 0:
+                    monitor(i, state(), self.lp, key, nevals=nevals)
+                    nevals = 0
+                mu_a, F_a = state_bufs[a]
+                mu_b, F_b = state_bufs[1 - a]
+                j = 0
+                while True:
                     try:
-                        vs = self.lp_g(X) if native else eng.host_score(self.lp_g, X)
-                    except Exception as e_score:            # noqa: BLE001
-                        if not (shard and world > 1):
-                            raise
-                        err, vs = e_score, None
-                    if shard and world > 1:                 # agree on failure BEFORE anybody enters the gather (as the dense fit)
-                        import torch
-                        fb = torch.tensor([0 if err is None else 1], dtype=torch.int32,
-                                          device=X.device if _is_torch(X) else "cpu")
-                        _dist.all_reduce(fb, op=_dist.ReduceOp.MAX, group=group)
-                        if int(fb.item()) != 0:
-                            raise err if err is not None else RuntimeError("score evaluation failed on another rank")
-                    nevals += B
-                    reg = regf(i)
-                    if shard:
-                        sharded_bam_factor_update(eng, Z, X, vs, mu_a, F_a, reg, group=group, out=(mu_b, F_b), flag=flag,
-                                                  n_reverts=n_rev)
-                    else:
-                        eng.bam_factor_update(Z, X, vs, mu_a, F_a, reg, out=(mu_b, F_b), flag=flag, n_reverts=n_rev)
-                    if check_update_flag and self._flag_raised(eng, flag, shard and world > 1, group):
-                        raise FloatingPointError("BaM update flagged a numerical failure (device flag != 0)")
-                    break
-                except Exception as e:                      # noqa: BLE001 -- reference behaviour
-                    if j < retries:
-                        j += 1
-                        print(f"Failed with exception {e}")
-                        print(f"Trying again {j} of {retries}")
-                    else:
-                        raise e
-            a = 1 - a               # the kernel already returned the reverted state when its test failed: accept = swap
+                        if dev_rng:
+                            if ndraw % KB == 0:
+                                eng.normal_batch(KB, B, D, seed, ndraw, out=Zblk)
+                                if self._zc is not None:
+                                    Zblk[:, :, self._zc:] = 0.0              # inert coordinates of an odd-D fit (_oddpad.py)
+                            Z = Zblk[ndraw % KB]
+                            ndraw += 1
+                        else:
+                            Z = eng.normal_from_host(rs.standard_normal((B, D)))
+                            if self._zc is not None:
+                                Z[:, self._zc:] = 0.0
+                        X = eng.sample(Z[lo:hi], mu_a, F_a, out=Xbuf)          # only this rank's rows when sharded
+                        err = None
+                        try:
+                            vs = self.lp_g(X) if native else eng.host_score(self.lp_g, X)
+                        except Exception as e_score:            # noqa: BLE001
+                            if not (shard and world > 1):
+                                raise
+                            err, vs = e_score, None
+                        if shard and world > 1:                 # agree on failure BEFORE anybody enters the gather (as the dense fit)
+                            import torch
+                            fb = torch.tensor([0 if err is None else 1], dtype=torch.int32,
+                                              device=X.device if _is_torch(X) else "cpu")
+                            _dist.all_reduce(fb, op=_dist.ReduceOp.MAX, group=group)
+                            if int(fb.item()) != 0:
+                                raise err if err is not None else RuntimeError("score evaluation failed on another rank")
+                        nevals += B
+                        reg = regf(i)
+                        if shard:
+                            sharded_bam_factor_update(eng, Z, X, vs, mu_a, F_a, reg, group=group, out=(mu_b, F_b), flag=flag,
+                                                      n_reverts=n_rev)
+                        else:
+                            eng.bam_factor_update(Z, X, vs, mu_a, F_a, reg, out=(mu_b, F_b), flag=flag, n_reverts=n_rev)
+                        if check_update_flag and self._flag_raised(eng, flag, shard and world > 1, group):
+                            raise FloatingPointError("BaM update flagged a numerical failure (device flag != 0)")
+                        break
+                    except Exception as e:                      # noqa: BLE001 -- reference behaviour
+                        if j < retries:
+                            j += 1
+                            print(f"Failed with exception {e}")
+                            print(f"Trying again {j} of {retries}")
+                        else:
+                            raise e
+                a = 1 - a               # the kernel already returned the reverted state when its test failed: accept = swap
+            i = blk_end
+        i = niter
         if monitor is not None:
             monitor(i, state(), self.lp, key, nevals=nevals)
         self.n_reverts = eng.read_flag(n_rev)

@@ -341,6 +341,13 @@ int gsmvi_last_path(gsmvi_ctx* ctx, unsigned* bits, int reset) {
     return GSMVI_OK;
 }
 
+/* BaM's regulariser from a device word read at execution time (graph replay), or by value again (NULL). */
+int gsmvi_bam_set_reg_source(gsmvi_ctx* ctx, const double* reg_dev) {
+    BAD_ARG(!ctx, "ctx is NULL");
+    ctx->reg_dev = reg_dev;
+    return GSMVI_OK;
+}
+
 int gsmvi_set_profiling(gsmvi_ctx* ctx, int on) {
     BAD_ARG(!ctx, "ctx is NULL");
     ctx->profiling = on ? 1 : 0;

@@ -37,11 +37,12 @@
 template <int NG, bool XT = false>   // sample groups per workgroup: 256 / NG columns x NG groups (4 for B <= 32, 16 above: round 4)
 __global__ __launch_bounds__(256) void k_bam_stats_h(int D, int B, const double* __restrict__ V, int ldv,
                                                      const double* __restrict__ shift, const double* __restrict__ X,
-                                                     int ldx, const double* __restrict__ G, int ldg, double reg,
+                                                     int ldx, const double* __restrict__ G, int ldg, bam_reg regs,
                                                      double* __restrict__ xbar, double* __restrict__ gbar,
                                                      double* __restrict__ zerov, double* __restrict__ Qt,
                                                      double* __restrict__ Vout, double* __restrict__ Vout2,
                                                      const double* __restrict__ xshift, double* __restrict__ Xh) {
+    const double reg = regs.get();
     constexpr int NC = 256 / NG;
     __shared__ double red[3][NG][NC];
     const int c = threadIdx.x % NC, g = threadIdx.x / NC;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void k_bam_stats_h(int D, int B, const double*
 // launch: 4 sample groups x 64 columns for small batches (the round-3 shape), 16 x 16 above (B = 128: 16 workgroups of four
 // 32-sample groups became 64 workgroups of sixteen 8-sample groups: every group's loads in one batch)
 static inline void bam_stats_launch(hipStream_t st, int D, int B, const double* V, int ldv, const double* shift, const double* X,
-                                    int ldx, const double* G, int ldg, double reg, double* xbar, double* gbar, double* zerov,
+                                    int ldx, const double* G, int ldg, bam_reg reg, double* xbar, double* gbar, double* zerov,
                                     double* Qt, double* Vout, double* Vout2, const double* xshift = nullptr, double* Xh = nullptr) {
 #define STATS(NGV, XTV, GX) hipLaunchKernelGGL((k_bam_stats_h<NGV, XTV>), dim3(GX), dim3(256), 0, st, D, B, V, ldv, shift, X, ldx, G, ldg, reg, xbar, gbar, zerov, Qt, Vout, Vout2, xshift, Xh)
     if (B <= 32) { if (Xh) STATS(4, true, (D + 63) / 64); else STATS(4, false, (D + 63) / 64); }
@@ -190,9 +191,10 @@ __global__ __launch_bounds__(COLS) void k_bam_forward(int D, int n, const double
                                                     const double* __restrict__ Ldinv,
                                                     const double* __restrict__ zg, const double* __restrict__ vg,
                                                     const double* __restrict__ mu0,
-                                                    const double* __restrict__ xbar, double reg,
+                                                    const double* __restrict__ xbar, bam_reg regs,
                                                     double* __restrict__ Ft, double* __restrict__ Fs,
                                                     double* __restrict__ mu) {
+    const double reg = regs.get();
     extern __shared__ double sm[];                 // vf[n][COLS], z[n][COLS]
     double* vf = sm;
     double* z = sm + (size_t)n * COLS;
@@ -381,9 +383,10 @@ __global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const doubl
                                                        const double* __restrict__ Ldinv,
                                                        const double* __restrict__ zg, const double* __restrict__ vg,
                                                        const double* __restrict__ mu0,
-                                                       const double* __restrict__ xbar, double reg,
+                                                       const double* __restrict__ xbar, bam_reg regs,
                                                        double* __restrict__ Ft, double* __restrict__ Fs,
                                                        double* __restrict__ mu, bamf_fix fx) {
+    const double reg = regs.get();
     __shared__ __attribute__((aligned(16))) double U[BAMF_NMAX * (BAMF_NMAX + 1) / 2];
     __shared__ double sdi[BAMF_NMAX], szg[BAMF_NMAX], svg[BAMF_NMAX];
     __shared__ double sM1[64 * 64];
@@ -536,8 +539,9 @@ __global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const doubl
 __global__ __launch_bounds__(512) void k_bam_zw(int D, int n, const double* __restrict__ P, const double* __restrict__ M1,
                                                 const double* __restrict__ Wt, const double* __restrict__ av,
                                                 const double* __restrict__ vg, const double* __restrict__ mu0,
-                                                const double* __restrict__ xbar, double reg, double* __restrict__ Ft,
+                                                const double* __restrict__ xbar, bam_reg regs, double* __restrict__ Ft,
                                                 double* __restrict__ Fs, double* __restrict__ mu) {
+    const double reg = regs.get();
     __shared__ __attribute__((aligned(16))) double Vs[128 * 16], As[128 * 16];
     __shared__ double sav[128], szg[128], svg[128], redz[8 * 4 * 16];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
@@ -868,7 +872,7 @@ __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, cons
 
 #include "gsmvi_chol128.h"   // cholw_job
 #include "gsmvi_smallgemm.h"
-int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* Nd, const double* M1,
+int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, bam_reg reg, const double* Nd, const double* M1,
                            const double* N0, double* scratch, double* Ld, int* info_dev, int* hint_host, int force_kenq,
                            double* Rscr, const cholw_job* beside, const bamq_side* side64, const double* G11);
 int gsmvi_bam_small_one_wg(const gsmvi_ctx* ctx, int n);
@@ -879,7 +883,7 @@ size_t gsmvi_bam_small_scratch_doubles(int n);
 int gsmvi_panel_t_product(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* A, int lda, const double* M,
                           int ldm, int mrows, double* Pp, int* kc_out);
 int gsmvi_bam_small_fused_nmax();
-int gsmvi_bam_small_fused(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* slabs, int kc, int ldslab,
+int gsmvi_bam_small_fused(gsmvi_ctx* ctx, hipStream_t st, int n, bam_reg reg, const double* slabs, int kc, int ldslab,
                           size_t slab_stride, double* M1, double* Ld, double* Upk, int* info_dev, const bamq_side* side);
 
 #define BAM_NMAT2(KC, NBQ, N_, SL, STR, LDP, N0_, M1_, ND_, G11_)                                                        \
@@ -891,8 +895,9 @@ int gsmvi_bam_small_fused(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, con
                                G11_);                                                                                   \
     } while (0)
 int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X, int ldx, const double* G,
-                   int ldg, const double* mu0, const double* S0, int lds0, double reg, double jitter, double* mu,
+                   int ldg, const double* mu0, const double* S0, int lds0, double reg_value, double jitter, double* mu,
                    double* S, int lds, int* info_dev) {
+    const bam_reg reg{reg_value, ctx->reg_dev};
     // n = B columns of Q and rows of Vf (round 3: the Helmert recombination of the B centred rows, k_bam_stats_h; the
     // reference's own factorisation has B + 1.  U = Q Q^T and Vf^T Vf -- all the update depends on -- are unchanged)
     const int n = B, n2 = 2 * n;
@@ -1000,8 +1005,9 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
 //   read + write of the update), no pass over a covariance.
 // mu = mu0/(1+reg) + r1 (S gbar) + r1 xbar, or mu0 on a reverted update (bam.py:112)
 __global__ __launch_bounds__(256) void k_bamf_commit(int D, const double* __restrict__ sg_r1, const double* __restrict__ mu0,
-                                                     const double* __restrict__ xbar, double reg,
+                                                     const double* __restrict__ xbar, bam_reg regs,
                                                      const int* __restrict__ bad, double* __restrict__ mu) {
+    const double reg = regs.get();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= D) return;
     const double r1 = reg / (1.0 + reg);
@@ -1125,8 +1131,9 @@ __global__ __launch_bounds__(256) void k_bamf_pi_vg(OpBasisPi op, int nblk, cons
 int gsmvi_cholw_small(hipStream_t st, int n, const double* A, double* R, double* W, int* info, int info_off);
 
 int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X, int ldx,
-                          const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double reg, double* mu,
+                          const double* G, int ldg, const double* mu0, const double* F0, int ldf0, double reg_value, double* mu,
                           double* F, int ldf, int* info_dev, int* n_reverts_dev) {
+    const bam_reg reg{reg_value, ctx->reg_dev};
     const int n = B, n2 = 2 * n;
     // workspace (ctx->sg holds 8 rmax max_D doubles, rmax = 2B + 8): 10 n + 5 rows of D
     double* Qt = ctx->sg;                          // n x D

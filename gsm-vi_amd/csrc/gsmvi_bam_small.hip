@@ -522,11 +522,12 @@ __global__ __launch_bounds__(256) void k_bam_ns_bb(int n, int ld, const double* 
 //                                           reads are 128-byte row segments (a one-workgroup version read Y by columns: 8 us)
 //   vg = Vf gbar = M1[:, n-1] / r1s,  a = P gbar + M1^T vg (bam.py:107 applied to gbar)      nb extra workgroups, 16 entries each
 // Outputs: BBg (n x n); behind the n x n slot of W: [a (n) | (n unused) | vg (n)].  A failed iteration (coef[42]) poisons BB.
-__global__ __launch_bounds__(256) void k_bam_bbav(int n, int ld, double reg, const double* __restrict__ Nm,
+__global__ __launch_bounds__(256) void k_bam_bbav(int n, int ld, bam_reg regs, const double* __restrict__ Nm,
                                                   const double* __restrict__ Ya, const double* __restrict__ Yb,
                                                   const double* __restrict__ coef, const double* __restrict__ M1,
                                                   const double* __restrict__ N0, double* __restrict__ BBg,
                                                   double* __restrict__ tail3) {
+    const double reg = regs.get();
     const int nb = (n + 15) >> 4, tid = threadIdx.x;
     if ((int)blockIdx.x < nb * nb) {
         __shared__ double Tt[16 * 17];
@@ -641,10 +642,11 @@ __global__ __launch_bounds__(512) void k_bam_cholw_pair(int n, const double* __r
 // One workgroup: Ld = R^T (lower), Ldinv, vg = Vf gbar = M1[:, n-1] / r1s, zg = L^-1 (P gbar + M1^T vg) by a column-oriented
 // forward substitution (row pp of R is contiguous; eight rows' loads in flight).  A failed factorisation (or a NaN in it)
 // poisons every output, as k_bam_cholw does.
-__global__ __launch_bounds__(1024) void k_bam_post_big(int n, double reg, const double* __restrict__ Rb,
+__global__ __launch_bounds__(1024) void k_bam_post_big(int n, bam_reg regs, const double* __restrict__ Rb,
                                                        const int* __restrict__ info_p, const double* __restrict__ M1,
                                                        const double* __restrict__ N0, double* __restrict__ Ld,
                                                        int* __restrict__ info) {
+    const double reg = regs.get();
     __shared__ double sc[BAMS_NBIG + 8], av[BAMS_NBIG + 8];
     __shared__ int sh_bad;
     const int tid = threadIdx.x;
@@ -720,11 +722,12 @@ __global__ __launch_bounds__(1024) void k_bam_post_big(int n, double reg, const 
 // PAIR: the launch's second workgroup is the side workgroup of the orthogonal basis (bamq_side_body above); wave 0 of the
 // chain adds t2 = L^-T zg behind zg.
 template <int NB, bool PAIR>
-__global__ __launch_bounds__(512) void k_bam_small48(int n, double reg, const double* __restrict__ slabs, int kc, int ldslab,
+__global__ __launch_bounds__(512) void k_bam_small48(int n, bam_reg regs, const double* __restrict__ slabs, int kc, int ldslab,
                                                      long long slab_stride, double* __restrict__ M1g,
                                                      double* __restrict__ Ld, double* __restrict__ Upk,
                                                      int* __restrict__ info, unsigned long long* __restrict__ stamps,
                                                      bamq_side sd) {
+    const double reg = regs.get();
 #define Q_STAMP(k)                                                                          \
     do {                                                                                    \
         if (stamps && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memrealtime();        \
@@ -1017,7 +1020,7 @@ __global__ __launch_bounds__(512) void k_bam_small48(int n, double reg, const do
 int gsmvi_bam_small_fused_nmax() { return BAMQ_SN; }
 
 // n <= 48: slabs of [N0; M1] in, everything out (see k_bam_small48)
-int gsmvi_bam_small_fused(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* slabs, int kc, int ldslab,
+int gsmvi_bam_small_fused(gsmvi_ctx* ctx, hipStream_t st, int n, bam_reg reg, const double* slabs, int kc, int ldslab,
                           size_t slab_stride, double* M1, double* Ld, double* Upk, int* info_dev, const bamq_side* side) {
     unsigned long long* stamps = (ctx->tune_cov_dbg & 256)           // diagnostic (scripts/bam48_timeline.py): phase stamps
                                      ? reinterpret_cast<unsigned long long*>(ctx->gram_slabs + (size_t)GSMVI_MAX_KC * ctx->rmax * ctx->rmax)
@@ -1040,7 +1043,7 @@ int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double*
 // n <= 128: k_bam_bbav forms BB and [a | . | vg] behind W's slot, k_bam_cholw leaves Wt = (L^-1)^T (n x n, upper) in Ld's slot and
 // the upper factor in Rscr (scratch); k_bam_zw (gsmvi_bam.hip) consumes Wt.  n > 128: blocked multi-workgroup Cholesky + the
 // small outputs of k_bam_post_big (Ld = L, Ldinv, zg, vg) for the generic forward-substitution kernel.
-int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, double reg, const double* Nd, const double* M1,
+int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, bam_reg reg, const double* Nd, const double* M1,
                            const double* N0, double* scratch, double* Ld, int* info_dev, int* hint_host, int force_kenq,
                            double* Rscr, const cholw_job* beside, const bamq_side* side64, const double* G11) {
     const int ld = n <= BAMS_NMAX ? BAMS_LD : ((n + 15) / 16) * 16;

@@ -71,6 +71,7 @@ struct gsmvi_ctx {
     int tune_bam_full = 0;     // 1 = always enqueue every Newton-Schulz step (ignore the hint; tests)
     int tune_lowrank_kp = 0;   // 64: BaM's low-rank update stages 64 rows per pass for KF > 96 (A/B runs: measured equal to 32)
     int tune_chain_pair = 1;   // two-level chain (128 < 2B <= 256): independent one-workgroup factorisations share a launch (0: A/B runs)
+    const double* reg_dev = nullptr;   // gsmvi_bam_set_reg_source: BaM's regulariser is read from here at execution time
     int tune_bam_basis = 1;    // 1 (default) = factor-form BaM in the basis [Vw; Zt], Zt = the part of Zw orthogonal to the whitened draws; 0 = [Vw; Zw]
                                // (round 5: no dependent rows at the fixed point of a Gaussian target); 0 = the
                                // round-4 basis [Vw; Zw] (A/B runs)
@@ -122,4 +123,15 @@ struct bamq_side {
     double* Dm;                        // n x n: M1 - M1'
     double* t2;                        // n: L^-T zg (written by the CHAIN workgroup: wave 0, behind zg)
     int* info1;                        // 0 or the 1-based failing pivot of Gvv's factorisation (dependent draws)
+};
+
+// BaM's regulariser as the kernels take it: by value, or -- so that a captured hipGraph can be replayed with another value
+// (bam.py:196 evaluates regf(i) on the host every iteration) -- from a device word read at execution time
+// (gsmvi_bam_set_reg_source, include/gsmvi_hip.h).
+struct bam_reg {
+    double v;
+    const double* p;
+#if defined(__HIPCC__)
+    __device__ __forceinline__ double get() const { return p ? *p : v; }
+#endif
 };

@@ -474,6 +474,15 @@ class HipEngine:
         _lib.check("gsmvi_last_path", self.lib.gsmvi_last_path(self._ctx, C.byref(bits), int(bool(reset))))
         return {k for k, v in self.PATH_BITS.items() if bits.value & v}
 
+    def bam_reg_source(self, word):
+        """gsmvi_bam_set_reg_source: ``word`` (a 1-element float64 device tensor) makes every BaM update launched from now on
+        read its regulariser from that word when its kernels EXECUTE (a captured graph can then be replayed with another
+        value; the ``reg`` argument is ignored); ``None`` restores the by-value argument."""
+        self._ensure(max(self._max_D, 1), max(self._max_B, 1))
+        self._reg_word = word                                   # (kept alive while it is the source)
+        ptr = None if word is None else C.c_void_p(word.data_ptr())
+        _lib.check("gsmvi_bam_set_reg_source", self.lib.gsmvi_bam_set_reg_source(self._ctx, ptr))
+
     def set_profiling(self, on):
         self._ensure(max(self._max_D, 1), max(self._max_B, 1))
         _lib.check("gsmvi_set_profiling", self.lib.gsmvi_set_profiling(self._ctx, int(bool(on))))

@@ -249,6 +249,16 @@ int gsmvi_get_profile(gsmvi_ctx* ctx, float* ms, int n);
 int gsmvi_last_path(gsmvi_ctx* ctx, unsigned* bits, int reset);
 
 /*
+ * Where the BaM entry points of this context take the regulariser from (round 5).  The reference evaluates regf(i) on the
+ * host in every iteration (bam.py:196) and passes a number; a caller that captures an iteration into a hipGraph needs a
+ * value that can change between replays.  reg_dev != NULL: every BaM update launched on this context from now on (dense,
+ * factor form, and the sharded forms built on them) reads *reg_dev on the DEVICE when its kernels execute and ignores its `reg`
+ * argument (which is still validated: pass any positive number; the value in the word is the caller's to check, reg > 0); the word
+ * must stay valid while such work is pending.  NULL (the default) restores the by-value argument.
+ */
+int gsmvi_bam_set_reg_source(gsmvi_ctx* ctx, const double* reg_dev);
+
+/*
  * Score of the Gaussian target N(m, P^-1) at the rows of X: G = -(X - 1 m^T) P.
  * Replaces the user callback of examples/example_gsm_numpy.py:24-29 (P symmetric precision matrix).
  */

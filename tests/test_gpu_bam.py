@@ -546,3 +546,64 @@ def test_round4_chain_rejects_nan_and_indefinite_inputs():
     assert eng.read_flag(f) != 0
     mu, S, f = eng.bam_update(X, G, mu0, S0, 1.0, 0.0)           # and the context is usable afterwards
     assert eng.read_flag(f) == 0 and bool(S.isfinite().all())
+
+
+@pytest.mark.parametrize("D,B", [(256, 8), (1024, 32), (1024, 64), (1024, 128)])
+def test_regulariser_from_a_device_word_equals_the_by_value_argument(D, B):
+    """gsmvi_bam_set_reg_source (bam.py:196 evaluates regf(i) on the host; a replayed graph needs it on the device): with a
+    device word as the source the `reg` argument is ignored and the update is bit-identical to the by-value call with the
+    word's value -- dense and factor form, one-workgroup and multi-launch chains; NULL restores the argument."""
+    import torch
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    mu0, F0, Z, X, G = _factor_state(eng, D, B, seed=3 * D + B)
+    dv = [eng.asarray(a) for a in (Z, X, G, mu0, F0)]
+    S0 = eng.gram(dv[4])
+    word = torch.tensor([2.5], dtype=torch.float64, device=dv[0].device)
+    ref_f = [t.clone() for t in eng.bam_factor_update(*dv, 2.5)[:2]]
+    ref_d = [t.clone() for t in eng.bam_update(dv[1], dv[2], dv[3], S0, 2.5, 1e-6)[:2]]
+    try:
+        eng.bam_reg_source(word)
+        got_f = [t.clone() for t in eng.bam_factor_update(*dv, 99.0)[:2]]
+        got_d = [t.clone() for t in eng.bam_update(dv[1], dv[2], dv[3], S0, 99.0, 1e-6)[:2]]
+        word.fill_(0.75)                                         # the value is read when the kernels run
+        got_f2 = [t.clone() for t in eng.bam_factor_update(*dv, 99.0)[:2]]
+    finally:
+        eng.bam_reg_source(None)
+    for a, b in zip(ref_f + ref_d, got_f + got_d):
+        assert torch.equal(a, b), float((a - b).abs().max())
+    ref_f2 = eng.bam_factor_update(*dv, 0.75)[:2]
+    for a, b in zip(ref_f2, got_f2):
+        assert torch.equal(a, b)
+    back = eng.bam_factor_update(*dv, 2.5)[:2]                   # by value again
+    for a, b in zip(ref_f, back):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("D,B,niter", [(256, 8, 95), (1024, 32, 79), (129, 6, 70)])
+def test_graph_replayed_bam_fit_is_bit_identical_to_the_eager_fit(D, B, niter):
+    """BaM.fit(graph=True) replays blocks of 16 iterations as ONE hipGraph: the draw counter and the regulariser table
+    (regf(i) changes every iteration: bam.py:196) live on the device.  'Same numbers either way': graph=False must give
+    bit-identical (mean, cov) and revert count.  A table that was not refilled, a counter that did not advance or a ping-pong
+    state off by one would change every bit.  (129: an odd dimension, the fit runs on 130 with an inert coordinate.)"""
+    import warnings
+    import torch
+    import gsmvi_amd
+    orc, _ = _o()
+    m, cov_t, P = orc.make_gaussian_target(D, 3)
+    tgt = gsmvi_amd.GaussianTarget(m, precision=P)
+    sched = lambda i: 100.0 / (1 + i)                            # noqa: E731  (examples/example_bam.py:58)
+    res = {}
+    for graph in (False, True):
+        bam = gsmvi_amd.BaM(D, tgt.lp, tgt.lp_g)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                       # a silent eager fallback would make this test vacuous
+            mean, cov = bam.fit(7, sched, niter=niter, batch_size=B, verbose=False, graph=graph, as_torch=True)
+        torch.cuda.synchronize()
+        res[graph] = (mean.clone(), cov.clone(), bam.n_reverts, bam.graph_replays, bam.method_used)
+    assert res[True][4] == "factor" and res[False][4] == "factor"
+    assert res[False][3] == 0
+    assert res[True][3] == (niter + 1) // 16 - 1 and res[True][3] >= 3, res[True][3]
+    assert torch.equal(res[True][0], res[False][0]), float((res[True][0] - res[False][0]).abs().max())
+    assert torch.equal(res[True][1], res[False][1]), float((res[True][1] - res[False][1]).abs().max())
+    assert res[True][2] == res[False][2]
