@@ -342,9 +342,13 @@ class BaM:
         # a device word at execution time (engine.bam_reg_source / gsmvi_bam_set_reg_source): iteration k of the block reads word k
         # of a KB-word table that is refilled (regf(i) .. regf(i + KB - 1), one small copy) before every replay.  Blocks with a
         # print or a monitor call, the first block and the tail run eagerly with the by-value argument -- same kernels, same
-        # numbers.  Default: where launch overhead is the bound (D <= 512, or B <= 48 where the update is a short chain of
-        # small launches: 148 us eager against 139 us replayed at D = 1024, B = 32); graph=True forces, graph=False forbids.
-        use_graph = ((graph is True or (graph is None and (D <= 512 or B <= 48))) and dev_rng and native and not shard
+        # numbers (tests/test_gpu_bam.py: bit-identical).  OFF unless graph=True: measured (scripts/bam_graph_ab.py, marginal
+        # iteration of 1200- against 400-iteration fits) the replayed block is not faster than eager launches on this host --
+        # 70.9 vs 71.5 us at (256, 8), 151.8 vs 150.1 at (1024, 32), 448 vs 440 at (1024, 128) -- the device is never waiting for
+        # the host (enqueueing an update takes 45 - 195 us of host time against 69 - 445 us of device time), and the capture
+        # costs ~3 ms.  The 148-against-139 us "eager vs replayed" of a single update is an artefact of timing each eager call
+        # from an idle device.  It is kept for callers whose host is slower or shared.
+        use_graph = (graph is True and dev_rng and native and not shard
                      and not check_update_flag and niter + 1 >= 3 * KB and bool(getattr(self.lp_g, "graph_safe", False)))
         takes_out = False
         if native:
