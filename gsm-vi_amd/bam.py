@@ -108,6 +108,8 @@ class BaM:
         more than one GPU (see GSM.fit).
         ``method="factor"`` with ``shard=True``: the (x_b, g_b) rows are all-gathered as in the dense form and every replica
         runs the identical factor-form update (dist.sharded_bam_factor_update); retries are collective in the same way.
+        ``graph=True``: factor-form fits replay blocks of 16 iterations as one hipGraph (the regulariser table on the device:
+        engine.bam_reg_source); bit-identical to the eager loop and, measured, not faster on an idle host -- off by default.
         ``method="auto"`` (default since round 5): "factor" whenever that form exists for the call (see below) and ``jitter`` is
         at most the reference's 1e-6, else "dense" (the reference's loop incl. its jitter).  The two loops are the same update to
         1e-10 on the same samples; the jitter itself moves the reference's trajectory by 2e-5 .. 3e-5 of max|cov|
