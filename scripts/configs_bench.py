@@ -176,7 +176,13 @@ for name, D, B in (("c4", 1024, 128), ("c4_B32", 1024, 32)):
         n, t0 = (400 if B <= 64 else 150), time.perf_counter()
         bam.fit(1, sched, niter=n - 1, batch_size=B, verbose=False, rng="device", method="factor")
         torch.cuda.synchronize()
-        r["F_fit_bam_factor"] = {"it_per_s": n / (time.perf_counter() - t0), "n": n, "n_reverts": bam.n_reverts,
+        t1 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        bam.fit(1, sched, niter=3 * n - 1, batch_size=B, verbose=False, rng="device", method="factor")
+        torch.cuda.synchronize()
+        t3 = time.perf_counter() - t0
+        # it_per_s: the whole call (initial Cholesky, buffers, final Gram product included); marginal: the iteration alone
+        r["F_fit_bam_factor"] = {"it_per_s": n / t1, "it_per_s_marginal": 2 * n / (t3 - t1), "n": n, "n_reverts": bam.n_reverts,
                                  "method": "factor (= the default, method='auto', since round 5)"}
     h = {k: st[k].cpu().numpy() for k in ("X", "G", "mu0", "S0")}
     r["cpu_lowrank_update"] = cpu_time(lambda: borc.bam_lowrank_update_exact(h["X"], h["G"], h["mu0"], h["S0"], 1.0), 4.0)
