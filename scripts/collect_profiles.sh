@@ -61,6 +61,14 @@ python3 scripts/callpath_bench.py $OUT/callpath.json > $OUT/callpath.log 2>&1
 python3 scripts/fit_kc_ab.py 1024 32 2>&1 | grep -v amdgpu.ids > $OUT/fit_kc_ab.txt
 python3 scripts/bam_basis_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/bam_basis_ab.txt
 python3 scripts/cov_ab_rounds.py 2>&1 | grep -v amdgpu.ids > $OUT/cov_ab_rounds.txt
+python3 scripts/bam_graph_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/bam_graph_ab.txt
+# factor-form BaM update, orthogonal basis (1) and round-4 basis (0): timed alone (median of event pairs) and back-to-back
+for cfg in "1024 128" "1024 64" "1024 32" "256 8" "4096 64"; do
+  for b in 1 0; do
+    echo "== D B = $cfg, bam_basis = $b (inputs of scripts/configs_bench.py)" >> $OUT/bamf_backtoback.txt
+    python3 scripts/bamf_trace.py $cfg $b cfg 2>&1 | grep -E "eager|host" >> $OUT/bamf_backtoback.txt
+  done
+done
 python3 scripts/soak_round3.py 120 > $OUT/soak.txt 2>&1
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 bench.py --steps 20 --warmup 3 > $OUT/bench_driver_flags.json 2>> $OUT/bench.err
