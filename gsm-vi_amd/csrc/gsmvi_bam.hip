@@ -1252,6 +1252,8 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     ctx->fo_Rt = Ft;
     ctx->fo_Tm = Tm;
     ctx->fo_Fs = Fsf;
+    ctx->bam_mean = gsmf_bam_mean{xbar, Tm + (size_t)n2 * D, reg};   // 2B <= 64: the update kernel writes BaM's mean itself
+    ctx->bam_mean_done = 0;
     int kcg = 1, rides = 0;
     // Large D, 64 < 2B <= 128 (the 2B x 2B chain is six small launches, ~115 us on a few CUs): the product Rt F0 (MFMA-bound,
     // 92 us at D = 4096) depends on Ft only, so it runs on the context's second stream beside the Gram product and the chain and is
@@ -1284,7 +1286,11 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     ctx->fo_Rt = ctx->fo_Tm = ctx->fo_Fs = nullptr;
     ctx->chain_pi = nullptr;
     ctx->chain_x = nullptr;
+    const bool mean_done = ctx->bam_mean_done != 0;
+    ctx->bam_mean = gsmf_bam_mean{nullptr, nullptr, {0.0, nullptr}};
+    ctx->bam_mean_done = 0;
     if (rc) return rc;
+    if (!mean_done)
     hipLaunchKernelGGL(k_bamf_commit, dim3((D + 255) / 256), dim3(256), 0, st, D, Tm + (size_t)n2 * D, mu0, xbar, reg, info_dev,
                        mu);
     hipError_t e = hipGetLastError();

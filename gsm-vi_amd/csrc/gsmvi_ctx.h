@@ -36,6 +36,26 @@ struct gsmvi_panel_extras {
     const double* rd_Pi = nullptr;          // jmode 2: the B x B coupling matrix of the orthogonal-basis BaM form (gsmvi_small16.h)
 };
 
+// BaM's regulariser as the kernels take it: by value, or -- so that a captured hipGraph can be replayed with another value
+// (bam.py:196 evaluates regf(i) on the host every iteration) -- from a device word read at execution time
+// (gsmvi_bam_set_reg_source, include/gsmvi_hip.h).
+struct bam_reg {
+    double v;
+    const double* p;
+#if defined(__HIPCC__)
+    __device__ __forceinline__ double get() const { return p ? *p : v; }
+#endif
+};
+
+// BaM's mean inside the factor update kernel (k_gsmf_update_fs): mu = mu0 / (1 + reg) + sg_r1 + r1 xbar (bam.py:112) instead of
+// the GSM form mu0 + sum_b coef_b Tm_b; xbar == nullptr: GSM.  The factor-form BaM update sets ctx->bam_mean before the back half
+// and finds ctx->bam_mean_done == 1 afterwards when the launch that ran honours it (else k_bamf_commit follows).
+struct gsmf_bam_mean {
+    const double* xbar;
+    const double* sg_r1;               // r1 (S gbar): the last row of Rt F0
+    bam_reg reg;
+};
+
 struct gsmvi_ctx {
     gsmvi_panel_extras px;     // see above
     int px_used = 0;
@@ -71,6 +91,8 @@ struct gsmvi_ctx {
     int tune_bam_full = 0;     // 1 = always enqueue every Newton-Schulz step (ignore the hint; tests)
     int tune_lowrank_kp = 0;   // 64: BaM's low-rank update stages 64 rows per pass for KF > 96 (A/B runs: measured equal to 32)
     int tune_chain_pair = 1;   // two-level chain (128 < 2B <= 256): independent one-workgroup factorisations share a launch (0: A/B runs)
+    gsmf_bam_mean bam_mean = {nullptr, nullptr, {0.0, nullptr}};
+    int bam_mean_done = 0;
     const double* reg_dev = nullptr;   // gsmvi_bam_set_reg_source: BaM's regulariser is read from here at execution time
     int tune_bam_basis = 1;    // 1 (default) = factor-form BaM in the basis [Vw; Zt], Zt = the part of Zw orthogonal to the whitened draws; 0 = [Vw; Zw]
                                // (round 5: no dependent rows at the fixed point of a Gaussian target); 0 = the
@@ -123,15 +145,4 @@ struct bamq_side {
     double* Dm;                        // n x n: M1 - M1'
     double* t2;                        // n: L^-T zg (written by the CHAIN workgroup: wave 0, behind zg)
     int* info1;                        // 0 or the 1-based failing pivot of Gvv's factorisation (dependent draws)
-};
-
-// BaM's regulariser as the kernels take it: by value, or -- so that a captured hipGraph can be replayed with another value
-// (bam.py:196 evaluates regf(i) on the host every iteration) -- from a device word read at execution time
-// (gsmvi_bam_set_reg_source, include/gsmvi_hip.h).
-struct bam_reg {
-    double v;
-    const double* p;
-#if defined(__HIPCC__)
-    __device__ __forceinline__ double get() const { return p ? *p : v; }
-#endif
 };

@@ -628,7 +628,8 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const doub
                                                         const double* __restrict__ F0, int ldf0, double* __restrict__ F,
                                                         int ldf, const double* __restrict__ coef,
                                                         const double* __restrict__ mu0, double* __restrict__ mu,
-                                                        const int* __restrict__ bad, int* __restrict__ n_reverts) {
+                                                        const int* __restrict__ bad, int* __restrict__ n_reverts,
+                                                        gsmf_bam_mean bm) {
     constexpr int N = 32 * NP, RS = 80, KS = N + 2;
     __shared__ __attribute__((aligned(16))) double bufA[N * RS];      // Tm1 tile [k][64 cols], later the Rt1 tile
     __shared__ __attribute__((aligned(16))) double bufB[N * RS];      // Fs tile
@@ -763,7 +764,11 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const doub
             double s = 0.0;
 #pragma unroll
             for (int g = 0; g < 8; ++g) s += msm[g * 64 + tid];
-            mu[J0 + tid] = skip ? mu0[J0 + tid] : mu0[J0 + tid] + s;
+            if (bm.xbar) {                         // factor-form BaM (bam.py:112): mu0/(1+reg) + r1 (S gbar) + r1 xbar
+                const double reg = bm.reg.get(), r1 = reg / (1.0 + reg);
+                mu[J0 + tid] = skip ? mu0[J0 + tid] : mu0[J0 + tid] / (1.0 + reg) + bm.sg_r1[J0 + tid] + r1 * bm.xbar[J0 + tid];
+            } else
+                mu[J0 + tid] = skip ? mu0[J0 + tid] : mu0[J0 + tid] + s;
         }
     }
 }
@@ -1308,7 +1313,8 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         ctx->path |= GSMVI_PATH_FUPD_FAST;
         // n <= 64: the skinny product Fs = K'' Tm1 is folded into the update kernel (k_gsmf_update_fs): one launch less
         const int ntl = (D + 63) / 64;
-#define UFS(NPV, KCBV, RG) hipLaunchKernelGGL((k_gsmf_update_fs<NPV, KCBV, RG>), dim3(ntl * ntl), dim3(512), 0, st, D, B, Rt, Kmat, Tm, vf_slabs, kcv, F0, ldf0, F, ldf, coef, mu0, mu, info_dev, n_reverts_dev)
+#define UFS(NPV, KCBV, RG) hipLaunchKernelGGL((k_gsmf_update_fs<NPV, KCBV, RG>), dim3(ntl * ntl), dim3(512), 0, st, D, B, Rt, Kmat, Tm, vf_slabs, kcv, F0, ldf0, F, ldf, coef, mu0, mu, info_dev, n_reverts_dev, ctx->bam_mean)
+        ctx->bam_mean_done = ctx->bam_mean.xbar ? 1 : 0;
         if (D % 64 != 0) {
             if (kcv <= 4) { if (n <= 32) UFS(1, 4, true); else UFS(2, 4, true); }
             else { if (n <= 32) UFS(1, GSMVI_MAX_KC, true); else UFS(2, GSMVI_MAX_KC, true); }
