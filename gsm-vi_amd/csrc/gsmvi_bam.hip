@@ -421,15 +421,6 @@ __global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const doubl
             svg[tid] = tid < n ? vg[r] : 0.0;
         }
     }
-    double vgfix = 0.0;
-    if (fx.Dm) {                                       // vg' = vg - Dm t2 (n <= 48: four lanes per row, k = part, part + 4, ...)
-        const int row = tid >> 2, part = tid & 3, rc = row < n ? row : n - 1;
-        double d = 0.0;
-        for (int k = part; k < n; k += 4) d += fx.Dm[(size_t)rc * n + k] * fx.t2[k];
-        d += __shfl_xor(d, 1, 64);
-        d += __shfl_xor(d, 2, 64);
-        vgfix = d;
-    }
     double x[9], vf[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -450,6 +441,23 @@ __global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const doubl
             const int e = tid + 256 * u;
             if (e < n * n) sM1[e] = mv[u];             // [k][r], ld n
         }
+    }
+    double vgfix = 0.0;
+    if (fx.Dm) {                                       // vg' = vg - Dm t2 (n <= 48: four lanes per row; twelve loads in one batch,
+        const int row = tid >> 2, part = tid & 3, rc = row < n ? row : n - 1;   // behind every other load of the prologue)
+        double dv[12], tv[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int k = part + 4 * u, kc = k < n ? k : n - 1;
+            dv[u] = fx.Dm[(size_t)rc * n + kc];
+            tv[u] = fx.t2[kc];
+        }
+        double d = 0.0;
+#pragma unroll
+        for (int u = 0; u < 12; ++u) d += (part + 4 * u < n) ? dv[u] * tv[u] : 0.0;
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        vgfix = d;
     }
     __syncthreads();
     if (fx.Dm) {                                       // (svg is read after the substitution: the barrier below orders it)

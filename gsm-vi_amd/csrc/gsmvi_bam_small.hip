@@ -995,13 +995,16 @@ __global__ __launch_bounds__(512) void k_bam_small48(int n, bam_reg regs, const 
             vg[l] = sc[l];
         }
         if (PAIR) {                                          // t2 = L^-T zg = R^-1 zg: column-oriented back substitution, the lane's
-            double y = (l < n) ? a0 : 0.0;                   // ROW of R read from LDS as the pivots come (i is wave-uniform: v_readlane)
+            double rrow[16 * NB];                            // ROW of R in registers (loaded in one batch: an LDS read per pivot
+#pragma unroll                                               // on the dependent chain cost ~2 us of this kernel)
+            for (int pp = 0; pp < 16 * NB; ++pp) rrow[pp] = E[lc * BAMQ_ES + pp];
+            double y = (l < n) ? a0 : 0.0;
 #pragma unroll
             for (int pp = 16 * NB - 1; pp >= 0; --pp) {
-                if (pp < n) {                                // uniform
+                if (pp < n) {                                // uniform (pp is a compile-time index: v_readlane, static registers)
                     const double ti = readlane_f64(y, pp) * readlane_f64(rinv, pp);
                     if (l == pp) y = ti;
-                    else if (l < pp) y -= E[l * BAMQ_ES + pp] * ti;
+                    else if (l < pp) y -= rrow[pp] * ti;
                 }
             }
             if (l < n) sd.t2[l] = y;
