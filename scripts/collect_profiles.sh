@@ -62,6 +62,7 @@ python3 scripts/fit_kc_ab.py 1024 32 2>&1 | grep -v amdgpu.ids > $OUT/fit_kc_ab.
 python3 scripts/bam_basis_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/bam_basis_ab.txt
 python3 scripts/cov_ab_rounds.py 2>&1 | grep -v amdgpu.ids > $OUT/cov_ab_rounds.txt
 python3 scripts/bam_graph_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/bam_graph_ab.txt
+python3 scripts/gsm_graph_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/gsm_graph_ab.txt
 # factor-form BaM update, orthogonal basis (1) and round-4 basis (0): timed alone (median of event pairs) and back-to-back
 for cfg in "1024 128" "1024 64" "1024 32" "256 8" "4096 64"; do
   for b in 1 0; do

@@ -68,6 +68,7 @@ plain = {
     "cov_persistent_ab.txt": "scripts/cov_p_ab.py",
     "bam_basis_ab.txt": "scripts/bam_basis_ab.py: factor-form BaM update in the orthogonal basis (default) against the round-4 basis",
     "bam_graph_ab.txt": "scripts/bam_graph_ab.py: BaM.fit eager against graph=True (marginal iteration, capture cost)",
+    "gsm_graph_ab.txt": "scripts/gsm_graph_ab.py: GSM.fit eager against graph=True by shape (marginal iteration)",
     "bamf_backtoback.txt": "scripts/bamf_trace.py: factor-form BaM update timed alone and back-to-back, both bases",
     "cov_ab_rounds.txt": "scripts/cov_ab_rounds.py: the dense update's three kernels, this tree against the round-4 library, same box",
     "traffic.json": "HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes + MFMA pipe utilisation",
