@@ -271,6 +271,7 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     else if (!strcmp(name, "gram_mt")) ctx->tune_gram_mt = value > 0 ? value : 4;
     else if (!strcmp(name, "bam_full")) ctx->tune_bam_full = value;
     else if (!strcmp(name, "bam_kenq")) ctx->tune_bam_kenq = value;
+    else if (!strcmp(name, "bam_hint_slack")) ctx->tune_bam_hint_slack = value;
     else if (!strcmp(name, "chain_pair")) ctx->tune_chain_pair = value;
     else if (!strcmp(name, "lowrank_kp")) ctx->tune_lowrank_kp = value;
     else if (!strcmp(name, "bam_basis")) ctx->tune_bam_basis = value;

@@ -1062,8 +1062,12 @@ int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, bam_reg reg, c
     // otherwise; k_bam_ns_tail makes up for a guess that turns out too small
     int kenq = BAMS_KMAX;
     if (hint_host) {                                         // k* + 1 (round 4; + 2 before): a step beyond k* costs two launches,
-        const int h = *reinterpret_cast<volatile int*>(hint_host);   // and k* moves by at most one between neighbouring calls
-        if (h > 0 && h + 1 < BAMS_KMAX) kenq = h + 1;
+        const int h = *reinterpret_cast<volatile int*>(hint_host);   // and k* moves by at most one between neighbouring calls.
+        // (+ 0 measured in round 5, knob "bam_hint_slack": the same update back-to-back gains 2 us -- 442 vs 444 at c4 -- but
+        // a FIT loses 20 us per iteration, 460 vs 440: k* moves with the regulariser and the one-workgroup tail step is slow.)
+        const int slack = ctx->tune_bam_hint_slack;
+        if (h > 0 && h + slack < BAMS_KMAX) kenq = h + slack;
+        if (kenq < 1) kenq = 1;
     }
     if (force_kenq > 0 && force_kenq < BAMS_KMAX) kenq = force_kenq;       // tests: exercise the safety net
     const int nb = (n + 15) / 16;

@@ -88,6 +88,7 @@ struct gsmvi_ctx {
     int tune_no_fast = 0;      // 1 = force the guarded generic kernels (tests)
     int* bam_hint_host = nullptr;       // pinned word: k* of the last device BaM chain (step-count hint, never synchronised on)
     int tune_bam_kenq = 0;     // > 0: enqueue exactly this many multi-workgroup steps (tests of the tail kernel)
+    int tune_bam_hint_slack = 1;   // Newton-Schulz steps enqueued beyond the previous call's k* (round 4: 1; before: 2; 0 measured in round 5)
     int tune_bam_full = 0;     // 1 = always enqueue every Newton-Schulz step (ignore the hint; tests)
     int tune_lowrank_kp = 0;   // 64: BaM's low-rank update stages 64 rows per pass for KF > 96 (A/B runs: measured equal to 32)
     int tune_chain_pair = 1;   // two-level chain (128 < 2B <= 256): independent one-workgroup factorisations share a launch (0: A/B runs)
