@@ -322,213 +322,41 @@ __global__ __launch_bounds__(256) void k_bam_nmat2(int n, int kc, const double* 
     }
 }
 
-// ---- Z = L^-1 (P + M1^T Vf) by substitution, n <= 64 (the n <= 48 sizes whose chain is the one-workgroup k_bam_small48) -------
-// Sixteen lanes per column of D, 16 columns per workgroup.  Lane q of a column group owns rows q, q+16, ...
-// U = L^T is staged in LDS in packed upper form (row p holds L[p..n-1][p], contiguous, so the lanes of a group read
-// consecutive words); pivot p is broadcast inside the group with one shuffle.  T1 = M1^T Vf is formed here: M1 (n x n, [k][r])
-// staged in LDS and the column's Vf values passed round the 16-lane group by shuffles -- n^2 / 16 multiply-adds per lane.
-// -Z goes to rows n..2n-1 of Fs.  (Larger n: k_bam_zw above, a product with the explicit inverse factor.)
-#define BAMF_NMAX 144
-// Orthogonal basis of the factor form (n <= 48, gsmvi_bam_factor_impl): what depends on the chain's L rides in this launch.
-//   prologue of every workgroup:  vg' = vg - Dm t2   (t2 = L^-T zg from k_bam_small48, Dm from its side workgroup; the mean of
-//                                 bam.py:112 needs Zw^T zg = Zt^T zg + Vw^T Pi^T zg and this kernel forms Vw^T vg - Z^T zg)
-//   one more workgroup (the last): Pi = L^-1 Dm^T by forward substitution, sixteen lanes per column (lane q keeps x_k for
-//                                 k = q, q + 16, q + 32 in registers; the row's partial dots meet in a DPP row sum), and the
-//                                 flag of Gvv's factorisation joins the flag of the chain (a dependent draw reverts the update)
+// Orthogonal basis of the factor form with the one-launch chain (n <= 48, gsmvi_bam_factor_impl): what depends on the chain's
+// W = L^-1 rides in k_bam_zw's launch.
+//   prologue of every workgroup:  vg' = vg - Dm t2   (t2 = W^T W a from k_bam_small48, Dm from its side workgroup; the mean of
+//                                 bam.py:112 needs Zw^T zg = Zt^T zg + Vw^T Pi^T zg and the kernel forms Vw^T vg - Z^T zg)
+//   one more workgroup (the last): Pi = W Dm^T (n^3 / 2 multiply-adds from LDS), and the flag of Gvv's factorisation joins the
+//                                 flag of the chain (a dependent draw reverts the update)
 struct bamf_fix {
-    const double* Dm;                  // null: plain substitution (dense form, bam_basis = 0)
+    const double* Dm;                  // null: none of this (dense form, n > 48, bam_basis = 0)
     const double* t2;
-    const double* Ld;                  // n x n lower
     double* Pi;
     int* info;
     const int* info1;
 };
 #define BAMB_SN 48
 #define BAMB_LS 49
-__device__ __forceinline__ void bamf_pi_rider(int n, const bamf_fix& fx, const double* __restrict__ Ldinv, double* Lsm, double* sdi) {
-    constexpr int LS = BAMB_LS, MS = BAMB_SN * BAMB_LS;
-    double* Ms = Lsm + MS;
-    double* Ps = Ms + MS;
+__device__ __forceinline__ void bamf_pi_rider(int n, const bamf_fix& fx, const double* __restrict__ Wt, double* Ws, double* Ms) {
+    constexpr int LS = BAMB_LS;
     const int tid = threadIdx.x;
-    for (int e = tid; e < n * n; e += 256) {
+    for (int e = tid; e < n * n; e += 512) {
         const int i = e / n, j = e - i * n;
-        Lsm[i * LS + j] = fx.Ld[e];
+        Ws[j * LS + i] = Wt[e];                              // Ws[r][k] = W[r][k] = Wt[k][r]
         Ms[i * LS + j] = fx.Dm[e];
     }
-    if (tid < n) sdi[tid] = Ldinv[tid];
     if (tid == 0 && *fx.info == 0 && *fx.info1 != 0) *fx.info = 1000 + *fx.info1;
     __syncthreads();
-    const int grp = tid >> 4, q = tid & 15;
-    for (int j = grp; j < n; j += 16) {                      // Pi[:, j] = L^-1 Dm[j, :]^T
-        double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-        for (int i = 0; i < n; ++i) {
-            double a = 0.0;
-            if (q < i) a += Lsm[i * LS + q] * x0;
-            if (q + 16 < i) a += Lsm[i * LS + q + 16] * x1;
-            if (q + 32 < i) a += Lsm[i * LS + q + 32] * x2;
-            a = row16_sum(a);                                // DPP (pure VALU): a ds_bpermute butterfly put ~500 cycles on every row
-            const double xi = (Ms[j * LS + i] - a) * sdi[i];
-            if ((i & 15) == q) {
-                if (i < 16) x0 = xi; else if (i < 32) x1 = xi; else x2 = xi;
-                Ps[i * LS + j] = xi;
-            }
+    for (int e = tid; e < n * n; e += 512) {                 // Pi[i][j] = sum_{k <= i} W[i][k] Dm[j][k]; four partial sums
+        const int i = e / n, j = e - i * n;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        int k = 0;
+        for (; k + 3 <= i; k += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += Ws[i * LS + k + u] * Ms[j * LS + k + u];
         }
-    }
-    __syncthreads();
-    for (int e = tid; e < n * n; e += 256) fx.Pi[e] = Ps[(e / n) * LS + (e % n)];
-}
-__global__ __launch_bounds__(256) void k_bam_forward16(int D, int n, const double* __restrict__ P,
-                                                       const double* __restrict__ M1,
-                                                       const double* __restrict__ Upk,
-                                                       const double* __restrict__ Ldinv,
-                                                       const double* __restrict__ zg, const double* __restrict__ vg,
-                                                       const double* __restrict__ mu0,
-                                                       const double* __restrict__ xbar, bam_reg regs,
-                                                       double* __restrict__ Ft, double* __restrict__ Fs,
-                                                       double* __restrict__ mu, bamf_fix fx) {
-    const double reg = regs.get();
-    __shared__ __attribute__((aligned(16))) double U[BAMF_NMAX * (BAMF_NMAX + 1) / 2];
-    __shared__ double sdi[BAMF_NMAX], szg[BAMF_NMAX], svg[BAMF_NMAX];
-    __shared__ double sM1[64 * 64];
-    static_assert(3 * BAMB_SN * BAMB_LS <= BAMF_NMAX * (BAMF_NMAX + 1) / 2, "the rider's matrices overlay U");
-    if (fx.Dm && blockIdx.x == (unsigned)((D + 15) / 16)) {      // block-uniform: the workgroup behind the column tiles
-        bamf_pi_rider(n, fx, Ldinv, U, sdi);
-        return;
-    }
-    const int tid = threadIdx.x, c = tid >> 4, q = tid & 15, grp = tid & 48;
-    const int j = blockIdx.x * 16 + c, jc = j < D ? j : D - 1;
-    const int npk = n * (n + 1) / 2;
-    {
-        constexpr int PER = (BAMF_NMAX * (BAMF_NMAX + 1) / 2 + 255) / 256;       // 41
-#pragma unroll
-        for (int it0 = 0; it0 < PER; it0 += 8) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = tid + 256 * (it0 + u);
-                v[u] = Upk[e < npk ? e : npk - 1];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = tid + 256 * (it0 + u);
-                if (e < npk) U[e] = v[u];
-            }
-        }
-        if (tid < BAMF_NMAX) {
-            const int r = tid < n ? tid : n - 1;
-            sdi[tid] = Ldinv[r];
-            szg[tid] = tid < n ? zg[r] : 0.0;
-            svg[tid] = tid < n ? vg[r] : 0.0;
-        }
-    }
-    double x[9], vf[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const int r = q + 16 * i, rc = r < n ? r : n - 1;
-        double a = P[(size_t)rc * D + jc];
-        x[i] = r < n ? a : 0.0;
-        vf[i] = r < n ? Ft[(size_t)rc * D + jc] : 0.0;
-    }
-    {
-        double mv[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int e = tid + 256 * u;
-            mv[u] = M1[e < n * n ? e : n * n - 1];
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int e = tid + 256 * u;
-            if (e < n * n) sM1[e] = mv[u];             // [k][r], ld n
-        }
-    }
-    double vgfix = 0.0;
-    if (fx.Dm) {                                       // vg' = vg - Dm t2 (n <= 48: four lanes per row; twelve loads in one batch,
-        const int row = tid >> 2, part = tid & 3, rc = row < n ? row : n - 1;   // behind every other load of the prologue)
-        double dv[12], tv[12];
-#pragma unroll
-        for (int u = 0; u < 12; ++u) {
-            const int k = part + 4 * u, kc = k < n ? k : n - 1;
-            dv[u] = fx.Dm[(size_t)rc * n + kc];
-            tv[u] = fx.t2[kc];
-        }
-        double d = 0.0;
-#pragma unroll
-        for (int u = 0; u < 12; ++u) d += (part + 4 * u < n) ? dv[u] * tv[u] : 0.0;
-        d += __shfl_xor(d, 1, 64);
-        d += __shfl_xor(d, 2, 64);
-        vgfix = d;
-    }
-    __syncthreads();
-    if (fx.Dm) {                                       // (svg is read after the substitution: the barrier below orders it)
-        if ((tid & 3) == 0 && (tid >> 2) < n) svg[tid >> 2] -= vgfix;
-        __syncthreads();
-    }
-    {                                                  // x += M1^T vf: vf_k lives in lane k & 15 of the group, register k >> 4
-#pragma unroll
-        for (int ik = 0; ik < 4; ++ik) {
-            if (16 * ik >= n) break;                   // uniform
-            for (int qk = 0; qk < 16; ++qk) {
-                const int k = 16 * ik + qk;
-                if (k >= n) break;                     // uniform
-                const double vk = __shfl(vf[ik], (tid & 48) | qk, 64);
-                const double* mrow = sM1 + k * n + q;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = q + 16 * i;
-                    x[i] += (r < n) ? mrow[r < n ? 16 * i : 0] * vk : 0.0;
-                }
-            }
-        }
-    }
-    // forward substitution; the 16 pivots of a block stay a rolled loop (static register index = block)
-#pragma unroll
-    for (int pb = 0; pb < 9; ++pb) {
-        if (16 * pb >= n) break;                                  // uniform
-#pragma unroll 2
-        for (int pq = 0; pq < 16; ++pq) {
-            const int p = 16 * pb + pq;
-            if (p >= n) break;                                    // uniform
-            const double mine = x[pb] * sdi[p];
-            if (q == pq) x[pb] = mine;
-            const double xp = __shfl(mine, grp | pq, 64);
-            // row p of U starts at p*n - p(p-1)/2 and holds columns p..n-1
-            const double* row = U + (p * n - (p * (p - 1)) / 2) - p + q;
-            {
-                const int t = q + 16 * pb;
-                const double uv = row[16 * pb < n - q ? 16 * pb : 0];
-                x[pb] -= (t > p && t < n) ? uv * xp : 0.0;
-            }
-#pragma unroll
-            for (int i = pb + 1; i < 9; ++i) {
-                const int t = q + 16 * i;
-                const double uv = row[t < n ? 16 * i : 0];
-                x[i] -= (t < n) ? uv * xp : 0.0;
-            }
-        }
-    }
-    double dot_z = 0.0, dot_v = 0.0;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const int r = q + 16 * i;
-        if (r < n) {
-            dot_z += x[i] * szg[r];
-            dot_v += vf[i] * svg[r];
-            if (j < D) {
-                Ft[(size_t)(n + r) * D + j] = x[i];
-                Fs[(size_t)(n + r) * D + j] = -x[i];
-            }
-        }
-    }
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) {
-        dot_z += __shfl_xor(dot_z, m, 64);
-        dot_v += __shfl_xor(dot_v, m, 64);
-    }
-    if (q == 0 && j < D) {
-        const double r1 = reg / (1.0 + reg);
-        const double s0g = P[(size_t)(n - 1) * D + j] / sqrt(r1);        // (S0 gbar)_j = P[n-1][j]/sqrt(r1)
-        mu[j] = mu0[j] / (1.0 + reg) + r1 * (s0g + dot_v - dot_z + xbar[j]);
+        for (; k <= i; ++k) a[0] += Ws[i * LS + k] * Ms[j * LS + k];
+        fx.Pi[e] = (a[0] + a[1]) + (a[2] + a[3]);
     }
 }
 
@@ -548,10 +376,15 @@ __global__ __launch_bounds__(512) void k_bam_zw(int D, int n, const double* __re
                                                 const double* __restrict__ Wt, const double* __restrict__ av,
                                                 const double* __restrict__ vg, const double* __restrict__ mu0,
                                                 const double* __restrict__ xbar, bam_reg regs, double* __restrict__ Ft,
-                                                double* __restrict__ Fs, double* __restrict__ mu) {
+                                                double* __restrict__ Fs, double* __restrict__ mu, bamf_fix fx) {
     const double reg = regs.get();
     __shared__ __attribute__((aligned(16))) double Vs[128 * 16], As[128 * 16];
     __shared__ double sav[128], szg[128], svg[128], redz[8 * 4 * 16];
+    if (fx.Dm && blockIdx.x == (unsigned)((D + 15) / 16)) {      // block-uniform: the workgroup behind the column tiles (n <= 48)
+        __shared__ double Prd[2 * BAMB_SN * BAMB_LS];
+        bamf_pi_rider(n, fx, Wt, Prd, Prd + BAMB_SN * BAMB_LS);
+        return;
+    }
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
     const int j0 = blockIdx.x * 16;
     const int nb = (n + 15) >> 4;
@@ -593,9 +426,28 @@ __global__ __launch_bounds__(512) void k_bam_zw(int D, int n, const double* __re
         sav[tid] = tid < n ? av[tid] : 0.0;
         svg[tid] = tid < n ? vg[tid] : 0.0;
     }
+    double vgfix = 0.0;
+    if (fx.Dm) {                                             // vg' = vg - Dm t2 (n <= 48: eight lanes per row, six loads each in one
+        const int row = tid >> 3, part = tid & 7, rc = row < n ? row : n - 1;   // batch behind every other load of the prologue)
+        double dv[6], tv2[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int k = part + 8 * u, kc = k < n ? k : n - 1;
+            dv[u] = fx.Dm[(size_t)rc * n + kc];
+            tv2[u] = fx.t2[kc];
+        }
+        double d = 0.0;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) d += (part + 8 * u < n) ? dv[u] * tv2[u] : 0.0;
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        d += __shfl_xor(d, 4, 64);
+        vgfix = d;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) Vs[tid + 512 * u] = vt[u];
     __syncthreads();
+    if (fx.Dm && (tid & 7) == 0 && (tid >> 3) < n) svg[tid >> 3] -= vgfix;   // (read behind two more barriers)
     if (w < nb) {
         {   // zg[rA] = sum_k W[rA][k] a[k]: this lane holds k = 4 st + ks of its row; the row's four lanes are cc, cc + 16, ...
             double z0 = 0.0, z1 = 0.0;
@@ -892,7 +744,7 @@ int gsmvi_panel_t_product(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
                           int ldm, int mrows, double* Pp, int* kc_out);
 int gsmvi_bam_small_fused_nmax();
 int gsmvi_bam_small_fused(gsmvi_ctx* ctx, hipStream_t st, int n, bam_reg reg, const double* slabs, int kc, int ldslab,
-                          size_t slab_stride, double* M1, double* Ld, double* Upk, int* info_dev, const bamq_side* side);
+                          size_t slab_stride, double* M1, double* Ld, int* info_dev, const bamq_side* side);
 
 #define BAM_NMAT2(KC, NBQ, N_, SL, STR, LDP, N0_, M1_, ND_, G11_)                                                        \
     do {                                                                                                                \
@@ -936,7 +788,7 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     } else if ((rc = gsmvi_panel_t_product(ctx, st, D, n2, P, D, Qt, D, n, ctx->pp, &kc))) return rc;
     double* Nd = Ld + (size_t)n * n + 3 * n;       // n x n
     double* M1T = Nd + (size_t)n * n;              // n x n
-    double* Upk = M1T + (size_t)n * n;             // n(n+1)/2: packed rows of L^T
+    double* Upk = M1T + (size_t)n * n;             // (n(n+1)/2 doubles once used by the substitution kernel: the layout is kept)
     const double* Ldinv = Ld + (size_t)n * n;
     // n <= 48: the whole small chain in ONE one-workgroup launch (k_bam_small48) + the 16-lanes-per-column substitution;
     // 48 < n <= 128 (and n <= 48 under the "bam_full" test knob): slab sums + N (k_bam_nmat2), the multi-workgroup Newton-Schulz
@@ -954,9 +806,9 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     int* info_p = info_dev ? info_dev : ctx->ints + 8;
     int* hint = ctx->tune_bam_full ? nullptr : ctx->bam_hint_host;
     if (fused48) {
-        if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, n, (size_t)n2 * n, M1, Ld, Upk, info_p, nullptr))) return rc;
-        hipLaunchKernelGGL(k_bam_forward16, dim3((D + 15) / 16), dim3(256), 0, st, D, n, P, M1, Upk, Ldinv, Ldinv + n,
-                           Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu, bamf_fix{});
+        if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, n, (size_t)n2 * n, M1, Ld, info_p, nullptr))) return rc;
+        hipLaunchKernelGGL(k_bam_zw, dim3((D + 15) / 16), dim3(512), 0, st, D, n, P, M1, Ld, Ldinv, Ldinv + 2 * n, mu0, xbar,
+                           reg, Ft, Fs, mu, bamf_fix{});
     } else if (use_w) {
         const int nbq = (n + 15) / 16;
         BAM_NMAT2(kc, nbq, n, ctx->pp, (long long)n2 * n, n, N0, M1, Nd, (double*)nullptr);
@@ -965,7 +817,7 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
         // Z = W (P + M1^T Vf) by two chained MFMA products per 16 columns of D, the mean with it (Wt = (L^-1)^T sits in Ld's slot,
         // [a | . | vg] behind it)
         hipLaunchKernelGGL(k_bam_zw, dim3((D + 15) / 16), dim3(512), 0, st, D, n, P, M1, Ld, Ldinv, Ldinv + 2 * n, mu0, xbar,
-                           reg, Ft, Fs, mu);
+                           reg, Ft, Fs, mu, bamf_fix{});
     } else {
         if ((rc = gsmvi_panel_finish(st, n, n2, kc, ctx->pp, nullptr, N0, n))) return rc;
         hipLaunchKernelGGL(k_bam_nmat, dim3((((n + 15) / 16) * ((n + 15) / 16) + 3) / 4), dim3(256), 0, st, n, M1, N0, Nd, M1T);
@@ -1194,14 +1046,14 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
         double* Pi = ctx->basis + 3 * q2;
         double* t2 = ctx->basis;                   // (the T block: T lives in the side workgroup's LDS here)
         const bamq_side side{M1p, Dm, t2, ctx->ints + 10};
-        if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, gcols, (size_t)n2 * gcols, M1, Ld, Upk, info_bam,
+        if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, gcols, (size_t)n2 * gcols, M1, Ld, info_bam,
                                         basis ? &side : nullptr)))
             return rc;
         ctx->chain_pi = basis ? Pi : nullptr;
         ctx->chain_x = basis ? ctx->basis + 4 * q2 : nullptr;
-        const bamf_fix fx = basis ? bamf_fix{Dm, t2, Ld, Pi, info_bam, ctx->ints + 10} : bamf_fix{};
-        hipLaunchKernelGGL(k_bam_forward16, dim3((D + 15) / 16 + (basis ? 1 : 0)), dim3(256), 0, st, D, n, Wq, basis ? M1p : M1, Upk,
-                           Ldinv, Ldinv + n, Ldinv + 2 * n, zerov, zerov, reg, Ft, T1, Ft + (size_t)n2 * D, fx);
+        const bamf_fix fx = basis ? bamf_fix{Dm, t2, Pi, info_bam, ctx->ints + 10} : bamf_fix{};
+        hipLaunchKernelGGL(k_bam_zw, dim3((D + 15) / 16 + (basis ? 1 : 0)), dim3(512), 0, st, D, n, Wq, basis ? M1p : M1, Ld, Ldinv,
+                           Ldinv + 2 * n, zerov, zerov, reg, Ft, T1, Ft + (size_t)n2 * D, fx);
     } else {
         if (!ctx->bam_hint_host) {
             if (hipHostMalloc(reinterpret_cast<void**>(&ctx->bam_hint_host), 64, hipHostMallocMapped) == hipSuccess)
@@ -1255,7 +1107,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
             ctx->chain_x = Pi + q2;
         }
         hipLaunchKernelGGL(k_bam_zw, dim3((D + 15) / 16), dim3(512), 0, st, D, n, Wq, M1z, Ld, Ldinv, Ldinv + 2 * n, zerov, zerov,
-                           reg, Ft, T1, Ft + (size_t)n2 * D);
+                           reg, Ft, T1, Ft + (size_t)n2 * D, bamf_fix{});
     }
     ctx->fo_Rt = Ft;
     ctx->fo_Tm = Tm;

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(1024) void k_bam_ns_tail(int n, int ld, int kenq, d
 // round-5 first form).  Nothing crosses between the two workgroups: the side workgroup reads Gvv and M1 from what the launch
 // BEFORE produced (SRC: the Gram slabs for k_bam_small48, summed in the chain's order so that M1 has the chain's bits; the
 // finished matrices of k_bam_nmat2 for k_bam_ns64).  What depends on the chain's L (Pi = L^-1 Dm^T, the correction of vg)
-// comes later (k_bam_forward16's launch / k_bamf_pi_vg).
+// comes later (k_bam_zw's launch / k_bamf_pi_vg).
 #define BAMQ_SIDE_ES 146
 #define BAMQ_SIDE_LS 65
 #define BAMQ_SIDE_DOUBLES (64 * BAMQ_SIDE_ES + 64 * BAMQ_SIDE_LS)
@@ -715,18 +715,16 @@ __global__ __launch_bounds__(1024) void k_bam_post_big(int n, bam_reg regs, cons
 // MFMA occupies a SIMD for ~107 cycles): only the nb x nb blocks that exist are computed (the round-2 kernel always ran nine
 // waves over a 3 x 3 block grid), dealt to the eight waves so that they spread over the four SIMDs.
 // Slab element (r, c) of slab k: slabs[k * slab_stride + r * ldslab + c], rows 0..n-1 = N0, rows n..2n-1 = M1.
-// Outputs: M1g (n x n finished M1), Ld (n x n lower), Ldinv, zg, vg behind it, Upk (packed rows of R), *info.
+// Outputs: M1g (n x n finished M1), Wt = (L^-1)^T (n x n) in Ld's slot with [a | . | vg] behind it, *info.
 #define BAMQ_SN 48
 #define BAMQ_LD 50
-#define BAMQ_ES 82
-// PAIR: the launch's second workgroup is the side workgroup of the orthogonal basis (bamq_side_body above); wave 0 of the
-// chain adds t2 = L^-T zg behind zg.
+// PAIR: the launch's second workgroup is the side workgroup of the orthogonal basis (bamq_side_body above); the chain
+// adds t2 = W^T W a.
 template <int NB, bool PAIR>
 __global__ __launch_bounds__(512) void k_bam_small48(int n, bam_reg regs, const double* __restrict__ slabs, int kc, int ldslab,
                                                      long long slab_stride, double* __restrict__ M1g,
-                                                     double* __restrict__ Ld, double* __restrict__ Upk,
-                                                     int* __restrict__ info, unsigned long long* __restrict__ stamps,
-                                                     bamq_side sd) {
+                                                     double* __restrict__ Ld, int* __restrict__ info,
+                                                     unsigned long long* __restrict__ stamps, bamq_side sd) {
     const double reg = regs.get();
 #define Q_STAMP(k)                                                                          \
     do {                                                                                    \
@@ -736,7 +734,7 @@ __global__ __launch_bounds__(512) void k_bam_small48(int n, bam_reg regs, const 
     if (stamps && (threadIdx.x & 63) == 0) stamps[8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg(2308);   // HW_ID.SIMD_ID
     constexpr int MSZ = BAMQ_SN * BAMQ_LD;                   // 2400 doubles per matrix
     __shared__ __attribute__((aligned(16))) double sm[7 * MSZ];
-    __shared__ __attribute__((aligned(16))) double scr[CHOLB_SCRATCH_DOUBLES(PAIR ? 1 : 0)];
+    __shared__ __attribute__((aligned(16))) double scr[CHOLB_SCRATCH_DOUBLES(1)];
     __shared__ double coefs[BAMS_KMAX + 4], n0c[BAMQ_SN], sc[BAMQ_SN], av[BAMQ_SN], red[8];
     __shared__ int sh_fail, sh_bad;
     static_assert(BAMQ_SIDE_DOUBLES <= 7 * MSZ, "the side workgroup's matrices overlay sm");
@@ -747,7 +745,6 @@ __global__ __launch_bounds__(512) void k_bam_small48(int n, bam_reg regs, const 
     double* Ms = sm + 4 * MSZ;
     double* M1s = sm + 5 * MSZ;
     double* Nm = sm + 6 * MSZ;
-    double* E = sm + 2 * MSZ;                                // 64 x 82 over Z0, Z1, Ms once the iteration is done (5248 <= 7200)
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
     constexpr int nb = NB, nblocks = NB * NB;              // NB = ceil(n / 16): the block grid is a compile-time shape
     const int nk = (n + 3) >> 2;
@@ -934,14 +931,21 @@ __global__ __launch_bounds__(512) void k_bam_small48(int n, bam_reg regs, const 
         __syncthreads();
     }
     Q_STAMP(3);
-    // BB = N + I/2 + sqrt(s) sym(Y) -> E (upper triangle, identity beyond n), then its Cholesky factor
+    // BB = N + I/2 + sqrt(s) sym(Y) -> EW ([BB | I], upper triangle, identity beyond n), then [R | W], W = R^-T = L^-1.
+    // Round 5: the factor WITH its inverse (chol64_blk's augmented columns, as k_bam_cholw), so that Z = W (P + M1^T Vf) is the
+    // two chained MFMA products of k_bam_zw for n <= 48 too (~8 us) instead of a 16-lanes-per-column substitution (k_bam_forward16,
+    // 19 - 20 us at n = 32).  EW (64 x 146) lies over the iteration's buffers from sm + 0: Y and N are read into registers, then
+    // a barrier, then EW is written.
+    constexpr int EWS = 146;
+    static_assert(64 * EWS <= 7 * MSZ, "EW overlays the iteration's matrices");
+    double* EW = sm;
     {
         const double* Yf = sm + (kstar & 1) * MSZ;
         const double rs = sqrt(s);
         int nan_in = failed ? 1 : 0;
         double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {                        // (E overlays Z and Ms, both dead; Y, Nm are not overlaid)
+        for (int u = 0; u < 8; ++u) {
             const int e = tid + 512 * u, i = e >> 6, j = e & 63;
             const bool in = i < n && j < n;
             double x = (i == j) ? 1.0 : 0.0;
@@ -952,68 +956,59 @@ __global__ __launch_bounds__(512) void k_bam_small48(int n, bam_reg regs, const 
             }
             v[u] = x;
         }
+        __syncthreads();                                     // every read of Y and N is done
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = tid + 512 * u, i = e >> 6, j = e & 63;
-            E[i * BAMQ_ES + j] = v[u];
+            EW[i * EWS + j] = v[u];
         }
         if (nan_in) sh_bad = 1;
     }
     __syncthreads();
     Q_STAMP(4);
-    chol64_blk<BAMQ_ES, false, 0>(E, scr, n, &sh_fail);
+    chol64_blk<EWS, false, 1>(EW, scr, n, &sh_fail);
     Q_STAMP(5);
-    double* Ldinv = Ld + (size_t)n * n;
-    double* zg = Ldinv + n;
-    double* vg = zg + n;
+    // outputs in k_bam_cholw / k_bam_bbav's layout: Wt (n x n, Wt[i][j] = W[j][i]) in Ld's slot, [a | . | vg] behind it
+    double* avo = Ld + (size_t)n * n;
+    double* vg = avo + 2 * n;
     const int bad = sh_bad || sh_fail != 0;
     if (tid == 0) *info = bad;
-    const size_t npk = (size_t)n * (n + 1) / 2;
     if (bad) {                                               // poison: nothing stale may be applied
         const double qn = __longlong_as_double(0x7ff8000000000000LL);
         for (size_t e = tid; e < (size_t)n * n + 3 * n; e += 512) Ld[e] = qn;
-        for (size_t e = tid; e < npk; e += 512) Upk[e] = qn;
+        if (PAIR && tid < n) sd.t2[tid] = qn;
         return;
     }
-    if (w == 0) {                                            // zg = L^-1 a (bam.py:110 applied to gbar), L = R^T: one row per lane,
-        double rcol[16 * NB];                                // the lane's column of R in registers: only shuffle + fma on the chain
-#pragma unroll
-        for (int pp = 0; pp < 16 * NB; ++pp) rcol[pp] = E[pp * BAMQ_ES + l];
-        const int lc = l < n ? l : 0;
-        const double dg = E[lc * BAMQ_ES + lc], rinv = 1.0 / dg;
-        double a0 = (l < n) ? av[l] : 0.0;
-#pragma unroll
-        for (int pp = 0; pp < 16 * NB; ++pp) {
-            if (pp < n) {                                    // uniform
-                const double zk = __shfl(a0 * rinv, pp, 64);
-                a0 = (l == pp) ? zk : ((l > pp) ? __builtin_fma(-rcol[pp], zk, a0) : a0);
+    for (int e = tid; e < n * n; e += 512) {
+        const int i = e / n, j = e - i * n;
+        Ld[e] = (i <= j) ? EW[j * EWS + 64 + i] : 0.0;
+    }
+    if (tid < n) {
+        avo[tid] = av[tid];
+        vg[tid] = sc[tid];
+    }
+    if (PAIR) {                                              // t2 = W^T (W a) for the vg correction (k_bam_zw's prologue): two
+        double* zgs = n0c;                                   // short dot products per thread straight from EW (n0c is dead)
+        if (tid < n) {
+            double z0 = 0.0, z1 = 0.0;
+            int k = 0;
+            for (; k + 1 <= tid; k += 2) {
+                z0 += EW[tid * EWS + 64 + k] * av[k];
+                z1 += EW[tid * EWS + 64 + k + 1] * av[k + 1];
             }
+            if (k <= tid) z0 += EW[tid * EWS + 64 + k] * av[k];
+            zgs[tid] = z0 + z1;
         }
-        if (l < n) {
-            zg[l] = a0;
-            Ldinv[l] = rinv;
-            vg[l] = sc[l];
-        }
-        if (PAIR) {                                          // t2 = L^-T zg = R^-1 zg: column-oriented back substitution, the lane's
-            double rrow[16 * NB];                            // ROW of R in registers (loaded in one batch: an LDS read per pivot
-#pragma unroll                                               // on the dependent chain cost ~2 us of this kernel)
-            for (int pp = 0; pp < 16 * NB; ++pp) rrow[pp] = E[lc * BAMQ_ES + pp];
-            double y = (l < n) ? a0 : 0.0;
-#pragma unroll
-            for (int pp = 16 * NB - 1; pp >= 0; --pp) {
-                if (pp < n) {                                // uniform (pp is a compile-time index: v_readlane, static registers)
-                    const double ti = readlane_f64(y, pp) * readlane_f64(rinv, pp);
-                    if (l == pp) y = ti;
-                    else if (l < pp) y -= rrow[pp] * ti;
-                }
+        __syncthreads();
+        if (tid < n) {
+            double t0 = 0.0, t1 = 0.0;
+            int r = tid;
+            for (; r + 1 < n; r += 2) {
+                t0 += EW[r * EWS + 64 + tid] * zgs[r];
+                t1 += EW[(r + 1) * EWS + 64 + tid] * zgs[r + 1];
             }
-            if (l < n) sd.t2[l] = y;
-        }
-    } else {
-        for (int e = tid - 64; e < n * n; e += 448) {
-            const int i = e / n, j = e - i * n;              // L[i][j] = R[j][i], j <= i
-            Ld[e] = (j <= i) ? E[j * BAMQ_ES + i] : 0.0;
-            if (j >= i) Upk[(size_t)i * n - ((size_t)i * (i - 1)) / 2 - i + j] = E[i * BAMQ_ES + j];
+            if (r < n) t0 += EW[r * EWS + 64 + tid] * zgs[r];
+            sd.t2[tid] = t0 + t1;
         }
     }
     if (stamps && tid == 0) { stamps[6] = __builtin_amdgcn_s_memrealtime(); stamps[7] = (unsigned long long)kstar; }
@@ -1024,11 +1019,11 @@ int gsmvi_bam_small_fused_nmax() { return BAMQ_SN; }
 
 // n <= 48: slabs of [N0; M1] in, everything out (see k_bam_small48)
 int gsmvi_bam_small_fused(gsmvi_ctx* ctx, hipStream_t st, int n, bam_reg reg, const double* slabs, int kc, int ldslab,
-                          size_t slab_stride, double* M1, double* Ld, double* Upk, int* info_dev, const bamq_side* side) {
+                          size_t slab_stride, double* M1, double* Ld, int* info_dev, const bamq_side* side) {
     unsigned long long* stamps = (ctx->tune_cov_dbg & 256)           // diagnostic (scripts/bam48_timeline.py): phase stamps
                                      ? reinterpret_cast<unsigned long long*>(ctx->gram_slabs + (size_t)GSMVI_MAX_KC * ctx->rmax * ctx->rmax)
                                      : nullptr;
-#define SMALL48(NBV, PR) hipLaunchKernelGGL((k_bam_small48<NBV, PR>), dim3(PR ? 2 : 1), dim3(512), 0, st, n, reg, slabs, kc, ldslab, (long long)slab_stride, M1, Ld, Upk, info_dev, stamps, PR ? *side : bamq_side{})
+#define SMALL48(NBV, PR) hipLaunchKernelGGL((k_bam_small48<NBV, PR>), dim3(PR ? 2 : 1), dim3(512), 0, st, n, reg, slabs, kc, ldslab, (long long)slab_stride, M1, Ld, info_dev, stamps, PR ? *side : bamq_side{})
     if (side) { if (n <= 16) SMALL48(1, true); else if (n <= 32) SMALL48(2, true); else SMALL48(3, true); }
     else { if (n <= 16) SMALL48(1, false); else if (n <= 32) SMALL48(2, false); else SMALL48(3, false); }
 #undef SMALL48
