@@ -607,3 +607,26 @@ def test_graph_replayed_bam_fit_is_bit_identical_to_the_eager_fit(D, B, niter):
     assert torch.equal(res[True][0], res[False][0]), float((res[True][0] - res[False][0]).abs().max())
     assert torch.equal(res[True][1], res[False][1]), float((res[True][1] - res[False][1]).abs().max())
     assert res[True][2] == res[False][2]
+
+
+@pytest.mark.parametrize("D,B", [(256, 20), (256, 40), (320, 56), (1024, 64)])
+def test_factor_update_on_the_multi_launch_chain_equals_the_one_workgroup_chains(D, B):
+    """The orthogonal basis' extras ride in the one-workgroup chains' launches for B <= 64 (side workgroup of k_bam_small48 /
+    k_bam_ns64, riders of k_bam_zw); under the "bam_full" test knob the same sizes take the multi-launch chain, where the
+    extras are launches of their own (Gvv's factorisation, T + t2, M1', Pi + vg').  Same update either way (covariance to
+    1e-11; the two chains order their sums differently), same flags."""
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    mu0, F0, Z, X, G = _factor_state(eng, D, B, seed=7 * D + B)
+    dv = [eng.asarray(a) for a in (Z, X, G, mu0, F0)]
+    mu_a, F_a, fl_a = eng.bam_factor_update(*dv, 1.5)
+    mu_a, F_a = mu_a.clone(), F_a.clone()
+    try:
+        eng.set_tuning("bam_full", 1)
+        mu_b, F_b, fl_b = eng.bam_factor_update(*dv, 1.5)
+    finally:
+        eng.set_tuning("bam_full", 0)
+    assert eng.read_flag(fl_a) == 0 and eng.read_flag(fl_b) == 0
+    Sa, Sb = eng.gram(F_a).cpu().numpy(), eng.gram(F_b).cpu().numpy()
+    # (the mean is r1 S gbar + ...: ||S|| ||gbar|| >> the result, as in test_factor_form_update_equals_the_dense_update)
+    assert rel_err(Sa, Sb) < 1e-11 and rel_err(mu_a.cpu().numpy(), mu_b.cpu().numpy()) < 1e-9
