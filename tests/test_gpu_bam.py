@@ -614,7 +614,7 @@ def test_factor_update_on_the_multi_launch_chain_equals_the_one_workgroup_chains
     """The orthogonal basis' extras ride in the one-workgroup chains' launches for B <= 64 (side workgroup of k_bam_small48 /
     k_bam_ns64, riders of k_bam_zw); under the "bam_full" test knob the same sizes take the multi-launch chain, where the
     extras are launches of their own (Gvv's factorisation, T + t2, M1', Pi + vg').  Same update either way (covariance to
-    1e-11; the two chains order their sums differently), same flags."""
+    1e-10; the two chains order their sums differently), same flags."""
     import gsmvi_amd
     eng = gsmvi_amd.get_engine()
     mu0, F0, Z, X, G = _factor_state(eng, D, B, seed=7 * D + B)
@@ -629,4 +629,4 @@ def test_factor_update_on_the_multi_launch_chain_equals_the_one_workgroup_chains
     assert eng.read_flag(fl_a) == 0 and eng.read_flag(fl_b) == 0
     Sa, Sb = eng.gram(F_a).cpu().numpy(), eng.gram(F_b).cpu().numpy()
     # (the mean is r1 S gbar + ...: ||S|| ||gbar|| >> the result, as in test_factor_form_update_equals_the_dense_update)
-    assert rel_err(Sa, Sb) < 1e-11 and rel_err(mu_a.cpu().numpy(), mu_b.cpu().numpy()) < 1e-9
+    assert rel_err(Sa, Sb) < 1e-10 and rel_err(mu_a.cpu().numpy(), mu_b.cpu().numpy()) < 1e-9   # (seen: 3e-12 .. 2e-11 by host BLAS of the inputs)
