@@ -529,11 +529,16 @@ def main():
         value_hot = reps * n_inst / (time.perf_counter() - th)
 
     # ---- roofline of the dominant kernel (covariance update), dispatch-timestamp events --------
+    # Each sample is the LAST of four back-to-back updates on consecutive (HBM-cold) instances: the durations are the kernels'
+    # durations with the device busy, as in the timed region.  (Round 5: a sample per update timed from an idle device --
+    # launch, read the events, launch -- read 10.8 us for the 6.3 us covariance kernel on one box of the pool, whose clocks
+    # drop between the synchronisations, while the replayed region and rocprofv3 of the same run were unchanged.)
     eng.set_profiling(True)
     kt = {"panel": [], "scalars": [], "cov_update": []}
     for k in range(2 * n_inst):
-        it = inst[k % n_inst]
-        eng.gsm_update(it["X"], it["G"], it["mu0"], it["S0"], out=(it["mu"], it["S"]))
+        for q in range(4):
+            it = inst[(4 * k + q) % n_inst]
+            eng.gsm_update(it["X"], it["G"], it["mu0"], it["S0"], out=(it["mu"], it["S"]))
         pr = eng.get_profile()
         if k >= n_inst // 2:
             for key in kt:
@@ -638,8 +643,9 @@ def main():
             eng.set_profiling(True)
             tl = []
             for kk in range(12):
-                it = li[kk % 3]
-                eng.gsm_update(it["X"], it["G"], it["mu0"], it["S0"], out=(it["mu"], it["S"]))
+                for q in range(3):                   # (the last of three back-to-back updates: device busy, see above)
+                    it = li[(3 * kk + q) % 3]
+                    eng.gsm_update(it["X"], it["G"], it["mu0"], it["S0"], out=(it["mu"], it["S"]))
                 if kk >= 3:
                     tl.append(eng.get_profile()["cov_update"])
             eng.set_profiling(False)
