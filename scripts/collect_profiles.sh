@@ -31,11 +31,22 @@ PYBOX
 cd /tmp && export TMPDIR=/tmp
 ARGS="$ROOT/bench.py --steps 420 --warmup 42 --no-cpu-baseline --no-large-point --no-callpath"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS --no-graph > $OUT/pmc_fetch.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS --no-graph > $OUT/pmc_write.log 2>&1
+# (each counter pass up to three times: the profiler's counter tool segfaulted inside a kernel launch once in ~15 passes of
+# this round -- a pass that leaves no counter file is repeated, its first log kept beside the final one)
+pmc_pass() {   # name, counters...
+  local name=$1; shift
+  for try in 1 2 3; do
+    rm -rf $OUT/$name
+    timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $ARGS --no-graph > $OUT/$name.log 2>&1
+    if ls $OUT/$name/*/*counter_collection.csv > /dev/null 2>&1; then break; fi
+    cp $OUT/$name.log $OUT/$name.failed_try$try.log
+  done
+}
+pmc_pass pmc_fetch FETCH_SIZE
+pmc_pass pmc_write WRITE_SIZE
 # MFMA pipe occupancy (north_star: "MFMA utilisation against gfx950 peak"): busy cycles of the matrix pipe and the
 # fp64 MFMA op count, against the time the GPU was active during the dispatch
-timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $ARGS --no-graph > $OUT/pmc_mfma.log 2>&1
+pmc_pass pmc_mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE
 # the >= 0.50 HBM-roofline point of the covariance kernel (D=4096, B=32) and the fit-iteration kernel tables
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_d4096 -- python3 $ROOT/bench.py --D 4096 --B 32 --steps 60 --warmup 12 --no-cpu-baseline --no-callpath > $OUT/trace_d4096.log 2>&1
 for cfg in "1024 32 factor" "1024 32 dense" "4096 64 factor" "256 8 factor" "1024 32 bam" "1024 32 bamf" "1024 128 bam" "1024 128 bamf"; do
