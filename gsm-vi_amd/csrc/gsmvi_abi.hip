@@ -272,6 +272,7 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     else if (!strcmp(name, "bam_full")) ctx->tune_bam_full = value;
     else if (!strcmp(name, "bam_kenq")) ctx->tune_bam_kenq = value;
     else if (!strcmp(name, "bam_hint_slack")) ctx->tune_bam_hint_slack = value;
+    else if (!strcmp(name, "rider_direct_max_D")) ctx->tune_rider_direct_max_D = value;
     else if (!strcmp(name, "chain_pair")) ctx->tune_chain_pair = value;
     else if (!strcmp(name, "lowrank_kp")) ctx->tune_lowrank_kp = value;
     else if (!strcmp(name, "bam_basis")) ctx->tune_bam_basis = value;

@@ -1137,7 +1137,12 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
             rc = gsmvi_factor_signed_back(ctx, st, D, n, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, kcg, 0, 0, 1);
     } else {
         rc = gsmvi_factor_signed_gram(ctx, st, D, n, &kcg, info_dev, &rides);   // Gram slabs of [Vw; Zw]; the 2B x 2B chain rides in ...
-        if (!rc) rc = gsmvi_panel_product_out(ctx, st, D, D, n + 1, Ft + (size_t)n * D, D, nullptr, 1.0, F0, ldf0, nullptr, Tm + (size_t)n * D, D);   // ... this
+        // ... this product; with the chain riding (~35 us on one CU) it is off the critical path: unsplit, finished output, no
+        // finish launch (gsmvi_factor_impl does the same with V Fm)
+        const int kc_user = ctx->tune_panel_kc;
+        if (rides && D >= 1024 && D <= ctx->tune_rider_direct_max_D) ctx->tune_panel_kc = 1;
+        if (!rc) rc = gsmvi_panel_product_out(ctx, st, D, D, n + 1, Ft + (size_t)n * D, D, nullptr, 1.0, F0, ldf0, nullptr, Tm + (size_t)n * D, D);
+        ctx->tune_panel_kc = kc_user;
         const int taken = ctx->px_used;
         ctx->px = gsmvi_panel_extras();
         if (!rc)

@@ -89,6 +89,8 @@ struct gsmvi_ctx {
     int* bam_hint_host = nullptr;       // pinned word: k* of the last device BaM chain (step-count hint, never synchronised on)
     int tune_bam_kenq = 0;     // > 0: enqueue exactly this many multi-workgroup steps (tests of the tail kernel)
     int tune_bam_hint_slack = 1;   // Newton-Schulz steps enqueued beyond the previous call's k* (round 4: 1; before: 2; 0 measured in round 5)
+    int tune_rider_direct_max_D = 2048;   // 1024 <= D <= this: a panel product that carries the chain as its rider runs UNSPLIT (kc = 1,
+                                          // finished output): it is hidden behind the ~35 us chain either way (0: never)
     int tune_bam_full = 0;     // 1 = always enqueue every Newton-Schulz step (ignore the hint; tests)
     int tune_lowrank_kp = 0;   // 64: BaM's low-rank update stages 64 rows per pass for KF > 96 (A/B runs: measured equal to 32)
     int tune_chain_pair = 1;   // two-level chain (128 < 2B <= 256): independent one-workgroup factorisations share a launch (0: A/B runs)

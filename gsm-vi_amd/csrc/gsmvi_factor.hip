@@ -1058,6 +1058,25 @@ int gsmvi_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double
             ctx->px.sj_len = n * n;
             ctx->px.sj_dst = w.Gam1;
         }
+        // The chain rides (~35 us on one CU): the product beside it is off the critical path, so it may as well run UNSPLIT
+        // and write the finished V Fm rows itself (64 workgroups instead of 256, ~3x longer, still hidden) -- the update kernel
+        // then loads 16 KB of finished rows per tile instead of four 16 KB slabs.  Round 5, 1024 <= D <= rider_direct_max_D:
+        // c3 iteration 77.3 -> 75.4 us, D = 2048: 129.4 -> 127.6; below D = 1024 the product is one chunk anyway and the eager
+        // iteration got SLOWER (D = 256: 50 -> 63 us); at D = 4096 the unsplit product would outlast the chain.
+        if (rider && D >= 1024 && D <= ctx->tune_rider_direct_max_D) {
+            const int kc_user = ctx->tune_panel_kc;
+            ctx->tune_panel_kc = 1;
+            ctx->px_used = 0;
+            rc = gsmvi_panel_product_out(ctx, st, D, D, B, w.Rt + (size_t)B * D, D, nullptr, 1.0, F0, ldf0, nullptr,
+                                         w.Tm + (size_t)B * D, D);
+            ctx->tune_panel_kc = kc_user;
+            if (rc) return rc;
+            if (!ctx->px_used) {
+                gsmvi_set_error("%s: %s", "gsmvi_factor_impl", "fast panel kernel expected (internal error)");
+                return GSMVI_ERR_UNSUPPORTED;
+            }
+            return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, w.Gp, kcg, nullptr, 0, 0, 1);
+        }
         if ((rc = gsmvi_panel_product_nc(ctx, st, nullptr, D, D, B, w.Rt + (size_t)B * D, D, nullptr, 1.0, F0, ldf0, ctx->pp,
                                          &kcv)))
             return rc;

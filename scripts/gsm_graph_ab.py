@@ -8,6 +8,8 @@ import _inputs as orc
 shapes = [(256, 8), (512, 16), (1024, 32), (2048, 32), (1024, 64)]
 if len(sys.argv) > 2:
     shapes = [(int(sys.argv[1]), int(sys.argv[2]))]
+for kv in sys.argv[3:]:                                  # name=value tuning knobs (diagnostics)
+    gsmvi_amd.get_engine().set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 for D, B in shapes:
     m, _, P = orc.make_gaussian_target(D, 0)
     tgt = gsmvi_amd.GaussianTarget(m, precision=P)
