@@ -1045,12 +1045,16 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
         double* Dm = ctx->basis + 2 * q2;
         double* Pi = ctx->basis + 3 * q2;
         double* t2 = ctx->basis;                   // (the T block: T lives in the side workgroup's LDS here)
-        const bamq_side side{M1p, Dm, t2, ctx->ints + 10};
+        double* R11s = ctx->early + 128 * 128;     // (the slots the n > 64 path uses for the same block)
+        double* W11s = ctx->early + 2 * 128 * 128;
+        const bamq_side side{M1p, Dm, t2, ctx->ints + 10, R11s, W11s};
         if ((rc = gsmvi_bam_small_fused(ctx, st, n, reg, ctx->pp, kc, gcols, (size_t)n2 * gcols, M1, Ld, info_bam,
                                         basis ? &side : nullptr)))
             return rc;
         ctx->chain_pi = basis ? Pi : nullptr;
         ctx->chain_x = basis ? ctx->basis + 4 * q2 : nullptr;
+        ctx->chain_r11 = (basis && ctx->tune_bam_basis != 3) ? R11s : nullptr;   // (bam_basis = 3: the chain factors Gamma11 itself, A/B)
+        ctx->chain_w11 = (basis && ctx->tune_bam_basis != 3) ? W11s : nullptr;
         const bamf_fix fx = basis ? bamf_fix{Dm, t2, Pi, info_bam, ctx->ints + 10} : bamf_fix{};
         hipLaunchKernelGGL(k_bam_zw, dim3((D + 15) / 16 + (basis ? 1 : 0)), dim3(512), 0, st, D, n, Wq, basis ? M1p : M1, Ld, Ldinv,
                            Ldinv + 2 * n, zerov, zerov, reg, Ft, T1, Ft + (size_t)n2 * D, fx);
@@ -1080,7 +1084,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
         // cross-queue waits cost more than the 50 us of work they hide once both queues are busy.  scripts/bamf_trace.py.)
         const bool side64 = basis && gsmvi_bam_small_one_wg(ctx, n);
         int* info_side = ctx->ints + 10;           // n <= 64: joined to BaM's flag by k_bamf_pi_vg (a dependent draw reverts the update)
-        const bamq_side sd{M1p, Dm, nullptr, info_side};
+        const bamq_side sd{M1p, Dm, nullptr, info_side, nullptr, nullptr};
         // (the magnitude guard of the rank-revealing rule sees this block's own diagonal: the second block's is not known yet)
         const cholw_job beside{n, G11, n, R11, n, W11, n, ctx->ints, 0, 0, nullptr, 0, 0};
         if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_bam,
@@ -1151,6 +1155,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     ctx->fo_Rt = ctx->fo_Tm = ctx->fo_Fs = nullptr;
     ctx->chain_pi = nullptr;
     ctx->chain_x = nullptr;
+    ctx->chain_r11 = ctx->chain_w11 = nullptr;
     const bool mean_done = ctx->bam_mean_done != 0;
     ctx->bam_mean = gsmf_bam_mean{nullptr, nullptr, {0.0, nullptr}};
     ctx->bam_mean_done = 0;

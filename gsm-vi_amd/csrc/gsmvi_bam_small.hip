@@ -324,7 +324,15 @@ __device__ __forceinline__ void bamq_side_body(int n, const SRC& src, double* sm
     chol64_blk<ES, false, 1>(E, scr, n, sh_f);               // (plain rule: dependent draws are a failure, not a drop)
     __syncthreads();
     if (tid == 0) *sd.info1 = *sh_f;
-    for (int e0 = 0; e0 < 64 * 64; e0 += 512 * 4) {          // M1 over R11 (which nobody reads for n <= 64)
+    if (sd.R11) {                                            // for the 2B x 2B chain: its first diagonal block is this one
+        for (int e = tid; e < n * n; e += 512) {
+            const int i = e / n, j = e - i * n;
+            sd.R11[e] = (j >= i) ? E[i * ES + j] : 0.0;
+            sd.W11[e] = (j <= i) ? E[i * ES + 64 + j] : 0.0;
+        }
+        __syncthreads();
+    }
+    for (int e0 = 0; e0 < 64 * 64; e0 += 512 * 4) {          // M1 over R11 (LDS copy: nobody reads it for n <= 64)
         double v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {

@@ -196,25 +196,30 @@ __device__ __forceinline__ void cholb_panel_half(double* E, int k0, int col, boo
     CHOLB_PSTAMP(H, 12);
 }
 
+// k_first > 0 (round 5): the first k_first 16-row panels are GIVEN -- the caller has put the finished rows [R | W] of a
+// BLOCK-DIAGONAL matrix there (no coupling between the given rows and the rest: R12 = 0, W21 = 0) and the factorisation resumes
+// at panel k_first on the untouched trailing block; the augmented columns of the given rows are the caller's.
 template <int ES, bool SEMIDEF, int AUG>
-__device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, int* sh_fail, bool allow_dep = true) {
+__device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, int* sh_fail, bool allow_dep = true,
+                                           int k_first = 0) {
     static_assert(ES % 2 == 0, "rows must stay 16-byte aligned");
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, g = l >> 4;
     const int nblk = (nb + 15) >> 4;
     if (AUG == 1) {
         for (int e = tid; e < 64 * 64; e += 512) {
             const int i = e >> 6, q = e & 63;
-            E[i * ES + 64 + q] = (i == q) ? 1.0 : 0.0;
+            if (i >= 16 * k_first) E[i * ES + 64 + q] = (i == q) ? 1.0 : 0.0;
         }
     }
     if (tid == 0) *sh_fail = 0x7fffffff;
-    if (tid < AUG + 1) *reinterpret_cast<volatile int*>(scratch + tid * CHOLB_SCRATCH_PER_SET + 16 * 64 + 8 * 64 + 16) = 0;
+    if (tid < AUG + 1)                                            // (the publish counter is monotone over the panels: 8 per panel)
+        *reinterpret_cast<volatile int*>(scratch + tid * CHOLB_SCRATCH_PER_SET + 16 * 64 + 8 * 64 + 16) = 8 * k_first;
 #ifdef CHOLB_TEST_FORCE_ORDER
     if (tid == 0) *reinterpret_cast<volatile int*>(scratch + 16 * 64 + 8 * 64 + 17) = 0;
 #endif
     __syncthreads();
 #pragma unroll 1
-    for (int k = 0; k < nblk; ++k) {                              // block-uniform
+    for (int k = k_first; k < nblk; ++k) {                        // block-uniform
         const int k0 = 16 * k;
         CHOLB_STAMP(1 + 2 * k);
         // ---- panel: block row k, columns to the right of (and including) the diagonal block, plus the right-half columns

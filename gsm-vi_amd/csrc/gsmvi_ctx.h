@@ -34,6 +34,8 @@ struct gsmvi_panel_extras {
     unsigned long long* rd_stamps = nullptr;
     const int* rd_prior = nullptr;
     const double* rd_Pi = nullptr;          // jmode 2: the B x B coupling matrix of the orthogonal-basis BaM form (gsmvi_small16.h)
+    const double* rd_R11 = nullptr;         // jmode 2, B % 16 == 0: the finished first diagonal block [R11 | W11] of the chain's Gram
+    const double* rd_W11 = nullptr;         // matrix (B x B each, compact; Gvv's factor from k_bam_small48's side workgroup)
 };
 
 // BaM's regulariser as the kernels take it: by value, or -- so that a captured hipGraph can be replayed with another value
@@ -96,6 +98,8 @@ struct gsmvi_ctx {
     int tune_chain_pair = 1;   // two-level chain (128 < 2B <= 256): independent one-workgroup factorisations share a launch (0: A/B runs)
     gsmf_bam_mean bam_mean = {nullptr, nullptr, {0.0, nullptr}};
     int bam_mean_done = 0;
+    const double* chain_r11 = nullptr;   // [R11 | W11] of Gvv for the one-workgroup 2B x 2B chain (gsmvi_small16.h, jmode 2)
+    const double* chain_w11 = nullptr;
     const double* reg_dev = nullptr;   // gsmvi_bam_set_reg_source: BaM's regulariser is read from here at execution time
     int tune_bam_basis = 1;    // 1 (default) = factor-form BaM in the basis [Vw; Zt], Zt = the part of Zw orthogonal to the whitened draws; 0 = [Vw; Zw]
                                // (round 5: no dependent rows at the fixed point of a Gaussian target); 0 = the
@@ -148,4 +152,6 @@ struct bamq_side {
     double* Dm;                        // n x n: M1 - M1'
     double* t2;                        // n: L^-T zg (written by the CHAIN workgroup: wave 0, behind zg)
     int* info1;                        // 0 or the 1-based failing pivot of Gvv's factorisation (dependent draws)
+    double* R11;                       // n x n each (compact), or null: Gvv's factor and its inverse transpose for the 2B x 2B chain
+    double* W11;
 };

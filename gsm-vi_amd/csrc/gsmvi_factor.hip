@@ -579,9 +579,10 @@ __global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double
                                                       double* __restrict__ Kmat, double* __restrict__ coef,
                                                       int* __restrict__ bad_out,
                                                       unsigned long long* __restrict__ stamps, int jmode,
-                                                      const int* __restrict__ prior_bad, const double* __restrict__ Pi) {
+                                                      const int* __restrict__ prior_bad, const double* __restrict__ Pi,
+                                                      const double* __restrict__ R11g, const double* __restrict__ W11g) {
     __shared__ __attribute__((aligned(16))) double lds[GSMF_SMALL16_LDS];
-    gsmf_small16_body(lds, n, B, Gp, kcg, Kmat, coef, bad_out, stamps, jmode, prior_bad, Pi);
+    gsmf_small16_body(lds, n, B, Gp, kcg, Kmat, coef, bad_out, stamps, jmode, prior_bad, Pi, R11g, W11g);
 }
 
 // ---- K'' = (W S)^T (T - I) (W S), W = Rg^-T, for n > 64: W comes out of the Gram matrix's factorisation itself (k_chol128w /
@@ -1119,6 +1120,8 @@ int gsmvi_factor_signed_gram(gsmvi_ctx* ctx, hipStream_t st, int D, int Bh, int*
         px.rd_stamps = w.stamps;
         px.rd_jmode = ctx->chain_pi ? 2 : 1;       // (2: the orthogonal-basis form, dense J' = S'^T diag(I, -I) S' given by Pi)
         px.rd_Pi = ctx->chain_pi;
+        px.rd_R11 = ctx->chain_pi ? ctx->chain_r11 : nullptr;
+        px.rd_W11 = ctx->chain_pi ? ctx->chain_w11 : nullptr;
         px.rd_prior = ctx->ints + 8;               // the flag of BaM's (B x B) chain
     } else if (*kcg > 1 && n <= 128) {             // (n > 128: no side job -- it would keep the caller's 2B + 1-row product off the
                                                    // 64 x 64-tile kernel, 36 us instead of ~15; k_gsmf_gamma_big sums the slabs itself)
@@ -1292,7 +1295,8 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         Kmat = w.Rg;
         if (!chain_done) {                         // (chain_done: it ran as the rider workgroup of the caller's panel product)
             hipLaunchKernelGGL(k_gsmf_small16, dim3(1), dim3(512), 0, st, n, B, Gp, kcg, Kmat, coef, info_dev, w.stamps, jmode, prior,
-                               jmode == 2 ? ctx->chain_pi : (const double*)nullptr);
+                               jmode == 2 ? ctx->chain_pi : (const double*)nullptr, jmode == 2 ? ctx->chain_r11 : (const double*)nullptr,
+                               jmode == 2 ? ctx->chain_w11 : (const double*)nullptr);
             if ((rc = chk("k_gsmf_small16"))) return rc;
         }
     } else if (n > 128) {

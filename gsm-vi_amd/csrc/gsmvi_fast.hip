@@ -72,7 +72,7 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
     if (RIDER && blockIdx.x == gridDim.x - 1) {                     // block-uniform
         if (blockIdx.y == 0 && blockIdx.z == 0)
             gsmf_small16_body(As, px.rd_n, px.rd_B, px.rd_Gp, px.rd_kcg, px.rd_Kmat, px.rd_coef, px.rd_bad, px.rd_stamps,
-                              px.rd_jmode, px.rd_prior, px.rd_Pi);
+                              px.rd_jmode, px.rd_prior, px.rd_Pi, px.rd_R11, px.rd_W11);
         return;
     }
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;

@@ -60,7 +60,9 @@ __device__ __forceinline__ void gsmf_small16_body(double* __restrict__ lds, int 
                                                   int kcg, double* __restrict__ Kmat, double* __restrict__ coef,
                                                   int* __restrict__ bad_out, unsigned long long* __restrict__ stamps,
                                                   int jmode, const int* __restrict__ prior_bad,
-                                                  const double* __restrict__ Pi = nullptr) {
+                                                  const double* __restrict__ Pi = nullptr,
+                                                  const double* __restrict__ R11g = nullptr,
+                                                  const double* __restrict__ W11g = nullptr) {
 #define SMALL_STAMP(k)                                                                      \
     do {                                                                                    \
         if (stamps && threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memrealtime();        \
@@ -101,6 +103,11 @@ __device__ __forceinline__ void gsmf_small16_body(double* __restrict__ lds, int 
         coef[B + tid] = jmode ? 0.0 : al / (double)B;
     }
     __syncthreads();
+    // jmode 2 with a GIVEN first block (round 5): in the orthogonal basis [Vw; Zt] the Gram matrix is block diagonal (Zt is
+    // orthogonal to the whitened draws by construction; Gamma12 holds rounding only), and its first block Gvv = Vw Vw^T has been
+    // factored already, beside BaM's B x B chain ([R11 | W11], bamq_side_body).  The factorisation below then resumes at row B:
+    // half the pivots of the chain's first 64-pivot factorisation.  B must be a multiple of the 16-row panel.
+    const bool given = jmode == 2 && R11g != nullptr && (B & 15) == 0 && B > 0;
     {   // Gamma = S Gamma1 S^T (upper triangle), S = [[I, 0], [diag(beta), diag(alpha)]]; identity beyond n
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -121,13 +128,20 @@ __device__ __forceinline__ void gsmf_small16_body(double* __restrict__ lds, int 
                     v -= GSMVI_DEP_TOL * v;
                 }
             } else if (i < n && q < n) v = 0.0;
+            if (given && i < B) v = (q < B && q >= i) ? R11g[i * B + q] : 0.0;   // the finished block; Gamma12 = Vw Zt^T is zero
             E1[i * ES1 + q] = v;
+        }
+        if (given) {                                   // W11 (lower) in the augmented columns of the given rows, zeros beside it
+            for (int e = tid; e < B * 64; e += 512) {
+                const int i = e >> 6, q = e & 63;
+                E1[i * ES1 + 64 + q] = (q <= i) ? W11g[i * B + q] : 0.0;
+            }
         }
     }
     __syncthreads();
     SMALL_STAMP(1);
     const bool moderate = sh_moderate != 0;
-    chol64_blk<ES1, true, true>(E1, scr, n, &fail_g, moderate);     // E1 = [Rg | W]
+    chol64_blk<ES1, true, true>(E1, scr, n, &fail_g, moderate, given ? B >> 4 : 0);     // E1 = [Rg | W]
     SMALL_STAMP(2);
     const int w = tid >> 6, l = tid & 63, cc = l & 15, ks = l >> 4;
     const int nblk = (n + 15) >> 4;

@@ -20,7 +20,7 @@ for D, B in ((256, 8), (1024, 32), (1024, 64), (1024, 128), (4096, 64)):
     out = (eng.empty(D), eng.empty(D, D)); flag = eng.new_flag()
     call = lambda: eng.bam_factor_update(Z, X, G, mu0, F0, 1.0, out=out, flag=flag)
     m, P = torch.rand(D, dtype=torch.float64, device=eng.device), None
-    for knob in (1, 0):
+    for knob in (1, 3, 0):                          # 1 = default; 3 = the chain factors Gamma11 itself (round-5 A/B); 0 = round-4 basis
         eng.set_tuning("bam_basis", knob)
         for _ in range(10): call()
         torch.cuda.synchronize()
