@@ -1084,7 +1084,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
         // cross-queue waits cost more than the 50 us of work they hide once both queues are busy.  scripts/bamf_trace.py.)
         const bool side64 = basis && gsmvi_bam_small_one_wg(ctx, n);
         int* info_side = ctx->ints + 10;           // n <= 64: joined to BaM's flag by k_bamf_pi_vg (a dependent draw reverts the update)
-        const bamq_side sd{M1p, Dm, nullptr, info_side, nullptr, nullptr};
+        const bamq_side sd{M1p, Dm, nullptr, info_side, R11, W11};       // ([R11 | W11] also for the 2B x 2B chain: its first block)
         // (the magnitude guard of the rank-revealing rule sees this block's own diagonal: the second block's is not known yet)
         const cholw_job beside{n, G11, n, R11, n, W11, n, ctx->ints, 0, 0, nullptr, 0, 0};
         if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_bam,
@@ -1109,6 +1109,10 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
             M1z = M1p;
             ctx->chain_pi = Pi;
             ctx->chain_x = Pi + q2;
+            if (n <= 64 && ctx->tune_bam_basis != 3) {   // 2B <= 128: the chain takes [R11 | W11] as given (side64: written by the side
+                ctx->chain_r11 = R11;                    // workgroup; else by gsmvi_cholw_small above)
+                ctx->chain_w11 = W11;
+            }
         }
         hipLaunchKernelGGL(k_bam_zw, dim3((D + 15) / 16), dim3(512), 0, st, D, n, Wq, M1z, Ld, Ldinv, Ldinv + 2 * n, zerov, zerov,
                            reg, Ft, T1, Ft + (size_t)n2 * D, bamf_fix{});

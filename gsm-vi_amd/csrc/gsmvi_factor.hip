@@ -779,7 +779,13 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const doub
 template <int KCT>   // compile-time bound of the slab count: every entry of Gamma1 costs KCT loads
 __global__ __launch_bounds__(256) void k_gsmf_gamma_big(int n, int B, const double* __restrict__ Gp, int kcg,
                                                         double* __restrict__ Gam, double* __restrict__ coef,
-                                                        double* __restrict__ ab, int jmode) {
+                                                        double* __restrict__ ab, int jmode,
+                                                        const double* __restrict__ R11g = nullptr,
+                                                        const double* __restrict__ W11g = nullptr,
+                                                        double* __restrict__ Rg = nullptr, double* __restrict__ Wm = nullptr) {
+    // R11g (jmode 2, 2B <= 128; round 5): the Gram matrix is block diagonal in the orthogonal basis and its first block comes
+    // factored ([R11 | W11], B x B compact).  This launch then also lays out everything of Rg and W = Rg^-T that is not the second
+    // diagonal block: the given block and the two zero blocks -- the factorisation that follows takes the second block alone.
     __shared__ double s_alpha[128], s_beta[128];       // B <= 128 (n = 2B <= 256 since round 4)
     const int tid = threadIdx.x;
     auto g1 = [&](int i, int q) {                      // one entry of Gamma1: the kcg slabs, all loads in one batch
@@ -818,6 +824,11 @@ __global__ __launch_bounds__(256) void k_gsmf_gamma_big(int n, int B, const doub
             s_alpha[a] * (s_beta[b] * g1(i, b) + s_alpha[b] * g1(i, q));
     }
     Gam[e] = v;
+    if (R11g && (i < B || q < B)) {
+        const bool first = i < B && q < B;
+        Rg[e] = (first && q >= i) ? R11g[(size_t)i * B + q] : 0.0;
+        Wm[e] = (first && q <= i) ? W11g[(size_t)i * B + q] : 0.0;
+    }
 }
 
 int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
@@ -1306,14 +1317,21 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         // 64 < n <= 128: Gamma, the two n x n Choleskys one workgroup each, W and K in their own kernels
         Kmat = w.Gam;                              // Gamma is dead once Rg exists
         double* Wm = w.Pm;
-        if (kcg <= 4) hipLaunchKernelGGL(k_gsmf_gamma_big<4>, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, w.Gam, coef, coef + n, jmode);
-        else hipLaunchKernelGGL(k_gsmf_gamma_big<GSMVI_MAX_KC>, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, w.Gam, coef, coef + n, jmode);
+        // (jmode 2 with the first diagonal block given: see k_gsmf_gamma_big)
+        const double* R11g = jmode == 2 ? ctx->chain_r11 : nullptr;
+        const double* W11g = jmode == 2 ? ctx->chain_w11 : nullptr;
+        if (kcg <= 4) hipLaunchKernelGGL(k_gsmf_gamma_big<4>, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, w.Gam, coef, coef + n, jmode, R11g, W11g, w.Rg, w.Pm);
+        else hipLaunchKernelGGL(k_gsmf_gamma_big<GSMVI_MAX_KC>, dim3((n * n + 255) / 256), dim3(256), 0, st, n, B, Gp, kcg, w.Gam, coef, coef + n, jmode, R11g, W11g, w.Rg, w.Pm);
         if (fork_vf == 1) {                        // V Fm on the second stream from here on: beside the one-workgroup kernels below
             if ((rc = factor_fork_vf(ctx, st, D, B, Rt, F0, ldf0, &kcv))) return rc;
             vf_slabs = ctx->pp;
         }
         // Gram matrix: semi-definite rule; W = Rg^-T comes out of the same factorisation (no substitution launch)
-        if (n > 64) hipLaunchKernelGGL(k_chol128w<true>, dim3(1), dim3(512), 0, st, n, w.Gam, w.Rg, w.Pm, info_g);
+        if (R11g) {                                // the second diagonal block alone (B <= 64 rows: one 64-pivot job instead of 128 pivots;
+            const size_t o22 = (size_t)B * n + B;  // the magnitude guard still looks at the whole diagonal)
+            hipLaunchKernelGGL((k_cholw_ld<true, false>), dim3(1), dim3(512), 0, st, B, w.Gam + o22, n, w.Rg + o22, n, w.Pm + o22, n,
+                               info_g, 0, 0, w.Gam, n, n + 1);
+        } else if (n > 64) hipLaunchKernelGGL(k_chol128w<true>, dim3(1), dim3(512), 0, st, n, w.Gam, w.Rg, w.Pm, info_g);
         else hipLaunchKernelGGL((k_cholw_ld<true, false>), dim3(1), dim3(512), 0, st, n, w.Gam, n, w.Rg, n, w.Pm, n, info_g, 0, 0,
                                 (const double*)nullptr, 0, 0);           // (n <= 64 comes here only with a dense J': jmode 2)
         // A' = I + Rg J Rg^T, then its plain factorisation T -- the accept / revert test.  (Round 4: the three n x n products of
