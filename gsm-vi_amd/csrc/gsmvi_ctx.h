@@ -101,7 +101,8 @@ struct gsmvi_ctx {
     const double* chain_r11 = nullptr;   // [R11 | W11] of Gvv for the one-workgroup 2B x 2B chain (gsmvi_small16.h, jmode 2)
     const double* chain_w11 = nullptr;
     const double* reg_dev = nullptr;   // gsmvi_bam_set_reg_source: BaM's regulariser is read from here at execution time
-    int tune_bam_basis = 1;    // 1 (default) = factor-form BaM in the basis [Vw; Zt], Zt = the part of Zw orthogonal to the whitened draws; 0 = [Vw; Zw]
+    int tune_bam_basis = 1;    // 1 (default) = factor-form BaM in the basis [Vw; Zt], Zt = the part of Zw orthogonal to the whitened draws; 0 = [Vw; Zw];
+                               // 3 = as 1, but the 2B x 2B chain factors its first diagonal block itself (A/B of the given-block form)
                                // (round 5: no dependent rows at the fixed point of a Gaussian target); 0 = the
                                // round-4 basis [Vw; Zw] (A/B runs)
     double* basis = nullptr;   // workspace of that form: five (R/2)^2 slots -- T, M1', M1 - M1', Pi, X
