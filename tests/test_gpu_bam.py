@@ -630,3 +630,39 @@ def test_factor_update_on_the_multi_launch_chain_equals_the_one_workgroup_chains
     Sa, Sb = eng.gram(F_a).cpu().numpy(), eng.gram(F_b).cpu().numpy()
     # (the mean is r1 S gbar + ...: ||S|| ||gbar|| >> the result, as in test_factor_form_update_equals_the_dense_update)
     assert rel_err(Sa, Sb) < 1e-10 and rel_err(mu_a.cpu().numpy(), mu_b.cpu().numpy()) < 1e-9   # (seen: 3e-12 .. 2e-11 by host BLAS of the inputs)
+
+
+@pytest.mark.parametrize("D,B", [(256, 16), (256, 24), (1024, 32), (512, 40), (1024, 64), (1024, 100), (1024, 128)])
+def test_dependent_draws_never_give_a_wrong_factor_update(D, B):
+    """Two identical whitened draws make Gvv = Vw Vw^T singular (bam.py:31-69 has no problem with a repeated sample; the
+    orthogonal basis inverts Gvv).  What the factor form may do: either the factorisation of Gvv still goes through (a last
+    pivot at rounding level) and the update equals the dense update on the same inputs, or it fails under the plain rule, its
+    flag joins the chain's and the update REVERTS -- (mu, F) = (mu0, F0) bit for bit, the revert counted.  Never a finite wrong
+    answer, on every chain variant, including the ones where the 2B x 2B chain takes Gvv's factor as its own first diagonal
+    block (round 5).  A NaN score always reverts."""
+    import gsmvi_amd
+    eng = gsmvi_amd.get_engine()
+    mu0, F0, Z, X, G = _factor_state(eng, D, B, seed=11 * D + B)
+    S0 = F0.T @ F0
+    for poison in ("draws", "score"):
+        Zp, Xp, Gp = Z.copy(), X.copy(), G.copy()
+        if poison == "draws":
+            Zp[B - 1] = Zp[0]
+            Xp[B - 1] = Xp[0]
+            Gp[B - 1] = Gp[0]
+        else:
+            Gp[B // 2, D // 3] = np.nan
+        dv = [eng.asarray(a) for a in (Zp, Xp, Gp, mu0, F0)]
+        n_rev = eng.new_flag()
+        mu, F, flag = eng.bam_factor_update(*dv, 1.0, n_reverts=n_rev)
+        if eng.read_flag(flag) != 0:
+            assert eng.read_flag(n_rev) == 1
+            assert np.array_equal(mu.cpu().numpy(), mu0) and np.array_equal(F.cpu().numpy(), F0), poison
+        else:
+            assert poison == "draws" and eng.read_flag(n_rev) == 0
+            mu_d, S_d, fd = eng.bam_update(dv[1], dv[2], dv[3], eng.asarray(S0), 1.0, 0.0)
+            assert eng.read_flag(fd) == 0
+            assert rel_err(eng.gram(F).cpu().numpy(), S_d.cpu().numpy()) < 1e-9
+            assert rel_err(mu.cpu().numpy(), mu_d.cpu().numpy()) < 1e-8
+    mu, F, flag = eng.bam_factor_update(*[eng.asarray(a) for a in (Z, X, G, mu0, F0)], 1.0)   # and the clean call is clean again
+    assert eng.read_flag(flag) == 0 and np.isfinite(F.cpu().numpy()).all()
