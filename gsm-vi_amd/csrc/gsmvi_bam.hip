@@ -15,8 +15,9 @@
 // The n x n matrix square root and the n x n Cholesky run on the DEVICE for n <= 129 (gsmvi_bam_small.hip: scaled
 // coupled Newton-Schulz iteration + one-workgroup Cholesky; the reference does this step as a host callback,
 // jax.pure_callback, bam.py:15-22).  Only the square-root term goes through the iteration
-// (N itself enters BB exactly) and BB^-1 is applied by triangular substitution, never as an explicit inverse:
-// with cond(N) ~ 1e7 the explicit-inverse form loses 3 digits.
+// (N itself enters BB exactly) and BB^-1 is applied through its Cholesky factor L -- by triangular substitution for n > 128, as
+// two products with the explicit W = L^-1 (cond(L) = sqrt(cond(BB)) <= ~1e4 on BASELINE config 4) for n <= 128 since round 4 / 5.
+// BB^-1 ITSELF is never formed: with cond(N) ~ 1e7 that form loses 3 digits.
 // Everything of size D runs in HIP kernels; S0 is read twice and S written once.
 #include <cmath>
 
@@ -790,7 +791,7 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     double* M1T = Nd + (size_t)n * n;              // n x n
     double* Upk = M1T + (size_t)n * n;             // (n(n+1)/2 doubles once used by the substitution kernel: the layout is kept)
     const double* Ldinv = Ld + (size_t)n * n;
-    // n <= 48: the whole small chain in ONE one-workgroup launch (k_bam_small48) + the 16-lanes-per-column substitution;
+    // n <= 48: the whole small chain in ONE one-workgroup launch (k_bam_small48) + the product-form Z (k_bam_zw; round 5);
     // 48 < n <= 128 (and n <= 48 under the "bam_full" test knob): slab sums + N (k_bam_nmat2), the multi-workgroup Newton-Schulz
     // steps, BB / Cholesky with the inverse factor (k_bam_bbav, k_bam_cholw) and the product-form Z (k_bam_zw); n > 128: blocked
     // multi-workgroup Cholesky and the generic forward substitution.
@@ -860,7 +861,7 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
 //     Wq = Qt F0^T,  [N0; M1] = [Wq; Vw] Wq^T,  Zw = L^-1 (Wq + M1^T Vw),   S = F0^T (I + Vw^T Vw - Zw^T Zw) F0,
 //   and the factor of M = I + Rt^T J Rt, Rt = [Vw; Zw], J = diag(I, -I) is taken by the SAME 2B x 2B chain as the GSM factor
 //   update (gsmvi_factor.hip, jmode): F = F0 + Rt^T K (Rt F0).  The mean (bam.py:112) needs S gbar = (h F0) with
-//   h = wg + Vw^T (Vw wg) - Zw^T (Zw wg), wg = F0 gbar: the forward-substitution kernel emits r1 h as an extra row of Rt (its
+//   h = wg + Vw^T (Vw wg) - Zw^T (Zw wg), wg = F0 gbar: k_bam_zw emits r1 h as an extra row of Rt (its
 //   "mean" output with mu0 = xbar = 0), which rides through the Rt F0 product.  Four passes over F0 (Wq, Rt F0, and the
 //   read + write of the update), no pass over a covariance.
 // mu = mu0/(1+reg) + r1 (S gbar) + r1 xbar, or mu0 on a reverted update (bam.py:112)
@@ -999,7 +1000,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     double* Qt = ctx->sg;                          // n x D
     double* Wq = Qt + (size_t)n * D;               // n x D      } [Wq; Vw]: left operand of the Gram product
     double* Ft = Wq + (size_t)n * D;               // [Vw; Zw; r1 h]  (2n + 1) x D: Rt of the factor chain + the mean's row
-    double* T1 = Ft + (size_t)(n2 + 1) * D;        // rows n .. 2n-1 hold M1^T Vw, then -Zw (the substitution kernel's Fs)
+    double* T1 = Ft + (size_t)(n2 + 1) * D;        // rows n .. 2n-1 hold -Zw (k_bam_zw's Fs)
     double* Tm = T1 + (size_t)n2 * D;              // (2n + 1) x D = Ft F0
     double* Fsf = Tm + (size_t)(n2 + 1) * D;       // 2n x D: K'' Tm of the generic update path
     double* xbar = Fsf + (size_t)n2 * D;
@@ -1015,12 +1016,12 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     const double* Ldinv = Ld + (size_t)n * n;
     int* info_bam = ctx->ints + 8;
     int kc = 1, rc;
-    // n <= 48: one one-workgroup launch for the small chain + the 16-lanes-per-column substitution; above: the chain of the
+    // n <= 48: one one-workgroup launch for the small chain (k_bam_small48); above: the chain of the
     // dense form (k_bam_nmat2, Newton-Schulz steps, k_bam_bbav, k_bam_cholw) and the product-form Zw (k_bam_zw).
     // Zw = L^-1 (Wq + M1^T Vw); the mean output of either kernel (mu0 = xbar = 0) is r1 (wg + Vw^T vg - Zw^T zg) = r1 h, row 2n of Ft
     // Orthogonal-basis form (round 5, "bam_basis"): Rt = [Vw; Zt] with Zt the part of Zw orthogonal to the whitened draws -- no
     // linearly dependent rows when the fit sits on the fixed point of a Gaussian target.  It needs the explicit
-    // W = L^-1 and Gvv = Vw Vw^T, i.e. the multi-kernel chain also for n <= 48.
+    // W = L^-1 (every chain variant delivers it since round 5) and the factor of Gvv = Vw Vw^T (beside the chain: DESIGN 4.7).
     const bool basis = ctx->tune_bam_basis != 0 && n <= 128 && ctx->basis != nullptr;
     const bool fused48 = n <= gsmvi_bam_small_fused_nmax() && !ctx->tune_bam_full;
 
@@ -1039,7 +1040,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
     } else if ((rc = gsmvi_panel_t_product(ctx, st, D, n2, Wq, D, Wq, D, gcols, ctx->pp, &kc))) return rc;
     if (fused48) {
         // orthogonal basis with the one-launch chain: everything that does not need the chain's L is the launch's second
-        // workgroup (bamq_side), what does rides in the substitution launch (bamf_fix)
+        // workgroup (bamq_side), what does rides in k_bam_zw's launch (bamf_fix)
         const size_t q2 = (size_t)(ctx->rmax / 2) * (ctx->rmax / 2);
         double* M1p = ctx->basis + q2;
         double* Dm = ctx->basis + 2 * q2;

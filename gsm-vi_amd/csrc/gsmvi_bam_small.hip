@@ -716,7 +716,7 @@ __global__ __launch_bounds__(1024) void k_bam_post_big(int n, bam_reg regs, cons
 }
 
 // ---- n <= 48: the WHOLE small chain in one workgroup (round 3) ---------------------------------------------------------
-// From the split-K slabs of the stacked Gram product [N0; M1] to everything the substitution kernel consumes: slab sum,
+// From the split-K slabs of the stacked Gram product [N0; M1] to everything k_bam_zw consumes: slab sum,
 // N = M1^T M1 + sym(N0), the scaled Newton-Schulz iteration (same recurrence, same product order as the multi-workgroup steps), BB, its
 // Cholesky factor (chol64_blk, gsmvi_chol64b.h) and the small outputs -- one launch instead of finish + nmat + iteration +
 // Cholesky (4 launches, 77 + 10 us at n = 32).  fp64 MFMA throughput of ONE CU is the bound of the iteration (a 16x16x4 fp64
