@@ -73,6 +73,9 @@ class HipEngine:
         self._ctx, self._max_D, self._max_B = ctx, newD, newB
         for k, v in self._tuning.items():          # knobs survive a context regrow
             _lib.check("gsmvi_set_tuning", self.lib.gsmvi_set_tuning(self._ctx, k.encode(), int(v)))
+        word = getattr(self, "_reg_word", None)    # ... and so does the regulariser's device source (bam_reg_source): a regrown
+        if word is not None:                       # context that silently fell back to the by-value argument would be WRONG
+            _lib.check("gsmvi_bam_set_reg_source", self.lib.gsmvi_bam_set_reg_source(self._ctx, C.c_void_p(word.data_ptr())))
 
     def release_retired(self):
         """Destroy the contexts a regrow left behind.  Only when no captured graph that used them will be replayed again."""

@@ -580,6 +580,30 @@ def test_regulariser_from_a_device_word_equals_the_by_value_argument(D, B):
         assert torch.equal(a, b)
 
 
+def test_regulariser_source_survives_a_context_regrow():
+    """engine.bam_reg_source is a property of the ENGINE: when a larger problem makes the engine create a new context, the
+    source is re-applied to it (a context that silently fell back to the by-value argument would compute with the dummy)."""
+    import torch
+    import gsmvi_amd
+    from gsmvi_amd.engine import HipEngine
+    eng = HipEngine()                                            # a private engine: its first context is sized by the first call
+    try:
+        mu0, F0, Z, X, G = _factor_state(eng, 64, 8, seed=1)
+        dv = [eng.asarray(a) for a in (Z, X, G, mu0, F0)]
+        eng.bam_factor_update(*dv, 1.0)
+        word = torch.tensor([0.5], dtype=torch.float64, device=dv[0].device)
+        eng.bam_reg_source(word)
+        mu0, F0, Z, X, G = _factor_state(eng, 320, 24, seed=2)   # forces a regrow
+        dv = [eng.asarray(a) for a in (Z, X, G, mu0, F0)]
+        got = [t.clone() for t in eng.bam_factor_update(*dv, 77.0)[:2]]
+        eng.bam_reg_source(None)
+        ref = eng.bam_factor_update(*dv, 0.5)[:2]
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("D,B,niter", [(256, 8, 95), (1024, 32, 79), (129, 6, 70)])
 def test_graph_replayed_bam_fit_is_bit_identical_to_the_eager_fit(D, B, niter):
     """BaM.fit(graph=True) replays blocks of 16 iterations as ONE hipGraph: the draw counter and the regulariser table
