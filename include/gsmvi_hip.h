@@ -365,8 +365,12 @@ int gsmvi_bam_update_sharded_f64(gsmvi_ctx* ctx, void* stream, void* nccl_comm, 
  * covariance is formed and no D x D factorisation is taken: four passes over F0 and a 2B x 2B chain (the one of
  * gsmvi_gsm_factor_update_f64).  Z (B x D) are the whitened draws of the samples: X = mu0 + Z F0 (the caller's contract, as
  * for the GSM factor update).  Needs 2B <= min(D, 256) (GSMVI_ERR_UNSUPPORTED otherwise, before anything is enqueued).
- * *info_dev = 1 and (mu, F) = (mu0, F0) if BaM's B x B matrix function or the 2B x 2B chain failed (non-finite input, or a
- * Sigma that is not positive definite to working precision); *n_reverts_dev (may be NULL) is then incremented.
+ * *info_dev != 0 and (mu, F) = (mu0, F0) if BaM's B x B matrix function or the 2B x 2B chain failed (non-finite input, or a
+ * Sigma that is not positive definite to working precision); *n_reverts_dev (may be NULL) is then incremented.  Since round 5
+ * the update works in the basis [Vw; Zt] (Zt: the part of Zw orthogonal to the whitened draws), which takes the Cholesky factor
+ * of Gvv = Vw Vw^T: LINEARLY DEPENDENT draws (a repeated sample; impossible for i.i.d. normal draws, legal in bam.py) make Gvv
+ * singular -- the update then either still equals the dense one (a last pivot at rounding level) or is reverted with
+ * *info_dev = 1000 + the failing pivot; it never returns a wrong finite result (tests/test_gpu_bam.py).
  */
 int gsmvi_bam_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
                                 const double* Z, int ldz, const double* X, int ldx, const double* G, int ldg,
