@@ -1087,7 +1087,7 @@ int gsmvi_bam_factor_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const do
         int* info_side = ctx->ints + 10;           // n <= 64: joined to BaM's flag by k_bamf_pi_vg (a dependent draw reverts the update)
         const bamq_side sd{M1p, Dm, nullptr, info_side, R11, W11};       // ([R11 | W11] also for the 2B x 2B chain: its first block)
         // (the magnitude guard of the rank-revealing rule sees this block's own diagonal: the second block's is not known yet)
-        const cholw_job beside{n, G11, n, R11, n, W11, n, ctx->ints, 0, 0, nullptr, 0, 0};
+        const cholw_job beside{n, G11, n, R11, n, W11, n, ctx->ints, 0, 0, nullptr, 0, 0, basis ? 1 : 0};
         if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_bam,
                                          ctx->tune_bam_full ? nullptr : ctx->bam_hint_host, ctx->tune_bam_kenq, M1T,
                                          early ? &beside : nullptr, side64 ? &sd : nullptr, G11)))

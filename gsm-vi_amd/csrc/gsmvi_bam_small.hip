@@ -323,6 +323,23 @@ __device__ __forceinline__ void bamq_side_body(int n, const SRC& src, double* sm
     __syncthreads();
     chol64_blk<ES, false, 1>(E, scr, n, sh_f);               // (plain rule: dependent draws are a failure, not a drop)
     __syncthreads();
+    // ... and so are NEARLY dependent ones.  Everything downstream leans on M1 + Gvv M1' = 0 (Zt orthogonal to the draws; the
+    // 2B x 2B chain even takes the Gram matrix as block diagonal), which holds to eps cond(Gvv): for i.i.d. normal draws
+    // cond(Gvv) <= ((sqrt(D) + sqrt(B)) / (sqrt(D) - sqrt(B)))^2 < 40 at 2B <= D, while a caller's almost repeated sample would
+    // buy a silently inaccurate update.  cond(Gvv) >= (max R_ii / min R_ii)^2: beyond 1e8 the factorisation counts as failed
+    // (flag, revert) -- the update then is never less accurate than 1e-8, flagged or not.
+    if (tid < 64) {
+        const double d = tid < n ? E[tid * ES + tid] : 0.0;
+        double dmax = d, dmin = tid < n ? d : 1.7976931348623157e308;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const double a = __shfl_xor(dmax, m, 64), b = __shfl_xor(dmin, m, 64);
+            dmax = a > dmax ? a : dmax;
+            dmin = b < dmin ? b : dmin;
+        }
+        if (tid == 0 && *sh_f == 0 && !(dmin > 1e-4 * dmax)) *sh_f = n;
+    }
+    __syncthreads();
     if (tid == 0) *sd.info1 = *sh_f;
     if (sd.R11) {                                            // for the 2B x 2B chain: its first diagonal block is this one
         for (int e = tid; e < n * n; e += 512) {
@@ -634,8 +651,31 @@ __global__ __launch_bounds__(512) void k_bam_cholw_pair(int n, const double* __r
     const int tid = threadIdx.x;
     if (blockIdx.x == 1) {
         chol128w_core<true, false>(E1, B12, scr, sh_fail, &sh_moderate, g.nb, g.A, g.lda, g.R, g.ldr, g.W, g.ldw, &sh_info);
+        __threadfence_block();
         __syncthreads();
-        if (tid == 0) *g.info = sh_info;
+        // The same guard as bamq_side_body's: the orthogonal basis of the factor form leans on M1 + Gvv M1' = 0, good to
+        // eps cond(Gvv).  Rows the rank-revealing rule DROPPED (exactly repeated draws: zero diagonal) are fine -- the update then
+        // equals the dense one --, an ALMOST repeated draw (kept, tiny pivot) is not: cond(Gvv) >= (max / min R_ii)^2 > 1e8
+        // counts as a failure (5e-6 off without a flag at cond 1e12, measured).
+        __shared__ double gd[2][2];
+        if (tid < 128) {
+            const double d = tid < g.nb ? g.R[(size_t)tid * g.ldr + tid] : 0.0;
+            double dmax = d, dmin = d > 0.0 ? d : 1.7976931348623157e308;
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                const double a = __shfl_xor(dmax, m, 64), b = __shfl_xor(dmin, m, 64);
+                dmax = a > dmax ? a : dmax;
+                dmin = b < dmin ? b : dmin;
+            }
+            if ((tid & 63) == 0) { gd[tid >> 6][0] = dmax; gd[tid >> 6][1] = dmin; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const double dmax = gd[0][0] > gd[1][0] ? gd[0][0] : gd[1][0], dmin = gd[0][1] < gd[1][1] ? gd[0][1] : gd[1][1];
+            int f = sh_info;
+            if (g.cond_guard && f == 0 && !(dmin > 1e-4 * dmax)) f = g.nb;
+            *g.info = f;
+        }
         return;
     }
     chol128w_core<false, true>(E1, B12, scr, sh_fail, &sh_moderate, n, BBg, n, Rg, n, Wt, n, info, &sh_info);

@@ -262,4 +262,5 @@ struct cholw_job {
     int info_off, tol_applied;
     const double* dg;                  // SEMIDEF jobs: diagonal the magnitude guard looks at (dg_n entries, stride dg_stride), or null
     int dg_n, dg_stride;
+    int cond_guard;                    // k_bam_cholw_pair's second job: (max / min R_ii)^2 > 1e8 over the kept rows counts as a failure
 };

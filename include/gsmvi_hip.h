@@ -369,8 +369,9 @@ int gsmvi_bam_update_sharded_f64(gsmvi_ctx* ctx, void* stream, void* nccl_comm, 
  * Sigma that is not positive definite to working precision); *n_reverts_dev (may be NULL) is then incremented.  Since round 5
  * the update works in the basis [Vw; Zt] (Zt: the part of Zw orthogonal to the whitened draws), which takes the Cholesky factor
  * of Gvv = Vw Vw^T: LINEARLY DEPENDENT draws (a repeated sample; impossible for i.i.d. normal draws, legal in bam.py) make Gvv
- * singular -- the update then either still equals the dense one (a last pivot at rounding level) or is reverted with
- * *info_dev = 1000 + the failing pivot; it never returns a wrong finite result (tests/test_gpu_bam.py).
+ * singular -- the update then either still equals the dense one or is reverted with *info_dev != 0; ALMOST dependent draws
+ * (cond(Gvv) > 1e8, estimated from the factor's diagonal) are reverted too, because the basis is orthogonal only to
+ * eps cond(Gvv).  The update never returns a finite result less accurate than ~1e-8 without a flag (tests/test_gpu_bam.py).
  */
 int gsmvi_bam_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
                                 const double* Z, int ldz, const double* X, int ldx, const double* G, int ldg,
