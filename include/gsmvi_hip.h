@@ -71,7 +71,11 @@ int gsmvi_destroy(gsmvi_ctx* ctx);
 /* Launch-heuristic knobs for tests and A/B measurements: "panel_kc" (split-K count of the panel products; <= 0 = auto),
  * "no_fast" (1 = force the guarded generic kernels), "direct_out" (0 = always product + finish pass), "update_sb",
  * "scalars_nt", "bam_full", "bam_kenq", "rider", "wide", "wide_kc", "gram_mt", "fork_min_D", "potrf_split_m", "chain_pair"
- * (0 = one launch per one-workgroup factorisation of the 128 < 2B <= 256 chain); diagnostics "timeline", "cov_dbg"
+ * (0 = one launch per one-workgroup factorisation of the 128 < 2B <= 256 chain); round 5: "bam_basis" (1 = factor-form BaM in
+ * the orthogonal basis [Vw; Zt], default; 0 = the round-4 basis [Vw; Zw]; 3 = as 1 but the 2B x 2B chain factors its first
+ * diagonal block itself), "bam_hint_slack" (Newton-Schulz steps enqueued beyond the previous call's count, default 1),
+ * "rider_direct_max_D" (largest D at which the panel product carrying the chain as its rider runs unsplit, default 2048),
+ * "lowrank_kp" (64 = 64-row staging passes of BaM's low-rank update); diagnostics "timeline", "cov_dbg"
  * (see gsmvi_hip_debug.h). */
 int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value);
 
