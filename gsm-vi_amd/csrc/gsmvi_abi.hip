@@ -158,6 +158,15 @@ static void ws_sizes(int D, int B, size_t* n_pp, size_t* n_sg, size_t* n_small, 
     size_t potrf_scratch = dpad * 64;                          // v1: one factored 64 x 64 block per step
     if (potrf_scratch < 3 * 64 * dpad + 2 * 64 * 64) potrf_scratch = 3 * 64 * dpad + 2 * 64 * 64;   // row buffers + W + X^T blocks
     if (*n_pp < potrf_scratch) *n_pp = potrf_scratch;
+    // the TRANSPOSED panel products (A M^T: BaM's stacked Gram matrices [P; Vf] Qt^T, the factor path's Rt Rt^T) leave kc slabs of
+    // up to R x R doubles, kc <= min(GSMVI_MAX_KC, D / 64): for B >> D that is more than the R x D slabs above (round 5: D = 64,
+    // B = 640 wrote 0.82 M doubles into a 0.66 M slab area and returned a wrong update without a flag -- found by a probe, now a test)
+    {
+        size_t kct = (size_t)(D + 63) / 64;
+        if (kct > GSMVI_MAX_KC) kct = GSMVI_MAX_KC;
+        if (kct < 1) kct = 1;
+        if (*n_pp < kct * (size_t)R * R) *n_pp = kct * (size_t)R * R;
+    }
     *n_sg = (size_t)R * D * 8;                                 // SG + BaM factor panels (the factor-form BaM update holds 10 B + 8 rows)
     // + the device chain of BaM's small matrix function: five padded 144 x 144 iterates, coefficients, BB (n <= 129)
     // + the factor path: a seventh R x R slot (finished Gram matrix) and the split-K slabs of the Gram product (+ 16 stamp words)

@@ -227,11 +227,13 @@ def test_full_form_gap_stays_small_at_moderate_reg(golden):
         assert rel_err(S, Sf) < 1e-6 and rel_err(mu, g[f"{c}/mu_full"]) < 1e-6, c
 
 
-@pytest.mark.parametrize("D,B,reg", [(300, 130, 1.0), (1024, 256, 1.0), (200, 300, 0.5), (512, 400, 2.0)])
+@pytest.mark.parametrize("D,B,reg", [(300, 130, 1.0), (1024, 256, 1.0), (200, 300, 0.5), (512, 400, 2.0), (64, 640, 1.0), (32, 500, 1.0),
+                                     (16, 300, 0.5)])
 def test_batches_beyond_the_one_workgroup_chain(D, B, reg):
     """bam.py:31-69 has no batch bound.  B > 128 takes the multi-workgroup Newton-Schulz steps on an n-sized grid, the
     blocked Cholesky of BB (the D x D path's gsmvi_potrf kernels) and the generic forward substitution; checked against the
-    restatement and the update's defining equation (round 2 returned UNSUPPORTED here)."""
+    restatement and the update's defining equation (round 2 returned UNSUPPORTED here).  B >> D (the last three): the stacked
+    Gram slabs are B-sized, not D-sized -- until round 5 the workspace was not, and (64, 640) returned garbage without a flag."""
     import gsmvi_amd
     orc, borc = _o()
     eng = gsmvi_amd.get_engine()
