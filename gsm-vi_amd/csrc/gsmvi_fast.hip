@@ -220,8 +220,11 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
         const int nwg = gridDim.x * gridDim.y * gridDim.z;
         const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         const int per = (px.sj_len + nwg - 1) / nwg;
-        const int i = wg * per + tid;
-        if (tid < per && i < px.sj_len) {
+        // (round 5: a LOOP over the slice.  With one element per thread a launch of fewer than sj_len / 512 workgroups left the
+        // tail of every slice unsummed -- D < 256 with 2B = 128: 12 - 24 workgroups for 16384 entries -- and the factor update
+        // reported a failure it did not have, on every call: GSM.fit(method="auto") at D = 192, B = 64 reverted every iteration)
+        const int i_end = (wg + 1) * per < px.sj_len ? (wg + 1) * per : px.sj_len;
+        for (int i = wg * per + tid; i < i_end; i += (int)blockDim.x) {
             double t[GSMVI_MAX_KC];
 #pragma unroll
             for (int q = 0; q < GSMVI_MAX_KC; ++q) t[q] = px.sj_src[(size_t)(q < px.sj_kc ? q : px.sj_kc - 1) * px.sj_stride + i];

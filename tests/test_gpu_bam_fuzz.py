@@ -48,3 +48,74 @@ def test_bam_updates_at_random_shapes(D, B):
         assert eng.read_flag(fl) == 0
         S_f = eng.gram(F).cpu().numpy()
         assert rel_err(S_f, S_d.cpu().numpy()) < 1e-8 and rel_err(mu_f.cpu().numpy(), mu_d.cpu().numpy()) < 1e-7, (D, B, reg)
+
+
+@pytest.mark.parametrize("D,B", [(192, 64), (130, 64), (132, 64), (144, 60), (200, 64), (160, 57), (250, 64), (128, 64), (256, 64)])
+def test_factor_forms_at_small_d_with_a_128_row_chain(D, B):
+    """64 < 2B <= 128 at SMALL D: the product beside the chain has few workgroups (D / 16 column strips), and they share the
+    side job that finishes the Gram slabs.  Until round 5 each workgroup summed one element per thread of its slice: with fewer
+    than (2B)^2 / 512 workgroups the slice tails stayed unsummed, and the GSM and BaM factor updates reported a failure they
+    did not have on EVERY call (D = 192, B = 64: GSM.fit(method="auto") reverted every iteration; found by a probe of default
+    fits against dense fits on forced samples).  Both factor forms against their dense forms, from an identity factor (the
+    fit's first iteration) and from a general one."""
+    import gsmvi_amd
+    from oracle import gsm_oracle as orc
+    eng = gsmvi_amd.get_engine()
+    m, _, P = orc.make_gaussian_target(D, D + B)
+    for kind in ("identity", "general"):
+        rs = np.random.RandomState(D + 3 * B)
+        F0 = np.eye(D) if kind == "identity" else rs.standard_normal((D, D)) / np.sqrt(D) + 0.7 * np.eye(D)
+        mu0 = np.zeros(D) if kind == "identity" else rs.standard_normal(D)
+        Z = rs.standard_normal((B, D))
+        X = mu0 + Z @ F0
+        G = orc.gaussian_score(X, m, P)
+        dv = [eng.asarray(a) for a in (Z, X, G, mu0, F0)]
+        S0 = eng.asarray(F0.T @ F0)
+        mu_g, F_g, fl_g = eng.gsm_factor_update(*dv)
+        mu_d, S_d = eng.gsm_update(dv[1], dv[2], dv[3], S0)
+        assert eng.read_flag(fl_g) == 0, kind
+        # (2B close to D with this target's large scores: the basis [Z; U] is nearly singular, cond(Gamma) reaches 1e14 - 1e16 and
+        # the rank-revealing rule drops a row, DESIGN 4.4 -- 1e-7 .. 1e-6 of the result there, BASELINE's bar is 1e-5)
+        tol = 1e-5 if 2 * B >= D - 2 else 1e-6
+        e_s = rel_err(eng.gram(F_g).cpu().numpy(), S_d.cpu().numpy())
+        assert e_s < tol and rel_err(mu_g.cpu().numpy(), mu_d.cpu().numpy()) < 1e-9, (kind, e_s)
+        mu_b, F_b, fl_b = eng.bam_factor_update(*dv, 1.0)
+        mu_bd, S_bd, fl_bd = eng.bam_update(dv[1], dv[2], dv[3], S0, 1.0, 0.0)
+        assert eng.read_flag(fl_b) == 0 and eng.read_flag(fl_bd) == 0, kind
+        assert rel_err(eng.gram(F_b).cpu().numpy(), S_bd.cpu().numpy()) < 1e-8 and rel_err(mu_b.cpu().numpy(), mu_bd.cpu().numpy()) < 1e-7, kind
+
+
+@pytest.mark.parametrize("D,B", [(192, 64), (130, 64), (96, 48), (200, 33)])
+def test_default_fits_follow_the_dense_fits_on_their_own_samples(D, B):
+    """The default fits (method="auto": factor forms here) record their samples; forced into the dense loops (jitter 0 for BaM)
+    both walk the same trajectory -- and in particular do not revert where the dense loop accepts."""
+    import gsmvi_amd
+    from gsmvi_amd.targets import GaussianTarget, device_score
+    from oracle import gsm_oracle as orc
+    m, _, P = orc.make_gaussian_target(D, D + B)
+    tgt = GaussianTarget(m, precision=P)
+    seen = []
+
+    @device_score
+    def lp_g(x):
+        seen.append(x.clone())
+        return tgt.lp_g(x)
+
+    niter = 20
+    sched = lambda i: 100.0 / (1 + i)                            # noqa: E731
+    for cls in ("bam", "gsm"):
+        seen.clear()
+        if cls == "bam":
+            f = gsmvi_amd.BaM(D, None, lp_g)
+            mean_f, cov_f = f.fit(7, sched, batch_size=B, niter=niter, verbose=False)
+            forced = [x.cpu().numpy() for x in seen]
+            mean_d, cov_d = gsmvi_amd.BaM(D, None, tgt.lp_g).fit(7, sched, batch_size=B, niter=niter, verbose=False, jitter=0.0,
+                                                                forced_samples=forced, method="dense")
+        else:
+            f = gsmvi_amd.GSM(D, None, lp_g)
+            mean_f, cov_f = f.fit(7, batch_size=B, niter=niter, verbose=False)
+            forced = [x.cpu().numpy() for x in seen]
+            mean_d, cov_d = gsmvi_amd.GSM(D, None, tgt.lp_g).fit(7, batch_size=B, niter=niter, verbose=False, forced_samples=forced,
+                                                                method="dense")
+        assert f.method_used == "factor" and f.n_reverts == 0, (cls, f.method_used, f.n_reverts)
+        assert rel_err(mean_f, mean_d) < 1e-6 and rel_err(cov_f, cov_d) < 1e-6, cls
