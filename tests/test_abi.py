@@ -75,6 +75,22 @@ def test_abi_version_and_status_strings():
     assert lib.gsmvi_workspace_bytes(0, 1) == 0
 
 
+def test_workspace_covers_the_b_sized_slabs_of_the_transposed_products():
+    """gsmvi_workspace_bytes is a pure function (no GPU): the slab area must hold what the TRANSPOSED panel products leave --
+    kc slabs of up to (2B + 8)^2 doubles, kc <= min(8, D / 64) -- not only the (2B + 8) x D slabs of the plain products.  For
+    B >> D it did not until round 5 (D = 64, B = 640: a wrong BaM update without a flag; tests/test_gpu_bam.py pins it on the
+    GPU, this pins the sizing rule)."""
+    from gsmvi_amd import _lib
+    lib = _lib.load_library()
+    for D in (2, 16, 64, 100, 256, 1024, 4096):
+        for B in (1, 8, 32, 128, 300, 640):
+            R = 2 * B + 8
+            kct = max(1, min(8, (D + 63) // 64))
+            assert lib.gsmvi_workspace_bytes(D, B) >= 8 * (kct * R * R + 8 * R * D), (D, B)
+    # monotone in both arguments (the engine regrows by comparing sizes)
+    assert lib.gsmvi_workspace_bytes(1024, 64) >= lib.gsmvi_workspace_bytes(1024, 32) >= lib.gsmvi_workspace_bytes(512, 32)
+
+
 def test_bad_arguments_are_rejected_without_a_gpu():
     from gsmvi_amd import _lib
     lib = _lib.load_library()
