@@ -44,7 +44,7 @@ def wrap_score(eng, lp_g, D):
         return padded_builtin(D + 1)
     if native:
         def g(Xp, out=None):
-            G = lp_g(Xp[:, :D])
+            G = lp_g(Xp[:, :D].contiguous())        # (round-5 advice) a contiguous, 16-byte aligned (B, D) tensor like every even-D fit hands over
             Gp = eng.zeros(Xp.shape[0], D + 1) if out is None else out
             Gp[:, :D] = G
             if out is not None:

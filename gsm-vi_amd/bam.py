@@ -4,7 +4,7 @@ import numpy as np
 import torch
 
 from .engine import get_engine
-from .gsm import _legacy_mvn, _is_torch
+from .gsm import _legacy_mvn, _is_torch, _host_draw
 
 
 def bam_lowrank_update(samples, vs, mu0, S0, reg, engine=None, jitter=0.0):
@@ -229,7 +229,7 @@ class BaM:
                             Z = Zblk[ndraw % KB]
                             ndraw += 1
                         else:
-                            Z = eng.normal_from_host(rs.standard_normal((B, D)))
+                            Z = eng.normal_from_host(_host_draw(rs, B, D, self._zc))
                             if self._zc is not None:
                                 Z[:, self._zc:] = 0.0
                         X = eng.sample(Z[lo:hi], mean_t, R, out=Xbuf)     # only this rank's rows when sharded
@@ -460,7 +460,7 @@ class BaM:
                             Z = Zblk[ndraw % KB]
                             ndraw += 1
                         else:
-                            Z = eng.normal_from_host(rs.standard_normal((B, D)))
+                            Z = eng.normal_from_host(_host_draw(rs, B, D, self._zc))
                             if self._zc is not None:
                                 Z[:, self._zc:] = 0.0
                         X = eng.sample(Z[lo:hi], mu_a, F_a, out=Xbuf)          # only this rank's rows when sharded

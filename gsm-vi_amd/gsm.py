@@ -66,6 +66,17 @@ def _legacy_mvn(rs, mean, cov, size):
     return mean + z @ (np.sqrt(s)[:, None] * vt)
 
 
+def _host_draw(rs, B, D, zc):
+    """(B, D) standard normals from the host stream (rng="numpy": the reference's z-stream, gsm_numpy.py:105,116).  In the padded
+    fit of an odd-D problem (zc = the literal D, _oddpad.py) the stream is drawn at the LITERAL width and the inert columns are
+    zeros, so a seed gives the same draws as the literal-D problem (round-5 advice: it drew (B, D + 1) and shifted the stream)."""
+    if zc is None:
+        return rs.standard_normal((B, D))
+    z = np.zeros((B, D))
+    z[:, :zc] = rs.standard_normal((B, zc))
+    return z
+
+
 class GSM:
     """Wrapper class for using GSM updates to fit a distribution (gsmvi/gsm_numpy.py:60-75,
     gsmvi/gsm.py:62-77).
@@ -239,7 +250,7 @@ class GSM:
                             Zblk[:, :, self._zc:] = 0.0                  # inert coordinates of an odd-D fit (_oddpad.py)
                     Z = Zblk[i % KB]
                 else:
-                    Z = eng.normal_from_host(rs.standard_normal((B, D)))
+                    Z = eng.normal_from_host(_host_draw(rs, B, D, self._zc))
                     if self._zc is not None:
                         Z[:, self._zc:] = 0.0
                 X = eng.sample(Z, mean_t, R, out=Xbuf)
@@ -418,7 +429,7 @@ class GSM:
                 if monitor is not None and j % monitor.checkpoint == 0:
                     monitor(j, state(), self.lp, key, nevals=nevals)
                     nevals = 0
-                Zi = Zblk[j - i] if dev_rng else eng.normal_from_host(rs.standard_normal((B, D)))
+                Zi = Zblk[j - i] if dev_rng else eng.normal_from_host(_host_draw(rs, B, D, self._zc))
                 if not dev_rng and self._zc is not None:
                     Zi[:, self._zc:] = 0.0
                 iteration(Zi, a)

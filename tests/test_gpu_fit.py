@@ -206,3 +206,24 @@ def test_replayed_draw_launch_advances_through_the_stream():
             ref = eng.normal(B, D, seed, i0 + KB * rep + c)
             assert torch.equal(Z[c], ref), (rep, c)
         assert int(ctr[0].item()) == i0 + KB * (rep + 1)
+
+
+@pytest.mark.parametrize("keep", ["array", "view"])
+def test_host_score_arrays_kept_by_the_callable_are_never_overwritten(keep):
+    """Round-5 advice: a host lp_g that KEEPS its argument (a recording wrapper) or a view of it must find it unchanged later --
+    the pinned pool of HipEngine.host_score reuses an array only when nobody else holds it (gsm_numpy.py:116-117 hands the
+    callable a fresh array every iteration)."""
+    import gsmvi_amd
+    held, copies = [], []
+
+    def lp_g(x):
+        held.append(x if keep == "array" else x[:, :3])
+        copies.append(held[-1].copy())
+        return -2.0 * (x - 0.5)
+
+    gsm = gsmvi_amd.GSM(8, None, lp_g)
+    gsm.fit(3, niter=9, batch_size=2, verbose=False)
+    assert len(held) == 10
+    for a, c in zip(held, copies):
+        assert np.array_equal(a, c)
+    assert len({a.__array_interface__["data"][0] for a in held}) == 10      # ten distinct buffers

@@ -257,3 +257,24 @@ def test_odd_d_fits_run_padded_and_converge(eng, D, B):
         path = eng.last_path()
         assert bam.padded_dim == D + 1 and bam.method_used == method and not _generic(path), (method, path)
         assert rel_err(mb, m) < 1e-3 and rel_err(cb, cov_t) < 1e-2, method
+
+
+@pytest.mark.parametrize("method", ["dense", "factor"])
+def test_odd_d_host_stream_is_the_literal_problems_stream(eng, method):
+    """Round-5 advice (_oddpad.py): with rng="numpy" the padded (D + 1)-dimensional fit of an odd-D problem draws its host normals
+    at the LITERAL width, so the first samples of key k are RandomState(k).standard_normal((B, D)) like the literal-D problem's
+    (mean 0, cov I: x = z) -- not a (B, D + 1) draw that shifts the stream.  The device score also gets a contiguous tensor."""
+    import gsmvi_amd
+    from gsmvi_amd.targets import device_score
+    D, B, key = 7, 2, 11
+    seen = []
+
+    @device_score
+    def lp_g(x):
+        assert x.is_contiguous() and x.shape == (B, D)
+        seen.append(x.clone())
+        return -2.0 * (x - 0.5)
+
+    gsmvi_amd.GSM(D, None, lp_g).fit(key, niter=2, batch_size=B, verbose=False, rng="numpy", method=method)
+    rs = np.random.RandomState(key)
+    assert rel_err(seen[0].cpu().numpy(), rs.standard_normal((B, D))) < 1e-15

@@ -233,3 +233,21 @@ def test_fit_factor_method_converges_and_keeps_cadence(golden):
     assert calls == [(0, 1), (100, 200), (200, 200), (300, 200), (400, 200), (500, 200), (500, 2)]
     with pytest.raises(AssertionError):
         GSM(4, None, lambda x: x, engine=OracleEngine()).fit(0, niter=1, batch_size=4, verbose=False, method="factor")
+
+
+def test_host_score_pool_never_hands_out_an_array_somebody_kept():
+    """Round-5 advice (engine.py host_score): the pinned samples array given to a host lp_g is reused only when nobody outside
+    the pool holds it -- a recording callable, or a retained VIEW (x[:, :k], whose .base is the array), keeps it out of reuse."""
+    from gsmvi_amd.engine import _unheld_entry
+    pool = [(object(), np.zeros((4, 6))) for _ in range(3)]
+    assert _unheld_entry(pool) is pool[0]                     # nobody holds anything: the first entry is free
+    kept = pool[0][1]                                         # a recording wrapper keeps its argument
+    assert _unheld_entry(pool) is pool[1]
+    view = pool[1][1][:, :2]                                  # ... another one keeps only a view of it
+    assert _unheld_entry(pool) is pool[2]
+    also = pool[2][1]
+    assert _unheld_entry(pool) is None                        # all held: host_score allocates a fresh array
+    del kept
+    assert _unheld_entry(pool) is pool[0]
+    del view, also
+    assert _unheld_entry(pool) is pool[0]
