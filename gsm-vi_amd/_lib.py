@@ -78,6 +78,7 @@ _SIGS = {
                                            _c_dp, C.c_int, _c_dp, C.c_int]),
     "gsmvi_potrf_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int, _c_dp]),
     "gsmvi_gram_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int]),
+    "gsmvi_gram_shift_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_dp, C.c_int, C.c_double, _c_dp, _c_dp, C.c_int]),
     "gsmvi_whiten_rows_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int,
                                         _c_dp, _c_dp, C.c_int, _c_dp]),
     "gsmvi_sample_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, _c_dp,

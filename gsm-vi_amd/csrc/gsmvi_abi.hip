@@ -44,7 +44,7 @@ bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, cons
 int gsmvi_panel_fast_chunk(int MT);
 int gsmvi_potrf_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                      int* info_dev);
-int gsmvi_gram_impl(hipStream_t st, int D, const double* F, int ldf, double* C, int ldc);
+int gsmvi_gram_impl(hipStream_t st, int D, const double* F, int ldf, double* C, int ldc, double shift, const double* shift_dev);
 int gsmvi_whiten_impl(hipStream_t st, int D, int nrows, const double* R, int ldr, const double* X, int ldx,
                       const double* mu, double* Z, int ldz, double* logdiag);
 int gsmvi_factor_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz, const double* X,
@@ -713,7 +713,16 @@ int gsmvi_gram_f64(gsmvi_ctx* ctx, void* stream, int D, const double* F, int ldf
     BAD_ARG(!ctx || !F || !C, "NULL argument");
     BAD_ARG(D <= 0 || ldf < D || ldc < D, "bad size");
     BAD_ARG(F == C, "output must not alias the input");
-    return gsmvi_gram_impl(reinterpret_cast<hipStream_t>(stream), D, F, ldf, C, ldc);
+    return gsmvi_gram_impl(reinterpret_cast<hipStream_t>(stream), D, F, ldf, C, ldc, 0.0, nullptr);
+}
+
+int gsmvi_gram_shift_f64(gsmvi_ctx* ctx, void* stream, int D, const double* F, int ldf, double shift, const double* shift_dev,
+                         double* C, int ldc) {
+    BAD_ARG(!ctx || !F || !C, "NULL argument");
+    BAD_ARG(D <= 0 || ldf < D || ldc < D, "bad size");
+    BAD_ARG(F == C, "output must not alias the input");
+    BAD_ARG(!(shift == shift), "shift is NaN");
+    return gsmvi_gram_impl(reinterpret_cast<hipStream_t>(stream), D, F, ldf, C, ldc, shift, shift_dev);
 }
 
 int gsmvi_whiten_rows_f64(gsmvi_ctx* ctx, void* stream, int D, int nrows, const double* R, int ldr, const double* X,

@@ -731,6 +731,170 @@ __global__ __launch_bounds__(512) void k_gsm_cov_sym_p(int D, int B, double invB
         for (int k = 0; k < SB / 8; ++k) dmuv[k] = dmun[k];
     }
 }
+
+// =====================================================================================
+// k_gsm_cov_sym for ANY batch size (round 6; until then B <= 128 only and B = 130 fell to the guarded kernel of
+// gsmvi_kernels.hip).  Same items, same tile layout, same store path as k_gsm_cov_sym; the samples come in a RUN-TIME loop of
+// 32-sample passes instead of SB / 32 compile-time passes over registers loaded up front:
+//   * the six record tiles of a pass are exactly one 16-byte unit per thread and tile (32 samples x 16 units = 512);
+//   * two register sets (even / odd passes): the loads of pass p + 2 are issued as soon as pass p has gone to LDS, so they fly
+//     during two passes of operand reads and MFMAs (~1 us each on a CU: 16 fp64 MFMAs per wave, two waves per SIMD);
+//   * LDS-only barriers (s_waitcnt lgkmcnt(0); s_barrier) as in the persistent form: __syncthreads() would drain the prefetch;
+//   * sample rows b >= B of the last pass are clamped re-reads staged as zeros; edge tiles (D % 32 != 0) as RAG = true above.
+// MFMA-bound (2 B D^2 flop on the upper triangle: 1.07 GFLOP at D = 1024, B = 512 against 17 MB of covariance), one item per
+// workgroup; the mean's dmu tile rides in the same passes on the diagonal workgroups.
+// =====================================================================================
+__global__ __launch_bounds__(512) void k_gsm_cov_sym_big(int D, int B, double invB, const double* __restrict__ rec, int ldrec,
+                                                         const double* __restrict__ mu0,
+                                                         const double* __restrict__ S0, int lds0,
+                                                         double* __restrict__ S, int lds,
+                                                         double* __restrict__ mu_out) {
+    constexpr int RS = 48;
+    constexpr int TILE = 32 * RS;
+    __shared__ __attribute__((aligned(16))) double smem[6 * TILE];
+    const int nt = (D + 31) >> 5;
+    const int n_two = ((nt >> 1) * ((nt + 1) >> 1));
+    int ti, tj0;
+    bool two;
+    if ((int)blockIdx.x < n_two) {
+        int rem = blockIdx.x;
+        ti = 0;
+        for (;;) {
+            const int inrow = (nt - ti) >> 1;
+            if (rem < inrow) break;
+            rem -= inrow;
+            ++ti;
+        }
+        tj0 = ti + ((nt - ti) & 1) + 2 * rem;
+        two = true;
+    } else {
+        const int k = blockIdx.x - n_two;
+        ti = ((nt & 1) ? 0 : 1) + 2 * k;
+        tj0 = ti;
+        two = false;
+    }
+    const bool diag = (tj0 == ti);
+    const int I0 = ti * 32, J0 = tj0 * 32;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+    const int t = w >> 2;
+    const int wr = (w >> 1) & 1, wc = w & 1;
+    const bool mine = (t == 0) || two;
+    const int Jt = J0 + 32 * ((t == 1 && two) ? 1 : 0);
+    const int tl = tid & 255;
+    v2d s0v[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int unit = q * 256 + tl, i = unit >> 4, j2 = unit & 15;
+        const int gr = (I0 + i >= D) ? D - 1 : I0 + i, gc = (Jt + 2 * j2 >= D) ? D - 2 : Jt + 2 * j2;
+        s0v[q] = *reinterpret_cast<const v2d*>(S0 + (size_t)gr * lds0 + gc);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int npass = (B + 31) >> 5;
+    const int sb = tid >> 4, sc2 = 2 * (tid & 15);               // this thread's unit of every tile: sample row, column pair
+    const int dcol = (I0 + (tid & 31) >= D) ? D - 1 : I0 + (tid & 31);
+    auto issue = [&](int pass, v2d (&sg)[6], double (&dm)[4]) {
+        const int bb = pass * 32 + sb;
+        const double* rp = rec + (size_t)(bb < B ? bb : B - 1) * ldrec;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int colbase = (q < 2) ? I0 : (J0 + ((q >= 4 && two) ? 32 : 0));
+            const int colc = (colbase + sc2 >= D) ? D - 2 : colbase + sc2;
+            sg[q] = (two || q < 4) ? *reinterpret_cast<const v2d*>(rp + (q & 1) * D + colc) : (v2d){0.0, 0.0};
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dm[k] = 0.0;
+        if (diag && tid < 256) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int b = pass * 32 + (tid >> 5) + 8 * k;
+                dm[k] = rec[(size_t)(b < B ? b : B - 1) * ldrec + 2 * D + dcol];
+            }
+        }
+    };
+    v4d accd = {0.0, 0.0, 0.0, 0.0}, acce = {0.0, 0.0, 0.0, 0.0};
+    double dmu_part = 0.0;
+    auto do_pass = [&](int pass, v2d (&sg)[6], double (&dm)[4]) {
+        if (pass > 0) LDS_BARRIER();                             // the previous pass's operand reads are done
+        const bool live = pass * 32 + sb < B;
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+            if (two || q < 4) *reinterpret_cast<v2d*>(smem + q * TILE + sb * RS + sc2) = live ? sg[q] : (v2d){0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dmu_part += (pass * 32 + (tid >> 5) + 8 * k < B) ? dm[k] : 0.0;
+        LDS_BARRIER();
+        if (pass + 2 < npass) issue(pass + 2, sg, dm);           // this register set is free: two passes ahead
+        if (mine) {
+            double ad[8], ae[8], bd[8], be[8];
+            const double* adp = smem + ks * RS + 16 * wr + c;
+            const double* aep = adp + TILE;
+            const double* bdp = smem + (2 + 2 * t) * TILE + ks * RS + 16 * wc + c;
+            const double* bep = bdp + TILE;
+#pragma unroll
+            for (int sI = 0; sI < 8; ++sI) {
+                ad[sI] = adp[4 * sI * RS];
+                ae[sI] = aep[4 * sI * RS];
+                bd[sI] = bdp[4 * sI * RS];
+                be[sI] = bep[4 * sI * RS];
+            }
+#pragma unroll
+            for (int sI = 0; sI < 8; ++sI) {
+                accd = GSMVI_MFMA_F64(ad[sI], bd[sI], accd);
+                acce = GSMVI_MFMA_F64(ae[sI], be[sI], acce);
+            }
+        }
+    };
+    v2d stgA[6], stgB[6];
+    double dmA[4], dmB[4];
+    issue(0, stgA, dmA);
+    if (npass > 1) issue(1, stgB, dmB);
+    for (int pass = 0; pass < npass; pass += 2) {
+        do_pass(pass, stgA, dmA);
+        if (pass + 1 < npass) do_pass(pass + 1, stgB, dmB);
+    }
+    // ---- stores: as k_gsm_cov_sym (update tile through LDS, S0 added in store layout, mirror by columns) ----
+    LDS_BARRIER();
+    double* LW = smem + t * 32 * 33;
+    if (mine) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) LW[(16 * wr + ks + 4 * r) * 33 + 16 * wc + c] = (accd[r] - acce[r]) * invB;
+    }
+    LDS_BARRIER();
+    if (mine) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int unit = q * 256 + tl, i = unit >> 4, j2 = unit & 15;
+            v2d wv2;
+            wv2.x = s0v[q].x + LW[i * 33 + 2 * j2];
+            wv2.y = s0v[q].y + LW[i * 33 + 2 * j2 + 1];
+            if (I0 + i < D && Jt + 2 * j2 < D) *reinterpret_cast<v2d*>(S + (size_t)(I0 + i) * lds + Jt + 2 * j2) = wv2;
+            LW[i * 33 + 2 * j2] = wv2.x;
+            LW[i * 33 + 2 * j2 + 1] = wv2.y;
+        }
+    }
+    const bool need = mine && !(t == 0 && diag);
+    LDS_BARRIER();
+    if (need) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int unit = q * 256 + tl, j = unit >> 4, i2 = unit & 15;
+            v2d m2;
+            m2.x = LW[(2 * i2) * 33 + j];
+            m2.y = LW[(2 * i2 + 1) * 33 + j];
+            if (Jt + j < D && I0 + 2 * i2 < D) *reinterpret_cast<v2d*>(S + (size_t)(Jt + j) * lds + I0 + 2 * i2) = m2;
+        }
+    }
+    if (diag) {
+        LDS_BARRIER();
+        if (tid < 256) smem[tid] = dmu_part;
+        LDS_BARRIER();
+        if (tid < 32) {
+            double sm_ = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sm_ += smem[q * 32 + tid];
+            if (I0 + tid < D) mu_out[I0 + tid] = mu0[I0 + tid] + sm_ * invB;
+        }
+    }
+}
 #undef LDS_BARRIER
 
 // ---- launch helpers ------------------------------------------------------------------------
@@ -808,7 +972,12 @@ bool gsmvi_launch_gsm_cov_sym(hipStream_t st, hipEvent_t* ev, int D, int B, cons
     // actual B and 1/B at run time -- rows b >= B are staged as zeros (they add nothing to either accumulator chain), so
     // B = 20 runs the SB = 32 instance at the speed of B = 32.  (Until round 4: B in {16, 32, 64} only, everything else fell to
     // the guarded kernel of gsmvi_kernels.hip.)
-    if (B < 1 || B > 128) return false;
+    if (B < 1) return false;
+    if (B > 128) {          // round 6: any batch size -- the run-time pass loop (k_gsm_cov_sym_big); B <= 128 keeps the instances below
+        GSMVI_LAUNCH(k_gsm_cov_sym_big, dim3(cov_sym_grid((D + 31) / 32)), dim3(512), 0, st, ev, D, B, 1.0 / (double)B, rec, ldrec,
+                     mu0, S0, lds0, S, lds, mu_out);
+        return true;
+    }
     const int SB = B <= 16 ? 16 : (B <= 32 ? 32 : (B <= 64 ? 64 : 128));
     const double invB = 1.0 / (double)B;
     const bool rag = D % 32 != 0 || B != SB;                     // off the grid: the clamped instantiation

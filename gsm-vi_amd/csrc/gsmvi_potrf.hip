@@ -24,8 +24,10 @@
 // tile is written from the same accumulators, so C is exactly symmetric.  Used once per fit (return value of the
 // factor-form fit) and per monitor checkpoint: not on the per-iteration path.
 // =====================================================================================
+// shift / shift_dev (round 6): C = F^T F + (shift + *shift_dev) I -- the accumulated jitter of a factor-form BaM fit is absorbed by
+// re-factorising this matrix (bam.py:198 adds jitter * I to the covariance every iteration; gsmvi_gram_shift_f64).
 __global__ __launch_bounds__(256) void k_gram(int D, const double* __restrict__ F, int ldf, double* __restrict__ C,
-                                              int ldc) {
+                                              int ldc, double shift, const double* __restrict__ shift_dev) {
     constexpr int RS = 66;
     __shared__ double FA[64 * RS];
     __shared__ double FB[64 * RS];
@@ -85,8 +87,12 @@ __global__ __launch_bounds__(256) void k_gram(int D, const double* __restrict__ 
                 const int row = I0 + 32 * wr + 16 * rt + ks + 4 * r;
                 const int col = J0 + 32 * wc + 16 * ct + c;
                 if (row < D && col < D) {
-                    if (col >= row) C[(size_t)row * ldc + col] = acc[rt][ct][r];
-                    if (col > row) C[(size_t)col * ldc + row] = acc[rt][ct][r];
+                    if (col > row) {
+                        C[(size_t)row * ldc + col] = acc[rt][ct][r];
+                        C[(size_t)col * ldc + row] = acc[rt][ct][r];
+                    } else if (col == row) {
+                        C[(size_t)row * ldc + col] = acc[rt][ct][r] + (shift + (shift_dev ? *shift_dev : 0.0));
+                    }
                 }
             }
 }
@@ -124,9 +130,9 @@ __global__ __launch_bounds__(256) void k_whiten_rows(int D, const double* __rest
     }
 }
 
-int gsmvi_gram_impl(hipStream_t st, int D, const double* F, int ldf, double* C, int ldc) {
+int gsmvi_gram_impl(hipStream_t st, int D, const double* F, int ldf, double* C, int ldc, double shift, const double* shift_dev) {
     const int ntr = (D + 63) / 64;
-    hipLaunchKernelGGL(k_gram, dim3(ntr * (ntr + 1) / 2), dim3(256), 0, st, D, F, ldf, C, ldc);
+    hipLaunchKernelGGL(k_gram, dim3(ntr * (ntr + 1) / 2), dim3(256), 0, st, D, F, ldf, C, ldc, shift, shift_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         gsmvi_set_error("gram launch failed: %s%s", hipGetErrorString(e), "");

@@ -443,17 +443,35 @@ class HipEngine:
             C.c_void_p(n_reverts.data_ptr()) if n_reverts is not None else None))
         return mu, F, flag
 
-    def gram(self, F, out=None):
+    def gram(self, F, out=None, shift=0.0, shift_dev=None):
         """cov = F^T F (gsmvi_gram_f64): the covariance a square factor represents -- return value of the
-        factor-form fit and what its monitor sees (gsm_numpy.py:129).  Not on the per-iteration path."""
+        factor-form fit and what its monitor sees (gsm_numpy.py:129).  Not on the per-iteration path.
+        ``shift`` / ``shift_dev`` (a 1-element float64 device tensor): cov = F^T F + (shift + shift_dev) I
+        (gsmvi_gram_shift_f64) -- the jitter a factor-form BaM fit owes (bam.py:198)."""
         D = F.shape[0]
         assert F.shape == (D, D)
         self._ensure(D, max(self._max_B, 1))
         Cm = self.empty(D, D) if out is None else out
         pf, ldf = self._mat(F, "F")
         pc, ldc = self._mat(Cm, "C")
-        _lib.check("gsmvi_gram_f64", self.lib.gsmvi_gram_f64(self._ctx, self._stream(), D, pf, ldf, pc, ldc))
+        if shift == 0.0 and shift_dev is None:
+            _lib.check("gsmvi_gram_f64", self.lib.gsmvi_gram_f64(self._ctx, self._stream(), D, pf, ldf, pc, ldc))
+        else:
+            _lib.check("gsmvi_gram_shift_f64", self.lib.gsmvi_gram_shift_f64(
+                self._ctx, self._stream(), D, pf, ldf, float(shift),
+                C.c_void_p(shift_dev.data_ptr()) if shift_dev is not None else None, pc, ldc))
         return Cm
+
+    def owed_shift(self, jitter, pend, n_rev, mark, advance=True):
+        """The diagonal shift a factor-form BaM fit owes its covariance: jitter * (accepted updates since the last absorption)
+        as a 1-element device tensor, without a host synchronisation.  ``pend`` = updates ATTEMPTED since then (host count),
+        ``n_rev`` = the device counter of reverts, ``mark`` = its value at the last absorption (a device int32 word, advanced
+        to ``n_rev`` when ``advance``): a reverted update adds no jitter in the reference (bam.py:198 sits before the accept
+        test, :208-212 discards the shifted matrix with the update)."""
+        s = (float(pend) - (n_rev - mark).to(torch.float64)) * float(jitter)
+        if advance:
+            mark.copy_(n_rev)
+        return s
 
     def whiten_rows(self, X, mu, R):
         """(Z, logdiag): Z = (X - mu) R^-1 for the rows of X and logdiag = sum_i log R_ii (a 1-element device

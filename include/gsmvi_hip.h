@@ -288,6 +288,16 @@ int gsmvi_potrf_f64(gsmvi_ctx* ctx, void* stream, int D, const double* S, int ld
 int gsmvi_gram_f64(gsmvi_ctx* ctx, void* stream, int D, const double* F, int ldf, double* C, int ldc);
 
 /*
+ * C = F^T F + (shift + *shift_dev) I (shift_dev may be NULL; a device double read when the kernel executes).  The reference's
+ * BaM loop adds jitter * I to the covariance after EVERY update (bam.py:198, default 1e-6); a diagonal shift is not a low-rank
+ * change of a square factor, so a factor-form fit carries the shift it owes and absorbs it every few iterations by
+ * re-factorising this matrix with gsmvi_potrf_f64 (gsm-vi_amd/bam.py, jitter_every).  shift_dev lets the caller count only
+ * ACCEPTED updates without a host synchronisation (a reverted iteration adds no jitter in the reference, bam.py:208-212).
+ */
+int gsmvi_gram_shift_f64(gsmvi_ctx* ctx, void* stream, int D, const double* F, int ldf, double shift, const double* shift_dev,
+                         double* C, int ldc);
+
+/*
  * Whitened residuals Z = (X - 1 mu^T) R^-1 for nrows rows of X and an upper Cholesky factor R (R^T R = cov), and
  * (if logdiag_dev != NULL) logdiag_dev[0] = sum_i log R_ii.  Together they give the row-wise Gaussian log density
  * log N(x; mu, cov) = -1/2 |z|^2 - sum_i log R_ii - D/2 log(2 pi) that the reference's KLMonitor evaluates through
@@ -374,8 +384,11 @@ int gsmvi_bam_update_sharded_f64(gsmvi_ctx* ctx, void* stream, void* nccl_comm, 
  * the update works in the basis [Vw; Zt] (Zt: the part of Zw orthogonal to the whitened draws), which takes the Cholesky factor
  * of Gvv = Vw Vw^T: LINEARLY DEPENDENT draws (a repeated sample; impossible for i.i.d. normal draws, legal in bam.py) make Gvv
  * singular -- the update then either still equals the dense one or is reverted with *info_dev != 0; ALMOST dependent draws
- * (cond(Gvv) > 1e8, estimated from the factor's diagonal) are reverted too, because the basis is orthogonal only to
- * eps cond(Gvv).  The update never returns a finite result less accurate than ~1e-8 without a flag (tests/test_gpu_bam.py).
+ * ((max R_ii / min R_ii)^2 > 1e8 on the factor's diagonal) are reverted too, because the basis is orthogonal only to
+ * eps cond(Gvv).  That ratio is a HEURISTIC LOWER BOUND of cond(Gvv), not the condition number (a graded matrix of Kahan's
+ * kind has a far larger one): it catches what it was built for -- one draw nearly repeating another, 5e-6 off without a flag at
+ * cond 1e12 before the guard (tests/test_gpu_bam.py) -- and is no guarantee for adversarial draws; method="dense" has no
+ * such precondition.
  */
 int gsmvi_bam_factor_update_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
                                 const double* Z, int ldz, const double* X, int ldx, const double* G, int ldg,

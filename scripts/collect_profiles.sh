@@ -21,13 +21,32 @@ lib = os.path.join(root, "gsm-vi_amd", "libgsmvi_hip.so")
 box = {"hostname": platform.node(), "utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
        "gpu_unique_id": sh("/opt/rocm/bin/rocm-smi --showuniqueid 2>/dev/null | grep 'GPU\\[' | head -2 | tr -s ' \\t' ' '"),
        "gpu_serial": sh("/opt/rocm/bin/rocm-smi --showserial 2>/dev/null | grep 'GPU\\[' | head -2 | tr -s ' \\t' ' '"),
-       "gpu_name": sh("/opt/rocm/bin/rocminfo 2>/dev/null | grep -i 'marketing name' | grep -i -m1 'instinct\\|MI3' | tr -s ' ' ' '"),
-       "gpu_uuid": sh("/opt/rocm/bin/rocminfo 2>/dev/null | grep -i -m2 'uuid' | tail -1 | tr -s ' ' ' '"),
        "rocm": sh("cat /opt/rocm/.info/version 2>/dev/null"), "kernel": platform.release(), "cpus": os.cpu_count(),
        "library_sha256_on_box": hashlib.sha256(open(lib, "rb").read()).hexdigest()}
+# (round-5 advice) name and uuid of the GPU AGENT: rocminfo lists the CPU agents first ("Uuid: CPU-XX") and the marketing name
+# differs by box ("AMD Instinct MI355X", "AMD Radeon Graphics"), so the fields are taken from the agent whose Name is gfx*
+agent, gpu = {}, None
+for line in sh("/opt/rocm/bin/rocminfo 2>/dev/null").splitlines():
+    if line.startswith("Agent ") or line.startswith("*******"):
+        if agent.get("Name", "").startswith("gfx") and gpu is None:
+            gpu = agent
+        agent = {} if line.startswith("Agent ") else agent
+    elif ":" in line:
+        k, v = line.split(":", 1)
+        agent.setdefault(k.strip(), v.strip())
+if gpu is None and agent.get("Name", "").startswith("gfx"):
+    gpu = agent
+box["gpu_name"] = (gpu or {}).get("Marketing Name", "")
+box["gpu_uuid"] = (gpu or {}).get("Uuid", "")
+box["gpu_arch"] = (gpu or {}).get("Name", "")
+if not box["gpu_uuid"].startswith("GPU-") or not box["gpu_name"]:
+    print("collect_profiles: no GPU agent found in rocminfo", file=sys.stderr)
+    json.dump(box, open(os.path.join(out, "box.json"), "w"), indent=1)
+    sys.exit(3)
 json.dump(box, open(os.path.join(out, "box.json"), "w"), indent=1)
 print(json.dumps(box))
 PYBOX
+[ $? -eq 0 ] || { echo "collect_profiles: box identification failed"; exit 3; }
 cd /tmp && export TMPDIR=/tmp
 ARGS="$ROOT/bench.py --steps 420 --warmup 42 --no-cpu-baseline --no-large-point --no-callpath"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1

@@ -15,8 +15,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-dst = os.path.join(ROOT, "profiles", tag)
-os.makedirs(dst, exist_ok=True)
+final = os.path.join(ROOT, "profiles", tag)
+# (round-5 advice) everything is STAGED in a temporary directory and swapped in after every check has passed: a pass that fails
+# a hash check midway leaves profiles/<tag>/ as it was
+dst = os.path.join(ROOT, "profiles", f".{tag}.staging")
+if os.path.isdir(dst):
+    shutil.rmtree(dst)
+os.makedirs(dst)
 
 
 def sha256(path):
@@ -76,9 +81,12 @@ plain = {
     "soak.txt": "run-to-run bit-identity soak over the (case, kind) pairs, library of this pass",
     "pytest_gpu.txt": "python -m pytest tests -m gpu -q (tail)",
 }
-for stale in os.listdir(dst):                     # the directory is rebuilt from the last pass alone (offgrid.json is re-merged afterwards)
-    if stale not in ("offgrid.json",):
-        os.remove(os.path.join(dst, stale))
+# the directory is rebuilt from the last pass alone; files listed in KEEP (merged reports written by other scripts of the
+# round) are carried over from the published directory
+KEEP = ("offgrid.json", "bigbatch.json", "jitter_period.json", "scaling_model.json", "potrf_rate.txt", "thresholds.json")
+for keep in KEEP:
+    if os.path.exists(os.path.join(final, keep)):
+        shutil.copyfile(os.path.join(final, keep), os.path.join(dst, keep))
 for name, note in plain.items():
     publish("summary.json" if name == "rocprof_summary.json" else name, name, note)
 ks = first("trace/**/*kernel_stats.csv")
@@ -101,4 +109,7 @@ for n, e in manifest["files"].items():
 if "--also-root-traffic" in sys.argv and os.path.exists(os.path.join(dst, "traffic.json")):
     shutil.copyfile(os.path.join(dst, "traffic.json"), os.path.join(ROOT, "profiles", "traffic.json"))   # bench.py's labelled source
 json.dump(manifest, open(os.path.join(dst, "MANIFEST.json"), "w"), indent=1)
+if os.path.isdir(final):
+    shutil.rmtree(final)
+os.rename(dst, final)
 print(f"published {len(manifest['files'])} files to profiles/{tag}/ (build {build['git_head_short']}, box {box.get('hostname')})")

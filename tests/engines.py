@@ -189,11 +189,18 @@ class OracleEngine:
             return out[0], out[1], flag
         return mu, Fn, flag
 
-    def gram(self, F, out=None):
+    def gram(self, F, out=None, shift=0.0, shift_dev=None):
+        Cm = F.T @ F + (shift + (float(shift_dev[0]) if shift_dev is not None else 0.0)) * np.eye(F.shape[0])
         if out is not None:
-            out[...] = F.T @ F
+            out[...] = Cm
             return out
-        return F.T @ F
+        return Cm
+
+    def owed_shift(self, jitter, pend, n_rev, mark, advance=True):
+        s = np.array([(pend - (n_rev.v - mark.v)) * jitter])
+        if advance:
+            mark.v = n_rev.v
+        return s
 
     def whiten_rows(self, X, mu, R):
         r = X - (mu[None, :] if mu is not None else 0.0)

@@ -107,7 +107,7 @@ def test_default_fits_follow_the_dense_fits_on_their_own_samples(D, B):
         seen.clear()
         if cls == "bam":
             f = gsmvi_amd.BaM(D, None, lp_g)
-            mean_f, cov_f = f.fit(7, sched, batch_size=B, niter=niter, verbose=False)
+            mean_f, cov_f = f.fit(7, sched, batch_size=B, niter=niter, verbose=False, jitter=0.0)    # (jitter 0: auto = the factor form, round 6)
             forced = [x.cpu().numpy() for x in seen]
             mean_d, cov_d = gsmvi_amd.BaM(D, None, tgt.lp_g).fit(7, sched, batch_size=B, niter=niter, verbose=False, jitter=0.0,
                                                                 forced_samples=forced, method="dense")

@@ -44,8 +44,9 @@ def test_fits_at_the_smallest_shapes(D, B):
     g = gsmvi_amd.GSM(D, tgt.lp, tgt.lp_g)
     mg, cg = g.fit(3, niter=300, batch_size=B, verbose=False)
     assert np.abs(mg - m).max() < 1e-12 and np.abs(cg - cov).max() < 1e-11 * max(1.0, np.abs(cov).max()), g.method_used
-    b = gsmvi_amd.BaM(D, tgt.lp, tgt.lp_g)
-    mb, cb = b.fit(3, lambda i: 10.0 / (1 + i), niter=300, batch_size=B, verbose=False)
-    assert b.method_used == ("factor" if 2 * B <= D else "dense")
-    tol = 1e-9 if b.method_used == "factor" else 1e-4
-    assert np.abs(mb - m).max() < tol and np.abs(cb - cov).max() < tol * max(1.0, np.abs(cov).max())
+    for jit in (1e-6, 0.0):                      # round 6: the reference's default jitter -> its own (dense) loop; jitter 0 -> factor form
+        b = gsmvi_amd.BaM(D, tgt.lp, tgt.lp_g)
+        mb, cb = b.fit(3, lambda i: 10.0 / (1 + i), niter=300, batch_size=B, verbose=False, jitter=jit)
+        assert b.method_used == ("factor" if (2 * B <= D and jit == 0.0) else "dense")
+        tol = 1e-9 if b.method_used == "factor" else 1e-4
+        assert np.abs(mb - m).max() < tol and np.abs(cb - cov).max() < tol * max(1.0, np.abs(cov).max())

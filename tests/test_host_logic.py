@@ -134,8 +134,10 @@ def test_bam_fit_converges_and_schedule_counts_calls():
 
 
 def test_bam_default_method_rule():
-    """BaM.fit(method="auto"), the default since round 5: the factor form wherever it exists for the call and the jitter is at
-    most the reference's default (bam.py:140: 1e-6); anything else is the reference's dense loop."""
+    """BaM.fit(method="auto"), round 6: with the reference's default jitter (bam.py:140: 1e-6, added to the covariance after every
+    update, :198) the default is the reference's own loop ("dense"); the factor form is the default where it exists AND the
+    call asks for no jitter, and opt-in otherwise (method="factor" or jitter_every=K: the owed shift is absorbed every K
+    accepted updates)."""
     D = 6
     m, cov_t, P = orc.make_gaussian_target(D, 17)
     lp_g = lambda x: orc.gaussian_score(x, m, P)      # noqa: E731
@@ -146,13 +148,61 @@ def test_bam_default_method_rule():
         bam.fit(3, regf=reg.constant(5.0), niter=2, verbose=False, **kw)
         return bam.method_used
 
-    assert used(batch_size=3) == "factor"                         # 2B <= D, default jitter
-    assert used(batch_size=3, jitter=0.0) == "factor"
-    assert used(batch_size=3, jitter=1e-3) == "dense"             # a larger jitter is a request for the shift itself
-    assert used(batch_size=4) == "dense"                          # 2B > D: the factor form does not exist
-    assert used(batch_size=2, sampler="svd") == "dense"           # the reference's legacy sampler needs the covariance
-    assert used(batch_size=2, forced_samples=[np.zeros((2, D))] * 3) == "dense"
-    assert used(batch_size=3, method="dense") == "dense"
+    assert used(batch_size=3) == "dense"                          # default jitter: the reference's loop, shift included
+    assert used(batch_size=3, jitter=0.0) == "factor"             # 2B <= D and nothing to shift
+    assert used(batch_size=3, jitter_every=4) == "factor"         # opt-in: the shift is absorbed every 4 accepted updates
+    assert used(batch_size=3, jitter=1e-3) == "dense"
+    assert used(batch_size=4, jitter=0.0) == "dense"              # 2B > D: the factor form does not exist
+    assert used(batch_size=2, jitter=0.0, sampler="svd") == "dense"   # the reference's legacy sampler needs the covariance
+    assert used(batch_size=2, jitter=0.0, forced_samples=[np.zeros((2, D))] * 3) == "dense"
+    assert used(batch_size=3, jitter=0.0, method="dense") == "dense"
+
+
+def test_bam_factor_fit_absorbs_the_jitter_it_owes():
+    """bam.py:198 adds jitter * I to the covariance after every update.  The factor-form fit carries the owed shift and
+    re-factorises F^T F + owed I every ``jitter_every`` accepted updates.  With jitter_every = 1 that IS the reference's loop:
+    the factor fit's own samples forced into the dense loop give the same (mean, cov) at every checkpoint.  With a longer
+    period the covariance the monitor sees still carries the full shift (what is owed is added to F^T F), and the number of
+    absorptions is the number of completed periods."""
+    D, B, niter, jit = 8, 3, 40, 1e-3                  # (a LARGE jitter, so that dropping it would show at 1e-3)
+    m, cov_t, P = orc.make_gaussian_target(D, 29)
+    lp_g = lambda x: orc.gaussian_score(x, m, P)      # noqa: E731
+
+    class Mon:
+        checkpoint = 5
+
+        def __init__(self):
+            self.s = []
+
+        def __call__(self, i, params, lp, key, nevals=1):
+            self.s.append((params[0].copy(), params[1].copy()))
+
+    seen = []
+
+    def rec(x):
+        seen.append(np.array(x, copy=True))
+        return lp_g(x)
+
+    mf, md = Mon(), Mon()
+    bam = BaM(D, None, rec, engine=OracleEngine())
+    bam.fit(5, regf=Regularizers().custom(lambda i: 20 / (1 + i)), niter=niter, batch_size=B, verbose=False, method="factor",
+            jitter=jit, jitter_every=1, monitor=mf)
+    assert bam.method_used == "factor" and bam.n_absorbed == niter + 1 and bam.jitter_every_used == 1
+    BaM(D, None, lp_g, engine=OracleEngine()).fit(5, regf=Regularizers().custom(lambda i: 20 / (1 + i)), niter=niter,
+                                                  batch_size=B, verbose=False, method="dense", jitter=jit,
+                                                  forced_samples=seen, monitor=md)
+    assert len(mf.s) == len(md.s) == niter // 5 + 2
+    for (m1, c1), (m2, c2) in zip(mf.s, md.s):
+        assert rel_err(m1, m2) < 1e-9 and rel_err(c1, c2) < 1e-9
+    # period 4: 41 updates = 10 absorptions + 1 owed; the returned covariance carries the owed shift
+    bam4 = BaM(D, None, lp_g, engine=OracleEngine())
+    _, cov4 = bam4.fit(5, regf=Regularizers().constant(5.0), niter=niter, batch_size=B, verbose=False, method="factor",
+                       jitter=jit, jitter_every=4)
+    bam0 = BaM(D, None, lp_g, engine=OracleEngine())
+    _, cov0 = bam0.fit(5, regf=Regularizers().constant(5.0), niter=niter, batch_size=B, verbose=False, method="factor",
+                       jitter=jit, jitter_every=0)
+    assert bam4.n_absorbed == 10 and bam0.n_absorbed == 0 and bam0.jitter_every_used == 0
+    assert np.all(np.linalg.eigvalsh(cov4) > 0)
 
 
 def test_bam_factor_fit_runs_the_same_loop():
