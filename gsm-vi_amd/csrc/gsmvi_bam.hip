@@ -183,7 +183,7 @@ static inline void bam_stats_launch(hipStream_t st, int D, int B, const double* 
 }
 
 // ---- Z = L^-1 (P + M1^T Vf), the new mean, and the signed factor panel -------------------------
-// One column of D per thread, COLS threads per block (64 for n <= 160, 32 for n <= 320, 16 for n <= 640: the LDS of a CU
+// One column of D per thread, COLS threads per block (64 for n <= 160, 32 for n <= 320, 16 for n <= 640, 8 for n <= 1024: the LDS of a CU
 // bounds n COLS); the thread's Vf column and running Z column live in LDS ([k][COLS], conflict-free).  M1, L are read with wave-uniform indices (scalar loads, L2 hits).
 // Ft = [Vf; Z], Fs = [Vf; -Z]  (rows n..2n-1 written here; rows 0..n-1 by k_bam_stats).
 template <int COLS>
@@ -774,7 +774,7 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
     double* Ld = M1 + (size_t)n * n;               // n x n, then Ldinv (n), zg (n), vg (n)
 
     if (n > gsmvi_bam_small_nmax()) {              // checked before anything is enqueued
-        gsmvi_set_error("%s: %s", "gsmvi_bam_update_f64", "B > 640 exceeds the device chain (LDS of the forward substitution)");
+        gsmvi_set_error("%s: %s", "gsmvi_bam_update_f64", "B > 1024 exceeds the device chain (one entry per thread in k_bam_post_big)");
         return GSMVI_ERR_UNSUPPORTED;
     }
     bam_stats_launch(st, D, B, X, ldx, mu0, (const double*)nullptr, 0, G, ldg, reg, xbar, gbar, (double*)nullptr, Qt, Ft, Fs);
@@ -825,7 +825,7 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
         if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_p, hint, ctx->tune_bam_kenq, nullptr, nullptr, nullptr, nullptr)))
             return rc;
 #define BFW(CV) hipLaunchKernelGGL(k_bam_forward<CV>, dim3((D + CV - 1) / CV), dim3(CV), sizeof(double) * 2 * n * CV, st, D, n, P, M1, Ld, Ldinv, Ldinv + n, Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu)
-        if (n <= 160) BFW(64); else if (n <= 320) BFW(32); else BFW(16);
+        if (n <= 160) BFW(64); else if (n <= 320) BFW(32); else if (n <= 640) BFW(16); else BFW(8);   // (LDS: 16 n COLS bytes <= 160 KB)
 #undef BFW
     }
     const int nt = (D + 63) / 64;
@@ -1184,6 +1184,9 @@ hipError_t gsmvi_bam_prepare() {
                                 160 * 1024);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bam_forward<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bam_forward<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024);
     return e;
 }

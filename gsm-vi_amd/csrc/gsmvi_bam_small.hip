@@ -30,7 +30,8 @@
 #include "../../include/gsmvi_hip.h"
 
 #define BAMS_NMAX 128                // largest n of the one-workgroup Cholesky k_bam_cholw; above it: blocked potrf + k_bam_post_big
-#define BAMS_NBIG 640                // largest n altogether (LDS of the forward substitution kernel, 16 columns per workgroup)
+#define BAMS_NBIG 1024               // largest n altogether: k_bam_post_big's substitution owns one entry per thread of its 1024-thread workgroup
+                                     // (round 6; 640 until then: LDS of the forward substitution kernel at 16 columns per workgroup -- now 8 above 640)
 #define BAMS_LD 144                  // padded leading dimension of the iteration matrices for n <= 128 (9 blocks of 16: n = B + 1 <= 129 until round 3);
                                      // larger n: n rounded up to 16 (passed to the kernels as `ld`)
 #define BAMS_KMAX 32                 // launches enqueued; k* <= BAMS_KMAX is checked on the device (else flagged)

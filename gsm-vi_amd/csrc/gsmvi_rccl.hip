@@ -173,7 +173,7 @@ extern "C" int gsmvi_bam_update_sharded_f64(gsmvi_ctx* ctx, void* stream, void* 
         return GSMVI_ERR_WORKSPACE;
     }
     if (B > gsmvi_bam_small_nmax()) {            // the combined batch, checked BEFORE the staging copies and the all-gathers
-        gsmvi_set_error("%s: %s", __func__, "B_local x ranks exceeds the device chain of the BaM update (B <= 640)");
+        gsmvi_set_error("%s: %s", __func__, "B_local x ranks exceeds the device chain of the BaM update (B <= 1024)");
         return GSMVI_ERR_UNSUPPORTED;
     }
     // BaM's statistics couple all samples: the ranks exchange their (x_b, g_b) rows -- two all-gathers of B_local x D doubles

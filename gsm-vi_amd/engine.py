@@ -37,8 +37,9 @@ class HipEngine:
     name = "hip"
     factor_max_rows = 256      # largest 2B of the factor-form updates (GSMVI_FACTOR_NMAX; the 2B x 2B chain: one workgroup up to 64,
                                # one-workgroup factorisations up to 128, two-level blocked above)
-    bam_max_batch = 640        # B <= 640: LDS of BaM's forward-substitution kernel (csrc/gsmvi_bam.hip); the one-workgroup
-                               # chain covers B <= 128, larger batches take the blocked multi-workgroup Cholesky
+    bam_max_batch = 1024       # B <= 1024 (round 6; 640 before): the B x B chain's last stage (k_bam_post_big, csrc/gsmvi_bam_small.hip) owns
+                               # one entry per thread of a 1024-thread workgroup.  The one-workgroup chain covers B <= 128, larger
+                               # batches take the blocked multi-workgroup Cholesky and an O(B^2 D) substitution: they work, untuned
 
     def __init__(self, device=None, max_D=0, max_B=0):
         self.lib = _lib.load_library()
@@ -53,6 +54,7 @@ class HipEngine:
         self._ctx_captured = False  # has the current context been used under stream capture (a graph may hold its pointers)
         self._stage = {}           # shape -> [pinned staging tensor, event behind its last host -> device copy] (from_host)
         self._hs = {}              # shape -> pinned buffers of the host-callable round trip (host_score)
+        self.host_score_profile = None   # a dict here makes host_score accumulate its three phases (benchmarks only)
         if max_D and max_B:
             self._ensure(max_D, max_B)
 
@@ -198,9 +200,17 @@ class HipEngine:
             ent = (xp, xp.numpy())
             if len(hs["pool"]) < 4:
                 hs["pool"].append(ent)
+        prof = self.host_score_profile                        # None, or a dict the call-path benchmark reads (bench.callpath_rates)
+        if prof is not None:
+            import time
+            t0 = time.perf_counter()
         ent[0].copy_(X.detach(), non_blocking=True)
         stream.synchronize()                                  # (polling an event instead was measured: no difference)
+        if prof is not None:
+            t1 = time.perf_counter()
         g = lp_g(ent[1])
+        if prof is not None:
+            t2 = time.perf_counter()
         if isinstance(g, torch.Tensor):
             g = g.detach().cpu().numpy()
         g = np.asarray(g)
@@ -208,6 +218,12 @@ class HipEngine:
         assert g.shape == key and tuple(out.shape) == key, f"lp_g returned shape {g.shape}, expected {key}"
         np.copyto(hs["gnp"], g, casting="unsafe")             # (also float32 -> float64: gsm_numpy.py:47 returns float64)
         out.copy_(hs["gpin"], non_blocking=True)
+        if prof is not None:
+            t3 = time.perf_counter()
+            prof["calls"] = prof.get("calls", 0) + 1
+            prof["d2h_and_sync_s"] = prof.get("d2h_and_sync_s", 0.0) + (t1 - t0)     # waits for the device work in front of it too
+            prof["callable_s"] = prof.get("callable_s", 0.0) + (t2 - t1)
+            prof["stage_and_h2d_enqueue_s"] = prof.get("stage_and_h2d_enqueue_s", 0.0) + (t3 - t2)
         return out
 
     def empty(self, *shape):

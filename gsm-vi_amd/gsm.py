@@ -43,7 +43,7 @@ def gsm_update(samples, vs, mu0, S0, engine=None, assume_symmetric=None):
             assume_symmetric = bool(np.array_equal(np.asarray(S0), np.asarray(S0).T))
     Xd, Gd, m0, S0d = eng.asarray(samples), eng.asarray(vs), eng.asarray(mu0), eng.asarray(S0)
     D = int(m0.shape[0])
-    if assume_symmetric and D % 2 == 1 and getattr(eng, "name", "") == "hip" and Xd.shape[0] <= 128:
+    if assume_symmetric and D % 2 == 1 and getattr(eng, "name", "") == "hip":
         # odd D: the (D + 1)-dimensional problem with an inert last coordinate runs on the tuned kernels (_oddpad.py); the
         # padding copies ride on the uploads for host inputs
         from . import _oddpad

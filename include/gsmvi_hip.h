@@ -351,8 +351,8 @@ int gsmvi_commit_f64(gsmvi_ctx* ctx, void* stream, int D, const int* info_dev,
  * The B x B matrix function of bam.py:108-110 (B + 1 columns in the reference's factorisation of U; an orthonormal
  * recombination of the centred score rows saves one without changing U) -- which the reference evaluates on the host through
  * jax.pure_callback (bam.py:15-22) -- runs on the device (scaled coupled Newton-Schulz square root on the MFMA pipe +
- * a one-workgroup Cholesky for B <= 129, the blocked Cholesky of gsmvi_potrf_f64 up to B = 640; csrc/gsmvi_bam_small.hip):
- * no synchronisation, graph-capturable.  For B > 640 the call returns GSMVI_ERR_UNSUPPORTED before anything is enqueued:
+ * a one-workgroup Cholesky for B <= 129, the blocked Cholesky of gsmvi_potrf_f64 up to B = 1024 (round 6; 640 before); csrc/gsmvi_bam_small.hip):
+ * no synchronisation, graph-capturable.  For B > 1024 the call returns GSMVI_ERR_UNSUPPORTED before anything is enqueued:
  * there is no host computation in this library.
  * *info_dev = 1 if that small problem was not finite / not positive definite (then mu, S are NaN-poisoned and the
  * caller's accept/revert must reject them).

@@ -83,7 +83,7 @@ def test_workspace_covers_the_b_sized_slabs_of_the_transposed_products():
     from gsmvi_amd import _lib
     lib = _lib.load_library()
     for D in (2, 16, 64, 100, 256, 1024, 4096):
-        for B in (1, 8, 32, 128, 300, 640):
+        for B in (1, 8, 32, 128, 300, 640, 1024):
             R = 2 * B + 8
             kct = max(1, min(8, (D + 63) // 64))
             assert lib.gsmvi_workspace_bytes(D, B) >= 8 * (kct * R * R + 8 * R * D), (D, B)

@@ -227,7 +227,7 @@ def test_full_form_gap_stays_small_at_moderate_reg(golden):
         assert rel_err(S, Sf) < 1e-6 and rel_err(mu, g[f"{c}/mu_full"]) < 1e-6, c
 
 
-@pytest.mark.parametrize("D,B,reg", [(300, 130, 1.0), (1024, 256, 1.0), (200, 300, 0.5), (512, 400, 2.0), (64, 640, 1.0), (32, 500, 1.0),
+@pytest.mark.parametrize("D,B,reg", [(300, 130, 1.0), (1024, 256, 1.0), (200, 300, 0.5), (512, 400, 2.0), (64, 640, 1.0), (32, 500, 1.0), (64, 1024, 1.0), (200, 800, 0.5), (1024, 700, 2.0),
                                      (16, 300, 0.5)])
 def test_batches_beyond_the_one_workgroup_chain(D, B, reg):
     """bam.py:31-69 has no batch bound.  B > 128 takes the multi-workgroup Newton-Schulz steps on an n-sized grid, the
@@ -249,12 +249,12 @@ def test_batches_beyond_the_one_workgroup_chain(D, B, reg):
 
 
 def test_batch_bound_is_reported_up_front():
-    """B + 1 > 640 is beyond the device chain: the Python driver says so before anything runs (no retry loop), and the
+    """B > 1024 is beyond the device chain: the Python driver says so before anything runs (no retry loop), and the
     C entry point returns GSMVI_ERR_UNSUPPORTED before anything is enqueued -- there is no host arithmetic in the library."""
     import gsmvi_amd
     orc, borc = _o()
     eng = gsmvi_amd.get_engine()
-    st = orc.make_update_state(64, 700, seed=2)
+    st = orc.make_update_state(64, 1100, seed=2)
     X, G, mu0, S0 = (eng.asarray(st[k]) for k in ("samples", "vs", "mu0", "S0"))
     with pytest.raises(ValueError):                                  # the Python driver refuses up front (no retry loop)
         eng.bam_update(X, G, mu0, S0, 1.0)
@@ -267,7 +267,7 @@ def test_batch_bound_is_reported_up_front():
     finally:
         eng.bam_max_batch = limit
     with pytest.raises(ValueError):
-        gsmvi_amd.BaM(64, None, lambda x: -x).fit(0, gsmvi_amd.Regularizers().constant(1.0), batch_size=700, niter=2,
+        gsmvi_amd.BaM(64, None, lambda x: -x).fit(0, gsmvi_amd.Regularizers().constant(1.0), batch_size=1100, niter=2,
                                                   verbose=False)
 
 
