@@ -245,6 +245,17 @@ def callpath_rates(D, B, methods=("auto",), n_fast=300, n_host=60, loop_variant=
               "native_diag_target": (tgt_d, tgt_d.lp_g), "host_lp_g_diag_target": (tgt_d, host_lp_g_diag)}
     if loop_variant:
         scores["host_lp_g_loop"] = (tgt, host_lp_g_loop)
+    # (round 6) the same numpy score with the BLAS pool limited: the worker threads of a many-threaded GEMM keep spinning after it
+    # returns and compete with the host side of the NEXT iteration's launches and synchronisation -- the engine's own share
+    # (d2h_and_sync - device time) shows up only when they do not
+    blas_limits = {}
+    try:
+        import threadpoolctl
+        for nthr in (1, 8):
+            scores[f"host_lp_g_blas_{nthr}_threads"] = (tgt, host_lp_g)
+            blas_limits[f"host_lp_g_blas_{nthr}_threads"] = nthr
+    except ImportError:
+        threadpoolctl = None
     ent = {"D": D, "B": B}
     for method in methods:
         r = {}
@@ -261,8 +272,14 @@ def callpath_rates(D, B, methods=("auto",), n_fast=300, n_host=60, loop_variant=
             if sname == "host_lp_g" and D >= 1024:
                 n = n_host
             fkw = {"graph": True} if (sname.endswith("graph_safe") and method != "dense") else {}
+            if sname.startswith("host_lp_g_blas"):
+                n = n_host
             try:
-                rate = _marginal_rate(lambda k: gsm.fit(1, niter=k, batch_size=B, verbose=False, method=method, **fkw), n)
+                if sname in blas_limits:
+                    with threadpoolctl.threadpool_limits(limits=blas_limits[sname], user_api="blas"):
+                        rate = _marginal_rate(lambda k: gsm.fit(1, niter=k, batch_size=B, verbose=False, method=method, **fkw), n)
+                else:
+                    rate = _marginal_rate(lambda k: gsm.fit(1, niter=k, batch_size=B, verbose=False, method=method, **fkw), n)
             except Exception as e:                      # reported, never hidden
                 r[sname] = {"error": f"{type(e).__name__}: {e}"[:200]}
                 continue
