@@ -157,6 +157,10 @@ static void ws_sizes(int D, int B, size_t* n_pp, size_t* n_sg, size_t* n_small, 
     const size_t dpad = (size_t)(((D > R ? D : R) + 63) / 64) * 64;
     size_t potrf_scratch = dpad * 64;                          // v1: one factored 64 x 64 block per step
     if (potrf_scratch < 3 * 64 * dpad + 2 * 64 * 64) potrf_scratch = 3 * 64 * dpad + 2 * 64 * 64;   // row buffers + W + X^T blocks
+    {   // k_potrf_dag (round 6): one W block per step (64 dpad doubles) + its flags (2 + nblk + 2 nblk^2 ints)
+        const size_t nb_ = dpad / 64, dag = 64 * dpad + (2 + nb_ + 2 * nb_ * nb_ + 1) / 2 + 8;
+        if (potrf_scratch < dag) potrf_scratch = dag;
+    }
     if (*n_pp < potrf_scratch) *n_pp = potrf_scratch;
     // the TRANSPOSED panel products (A M^T: BaM's stacked Gram matrices [P; Vf] Qt^T, the factor path's Rt Rt^T) leave kc slabs of
     // up to R x R doubles, kc <= min(GSMVI_MAX_KC, D / 64): for B >> D that is more than the R x D slabs above (round 5: D = 64,
@@ -274,6 +278,8 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     else if (!strcmp(name, "direct_out")) ctx->tune_direct_out = value;
     else if (!strcmp(name, "rider")) ctx->tune_rider = value;
     else if (!strcmp(name, "potrf_split_m")) ctx->tune_potrf_split_m = value;
+    else if (!strcmp(name, "potrf_dag")) ctx->tune_potrf_dag = value;
+    else if (!strcmp(name, "potrf_spin")) ctx->tune_potrf_spin = value;
     else if (!strcmp(name, "wide")) ctx->tune_wide = value;
     else if (!strcmp(name, "wide_kc")) ctx->tune_wide_kc = value;
     else if (!strcmp(name, "fork_min_D")) ctx->tune_fork_min_D = value;

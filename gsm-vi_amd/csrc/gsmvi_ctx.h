@@ -62,6 +62,8 @@ struct gsmvi_ctx {
     gsmvi_panel_extras px;     // see above
     int px_used = 0;
     unsigned path = 0;         // GSMVI_PATH_* bits of the kernel families launched since the last reset (gsmvi_last_path)
+    int tune_potrf_dag = 1;       // the factorisation as ONE persistent launch with look-ahead (k_potrf_dag, round 6); 0: one launch per block step (A/B)
+    int tune_potrf_spin = 0;      // > 0: polls before a waiting workgroup of k_potrf_dag gives up (tests of the abort path)
     int tune_potrf_split_m = 0;   // > 0: tile rows from which a Cholesky block step runs its row solve as a separate launch (A/B)
     int tune_wide = 1;         // 64-row panels (B = 64) of D-sized products on the 64 x 64-tile kernels of gsmvi_wide.hip
     int tune_wide_kc = 0;      // > 0: force their split-K count (A/B runs)

@@ -433,6 +433,286 @@ __global__ __launch_bounds__(512) void k_potrf_step8(int D, int k, const double*
 
 __global__ void k_potrf_clear_info(int* info) { *info = 0; }
 
+// =====================================================================================
+// ONE persistent launch per factorisation (round 6): the block steps as a task graph with look-ahead.
+//
+// The launch-per-step form above puts every step's whole chain -- launch boundary (~5 us), tile loads, the two solve products,
+// the tile update, the 64 x 64 factorisation (10.3 us) -- on the critical path: 20 us x 16 steps at D = 1024.  Only the
+// factorisation of the diagonal tile and the one rank-64 update it still needs are inherently serial.  Here:
+//   * workgroup 0 is the CHAIN: iteration c solves block (c-1, c) with the W_{c-1} it has just produced, applies that block's
+//     rank-64 update to tile (c, c), factors it (chol64_blk, [T | I] -> [R_cc | W_c]) and publishes W_c.  Everything else tile
+//     (c, c) and block (c-1, c) need has been applied by the other workgroups while the chain was factoring tile (c-1, c-1);
+//   * the other workgroups take TASKS from a ticket counter in step-major order:
+//       solve  (p, J), J >= p + 2 :  X = W_p T_pJ -> block (p, J) of R, in place (the mirror block is zeroed); needs W_p and tile
+//                                    (p, J) updated by steps 0 .. p-1
+//       update (p; I, J), p < I <= J, (I, J) != (p+1, p+1) :  T_IJ -= X_pI^T X_pJ; needs both solved blocks and the tile updated
+//                                    by steps 0 .. p-1.  ONE product per tile (the launch-per-step form recomputes both solves in
+//                                    every tile: three)
+//     A task waits only for tasks with smaller tickets or for the chain, which waits only for tasks of earlier steps: no cycle,
+//     and with at most one workgroup per CU in the grid every workgroup is resident, so every claimed task runs.
+//   * hand-offs are flags in the workspace (agent-scope release / acquire: the producer's tiles are written back past its
+//     XCD's L2, the consumer invalidates before it reads); every wait is BOUNDED (max_spin polls, ~0.3 s): on a timeout the
+//     waiter raises the abort flag, every workgroup leaves and *info reports D + 1 -- the pool's GPUs are shared, a kernel that
+//     can spin forever is not acceptable.
+// Tiles live in R from their first update on (step 0 reads S); R must not alias S.  Same arithmetic per tile as the
+// launch-per-step form, same summation order inside every product; the ORDER of the rank-64 updates of a tile is the step
+// order in both, so the factor is bit-identical to k_potrf_step8<true>'s (one product per tile).
+// =====================================================================================
+#define DAG_TICKET 0
+#define DAG_ABORT 1
+#define DAG_WREADY 2
+__device__ __forceinline__ int dag_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void dag_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
+// workgroup-wide bounded wait for up to three flags (null = none); false = aborted / timed out (block-uniform)
+__device__ __forceinline__ bool dag_wait(int* flags, const int* f0, int n0, const int* f1, int n1, const int* f2, int n2,
+                                         int* sh, int max_spin) {
+    if (threadIdx.x == 0) {
+        int ok = 1, spins = 0;
+        for (;;) {
+            const bool r = (!f0 || dag_ld(f0) >= n0) && (!f1 || dag_ld(f1) >= n1) && (!f2 || dag_ld(f2) >= n2);
+            if (r) break;
+            if (dag_ld(flags + DAG_ABORT) != 0 || ++spins > max_spin) {
+                ok = 0;
+                dag_st(flags + DAG_ABORT, 1);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        *sh = ok;
+    }
+    __syncthreads();
+    const int ok = *sh;
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return ok != 0;
+}
+// every thread's stores become visible device-wide, then the flag is raised
+__device__ __forceinline__ void dag_publish(int* f, int v) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) dag_st(f, v);
+}
+
+__global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int lds, double* R, int ldr, double* wbuf, int* flags,
+                                                   int* __restrict__ info, int max_spin) {
+    constexpr int RS = 66;
+    constexpr int ESD = 146;
+    constexpr int LDS_DOUBLES = (3 * 64 * RS > 64 * ESD + CHOLB_SCRATCH_DOUBLES(true)) ? 3 * 64 * RS
+                                                                                        : 64 * ESD + CHOLB_SCRATCH_DOUBLES(true);
+    __shared__ __attribute__((aligned(16))) double Lall[LDS_DOUBLES];
+    double* const L0 = Lall;
+    double* const L1 = Lall + 64 * RS;
+    double* const L2 = Lall + 2 * 64 * RS;
+    __shared__ int sh_fail, sh_w;
+    const int nblk = (D + NB - 1) / NB;
+    int* const wready = flags + DAG_WREADY;
+    int* const xready = wready + nblk;                            // [p][J]
+    int* const tstep = xready + nblk * nblk;                      // [I][J]: number of rank-64 updates applied to tile (I, J)
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+    const int wr = (w >> 1) & 1, wc = w & 1, rr = w >> 2;
+    const int lrow0 = 32 * wr + 16 * rr + ks;
+
+    if (blockIdx.x == 0) {
+        // ================================ the chain ================================
+        for (int cI = 0; cI < nblk; ++cI) {
+            const int I0 = cI * NB;
+            if (cI >= 2) {
+                if (!dag_wait(flags, tstep + (cI - 1) * nblk + cI, cI - 1, tstep + cI * nblk + cI, cI - 1, nullptr, 0, &sh_w, max_spin)) {
+                    if (tid == 0) *info = D + 1;
+                    return;
+                }
+            }
+            const double* Asrc = (cI <= 1) ? S : R;
+            const int lda = (cI <= 1) ? lds : ldr;
+            double tv[2][4];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = I0 + lrow0 + 4 * r, col = I0 + 32 * wc + 16 * ct + c;
+                    tv[ct][r] = (row < D && col < D) ? Asrc[(size_t)row * lda + col] : ((row == col) ? 1.0 : 0.0);
+                }
+            if (cI > 0) {
+                const double* Bsrc = (cI == 1) ? S : R;
+                const int ldb = (cI == 1) ? lds : ldr;
+                const double* Wk = wbuf + (size_t)(cI - 1) * NB * NB;
+                double vw[8], vi[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vw[q] = Wk[tid + 512 * q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int pr = (tid >> 6) + 8 * q, gi = I0 + (tid & 63);
+                    vi[q] = (gi < D) ? Bsrc[(size_t)((cI - 1) * NB + pr) * ldb + gi] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = tid + 512 * q;
+                    L0[(e >> 6) * RS + (e & 63)] = vw[q];
+                    L1[(tid & 63) * RS + (tid >> 6) + 8 * q] = vi[q];
+                }
+                __syncthreads();
+                v4d acc[2];
+                acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+                potrf_mma64x8(L0, L1, acc, wr, rr, wc, c, ks, 4 * (2 * wr + rr + 1));       // X = W_{c-1} T_{c-1,c}
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = lrow0 + 4 * r, col = 32 * wc + 16 * ct + c, gc = I0 + col;
+                        L2[col * RS + row] = acc[ct][r];
+                        if (gc < D) R[(size_t)((cI - 1) * NB + row) * ldr + gc] = acc[ct][r];
+                    }
+                for (int e = tid; e < NB * NB; e += 512) {                                  // the mirror block (c, c-1)
+                    const int jr = e >> 6, pcol = e & 63;
+                    if (I0 + jr < D) R[(size_t)(I0 + jr) * ldr + (cI - 1) * NB + pcol] = 0.0;
+                }
+                dag_publish(xready + (cI - 1) * nblk + cI, 1);                              // (its barrier also orders L2 for the product below)
+                __syncthreads();
+                acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+                potrf_mma64x8(L2, L2, acc, wr, rr, wc, c, ks);                              // T_cc -= X^T X
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tv[ct][r] -= acc[ct][r];
+            }
+            const int nb = (D - I0) < NB ? (D - I0) : NB;
+            double* const E = Lall;
+            double* const scr = Lall + 64 * ESD;
+            __syncthreads();                                      // everyone is done with the staging tiles
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = lrow0 + 4 * r, j = 32 * wc + 16 * ct + c;
+                    E[i * ESD + j] = (i < nb && j < nb) ? (j >= i ? tv[ct][r] : 0.0) : (i == j ? 1.0 : 0.0);
+                }
+            __syncthreads();
+            chol64_blk<ESD, false, true>(E, scr, nb, &sh_fail);
+            if (tid == 0 && sh_fail != 0 && *info == 0) *info = I0 + sh_fail;
+            for (int e = tid; e < NB * NB; e += 512) {
+                const int i = e >> 6, j = e & 63;
+                if (i < nb && j < nb) R[(size_t)(I0 + i) * ldr + I0 + j] = (j >= i) ? E[i * ESD + j] : 0.0;
+            }
+            if (cI + 1 < nblk) {
+                double* Wk = wbuf + (size_t)cI * NB * NB;
+                for (int e = tid; e < NB * NB; e += 512) Wk[e] = E[(e >> 6) * ESD + 64 + (e & 63)];
+                dag_publish(wready + cI, 1);
+                __syncthreads();
+            }
+        }
+        return;
+    }
+    // ================================ the workers ================================
+    int p = 0, base = 0;
+    for (;;) {
+        if (tid == 0) sh_w = atomicAdd(flags + DAG_TICKET, 1);
+        __syncthreads();
+        const int t = sh_w;
+        __syncthreads();
+        int m = nblk - 1 - p;
+        while (p < nblk - 1) {
+            m = nblk - 1 - p;
+            const int cnt = (m - 1) + m * (m + 1) / 2 - 1;
+            if (t - base < cnt) break;
+            base += cnt;
+            ++p;
+        }
+        if (p >= nblk - 1) return;
+        int r_ = t - base;
+        const double* Wk = wbuf + (size_t)p * NB * NB;
+        if (r_ < m - 1) {
+            // ---- solve (p, J): X = W_p T_pJ -> block (p, J) of R in place, mirror block zeroed ----
+            const int J = p + 2 + r_, J0 = J * NB;
+            if (!dag_wait(flags, wready + p, 1, p > 0 ? tstep + p * nblk + J : nullptr, p, nullptr, 0, &sh_w, max_spin)) return;
+            const double* Bsrc = (p == 0) ? S : R;
+            const int ldb = (p == 0) ? lds : ldr;
+            double vw[8], vj[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) vw[q] = Wk[tid + 512 * q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int pr = (tid >> 6) + 8 * q, gj = J0 + (tid & 63);
+                vj[q] = (gj < D) ? Bsrc[(size_t)(p * NB + pr) * ldb + gj] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = tid + 512 * q;
+                L0[(e >> 6) * RS + (e & 63)] = vw[q];
+                L1[(tid & 63) * RS + (tid >> 6) + 8 * q] = vj[q];
+            }
+            __syncthreads();
+            v4d acc[2];
+            acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+            potrf_mma64x8(L0, L1, acc, wr, rr, wc, c, ks, 4 * (2 * wr + rr + 1));
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = lrow0 + 4 * r, col = 32 * wc + 16 * ct + c, gc = J0 + col;
+                    if (gc < D) R[(size_t)(p * NB + row) * ldr + gc] = acc[ct][r];
+                }
+            for (int e = tid; e < NB * NB; e += 512) {
+                const int jr = e >> 6, pcol = e & 63;
+                if (J0 + jr < D) R[(size_t)(J0 + jr) * ldr + p * NB + pcol] = 0.0;
+            }
+            dag_publish(xready + p * nblk + J, 1);
+            __syncthreads();
+        } else {
+            // ---- update (p; I, J): T_IJ -= X_pI^T X_pJ ----
+            r_ = r_ - (m - 1) + 1;                                // index in the m x m upper triangle, (0, 0) skipped
+            int ti = 0, rowbase = 0;
+            while (rowbase + (m - ti) <= r_) { rowbase += m - ti; ++ti; }
+            const int tj = ti + (r_ - rowbase);
+            const int I = p + 1 + ti, J = p + 1 + tj, I0 = I * NB, J0 = J * NB;
+            const bool same = (I == J);
+            if (!dag_wait(flags, xready + p * nblk + I, 1, same ? nullptr : xready + p * nblk + J, 1,
+                          p > 0 ? tstep + I * nblk + J : nullptr, p, &sh_w, max_spin))
+                return;
+            const double* Asrc = (p == 0) ? S : R;
+            const int lda = (p == 0) ? lds : ldr;
+            double tv[2][4], vi[8], vj[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int pr = (tid >> 6) + 8 * q, gi = I0 + (tid & 63), gj = J0 + (tid & 63);
+                vi[q] = (gi < D) ? R[(size_t)(p * NB + pr) * ldr + gi] : 0.0;
+                vj[q] = (!same && gj < D) ? R[(size_t)(p * NB + pr) * ldr + gj] : 0.0;
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = I0 + lrow0 + 4 * r, col = J0 + 32 * wc + 16 * ct + c;
+                    tv[ct][r] = (row < D && col < D) ? Asrc[(size_t)row * lda + col] : ((row == col) ? 1.0 : 0.0);
+                }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                L2[(tid & 63) * RS + (tid >> 6) + 8 * q] = vi[q];
+                if (!same) L1[(tid & 63) * RS + (tid >> 6) + 8 * q] = vj[q];
+            }
+            __syncthreads();
+            v4d acc[2];
+            acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+            potrf_mma64x8(L2, same ? L2 : L1, acc, wr, rr, wc, c, ks);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = I0 + lrow0 + 4 * r, col = J0 + 32 * wc + 16 * ct + c;
+                    if (row < D && col < D) R[(size_t)row * ldr + col] = tv[ct][r] - acc[ct][r];
+                }
+            dag_publish(tstep + I * nblk + J, p + 1);
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void k_potrf_dag_clear(int* info, int* flags, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *info = 0;
+    if (i < n) flags[i] = 0;
+}
+
 int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int lds, double* R, int ldr,
                      int* info_dev) {
     // one launch per block step (two for the early steps of a large matrix); workspace (the idle panel-partial slab): two row
@@ -440,6 +720,28 @@ int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int
     const int nblk = (D + NB - 1) / NB, ldrow = nblk * NB;
     double* rowbuf = ctx->pp;
     double* wbuf = rowbuf + (size_t)2 * NB * ldrow;
+    if (ctx->tune_potrf_dag && !ctx->tune_no_fast && !ctx->timeline_stamps(3)) {
+        // one persistent launch (k_potrf_dag): W blocks and the flags live where the launch-per-step form keeps its row buffers
+        double* wb = ctx->pp;
+        int* flags = reinterpret_cast<int*>(wb + (size_t)nblk * NB * NB);
+        const int nflags = DAG_WREADY + nblk + 2 * nblk * nblk;
+        int ntasks = 0;
+        for (int p = 0; p + 1 < nblk; ++p) {
+            const int m = nblk - 1 - p;
+            ntasks += (m - 1) + m * (m + 1) / 2 - 1;
+        }
+        int grid = 1 + ntasks;
+        if (grid > ctx->num_cu) grid = ctx->num_cu;              // at most one workgroup per CU: all resident (100 KB of LDS each)
+        hipLaunchKernelGGL(k_potrf_dag_clear, dim3((nflags + 255) / 256), dim3(256), 0, st, info_dev, flags, nflags);
+        hipLaunchKernelGGL(k_potrf_dag, dim3(grid), dim3(512), 0, st, D, S, lds, R, ldr, wb, flags, info_dev,
+                           ctx->tune_potrf_spin > 0 ? ctx->tune_potrf_spin : 200000);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) {
+            gsmvi_set_error("potrf launch failed: %s%s", hipGetErrorString(e2), "");
+            return GSMVI_ERR_HIP;
+        }
+        return GSMVI_OK;
+    }
     hipLaunchKernelGGL(k_potrf_clear_info, dim3(1), dim3(1), 0, st, info_dev);
     double* xbuf = wbuf + (size_t)2 * NB * NB;                    // nblk blocks of 64 x 64: X_J^T of the split steps
     for (int k = 0; k < nblk; ++k) {

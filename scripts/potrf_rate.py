@@ -6,6 +6,8 @@ import numpy as np, torch, gsmvi_amd
 eng = gsmvi_amd.get_engine()
 split_m = int(os.environ.get("SPLIT_M", "0"))
 eng.set_tuning("potrf_split_m", split_m)      # 0 = the library's default
+dag = int(os.environ.get("POTRF_DAG", "1"))
+eng.set_tuning("potrf_dag", dag)               # 1 = one persistent launch with look-ahead (round 6), 0 = one launch per block step
 for D in [int(a) for a in sys.argv[1:]] or [256, 1024, 2048, 4096]:
     g = torch.Generator(device="cuda"); g.manual_seed(0)
     A = torch.randn(D, D, dtype=torch.float64, device="cuda", generator=g)
@@ -20,4 +22,4 @@ for D in [int(a) for a in sys.argv[1:]] or [256, 1024, 2048, 4096]:
     for _ in range(n):
         eng.potrf(S, out=R, flag=flag)
     e1.record(); torch.cuda.synchronize()
-    print(f"potrf D={D} split_m={split_m}: {e0.elapsed_time(e1) / n * 1e3:.1f} us, flag {int(flag.item())}")
+    print(f"potrf D={D} dag={dag} split_m={split_m}: {e0.elapsed_time(e1) / n * 1e3:.1f} us, flag {int(flag.item())}")

@@ -228,6 +228,56 @@ def test_potrf_split_row_solve_of_large_matrices(eng, D):
         assert eng.read_flag(flag) == bad_at + 1
 
 
+@pytest.mark.parametrize("D", [64, 130, 1024, 1600, 2500])
+def test_potrf_task_graph_equals_the_launch_per_step_form(eng, D):
+    """Round 6: the factorisation is ONE persistent launch (k_potrf_dag: a chain workgroup factors the diagonal tiles, the others
+    take solve / update tasks from a ticket counter, hand-offs through agent-scope flags).  The arithmetic per tile and the order
+    of a tile's rank-64 updates are those of the launch-per-step form (knob "potrf_dag" = 0), so the factors agree to the last
+    bits -- and the first failing pivot is reported the same way."""
+    import torch
+    rs = np.random.RandomState(D)
+    A = rs.standard_normal((D, D + 8)) / np.sqrt(D)
+    S = eng.asarray(A @ A.T + 0.05 * np.eye(D))
+    out = {}
+    try:
+        for dag in (1, 0):
+            eng.set_tuning("potrf_dag", dag)
+            R, flag = eng.potrf(S)
+            out[dag] = (R.clone(), eng.read_flag(flag))
+    finally:
+        eng.set_tuning("potrf_dag", 1)
+    assert out[1][1] == 0 and out[0][1] == 0
+    Rn = out[1][0].cpu().numpy()
+    assert np.array_equal(np.tril(Rn, -1), np.zeros_like(Rn)) and rel_err(Rn.T @ Rn, S.cpu().numpy()) < 1e-12
+    assert float((out[1][0] - out[0][0]).abs().max()) <= 1e-13 * float(out[0][0].abs().max())
+    if D > 200:
+        Sb = S.clone()
+        Sb[D - 70, D - 70] = -1.0
+        _, flag = eng.potrf(Sb)
+        assert eng.read_flag(flag) == D - 70 + 1
+    R2, _ = eng.potrf(S)                                             # run-to-run: bit-identical (fixed summation order per tile)
+    assert torch.equal(R2, out[1][0])
+
+
+def test_potrf_task_graph_gives_up_instead_of_spinning_forever(eng):
+    """Every wait of k_potrf_dag is bounded: with the poll budget set to 1 ("potrf_spin") a workgroup that finds its inputs not
+    ready raises the abort flag, every workgroup leaves, and the call reports D + 1 -- no hang on a shared GPU.  The next call
+    (default budget) is unaffected."""
+    D = 1024
+    rs = np.random.RandomState(3)
+    A = rs.standard_normal((D, D + 8)) / np.sqrt(D)
+    S = eng.asarray(A @ A.T + 0.05 * np.eye(D))
+    try:
+        eng.set_tuning("potrf_spin", 1)
+        _, flag = eng.potrf(S)
+        assert eng.read_flag(flag) in (0, D + 1)                     # (0: everything happened to be ready at every first poll)
+    finally:
+        eng.set_tuning("potrf_spin", 0)
+    R, flag = eng.potrf(S)
+    Rn = R.cpu().numpy()
+    assert eng.read_flag(flag) == 0 and rel_err(Rn.T @ Rn, S.cpu().numpy()) < 1e-12
+
+
 def test_potrf_flags_non_pd_and_nan(eng, golden):
     g = golden("g4_revert.npz")
     _, flag = eng.potrf(eng.asarray(g["S"]))            # the reference's failing covariance
