@@ -224,6 +224,122 @@ __global__ __launch_bounds__(COLS) void k_bam_forward(int D, int n, const double
     }
 }
 
+// ---- n > 128 (round 6): the same Z as a BLOCKED forward substitution on the MFMA pipe --------------------------------------
+// k_bam_forward above runs one column of D per thread through an n-step substitution with O(n^2) scalar loads: 0.8 ms at
+// n = 130, 3.4 ms at n = 256, 14 ms at n = 512 (D = 1024) -- 63 .. 90 % of an update whose other launches take ~0.3 ms.  Here,
+// with L = Rb^T from the blocked Cholesky and its diagonal blocks' inverses W_rr = L_rr^-1 (what k_potrf_dag's chain produces
+// anyway: W_k = R_kk^-T), block row r of 64 rows is
+//     Z_r = W_rr ( P_r + (M1^T)_r Vf - sum_{q < r} L_rq Z_q )
+// one launch per block row, a workgroup per 16 columns of D: the inner dimension n + 64 r is split over the eight waves
+// (operands straight from L2: for a fixed k both M1[k][64 r + i] and Rb[k][64 r + i] are contiguous in i), the partial tiles are
+// summed in fixed order through LDS, P_r is added, and the 64 x 64 by 64 x 16 product with W_rr (staged in LDS) finishes the block.
+__global__ __launch_bounds__(512) void k_bam_fwd_block(int D, int n, int r, const double* __restrict__ P,
+                                                       const double* __restrict__ M1, const double* __restrict__ Rb,
+                                                       const double* __restrict__ Wblk, double* Ft, double* __restrict__ Fs) {
+    constexpr int RS = 66;
+    __shared__ double red[8 * 64 * 17];
+    __shared__ double Ws[64 * RS];
+    __shared__ double Ts[64 * 17];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+    const int j0 = blockIdx.x * 16, jc = (j0 + c < D) ? j0 + c : D - 1;
+    const int r0 = 64 * r, K = n + r0, ksteps = (K + 3) >> 2;
+    double wv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) wv[q] = Wblk[(size_t)r * 4096 + tid + 512 * q];
+    v4d acc[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[rt] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int s0 = w; s0 < ksteps; s0 += 32) {                    // four k-steps of this wave per trip: 20 loads in flight
+        double a[4][4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 4 * (s0 + 8 * u) + ks;
+            const bool live = k < K, low = k < n;
+            const int kk = live ? (low ? k : k - n) : 0;
+            b[u] = Ft[(size_t)(low ? kk : n + kk) * D + jc];
+            const double* arow = (low ? M1 : Rb) + (size_t)kk * n + r0;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const int i = 16 * rt + c;
+                const double v = arow[(r0 + i < n) ? i : 0];
+                a[u][rt] = (live && r0 + i < n) ? (low ? v : -v) : 0.0;
+            }
+            if (!live) b[u] = 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) acc[rt] = GSMVI_MFMA_F64(a[u][rt], b[u], acc[rt]);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[(w * 64 + 16 * rt + ks + 4 * q) * 17 + c] = acc[rt][q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int e = tid + 512 * q;
+        Ws[(e >> 6) * RS + (e & 63)] = wv[q];
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * 16; e += 512) {
+        const int row = e >> 4, col = e & 15;
+        double t = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < 8; ww += 2) t += red[(ww * 64 + row) * 17 + col] + red[((ww + 1) * 64 + row) * 17 + col];
+        const int gc = (j0 + col < D) ? j0 + col : D - 1;
+        Ts[row * 17 + col] = (r0 + row < n) ? t + P[(size_t)(r0 + row) * D + gc] : 0.0;
+    }
+    __syncthreads();
+    if (w < 4) {
+        v4d z = {0.0, 0.0, 0.0, 0.0};
+        const double* ap = Ws + (16 * w + c) * RS + ks;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) z = GSMVI_MFMA_F64(ap[4 * s], Ts[(4 * s + ks) * 17 + c], z);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = r0 + 16 * w + ks + 4 * q;
+            if (row < n && j0 + c < D) {
+                Ft[(size_t)(n + row) * D + j0 + c] = z[q];
+                Fs[(size_t)(n + row) * D + j0 + c] = -z[q];
+            }
+        }
+    }
+}
+
+// the new mean behind the blocked substitution (bam.py:112): one column of D per thread, the 2n rows of [Vf; Z] streamed
+__global__ __launch_bounds__(256) void k_bam_mean_big(int D, int n, const double* __restrict__ P, const double* __restrict__ Ft,
+                                                      const double* __restrict__ zg, const double* __restrict__ vg,
+                                                      const double* __restrict__ mu0, const double* __restrict__ xbar,
+                                                      bam_reg regs, double* __restrict__ mu) {
+    const double reg = regs.get();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= D) return;
+    double dv0 = 0.0, dv1 = 0.0, dz0 = 0.0, dz1 = 0.0;
+    int k = 0;
+    for (; k + 4 <= n; k += 4) {
+        double v[4], z[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] = Ft[(size_t)(k + u) * D + i];
+            z[u] = Ft[(size_t)(n + k + u) * D + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u += 2) {
+            dv0 += v[u] * vg[k + u];
+            dv1 += v[u + 1] * vg[k + u + 1];
+            dz0 += z[u] * zg[k + u];
+            dz1 += z[u + 1] * zg[k + u + 1];
+        }
+    }
+    for (; k < n; ++k) {
+        dv0 += Ft[(size_t)k * D + i] * vg[k];
+        dz0 += Ft[(size_t)(n + k) * D + i] * zg[k];
+    }
+    const double r1 = reg / (1.0 + reg);
+    const double s0g = P[(size_t)(n - 1) * D + i] / sqrt(r1);
+    mu[i] = mu0[i] / (1.0 + reg) + r1 * (s0g + (dv0 + dv1) - (dz0 + dz1) + xbar[i]);
+}
+
 // ---- N = M1^T M1 + sym(N0) and M1^T (n x n), on the device ---------------------------------------
 // One 16 x 16 block of N per wave on the MFMA pipe (round 3; it was an n-long scalar loop per element: 20 us at n = 128):
 // k runs over the rows of M1 in batches of 64, operands straight from L2 (a wave's 16 lanes read 128 contiguous bytes of a
@@ -824,9 +940,18 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
         hipLaunchKernelGGL(k_bam_nmat, dim3((((n + 15) / 16) * ((n + 15) / 16) + 3) / 4), dim3(256), 0, st, n, M1, N0, Nd, M1T);
         if ((rc = gsmvi_bam_small_device(ctx, st, n, reg, Nd, M1, N0, scratch, Ld, info_p, hint, ctx->tune_bam_kenq, nullptr, nullptr, nullptr, nullptr)))
             return rc;
+        // round 6: blocked substitution on the MFMA pipe when the factorisation left its diagonal blocks' inverses (k_potrf_dag)
+        if (ctx->potrf_w && ctx->potrf_w_n == n && !ctx->tune_no_fast) {
+            for (int rb = 0; rb < (n + 63) / 64; ++rb)
+                hipLaunchKernelGGL(k_bam_fwd_block, dim3((D + 15) / 16), dim3(512), 0, st, D, n, rb, P, M1, ctx->potrf_r, ctx->potrf_w,
+                                   Ft, Fs);
+            hipLaunchKernelGGL(k_bam_mean_big, dim3((D + 255) / 256), dim3(256), 0, st, D, n, P, Ft, Ldinv + n, Ldinv + 2 * n, mu0,
+                               xbar, reg, mu);
+        } else {
 #define BFW(CV) hipLaunchKernelGGL(k_bam_forward<CV>, dim3((D + CV - 1) / CV), dim3(CV), sizeof(double) * 2 * n * CV, st, D, n, P, M1, Ld, Ldinv, Ldinv + n, Ldinv + 2 * n, mu0, xbar, reg, Ft, Fs, mu)
         if (n <= 160) BFW(64); else if (n <= 320) BFW(32); else if (n <= 640) BFW(16); else BFW(8);   // (LDS: 16 n COLS bytes <= 160 KB)
 #undef BFW
+        }
     }
     const int nt = (D + 63) / 64;
     ctx->path |= (!ctx->tune_no_fast && D % 2 == 0 && n2 <= 288) ? GSMVI_PATH_LOWRANK_FAST : GSMVI_PATH_LOWRANK_GENERIC;

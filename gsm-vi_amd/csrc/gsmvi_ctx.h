@@ -62,6 +62,9 @@ struct gsmvi_ctx {
     gsmvi_panel_extras px;     // see above
     int px_used = 0;
     unsigned path = 0;         // GSMVI_PATH_* bits of the kernel families launched since the last reset (gsmvi_last_path)
+    const double* potrf_w = nullptr;   // after a k_potrf_dag factorisation: its W blocks (W_k = R_kk^-T, [nblk][64 x 64], in the slab area:
+    const double* potrf_r = nullptr;   //   valid until the next panel product), the factor it wrote and its size; null after the
+    int potrf_w_n = 0;                 //   launch-per-step form
     int tune_potrf_dag = 1;       // the factorisation as ONE persistent launch with look-ahead (k_potrf_dag, round 6); 0: one launch per block step (A/B)
     int tune_potrf_spin = 0;      // > 0: polls before a waiting workgroup of k_potrf_dag gives up (tests of the abort path)
     int tune_potrf_split_m = 0;   // > 0: tile rows from which a Cholesky block step runs its row solve as a separate launch (A/B)

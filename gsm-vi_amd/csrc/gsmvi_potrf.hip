@@ -461,8 +461,17 @@ __global__ void k_potrf_clear_info(int* info) { *info = 0; }
 #define DAG_TICKET 0
 #define DAG_ABORT 1
 #define DAG_WREADY 2
-__device__ __forceinline__ int dag_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void dag_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+// Hand-offs (cdna_hip_programming.md, Guideline 16, form R1): every handed-off byte is stored WRITE-THROUGH (sc1: a relaxed
+// agent-scope atomic store of the double), every storing wave drains its stores (s_waitcnt vmcnt(0)) in front of the workgroup
+// barrier, ONE lane raises the flag with a relaxed agent-scope store; the consumer's lane 0 polls the flag words with relaxed
+// agent-scope loads, and EVERY load of handed-off data is an sc1 load (relaxed agent-scope atomic load), so no acquire fence is
+// needed.  (The first version used acquire loads in the poll and release / acquire fences around it: each poll invalidated
+// the caches, each publish wrote the XCD's L2 back -- 1070 us at D = 1024 against 324 for the launch-per-step form.)
+#define DAG_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ int dag_ld(const int* p) { return __hip_atomic_load(p, DAG_RLX); }
+__device__ __forceinline__ void dag_st(int* p, int v) { __hip_atomic_store(p, v, DAG_RLX); }
+__device__ __forceinline__ double dag_ldd(const double* p) { return __hip_atomic_load(p, DAG_RLX); }
+__device__ __forceinline__ void dag_std(double* p, double v) { __hip_atomic_store(p, v, DAG_RLX); }
 
 // workgroup-wide bounded wait for up to three flags (null = none); false = aborted / timed out (block-uniform)
 __device__ __forceinline__ bool dag_wait(int* flags, const int* f0, int n0, const int* f1, int n1, const int* f2, int n2,
@@ -477,19 +486,19 @@ __device__ __forceinline__ bool dag_wait(int* flags, const int* f0, int n0, cons
                 dag_st(flags + DAG_ABORT, 1);
                 break;
             }
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(2);
         }
         *sh = ok;
     }
     __syncthreads();
     const int ok = *sh;
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // (no instruction: keeps the compiler from hoisting loads above the poll)
     return ok != 0;
 }
-// every thread's stores become visible device-wide, then the flag is raised
+// every storing wave drains its write-through stores, then one lane raises the flag
 __device__ __forceinline__ void dag_publish(int* f, int v) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) dag_st(f, v);
 }
@@ -498,12 +507,12 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
                                                    int* __restrict__ info, int max_spin) {
     constexpr int RS = 66;
     constexpr int ESD = 146;
-    constexpr int LDS_DOUBLES = (3 * 64 * RS > 64 * ESD + CHOLB_SCRATCH_DOUBLES(true)) ? 3 * 64 * RS
-                                                                                        : 64 * ESD + CHOLB_SCRATCH_DOUBLES(true);
-    __shared__ __attribute__((aligned(16))) double Lall[LDS_DOUBLES];
-    double* const L0 = Lall;
-    double* const L1 = Lall + 64 * RS;
-    double* const L2 = Lall + 2 * 64 * RS;
+    // LDS: the [tile | W] matrix of chol64_blk and its panel scratch; the two staging tiles of the products share the matrix's
+    // space (dead while they are live); the W tile (left operand of the solves) has its own, so the chain keeps W_{c-1} in LDS
+    __shared__ __attribute__((aligned(16))) double Lall[64 * ESD + CHOLB_SCRATCH_DOUBLES(true)];
+    __shared__ __attribute__((aligned(16))) double L0[64 * RS];
+    double* const L1 = Lall;
+    double* const L2 = Lall + 64 * RS;
     __shared__ int sh_fail, sh_w;
     const int nblk = (D + NB - 1) / NB;
     int* const wready = flags + DAG_WREADY;
@@ -523,35 +532,34 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
                     return;
                 }
             }
-            const double* Asrc = (cI <= 1) ? S : R;
-            const int lda = (cI <= 1) ? lds : ldr;
+            const bool a_s = (cI <= 1);                           // tile (c, c) still in S
+            const double* Asrc = a_s ? S : R;
+            const int lda = a_s ? lds : ldr;
             double tv[2][4];
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = I0 + lrow0 + 4 * r, col = I0 + 32 * wc + 16 * ct + c;
-                    tv[ct][r] = (row < D && col < D) ? Asrc[(size_t)row * lda + col] : ((row == col) ? 1.0 : 0.0);
+                    const double* ap = Asrc + (size_t)(row < D ? row : 0) * lda + (col < D ? col : 0);
+                    const double v = a_s ? *ap : dag_ldd(ap);
+                    tv[ct][r] = (row < D && col < D) ? v : ((row == col) ? 1.0 : 0.0);
                 }
             if (cI > 0) {
-                const double* Bsrc = (cI == 1) ? S : R;
-                const int ldb = (cI == 1) ? lds : ldr;
-                const double* Wk = wbuf + (size_t)(cI - 1) * NB * NB;
-                double vw[8], vi[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) vw[q] = Wk[tid + 512 * q];
+                const bool b_s = (cI == 1);
+                const double* Bsrc = b_s ? S : R;
+                const int ldb = b_s ? lds : ldr;
+                double vi[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int pr = (tid >> 6) + 8 * q, gi = I0 + (tid & 63);
-                    vi[q] = (gi < D) ? Bsrc[(size_t)((cI - 1) * NB + pr) * ldb + gi] : 0.0;
+                    const double* bp = Bsrc + (size_t)((cI - 1) * NB + pr) * ldb + (gi < D ? gi : 0);
+                    const double v = b_s ? *bp : dag_ldd(bp);
+                    vi[q] = (gi < D) ? v : 0.0;
                 }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int e = tid + 512 * q;
-                    L0[(e >> 6) * RS + (e & 63)] = vw[q];
-                    L1[(tid & 63) * RS + (tid >> 6) + 8 * q] = vi[q];
-                }
-                __syncthreads();
+                for (int q = 0; q < 8; ++q) L1[(tid & 63) * RS + (tid >> 6) + 8 * q] = vi[q];
+                __syncthreads();                                  // (L0 holds W_{c-1}: written at the end of the previous iteration)
                 v4d acc[2];
                 acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
                 potrf_mma64x8(L0, L1, acc, wr, rr, wc, c, ks, 4 * (2 * wr + rr + 1));       // X = W_{c-1} T_{c-1,c}
@@ -561,14 +569,13 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
                     for (int r = 0; r < 4; ++r) {
                         const int row = lrow0 + 4 * r, col = 32 * wc + 16 * ct + c, gc = I0 + col;
                         L2[col * RS + row] = acc[ct][r];
-                        if (gc < D) R[(size_t)((cI - 1) * NB + row) * ldr + gc] = acc[ct][r];
+                        if (gc < D) dag_std(R + (size_t)((cI - 1) * NB + row) * ldr + gc, acc[ct][r]);
                     }
-                for (int e = tid; e < NB * NB; e += 512) {                                  // the mirror block (c, c-1)
+                for (int e = tid; e < NB * NB; e += 512) {                                  // the mirror block (c, c-1): nobody's input
                     const int jr = e >> 6, pcol = e & 63;
                     if (I0 + jr < D) R[(size_t)(I0 + jr) * ldr + (cI - 1) * NB + pcol] = 0.0;
                 }
                 dag_publish(xready + (cI - 1) * nblk + cI, 1);                              // (its barrier also orders L2 for the product below)
-                __syncthreads();
                 acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
                 potrf_mma64x8(L2, L2, acc, wr, rr, wc, c, ks);                              // T_cc -= X^T X
 #pragma unroll
@@ -590,16 +597,21 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
             __syncthreads();
             chol64_blk<ESD, false, true>(E, scr, nb, &sh_fail);
             if (tid == 0 && sh_fail != 0 && *info == 0) *info = I0 + sh_fail;
-            for (int e = tid; e < NB * NB; e += 512) {
+            // W_c first (it is what the other workgroups wait for), into the chain's own operand tile and out to the workers
+            {
+                double* Wk = wbuf + (size_t)cI * NB * NB;
+                for (int e = tid; e < NB * NB; e += 512) {
+                    const double wv = E[(e >> 6) * ESD + 64 + (e & 63)];
+                    L0[(e >> 6) * RS + (e & 63)] = wv;
+                    dag_std(Wk + e, wv);
+                }
+                if (cI + 1 < nblk) dag_publish(wready + cI, 1);
+            }
+            for (int e = tid; e < NB * NB; e += 512) {           // the factor's diagonal block: nobody's input in this launch
                 const int i = e >> 6, j = e & 63;
                 if (i < nb && j < nb) R[(size_t)(I0 + i) * ldr + I0 + j] = (j >= i) ? E[i * ESD + j] : 0.0;
             }
-            if (cI + 1 < nblk) {
-                double* Wk = wbuf + (size_t)cI * NB * NB;
-                for (int e = tid; e < NB * NB; e += 512) Wk[e] = E[(e >> 6) * ESD + 64 + (e & 63)];
-                dag_publish(wready + cI, 1);
-                __syncthreads();
-            }
+            __syncthreads();
         }
         return;
     }
@@ -621,19 +633,22 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
         if (p >= nblk - 1) return;
         int r_ = t - base;
         const double* Wk = wbuf + (size_t)p * NB * NB;
+        const bool from_s = (p == 0);                             // tiles of step 0 are still in S (plain loads)
         if (r_ < m - 1) {
             // ---- solve (p, J): X = W_p T_pJ -> block (p, J) of R in place, mirror block zeroed ----
             const int J = p + 2 + r_, J0 = J * NB;
             if (!dag_wait(flags, wready + p, 1, p > 0 ? tstep + p * nblk + J : nullptr, p, nullptr, 0, &sh_w, max_spin)) return;
-            const double* Bsrc = (p == 0) ? S : R;
-            const int ldb = (p == 0) ? lds : ldr;
+            const double* Bsrc = from_s ? S : R;
+            const int ldb = from_s ? lds : ldr;
             double vw[8], vj[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) vw[q] = Wk[tid + 512 * q];
+            for (int q = 0; q < 8; ++q) vw[q] = dag_ldd(Wk + tid + 512 * q);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int pr = (tid >> 6) + 8 * q, gj = J0 + (tid & 63);
-                vj[q] = (gj < D) ? Bsrc[(size_t)(p * NB + pr) * ldb + gj] : 0.0;
+                const double* bp = Bsrc + (size_t)(p * NB + pr) * ldb + (gj < D ? gj : 0);
+                const double v = from_s ? *bp : dag_ldd(bp);
+                vj[q] = (gj < D) ? v : 0.0;
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -650,7 +665,7 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = lrow0 + 4 * r, col = 32 * wc + 16 * ct + c, gc = J0 + col;
-                    if (gc < D) R[(size_t)(p * NB + row) * ldr + gc] = acc[ct][r];
+                    if (gc < D) dag_std(R + (size_t)(p * NB + row) * ldr + gc, acc[ct][r]);
                 }
             for (int e = tid; e < NB * NB; e += 512) {
                 const int jr = e >> 6, pcol = e & 63;
@@ -669,21 +684,25 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
             if (!dag_wait(flags, xready + p * nblk + I, 1, same ? nullptr : xready + p * nblk + J, 1,
                           p > 0 ? tstep + I * nblk + J : nullptr, p, &sh_w, max_spin))
                 return;
-            const double* Asrc = (p == 0) ? S : R;
-            const int lda = (p == 0) ? lds : ldr;
+            const double* Asrc = from_s ? S : R;
+            const int lda = from_s ? lds : ldr;
             double tv[2][4], vi[8], vj[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int pr = (tid >> 6) + 8 * q, gi = I0 + (tid & 63), gj = J0 + (tid & 63);
-                vi[q] = (gi < D) ? R[(size_t)(p * NB + pr) * ldr + gi] : 0.0;
-                vj[q] = (!same && gj < D) ? R[(size_t)(p * NB + pr) * ldr + gj] : 0.0;
+                const double a = dag_ldd(R + (size_t)(p * NB + pr) * ldr + (gi < D ? gi : 0));
+                const double b = same ? 0.0 : dag_ldd(R + (size_t)(p * NB + pr) * ldr + (gj < D ? gj : 0));
+                vi[q] = (gi < D) ? a : 0.0;
+                vj[q] = (!same && gj < D) ? b : 0.0;
             }
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = I0 + lrow0 + 4 * r, col = J0 + 32 * wc + 16 * ct + c;
-                    tv[ct][r] = (row < D && col < D) ? Asrc[(size_t)row * lda + col] : ((row == col) ? 1.0 : 0.0);
+                    const double* ap = Asrc + (size_t)(row < D ? row : 0) * lda + (col < D ? col : 0);
+                    const double v = from_s ? *ap : dag_ldd(ap);
+                    tv[ct][r] = (row < D && col < D) ? v : ((row == col) ? 1.0 : 0.0);
                 }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -699,7 +718,7 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = I0 + lrow0 + 4 * r, col = J0 + 32 * wc + 16 * ct + c;
-                    if (row < D && col < D) R[(size_t)row * ldr + col] = tv[ct][r] - acc[ct][r];
+                    if (row < D && col < D) dag_std(R + (size_t)row * ldr + col, tv[ct][r] - acc[ct][r]);
                 }
             dag_publish(tstep + I * nblk + J, p + 1);
             __syncthreads();
@@ -740,8 +759,13 @@ int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int
             gsmvi_set_error("potrf launch failed: %s%s", hipGetErrorString(e2), "");
             return GSMVI_ERR_HIP;
         }
+        ctx->potrf_w = wb;
+        ctx->potrf_r = R;
+        ctx->potrf_w_n = D;
         return GSMVI_OK;
     }
+    ctx->potrf_w = nullptr;
+    ctx->potrf_w_n = 0;
     hipLaunchKernelGGL(k_potrf_clear_info, dim3(1), dim3(1), 0, st, info_dev);
     double* xbuf = wbuf + (size_t)2 * NB * NB;                    // nblk blocks of 64 x 64: X_J^T of the split steps
     for (int k = 0; k < nblk; ++k) {

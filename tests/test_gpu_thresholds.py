@@ -66,6 +66,9 @@ def test_update_kinds_around_every_dispatch_threshold(kind, D, B, why):
             mu, S = gsmvi_amd.gsm_update(X, G, mu0, S0, engine=eng)
             assert rel_err(mu, mu_o) < 1e-10 and rel_err(S, S_o) < 1e-11, why
             assert np.array_equal(S, S.T), why
+        elif kind == "bam" and B > HipEngine.bam_max_batch:
+            with pytest.raises(ValueError):                          # beyond the largest chain: refused by the driver, up front
+                gsmvi_amd.bam_update(X, G, mu0, S0, reg, engine=eng)
         elif kind == "bam":
             mu_o, S_o = borc.bam_lowrank_update_exact(X, G, mu0, S0, reg)
             mu, S = gsmvi_amd.bam_update(X, G, mu0, S0, reg, engine=eng)
