@@ -83,6 +83,11 @@ _SIGS = {
                                         _c_dp, _c_dp, C.c_int, _c_dp]),
     "gsmvi_sample_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, _c_dp,
                                    C.c_int, _c_dp, C.c_int]),
+    "gsmvi_sample_cols_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, _c_dp, C.c_int,
+                                        _c_dp, C.c_int]),
+    "gsmvi_gsm_factor_apply_cols_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _c_dp, C.c_int,
+                                                  _c_dp, _c_dp, C.c_int, _c_dp, _c_dp, C.c_int, _c_dp, _c_dp, C.c_int, _c_dp,
+                                                  _c_dp]),
     "gsmvi_commit_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _c_dp, _c_dp, _c_dp, C.c_int, _c_dp, _c_dp,
                                    C.c_int, _c_dp]),
     "gsmvi_bam_update_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _c_dp, C.c_int, _c_dp, C.c_int,

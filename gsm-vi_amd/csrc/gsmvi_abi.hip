@@ -56,6 +56,10 @@ int gsmvi_factor_local_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int Bl
 int gsmvi_factor_apply_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* Z, int ldz,
                             const double* rec, int ldrec, const double* mu0, const double* F0, int ldf0, double* mu,
                             double* F, int ldf, int* info_dev, int* n_reverts_dev);
+int gsmvi_factor_apply_cols_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, int col0, int ncols, const double* Z,
+                                 int ldz, const double* W, int ldw, const double* X, int ldx, const double* mu0,
+                                 const double* F0c, int ldf0, double* mu, double* Fc, int ldf, int* info_dev,
+                                 int* n_reverts_dev);
 int gsmvi_bam_impl(struct gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X, int ldx,
                    const double* G, int ldg, const double* mu0, const double* S0, int lds0, double reg,
                    double jitter, double* mu, double* S, int lds, int* info_dev);
@@ -692,6 +696,37 @@ int gsmvi_sample_f64(gsmvi_ctx* ctx, void* stream, int D, int B, const double* Z
     BAD_ARG(ldz < D || ldr < D || ldx < D, "leading dimension smaller than D");
     hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
     return gsmvi_panel_product_out(ctx, hs, D, D, B, Z, ldz, nullptr, 1.0, R, ldr, mu, X, ldx);
+}
+
+int gsmvi_sample_cols_f64(gsmvi_ctx* ctx, void* stream, int D, int B, int ncols, const double* Z, int ldz,
+                          const double* mu_cols, const double* Fcols, int ldf, double* Xcols, int ldx) {
+    int st = check_common(ctx, D, B, __func__);
+    if (st != GSMVI_OK) return st;
+    BAD_ARG(!Z || !mu_cols || !Fcols || !Xcols, "NULL array");
+    BAD_ARG(ncols <= 0 || ncols > D, "ncols out of range");
+    BAD_ARG(ldz < D || ldf < ncols || ldx < ncols, "leading dimension too small");
+    hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+    return gsmvi_panel_product_out(ctx, hs, D, ncols, B, Z, ldz, nullptr, 1.0, Fcols, ldf, mu_cols, Xcols, ldx);
+}
+
+int gsmvi_gsm_factor_apply_cols_f64(gsmvi_ctx* ctx, void* stream, int D, int B, int col0, int ncols, const double* Z, int ldz,
+                                    const double* W, const double* X, int ldx, const double* mu0, const double* F0cols,
+                                    int ldf0, double* mu, double* Fcols, int ldf, int* info_dev, int* n_reverts_dev) {
+    int st = check_common(ctx, D, B, __func__);
+    if (st != GSMVI_OK) return st;
+    BAD_ARG(!Z || !W || !X || !mu0 || !F0cols || !mu || !Fcols || !info_dev, "NULL argument");
+    BAD_ARG(col0 < 0 || ncols <= 0 || col0 + ncols > D, "column block out of range");
+    BAD_ARG(col0 % 64 != 0 || (ncols % 64 != 0 && col0 + ncols != D), "column blocks are tile aligned (multiples of 64; the last one may be ragged)");
+    BAD_ARG(ldz < D || ldx < D || ldf0 < ncols || ldf < ncols, "leading dimension too small");
+    BAD_ARG(Fcols == F0cols || mu == mu0, "outputs must not alias inputs");
+    BAD_ARG(D % 2 != 0 || ldf0 % 2 != 0 || ldf % 2 != 0 || !aligned16(F0cols) || !aligned16(Fcols),
+            "the column-sharded form takes even D, even leading dimensions and 16-byte aligned blocks");
+    if (2 * B > D || 2 * B > GSMVI_FACTOR_NMAX || D > 16384) {
+        gsmvi_set_error("%s: %s", __func__, "the factor form needs 2B <= D and 2B <= 256");
+        return GSMVI_ERR_UNSUPPORTED;
+    }
+    return gsmvi_factor_apply_cols_impl(ctx, reinterpret_cast<hipStream_t>(stream), D, B, col0, ncols, Z, ldz, W, D, X, ldx, mu0,
+                                        F0cols, ldf0, mu, Fcols, ldf, info_dev, n_reverts_dev);
 }
 
 int gsmvi_commit_f64(gsmvi_ctx* ctx, void* stream, int D, const int* info_dev, const double* mu_new,

@@ -62,6 +62,7 @@ struct gsmvi_ctx {
     gsmvi_panel_extras px;     // see above
     int px_used = 0;
     unsigned path = 0;         // GSMVI_PATH_* bits of the kernel families launched since the last reset (gsmvi_last_path)
+    int colwin_0 = 0, colwin_n = 0;    // column-tile window of the factor update launches (colwin_n = 0: all of F)
     const double* potrf_w = nullptr;   // after a k_potrf_dag factorisation: its W blocks (W_k = R_kk^-T, [nblk][64 x 64], in the slab area:
     const double* potrf_r = nullptr;   //   valid until the next panel product), the factor it wrote and its size; null after the
     int potrf_w_n = 0;                 //   launch-per-step form

@@ -409,12 +409,12 @@ __global__ __launch_bounds__(512) void k_cholw_pair(cholw_job a, cholw_job b) {
 __global__ __launch_bounds__(256) void k_gsmf_update(int D, int KF, const double* __restrict__ Ft,
                                                      const double* __restrict__ Fs, const double* __restrict__ F0,
                                                      int ldf0, double* __restrict__ F, int ldf,
-                                                     const int* __restrict__ bad) {
+                                                     const int* __restrict__ bad, int tj0, int ntc) {
+    // (tj0, ntc: the window of column tiles this launch updates -- all of them, or the owned column block of a column-sharded fit)
     constexpr int RS = 66;
     __shared__ double FA[64 * RS];
     __shared__ double FB[64 * RS];
-    const int ntiles = (D + 63) >> 6;
-    const int ti = blockIdx.x / ntiles, tj = blockIdx.x % ntiles;
+    const int ti = blockIdx.x / ntc, tj = tj0 + blockIdx.x % ntc;
     const int I0 = ti * 64, J0 = tj * 64;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
     const int wr = w >> 1, wc = w & 1;
@@ -484,11 +484,11 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fast(int D, int B, const do
                                                           const double* __restrict__ Tm,
                                                           const double* __restrict__ coef,
                                                           const double* __restrict__ mu0, double* __restrict__ mu,
-                                                          const int* __restrict__ bad, int* __restrict__ n_reverts) {
+                                                          const int* __restrict__ bad, int* __restrict__ n_reverts, int tj0, int ntc) {
     constexpr int RS = 80, KP = 32;
     __shared__ __attribute__((aligned(16))) double sm[2 * KP * RS];
-    const int nt = (D + 63) >> 6;                  // any even D (round 5): edge tiles re-read clamped rows / columns, store what lies inside
-    const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
+    // any even D (round 5): edge tiles re-read clamped rows / columns, store what lies inside.  (tj0, ntc): window of column tiles (round 6)
+    const int ti = blockIdx.x / ntc, tj = tj0 + blockIdx.x % ntc;
     const int I0 = ti * 64, J0 = tj * 64;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
     const int wr = w >> 1, wc = w & 1;
@@ -593,10 +593,10 @@ __global__ __launch_bounds__(512) void k_gsmf_small16(int n, int B, const double
 __global__ __launch_bounds__(256) void k_gsmf_mean(int D, int B, const double* __restrict__ Tm,
                                                    const double* __restrict__ coef,
                                                    const double* __restrict__ mu0, double* __restrict__ mu,
-                                                   const int* __restrict__ bad, int* __restrict__ n_reverts) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= D) return;
-    if (j == 0 && n_reverts && *bad) *n_reverts += 1;      // one launch per update on the stream: no race
+                                                   const int* __restrict__ bad, int* __restrict__ n_reverts, int j0, int j1) {
+    const int j = j0 + blockIdx.x * 256 + threadIdx.x;     // (j0 .. j1: the window of columns: all of them, or the owned block)
+    if (j >= j1) return;
+    if (j == j0 && n_reverts && *bad) *n_reverts += 1;     // one launch per update on the stream: no race
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     const int n = 2 * B;
     int b = 0;
@@ -630,14 +630,14 @@ __global__ __launch_bounds__(512) void k_gsmf_update_fs(int D, int B, const doub
                                                         int ldf, const double* __restrict__ coef,
                                                         const double* __restrict__ mu0, double* __restrict__ mu,
                                                         const int* __restrict__ bad, int* __restrict__ n_reverts,
-                                                        gsmf_bam_mean bm) {
+                                                        gsmf_bam_mean bm, int tj0, int ntc) {
     constexpr int N = 32 * NP, RS = 80, KS = N + 2;
     __shared__ __attribute__((aligned(16))) double bufA[N * RS];      // Tm1 tile [k][64 cols], later the Rt1 tile
     __shared__ __attribute__((aligned(16))) double bufB[N * RS];      // Fs tile
     __shared__ __attribute__((aligned(16))) double bufK[N * KS];      // K''
     __shared__ double msm[8 * 64];
-    const int nt = (D + 63) >> 6;                  // any even D (round 5): edge tiles as in k_gsmf_update_fast
-    const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
+    // any even D (round 5): edge tiles as in k_gsmf_update_fast; (tj0, ntc): window of column tiles (round 6)
+    const int ti = blockIdx.x / ntc, tj = tj0 + blockIdx.x % ntc;
     const int I0 = ti * 64, J0 = tj * 64;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
     const int wr = w >> 1, wc = w & 1;
@@ -1195,6 +1195,37 @@ int gsmvi_factor_apply_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const 
     return factor_back(ctx, st, D, B, mu0, F0, ldf0, mu, F, ldf, info_dev, n_reverts_dev, w.Gp, kcg, nullptr, 0);
 }
 
+// Column-sharded form (round 6; SURVEY 8(e) row 3 / (f) 3: the decomposition that divides the D^2 traffic and the D^2 memory
+// of a factor-form fit): the rank owns the columns [col0, col0 + ncols) of Fm -- D x ncols, its own leading dimension.
+//   sampler   x[:, C] = mu[C] + z Fm[:, C]                      owned slice (gsmvi_sample_cols_f64), all-gathered by the caller
+//   W = G Fm^T = sum over ranks of G[:, C] Fm[:, C]^T            partial sums (gsmvi_gsm_rows_stage_f64 on the block), all-reduced
+//   this call  Rt = [Z; W + Z], Tm[:, C] = [X - mu; V Fm[:, C]], the Gram matrix and the 2B x 2B chain (replicated: identical
+//              inputs, identical arithmetic on every rank), then Fm'[:, C] = Fm[:, C] + Rt^T (K'' Tm[:, C]) and mu'[C]:
+//              the update touches the owned block only -- no D x D matrix is ever sent, read or written whole.
+// W: the all-reduced B x D product; X: the gathered samples (only its columns C are used); mu0 / mu: full-length vectors,
+// entries C read / written.  col0 % 64 == 0 (tile aligned; the last block may be ragged).
+int gsmvi_factor_apply_cols_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, int col0, int ncols, const double* Z, int ldz,
+                                 const double* W, int ldw, const double* X, int ldx, const double* mu0, const double* F0c,
+                                 int ldf0, double* mu, double* Fc, int ldf, int* info_dev, int* n_reverts_dev) {
+    const int n = 2 * B;
+    const factor_ws w = factor_carve(ctx, D, n);
+    // Rt = [Z; V], top half of Tm = X - mu0: k_gsmf_prep with the finished W as its one "slab" (needs ldw == D)
+    hipLaunchKernelGGL(k_gsmf_prep, dim3((D + 255) / 256, B), dim3(256), 0, st, D, B, 1, Z, ldz, X, ldx, mu0, W, w.Rt, w.Tm);
+    int rc = chk("k_gsmf_prep");
+    if (rc) return rc;
+    // V Fm on the owned columns, finished rows straight into Tm's lower half
+    if ((rc = gsmvi_panel_product_out(ctx, st, D, ncols, B, w.Rt + (size_t)B * D, D, nullptr, 1.0, F0c, ldf0, nullptr,
+                                      w.Tm + (size_t)B * D + col0, D)))
+        return rc;
+    int kcg = 1;
+    if ((rc = factor_gram(ctx, st, D, n, w, &kcg))) return rc;
+    ctx->colwin_0 = col0 / 64;
+    ctx->colwin_n = (ncols + 63) / 64;
+    rc = factor_back(ctx, st, D, B, mu0, F0c - col0, ldf0, mu, Fc - col0, ldf, info_dev, n_reverts_dev, w.Gp, kcg, nullptr, 0);
+    ctx->colwin_0 = ctx->colwin_n = 0;
+    return rc;
+}
+
 // ---- the 2B x 2B chain for 128 < n <= 256 (round 4; BASELINE config 4 in factor form has 2B = 256) ---------------------------
 // Same algebra as the n <= 128 chain (Gamma = Rg^T Rg with W = Rg^-T, A' = I + Rg J Rg^T = T^T T, P = (T - I)(W S),
 // K'' = (W S)^T P), built from the pieces that exist: the one-workgroup 128-row factorisation with the inverse factor
@@ -1295,6 +1326,9 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
     const int n = 2 * B;                           // n is even
     const factor_ws w = factor_carve(ctx, D, n);
     double *Rt = w.Rt, *Tm = w.Tm, *Fs = w.Fs, *coef = w.coef;
+    // the window of 64-column tiles the update launches write: all of F, or the owned column block of a column-sharded fit
+    // (gsmvi_gsm_factor_apply_cols_f64: F0 / F are then base pointers shifted so that GLOBAL column indices address the block)
+    const int cw_n = ctx->colwin_n > 0 ? ctx->colwin_n : (D + 63) / 64, cw_0 = ctx->colwin_n > 0 ? ctx->colwin_0 : 0;
     int* info_g = ctx->ints;
     int* info_t = ctx->ints + 1;
     int rc, kc2 = 1;
@@ -1354,7 +1388,7 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         ctx->path |= GSMVI_PATH_FUPD_FAST;
         // n <= 64: the skinny product Fs = K'' Tm1 is folded into the update kernel (k_gsmf_update_fs): one launch less
         const int ntl = (D + 63) / 64;
-#define UFS(NPV, KCBV, RG) hipLaunchKernelGGL((k_gsmf_update_fs<NPV, KCBV, RG>), dim3(ntl * ntl), dim3(512), 0, st, D, B, Rt, Kmat, Tm, vf_slabs, kcv, F0, ldf0, F, ldf, coef, mu0, mu, info_dev, n_reverts_dev, ctx->bam_mean)
+#define UFS(NPV, KCBV, RG) hipLaunchKernelGGL((k_gsmf_update_fs<NPV, KCBV, RG>), dim3(ntl * cw_n), dim3(512), 0, st, D, B, Rt, Kmat, Tm, vf_slabs, kcv, F0, ldf0, F, ldf, coef, mu0, mu, info_dev, n_reverts_dev, ctx->bam_mean, cw_0, cw_n)
         ctx->bam_mean_done = ctx->bam_mean.xbar ? 1 : 0;
         if (D % 64 != 0) {
             if (kcv <= 4) { if (n <= 32) UFS(1, 4, true); else UFS(2, 4, true); }
@@ -1392,7 +1426,7 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
     const int nt = (D + 63) / 64;
     if (!ctx->tune_no_fast && D % 2 == 0 && n <= 256) {
         // the fast kernel also writes the mean and counts the revert (any even n <= 256 since round 5)
-#define UF(NPV, RG) hipLaunchKernelGGL((k_gsmf_update_fast<NPV, RG>), dim3(nt * nt), dim3(512), 0, st, D, B, Rt, Fs, F0, ldf0, F, ldf, Tm, coef, mu0, mu, info_dev, n_reverts_dev)
+#define UF(NPV, RG) hipLaunchKernelGGL((k_gsmf_update_fast<NPV, RG>), dim3(nt * cw_n), dim3(512), 0, st, D, B, Rt, Fs, F0, ldf0, F, ldf, Tm, coef, mu0, mu, info_dev, n_reverts_dev, cw_0, cw_n)
         const int npsel = n <= 32 ? 1 : (n <= 64 ? 2 : (n <= 128 ? 4 : 8));       // instantiated pass counts; RAG unless n fills them all
         if (D % 64 != 0 || n != 32 * npsel) { if (n <= 32) UF(1, true); else if (n <= 64) UF(2, true); else if (n <= 128) UF(4, true); else UF(8, true); }
         else { if (n <= 32) UF(1, false); else if (n <= 64) UF(2, false); else if (n <= 128) UF(4, false); else UF(8, false); }
@@ -1401,8 +1435,11 @@ static int factor_back(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const doubl
         return chk("k_gsmf_update_fast");
     }
     ctx->path |= GSMVI_PATH_FUPD_GENERIC;
-    hipLaunchKernelGGL(k_gsmf_mean, dim3((D + 255) / 256), dim3(256), 0, st, D, B, Tm, coef, mu0, mu, info_dev, n_reverts_dev);
+    {
+        const int c0 = 64 * cw_0, c1 = (64 * (cw_0 + cw_n) < D) ? 64 * (cw_0 + cw_n) : D;
+        hipLaunchKernelGGL(k_gsmf_mean, dim3((c1 - c0 + 255) / 256), dim3(256), 0, st, D, B, Tm, coef, mu0, mu, info_dev, n_reverts_dev, c0, c1);
+    }
     if ((rc = chk("k_gsmf_mean"))) return rc;
-    hipLaunchKernelGGL(k_gsmf_update, dim3(nt * nt), dim3(256), 0, st, D, n, Rt, Fs, F0, ldf0, F, ldf, info_dev);
+    hipLaunchKernelGGL(k_gsmf_update, dim3(nt * cw_n), dim3(256), 0, st, D, n, Rt, Fs, F0, ldf0, F, ldf, info_dev, cw_0, cw_n);
     return chk("k_gsmf_update");
 }

@@ -142,6 +142,69 @@ def row_sharded_gsm_update(eng, X, G, mu0, S0_rows, group=None, out=None):
     return eng.gsm_apply_rows(rec, mu0, S0_rows, lo, out=out)
 
 
+def _all_reduce_sum(t, group=None):
+    """in-place SUM all-reduce on the group's backend (device tensors staged through the host for a gloo group)"""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def col_bounds(D, world, rank):
+    """Columns [lo, hi) of the square factor owned by ``rank``: equal, tile-aligned blocks (D must be a multiple of
+    64 * world: one fixed-size all-gather of the sample slices, whole 64-column tiles for the update kernels)."""
+    assert D % (64 * world) == 0, f"column sharding needs D ({D}) to be a multiple of 64 x the number of ranks ({world})"
+    per = D // world
+    return rank * per, (rank + 1) * per
+
+
+def col_gather_samples(eng, X_cols, group=None, stats=None):
+    """(B, D) samples from every rank's (B, D / P) slice: ONE all-gather of B D / P doubles per rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return X_cols
+    B, nc = X_cols.shape
+    recv = eng.empty(world * B, nc)
+    if stats is not None:
+        stats["all_gather_bytes_per_rank"] = B * nc * 8
+        stats["collectives"] = stats.get("collectives", 0) + 1
+    _all_gather(_as_torch(recv), _as_torch(X_cols), group)
+    r = recv if isinstance(recv, torch.Tensor) else _as_torch(recv).numpy()
+    X = eng.empty(B, world * nc)
+    for p in range(world):
+        X[:, p * nc:(p + 1) * nc] = r[p * B:(p + 1) * B]
+    return X
+
+
+def col_sharded_gsm_factor_update(eng, Z, X, G, mu0, F0_cols, group=None, out=None, flag=None, n_reverts=None, stats=None):
+    """Factor-form GSM update with the square factor sharded by COLUMN BLOCKS (gsm_numpy.py:27-55 in
+    the form of SURVEY A.2): (mu, F_cols, flag).  Every rank holds the columns ``col_bounds(D, P, r)`` of F0 (Sigma = F0^T F0)
+    and gets back the same columns of the new factor and ITS entries of the new mean (``mu`` is full length; only the owned
+    entries are written).  Z (the whitened draws), X (the samples, e.g. from ``col_gather_samples``) and G (their scores) are
+    replicated.  One exchange: the all-reduce of the partial products G[:, C] F0[:, C]^T to W = G F0^T (B D doubles); the
+    2B x 2B chain is replicated (identical inputs and arithmetic: every rank takes the same accept / revert decision) and the
+    update reads and writes the owned block only -- the D^2-sized traffic and memory of the factor form are divided by P."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B, D = Z.shape
+    lo, hi = col_bounds(D, world, rank)
+    assert tuple(F0_cols.shape) == (D, hi - lo), f"rank {rank} must hold columns [{lo}, {hi}) of F0"
+    W = eng.gsm_factor_w_partial(G, lo, F0_cols)
+    if world > 1:
+        if stats is not None:
+            stats["all_reduce_bytes"] = B * D * 8
+            stats["collectives"] = stats.get("collectives", 0) + 1
+        if isinstance(W, torch.Tensor):
+            _all_reduce_sum(W, group)
+        else:
+            t = _as_torch(W)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            W = t.numpy()
+    return eng.gsm_factor_apply_cols(Z, W, X, mu0, F0_cols, lo, out=out, flag=flag, n_reverts=n_reverts)
+
+
 def sharded_bam_update(eng, X_local, G_local, mu0, S0, reg, jitter=0.0, group=None, out=None, flag=None, stats=None):
     """(mu, S, flag) of the BaM update for the union of all ranks' samples (gsmvi/bam.py:72-114;
     BASELINE config 4: B=128 sharded 16 per GPU).  BaM's statistics couple all samples (batch means

@@ -459,6 +459,46 @@ class HipEngine:
             C.c_void_p(n_reverts.data_ptr()) if n_reverts is not None else None))
         return mu, F, flag
 
+    # ---- column-sharded factor form (dist.col_sharded_gsm_factor_update) --------------------------
+    def sample_cols(self, Z, mu_cols, Fcols, out=None):
+        """X[:, C] = mu[C] + Z F[:, C]: the owned column slice of x = mu + z F (gsm_numpy.py:116) from the owned block of F."""
+        B, D = Z.shape
+        nc = Fcols.shape[1]
+        assert Fcols.shape == (D, nc) and mu_cols.shape == (nc,)
+        self._ensure(D, B)
+        X = self.empty(B, nc) if out is None else out
+        pz, ldz = self._mat(Z, "Z")
+        pf, ldf = self._mat(Fcols, "Fcols")
+        px, ldx = self._mat(X, "Xcols")
+        _lib.check("gsmvi_sample_cols_f64", self.lib.gsmvi_sample_cols_f64(
+            self._ctx, self._stream(), D, B, nc, pz, ldz, self._vec(mu_cols, "mu_cols"), pf, ldf, px, ldx))
+        return X
+
+    def gsm_factor_w_partial(self, G, col0, Fcols, out=None):
+        """The rank's PARTIAL sum of W = G F^T over its owned columns: G[:, C] F[:, C]^T (B x D) -- gsmvi_gsm_rows_stage_f64 on the
+        block (the caller all-reduces the partials)."""
+        nc = Fcols.shape[1]
+        return self.gsm_rows_stage(G[:, col0:col0 + nc], Fcols, out=out)
+
+    def gsm_factor_apply_cols(self, Z, W, X, mu0, F0cols, col0, out=None, flag=None, n_reverts=None):
+        """(mu, Fcols, flag): the factor-form update of the OWNED column block from the replicated draws Z, the all-reduced
+        W = G F^T and the gathered samples X; mu is full length, entries C written (gsmvi_gsm_factor_apply_cols_f64)."""
+        B, D = Z.shape
+        nc = F0cols.shape[1]
+        assert W.shape == (B, D) and W.is_contiguous() and X.shape == (B, D) and F0cols.shape == (D, nc)
+        self._ensure(D, B)
+        mu, F = (self.empty(D), self.empty(D, nc)) if out is None else out
+        flag = self.new_flag() if flag is None else flag
+        pz, ldz = self._mat(Z, "Z")
+        px, ldx = self._mat(X, "X")
+        pf0, ldf0 = self._mat(F0cols, "F0cols")
+        pf, ldf = self._mat(F, "Fcols")
+        _lib.check("gsmvi_gsm_factor_apply_cols_f64", self.lib.gsmvi_gsm_factor_apply_cols_f64(
+            self._ctx, self._stream(), D, B, int(col0), nc, pz, ldz, C.c_void_p(W.data_ptr()), px, ldx, self._vec(mu0, "mu0"),
+            pf0, ldf0, self._vec(mu, "mu"), pf, ldf, C.c_void_p(flag.data_ptr()),
+            C.c_void_p(n_reverts.data_ptr()) if n_reverts is not None else None))
+        return mu, F, flag
+
     def gram(self, F, out=None, shift=0.0, shift_dev=None):
         """cov = F^T F (gsmvi_gram_f64): the covariance a square factor represents -- return value of the
         factor-form fit and what its monitor sees (gsm_numpy.py:129).  Not on the per-iteration path.

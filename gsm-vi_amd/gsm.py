@@ -123,8 +123,14 @@ class GSM:
                     "device" (counter-based Philox stream generated by gsmvi_randn_f64 from (key, iteration):
                     nothing crosses PCIe, and sharded ranks draw identical Z).
           forced_samples : (niter+1, B, D) teacher-forced samples replacing the sampler.
-          shard   : batch-sharded multi-GPU fit (one process per GPU, torch.distributed initialised; both
-                    methods).  Every rank draws the same z-stream (same key, either rng), so samples are
+          shard   : True / "batch": batch-sharded multi-GPU fit (one process per GPU, torch.distributed initialised; both
+                    methods).  "cols" (round 6): the COLUMN-sharded factor form -- every rank keeps D / P
+                    columns of the square factor and its entries of the mean, samples its slice x[:, C] = mean[C] + z F[:, C]
+                    (all-gathered: B D / P doubles per rank), evaluates lp_g on all B samples, contributes the partial
+                    product G[:, C] F[:, C]^T to one all-reduce (B D doubles) and updates its block alone: the D^2-sized
+                    traffic and memory of the factor form are divided by P (the batch-sharded form divides neither).  Needs
+                    D % (64 P) == 0 and 2 batch_size <= min(D, 256).  All ranks return the same (mean, cov).
+                    batch-sharded (True):  Every rank draws the same z-stream (same key, either rng), so samples are
                     replicated; each rank evaluates ``lp_g`` only on its batch_size/world rows, the
                     per-sample records are all-gathered (RCCL) and every replica applies the identical
                     combined update (gsm-vi_amd/dist.py).  All ranks return the same (mean, cov).
@@ -185,6 +191,8 @@ class GSM:
             mean_o, cov_o = mp[:D_].contiguous(), cp[:D_, :D_].contiguous()
             return (mean_o, cov_o) if as_torch else (eng0.to_numpy(mean_o), eng0.to_numpy(cov_o))
         self._zc = _zero_cols_from
+        if shard == "cols" and method == "auto":
+            method = "factor"
         if method == "auto":
             # 2B <= 128: always (the measured range of rounds 2-4).  128 < 2B <= 256 (two-level chain): where the dense loop's
             # O(D^3) Cholesky costs more than the whole factor update -- measured at (1024, 128): factor update 271 us against
@@ -192,6 +200,11 @@ class GSM:
             nmax = 256 if D_ >= 1024 else 128
             method = "factor" if (sampler == "cholesky" and forced_samples is None
                                   and 2 * B_ <= min(D_, nmax)) else "dense"
+        if shard == "cols":
+            assert method in ("auto", "factor") and sampler == "cholesky" and forced_samples is None, \
+                "shard='cols' is the column-sharded FACTOR form (device sampler, no forced samples)"
+            self.method_used = "factor"
+            return self._fit_factor_cols(key, mean, cov, batch_size, niter, nprint, verbose, monitor, rng, as_torch, group)
         self.method_used = method
         if method == "factor":
             return self._fit_factor(key, mean, cov, batch_size, niter, nprint, verbose, monitor, rng, as_torch,
@@ -287,6 +300,107 @@ class GSM:
         if as_torch:
             return mean_t, cov_t
         return eng.to_numpy(mean_t), eng.to_numpy(cov_t)
+
+    # ------------------------------------------------------------------------------
+    def _fit_factor_cols(self, key, mean, cov, batch_size, niter, nprint, verbose, monitor, rng, as_torch, group=None):
+        """Column-sharded factor-form fit (see ``fit(shard="cols")``): the loop of gsm_numpy.py:77-129 on the state
+        (mean[C], F[:, C]) per rank.  Per iteration and rank: one pass over the block for the sample slice, one for the partial
+        W, two for the update (read + write) and the V F product -- 32 D (D / P) bytes --, one all-gather of B D / P doubles and
+        one all-reduce of B D doubles; the 2B x 2B chain and the score evaluation are replicated.  The initial factorisation is
+        replicated too (once per fit); the covariance is assembled only for the monitor and the return value."""
+        import torch.distributed as _dist
+        from .dist import col_bounds, col_gather_samples, col_sharded_gsm_factor_update, _all_gather, _as_torch
+        eng = self._engine if self._engine is not None else get_engine()
+        D, B = self.D, int(batch_size)
+        assert 2 * B <= min(D, 256), "the factor form needs 2*batch_size <= min(D, 256)"
+        world = _dist.get_world_size(group) if _dist.is_initialized() else 1
+        rank = _dist.get_rank(group) if _dist.is_initialized() else 0
+        lo, hi = col_bounds(D, world, rank)
+        nc = hi - lo
+        mean_a = eng.zeros(D) if mean is None else eng.clone(mean).reshape(D)
+        cov0 = eng.eye(D) if cov is None else eng.clone(cov).reshape(D, D)
+        flag, n_rev = eng.new_flag(), eng.new_flag()
+        F0, _ = eng.potrf(cov0, flag=flag)
+        if eng.read_flag(flag) != 0:
+            raise ValueError("initial covariance is not positive definite")
+        Fc_a = eng.clone(F0[:, lo:hi])                      # the owned block, D x D / P, its own leading dimension
+        del F0, cov0
+        mean_b, Fc_b = eng.clone(mean_a), eng.empty(D, nc)
+        bufs = [(mean_a, Fc_a), (mean_b, Fc_b)]
+        a = 0
+        seed = int(key) if not _is_torch(key) else int(key.flatten()[0])
+        rs = np.random.RandomState(seed)
+        assert rng in ("auto", "numpy", "device"), "rng must be 'auto', 'numpy' or 'device'"
+        dev_rng = rng != "numpy"
+        native = bool(getattr(self.lp_g, "device_native", False))
+        mon_native = bool(getattr(monitor, "device_native", False)) if monitor is not None else False
+        KB = 16
+        Zblk = eng.empty(KB, B, D) if dev_rng else None
+        self.shard_stats = {}
+
+        def assemble():
+            """(mean, F) in full on every rank: all-gather of the owned mean entries and column blocks"""
+            m_c, F_c = bufs[a]
+            if world == 1:
+                return m_c, F_c
+            recv = eng.empty(world * D, nc)
+            _all_gather(_as_torch(recv), _as_torch(F_c), group)
+            r = recv if _is_torch(recv) else _as_torch(recv).numpy()
+            F = eng.empty(D, D)
+            for p in range(world):
+                F[:, p * nc:(p + 1) * nc] = r[p * D:(p + 1) * D]
+            mrecv = eng.empty(world * nc)
+            _all_gather(_as_torch(mrecv), _as_torch(eng.clone(m_c[lo:hi])), group)
+            m = eng.clone(mrecv) if _is_torch(mrecv) else np.array(_as_torch(mrecv).numpy(), copy=True)
+            return m, F
+
+        def state():
+            m, F = assemble()
+            c = eng.gram(F)
+            return [m, c] if mon_native else [eng.to_numpy(m).copy(), eng.to_numpy(c).copy()]
+
+        nevals = 1
+        nprint = max(1, min(int(nprint), int(niter))) if niter > 0 else 1
+        every = max(1, niter // nprint) if niter > 0 else 1
+        reverts_seen = 0
+        for i in range(niter + 1):
+            if verbose and i % every == 0:
+                print(f"Iteration {i} of {niter}")
+                r = eng.read_flag(n_rev)
+                if r > reverts_seen:
+                    print(f"Bad update for covariance matrix. Revert ({r - reverts_seen} since last print)")
+                    reverts_seen = r
+            if monitor is not None and i % monitor.checkpoint == 0:
+                monitor(i, state(), self.lp, key, nevals=nevals)
+                nevals = 0
+            if dev_rng:
+                if i % KB == 0:
+                    eng.normal_batch(min(KB, niter + 1 - i), B, D, seed, i, out=Zblk[:min(KB, niter + 1 - i)])
+                Z = Zblk[i % KB]
+            else:
+                Z = eng.normal_from_host(rs.standard_normal((B, D)))
+            m_c, F_c = bufs[a]
+            m_n, F_n = bufs[1 - a]
+            Xc = eng.sample_cols(Z, m_c[lo:hi], F_c)
+            X = col_gather_samples(eng, Xc, group, stats=self.shard_stats if i == 0 else None)
+            vs = self.lp_g(X) if native else eng.host_score(self.lp_g, X)
+            col_sharded_gsm_factor_update(eng, Z, X, vs, m_c, F_c, group=group, out=(m_n, F_n), flag=flag, n_reverts=n_rev,
+                                          stats=self.shard_stats if i == 0 else None)
+            nevals += B
+            a = 1 - a
+        if verbose:
+            r = eng.read_flag(n_rev)
+            if r > reverts_seen:
+                print(f"Bad update for covariance matrix. Revert ({r - reverts_seen} since last print)")
+        if monitor is not None:
+            monitor(niter, state(), self.lp, key, nevals=nevals)
+        self.n_reverts = eng.read_flag(n_rev)
+        self.shard_stats["block_bytes"] = D * nc * 8
+        m, F = assemble()
+        cov_t = eng.gram(F)
+        if as_torch:
+            return m, cov_t
+        return eng.to_numpy(m), eng.to_numpy(cov_t)
 
     # ------------------------------------------------------------------------------
     def _fit_factor(self, key, mean, cov, batch_size, niter, nprint, verbose, monitor, rng, as_torch, shard=False,

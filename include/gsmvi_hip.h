@@ -317,6 +317,28 @@ int gsmvi_sample_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
                      double* X, int ldx);
 
 /*
+ * COLUMN-SHARDED factor-form GSM update (round 6; SURVEY 8(e) row 3 / (f) 3: the decomposition that divides the HBM-bound
+ * D^2 passes and the D^2 memory of a fit by the number of ranks).  A rank owns the columns C = [col0, col0 + ncols) of the
+ * square factor Fm (Sigma = Fm^T Fm) as a D x ncols block with its own leading dimension, and the entries C of the mean.
+ *   gsmvi_sample_cols_f64          Xcols (B x ncols) = mu_cols + Z Fcols: the owned slice of x = mu + z Fm (gsm_numpy.py:116);
+ *                                  the caller all-gathers the slices (B ncols doubles per rank).
+ *   gsmvi_gsm_rows_stage_f64       on the block (D := ncols, nrows := D, G + col0, Fcols) gives the PARTIAL product
+ *                                  G[:, C] Fm[:, C]^T (B x D); the caller all-reduces the partials to W = G Fm^T.
+ *   gsmvi_gsm_factor_apply_cols_f64  from the replicated draws Z, the all-reduced W (B x D, contiguous) and the gathered
+ *                                  samples X: the 2B x 2B chain of gsmvi_gsm_factor_update_f64 (replicated: identical inputs
+ *                                  and arithmetic on every rank, so the accept / revert decision agrees) and the update of the
+ *                                  OWNED block alone, Fcols' = Fcols + Rt^T (K'' Tm[:, C]), mu[C].  mu0 / mu are full-length
+ *                                  vectors of which entries C are read / written.  col0 % 64 == 0, ncols % 64 == 0 (the last
+ *                                  block may be ragged), even D and leading dimensions, 16-byte aligned blocks.
+ * Per update a rank reads its block three times and writes it once (32 D ncols bytes) and exchanges B (ncols + D) doubles.
+ */
+int gsmvi_sample_cols_f64(gsmvi_ctx* ctx, void* stream, int D, int B, int ncols, const double* Z, int ldz,
+                          const double* mu_cols, const double* Fcols, int ldf, double* Xcols, int ldx);
+int gsmvi_gsm_factor_apply_cols_f64(gsmvi_ctx* ctx, void* stream, int D, int B, int col0, int ncols, const double* Z, int ldz,
+                                    const double* W, const double* X, int ldx, const double* mu0, const double* F0cols,
+                                    int ldf0, double* mu, double* Fcols, int ldf, int* info_dev, int* n_reverts_dev);
+
+/*
  * Whitened draws: out[0..n) ~ N(0, 1), a pure function of (seed, call, element index) -- counter-based
  * Philox4x32-10 (key = seed, counter = (pair index, call)) + Box-Muller in fp64; see csrc/gsmvi_rng.hip.
  * Replaces the standard-normal stream behind np.random.multivariate_normal (gsm_numpy.py:105,116) in

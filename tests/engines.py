@@ -189,6 +189,52 @@ class OracleEngine:
             return out[0], out[1], flag
         return mu, Fn, flag
 
+    def sample_cols(self, Z, mu_cols, Fcols, out=None):
+        X = mu_cols[None, :] + Z @ Fcols
+        if out is not None:
+            out[...] = X
+            return out
+        return X
+
+    def gsm_factor_w_partial(self, G, col0, Fcols, out=None):
+        Wp = G[:, col0:col0 + Fcols.shape[1]] @ Fcols.T
+        if out is not None:
+            out[...] = Wp
+            return out
+        return Wp
+
+    def gsm_factor_apply_cols(self, Z, W, X, mu0, F0cols, col0, out=None, flag=None, n_reverts=None):
+        """SURVEY A.2 from the whitened quantities alone: u from (z, w), M = I + (Z^T Z - Y^T Y) / B = C C^T, F' = C^T F, so the
+        owned columns of F' are C^T F[:, C] and mu'[C] = mu0[C] + mean_b u_b F[:, C]."""
+        flag = Flag() if flag is None else flag
+        B, D = Z.shape
+        nc = F0cols.shape[1]
+        ww = np.einsum("bi,bi->b", W, W)
+        zw = np.einsum("bi,bi->b", Z, W)
+        rho = 0.5 * np.sqrt(1.0 + 4.0 * (ww + zw * zw)) - 0.5
+        den = 1.0 + rho - zw
+        U = ((W + Z) + Z * ((ww + zw) / den)[:, None]) / (1.0 + rho)[:, None]
+        Y = U - Z
+        M = np.eye(D) + (Z.T @ Z - Y.T @ Y) / B
+        mu = np.array(mu0, copy=True)
+        try:
+            Cm = np.linalg.cholesky(0.5 * (M + M.T))
+            ok = bool(np.isfinite(Cm).all())
+        except np.linalg.LinAlgError:
+            ok = False
+        if ok:
+            Fn, flag.v = Cm.T @ F0cols, 0
+            mu[col0:col0 + nc] = mu0[col0:col0 + nc] + (U @ F0cols).mean(axis=0)
+        else:
+            Fn, flag.v = F0cols.copy(), 1
+            if n_reverts is not None:
+                n_reverts.v += 1
+        if out is not None:
+            out[0][...] = mu
+            out[1][...] = Fn
+            return out[0], out[1], flag
+        return mu, Fn, flag
+
     def gram(self, F, out=None, shift=0.0, shift_dev=None):
         Cm = F.T @ F + (shift + (float(shift_dev[0]) if shift_dev is not None else 0.0)) * np.eye(F.shape[0])
         if out is not None:
