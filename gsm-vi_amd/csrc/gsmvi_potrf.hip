@@ -479,8 +479,8 @@ __device__ __forceinline__ bool dag_wait(int* flags, const int* f0, int n0, cons
     if (threadIdx.x == 0) {
         int ok = 1, spins = 0;
         for (;;) {
-            const bool r = (!f0 || dag_ld(f0) >= n0) && (!f1 || dag_ld(f1) >= n1) && (!f2 || dag_ld(f2) >= n2);
-            if (r) break;
+            const int v0 = f0 ? dag_ld(f0) : n0, v1 = f1 ? dag_ld(f1) : n1, v2 = f2 ? dag_ld(f2) : n2;   // (one round trip, not three)
+            if (v0 >= n0 && v1 >= n1 && v2 >= n2) break;
             if (dag_ld(flags + DAG_ABORT) != 0 || ++spins > max_spin) {
                 ok = 0;
                 dag_st(flags + DAG_ABORT, 1);
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
                     const int jr = e >> 6, pcol = e & 63;
                     if (I0 + jr < D) R[(size_t)(I0 + jr) * ldr + (cI - 1) * NB + pcol] = 0.0;
                 }
-                dag_publish(xready + (cI - 1) * nblk + cI, 1);                              // (its barrier also orders L2 for the product below)
+                __syncthreads();                                                            // L2 (the X^T tile) is complete
                 acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
                 potrf_mma64x8(L2, L2, acc, wr, rr, wc, c, ks);                              // T_cc -= X^T X
 #pragma unroll
@@ -594,7 +594,10 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
                     const int i = lrow0 + 4 * r, j = 32 * wc + 16 * ct + c;
                     E[i * ESD + j] = (i < nb && j < nb) ? (j >= i ? tv[ct][r] : 0.0) : (i == j ? 1.0 : 0.0);
                 }
-            __syncthreads();
+            // the solved block (c-1, c) is published here: its write-through stores have had the product and the staging above to
+            // land, so the drain in front of the flag costs the chain next to nothing (dag_publish's barrier is the one E needs)
+            if (cI > 0) dag_publish(xready + (cI - 1) * nblk + cI, 1);
+            else __syncthreads();
             chol64_blk<ESD, false, true>(E, scr, nb, &sh_fail);
             if (tid == 0 && sh_fail != 0 && *info == 0) *info = I0 + sh_fail;
             // W_c first (it is what the other workgroups wait for), into the chain's own operand tile and out to the workers
@@ -739,7 +742,9 @@ int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int
     const int nblk = (D + NB - 1) / NB, ldrow = nblk * NB;
     double* rowbuf = ctx->pp;
     double* wbuf = rowbuf + (size_t)2 * NB * ldrow;
-    if (ctx->tune_potrf_dag && !ctx->tune_no_fast && !ctx->timeline_stamps(3)) {
+    // (D <= 6144: measured 310 / 677 / 1871 us against 323 / 716 / 2010 at D = 1024 / 2048 / 4096, but 10.4 against 10.2 ms at
+    // D = 8192, where one workgroup per CU cannot keep up with 3.5e5 tile tasks; knob "potrf_dag" = 2 forces it at any size)
+    if (ctx->tune_potrf_dag && (nblk <= 96 || ctx->tune_potrf_dag == 2) && !ctx->tune_no_fast && !ctx->timeline_stamps(3)) {
         // one persistent launch (k_potrf_dag): W blocks and the flags live where the launch-per-step form keeps its row buffers
         double* wb = ctx->pp;
         int* flags = reinterpret_cast<int*>(wb + (size_t)nblk * NB * NB);

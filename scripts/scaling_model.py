@@ -112,6 +112,55 @@ def collective(P, m_bytes):
     return floor + ALPHA_US + wire, floor + (P - 1) * (ALPHA_US + wire)
 
 
+def allreduce(P, m_bytes):
+    """(direct, ring) microseconds for a SUM all-reduce of m_bytes among P ranks: a reduce-scatter and an all-gather of m / P
+    per rank, over P - 1 links at once (direct) or around the ring"""
+    if P == 1:
+        return 0.0, 0.0
+    fl = rccl_floor(m_bytes)
+    floor = max(fl["host_enqueue_us"], fl["device_us_back_to_back"]) if fl else 10.0
+    wire = (m_bytes / P) / (EFF * LINK_GBS * 1e3)
+    return floor + 2.0 * (ALPHA_US + wire), floor + 2.0 * (P - 1) * (ALPHA_US + wire)
+
+
+# ---- the COLUMN-sharded factor form (gsm-vi_amd/dist.py: col_sharded_gsm_factor_update; SURVEY 8(e) row 3): every stage a rank
+# runs is measured here on a D x D / P block; the all-gather of the sample slices and the all-reduce of W are modelled ----------
+for name, D, B in (("c3_cols", 1024, 32), ("c5_cols", 4096, 64)):
+    st = state(D, B, 7)
+    flag = eng.new_flag()
+    rows = {}
+    for Pn in (1, 2, 4, 8):
+        nc = D // Pn
+        Fc = st["F0"][:, :nc].contiguous()
+        Fo, mu = eng.empty(D, nc), eng.empty(D)
+        Xc = eng.empty(B, nc)
+        W = eng.gsm_factor_w_partial(st["G"], 0, Fc)
+        t_sample = b2b(lambda: eng.sample_cols(st["Z"], st["mu0"][:nc], Fc, out=Xc), 5, 50)
+        Wp = eng.empty(B, D)
+        t_w = b2b(lambda: eng.gsm_factor_w_partial(st["G"], 0, Fc, out=Wp), 5, 50)
+        t_apply = b2b(lambda: eng.gsm_factor_apply_cols(st["Z"], W, st["X"], st["mu0"], Fc, 0, out=(mu, Fo), flag=flag), 5, 40)
+        Go = eng.empty(B, D)
+        t_score = b2b(lambda: eng.gaussian_score(st["X"], st["m"], st["P"], out=Go))      # replicated: every rank scores all B samples
+        ag_d, ag_r = collective(Pn, B * nc * 8)
+        ar_d, ar_r = allreduce(Pn, B * D * 8)
+        upd = t_w + t_apply
+        it = t_sample + t_score + upd
+        rows[str(Pn)] = {
+            "columns_per_rank": nc, "factor_block_bytes": D * nc * 8, "all_gather_bytes_per_rank": B * nc * 8 if Pn > 1 else 0,
+            "all_reduce_bytes": B * D * 8 if Pn > 1 else 0, "collectives_per_update": 0 if Pn == 1 else 2,
+            "measured_us": {"sample_slice": t_sample, "score_all_rows": t_score, "partial_w": t_w, "apply_owned_block": t_apply},
+            "collective_us": {"direct": ag_d + ar_d, "ring": ag_r + ar_r},
+            "U_updates_per_s": {"direct": 1e6 / (upd + ar_d), "ring": 1e6 / (upd + ar_r)},
+            "F_iterations_per_s": {"direct": 1e6 / (it + ag_d + ar_d), "ring": 1e6 / (it + ag_r + ar_r)},
+            "status": "measured on one GPU (no collective)" if Pn == 1 else "model, not measured",
+        }
+        del Fc, Fo, W, Wp
+        torch.cuda.empty_cache()
+    res["configs"][name] = {"D": D, "B": B, "kind": "gsm_factor, column-sharded (GSM.fit(shard='cols'))", "by_world_size": rows}
+    print(name, json.dumps(rows), flush=True)
+    del st
+    torch.cuda.empty_cache()
+
 for name, D, B, kind in (("c3", 1024, 32, "gsm_dense"), ("c4", 1024, 128, "bam_dense"), ("c5", 4096, 64, "gsm_factor")):
     st = state(D, B, 7)
     mu, S, Fo, flag = eng.empty(D), eng.empty(D, D), eng.empty(D, D), eng.new_flag()
