@@ -283,6 +283,7 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     else if (!strcmp(name, "rider")) ctx->tune_rider = value;
     else if (!strcmp(name, "potrf_split_m")) ctx->tune_potrf_split_m = value;
     else if (!strcmp(name, "potrf_dag")) ctx->tune_potrf_dag = value;
+    else if (!strcmp(name, "panel_w4_min_D")) ctx->tune_panel_w4_min_D = value;
     else if (!strcmp(name, "potrf_spin")) ctx->tune_potrf_spin = value;
     else if (!strcmp(name, "wide")) ctx->tune_wide = value;
     else if (!strcmp(name, "wide_kc")) ctx->tune_wide_kc = value;
@@ -463,6 +464,27 @@ int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D
     }
     const int chw = fast ? gsmvi_panel_fast_chunk(MT) : 256;       // rows of M per chunk
     const int nchunks = (D + chw - 1) / chw;
+    // round 6: 64-column strips for large D (k_panel_fast_w4: a quarter of the left-operand re-reads) -- plain products on the grid
+    const bool w4 = fast && MT <= 2 && ctx->tune_panel_w4_min_D > 0 && D >= ctx->tune_panel_w4_min_D && D % 256 == 0 &&
+                    ncols % 64 == 0 && ldm % 2 == 0 && !ctx->px.msl && !ctx->px.sj_src && !ctx->px.rd_on;
+    if (w4) {
+        const int strips4 = ncols / 64;
+        int kc4 = ctx->tune_panel_kc > 0 ? ctx->tune_panel_kc : (2 * ctx->num_cu + strips4 * zblocks - 1) / (strips4 * zblocks);
+        if (kc4 > nchunks) kc4 = nchunks;
+        if (kc4 > GSMVI_MAX_KC) kc4 = GSMVI_MAX_KC;
+        if (kc4 < 1) kc4 = 1;
+        const int cpw4 = (nchunks + kc4 - 1) / kc4;
+        kc4 = (nchunks + cpw4 - 1) / cpw4;
+        *kc_out = kc4;
+        gsmvi_panel_extras px4;
+        px4.w4 = 1;
+        ctx->px = gsmvi_panel_extras();
+        ctx->px_used = 1;
+        gsmvi_launch_panel_fast(st, ev, MT, dim3(strips4, kc4, zblocks), D, nrows, A, lda, shift, alpha, M, ldm, Pp, cpw4, ncols,
+                                nullptr, nullptr, 0, nullptr, &px4);
+        ctx->path |= GSMVI_PATH_PANEL_FAST;
+        return check_launch("k_panel_fast_w4");
+    }
     int kc = ctx->tune_panel_kc > 0 ? ctx->tune_panel_kc
                                     : (2 * ctx->num_cu + strips * zblocks - 1) / (strips * zblocks);
     if (kc > nchunks) kc = nchunks;
@@ -637,7 +659,9 @@ int gsmvi_gsm_rows_stage_f64(gsmvi_ctx* ctx, void* stream, int D, int B, int nro
     int st = check_common(ctx, D, B, __func__);
     if (st != GSMVI_OK) return st;
     BAD_ARG(!G || !S0rows || !SGcols, "NULL array");
-    BAD_ARG(nrows <= 0 || nrows > D, "nrows out of range");
+    // (nrows <= the context's max_D, not <= D: the column-sharded factor form calls this with the roles exchanged -- D = the owned
+    // columns of the factor, nrows = its D rows -- for the partial product G[:, C] F[:, C]^T; round 6)
+    BAD_ARG(nrows <= 0 || nrows > ctx->max_D, "nrows out of range");
     BAD_ARG(ldg < D || lds0 < D || ldsg < nrows, "leading dimension too small");
     hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
     int kc = 1;

@@ -478,6 +478,7 @@ class HipEngine:
         """The rank's PARTIAL sum of W = G F^T over its owned columns: G[:, C] F[:, C]^T (B x D) -- gsmvi_gsm_rows_stage_f64 on the
         block (the caller all-reduces the partials)."""
         nc = Fcols.shape[1]
+        self._ensure(Fcols.shape[0], G.shape[0])         # (the product's output is D wide: the context must be sized for D, not for the block)
         return self.gsm_rows_stage(G[:, col0:col0 + nc], Fcols, out=out)
 
     def gsm_factor_apply_cols(self, Z, W, X, mu0, F0cols, col0, out=None, flag=None, n_reverts=None):

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats and, in separate passes, the HBM
 # traffic counters for the bench workload.  Output: gpurun_out/prof_$1/ (copy summaries to profiles/).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT
@@ -100,6 +100,13 @@ for cfg in "1024 128" "1024 64" "1024 32" "256 8" "4096 64"; do
     python3 scripts/bamf_trace.py $cfg $b cfg 2>&1 | grep -E "eager|host" >> $OUT/bamf_backtoback.txt
   done
 done
+# round 6: the jitter-period table of the factor-form BaM fit, batch sizes beyond the old ceilings, the Cholesky as one persistent
+# launch against one launch per block step, 64-column panel strips at large D, the analytic multi-GPU model
+python3 scripts/jitter_period.py $OUT/jitter_period.json > $OUT/jitter_period.log 2>&1
+python3 scripts/bigbatch_bench.py $OUT/bigbatch.json > $OUT/bigbatch.log 2>&1
+for d in 1 0; do POTRF_DAG=$d python3 scripts/potrf_rate.py 256 512 1024 2048 4096 8192 2>&1 | grep "^potrf" >> $OUT/potrf_rate.txt; done
+python3 scripts/panel_w4_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/panel_w4_ab.txt
+timeout 600 python3 scripts/scaling_model.py $OUT/scaling_model.json > $OUT/scaling_model.log 2>&1
 python3 scripts/soak_round3.py 120 > $OUT/soak.txt 2>&1
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 bench.py --steps 20 --warmup 3 > $OUT/bench_driver_flags.json 2>> $OUT/bench.err

@@ -161,7 +161,14 @@ for name, D, B in (("c4", 1024, 128), ("c4_B32", 1024, 32)):
     n, t0 = 60, time.perf_counter()
     bam.fit(1, sched, niter=n - 1, batch_size=B, verbose=False, rng="device", method="dense")
     torch.cuda.synchronize()
-    r["F_fit_bam"] = {"it_per_s": n / (time.perf_counter() - t0), "n": n, "method": "dense (the reference's loop incl. jitter)"}
+    r["F_fit_bam"] = {"it_per_s": n / (time.perf_counter() - t0), "n": n,
+                      "method": "dense (the reference's loop incl. jitter) = the default, method='auto', at the reference's jitter (round 6)"}
+    bam.fit(1, sched, niter=3, batch_size=B, verbose=False, rng="device")                       # every argument at its default
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bam.fit(1, sched, niter=3 * n - 1, batch_size=B, verbose=False, rng="device")
+    torch.cuda.synchronize()
+    r["F_fit_bam_default_args"] = {"it_per_s": 3 * n / (time.perf_counter() - t0), "n": 3 * n, "method_used": bam.method_used}
     if 2 * B <= 256:                                              # factor form: Sigma = F^T F, no D^3 step per iteration (2B <= 256 since round 4)
         F0, _ = eng.potrf(st["S0"])
         Z = eng.normal(B, D, 5, 0)
@@ -171,19 +178,20 @@ for name, D, B in (("c4", 1024, 128), ("c4_B32", 1024, 32)):
         f_bamf = lambda: eng.bam_factor_update(Z, Xf, Gf, st["mu0"], F0, 1.0, out=(mu, Fo), flag=flag)
         r["U_bam_factor_update"] = ev_times(f_bamf, 5, 100)
         r["U_bam_factor_update"]["graph_us"] = graph_time(f_bamf, 4, 4)
-        bam.fit(1, sched, niter=3, batch_size=B, verbose=False, rng="device", method="factor")
-        torch.cuda.synchronize()
-        n, t0 = (400 if B <= 64 else 150), time.perf_counter()
-        bam.fit(1, sched, niter=n - 1, batch_size=B, verbose=False, rng="device", method="factor")
-        torch.cuda.synchronize()
-        t1 = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        bam.fit(1, sched, niter=3 * n - 1, batch_size=B, verbose=False, rng="device", method="factor")
-        torch.cuda.synchronize()
-        t3 = time.perf_counter() - t0
-        # it_per_s: the whole call (initial Cholesky, buffers, final Gram product included); marginal: the iteration alone
-        r["F_fit_bam_factor"] = {"it_per_s": n / t1, "it_per_s_marginal": 2 * n / (t3 - t1), "n": n, "n_reverts": bam.n_reverts,
-                                 "method": "factor (= the default, method='auto', since round 5)"}
+        for key, jit, what in (("F_fit_bam_factor", 0.0, "factor, jitter = 0 (= method='auto' for a call without jitter)"),
+                               ("F_fit_bam_factor_absorbing", 1e-6, "factor, the reference's jitter absorbed every 4 accepted updates (opt-in)")):
+            bam.fit(1, sched, niter=3, batch_size=B, verbose=False, rng="device", method="factor", jitter=jit)
+            torch.cuda.synchronize()
+            n, t0 = (400 if B <= 64 else 150), time.perf_counter()
+            bam.fit(1, sched, niter=n - 1, batch_size=B, verbose=False, rng="device", method="factor", jitter=jit)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            bam.fit(1, sched, niter=3 * n - 1, batch_size=B, verbose=False, rng="device", method="factor", jitter=jit)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter() - t0
+            # it_per_s: the whole call (initial Cholesky, buffers, final Gram product included); marginal: the iteration alone
+            r[key] = {"it_per_s": n / t1, "it_per_s_marginal": 2 * n / (t3 - t1), "n": n, "n_reverts": bam.n_reverts, "method": what}
     h = {k: st[k].cpu().numpy() for k in ("X", "G", "mu0", "S0")}
     r["cpu_lowrank_update"] = cpu_time(lambda: borc.bam_lowrank_update_exact(h["X"], h["G"], h["mu0"], h["S0"], 1.0), 4.0)
     res["configs"][name] = r

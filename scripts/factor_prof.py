@@ -8,7 +8,7 @@ tgt = gsmvi_amd.GaussianTarget(m, precision=P)
 method = sys.argv[3] if len(sys.argv) > 3 else "factor"
 if method == "bamf":
     gsmvi_amd.BaM(D, tgt.lp, tgt.lp_g).fit(1, gsmvi_amd.Regularizers().constant(1.0), niter=40, batch_size=B, verbose=False,
-                                          method="factor")
+                                          method="factor", jitter=0.0)
 elif method == "bam":
     gsmvi_amd.BaM(D, tgt.lp, tgt.lp_g).fit(1, gsmvi_amd.Regularizers().constant(1.0), niter=40, batch_size=B, verbose=False,
                                           method="dense")

@@ -79,11 +79,16 @@ plain = {
     "traffic.json": "HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes + MFMA pipe utilisation",
     "rocprof_summary.json": "per-kernel stats and raw counters of the bench passes (summary.json of the collection)",
     "soak.txt": "run-to-run bit-identity soak over the (case, kind) pairs, library of this pass",
+    "jitter_period.json": "scripts/jitter_period.py: factor-form BaM fit absorbing its jitter every K updates against the reference's loop (deviation and rate by K)",
+    "bigbatch.json": "scripts/bigbatch_bench.py: U and F at D = 1024 for B = 128 ... 1024 (GSM dense, BaM dense), per-sample cost relative to B = 128",
+    "potrf_rate.txt": "scripts/potrf_rate.py: gsmvi_potrf_f64 by size, k_potrf_dag (dag=1) against one launch per block step (dag=0)",
+    "panel_w4_ab.txt": "scripts/panel_w4_ab.py: panel product at D >= 2048 with 64-column strips against 16-column strips",
+    "scaling_model.json": "scripts/scaling_model.py: per-rank stages measured on one GPU + RCCL world-1 floor + xGMI wire model; N > 1 entries are a model, not measured",
     "pytest_gpu.txt": "python -m pytest tests -m gpu -q (tail)",
 }
 # the directory is rebuilt from the last pass alone; files listed in KEEP (merged reports written by other scripts of the
 # round) are carried over from the published directory
-KEEP = ("offgrid.json", "bigbatch.json", "jitter_period.json", "scaling_model.json", "potrf_rate.txt", "thresholds.json")
+KEEP = ("offgrid.json",)
 for keep in KEEP:
     if os.path.exists(os.path.join(final, keep)):
         shutil.copyfile(os.path.join(final, keep), os.path.join(dst, keep))
