@@ -464,27 +464,6 @@ int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D
     }
     const int chw = fast ? gsmvi_panel_fast_chunk(MT) : 256;       // rows of M per chunk
     const int nchunks = (D + chw - 1) / chw;
-    // round 6: 64-column strips for large D (k_panel_fast_w4: a quarter of the left-operand re-reads) -- plain products on the grid
-    const bool w4 = fast && MT <= 2 && ctx->tune_panel_w4_min_D > 0 && D >= ctx->tune_panel_w4_min_D && D % 256 == 0 &&
-                    ncols % 64 == 0 && ldm % 2 == 0 && !ctx->px.msl && !ctx->px.sj_src && !ctx->px.rd_on;
-    if (w4) {
-        const int strips4 = ncols / 64;
-        int kc4 = ctx->tune_panel_kc > 0 ? ctx->tune_panel_kc : (2 * ctx->num_cu + strips4 * zblocks - 1) / (strips4 * zblocks);
-        if (kc4 > nchunks) kc4 = nchunks;
-        if (kc4 > GSMVI_MAX_KC) kc4 = GSMVI_MAX_KC;
-        if (kc4 < 1) kc4 = 1;
-        const int cpw4 = (nchunks + kc4 - 1) / kc4;
-        kc4 = (nchunks + cpw4 - 1) / cpw4;
-        *kc_out = kc4;
-        gsmvi_panel_extras px4;
-        px4.w4 = 1;
-        ctx->px = gsmvi_panel_extras();
-        ctx->px_used = 1;
-        gsmvi_launch_panel_fast(st, ev, MT, dim3(strips4, kc4, zblocks), D, nrows, A, lda, shift, alpha, M, ldm, Pp, cpw4, ncols,
-                                nullptr, nullptr, 0, nullptr, &px4);
-        ctx->path |= GSMVI_PATH_PANEL_FAST;
-        return check_launch("k_panel_fast_w4");
-    }
     int kc = ctx->tune_panel_kc > 0 ? ctx->tune_panel_kc
                                     : (2 * ctx->num_cu + strips * zblocks - 1) / (strips * zblocks);
     if (kc > nchunks) kc = nchunks;
@@ -493,9 +472,13 @@ int gsmvi_panel_product_nc(gsmvi_ctx* ctx, hipStream_t st, hipEvent_t* ev, int D
     const int cpw = (nchunks + kc - 1) / kc;
     kc = (nchunks + cpw - 1) / cpw;
     *kc_out = kc;
-    const gsmvi_panel_extras px = ctx->px;
+    gsmvi_panel_extras px = ctx->px;
     ctx->px = gsmvi_panel_extras();                // extras are for ONE launch; px_used reports whether the fast kernel took them
     ctx->px_used = fast ? 1 : 0;
+    // round 6: plain products on the grid at large D walk several chunks per workgroup: the prefetching form (k_panel_fast_p)
+    if (fast && MT <= 2 && cpw >= 2 && ctx->tune_panel_w4_min_D > 0 && D >= ctx->tune_panel_w4_min_D && D % 256 == 0 &&
+        ncols % 16 == 0 && !px.msl && !px.sj_src && !px.rd_on)
+        px.w4 = 1;
     if (fast) {
         gsmvi_launch_panel_fast(st, ev, MT, dim3(strips, kc, zblocks), D, nrows, A, lda, shift, alpha, M, ldm, Pp,
                                 cpw, ncols, ctx->timeline_stamps(0), nullptr, 0, nullptr, &px);

@@ -36,7 +36,7 @@ struct gsmvi_panel_extras {
     const double* rd_Pi = nullptr;          // jmode 2: the B x B coupling matrix of the orthogonal-basis BaM form (gsmvi_small16.h)
     const double* rd_R11 = nullptr;         // jmode 2, B % 16 == 0: the finished first diagonal block [R11 | W11] of the chain's Gram
     const double* rd_W11 = nullptr;         // matrix (B x B each, compact; Gvv's factor from k_bam_small48's side workgroup)
-    int w4 = 0;                             // this launch's grid.x counts 64-column strips: k_panel_fast_w4 (round 6; set by the product drivers)
+    int w4 = 0;                             // this launch takes the prefetching form k_panel_fast_p (round 6; set by the product drivers: large D, on the grid)
 };
 
 // BaM's regulariser as the kernels take it: by value, or -- so that a captured hipGraph can be replayed with another value
@@ -63,7 +63,7 @@ struct gsmvi_ctx {
     gsmvi_panel_extras px;     // see above
     int px_used = 0;
     unsigned path = 0;         // GSMVI_PATH_* bits of the kernel families launched since the last reset (gsmvi_last_path)
-    int tune_panel_w4_min_D = 2048;    // from this D on, products with <= 32 rows on the grid take 64-column strips (0: never; A/B runs)
+    int tune_panel_w4_min_D = 2048;    // from this D on, plain products with <= 32 rows on the grid keep the next chunk's loads in flight (k_panel_fast_p; 0: never; A/B runs)
     int colwin_0 = 0, colwin_n = 0;    // column-tile window of the factor update launches (colwin_n = 0: all of F)
     const double* potrf_w = nullptr;   // after a k_potrf_dag factorisation: its W blocks (W_k = R_kk^-T, [nblk][64 x 64], in the slab area:
     const double* potrf_r = nullptr;   //   valid until the next panel product), the factor it wrote and its size; null after the

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Round-5 verdict, item 5: the panel product at D >= 2048 (rows <= 32) with 64-column strips (k_panel_fast_w4, knob
-panel_w4_min_D = 2048, the default) against the 16-column strips of k_panel_fast (knob = 0): the built-in score G = -(X - m) P
-(product + finish launch) and the dense GSM update's first stage, back-to-back medians, and the bit-level agreement of the two.
+"""Round-5 verdict, item 5: the panel product at D >= 2048 (rows <= 32) with the next chunk's loads in flight (k_panel_fast_p, knob
+panel_w4_min_D = 2048, the default) against k_panel_fast (knob = 0): the built-in score G = -(X - m) P (product + finish launch)
+over a ring of HBM-cold matrices, back to back, and the bit-level agreement of the two.  (The knob's name is that of the first
+attempt -- 64-column strips, four tiles per staged chunk -- which measured 47.1 against 47.1 us at (4096, 32) and was removed.)
 usage: panel_w4_ab.py"""
 import os
 import sys
@@ -49,7 +50,7 @@ for D in (1024, 2048, 4096, 8192):
         eng.set_tuning("panel_w4_min_D", 2048)
         dmax = float((outs[2048] - outs[0]).abs().max() / outs[0].abs().max())
         gb = 8.0 * D * D / 1e3
-        print(f"D={D} B={B}: score (product + finish) 64-column strips {res[2048]:.1f} us ({gb / res[2048]:.0f} GB/s of M), "
-              f"16-column strips {res[0]:.1f} us ({gb / res[0]:.0f} GB/s); max rel difference {dmax:.1e}", flush=True)
+        print(f"D={D} B={B}: score (product + finish) prefetching {res[2048]:.1f} us ({gb / res[2048]:.0f} GB/s of M), "
+              f"k_panel_fast {res[0]:.1f} us ({gb / res[0]:.0f} GB/s); max rel difference {dmax:.1e}", flush=True)
         del Ps
         torch.cuda.empty_cache()
