@@ -752,6 +752,34 @@ def main():
             except Exception as e:      # reported, never hidden
                 fit_rate[method] = f"failed: {type(e).__name__}: {e}"
 
+    # ---- BASELINE config 4 beside the headline (round 6): BaM.fit at DEFAULT arguments (the reference's jitter => its own loop,
+    # update + jitter + Cholesky accept test), D = 1024, B = 128, reg = 100 / (1 + i) (examples/example_bam.py:58); and the Cholesky
+    # alone, the accept test of every reference-faithful loop ----
+    if fit_rate is not None and rank == 0 and D == 1024 and not args.no_large_point:
+        try:
+            bam = gsmvi_amd.BaM(D, tgt.lp, tgt.lp_g)
+            sched = lambda i: 100.0 / (1 + i)                                       # noqa: E731
+            bam.fit(1, sched, niter=5, batch_size=128, verbose=False)
+            torch.cuda.synchronize()
+            tb0 = time.perf_counter()
+            bam.fit(1, sched, niter=149, batch_size=128, verbose=False)
+            torch.cuda.synchronize()
+            fit_rate["bam_c4_default_args"] = {"it_per_s": 150 / (time.perf_counter() - tb0), "method_used": bam.method_used,
+                                               "n_reverts": int(bam.n_reverts)}
+            Sx, Rx, fx = inst[0]["S0"], eng.empty(D, D), eng.new_flag()
+            for _ in range(3):
+                eng.potrf(Sx, out=Rx, flag=fx)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                eng.potrf(Sx, out=Rx, flag=fx)
+            e1.record()
+            e1.synchronize()
+            fit_rate["potrf_us"] = e0.elapsed_time(e1) * 1e2
+        except Exception as e:                  # secondary figures only
+            fit_rate["bam_c4_default_args"] = f"failed: {type(e).__name__}: {e}"
+
     # ---- the drop-in call path: host numpy score and torch-autograd score (round-4 verdict, item 4), c3 (this shape) and c2 ----
     if fit_rate is not None and rank == 0 and not args.no_callpath:
         try:

@@ -403,3 +403,32 @@ def test_nonsymmetric_s0_keeps_the_reference_semantics(eng):
         mu_o2, S_o2 = orc.gsm_update_faithful(st2["samples"], st2["vs"], st2["mu0"], S0n)
         mu4, S4 = gsmvi_amd.gsm_update(st2["samples"], st2["vs"], st2["mu0"], S0n)
         assert rel_err(mu4, mu_o2) < 1e-11 and rel_err(S4, S_o2) < 1e-11, (D, B)
+
+
+@pytest.mark.parametrize("D,B", [(2048, 16), (4096, 32), (2304, 24)])
+def test_prefetching_panel_product_is_bit_identical(eng, D, B):
+    """Round 6: plain panel products on the grid at D >= 2048 keep the next chunk's loads in flight (k_panel_fast_p; knob
+    "panel_w4_min_D").  Same chunks, same k order inside a slab, same cross-wave reduction: the score, the sampler and the dense
+    update must not change by a bit against k_panel_fast (knob 0)."""
+    import torch
+    g = torch.Generator(device=eng.device)
+    g.manual_seed(D + B)
+    kw = dict(dtype=torch.float64, device=eng.device, generator=g)
+    P, X, m = torch.randn(D, D, **kw), torch.randn(B, D, **kw), torch.rand(D, **kw)
+    A = torch.randn(D, D, **kw)
+    S0 = (A @ A.T / D + 0.1 * torch.eye(D, dtype=torch.float64, device=eng.device)).contiguous()
+    S0 = (0.5 * (S0 + S0.T)).contiguous()
+    out = {}
+    try:
+        for knob in (2048, 0):
+            eng.set_tuning("panel_w4_min_D", knob)
+            G = eng.gaussian_score(X, m, P)
+            Xs = eng.sample(X, m, P)
+            mu, S = eng.gsm_update(X, G, m, S0)
+            out[knob] = (G.clone(), Xs.clone(), mu.clone(), S.clone())
+    finally:
+        eng.set_tuning("panel_w4_min_D", 2048)
+    for a, b in zip(out[2048], out[0]):
+        assert torch.equal(a, b)
+    ref = -(X - m) @ P
+    assert float((out[2048][0] - ref).abs().max() / ref.abs().max()) < 1e-12
