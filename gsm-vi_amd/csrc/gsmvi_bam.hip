@@ -838,6 +838,84 @@ __global__ __launch_bounds__(512) void k_lowrank_update_fast(int D, int KF, cons
 #undef LR_LDS_BARRIER
 }
 
+// The same update for ANY number of factor rows (round 6; KF > 288, i.e. BaM batches beyond 144: until then the guarded kernel
+// k_lowrank_update, 74 us at KF = 512): a run-time loop of 64-row passes instead of NPMAX compile-time passes over registers loaded
+// up front -- the loads of pass p + 1 go out as soon as pass p has been staged (one register set: it is consumed by the staging),
+// LDS-only barriers.  Same tiles, same k order, same stores as k_lowrank_update_fast.
+template <bool RAG>
+__global__ __launch_bounds__(512) void k_lowrank_update_big(int D, int KF, const double* __restrict__ Ft,
+                                                            const double* __restrict__ Fs,
+                                                            const double* __restrict__ S0, int lds0,
+                                                            double* __restrict__ S, int lds, double jitter) {
+#define LR_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    constexpr int RS = 80, KP = 64;
+    constexpr int UQ = KP * 32 / 512;
+    __shared__ __attribute__((aligned(16))) double sm[2 * KP * RS];
+    const int nt = (D + 63) >> 6, np = (KF + KP - 1) / KP;
+    const int ti = blockIdx.x / nt, tj = blockIdx.x % nt;
+    const int I0 = ti * 64, J0 = tj * 64;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
+    const int wr = w >> 1, wc = w & 1;
+    double s0[2][4];
+    const int frow = I0 + 16 * wr + ks;
+    const int fcol = J0 + 32 * wc + c;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = (RAG && frow + 4 * r >= D) ? D - 1 : frow + 4 * r, cq = (RAG && fcol + 16 * blk >= D) ? D - 1 : fcol + 16 * blk;
+            s0[blk][r] = S0[(size_t)rr * lds0 + cq];
+        }
+    v2d ga[UQ], gb[UQ];
+    auto issue = [&](int p) {
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+            const int u = q * 512 + tid, row = KP * p + (u >> 5), c2 = 2 * (u & 31);
+            const int rc = row < KF ? row : KF - 1;
+            ga[q] = *reinterpret_cast<const v2d*>(Ft + (size_t)rc * D + ((RAG && I0 + c2 >= D) ? D - 2 : I0 + c2));
+            gb[q] = *reinterpret_cast<const v2d*>(Fs + (size_t)rc * D + ((RAG && J0 + c2 >= D) ? D - 2 : J0 + c2));
+        }
+    };
+    issue(0);
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int p = 0; p < np; ++p) {
+        if (p > 0) LR_LDS_BARRIER();
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+            const int u = q * 512 + tid, row = u >> 5, c2 = 2 * (u & 31);
+            const bool in = KP * p + row < KF;
+            *reinterpret_cast<v2d*>(sm + row * RS + c2) = in ? ga[q] : (v2d){0.0, 0.0};
+            *reinterpret_cast<v2d*>(sm + (KP + row) * RS + c2) = in ? gb[q] : (v2d){0.0, 0.0};
+        }
+        LR_LDS_BARRIER();
+        if (p + 1 < np) issue(p + 1);
+        const double* ap = sm + ks * RS + 16 * wr + c;
+        const double* bp = sm + (KP + ks) * RS + 32 * wc + c;
+#pragma unroll
+        for (int h = 0; h < KP / 32; ++h) {
+            double a[8], b0[8], b1[8];
+#pragma unroll
+            for (int sI = 0; sI < 8; ++sI) {
+                a[sI] = ap[(32 * h + 4 * sI) * RS];
+                b0[sI] = bp[(32 * h + 4 * sI) * RS];
+                b1[sI] = bp[(32 * h + 4 * sI) * RS + 16];
+            }
+#pragma unroll
+            for (int sI = 0; sI < 8; ++sI) {
+                acc0 = GSMVI_MFMA_F64(a[sI], b0[sI], acc0);
+                acc1 = GSMVI_MFMA_F64(a[sI], b1[sI], acc1);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = frow + 4 * r;
+        if (!RAG || (row < D && fcol < D)) S[(size_t)row * lds + fcol] = s0[0][r] + acc0[r] + (row == fcol ? jitter : 0.0);
+        if (!RAG || (row < D && fcol + 16 < D)) S[(size_t)row * lds + fcol + 16] = s0[1][r] + acc1[r] + (row == fcol + 16 ? jitter : 0.0);
+    }
+#undef LR_LDS_BARRIER
+}
+
 #define HIPCHK(expr)                                                          \
     do {                                                                      \
         hipError_t e_ = (expr);                                               \
@@ -954,8 +1032,11 @@ int gsmvi_bam_impl(gsmvi_ctx* ctx, hipStream_t st, int D, int B, const double* X
         }
     }
     const int nt = (D + 63) / 64;
-    ctx->path |= (!ctx->tune_no_fast && D % 2 == 0 && n2 <= 288) ? GSMVI_PATH_LOWRANK_FAST : GSMVI_PATH_LOWRANK_GENERIC;
-    if (!ctx->tune_no_fast && D % 2 == 0 && n2 <= 288) {
+    ctx->path |= (!ctx->tune_no_fast && D % 2 == 0) ? GSMVI_PATH_LOWRANK_FAST : GSMVI_PATH_LOWRANK_GENERIC;
+    if (!ctx->tune_no_fast && D % 2 == 0 && n2 > 288) {          // round 6: any number of factor rows on the MFMA tile kernel
+        if (D % 64 != 0) hipLaunchKernelGGL(k_lowrank_update_big<true>, dim3(nt * nt), dim3(512), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds, jitter);
+        else hipLaunchKernelGGL(k_lowrank_update_big<false>, dim3(nt * nt), dim3(512), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds, jitter);
+    } else if (!ctx->tune_no_fast && D % 2 == 0 && n2 <= 288) {
 #define LRU(NPV, KPV, RG) hipLaunchKernelGGL((k_lowrank_update_fast<NPV, KPV, RG>), dim3(nt * nt), dim3(512), 0, st, D, n2, Ft, Fs, S0, lds0, S, lds, jitter)
         // (KF > 96: 32-row staging passes as in round 4; 64-row passes -- half the barriers -- measured equal: knob "lowrank_kp" = 64)
         if (D % 64 != 0) {

@@ -694,7 +694,7 @@ __global__ __launch_bounds__(512) void k_bam_cholw_pair(int n, const double* __r
 __global__ __launch_bounds__(1024) void k_bam_post_big(int n, bam_reg regs, const double* __restrict__ Rb,
                                                        const int* __restrict__ info_p, const double* __restrict__ M1,
                                                        const double* __restrict__ N0, double* __restrict__ Ld,
-                                                       int* __restrict__ info) {
+                                                       int* __restrict__ info, const double* __restrict__ Wblk) {
     const double reg = regs.get();
     __shared__ double sc[BAMS_NBIG + 8], av[BAMS_NBIG + 8];
     __shared__ int sh_bad;
@@ -734,6 +734,32 @@ __global__ __launch_bounds__(1024) void k_bam_post_big(int n, bam_reg regs, cons
         Ld[e] = (j <= i) ? Rb[(size_t)j * n + i] : 0.0;
     }
     for (int p = tid; p < n; p += 1024) { Ldinv[p] = 1.0 / Rb[(size_t)p * n + p]; vg[p] = sc[p]; }
+    if (Wblk) {
+        // round 6: zg = L^-1 a BLOCKED on the inverses of the diagonal blocks that the factorisation left behind (k_potrf_dag's
+        // W_r = R_rr^-T = L_rr^-1, 64 x 64 each): zg_r = W_rr (a_r - sum_{k < 64 r} L[., k] zg[k]), sixteen lanes per row, two barriers
+        // per 64 rows instead of two per row (n = 256: 77 us of pivots-with-barriers -> 4 blocks)
+        const int row = tid >> 4, sub = tid & 15;                // 64 rows x 16 lanes
+        for (int r0 = 0; r0 < n; r0 += 64) {
+            const int i = r0 + row;
+            double acc_ = 0.0;
+            if (i < n)
+                for (int k = sub; k < r0; k += 16) acc_ += Rb[(size_t)k * n + i] * av[k];       // L[i][k] = R[k][i]; av[k] = zg[k], k < r0
+            acc_ = row16_sum(acc_);
+            __syncthreads();                                     // (all reads of av[0 .. r0) by this block's rows are done)
+            if (sub == 0) sc[row] = (i < n) ? av[i] - acc_ : 0.0; // the block's right-hand side (sc: vg was copied out above)
+            __syncthreads();
+            double z = 0.0;
+            const double* wrow = Wblk + (size_t)(r0 >> 6) * 4096 + row * 64;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) z += wrow[sub + 16 * q] * sc[sub + 16 * q];
+            z = row16_sum(z);
+            __syncthreads();
+            if (sub == 0 && i < n) av[i] = z;
+            __syncthreads();
+        }
+        if (tid < n) zg[tid] = av[tid];
+        return;
+    }
     // zg = L^-1 a: thread p owns a[p] (n <= 1024 threads... n <= BAMS_NBIG); step pp needs R[pp][p], p > pp
     double mine = (tid < n) ? av[tid] : 0.0;
     const int pc = tid < n ? tid : n - 1;
@@ -1147,7 +1173,8 @@ int gsmvi_bam_small_device(gsmvi_ctx* ctx, hipStream_t st, int n, bam_reg reg, c
         int* info_p = ctx->ints + 9;
         int rc = gsmvi_potrf_impl(ctx, st, n, BBg, n, Rb, n, info_p);
         if (rc != GSMVI_OK) return rc;
-        hipLaunchKernelGGL(k_bam_post_big, dim3(1), dim3(1024), 0, st, n, reg, Rb, info_p, M1, N0, Ld, info_dev);
+        hipLaunchKernelGGL(k_bam_post_big, dim3(1), dim3(1024), 0, st, n, reg, Rb, info_p, M1, N0, Ld, info_dev,
+                           (ctx->potrf_w && ctx->potrf_w_n == n && !ctx->tune_no_fast) ? ctx->potrf_w : (const double*)nullptr);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

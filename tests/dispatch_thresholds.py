@@ -25,7 +25,7 @@ THRESHOLDS = [
     ("bam one-workgroup Newton-Schulz", "n", 64, ("bam", "bamf"), CSRC + "gsmvi_bam_small.hip", "whole iteration in ONE workgroup for n <= 64"),
     ("bam one-workgroup Cholesky", "n", 128, ("bam", "bamf"), CSRC + "gsmvi_bam_small.hip", "#define BAMS_NMAX 128"),
     ("bam low-rank update passes 96", "n", 48, ("bam",), CSRC + "gsmvi_bam.hip", "if (n2 <= 96) LRU(3, 32, false);"),
-    ("bam low-rank update fast <= 288", "n", 144, ("bam",), CSRC + "gsmvi_bam.hip", "D % 2 == 0 && n2 <= 288)"),
+    ("bam low-rank update: run-time pass loop above 288 rows", "n", 144, ("bam",), CSRC + "gsmvi_bam.hip", "D % 2 == 0 && n2 > 288) {"),
     ("bam substitution 64 columns", "n", 160, ("bam",), CSRC + "gsmvi_bam.hip", "if (n <= 160) BFW(64); else if (n <= 320) BFW(32); else if (n <= 640) BFW(16); else BFW(8);"),
     ("bam substitution 32 columns", "n", 320, ("bam",), CSRC + "gsmvi_bam.hip", "if (n <= 160) BFW(64); else if (n <= 320) BFW(32); else if (n <= 640) BFW(16); else BFW(8);"),
     ("bam substitution 16 columns", "n", 640, ("bam",), CSRC + "gsmvi_bam.hip", "if (n <= 160) BFW(64); else if (n <= 320) BFW(32); else if (n <= 640) BFW(16); else BFW(8);"),
