@@ -39,7 +39,9 @@ if gpu is None and agent.get("Name", "").startswith("gfx"):
 box["gpu_name"] = (gpu or {}).get("Marketing Name", "")
 box["gpu_uuid"] = (gpu or {}).get("Uuid", "")
 box["gpu_arch"] = (gpu or {}).get("Name", "")
-if not box["gpu_uuid"].startswith("GPU-") or not box["gpu_name"]:
+if not box["gpu_name"]:                                  # (some boxes of the pool print an empty marketing name for the GPU agent)
+    box["gpu_name"] = sh("/opt/rocm/bin/rocm-smi --showproductname 2>/dev/null | grep -i -m1 'card series\\|card model' | tr -s ' \\t' ' '") or box["gpu_arch"]
+if not box["gpu_uuid"].startswith("GPU-") or not box["gpu_arch"].startswith("gfx"):
     print("collect_profiles: no GPU agent found in rocminfo", file=sys.stderr)
     json.dump(box, open(os.path.join(out, "box.json"), "w"), indent=1)
     sys.exit(3)
