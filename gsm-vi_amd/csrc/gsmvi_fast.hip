@@ -154,14 +154,19 @@ __global__ __launch_bounds__(512) void k_panel_fast(int D, int nrows, const doub
 #pragma unroll
                 for (int s = 0; s < NST; ++s) fp[(size_t)(4 * s) * px.ldfin] = m[s];
             }
-        } else if (!RAG || wbase + RW <= D || !wave_in) {  // wave-uniform: all RW rows of this wave exist (or none: the values are unused)
+        } else if (!RAG || wbase + RW <= D) {      // wave-uniform: all RW rows of this wave exist (!RAG: D % 64 == 0, so a wave
+            // beyond row D -- its values are unused -- re-reads rows 0 .. RW - 1, which exist)
             const double* mp = M + (size_t)((wave_in ? wbase : 0) + ks) * ldm + j;
 #pragma unroll
             for (int s = 0; s < NST; ++s) m[s] = mp[(size_t)(4 * s) * ldm];
-        } else {                                   // the wave that straddles row D (D % RW != 0): clamped rows
+        } else {                                   // the wave that straddles row D (D % RW != 0) and, for D < RW, the waves beyond it:
+            // clamped rows.  (Round 6: the waves beyond row D used to take the unclamped branch with base row 0 -- for D < 32 that
+            // read rows D .. 31 of a D-row matrix, past the END of the caller's array; harmless inside an allocator block, a
+            // memory access fault when the array ends its mapping: found by the whole suite in one process)
+            const int rb = wave_in ? wbase : 0;
 #pragma unroll
             for (int s = 0; s < NST; ++s) {
-                const int r = wbase + ks + 4 * s;
+                const int r = rb + ks + 4 * s;
                 m[s] = M[(size_t)(r < D ? r : D - 1) * ldm + j];
             }
         }
