@@ -20,7 +20,8 @@ keep = []
 def tail(shape, src=None):
     """a tensor of this shape whose last element is the last double of a fresh 2 MiB allocation"""
     n = int(np.prod(shape))
-    big = torch.empty(SEG // 8, dtype=torch.float64, device=eng.device)
+    seg = max(SEG, -(-8 * n // (2 * 2 ** 20)) * 2 * 2 ** 20)           # whole 2 MiB granules; the array ends the allocation
+    big = torch.empty(seg // 8, dtype=torch.float64, device=eng.device)
     keep.append(big)
     t = big[big.numel() - n:].view(*shape)
     if src is not None:
