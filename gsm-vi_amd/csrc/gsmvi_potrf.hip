@@ -524,79 +524,86 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
 
     if (blockIdx.x == 0) {
         // ================================ the chain ================================
-        // The two tiles of iteration c -- tile (c, c) and the unsolved block (c-1, c) -- as they stand after the updates of
-        // steps 0 .. c-2.  They are loaded (sc1, or plainly from S while nothing has touched them) at the END of iteration
-        // c-1, behind the factorisation and in front of the W / factor stores, when their flags are already up (the workers had
-        // the whole factorisation to produce them): the loads land in the shadow of the stores, their drain and the publish.
-        auto load_tiles = [&](int cN, double (&tvx)[2][4], double (&vix)[8]) {
-            const int I0n = cN * NB;
-            const bool a_s = (cN <= 1);
+        for (int cI = 0; cI < nblk; ++cI) {
+            const int I0 = cI * NB;
+            if (cI >= 2) {
+                if (!dag_wait(flags, tstep + (cI - 1) * nblk + cI, cI - 1, tstep + cI * nblk + cI, cI - 1, nullptr, 0, &sh_w, max_spin)) {
+                    if (tid == 0) *info = D + 1;
+                    return;
+                }
+            }
+            const bool a_s = (cI <= 1);                           // tile (c, c) still in S
             const double* Asrc = a_s ? S : R;
             const int lda = a_s ? lds : ldr;
+            double tv[2][4];
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = I0n + lrow0 + 4 * r, col = I0n + 32 * wc + 16 * ct + c;
+                    const int row = I0 + lrow0 + 4 * r, col = I0 + 32 * wc + 16 * ct + c;
                     const double* ap = Asrc + (size_t)(row < D ? row : 0) * lda + (col < D ? col : 0);
                     const double v = a_s ? *ap : dag_ldd(ap);
-                    tvx[ct][r] = (row < D && col < D) ? v : ((row == col) ? 1.0 : 0.0);
+                    tv[ct][r] = (row < D && col < D) ? v : ((row == col) ? 1.0 : 0.0);
                 }
-            if (cN > 0) {
-                const bool b_s = (cN == 1);
+            if (cI > 0) {
+                const bool b_s = (cI == 1);
                 const double* Bsrc = b_s ? S : R;
                 const int ldb = b_s ? lds : ldr;
+                double vi[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const int pr = (tid >> 6) + 8 * q, gi = I0n + (tid & 63);
-                    const double* bp = Bsrc + (size_t)((cN - 1) * NB + pr) * ldb + (gi < D ? gi : 0);
+                    const int pr = (tid >> 6) + 8 * q, gi = I0 + (tid & 63);
+                    const double* bp = Bsrc + (size_t)((cI - 1) * NB + pr) * ldb + (gi < D ? gi : 0);
                     const double v = b_s ? *bp : dag_ldd(bp);
-                    vix[q] = (gi < D) ? v : 0.0;
+                    vi[q] = (gi < D) ? v : 0.0;
                 }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) L1[(tid & 63) * RS + (tid >> 6) + 8 * q] = vi[q];
+                __syncthreads();                                  // (L0 holds W_{c-1}: written at the end of the previous iteration)
+                v4d acc[2];
+                acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+                potrf_mma64x8(L0, L1, acc, wr, rr, wc, c, ks, 4 * (2 * wr + rr + 1));       // X = W_{c-1} T_{c-1,c}
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = lrow0 + 4 * r, col = 32 * wc + 16 * ct + c, gc = I0 + col;
+                        L2[col * RS + row] = acc[ct][r];
+                        if (gc < D) dag_std(R + (size_t)((cI - 1) * NB + row) * ldr + gc, acc[ct][r]);
+                    }
+                for (int e = tid; e < NB * NB; e += 512) {                                  // the mirror block (c, c-1): nobody's input
+                    const int jr = e >> 6, pcol = e & 63;
+                    if (I0 + jr < D) R[(size_t)(I0 + jr) * ldr + (cI - 1) * NB + pcol] = 0.0;
+                }
+                __syncthreads();                                                            // L2 (the X^T tile) is complete
+                acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+                potrf_mma64x8(L2, L2, acc, wr, rr, wc, c, ks);                              // T_cc -= X^T X
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tv[ct][r] -= acc[ct][r];
             }
-        };
-        // Loop rotated so that nothing but LDS crosses the back edge: iteration c ends by preparing tile (c+1, c+1) in LDS.
-        //   prologue : tile (0, 0) -> E
-        //   body c   : [publish the solved block (c-1, c)]  factor E -> [R_cc | W_c]
-        //              wait for the two tiles of c+1 (normally up: the workers had the factorisation's 10 us) and ISSUE their loads
-        //              W_c -> L0 and out to the workers, R_cc out; drain (the tile loads land with the stores), publish W_c
-        //              X = W_c T_{c,c+1} -> out;  T_{c+1,c+1} -= X^T X -> E
-        double* const E = Lall;
-        double* const scr = Lall + 64 * ESD;
-        auto stage_E = [&](const double (&tvx)[2][4], int nbx) {
+            const int nb = (D - I0) < NB ? (D - I0) : NB;
+            double* const E = Lall;
+            double* const scr = Lall + 64 * ESD;
+            __syncthreads();                                      // everyone is done with the staging tiles
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = lrow0 + 4 * r, j = 32 * wc + 16 * ct + c;
-                    E[i * ESD + j] = (i < nbx && j < nbx) ? (j >= i ? tvx[ct][r] : 0.0) : (i == j ? 1.0 : 0.0);
+                    E[i * ESD + j] = (i < nb && j < nb) ? (j >= i ? tv[ct][r] : 0.0) : (i == j ? 1.0 : 0.0);
                 }
-        };
-        {
-            double tv0[2][4], vdummy[8];
-            load_tiles(0, tv0, vdummy);
-            stage_E(tv0, D < NB ? D : NB);
-        }
-        for (int cI = 0; cI < nblk; ++cI) {
-            const int I0 = cI * NB;
-            const int nb = (D - I0) < NB ? (D - I0) : NB;
-            // the solved block (c-1, c) is published here: its write-through stores have had the update product and the staging
-            // to land, so the drain in front of the flag costs next to nothing (dag_publish's barrier is the one E needs)
+            // the solved block (c-1, c) is published here: its write-through stores have had the product and the staging above to
+            // land, so the drain in front of the flag costs the chain next to nothing (dag_publish's barrier is the one E needs)
             if (cI > 0) dag_publish(xready + (cI - 1) * nblk + cI, 1);
             else __syncthreads();
             chol64_blk<ESD, false, true>(E, scr, nb, &sh_fail);
             if (tid == 0 && sh_fail != 0 && *info == 0) *info = I0 + sh_fail;
-            const bool more = cI + 1 < nblk;
-            double tv[2][4], vi[8];
-            if (more) {
-                if (cI + 1 >= 2) {
-                    if (!dag_wait(flags, tstep + cI * nblk + cI + 1, cI, tstep + (cI + 1) * nblk + cI + 1, cI, nullptr, 0, &sh_w, max_spin)) {
-                        if (tid == 0) *info = D + 1;
-                        return;
-                    }
-                }
-                load_tiles(cI + 1, tv, vi);                       // in flight across the stores below
-            }
+            // (Measured and dropped, round 6: the loop rotated so that the two tiles of iteration c+1 are loaded right behind the
+            // factorisation and land with the W / factor stores -- 351 us at D = 1024 against 310 for this form and 324 for one
+            // launch per step: the earlier wait for their flags sits on the chain, and the rotated body spilled 22 VGPRs.)
+            // W_c first (it is what the other workgroups wait for), into the chain's own operand tile and out to the workers
             {
                 double* Wk = wbuf + (size_t)cI * NB * NB;
                 for (int e = tid; e < NB * NB; e += 512) {
@@ -604,42 +611,13 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
                     L0[(e >> 6) * RS + (e & 63)] = wv;
                     dag_std(Wk + e, wv);
                 }
+                if (cI + 1 < nblk) dag_publish(wready + cI, 1);
             }
             for (int e = tid; e < NB * NB; e += 512) {           // the factor's diagonal block: nobody's input in this launch
                 const int i = e >> 6, j = e & 63;
                 if (i < nb && j < nb) R[(size_t)(I0 + i) * ldr + I0 + j] = (j >= i) ? E[i * ESD + j] : 0.0;
             }
-            if (!more) break;
-            dag_publish(wready + cI, 1);                          // (drains the W stores -- and with them the tile loads)
-            // ---- tile (c+1, c+1) into E: X = W_c T_{c,c+1}, T -= X^T X ----
-            const int I1 = I0 + NB;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) L1[(tid & 63) * RS + (tid >> 6) + 8 * q] = vi[q];
             __syncthreads();
-            v4d acc[2];
-            acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
-            potrf_mma64x8(L0, L1, acc, wr, rr, wc, c, ks, 4 * (2 * wr + rr + 1));
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = lrow0 + 4 * r, col = 32 * wc + 16 * ct + c, gc = I1 + col;
-                    L2[col * RS + row] = acc[ct][r];
-                    if (gc < D) dag_std(R + (size_t)(I0 + row) * ldr + gc, acc[ct][r]);
-                }
-            for (int e = tid; e < NB * NB; e += 512) {           // the mirror block (c+1, c): nobody's input
-                const int jr = e >> 6, pcol = e & 63;
-                if (I1 + jr < D) R[(size_t)(I1 + jr) * ldr + I0 + pcol] = 0.0;
-            }
-            __syncthreads();
-            acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
-            potrf_mma64x8(L2, L2, acc, wr, rr, wc, c, ks);
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) tv[ct][r] -= acc[ct][r];
-            __syncthreads();                                      // everyone is done with the staging tiles
-            stage_E(tv, (D - I1) < NB ? (D - I1) : NB);
         }
         return;
     }
