@@ -110,17 +110,24 @@ class BaM:
         runs the identical factor-form update (dist.sharded_bam_factor_update); retries are collective in the same way.
         ``graph=True``: factor-form fits replay blocks of 16 iterations as one hipGraph (the regulariser table on the device:
         engine.bam_reg_source); bit-identical to the eager loop and, measured, not faster on an idle host -- off by default.
-        ``method="auto"`` (default since round 5): "factor" whenever that form exists for the call (see below) and ``jitter`` is
-        at most the reference's 1e-6, else "dense" (the reference's loop incl. its jitter).  The two loops are the same update to
-        1e-10 on the same samples; the jitter itself moves the reference's trajectory by 2e-5 .. 3e-5 of max|cov|
-        (tests/test_gpu_bam.py::test_factor_fit_without_jitter_tracks_the_dense_fit_with_it).
+        ``method="auto"`` (round 6): "dense" -- the reference's own loop: update, + jitter * I, symmetrise, Cholesky accept test
+        (:189-212) -- whenever ``jitter`` > 0, i.e. at the reference's default arguments (1e-10 from the restated reference loop on the
+        same samples: tests/test_gpu_bam.py::test_default_fit_is_the_reference_loop); "factor" for ``jitter`` = 0 where that form
+        exists (below), or when ``jitter_every`` is given.  Round 5 took the factor form up to jitter = 1e-6 and dropped the shift:
+        2e-5 .. 3e-5 (B = 128) and 1.7e-4 (B = 32) of max|cov| from the reference loop at D = 1024, above the 1e-5 bar.
         ``method="factor"`` (needs 2*batch_size <= min(D, 256), sampler="cholesky", no forced samples):
         the state is (mean, F) with cov = F^T F; every iteration samples with F itself and applies the factor-form BaM
         update (engine.bam_factor_update) -- four passes over F, no D x D covariance, no D^3 Cholesky for the accept
         test (the update's own 2B x 2B positive-definiteness test decides accept/revert, counted in ``n_reverts``).
-        The covariance is formed once, for the return value (and for each monitor call).  ``jitter`` is NOT applied in
-        this form (a diagonal shift is not a low-rank change of the factor); everything else -- niter+1 iterations, reg =
-        regf(i) per attempt, retries, monitor cadence -- is the loop above."""
+        The covariance is formed once, for the return value (and for each monitor call).  ``jitter``: a diagonal shift is not a
+        low-rank change of a factor, so the fit carries the shift it OWES -- jitter x the accepted updates since the last
+        absorption, counted on the device -- adds it to every covariance it hands out, and every ``jitter_every`` (default
+        BaM.JITTER_EVERY = 4; 0 = never, the round-5 behaviour) accepted updates absorbs it: F <- chol(F^T F + owed I)
+        (gsmvi_gram_shift_f64 + gsmvi_potrf_f64).  Deferring is not free -- the distance to the reference's loop grows in
+        proportion to the period (4: 7e-6 at B = 128, 1.8e-5 at B = 32; 16: no better than dropping the jitter;
+        profiles/r06/jitter_period.json) -- which is why this form is opt-in whenever jitter > 0.  Everything else -- niter+1
+        iterations, reg = regf(i) per attempt, retries, monitor cadence -- is the loop above.
+        ``method="dense"`` takes any batch size up to 1024 (the device chain's bound; tuned to 128, a blocked MFMA path above)."""
         eng = self._engine if self._engine is not None else get_engine()
         D, B = self.D, int(batch_size)
         assert method in ("auto", "dense", "factor"), "method must be 'auto', 'dense' or 'factor'"
