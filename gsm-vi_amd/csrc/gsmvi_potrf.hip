@@ -451,7 +451,7 @@ __global__ void k_potrf_clear_info(int* info) { *info = 0; }
 //     A task waits only for tasks with smaller tickets or for the chain, which waits only for tasks of earlier steps: no cycle,
 //     and with at most one workgroup per CU in the grid every workgroup is resident, so every claimed task runs.
 //   * hand-offs are flags in the workspace (agent-scope release / acquire: the producer's tiles are written back past its
-//     XCD's L2, the consumer invalidates before it reads); every wait is BOUNDED (max_spin polls, ~0.3 s): on a timeout the
+//     XCD's L2, the consumer invalidates before it reads); every wait is BOUNDED (max_spin polls, ~3 s): on a timeout the
 //     waiter raises the abort flag, every workgroup leaves and *info reports D + 1 -- the pool's GPUs are shared, a kernel that
 //     can spin forever is not acceptable.
 // Tiles live in R from their first update on (step 0 reads S); R must not alias S.  Same arithmetic per tile as the
@@ -761,7 +761,8 @@ int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int
         if (grid > ctx->num_cu) grid = ctx->num_cu;              // at most one workgroup per CU: all resident (100 KB of LDS each)
         hipLaunchKernelGGL(k_potrf_dag_clear, dim3((nflags + 255) / 256), dim3(256), 0, st, info_dev, flags, nflags);
         hipLaunchKernelGGL(k_potrf_dag, dim3(grid), dim3(512), 0, st, D, S, lds, R, ldr, wb, flags, info_dev,
-                           ctx->tune_potrf_spin > 0 ? ctx->tune_potrf_spin : 200000);
+                           ctx->tune_potrf_spin > 0 ? ctx->tune_potrf_spin : 2000000);   // (~3 s of polls: far above any scheduling gap of a shared GPU -- eight
+                           // processes time-slicing one device in tests/test_gpu_dist.py --, far below a harness's patience)
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) {
             gsmvi_set_error("potrf launch failed: %s%s", hipGetErrorString(e2), "");
