@@ -504,7 +504,12 @@ __device__ __forceinline__ void dag_publish(int* f, int v) {
 }
 
 __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int lds, double* R, int ldr, double* wbuf, int* flags,
-                                                   int* __restrict__ info, int max_spin) {
+                                                   int* __restrict__ info, int max_spin, unsigned long long* __restrict__ stamps) {
+    // timeline diagnostic (knob "timeline" = 2): the chain's thread 0 stamps eight points of each of its first 64 iterations
+#define DSTAMP(i)                                                                                              \
+    do {                                                                                                       \
+        if (stamps && threadIdx.x == 0 && cI < 64) stamps[cI * 8 + (i)] = __builtin_amdgcn_s_memrealtime();    \
+    } while (0)
     constexpr int RS = 66;
     constexpr int ESD = 146;
     // LDS: the [tile | W] matrix of chol64_blk and its panel scratch; the two staging tiles of the products share the matrix's
@@ -526,12 +531,14 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
         // ================================ the chain ================================
         for (int cI = 0; cI < nblk; ++cI) {
             const int I0 = cI * NB;
+            DSTAMP(0);
             if (cI >= 2) {
                 if (!dag_wait(flags, tstep + (cI - 1) * nblk + cI, cI - 1, tstep + cI * nblk + cI, cI - 1, nullptr, 0, &sh_w, max_spin)) {
                     if (tid == 0) *info = D + 1;
                     return;
                 }
             }
+            DSTAMP(1);                                            // flags seen
             const bool a_s = (cI <= 1);                           // tile (c, c) still in S
             const double* Asrc = a_s ? S : R;
             const int lda = a_s ? lds : ldr;
@@ -560,6 +567,7 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
 #pragma unroll
                 for (int q = 0; q < 8; ++q) L1[(tid & 63) * RS + (tid >> 6) + 8 * q] = vi[q];
                 __syncthreads();                                  // (L0 holds W_{c-1}: written at the end of the previous iteration)
+                DSTAMP(2);                                        // both tiles loaded (sc1) and staged
                 v4d acc[2];
                 acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
                 potrf_mma64x8(L0, L1, acc, wr, rr, wc, c, ks, 4 * (2 * wr + rr + 1));       // X = W_{c-1} T_{c-1,c}
@@ -596,9 +604,12 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
                 }
             // the solved block (c-1, c) is published here: its write-through stores have had the product and the staging above to
             // land, so the drain in front of the flag costs the chain next to nothing (dag_publish's barrier is the one E needs)
+            DSTAMP(3);                                            // solve + update products done, E staged
             if (cI > 0) dag_publish(xready + (cI - 1) * nblk + cI, 1);
             else __syncthreads();
+            DSTAMP(4);                                            // solved block published
             chol64_blk<ESD, false, true>(E, scr, nb, &sh_fail);
+            DSTAMP(5);                                            // factorisation done
             if (tid == 0 && sh_fail != 0 && *info == 0) *info = I0 + sh_fail;
             // (Measured and dropped, round 6: the loop rotated so that the two tiles of iteration c+1 are loaded right behind the
             // factorisation and land with the W / factor stores -- 351 us at D = 1024 against 310 for this form and 324 for one
@@ -612,15 +623,18 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
                     dag_std(Wk + e, wv);
                 }
                 if (cI + 1 < nblk) dag_publish(wready + cI, 1);
+                DSTAMP(6);                                        // W_c copied, stored, drained, published
             }
             for (int e = tid; e < NB * NB; e += 512) {           // the factor's diagonal block: nobody's input in this launch
                 const int i = e >> 6, j = e & 63;
                 if (i < nb && j < nb) R[(size_t)(I0 + i) * ldr + I0 + j] = (j >= i) ? E[i * ESD + j] : 0.0;
             }
             __syncthreads();
+            DSTAMP(7);
         }
         return;
     }
+#undef DSTAMP
     // ================================ the workers ================================
     int p = 0, base = 0;
     for (;;) {
@@ -747,7 +761,8 @@ int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int
     double* wbuf = rowbuf + (size_t)2 * NB * ldrow;
     // (D <= 6144: measured 310 / 677 / 1871 us against 323 / 716 / 2010 at D = 1024 / 2048 / 4096, but 10.4 against 10.2 ms at
     // D = 8192, where one workgroup per CU cannot keep up with 3.5e5 tile tasks; knob "potrf_dag" = 2 forces it at any size)
-    if (ctx->tune_potrf_dag && (nblk <= 96 || ctx->tune_potrf_dag == 2) && !ctx->tune_no_fast && !ctx->timeline_stamps(3)) {
+    if (ctx->tune_potrf_dag && (nblk <= 96 || ctx->tune_potrf_dag == 2) && !ctx->tune_no_fast &&
+        (!ctx->timeline_stamps(3) || ctx->tune_timeline == 2)) {
         // one persistent launch (k_potrf_dag): W blocks and the flags live where the launch-per-step form keeps its row buffers
         double* wb = ctx->pp;
         int* flags = reinterpret_cast<int*>(wb + (size_t)nblk * NB * NB);
@@ -761,8 +776,9 @@ int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int
         if (grid > ctx->num_cu) grid = ctx->num_cu;              // at most one workgroup per CU: all resident (100 KB of LDS each)
         hipLaunchKernelGGL(k_potrf_dag_clear, dim3((nflags + 255) / 256), dim3(256), 0, st, info_dev, flags, nflags);
         hipLaunchKernelGGL(k_potrf_dag, dim3(grid), dim3(512), 0, st, D, S, lds, R, ldr, wb, flags, info_dev,
-                           ctx->tune_potrf_spin > 0 ? ctx->tune_potrf_spin : 2000000);   // (~3 s of polls: far above any scheduling gap of a shared GPU -- eight
+                           ctx->tune_potrf_spin > 0 ? ctx->tune_potrf_spin : 2000000,    // (~3 s of polls: far above any scheduling gap of a shared GPU -- eight
                            // processes time-slicing one device in tests/test_gpu_dist.py --, far below a harness's patience)
+                           ctx->tune_timeline == 2 ? ctx->timeline_stamps(3) : nullptr);
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) {
             gsmvi_set_error("potrf launch failed: %s%s", hipGetErrorString(e2), "");
