@@ -188,6 +188,39 @@ __device__ __forceinline__ void potrf_mma64x8(const double* FA, const double* FB
     }
 }
 
+// The same product with every operand read issued ahead of the first MFMA (NS k-steps, compile time): with two waves per SIMD the
+// unroll-by-4 loop above runs the 64^3 product in 1.52 us on the persistent kernel's chain -- 57 cycles per MFMA where the pipe
+// needs 32 -- because each group of four steps waits out the LDS latency on its own.  3 NS operand registers (96 VGPRs at NS = 16;
+// the persistent kernel has 256).  Same MFMA order per accumulator, hence the same bits.
+template <int NS>
+__device__ __forceinline__ void potrf_mma64x8_u(const double* FA, const double* FB, v4d (&acc)[2], int rb, int wc, int c, int ks) {
+    constexpr int RS = 66;
+    const double* ap = FA + (16 * rb + c) * RS + ks;
+    const double* b0p = FB + (32 * wc + c) * RS + ks;
+    const double* b1p = b0p + 16 * RS;
+    double a[NS], b0[NS], b1[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        a[s] = ap[4 * s];
+        b0[s] = b0p[4 * s];
+        b1[s] = b1p[4 * s];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        acc[0] = GSMVI_MFMA_F64(a[s], b0[s], acc[0]);
+        acc[1] = GSMVI_MFMA_F64(a[s], b1[s], acc[1]);
+    }
+}
+// row block rb of X = W B with W lower triangular: 4 (rb + 1) k-steps (rb is wave-uniform)
+__device__ __forceinline__ void potrf_mma64x8_tri(const double* FA, const double* FB, v4d (&acc)[2], int rb, int wc, int c, int ks) {
+    switch (rb) {
+    case 0: potrf_mma64x8_u<4>(FA, FB, acc, 0, wc, c, ks); break;
+    case 1: potrf_mma64x8_u<8>(FA, FB, acc, 1, wc, c, ks); break;
+    case 2: potrf_mma64x8_u<12>(FA, FB, acc, 2, wc, c, ks); break;
+    default: potrf_mma64x8_u<16>(FA, FB, acc, 3, wc, c, ks); break;
+    }
+}
+
 // ---- split form of the early steps of a LARGE matrix (round 3) ----------------------------------------------------------
 // In the fused step every tile (I, J) recomputes X_I and X_J: three 64^3 products per tile where one is needed.  That is
 // free while a step has fewer tiles than the chip has CUs (the diagonal tile's chain bounds the step), and it is 2/3 of the
@@ -468,6 +501,12 @@ __global__ void k_potrf_clear_info(int* info) { *info = 0; }
 // needed.  (The first version used acquire loads in the poll and release / acquire fences around it: each poll invalidated
 // the caches, each publish wrote the XCD's L2 back -- 1070 us at D = 1024 against 324 for the launch-per-step form.)
 #define DAG_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+// Workgroup barrier that waits for this wave's LDS operations only.  __syncthreads() carries a workgroup fence that drains the
+// vector-memory counter: behind the write-through stores of a solved block the chain's next barrier waited ~3 us for memory to
+// acknowledge them (measured with the chain's timeline: "products + E" 4.84 us for two 64^3 products).  Nothing in this kernel
+// orders GLOBAL data through a workgroup barrier -- flags are atomics, handed-off data is read with sc1 loads, and dag_publish
+// drains explicitly -- so every barrier outside chol64_blk is of this kind.
+#define DAG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 __device__ __forceinline__ int dag_ld(const int* p) { return __hip_atomic_load(p, DAG_RLX); }
 __device__ __forceinline__ void dag_st(int* p, int v) { __hip_atomic_store(p, v, DAG_RLX); }
 __device__ __forceinline__ double dag_ldd(const double* p) { return __hip_atomic_load(p, DAG_RLX); }
@@ -490,25 +529,42 @@ __device__ __forceinline__ bool dag_wait(int* flags, const int* f0, int n0, cons
         }
         *sh = ok;
     }
-    __syncthreads();
+    DAG_BARRIER();
     const int ok = *sh;
-    __syncthreads();
+    DAG_BARRIER();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // (no instruction: keeps the compiler from hoisting loads above the poll)
     return ok != 0;
 }
 // every storing wave drains its write-through stores, then one lane raises the flag
 __device__ __forceinline__ void dag_publish(int* f, int v) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    DAG_BARRIER();
     if (threadIdx.x == 0) dag_st(f, v);
+}
+
+// The chain's stores that nobody reads in this launch, for block step cblk: the factor's diagonal block (upper triangle of the
+// [R | W] matrix chol64_blk left in E, 146 doubles per row) and the mirror block (cblk, cblk - 1) below the solved block.
+template <int ESD>
+__device__ __forceinline__ void dag_store_own_t(int D, double* R, int ldr, const double* E, int cblk, int tid) {
+    const int I0 = cblk * NB;
+    const int nb = (D - I0) < NB ? (D - I0) : NB;
+    for (int e = tid; e < NB * NB; e += 512) {
+        const int i = e >> 6, j = e & 63;
+        if (i < nb && j < nb) R[(size_t)(I0 + i) * ldr + I0 + j] = (j >= i) ? E[i * ESD + j] : 0.0;
+    }
+    if (cblk > 0)
+        for (int e = tid; e < NB * NB; e += 512) {
+            const int jr = e >> 6, pcol = e & 63;
+            if (I0 + jr < D) R[(size_t)(I0 + jr) * ldr + (cblk - 1) * NB + pcol] = 0.0;
+        }
 }
 
 __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int lds, double* R, int ldr, double* wbuf, int* flags,
                                                    int* __restrict__ info, int max_spin, unsigned long long* __restrict__ stamps) {
-    // timeline diagnostic (knob "timeline" = 2): the chain's thread 0 stamps eight points of each of its first 64 iterations
+    // timeline diagnostic (knob "timeline" = 2): the chain's thread 0 stamps up to sixteen points (0-7 phases, 8-10 inside the products) of each of its first 64 iterations
 #define DSTAMP(i)                                                                                              \
     do {                                                                                                       \
-        if (stamps && threadIdx.x == 0 && cI < 64) stamps[cI * 8 + (i)] = __builtin_amdgcn_s_memrealtime();    \
+        if (stamps && threadIdx.x == 0 && cI < 64) stamps[cI * 16 + (i)] = __builtin_amdgcn_s_memrealtime();   \
     } while (0)
     constexpr int RS = 66;
     constexpr int ESD = 146;
@@ -542,6 +598,8 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
             const bool a_s = (cI <= 1);                           // tile (c, c) still in S
             const double* Asrc = a_s ? S : R;
             const int lda = a_s ? lds : ldr;
+            // raw loads first, masks after the own stores below: a select right behind a load would put the wait for the loads in
+            // front of those stores (measured: 3.0 us for this phase that way)
             double tv[2][4];
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
@@ -549,8 +607,7 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
                 for (int r = 0; r < 4; ++r) {
                     const int row = I0 + lrow0 + 4 * r, col = I0 + 32 * wc + 16 * ct + c;
                     const double* ap = Asrc + (size_t)(row < D ? row : 0) * lda + (col < D ? col : 0);
-                    const double v = a_s ? *ap : dag_ldd(ap);
-                    tv[ct][r] = (row < D && col < D) ? v : ((row == col) ? 1.0 : 0.0);
+                    tv[ct][r] = a_s ? *ap : dag_ldd(ap);
                 }
             if (cI > 0) {
                 const bool b_s = (cI == 1);
@@ -561,31 +618,40 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
                 for (int q = 0; q < 8; ++q) {
                     const int pr = (tid >> 6) + 8 * q, gi = I0 + (tid & 63);
                     const double* bp = Bsrc + (size_t)((cI - 1) * NB + pr) * ldb + (gi < D ? gi : 0);
-                    const double v = b_s ? *bp : dag_ldd(bp);
-                    vi[q] = (gi < D) ? v : 0.0;
+                    vi[q] = b_s ? *bp : dag_ldd(bp);
                 }
+                // behind the loads (their ~1.9 us of latency is the chain's): the stores of the PREVIOUS iteration that are nobody's
+                // input in this launch -- the factor's diagonal block, still in E, and the mirror block below it
+                dag_store_own_t<ESD>(D, R, ldr, Lall, cI - 1, tid);
+                if (I0 + (tid & 63) >= D) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) vi[q] = 0.0;
+                }
+                DAG_BARRIER();                                  // E has been read: its space becomes the staging tiles
 #pragma unroll
                 for (int q = 0; q < 8; ++q) L1[(tid & 63) * RS + (tid >> 6) + 8 * q] = vi[q];
-                __syncthreads();                                  // (L0 holds W_{c-1}: written at the end of the previous iteration)
+                DAG_BARRIER();                                  // (L0 holds W_{c-1}: written at the end of the previous iteration)
                 DSTAMP(2);                                        // both tiles loaded (sc1) and staged
                 v4d acc[2];
                 acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
-                potrf_mma64x8(L0, L1, acc, wr, rr, wc, c, ks, 4 * (2 * wr + rr + 1));       // X = W_{c-1} T_{c-1,c}
+                // the solve's row blocks cost 4, 8, 12, 16 k-steps (W is lower triangular): waves w and w + 4 share a SIMD, so they
+                // take row blocks {0, 3} and {1, 2} -- 20 k-steps per SIMD where the products' own mapping gives 12 and 28
+                const int rbS = rr ? 3 - wr : wr;
+                potrf_mma64x8_tri(L0, L1, acc, rbS, wc, c, ks);                              // X = W_{c-1} T_{c-1,c}
+                DSTAMP(8);
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = lrow0 + 4 * r, col = 32 * wc + 16 * ct + c, gc = I0 + col;
+                        const int row = 16 * rbS + ks + 4 * r, col = 32 * wc + 16 * ct + c, gc = I0 + col;
                         L2[col * RS + row] = acc[ct][r];
                         if (gc < D) dag_std(R + (size_t)((cI - 1) * NB + row) * ldr + gc, acc[ct][r]);
                     }
-                for (int e = tid; e < NB * NB; e += 512) {                                  // the mirror block (c, c-1): nobody's input
-                    const int jr = e >> 6, pcol = e & 63;
-                    if (I0 + jr < D) R[(size_t)(I0 + jr) * ldr + (cI - 1) * NB + pcol] = 0.0;
-                }
-                __syncthreads();                                                            // L2 (the X^T tile) is complete
+                DAG_BARRIER();                                                            // L2 (the X^T tile) is complete
+                DSTAMP(9);
                 acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
-                potrf_mma64x8(L2, L2, acc, wr, rr, wc, c, ks);                              // T_cc -= X^T X
+                potrf_mma64x8_u<16>(L2, L2, acc, 2 * wr + rr, wc, c, ks);                    // T_cc -= X^T X
+                DSTAMP(10);
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -594,7 +660,7 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
             const int nb = (D - I0) < NB ? (D - I0) : NB;
             double* const E = Lall;
             double* const scr = Lall + 64 * ESD;
-            __syncthreads();                                      // everyone is done with the staging tiles
+            DAG_BARRIER();                                      // everyone is done with the staging tiles
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -606,7 +672,7 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
             // land, so the drain in front of the flag costs the chain next to nothing (dag_publish's barrier is the one E needs)
             DSTAMP(3);                                            // solve + update products done, E staged
             if (cI > 0) dag_publish(xready + (cI - 1) * nblk + cI, 1);
-            else __syncthreads();
+            else DAG_BARRIER();
             DSTAMP(4);                                            // solved block published
             chol64_blk<ESD, false, true>(E, scr, nb, &sh_fail);
             DSTAMP(5);                                            // factorisation done
@@ -625,23 +691,22 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
                 if (cI + 1 < nblk) dag_publish(wready + cI, 1);
                 DSTAMP(6);                                        // W_c copied, stored, drained, published
             }
-            for (int e = tid; e < NB * NB; e += 512) {           // the factor's diagonal block: nobody's input in this launch
-                const int i = e >> 6, j = e & 63;
-                if (i < nb && j < nb) R[(size_t)(I0 + i) * ldr + I0 + j] = (j >= i) ? E[i * ESD + j] : 0.0;
-            }
-            __syncthreads();
-            DSTAMP(7);
+            DSTAMP(7);                                            // (the factor block itself is stored behind the next iteration's loads)
         }
+        dag_store_own_t<ESD>(D, R, ldr, Lall, nblk - 1, tid);
         return;
     }
 #undef DSTAMP
     // ================================ the workers ================================
+    // (Measured and dropped, round 6: drawing the NEXT ticket while the current task runs, and drawing two or four at a time --
+    // 689 / 1866 us at D = 2048 / 4096 against 653 / 1834, 394 us at D = 1024 with four: a ticket held by a busy workgroup is
+    // a task nobody runs, and the early tickets of a step are the chain's inputs.  The ticket word is not the bottleneck.)
     int p = 0, base = 0;
     for (;;) {
         if (tid == 0) sh_w = atomicAdd(flags + DAG_TICKET, 1);
-        __syncthreads();
+        DAG_BARRIER();
         const int t = sh_w;
-        __syncthreads();
+        DAG_BARRIER();
         int m = nblk - 1 - p;
         while (p < nblk - 1) {
             m = nblk - 1 - p;
@@ -676,15 +741,16 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
                 L0[(e >> 6) * RS + (e & 63)] = vw[q];
                 L1[(tid & 63) * RS + (tid >> 6) + 8 * q] = vj[q];
             }
-            __syncthreads();
+            DAG_BARRIER();
             v4d acc[2];
             acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
-            potrf_mma64x8(L0, L1, acc, wr, rr, wc, c, ks, 4 * (2 * wr + rr + 1));
+            const int rbS = rr ? 3 - wr : wr;                     // (row blocks {0, 3} and {1, 2} per SIMD: see the chain)
+            potrf_mma64x8_tri(L0, L1, acc, rbS, wc, c, ks);
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = lrow0 + 4 * r, col = 32 * wc + 16 * ct + c, gc = J0 + col;
+                    const int row = 16 * rbS + ks + 4 * r, col = 32 * wc + 16 * ct + c, gc = J0 + col;
                     if (gc < D) dag_std(R + (size_t)(p * NB + row) * ldr + gc, acc[ct][r]);
                 }
             for (int e = tid; e < NB * NB; e += 512) {
@@ -692,7 +758,7 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
                 if (J0 + jr < D) R[(size_t)(J0 + jr) * ldr + p * NB + pcol] = 0.0;
             }
             dag_publish(xready + p * nblk + J, 1);
-            __syncthreads();
+            DAG_BARRIER();
         } else {
             // ---- update (p; I, J): T_IJ -= X_pI^T X_pJ ----
             r_ = r_ - (m - 1) + 1;                                // index in the m x m upper triangle, (0, 0) skipped
@@ -729,10 +795,10 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
                 L2[(tid & 63) * RS + (tid >> 6) + 8 * q] = vi[q];
                 if (!same) L1[(tid & 63) * RS + (tid >> 6) + 8 * q] = vj[q];
             }
-            __syncthreads();
+            DAG_BARRIER();
             v4d acc[2];
             acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
-            potrf_mma64x8(L2, same ? L2 : L1, acc, wr, rr, wc, c, ks);
+            potrf_mma64x8_u<16>(L2, same ? L2 : L1, acc, 2 * wr + rr, wc, c, ks);
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -741,7 +807,7 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
                     if (row < D && col < D) dag_std(R + (size_t)row * ldr + col, tv[ct][r] - acc[ct][r]);
                 }
             dag_publish(tstep + I * nblk + J, p + 1);
-            __syncthreads();
+            DAG_BARRIER();
         }
     }
 }
