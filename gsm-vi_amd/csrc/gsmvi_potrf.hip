@@ -475,21 +475,25 @@ __global__ void k_potrf_clear_info(int* info) { *info = 0; }
 //   * workgroup 0 is the CHAIN: iteration c solves block (c-1, c) with the W_{c-1} it has just produced, applies that block's
 //     rank-64 update to tile (c, c), factors it (chol64_blk, [T | I] -> [R_cc | W_c]) and publishes W_c.  Everything else tile
 //     (c, c) and block (c-1, c) need has been applied by the other workgroups while the chain was factoring tile (c-1, c-1);
-//   * the other workgroups take TASKS from a ticket counter in step-major order:
-//       solve  (p, J), J >= p + 2 :  X = W_p T_pJ -> block (p, J) of R, in place (the mirror block is zeroed); needs W_p and tile
-//                                    (p, J) updated by steps 0 .. p-1
-//       update (p; I, J), p < I <= J, (I, J) != (p+1, p+1) :  T_IJ -= X_pI^T X_pJ; needs both solved blocks and the tile updated
-//                                    by steps 0 .. p-1.  ONE product per tile (the launch-per-step form recomputes both solves in
-//                                    every tile: three)
-//     A task waits only for tasks with smaller tickets or for the chain, which waits only for tasks of earlier steps: no cycle,
-//     and with at most one workgroup per CU in the grid every workgroup is resident, so every claimed task runs.
-//   * hand-offs are flags in the workspace (agent-scope release / acquire: the producer's tiles are written back past its
-//     XCD's L2, the consumer invalidates before it reads); every wait is BOUNDED (max_spin polls, ~3 s): on a timeout the
+//   * the other workgroups take TILES from a ticket counter, block rows in order: a task is tile (I, J) with ALL the rank-64
+//     updates it needs -- steps 0 .. I-1 (0 .. I-2 on the diagonal) -- applied in step order with the tile in registers, the two
+//     solved blocks of step p + 1 travelling while step p's product runs; then
+//       (I, I), (I, I+1)  : the tile goes to R for the chain, which applies the last update / the solve itself;
+//       (I, J >= I+2)     : X = W_I T -> block (I, J) of R, in place (the mirror block is zeroed).
+//     One product per tile and step (the launch-per-step form recomputes both solves in every tile: three), and the tile is read
+//     once (from S) and written once.  (The first version of this kernel took one task per tile AND step: every product paid a
+//     ticket, a flag poll, the tile's round trip through memory and a drain -- 10 us per 64^3 product, 1.83 ms at D = 4096
+//     where the chain needs 1.17; this form: 1.19 ms, and 15.8 ms at D = 12288 = 84 % of the fp64 MFMA rate the chip sustains.)
+//     A task waits only for tiles with smaller tickets or for the chain, which waits only for tiles of its own and earlier rows
+//     that precede every tile waiting for it: no cycle, and with at most one workgroup per CU in the grid every workgroup is
+//     resident, so every claimed task runs.
+//   * hand-offs are flags in the workspace (form R1 below: write-through stores, a drain, a relaxed flag, sc1 loads of everything
+//     handed off); every wait is BOUNDED (max_spin polls, ~3 s): on a timeout the
 //     waiter raises the abort flag, every workgroup leaves and *info reports D + 1 -- the pool's GPUs are shared, a kernel that
 //     can spin forever is not acceptable.
-// Tiles live in R from their first update on (step 0 reads S); R must not alias S.  Same arithmetic per tile as the
-// launch-per-step form, same summation order inside every product; the ORDER of the rank-64 updates of a tile is the step
-// order in both, so the factor is bit-identical to k_potrf_step8<true>'s (one product per tile).
+// R must not alias S.  Same arithmetic per tile as the launch-per-step form, same summation order inside every product; the
+// ORDER of the rank-64 updates of a tile is the step order in both (T = ((S - P_0) - P_1) - ..., never S - (P_0 + P_1 + ...)),
+// so the factor is bit-identical to k_potrf_step8<true>'s (one product per tile).
 // =====================================================================================
 #define DAG_TICKET 0
 #define DAG_ABORT 1
@@ -542,6 +546,38 @@ __device__ __forceinline__ void dag_publish(int* f, int v) {
     if (threadIdx.x == 0) dag_st(f, v);
 }
 
+// How many of the steps pp, pp + 1, ... < P have their solved block(s) in R: lane l of wave 0 reads the flag(s) of step pp + l
+// (64 consecutive words per operand column), the count of leading ready steps goes to everybody.  Blocks until step pp is there;
+// returns the first step NOT known ready, or -1 (aborted / timed out).
+__device__ __forceinline__ int dag_upto(int* flags, const int* colI, const int* colJ, int pp, int P, int* sh, int max_spin) {
+    if (threadIdx.x < 64) {
+        const int q = pp + (int)threadIdx.x;
+        int n = 0, spins = 0;
+        for (;;) {
+            int ok = 0;
+            if (q < P) ok = (dag_ld(colI + q) != 0) && (colJ == nullptr || dag_ld(colJ + q) != 0);
+            const unsigned long long m = __ballot(ok);
+            n = (m == ~0ull) ? 64 : (int)__builtin_ctzll(~m);
+            if (n > 0) break;
+            const int ab = (threadIdx.x == 0) ? dag_ld(flags + DAG_ABORT) : 0;
+            if (__builtin_amdgcn_readfirstlane(ab) != 0 || ++spins > max_spin) {
+                n = -1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (threadIdx.x == 0) {
+            if (n < 0) dag_st(flags + DAG_ABORT, 1);
+            *sh = n;
+        }
+    }
+    DAG_BARRIER();
+    const int n = *sh;
+    DAG_BARRIER();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return n < 0 ? -1 : pp + n;
+}
+
 // The chain's stores that nobody reads in this launch, for block step cblk: the factor's diagonal block (upper triangle of the
 // [R | W] matrix chol64_blk left in E, 146 doubles per row) and the mirror block (cblk, cblk - 1) below the solved block.
 template <int ESD>
@@ -577,8 +613,8 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
     __shared__ int sh_fail, sh_w;
     const int nblk = (D + NB - 1) / NB;
     int* const wready = flags + DAG_WREADY;
-    int* const xready = wready + nblk;                            // [p][J]
-    int* const tstep = xready + nblk * nblk;                      // [I][J]: number of rank-64 updates applied to tile (I, J)
+    int* const xready = wready + nblk;                            // [J][p]: block (p, J) of the factor is in R (one line per column J)
+    int* const tstep = xready + nblk * nblk;                      // [I][J]: rank-64 updates applied to the tile a worker left in R for the chain
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c = l & 15, ks = l >> 4;
     const int wr = (w >> 1) & 1, wc = w & 1, rr = w >> 2;
     const int lrow0 = 32 * wr + 16 * rr + ks;
@@ -671,7 +707,7 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
             // the solved block (c-1, c) is published here: its write-through stores have had the product and the staging above to
             // land, so the drain in front of the flag costs the chain next to nothing (dag_publish's barrier is the one E needs)
             DSTAMP(3);                                            // solve + update products done, E staged
-            if (cI > 0) dag_publish(xready + (cI - 1) * nblk + cI, 1);
+            if (cI > 0) dag_publish(xready + cI * nblk + (cI - 1), 1);
             else DAG_BARRIER();
             DSTAMP(4);                                            // solved block published
             chol64_blk<ESD, false, true>(E, scr, nb, &sh_fail);
@@ -698,48 +734,111 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
     }
 #undef DSTAMP
     // ================================ the workers ================================
-    // (Measured and dropped, round 6: drawing the NEXT ticket while the current task runs, and drawing two or four at a time --
-    // 689 / 1866 us at D = 2048 / 4096 against 653 / 1834, 394 us at D = 1024 with four: a ticket held by a busy workgroup is
-    // a task nobody runs, and the early tickets of a step are the chain's inputs.  The ticket word is not the bottleneck.)
-    int p = 0, base = 0;
+    // A task is one TILE (I, J) of block row I with ALL the rank-64 updates it needs, applied in step order with the tile in
+    // registers (block rows in ticket order):
+    //   kind 0  (I, I),   I >= 2 : steps 0 .. I-2, tile -> R, tstep[I][I] = I - 1       (the chain applies step I-1 itself)
+    //   kind 1  (I, I+1), I >= 1 : steps 0 .. I-1, tile -> R, tstep[I][I+1] = I         (the chain solves it)
+    //   kind 2  (I, J >= I+2)    : steps 0 .. I-1, then X = W_I T -> block (I, J) of R, mirror block zeroed, xready[J][I]
+    // The operands of step p + 1 (two solved blocks, sc1 loads) travel while step p's product runs; how many steps are ready is
+    // polled 64 at a time (one line per operand column: xready is [column][step]), so a tile whose inputs are there runs its
+    // products back to back.
+    int row = 0, base = 0;
     for (;;) {
         if (tid == 0) sh_w = atomicAdd(flags + DAG_TICKET, 1);
         DAG_BARRIER();
         const int t = sh_w;
         DAG_BARRIER();
-        int m = nblk - 1 - p;
-        while (p < nblk - 1) {
-            m = nblk - 1 - p;
-            const int cnt = (m - 1) + m * (m + 1) / 2 - 1;
+        int hasD = 0, hasU = 0;
+        while (row < nblk) {
+            hasD = (row >= 2) ? 1 : 0;
+            hasU = (row >= 1 && row + 1 < nblk) ? 1 : 0;
+            const int nG = nblk - row - 2 > 0 ? nblk - row - 2 : 0;
+            const int cnt = hasD + hasU + nG;
             if (t - base < cnt) break;
             base += cnt;
-            ++p;
+            ++row;
         }
-        if (p >= nblk - 1) return;
-        int r_ = t - base;
-        const double* Wk = wbuf + (size_t)p * NB * NB;
-        const bool from_s = (p == 0);                             // tiles of step 0 are still in S (plain loads)
-        if (r_ < m - 1) {
-            // ---- solve (p, J): X = W_p T_pJ -> block (p, J) of R in place, mirror block zeroed ----
-            const int J = p + 2 + r_, J0 = J * NB;
-            if (!dag_wait(flags, wready + p, 1, p > 0 ? tstep + p * nblk + J : nullptr, p, nullptr, 0, &sh_w, max_spin)) return;
-            const double* Bsrc = from_s ? S : R;
-            const int ldb = from_s ? lds : ldr;
-            double vw[8], vj[8];
+        if (row >= nblk) return;
+        const int r_ = t - base, I = row;
+        const int kind = (r_ < hasD) ? 0 : (r_ < hasD + hasU ? 1 : 2);
+        const int J = (kind == 0) ? I : (kind == 1 ? I + 1 : I + 2 + (r_ - hasD - hasU));
+        const int P = (kind == 0) ? I - 1 : I;                    // rank-64 updates this task applies
+        const bool same = (kind == 0);
+        const int I0 = I * NB, J0 = J * NB;
+        const int gi = I0 + (tid & 63), gj = J0 + (tid & 63);
+        double tv[2][4];                                          // the tile, from S (plain loads, in flight while the operands arrive)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rw = I0 + lrow0 + 4 * r, col = J0 + 32 * wc + 16 * ct + c;
+                tv[ct][r] = S[(size_t)(rw < D ? rw : 0) * lds + (col < D ? col : 0)];
+            }
+        double vi[8], vj[8];
+        int upto = 0;
+        bool have = false;
+        for (int pp = 0; pp < P; ++pp) {
+            if (!have) {
+                if (pp >= upto) {
+                    upto = dag_upto(flags, xready + I * nblk, same ? nullptr : xready + J * nblk, pp, P, &sh_w, max_spin);
+                    if (upto < 0) return;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const size_t ro = (size_t)(pp * NB + (tid >> 6) + 8 * q) * ldr;
+                    vi[q] = dag_ldd(R + ro + (gi < D ? gi : 0));
+                    if (!same) vj[q] = dag_ldd(R + ro + (gj < D ? gj : 0));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                L2[(tid & 63) * RS + (tid >> 6) + 8 * q] = (gi < D) ? vi[q] : 0.0;
+                if (!same) L1[(tid & 63) * RS + (tid >> 6) + 8 * q] = (gj < D) ? vj[q] : 0.0;
+            }
+            DAG_BARRIER();
+            have = (pp + 1 < P && pp + 1 < upto);
+            if (have) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const size_t ro = (size_t)((pp + 1) * NB + (tid >> 6) + 8 * q) * ldr;
+                    vi[q] = dag_ldd(R + ro + (gi < D ? gi : 0));
+                    if (!same) vj[q] = dag_ldd(R + ro + (gj < D ? gj : 0));
+                }
+            }
+            v4d acc[2];
+            acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
+            potrf_mma64x8_u<16>(L2, same ? L2 : L1, acc, 2 * wr + rr, wc, c, ks);          // X_pI^T X_pJ
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tv[ct][r] -= acc[ct][r];                        // (step order: the launch-per-step form's bits)
+            DAG_BARRIER();                                        // the staging tiles are free again
+        }
+        if (kind != 2) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rw = I0 + lrow0 + 4 * r, col = J0 + 32 * wc + 16 * ct + c;
+                    if (rw < D && col < D) dag_std(R + (size_t)rw * ldr + col, tv[ct][r]);
+                }
+            dag_publish(tstep + I * nblk + J, kind == 0 ? I - 1 : I);
+            DAG_BARRIER();
+        } else {
+            // the updated tile, transposed, is the solve's right operand; W_I arrives from the chain
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) L1[(32 * wc + 16 * ct + c) * RS + lrow0 + 4 * r] = tv[ct][r];
+            if (!dag_wait(flags, wready + I, 1, nullptr, 0, nullptr, 0, &sh_w, max_spin)) return;
+            const double* Wk = wbuf + (size_t)I * NB * NB;
+            double vw[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) vw[q] = dag_ldd(Wk + tid + 512 * q);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int pr = (tid >> 6) + 8 * q, gj = J0 + (tid & 63);
-                const double* bp = Bsrc + (size_t)(p * NB + pr) * ldb + (gj < D ? gj : 0);
-                const double v = from_s ? *bp : dag_ldd(bp);
-                vj[q] = (gj < D) ? v : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
                 const int e = tid + 512 * q;
                 L0[(e >> 6) * RS + (e & 63)] = vw[q];
-                L1[(tid & 63) * RS + (tid >> 6) + 8 * q] = vj[q];
             }
             DAG_BARRIER();
             v4d acc[2];
@@ -750,63 +849,14 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * rbS + ks + 4 * r, col = 32 * wc + 16 * ct + c, gc = J0 + col;
-                    if (gc < D) dag_std(R + (size_t)(p * NB + row) * ldr + gc, acc[ct][r]);
+                    const int rw = 16 * rbS + ks + 4 * r, col = 32 * wc + 16 * ct + c, gc = J0 + col;
+                    if (gc < D) dag_std(R + (size_t)(I0 + rw) * ldr + gc, acc[ct][r]);
                 }
             for (int e = tid; e < NB * NB; e += 512) {
                 const int jr = e >> 6, pcol = e & 63;
-                if (J0 + jr < D) R[(size_t)(J0 + jr) * ldr + p * NB + pcol] = 0.0;
+                if (J0 + jr < D) R[(size_t)(J0 + jr) * ldr + I0 + pcol] = 0.0;
             }
-            dag_publish(xready + p * nblk + J, 1);
-            DAG_BARRIER();
-        } else {
-            // ---- update (p; I, J): T_IJ -= X_pI^T X_pJ ----
-            r_ = r_ - (m - 1) + 1;                                // index in the m x m upper triangle, (0, 0) skipped
-            int ti = 0, rowbase = 0;
-            while (rowbase + (m - ti) <= r_) { rowbase += m - ti; ++ti; }
-            const int tj = ti + (r_ - rowbase);
-            const int I = p + 1 + ti, J = p + 1 + tj, I0 = I * NB, J0 = J * NB;
-            const bool same = (I == J);
-            if (!dag_wait(flags, xready + p * nblk + I, 1, same ? nullptr : xready + p * nblk + J, 1,
-                          p > 0 ? tstep + I * nblk + J : nullptr, p, &sh_w, max_spin))
-                return;
-            const double* Asrc = from_s ? S : R;
-            const int lda = from_s ? lds : ldr;
-            double tv[2][4], vi[8], vj[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int pr = (tid >> 6) + 8 * q, gi = I0 + (tid & 63), gj = J0 + (tid & 63);
-                const double a = dag_ldd(R + (size_t)(p * NB + pr) * ldr + (gi < D ? gi : 0));
-                const double b = same ? 0.0 : dag_ldd(R + (size_t)(p * NB + pr) * ldr + (gj < D ? gj : 0));
-                vi[q] = (gi < D) ? a : 0.0;
-                vj[q] = (!same && gj < D) ? b : 0.0;
-            }
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = I0 + lrow0 + 4 * r, col = J0 + 32 * wc + 16 * ct + c;
-                    const double* ap = Asrc + (size_t)(row < D ? row : 0) * lda + (col < D ? col : 0);
-                    const double v = from_s ? *ap : dag_ldd(ap);
-                    tv[ct][r] = (row < D && col < D) ? v : ((row == col) ? 1.0 : 0.0);
-                }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                L2[(tid & 63) * RS + (tid >> 6) + 8 * q] = vi[q];
-                if (!same) L1[(tid & 63) * RS + (tid >> 6) + 8 * q] = vj[q];
-            }
-            DAG_BARRIER();
-            v4d acc[2];
-            acc[0] = acc[1] = (v4d){0.0, 0.0, 0.0, 0.0};
-            potrf_mma64x8_u<16>(L2, same ? L2 : L1, acc, 2 * wr + rr, wc, c, ks);
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = I0 + lrow0 + 4 * r, col = J0 + 32 * wc + 16 * ct + c;
-                    if (row < D && col < D) dag_std(R + (size_t)row * ldr + col, tv[ct][r] - acc[ct][r]);
-                }
-            dag_publish(tstep + I * nblk + J, p + 1);
+            dag_publish(xready + J * nblk + I, 1);
             DAG_BARRIER();
         }
     }
@@ -825,19 +875,17 @@ int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int
     const int nblk = (D + NB - 1) / NB, ldrow = nblk * NB;
     double* rowbuf = ctx->pp;
     double* wbuf = rowbuf + (size_t)2 * NB * ldrow;
-    // (D <= 6144: measured 310 / 677 / 1871 us against 323 / 716 / 2010 at D = 1024 / 2048 / 4096, but 10.4 against 10.2 ms at
-    // D = 8192, where one workgroup per CU cannot keep up with 3.5e5 tile tasks; knob "potrf_dag" = 2 forces it at any size)
-    if (ctx->tune_potrf_dag && (nblk <= 96 || ctx->tune_potrf_dag == 2) && !ctx->tune_no_fast &&
+    // (every size: 72 / 292 / 585 us and 1.19 / 2.35 / 4.99 / 15.8 ms at D = 256 / 1024 / 2048 / 4096 / 6144 / 8192 / 12288 against
+    // 77 / 323 / 712 us and 2.01 / 4.9 / 10.2 / 33.6 ms for one launch per step; knob "potrf_dag" = 0 selects the latter)
+    if (ctx->tune_potrf_dag && !ctx->tune_no_fast &&
         (!ctx->timeline_stamps(3) || ctx->tune_timeline == 2)) {
         // one persistent launch (k_potrf_dag): W blocks and the flags live where the launch-per-step form keeps its row buffers
         double* wb = ctx->pp;
         int* flags = reinterpret_cast<int*>(wb + (size_t)nblk * NB * NB);
         const int nflags = DAG_WREADY + nblk + 2 * nblk * nblk;
         int ntasks = 0;
-        for (int p = 0; p + 1 < nblk; ++p) {
-            const int m = nblk - 1 - p;
-            ntasks += (m - 1) + m * (m + 1) / 2 - 1;
-        }
+        for (int r = 0; r < nblk; ++r)                           // tiles the workers own: (r, r) from row 2, (r, r+1) from row 1, (r, J >= r+2)
+            ntasks += (r >= 2) + (r >= 1 && r + 1 < nblk) + (nblk - r - 2 > 0 ? nblk - r - 2 : 0);
         int grid = 1 + ntasks;
         if (grid > ctx->num_cu) grid = ctx->num_cu;              // at most one workgroup per CU: all resident (100 KB of LDS each)
         hipLaunchKernelGGL(k_potrf_dag_clear, dim3((nflags + 255) / 256), dim3(256), 0, st, info_dev, flags, nflags);

@@ -45,9 +45,6 @@ THRESHOLDS = [
     ("scalars: one element per thread", "D", 512, ("gsm",), CSRC + "gsmvi_fast.hip", "if (nt != 256 && nt != 512 && nt != 1024) nt = 512;"),
     ("scalars: two elements per thread / wide panels / unsplit rider product", "D", 1024, ("gsm", "gsmf", "bamf"), CSRC + "gsmvi_abi.hip", "ncols % 64 == 0 && ncols >= 1024 && D >= 1024 && D % 64 == 0"),
     ("potrf split solve from 24 tile rows", "D", 1536, ("potrf",), CSRC + "gsmvi_potrf.hip", "#define POTRF_SPLIT_M 24"),
-    ("potrf: one persistent launch up to 96 block steps (mirrored only: an O(D^3) host check at D = 6144 is not a unit test;"
-     " tests/test_gpu_large_d.py factors D = 6144 ... 12288 against the dense update)", "D", 6144, (), CSRC + "gsmvi_potrf.hip",
-     "(nblk <= 96 || ctx->tune_potrf_dag == 2)"),
     ("panel product keeps the next chunk's loads in flight from D = 2048", "D", 2048, ("gsm",), CSRC + "gsmvi_ctx.h",
      "int tune_panel_w4_min_D = 2048;"),
     ("unsplit rider product up to 2048", "D", 2048, ("gsm", "gsmf"), CSRC + "gsmvi_ctx.h", "int tune_rider_direct_max_D = 2048;"),
