@@ -663,7 +663,12 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
 #pragma unroll
                     for (int q = 0; q < 8; ++q) vi[q] = 0.0;
                 }
+                // W_{c-1} is published HERE, not behind its own drain at the end of the previous iteration: the wait for this
+                // iteration's loads is a wait for those older write-through stores too, and W_{c-1}'s readers -- the solves of
+                // row c-1 -- feed iteration c+1, a whole iteration away (0.7 us per iteration off the chain)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 DAG_BARRIER();                                  // E has been read: its space becomes the staging tiles
+                if (tid == 0) dag_st(wready + (cI - 1), 1);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) L1[(tid & 63) * RS + (tid >> 6) + 8 * q] = vi[q];
                 DAG_BARRIER();                                  // (L0 holds W_{c-1}: written at the end of the previous iteration)
@@ -724,8 +729,7 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
                     L0[(e >> 6) * RS + (e & 63)] = wv;
                     dag_std(Wk + e, wv);
                 }
-                if (cI + 1 < nblk) dag_publish(wready + cI, 1);
-                DSTAMP(6);                                        // W_c copied, stored, drained, published
+                DSTAMP(6);                                        // W_c copied and on its way (published by the next iteration)
             }
             DSTAMP(7);                                            // (the factor block itself is stored behind the next iteration's loads)
         }

@@ -106,7 +106,8 @@ done
 # launch against one launch per block step, 64-column panel strips at large D, the analytic multi-GPU model
 python3 scripts/jitter_period.py $OUT/jitter_period.json > $OUT/jitter_period.log 2>&1
 python3 scripts/bigbatch_bench.py $OUT/bigbatch.json > $OUT/bigbatch.log 2>&1
-for d in 1 0; do POTRF_DAG=$d python3 scripts/potrf_rate.py 256 512 1024 2048 4096 8192 2>&1 | grep "^potrf" >> $OUT/potrf_rate.txt; done
+for d in 1 0; do POTRF_DAG=$d python3 scripts/potrf_rate.py 256 512 1024 2048 4096 6144 8192 12288 2>&1 | grep "^potrf" >> $OUT/potrf_rate.txt; done
+for d in 1024 4096; do python3 scripts/potrf_dag_timeline.py $d 2>&1 | grep -v amdgpu.ids >> $OUT/potrf_dag_timeline.txt; done
 python3 scripts/panel_w4_ab.py 2>&1 | grep -v amdgpu.ids > $OUT/panel_w4_ab.txt
 timeout 600 python3 scripts/scaling_model.py $OUT/scaling_model.json > $OUT/scaling_model.log 2>&1
 python3 scripts/soak_round3.py 120 > $OUT/soak.txt 2>&1

@@ -24,7 +24,7 @@ eng.lib.gsmvi_debug_read_stamps(eng._ctx, buf, 4 * 4096)
 n = min(64, (D + 63) // 64)
 st16 = np.array(buf, dtype=np.uint64).reshape(4, 4096)[3][:16 * n].reshape(-1, 16).astype(np.int64)
 st = st16[:, :8]
-names = ["wait flags", "sc1 loads + own stores + staging", "products + E", "drain + publish X", "chol64_blk", "W copy/store/drain/publish", "(end)"]
+names = ["wait flags", "sc1 loads, own stores, W publish, staging", "products + E", "drain + publish X", "chol64_blk", "W copy + stores (published next iteration)", "(end)"]
 d = np.diff(st, axis=1) / 100.0
 print(f"k_potrf_dag chain, D = {D}: {n} iterations, {(st[-1, 7] - st[0, 0]) / 100.0:.1f} us from the first stamp to the last "
       f"({(st[-1, 7] - st[0, 0]) / 100.0 / n:.2f} us per iteration)")

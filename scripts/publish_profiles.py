@@ -82,6 +82,7 @@ plain = {
     "jitter_period.json": "scripts/jitter_period.py: factor-form BaM fit absorbing its jitter every K updates against the reference's loop (deviation and rate by K)",
     "bigbatch.json": "scripts/bigbatch_bench.py: U and F at D = 1024 for B = 128 ... 1024 (GSM dense, BaM dense), per-sample cost relative to B = 128",
     "potrf_rate.txt": "scripts/potrf_rate.py: gsmvi_potrf_f64 by size, k_potrf_dag (dag=1) against one launch per block step (dag=0)",
+    "potrf_dag_timeline.txt": "scripts/potrf_dag_timeline.py: phases of k_potrf_dag's chain workgroup per iteration (s_memrealtime stamps), D = 1024 and 4096",
     "panel_w4_ab.txt": "scripts/panel_w4_ab.py: panel product at D >= 2048 with 64-column strips against 16-column strips",
     "scaling_model.json": "scripts/scaling_model.py: per-rank stages measured on one GPU + RCCL world-1 floor + xGMI wire model; N > 1 entries are a model, not measured",
     "pytest_gpu.txt": "python -m pytest tests -m gpu -q (tail)",
