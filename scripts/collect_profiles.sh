@@ -173,6 +173,10 @@ if cov:
 json.dump(res, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])
 PY
+# the whole GPU suite in ONE process on the same box, same library (GSMVI_PASS_PYTEST=1: the round's published pass)
+if [ "${GSMVI_PASS_PYTEST:-0}" = "1" ]; then
+  (cd $ROOT && timeout 1800 python3 -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu.ids | tail -15 > $OUT/pytest_gpu.txt)
+fi
 # what THIS pass produced, with hashes: scripts/publish_profiles.py publishes only files listed here (the local gpurun_out/ keeps
 # files of earlier passes: gpurun merges, it does not mirror)
 python3 - "$OUT" <<'PYLIST'
