@@ -285,6 +285,7 @@ int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value) {
     else if (!strcmp(name, "potrf_dag")) ctx->tune_potrf_dag = value;
     else if (!strcmp(name, "panel_w4_min_D")) ctx->tune_panel_w4_min_D = value;
     else if (!strcmp(name, "potrf_spin")) ctx->tune_potrf_spin = value;
+    else if (!strcmp(name, "potrf_workers")) ctx->tune_potrf_workers = value;
     else if (!strcmp(name, "wide")) ctx->tune_wide = value;
     else if (!strcmp(name, "wide_kc")) ctx->tune_wide_kc = value;
     else if (!strcmp(name, "fork_min_D")) ctx->tune_fork_min_D = value;

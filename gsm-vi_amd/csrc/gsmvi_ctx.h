@@ -69,6 +69,7 @@ struct gsmvi_ctx {
     const double* potrf_r = nullptr;   //   valid until the next panel product), the factor it wrote and its size; null after the
     int potrf_w_n = 0;                 //   launch-per-step form
     int tune_potrf_dag = 1;       // the factorisation as ONE persistent launch with look-ahead (k_potrf_dag, round 6); 0: one launch per block step (A/B)
+    int tune_potrf_workers = 0;   // > 0: at most this many worker workgroups beside k_potrf_dag's chain (tests of the ticket order on a small grid)
     int tune_potrf_spin = 0;      // > 0: polls before a waiting workgroup of k_potrf_dag gives up (tests of the abort path)
     int tune_potrf_split_m = 0;   // > 0: tile rows from which a Cholesky block step runs its row solve as a separate launch (A/B)
     int tune_wide = 1;         // 64-row panels (B = 64) of D-sized products on the 64 x 64-tile kernels of gsmvi_wide.hip

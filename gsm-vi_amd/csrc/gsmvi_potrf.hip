@@ -579,7 +579,7 @@ __device__ __forceinline__ int dag_upto(int* flags, const int* colI, const int* 
 }
 
 // The chain's stores that nobody reads in this launch, for block step cblk: the factor's diagonal block (upper triangle of the
-// [R | W] matrix chol64_blk left in E, 146 doubles per row) and the mirror block (cblk, cblk - 1) below the solved block.
+// [R | W] matrix chol64_blk left in E, 146 doubles per row) and, for the block the chain solved from S, the mirror block (1, 0).
 template <int ESD>
 __device__ __forceinline__ void dag_store_own_t(int D, double* R, int ldr, const double* E, int cblk, int tid) {
     const int I0 = cblk * NB;
@@ -588,7 +588,7 @@ __device__ __forceinline__ void dag_store_own_t(int D, double* R, int ldr, const
         const int i = e >> 6, j = e & 63;
         if (i < nb && j < nb) R[(size_t)(I0 + i) * ldr + I0 + j] = (j >= i) ? E[i * ESD + j] : 0.0;
     }
-    if (cblk > 0)
+    if (cblk == 1)                                                // (from block row 1 on the worker that owned tile (c-1, c) zeroes its mirror)
         for (int e = tid; e < NB * NB; e += 512) {
             const int jr = e >> 6, pcol = e & 63;
             if (I0 + jr < D) R[(size_t)(I0 + jr) * ldr + (cblk - 1) * NB + pcol] = 0.0;
@@ -738,11 +738,14 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
     }
 #undef DSTAMP
     // ================================ the workers ================================
-    // A task is one TILE (I, J) of block row I with ALL the rank-64 updates it needs, applied in step order with the tile in
-    // registers (block rows in ticket order):
-    //   kind 0  (I, I),   I >= 2 : steps 0 .. I-2, tile -> R, tstep[I][I] = I - 1       (the chain applies step I-1 itself)
-    //   kind 1  (I, I+1), I >= 1 : steps 0 .. I-1, tile -> R, tstep[I][I+1] = I         (the chain solves it)
-    //   kind 2  (I, J >= I+2)    : steps 0 .. I-1, then X = W_I T -> block (I, J) of R, mirror block zeroed, xready[J][I]
+    // A task is one TILE (I, J) with ALL the rank-64 updates it needs, applied in step order with the tile in registers.  Ticket
+    // order, per block row r:
+    //   kind 1  (r, r+1),   1 <= r <= nblk-2 : steps 0 .. r-1, tile -> R, tstep[r][r+1] = r           (the chain solves it)
+    //   kind 0  (r+1, r+1), same rows        : steps 0 .. r-1, tile -> R, tstep[r+1][r+1] = r         (the chain applies step r itself)
+    //   kind 2  (r, J >= r+2)                : steps 0 .. r-1, then X = W_r T -> block (r, J) of R, mirror block zeroed, xready[J][r]
+    // The two tiles chain iteration r + 1 waits for come BEFORE row r's solves: those wait for W_r, which that iteration
+    // publishes behind its own wait -- with the diagonal tile (r+1, r+1) at the head of row r + 1 a grid of fewer workgroups than
+    // row r has solves would hold them all and leave nobody for it (tests/test_potrf_dag_order.py simulates the order).
     // The operands of step p + 1 (two solved blocks, sc1 loads) travel while step p's product runs; how many steps are ready is
     // polled 64 at a time (one line per operand column: xready is [column][step]), so a tile whose inputs are there runs its
     // products back to back.
@@ -752,20 +755,20 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
         DAG_BARRIER();
         const int t = sh_w;
         DAG_BARRIER();
-        int hasD = 0, hasU = 0;
+        int hasC = 0;
         while (row < nblk) {
-            hasD = (row >= 2) ? 1 : 0;
-            hasU = (row >= 1 && row + 1 < nblk) ? 1 : 0;
+            hasC = (row >= 1 && row + 1 < nblk) ? 1 : 0;          // the two tiles chain iteration row + 1 waits for
             const int nG = nblk - row - 2 > 0 ? nblk - row - 2 : 0;
-            const int cnt = hasD + hasU + nG;
+            const int cnt = 2 * hasC + nG;
             if (t - base < cnt) break;
             base += cnt;
             ++row;
         }
         if (row >= nblk) return;
-        const int r_ = t - base, I = row;
-        const int kind = (r_ < hasD) ? 0 : (r_ < hasD + hasU ? 1 : 2);
-        const int J = (kind == 0) ? I : (kind == 1 ? I + 1 : I + 2 + (r_ - hasD - hasU));
+        const int r_ = t - base;
+        const int kind = (r_ < hasC) ? 1 : (r_ < 2 * hasC ? 0 : 2);
+        const int I = (kind == 0) ? row + 1 : row;
+        const int J = (kind == 2) ? row + 2 + (r_ - 2 * hasC) : row + 1;
         const int P = (kind == 0) ? I - 1 : I;                    // rank-64 updates this task applies
         const bool same = (kind == 0);
         const int I0 = I * NB, J0 = J * NB;
@@ -827,6 +830,11 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
                     if (rw < D && col < D) dag_std(R + (size_t)rw * ldr + col, tv[ct][r]);
                 }
             dag_publish(tstep + I * nblk + J, kind == 0 ? I - 1 : I);
+            if (kind == 1)                                        // the mirror of the block the chain is about to solve: off its path
+                for (int e = tid; e < NB * NB; e += 512) {
+                    const int jr = e >> 6, pcol = e & 63;
+                    if (J0 + jr < D) R[(size_t)(J0 + jr) * ldr + I0 + pcol] = 0.0;
+                }
             DAG_BARRIER();
         } else {
             // the updated tile, transposed, is the solve's right operand; W_I arrives from the chain
@@ -888,10 +896,11 @@ int gsmvi_potrf_impl(gsmvi_ctx* ctx, hipStream_t st, int D, const double* S, int
         int* flags = reinterpret_cast<int*>(wb + (size_t)nblk * NB * NB);
         const int nflags = DAG_WREADY + nblk + 2 * nblk * nblk;
         int ntasks = 0;
-        for (int r = 0; r < nblk; ++r)                           // tiles the workers own: (r, r) from row 2, (r, r+1) from row 1, (r, J >= r+2)
-            ntasks += (r >= 2) + (r >= 1 && r + 1 < nblk) + (nblk - r - 2 > 0 ? nblk - r - 2 : 0);
+        for (int r = 0; r < nblk; ++r)                           // tiles the workers own: (r, r+1) and (r+1, r+1) for 1 <= r <= nblk-2, (r, J >= r+2)
+            ntasks += 2 * (r >= 1 && r + 1 < nblk) + (nblk - r - 2 > 0 ? nblk - r - 2 : 0);
         int grid = 1 + ntasks;
-        if (grid > ctx->num_cu) grid = ctx->num_cu;              // at most one workgroup per CU: all resident (100 KB of LDS each)
+        if (grid > ctx->num_cu) grid = ctx->num_cu;              // at most one workgroup per CU: all resident (133 KB of LDS each)
+        if (ctx->tune_potrf_workers > 0 && grid > 1 + ctx->tune_potrf_workers) grid = 1 + ctx->tune_potrf_workers;   // (tests: a small grid)
         hipLaunchKernelGGL(k_potrf_dag_clear, dim3((nflags + 255) / 256), dim3(256), 0, st, info_dev, flags, nflags);
         hipLaunchKernelGGL(k_potrf_dag, dim3(grid), dim3(512), 0, st, D, S, lds, R, ldr, wb, flags, info_dev,
                            ctx->tune_potrf_spin > 0 ? ctx->tune_potrf_spin : 2000000,    // (~3 s of polls: far above any scheduling gap of a shared GPU -- eight

@@ -231,7 +231,8 @@ def test_potrf_split_row_solve_of_large_matrices(eng, D):
 @pytest.mark.parametrize("D", [64, 130, 1024, 1600, 2500])
 def test_potrf_task_graph_equals_the_launch_per_step_form(eng, D):
     """Round 6: the factorisation is ONE persistent launch (k_potrf_dag: a chain workgroup factors the diagonal tiles, the others
-    take solve / update tasks from a ticket counter, hand-offs through agent-scope flags).  The arithmetic per tile and the order
+    take whole tiles from a ticket counter -- all rank-64 updates of a tile, then its solve --, hand-offs through agent-scope
+    flags).  The arithmetic per tile and the order
     of a tile's rank-64 updates are those of the launch-per-step form (knob "potrf_dag" = 0), so the factors agree to the last
     bits -- and the first failing pivot is reported the same way."""
     import torch
@@ -257,6 +258,31 @@ def test_potrf_task_graph_equals_the_launch_per_step_form(eng, D):
         assert eng.read_flag(flag) == D - 70 + 1
     R2, _ = eng.potrf(S)                                             # run-to-run: bit-identical (fixed summation order per tile)
     assert torch.equal(R2, out[1][0])
+
+
+@pytest.mark.parametrize("workers", [1, 2, 5, 40])
+def test_potrf_task_graph_on_a_small_grid(eng, workers):
+    """The ticket order must not need more workgroups than it has: every worker BLOCKS on its tile's inputs, so with one, two
+    or five workers beside the chain (knob "potrf_workers"; a row of D = 1024 has up to 14 solves) the launch finishes only if
+    whatever a claimed tile waits for is itself claimed or done (tests/test_potrf_dag_order.py simulates the same on the CPU;
+    the first whole-tile order held row r's solves while the tile their W_r depended on had no taker).  Same bits as the full
+    grid; a failure here is D + 1 after the poll budget, not a hang."""
+    import torch
+    D = 1024
+    rs = np.random.RandomState(11)
+    A = rs.standard_normal((D, D + 8)) / np.sqrt(D)
+    S = eng.asarray(A @ A.T + 0.05 * np.eye(D))
+    R0, flag = eng.potrf(S)
+    assert eng.read_flag(flag) == 0
+    try:
+        eng.set_tuning("potrf_workers", workers)
+        eng.set_tuning("potrf_spin", 200000)                         # (~0.3 s: a wrong order fails fast)
+        R1, flag = eng.potrf(S)
+        assert eng.read_flag(flag) == 0
+    finally:
+        eng.set_tuning("potrf_workers", 0)
+        eng.set_tuning("potrf_spin", 0)
+    assert torch.equal(R1, R0)
 
 
 def test_potrf_task_graph_gives_up_instead_of_spinning_forever(eng):
