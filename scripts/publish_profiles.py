@@ -89,7 +89,7 @@ plain = {
 }
 # the directory is rebuilt from the last pass alone; files listed in KEEP (merged reports written by other scripts of the
 # round) are carried over from the published directory
-KEEP = ("offgrid.json",)
+KEEP = ("offgrid.json", "potrf_soak.txt")
 for keep in KEEP:
     if os.path.exists(os.path.join(final, keep)):
         shutil.copyfile(os.path.join(final, keep), os.path.join(dst, keep))
