@@ -75,7 +75,9 @@ int gsmvi_destroy(gsmvi_ctx* ctx);
  * the orthogonal basis [Vw; Zt], default; 0 = the round-4 basis [Vw; Zw]; 3 = as 1 but the 2B x 2B chain factors its first
  * diagonal block itself), "bam_hint_slack" (Newton-Schulz steps enqueued beyond the previous call's count, default 1),
  * "rider_direct_max_D" (largest D at which the panel product carrying the chain as its rider runs unsplit, default 2048),
- * "lowrank_kp" (64 = 64-row staging passes of BaM's low-rank update); diagnostics "timeline", "cov_dbg"
+ * "lowrank_kp" (64 = 64-row staging passes of BaM's low-rank update); round 6: "potrf_dag" (0 = one launch per block step),
+ * "potrf_spin" (poll budget of a wait inside k_potrf_dag), "potrf_workers" (cap on its worker workgroups: tests of the ticket
+ * order), "panel_w4_min_D"; diagnostics "timeline", "cov_dbg"
  * (see gsmvi_hip_debug.h). */
 int gsmvi_set_tuning(gsmvi_ctx* ctx, const char* name, int value);
 
@@ -275,7 +277,9 @@ int gsmvi_gaussian_score_f64(gsmvi_ctx* ctx, void* stream, int D, int B,
  * symmetric matrix; *info_dev (device int) = 0 if S is positive definite, else 1 + index of the
  * first failing pivot (also set when a NaN is met).  Replaces np.linalg.cholesky inside
  * _check_goodness (gsm_numpy.py:132-146) and supplies the sampling factor.  R must not alias S; only the upper
- * triangle of S is read (plus the full diagonal blocks).  ceil(D/64) launches.
+ * triangle of S is read (plus the full diagonal blocks).  Two launches (a flag-clearing one and the persistent task graph
+ * k_potrf_dag, round 6; ceil(D/64) launches before, still behind the knob "potrf_dag" = 0); every wait inside it is bounded:
+ * *info_dev = D + 1 reports a wait that ran out of its poll budget (a shared, stalled GPU), never a hang.
  */
 int gsmvi_potrf_f64(gsmvi_ctx* ctx, void* stream, int D, const double* S, int lds,
                     double* R, int ldr, int* info_dev);
