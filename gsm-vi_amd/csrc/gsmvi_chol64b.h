@@ -199,7 +199,10 @@ __device__ __forceinline__ void cholb_panel_half(double* E, int k0, int col, boo
 // k_first > 0 (round 5): the first k_first 16-row panels are GIVEN -- the caller has put the finished rows [R | W] of a
 // BLOCK-DIAGONAL matrix there (no coupling between the given rows and the rest: R12 = 0, W21 = 0) and the factorisation resumes
 // at panel k_first on the untouched trailing block; the augmented columns of the given rows are the caller's.
-template <int ES, bool SEMIDEF, int AUG>
+// LA (round 6, the persistent Cholesky's chain only): look-ahead inside the block.  Behind panel k only block row k + 1 -- what
+// panel k + 1 needs -- is updated by all eight waves; the rows beyond it are updated by the waves the NEXT panel leaves idle,
+// beside that panel (it touches block row k + 1 and the scratch only).  Same products, same operands, same order per element.
+template <int ES, bool SEMIDEF, int AUG, bool LA = false>
 __device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, int* sh_fail, bool allow_dep = true,
                                            int k_first = 0) {
     static_assert(ES % 2 == 0, "rows must stay 16-byte aligned");
@@ -218,6 +221,36 @@ __device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, i
     if (tid == 0) *reinterpret_cast<volatile int*>(scratch + 16 * 64 + 8 * 64 + 17) = 0;
 #endif
     __syncthreads();
+    // products of step ks for the block rows [i_lo, i_hi), dealt to `nwv` waves of which this is number `wv` (wave-uniform walk
+    // over the flat product list)
+    auto trailing = [&](int ks, int i_lo, int i_hi, int wv, int nwv) {
+        const int kk0 = 16 * ks;
+        const int nWs = (AUG == 1) ? ks + 1 : (AUG == 2 ? 4 : 0);
+        int idx = wv;
+        for (int i = i_lo; i < i_hi && i < nblk; ++i) {
+            const int cnt = (nblk - i) + nWs;
+            while (idx < cnt) {
+                const int gcol = (idx < nblk - i) ? 16 * (i + idx) : 64 + 16 * (idx - (nblk - i));
+                const double* ap = E + (kk0 + g) * ES + 16 * i + c;
+                const double* bp = E + (kk0 + g) * ES + gcol + c;
+                double a[4], b[4], tv[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { a[s] = ap[4 * s * ES]; b[s] = bp[4 * s * ES]; }
+                double* tp = E + (16 * i + g) * ES + gcol + c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tv[r] = tp[4 * r * ES];
+                v4d acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};   // two chains of two
+                acc = GSMVI_MFMA_F64(a[0], b[0], acc);
+                acc1 = GSMVI_MFMA_F64(a[1], b[1], acc1);
+                acc = GSMVI_MFMA_F64(a[2], b[2], acc);
+                acc1 = GSMVI_MFMA_F64(a[3], b[3], acc1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tp[4 * r * ES] = tv[r] - (acc[r] + acc1[r]);
+                idx += nwv;
+            }
+            idx -= cnt;
+        }
+    };
 #pragma unroll 1
     for (int k = k_first; k < nblk; ++k) {                        // block-uniform
         const int k0 = 16 * k;
@@ -269,6 +302,10 @@ __device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, i
             asm volatile("" ::: "memory");                        // a wave's LDS operations execute in program order
             if (set == 0 && l == 0) atomicAdd(const_cast<int*>(order_flag), 1);
 #endif
+        } else if (LA && k > k_first) {
+            // the rows beyond this panel's, step k - 1: on the waves the panel leaves idle
+            constexpr int NPW = 2 * (AUG + 1);
+            trailing(k - 1, k + 1, nblk, w - NPW, 8 - NPW);
         }
         __syncthreads();
 #ifndef CHOLB_TEST_OLD_WRITEBACK
@@ -282,32 +319,8 @@ __device__ __forceinline__ void chol64_blk(double* E, double* scratch, int nb, i
         if (k + 1 >= nblk) break;                                 // block-uniform: no trailing matrix
         // ---- trailing: for every remaining block row i and every column group j (A-groups i .. nblk-1, W-groups 0 .. k):
         //   E[rows of i][group j] -= R_ki^T E[rows of k][group j],   K = 16 = four fp64 MFMA 16x16x4
-        {
-            int idx = w;
-            for (int i = k + 1; i < nblk; ++i) {                  // wave-uniform walk over the flat product list
-                const int cnt = (nblk - i) + nW;
-                while (idx < cnt) {
-                    const int gcol = (idx < nblk - i) ? 16 * (i + idx) : 64 + 16 * (idx - (nblk - i));
-                    const double* ap = E + (k0 + g) * ES + 16 * i + c;
-                    const double* bp = E + (k0 + g) * ES + gcol + c;
-                    double a[4], b[4], tv[4];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) { a[s] = ap[4 * s * ES]; b[s] = bp[4 * s * ES]; }
-                    double* tp = E + (16 * i + g) * ES + gcol + c;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) tv[r] = tp[4 * r * ES];
-                    v4d acc = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};   // two chains of two
-                    acc = GSMVI_MFMA_F64(a[0], b[0], acc);
-                    acc1 = GSMVI_MFMA_F64(a[1], b[1], acc1);
-                    acc = GSMVI_MFMA_F64(a[2], b[2], acc);
-                    acc1 = GSMVI_MFMA_F64(a[3], b[3], acc1);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) tp[4 * r * ES] = tv[r] - (acc[r] + acc1[r]);
-                    idx += 8;
-                }
-                idx -= cnt;
-            }
-        }
+        // (LA: block row k + 1 here, the rows beyond it beside the next panel -- see the top of the loop)
+        trailing(k, k + 1, LA ? k + 2 : nblk, w, 8);
         __syncthreads();
     }
     if (tid == 0) {                                               // failures beyond nb are the identity padding: none

@@ -715,7 +715,7 @@ __global__ __launch_bounds__(512) void k_potrf_dag(int D, const double* S, int l
             if (cI > 0) dag_publish(xready + cI * nblk + (cI - 1), 1);
             else DAG_BARRIER();
             DSTAMP(4);                                            // solved block published
-            chol64_blk<ESD, false, true>(E, scr, nb, &sh_fail);
+            chol64_blk<ESD, false, 1, true>(E, scr, nb, &sh_fail);   // (look-ahead inside the block: gsmvi_chol64b.h)
             DSTAMP(5);                                            // factorisation done
             if (tid == 0 && sh_fail != 0 && *info == 0) *info = I0 + sh_fail;
             // (Measured and dropped, round 6: the loop rotated so that the two tiles of iteration c+1 are loaded right behind the
